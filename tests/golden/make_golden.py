@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by running the REAL reference.
+
+TEST INFRASTRUCTURE.  Runs oracle/_ref/{geninit,rxmd} (the unmodified USCCACS/RXMD Fortran
+sources compiled by oracle/Makefile, `-DNOMPI -DRFDUMP -DQEQDUMP`) on the data files under
+tests/golden/inputs/ and converts the reference's own debug dumps into small npz fixtures:
+
+  rfdump0.txt   gid / pos / force / charge, f20.12     (reference src/pot.F90:76-88)
+  qeqdump0.txt  every hessian entry                     (reference src/qeq.F90:75-82)
+  stdout        per-iteration QEq trace (qeq.F90:111), `MDstep:` energy line (main.F90:261)
+
+Only this container has oracle/_ref (built from /root/reference); the fixtures travel.
+Usage: python tests/golden/make_golden.py [case ...]
+"""
+import os, re, subprocess, sys, tempfile, shutil
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+INP = os.path.join(HERE, "inputs")
+
+
+def perturbed_ice_fractional(path, seed=12345, sigma=0.02):
+    """conf/init.water/ice-1h.xyz holds REAL coordinates and exactly collinear O-H...O triples
+    (NaN in the reference): write fractional coords with a seeded Gaussian kick."""
+    lines = open(os.path.join(INP, "ice-1h_real.xyz")).read().split("\n")
+    n = int(lines[0].split()[0])
+    lat = [float(x) for x in lines[1].split()[:6]]
+    rng = np.random.default_rng(seed)
+    out = [lines[0], lines[1]]
+    for l in lines[2:2 + n]:
+        e, x, y, z = l.split()[:4]
+        r = np.array([float(x), float(y), float(z)]) + rng.normal(0.0, sigma, 3)
+        fr = r / np.array(lat[:3])
+        out.append("%s %.12f %.12f %.12f" % (e, fr[0], fr[1], fr[2]))
+    open(path, "w").write("\n".join(out) + "\n")
+
+
+CASES = {
+    # name: (xyz, ffield, mc, extra rxmd flags, nsteps for the dump run)
+    "rdx168_tol7":   ("rdx.xyz", "ffield_rdx", (1, 1, 1), [], 0),
+    "rdx168_tight":  ("rdx.xyz", "ffield_rdx", (1, 1, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
+    "rdx168_noqeq":  ("rdx.xyz", "ffield_rdx", (1, 1, 1), ["--isQEq", "0"], 0),
+    "rdx168_md10":   ("rdx.xyz", "ffield_rdx", (1, 1, 1), [], 10),
+    "rdx222_tight":  ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
+    "rdx222_md5":    ("rdx.xyz", "ffield_rdx", (2, 2, 2), [], 5),
+    "ice644_tight":  ("ICE", "ffield_water", (6, 4, 4), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
+}
+
+
+def run(cmd, cwd):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0 or "successfully finished" not in p.stdout:
+        raise RuntimeError("%s failed:\n%s" % (cmd, p.stdout[-3000:]))
+    return p.stdout
+
+
+def parse_rfdump(path):
+    gid, typ, pos, frc, chg = [], [], [], [], []
+    for l in open(path):
+        t = l.split()
+        if t[1] == "pos":
+            gid.append(int(t[0])); typ.append(int(t[2])); pos.append([float(x) for x in t[3:6]])
+        elif t[1] == "frc":
+            frc.append([float(x) for x in t[3:6]])
+        elif t[1] == "chg":
+            chg.append(float(t[3]))
+    return (np.array(gid, np.int64), np.array(typ, np.int32), np.array(pos), np.array(frc), np.array(chg))
+
+
+def parse_trace(out):
+    """lines printed by qeq.F90:111 :  iter  log|gs| log|gt|  Est  Est_old  qsum  (last QEq call)"""
+    rows, cur = [], []
+    for l in out.split("\n"):
+        t = l.split()
+        if len(t) == 6 and re.fullmatch(r"\d+", t[0]):
+            try:
+                v = [float(x) for x in t[1:]]
+            except ValueError:
+                continue
+            if int(t[0]) == 0 and cur:
+                rows.append(cur); cur = []
+            cur.append([int(t[0])] + v)
+    if cur:
+        rows.append(cur)
+    return rows
+
+
+def parse_mdstep(out):
+    res = []
+    for l in out.split("\n"):
+        if l.startswith("MDstep:"):
+            t = l.split()
+            res.append([float(x) for x in t[1:16]])
+    return np.array(res)
+
+
+def make(name):
+    xyz, ff, mc, flags, nsteps = CASES[name]
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        if xyz == "ICE":
+            perturbed_ice_fractional(os.path.join(tmp, "input.xyz"))
+        else:
+            shutil.copy(os.path.join(INP, xyz), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(INP, ff), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT",
+             "-mc", str(mc[0]), str(mc[1]), str(mc[2])], tmp)
+        rxffbin = open(os.path.join(tmp, "DAT", "rxff.bin"), "rb").read()
+        # run A: the dump run
+        out = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(nsteps), "--pstep", "1",
+                   "--fstep", "100000"] + flags, tmp)
+        gid, typ, pos, frc, chg = parse_rfdump(os.path.join(tmp, "rfdump0.txt"))
+        traces = parse_trace(out)
+        md = parse_mdstep(out)
+        d = dict(gid=gid, type=typ, pos=pos, force=frc, charge=chg, mc=np.array(mc),
+                 nsteps=np.array(nsteps), flags=np.array(" ".join(flags)))
+        if traces:
+            d["qeq_iters"] = np.array([len(t) - 1 for t in traces])   # last printed row is the exit row
+            d["qeq_trace_last"] = np.array(traces[-1])
+            d["qeq_trace_first"] = np.array(traces[0])
+        # hessian summary of the LAST QEq call (file is rewritten per call)
+        qd = os.path.join(tmp, "qeqdump0.txt")
+        if os.path.exists(qd) and os.path.getsize(qd) > 0:
+            h = np.loadtxt(qd, usecols=(1, 3, 4))
+            gi = h[:, 0].astype(np.int64); gj = h[:, 1].astype(np.int64); hv = h[:, 2]
+            nn = np.bincount(gi, minlength=gid.max() + 1)
+            rs = np.bincount(gi, weights=hv, minlength=gid.max() + 1)
+            d["hess_nnz"] = nn[1:]; d["hess_rowsum"] = rs[1:]
+            sel = np.linspace(0, len(hv) - 1, 400).astype(int)
+            d["hess_sample"] = np.stack([gi[sel], gj[sel], hv[sel]], 1)
+        # run B: energies of step 0 .. (printed by PRINTE before each step)
+        outB = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(max(nsteps, 1)), "--pstep", "1",
+                    "--fstep", "100000"] + flags, tmp)
+        d["mdstep"] = parse_mdstep(outB)
+        if name.startswith("ice"):
+            d["input_xyz"] = np.array(open(os.path.join(tmp, "input.xyz")).read())
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, "natoms", len(gid), "qeq_iters", d.get("qeq_iters"), "PE/atom", d["mdstep"][0][2] if len(d["mdstep"]) else None)
+    finally:
+        shutil.rmtree(tmp)
+
+
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or list(CASES)):
+        make(n)
