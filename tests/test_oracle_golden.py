@@ -1,0 +1,107 @@
+"""Pins the plain-C oracle (oracle/rxmd_oracle.c) against golden vectors produced by the REAL
+reference (tests/golden/make_golden.py -> oracle/_ref/rxmd).  CPU only.
+
+Dump resolution of the reference is f20.12, so 'exact' here means |diff| <= 1e-11 absolute.
+"""
+import os
+import numpy as np
+import pytest
+import oracle_api as oa
+
+GOLD = oa.GOLD
+
+
+def _run(case, mc, steps=0, **kw):
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    ff, names, frac, lat = oa.make_system(case)
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=mc)
+    o = oa.Oracle(ff, lat2, ranks, **kw)
+    iters = [o.qeq()]
+    o.force()
+    pe0 = o.energy()
+    for _ in range(steps):
+        o.step(1)
+        iters.append(o.L.rxo_qeq_iters(o.w))
+    return g, o, iters, pe0
+
+
+def _compare(g, o, ftol=1e-10, qtol=1e-11):
+    gid = o.gids()
+    order = np.argsort(gid)
+    gorder = np.argsort(g["gid"])
+    assert (gid[order] == g["gid"][gorder]).all()
+    dq = np.abs(o.charges()[order] - g["charge"][gorder]).max()
+    df = np.abs(o.forces()[order] - g["force"][gorder]).max()
+    dp = np.abs(o.pos()[order] - g["pos"][gorder]).max()
+    assert dp < 1e-11, dp
+    assert dq < qtol, dq
+    assert df < ftol, df
+    return dq, df
+
+
+def _check_energy(g, pe, n, row=0):
+    m = g["mdstep"][row]   # step TE PE KE E1 E2-4 E5-7 E8-9 E10 E11-13 ...
+    ref = np.array([m[2], m[4], m[5], m[6], m[7], m[8], m[9]]) * n
+    got = np.array([pe[0], pe[1], pe[2:5].sum(), pe[5:8].sum(), pe[8:10].sum(), pe[10], pe[11:14].sum()])
+    # printed with es13.5 / es11.3 -> 6 and 4 significant digits
+    assert abs(got[0] - ref[0]) <= 1e-5 * abs(ref[0])
+    assert np.all(np.abs(got[1:] - ref[1:]) <= 1.1e-3 * np.abs(ref[1:]) + 1e-12)
+
+
+def test_rdx168_default_tolerance_bitpath():
+    g, o, iters, pe = _run("rdx168_tol7", (1, 1, 1))
+    assert iters[0] == int(g["qeq_iters"][0]) == 35
+    _compare(g, o)
+    _check_energy(g, pe, 168)
+    # per-iteration Est trace of the reference (printed es25.15)
+    tr = o.trace(); ref = g["qeq_trace_last"]
+    assert len(tr) == len(ref)
+    assert np.allclose(tr[:, 0], ref[:, 3], rtol=1e-13, atol=0)
+    # known answers quoted in SURVEY 8(c)
+    assert abs(tr[-1, 0] - (-1.260035970464605E+02)) < 1e-10
+
+
+def test_rdx168_tight():
+    g, o, iters, pe = _run("rdx168_tight", (1, 1, 1), QEq_tol=1e-12, NMAXQEq=2000)
+    assert iters[0] == int(g["qeq_iters"][0])
+    _compare(g, o)
+
+
+def test_rdx168_no_qeq_forces_only():
+    g, o, iters, pe = _run("rdx168_noqeq", (1, 1, 1), isQEq=0)
+    _compare(g, o)
+    _check_energy(g, pe, 168)
+
+
+def test_rdx168_md10_trajectory():
+    g, o, iters, pe = _run("rdx168_md10", (1, 1, 1), steps=10)
+    assert iters == [int(x) for x in g["qeq_iters"]]
+    _compare(g, o, ftol=1e-9, qtol=1e-10)
+
+
+def test_hessian_rowsums_and_counts():
+    g = np.load(os.path.join(GOLD, "rdx168_tol7.npz"))
+    ff, names, frac, lat = oa.make_system("rdx168")
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff))
+    o = oa.Oracle(ff, lat2, ranks)
+    o.qeq()
+    assert (o.get(104).astype(int) == g["hess_nnz"]).all()
+    assert np.allclose(o.get(108), g["hess_rowsum"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("case,mc,steps", [("rdx222_tight", (2, 2, 2), 0), ("rdx222_md5", (2, 2, 2), 5)])
+def test_rdx222(case, mc, steps):
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000) if "tight" in case else {}
+    g, o, iters, pe = _run(case, mc, steps=steps, **kw)
+    assert iters == [int(x) for x in g["qeq_iters"]]
+    _compare(g, o, ftol=1e-9, qtol=1e-10)
+    if steps == 0:
+        _check_energy(g, pe, 1344)
+
+
+def test_ice_type_order_and_zero_hbond():
+    g, o, iters, pe = _run("ice644_tight", (6, 4, 4), QEq_tol=1e-12, NMAXQEq=2000)
+    assert iters[0] == int(g["qeq_iters"][0])
+    _compare(g, o, ftol=1e-9)
+    assert pe[10] == 0.0          # hydrogen is hard-coded as type 2; water ffield has H = 1  
+    _check_energy(g, pe, 2304)
