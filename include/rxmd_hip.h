@@ -1,0 +1,154 @@
+/* rxmd_hip.h -- C ABI of the MI355X-native ReaxFF force + charge-equilibration engine.
+ *
+ * This is the drop-in boundary for the per-step hot path of USCCACS/RXMD.  The reference has
+ * no FFI layer: the path sits behind three external Fortran subroutines with implicit
+ * interfaces plus module-global state:
+ *
+ *     subroutine QEq  (atype, pos, q)       reference src/qeq.F90:2
+ *     subroutine FORCE(atype, pos, f, q)    reference src/pot.F90:2
+ *     subroutine COPYATOMS(imode,dr,...)    reference src/comm.F90:2   (MODE_MOVE from main.F90:75)
+ *
+ * and the velocity-Verlet loop body around them (reference src/main.F90:64-98).  Every entry
+ * point below names the reference interface it replaces.  All functions return 0 on success or
+ * a negative RXMD_E_* code (the reference prints and calls MPI_FINALIZE/stop instead,
+ * main.F90:402-407, qeq.F90:248-252, comm.F90:467-472); rxmd_hip_last_error() gives the text.
+ *
+ * Plain C types only (pointers and sizes); one handle per GPU / rank; the caller owns host
+ * arrays, the library owns device state.  Not re-entrant per handle (as the reference).
+ * The Fortran-side binding a maintainer would add is shown in INTEGRATION.md and shipped as
+ * bindings/rxmd_hip_mod.F90 (iso_c_binding).
+ */
+#ifndef RXMD_HIP_H
+#define RXMD_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rxmd_hip_engine *rxmd_handle;
+
+#define RXMD_OK 0
+#define RXMD_E_ARG (-1)         /* bad argument / missing file */
+#define RXMD_E_FFIELD (-2)      /* ffield could not be parsed */
+#define RXMD_E_NBUFFER (-3)     /* residents+ghosts exceed capacity      (comm.F90:467-472) */
+#define RXMD_E_MAXNEIGHBS (-4)  /* bonded neighbour overflow             (main.F90:402-407) */
+#define RXMD_E_MAXNEIGHBS10 (-5)/* 10 A neighbour overflow               (qeq.F90:248-252)  */
+#define RXMD_E_HIP (-6)         /* HIP runtime error / no device */
+#define RXMD_E_STATE (-7)       /* call order (e.g. force before atoms were set) */
+#define RXMD_E_COMM (-8)        /* multi-rank exchange failed */
+#define RXMD_E_NAN (-9)         /* non-finite energy (e.g. collinear torsion, pot.F90:1391-1394) */
+
+/* Run parameters: the union of what GETPARAMS/INITSYSTEM/get_rxmd_parms hand to the path through
+ * module globals (reference src/cmdline.F90:255-297, src/init.F90:28-106, src/module.F90:80-84). */
+typedef struct rxmd_config {
+  const char *ffield_path; /* --ffield ; parsed as src/param.F90:2-375 */
+  double lattice[6];       /* lata,latb,latc,lalpha,lbeta,lgamma of the WHOLE box (rxff.bin header, fileio.F90:493-494) */
+  int vprocs[3];           /* rxmd.in `processors`; 1 1 1 for a single GPU */
+  int myid;                /* rank in the vprocs grid, x fastest (init.F90:75-77) */
+  int isQEq;               /* 0 off, 1 CG, 2 extended Lagrangian (qeq.F90:36-63) */
+  int NMAXQEq;             /* max CG iterations */
+  double QEq_tol;          /* energy criterion (qeq.F90:114-115) */
+  int qstep;               /* QEq every qstep MD steps (main.F90:77) */
+  double dt_fs;            /* time step in fs (rxmd.in `time`) */
+  double Lex_fqs, Lex_k;   /* rxmd.in `exL` (module.F90:164) */
+  int nbuffer;             /* capacity residents+ghosts (NBUFFER); 0 = size from the box */
+  int maxneighbs;          /* MAXNEIGHBS, 0 = 30 */
+  int maxneighbs10;        /* MAXNEIGHBS10 (row stride of the 10 A list), 0 = size from density */
+  int device;              /* HIP device ordinal */
+  int qeq_mode;            /* 0 = reference algebra (two matrix passes per CG iteration, qeq.F90:96-166)
+                              1 = one pass per iteration (gradient by recurrence); same fixed point */
+  int reserved[7];
+} rxmd_config;
+
+void rxmd_hip_default_config(rxmd_config *cfg);
+int rxmd_hip_create(const rxmd_config *cfg, rxmd_handle *out);
+int rxmd_hip_destroy(rxmd_handle h);
+const char *rxmd_hip_last_error(rxmd_handle h);
+
+/* ---- state in / out ------------------------------------------------------------------------- */
+/* ReadBIN (src/fileio.F90:444-555): natoms records of 10 doubles exactly as DAT/rxff.bin holds them
+ * for this rank: normalised LOCAL pos[3], v[3], q, atype(=type+gid*1e-13), qsfp, qsfv. */
+int rxmd_hip_set_atoms_rxff(rxmd_handle h, int natoms, const double *rec10);
+/* WriteBIN (src/fileio.F90:558-653): the same record layout back; returns natoms (may have changed
+ * by migration).  Pass NULL to query the count. */
+int rxmd_hip_get_atoms_rxff(rxmd_handle h, double *rec10, int capacity);
+/* Per-atom arrays of the residents in the engine's current local order (the reference's local
+ * index order, which the force semantics depend on -- SURVEY 0.9): any pointer may be NULL.
+ * pos/v/f are [natoms][3] row-major REAL coordinates; gid = l2g(atype) (main.F90:582-593). */
+int rxmd_hip_get_atoms(rxmd_handle h, int capacity, long long *gid, int *type, double *pos, double *v, double *f, double *q);
+int rxmd_hip_set_charges(rxmd_handle h, int natoms, const double *q);
+int rxmd_hip_set_velocities(rxmd_handle h, int natoms, const double *v);
+
+/* ---- the hot path, device resident ---------------------------------------------------------- */
+/* QEq(atype,pos,q), src/qeq.F90:2-178.  iters = nstep_qeq, est = last GEst1. */
+int rxmd_hip_qeq(rxmd_handle h, int *iters, double *est);
+/* FORCE(atype,pos,f,q), src/pot.F90:2-90.  pe[0:13] as module.F90:143-146 (pe[0]=sum). */
+int rxmd_hip_force(rxmd_handle h, double pe[14]);
+/* nsteps passes of the MD loop body, src/main.F90:64-98 (vkick, Lex charges, drift, COPYATOMS(MOVE),
+ * QEq every qstep, FORCE, vkick); mdmode 1 (NVE).  Call rxmd_hip_qeq + rxmd_hip_force once before
+ * the first step, as main.F90:27-32 does. */
+int rxmd_hip_step(rxmd_handle h, int nsteps);
+/* PRINTE reductions (src/main.F90:210-274) for this rank: ke = sum hmas*v^2, qsum, pe[14], astr[6]. */
+int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], double astr[6]);
+
+/* ---- the same path behind the reference's own argument shapes ------------------------------- */
+/* Host arrays in the reference layout: atype(NBUFFER) packed type+gid*1e-13, pos/f(NBUFFER,3)
+ * column-major REAL coordinates, residents 1..natoms.  These upload, run the device path and
+ * download; they are what a Fortran `QEq`/`FORCE` shim calls (bindings/rxmd_hip_mod.F90). */
+int rxmd_hip_QEq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *q);
+int rxmd_hip_FORCE(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *f, const double *q, double pe[14]);
+
+/* ---- introspection for tests, roofline accounting and the timers table (main.F90:135-182) ---- */
+typedef struct rxmd_stats {
+  int natoms, nghost_qeq, nghost_force; /* copyptr(6)-NATOMS after the QEq / FORCE ghost builds */
+  long long nnz10;                      /* entries of the 10 A list (sum nbplist(0,:)) */
+  long long nbonds;                     /* sum nbrlist(:,0) over residents+ghosts */
+  int max_n10, max_nb;                  /* maxas(:,3), maxas(:,2) */
+  int qeq_iters_last; long long qeq_iters_total; long long qeq_calls;
+  double ms_qeq, ms_qeq_list, ms_qeq_spmv, ms_force, ms_lists, ms_bo, ms_nonbond, ms_bonded, ms_step_total;
+  long long spmv_launches;              /* number of matrix passes timed in ms_qeq_spmv */
+  int n10_stride, nbuffer, cells10[3], cells3[3];
+  int reserved[8];
+} rxmd_stats;
+int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
+int rxmd_hip_reset_timers(rxmd_handle h);
+
+/* host-side derived tables for unit tests (CUTOFFLENGTH/POTENTIALTABLE, src/init.F90:363-522):
+ * which: 0 Evdw 1 dEvdw 2 Eclmb 3 dEclmb 4 Eclmb_QEq  -> out[nboty][5000]; returns nboty */
+int rxmd_hip_get_table(rxmd_handle h, int which, double *out, int capacity);
+int rxmd_hip_get_cutoffs(rxmd_handle h, double *rc, int capacity, double *maxrc);
+/* debugging taps on device state after rxmd_hip_force (residents+ghosts, engine order):
+ * what: 0 delta  1 deltap  2 bonded neighbour count  3 real pos (x3)  4 gid  5 type  6 n10 count (residents)
+ *       7 hessian row sums (residents) */
+int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity);
+
+/* ---- multi-rank surface (COPYATOMS, src/comm.F90) ------------------------------------------- */
+/* The engine performs the reference's six-direction staged exchange.  With vprocs = 1 1 1 every
+ * partner is the rank itself and the exchange is a device-side copy.  For vprocs > 1 the host
+ * supplies the transport: `exchange` must deliver `nsend` doubles from device pointer `send` to
+ * rank `to` and receive up to `cap` doubles from rank `from` into device pointer `recv`, return the
+ * number received; `allreduce_sum` sums n host doubles in place over all ranks.  (RCCL via
+ * torch.distributed in bench.py; MPI_Send/Recv + MPI_Allreduce in a Fortran driver.) */
+typedef struct rxmd_comm_ops {
+  void *ctx;
+  long long (*exchange)(void *ctx, int to, const double *send, long long nsend, int from, double *recv, long long cap);
+  int (*allreduce_sum)(void *ctx, double *buf, int n);
+} rxmd_comm_ops;
+int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops);
+
+/* ---- host front-end helpers (no GPU needed) ------------------------------------------------- */
+/* geninit (reference init/geninit.F90:399-575): replicate a fractional-coordinate unit cell mc times,
+ * split into vprocs domains, and return this rank's rxff.bin records.  `elem` holds natoms0
+ * 2-character element names ("C\0","H\0"...) 4 bytes apart.  Returns the number of atoms of rank
+ * `myid` (call with rec10 == NULL to size); lattice_out gets the super-cell lattice. */
+long long rxmd_host_geninit(const char *ffield_path, int natoms0, const char *elem4, const double *frac,
+                            const double lattice[6], const int mc[3], const int vprocs[3], int myid,
+                            double *rec10, long long capacity, double lattice_out[6]);
+/* rxff.bin header + this rank's records (ReadBIN); returns natoms of `myid` or <0 */
+long long rxmd_host_read_rxff(const char *path, int myid, double lattice_out[6], int vprocs_out[3], double *rec10, long long capacity);
+/* library build info: returns 1 if the HIP code object for gfx950 is linked in */
+int rxmd_hip_has_device_code(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

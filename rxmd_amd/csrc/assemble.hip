@@ -1,0 +1,172 @@
+// assemble.hip -- turns the per-slot accumulators of bonded.hip into forces, and the MD step.
+//   ForceBondedTerms + ForceD   reference src/pot.F90:113-144, 1230-1273  -> k_cd_gather, k_ccbnd, k_bond_forces
+//   COPYATOMS(MODE_CPBK)        reference src/comm.F90:385-396, 474-482   -> Engine::fold_ghost_forces (engine.hip)
+//   FORCE driver                reference src/pot.F90:2-90                -> Engine::force
+//   MD loop body                reference src/main.F90:64-98              -> Engine::step
+//
+// The reference's ForceBondedTerms is a SERIAL loop over the local index i that (1) applies ForceD(i)
+// -- which also adds Cbond(3) to ccbnd of every neighbour -- and (2) consumes and zeroes ccbnd(i) at
+// once.  An increment that ForceD(k) makes to ccbnd(i) is therefore used only when k < i.  The same
+// result as a gather:
+//     cd(i)  = all cdbnd contributions to i
+//     cc(i)  = ccbnd from the energy terms
+//            + sum_s BO(i,s) A2(i,s) * [ cd(i) + (nbr(i,s) < i ? cd(nbr(i,s)) : 0) ]
+//     f(i)   = self + sum_s fn(from neighbour) - sum_s { Cbond1(i,s) + (cd(i)+cd(j)) (A0+BO A1) dBOp
+//                                                         + (cc(i)+cc(j)) dBOp } * (r_i - r_j)
+// Atoms are stored in the reference's local order, so "k < i" is a plain index compare.
+#include "engine.h"
+
+#include <cmath>
+
+namespace rxmd {
+
+static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+
+__global__ void __launch_bounds__(256) k_cd_gather(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
+                                                    const double *__restrict__ cds, const double *__restrict__ cdn, double *__restrict__ cd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G) return;
+  const int cnt = nbrcnt[i];
+  double s = cds[i];
+  for (int t = 0; t < cnt; ++t) {
+    const size_t o = static_cast<size_t>(t) * NB + i;
+    const int j = nbr[o];
+    s += cdn[static_cast<size_t>(nbrindx[o]) * NB + j];
+  }
+  cd[i] = s;
+}
+
+__global__ void __launch_bounds__(256) k_ccbnd(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
+                                                const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
+                                                const double *__restrict__ A2, const double *__restrict__ A3,
+                                                const double *__restrict__ cf1, const double *__restrict__ cf2, const double *__restrict__ cf3,
+                                                const double *__restrict__ cd, double *__restrict__ cc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G) return;
+  const int cnt = nbrcnt[i];
+  const double cdi = cd[i];
+  double s = 0.0;
+  for (int t = 0; t < cnt; ++t) {
+    const size_t o = static_cast<size_t>(t) * NB + i;
+    const int j = nbr[o];
+    const size_t oj = static_cast<size_t>(nbrindx[o]) * NB + j;
+    const double c1 = cf1[o] + cf1[oj], c2 = cf2[o] + cf2[oj], c3 = cf3[o] + cf3[oj];
+    const double B0 = bo0[o];
+    // ForceBbo: Cbond(2) = cBO(1) A2 + (cBO(2)+cBO(3)) A3   (pot.F90:1354-1357)
+    s += (c1 * B0) * A2[o] + (c2 * bo2[o] + c3 * bo3[o]) * A3[o];
+    // ForceD(i): Cbond(2) ; ForceD(j) with j < i: Cbond(3)   (pot.F90:1262-1268, 125-138)
+    s += B0 * A2[o] * (cdi + ((j < i) ? cd[j] : 0.0));
+  }
+  cc[i] = s;
+}
+
+__global__ void __launch_bounds__(256) k_bond_forces(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
+                                                      const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                      const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
+                                                      const double *__restrict__ dln2, const double *__restrict__ dln3, const double *__restrict__ dBOp,
+                                                      const double *__restrict__ A0, const double *__restrict__ A1,
+                                                      const double *__restrict__ cf1, const double *__restrict__ cf2, const double *__restrict__ cf3,
+                                                      const double *__restrict__ fnx, const double *__restrict__ fny, const double *__restrict__ fnz,
+                                                      const double *__restrict__ cd, const double *__restrict__ cc,
+                                                      double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G) return;
+  const int cnt = nbrcnt[i];
+  const double xi = x[i], yi = y[i], zi = z[i], cdi = cd[i], cci = cc[i];
+  double f0 = fx[i], f1 = fy[i], f2 = fz[i];
+  for (int t = 0; t < cnt; ++t) {
+    const size_t o = static_cast<size_t>(t) * NB + i;
+    const int j = nbr[o];
+    const size_t oj = static_cast<size_t>(nbrindx[o]) * NB + j;
+    const double c1 = cf1[o] + cf1[oj], c2 = cf2[o] + cf2[oj], c3 = cf3[o] + cf3[oj];
+    const double B0 = bo0[o], dB = dBOp[o], a1 = A1[o];
+    const double a01 = A0[o] + B0 * a1;
+    // ForceBbo Cbond(1) (pot.F90:1333-1335) + ForceD of both ends (pot.F90:1244-1246) + ccbnd of both ends (pot.F90:129-135)
+    const double cb = c1 * a01 * dB + c2 * bo2[o] * (dln2[o] + a1 * dB) + c3 * bo3[o] * (dln3[o] + a1 * dB)
+                    + (cdi + cd[j]) * a01 * dB + (cci + cc[j]) * dB;
+    f0 += fnx[oj] - cb * (xi - x[j]);
+    f1 += fny[oj] - cb * (yi - y[j]);
+    f2 += fnz[oj] - cb * (zi - z[j]);
+  }
+  fx[i] = f0; fy[i] = f1; fz[i] = f2;
+}
+
+void Engine::assemble_forces() {
+  k_cd_gather<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, cds, cdn, cd);
+  k_ccbnd<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, bo0, bo2, bo3, A2, A3, cf1, cf2, cf3, cd, cc_);
+  k_bond_forces<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, pos[0], pos[1], pos[2], bo0, bo2, bo3, dln2, dln3, dBOp, A0, A1, cf1, cf2, cf3,
+                                                  fnx, fny, fnz, cd, cc_, frc[0], frc[1], frc[2]);
+}
+
+void Engine::force() {
+  if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+  tic(6);
+  if (!lists_valid) build_ghosts_and_lists();
+  double *pe_d = scal + 32;
+  RX_HIP(hipMemsetAsync(pe_d, 0, sizeof(double) * 16, stream));
+  hipEventRecord(ev[2], stream);
+  bond_orders();
+  hipEventRecord(ev[3], stream);
+  nonbonded();
+  hipEventRecord(ev[4], stream);
+  bonded_energies();
+  assemble_forces();
+  fold_ghost_forces();
+  hipEventRecord(ev[5], stream);
+  RX_HIP(hipMemcpyAsync(h_scal + 32, pe_d, sizeof(double) * 16, hipMemcpyDeviceToHost, stream));
+  RX_HIP(hipStreamSynchronize(stream));
+  pe[0] = 0.0;
+  for (int k = 1; k < 14; ++k) { pe[k] = h_scal[32 + k]; pe[0] += pe[k]; }   // PE(0)=sum(PE(1:13)), main.F90:236
+  float ms = 0;
+  hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_bo += ms;
+  hipEventElapsedTime(&ms, ev[3], ev[4]); st.ms_nonbond += ms;
+  hipEventElapsedTime(&ms, ev[4], ev[5]); st.ms_bonded += ms;
+  st.ms_force += toc(6, 7);
+  if (!std::isfinite(pe[0])) throw EngineError(RXMD_E_NAN, "non-finite potential energy (degenerate geometry?)");
+}
+
+// ------------------------------------------------------------------------------------------------
+// vkick (main.F90:192-207), extended-Lagrangian charges (main.F90:67-68,98) and the drift (main.F90:72)
+__global__ void k_kick_drift(int N, DevFF ff, double dt, double lex_w2, const int *__restrict__ type,
+                             double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+                             const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
+                             double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                             const double *__restrict__ q, double *__restrict__ qsfp, double *__restrict__ qsfv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double dthm = dt * 0.5 / ff.atom[type[i]].mass;       // init.F90:106
+  const double v0 = vx[i] + 1.0 * dthm * fx[i], v1 = vy[i] + 1.0 * dthm * fy[i], v2 = vz[i] + 1.0 * dthm * fz[i];
+  vx[i] = v0; vy[i] = v1; vz[i] = v2;
+  const double w = qsfv[i] + 0.5 * dt * lex_w2 * (q[i] - qsfp[i]);
+  qsfv[i] = w;
+  qsfp[i] = qsfp[i] + dt * w;
+  x[i] = x[i] + dt * v0; y[i] = y[i] + dt * v1; z[i] = z[i] + dt * v2;
+}
+__global__ void k_kick(int N, DevFF ff, double dt, double lex_w2, const int *__restrict__ type,
+                       double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+                       const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
+                       const double *__restrict__ q, const double *__restrict__ qsfp, double *__restrict__ qsfv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double dthm = dt * 0.5 / ff.atom[type[i]].mass;
+  vx[i] = vx[i] + 1.0 * dthm * fx[i]; vy[i] = vy[i] + 1.0 * dthm * fy[i]; vz[i] = vz[i] + 1.0 * dthm * fz[i];
+  qsfv[i] = qsfv[i] + 0.5 * dt * lex_w2 * (q[i] - qsfp[i]);
+}
+
+void Engine::step(int nsteps) {
+  if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+  for (int s = 0; s < nsteps; ++s) {
+    tic(0);
+    hipEventRecord(ev[0], stream);
+    k_kick_drift<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], pos[0], pos[1], pos[2], q, qsfp, qsfv);
+    migrate();                                                           // main.F90:75
+    const int qs = cfg.qstep > 0 ? cfg.qstep : 1;
+    if (step_count % qs == 0) qeq();                                     // main.F90:77-83
+    force();                                                             // main.F90:84
+    k_kick<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], q, qsfp, qsfv);
+    ++step_count;
+  }
+  RX_HIP(hipStreamSynchronize(stream));
+}
+
+}  // namespace rxmd

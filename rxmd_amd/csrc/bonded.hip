@@ -1,0 +1,479 @@
+// bonded.hip -- bonded energy terms of FORCE (reference src/pot.F90) as own-slot accumulation kernels.
+//   Ebond (pot.F90:926-977) + Elnpr (pot.F90:148-316) -> k_ebond_elnpr
+//   E3b   (pot.F90:319-557)                           -> k_e3b
+//   E4b   (pot.F90:980-1227)                          -> k_e4b   (every torsion visited from both ends)
+//   Ehb   (pot.F90:559-673)                           -> k_ehb   (one wavefront per donor atom)
+// The reference scatters every derivative at once with atomics (ForceB/ForceBbo/ForceA3/ForceA4,
+// pot.F90:1276-1521).  Here a thread owns one centre atom and accumulates ONLY into that atom's own
+// rows of the slot-major tables:
+//     cf1,cf2,cf3[slot]  dE/dBO of the bond in that slot, in ForceBbo's cf() form (pot.F90:1331):
+//                        full BO, pi-minus-full, pipi-minus-full.  ForceB(c) == cf (c,0,0).
+//     cdn[slot]          contribution to cdbnd of the NEIGHBOUR in that slot (pot.F90:304,536,539,1183)
+//     fnx,fny,fnz[slot]  angle/torsion force on the neighbour in that slot
+//     cds, f (self)      contribution to the centre's own cdbnd / force
+// assemble.hip turns these into forces by pure gathers through nbrindx: deterministic, no FP64 atomics
+// (except the acceptor atom of a hydrogen bond, which is a 10 A partner and has no slot).
+#include "engine.h"
+
+namespace rxmd {
+
+static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+
+static constexpr double MINBO0 = 1e-4, cutof2_esub = 1e-4;                                        // module.F90:61-62
+static constexpr double MAXANGLE = 0.999999999999, MINANGLE = -0.999999999999, NSMALL = 1e-10;   // module.F90:85-87
+static constexpr double PI_ = 3.14159265358979;                                                  // module.F90:90
+
+__device__ inline double wave_sum_b(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the block, then one atomic per block into the energy accumulator
+__device__ inline void block_energy_add(double v, double *dst) {
+  __shared__ double sm[8];
+  v = wave_sum_b(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < (blockDim.x >> 6); ++k) s += sm[k];
+    if (s != 0.0) atomicAdd(dst, s);
+  }
+}
+__device__ inline double ipow7(double a) { const double a2 = a * a, a4 = a2 * a2; return (a * a2) * a4; }
+
+struct V3 { double x, y, z; };
+__device__ inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// derivative of cos(i,j,k) (ForceA3, pot.F90:1462-1521): forces on i and on k; j gets -(fi+fk)
+__device__ inline void angle_forces(double coeff, const V3 &rij, double nij, const V3 &rjk, double njk, V3 &fi, V3 &fk) {
+  const double C00 = nij * nij, C01 = dot(rij, rjk), C11 = njk * njk;
+  const double coCC = coeff * (1.0 / (nij * njk));
+  const double Ci1 = -(C01 / C00), Ck2 = C01 / C11;
+  fi.x = coCC * (Ci1 * rij.x + rjk.x); fi.y = coCC * (Ci1 * rij.y + rjk.y); fi.z = coCC * (Ci1 * rij.z + rjk.z);
+  // fjk = -coCC*(Ck1*rij + Ck2*rjk), Ck1 = -1 ; force on k is -fjk
+  fk.x = coCC * (-rij.x + Ck2 * rjk.x); fk.y = coCC * (-rij.y + Ck2 * rjk.y); fk.z = coCC * (-rij.z + Ck2 * rjk.z);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ebond_elnpr(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+                                                      const long long *__restrict__ gid, const double *__restrict__ bo0, const double *__restrict__ bo1,
+                                                      const double *__restrict__ bo2, const double *__restrict__ bo3, const double *__restrict__ delta,
+                                                      const double *__restrict__ deltalp, const double *__restrict__ dDlp,
+                                                      double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn, double *__restrict__ pe) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double e1 = 0.0, e2 = 0.0, e3 = 0.0, e4 = 0.0;
+  if (i < N) {
+    const int ti = type[i], cnt = nbrcnt[i];
+    const DevAtomP ai = ff.atom[ti];
+    const long long iid = gid[i];
+    double sum_ovun1 = 0.0, sum_ovun2 = 0.0;
+    for (int s = 0; s < cnt; ++s) {
+      const size_t o = static_cast<size_t>(s) * NB + i;
+      const int j = nbr[o];
+      const DevBondP bp = ff.bond[ff.inxn2[ti * ff.n1 + type[j]]];
+      sum_ovun1 += bp.povun1 * bp.Desig * bo0[o];                         // pot.F90:223
+      sum_ovun2 += (delta[j] - deltalp[j]) * (bo2[o] + bo3[o]);           // pot.F90:224
+      if (gid[j] < iid) {                                                 // Ebond, pot.F90:949
+        const double B1 = bo1[o];
+        const double pw = pow(B1, bp.pbe2);
+        const double ex = exp(bp.pbe1 * (1.0 - pw));
+        e1 += -bp.Desig * B1 * ex - bp.Depi * bo2[o] - bp.Depipi * bo3[o];
+        const double CEbo = -bp.Desig * ex * (1.0 - bp.pbe1 * bp.pbe2 * pw);
+        cf1[o] += CEbo; cf2[o] += (-bp.Depi - CEbo); cf3[o] += (-bp.Depipi - CEbo);   // coeff = (CEbo,-Depi,-Depipi)
+      }
+    }
+    const double dlp = deltalp[i], dl = delta[i], dD = dDlp[i];
+    const double expvd2 = exp(-75.0 * dlp);
+    const double dElp = ai.plp2 * ((1.0 + expvd2) + 75.0 * dlp * expvd2) / ((1.0 + expvd2) * (1.0 + expvd2));
+    const double expovun1 = ff.povun3 * exp(ff.povun4 * sum_ovun2);
+    const double dcorr = dl - dlp / (1.0 + expovun1);
+    const double expovun2 = exp(ai.povun2 * dcorr);
+    const double DlpV = 1.0 / (dcorr + ai.Val + 1e-8);
+    const double expovun2n = 1.0 / expovun2;
+    const double expovun6 = exp(ff.povun6 * dcorr);
+    const double expovun8 = ff.povun7 * exp(ff.povun8 * sum_ovun2);
+    const double d1 = 1.0 / (1.0 + expovun1), d2 = 1.0 / (1.0 + expovun2), d2n = 1.0 / (1.0 + expovun2n), d8 = 1.0 / (1.0 + expovun8);
+    e2 = ai.plp2 * dlp / (1.0 + expvd2);
+    e3 = sum_ovun1 * DlpV * dcorr * d2;
+    const double PEunder = -ai.povun5 * (1.0 - expovun6) * d2n * d8;
+    e4 = PEunder;
+    const double CElp1 = dElp * dD;
+    const double CEo1 = dcorr * DlpV * d2;
+    const double CEo2 = sum_ovun1 * DlpV * d2 * (1.0 - dcorr * DlpV - ai.povun2 * dcorr * d2n);
+    const double CEo3 = CEo2 * (1.0 - dD * d1);
+    const double CEo4 = CEo2 * dlp * ff.povun4 * expovun1 * (d1 * d1);
+    const double CEu1 = (ai.povun5 * ff.povun6 * expovun6 * d8 + PEunder * ai.povun2 * expovun2n) * d2n;
+    const double CEu2 = -PEunder * ff.povun8 * expovun8 * d8;
+    const double CEu3 = CEu1 * (1.0 - dD * d1);
+    const double CEu4 = CEu1 * dlp * ff.povun4 * expovun1 * (d1 * d1) + CEu2;
+    for (int s = 0; s < cnt; ++s) {                                        // pot.F90:282-305
+      const size_t o = static_cast<size_t>(s) * NB + i;
+      const int j = nbr[o];
+      const DevBondP bp = ff.bond[ff.inxn2[ti * ff.n1 + type[j]]];
+      const double bpp = bo2[o] + bo3[o], dj = delta[j] - deltalp[j], oneD = 1.0 - dDlp[j];
+      const double CEo5 = CEo1 * bp.povun1 * bp.Desig;
+      const double CElp_b = CElp1 + CEo3 + CEo5 + CEu3;
+      const double CElp_bpp = CEo4 * dj + CEu4 * dj;
+      cf1[o] += CElp_b; cf2[o] += CElp_bpp; cf3[o] += CElp_bpp;           // coeff = CElp_b + (0,bpp,bpp)
+      cdn[o] += CEo4 * oneD * bpp + CEu4 * oneD * bpp;                     // cdbnd(j) += CElp_d
+    }
+  }
+  block_energy_add(e1, pe + 1); block_energy_add(e2, pe + 2); block_energy_add(e3, pe + 3); block_energy_add(e4, pe + 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+                                              const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                              const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
+                                              const double *__restrict__ delta, const double *__restrict__ nlp, const double *__restrict__ dDlp,
+                                              double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
+                                              double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
+                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double e5 = 0.0, e6 = 0.0, e7 = 0.0;
+  if (j < N) {
+    const int tj = type[j], nj = nbrcnt[j];
+    const DevAtomP aj = ff.atom[tj];
+    const double xj = x[j], yj = y[j], zj = z[j];
+    double sum_BO8 = 0.0, sum_SBO1 = 0.0;
+    for (int n1 = 0; n1 < nj; ++n1) {
+      const size_t o = static_cast<size_t>(n1) * NB + j;
+      const double b = bo0[o], b2 = b * b, b4 = b2 * b2;
+      sum_BO8 -= b4 * b4;                                                  // BO**8, pot.F90:362
+      sum_SBO1 += bo2[o] + bo3[o];
+    }
+    const double prod_SBO = exp(sum_BO8);
+    const double dlj = delta[j];
+    const double delta_ang = dlj + aj.Val - aj.Valangle;
+    const double nlpj = nlp[j], dDj = dDlp[j];
+    // sums over all angles of the terms that ForceBbo(j,n1,...) applies to EVERY bond of j (pot.F90:526-532)
+    double S_d1 = 0.0, S_v6 = 0.0, S_v5 = 0.0;
+    V3 fself = {0.0, 0.0, 0.0};
+    for (int i1 = 0; i1 < nj - 1; ++i1) {
+      const size_t oi = static_cast<size_t>(i1) * NB + j;
+      const double BOij_f = bo0[oi], BOij = BOij_f - cutof2_esub;
+      if (!(BOij > 0.0)) continue;
+      const int i = nbr[oi], ti = type[i];
+      const V3 rij = {x[i] - xj, y[i] - yj, z[i] - zj};
+      const double nij = sqrt(dot(rij, rij));
+      for (int k1 = i1 + 1; k1 < nj; ++k1) {
+        const size_t ok = static_cast<size_t>(k1) * NB + j;
+        const double BOjk_f = bo0[ok], BOjk = BOjk_f - cutof2_esub;
+        if (!(BOjk > 0.0)) continue;
+        if (!(BOij_f * BOjk_f > cutof2_esub)) continue;
+        const int k = nbr[ok], tk = type[k];
+        const int inxn = ff.inxn3[(ti * ff.n1 + tj) * ff.n1 + tk];
+        if (inxn == 0) continue;
+        const DevAngleP ap = ff.angle[inxn];
+        const V3 rjk = {xj - x[k], yj - y[k], zj - z[k]};
+        const double njk = sqrt(dot(rjk, rjk));
+        double cos_ijk = -dot(rij, rjk) / (nij * njk);
+        if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
+        if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
+        const double theta_ijk = acos(cos_ijk), sin_ijk = sin(theta_ijk);
+        const double BOij_p4 = pow(BOij, ap.pval4), exp3ij = exp(-aj.pval3 * BOij_p4), fn7ij = 1.0 - exp3ij;
+        const double BOjk_p4 = pow(BOjk, ap.pval4), exp3jk = exp(-aj.pval3 * BOjk_p4), fn7jk = 1.0 - exp3jk;
+        const double exp6 = exp(ff.pval6 * delta_ang), exp7 = exp(-ap.pval7 * delta_ang), trm8 = 1.0 + exp6 + exp7;
+        const double fn8j = aj.pval5 - (aj.pval5 - 1.0) * (2.0 + exp6) / trm8;
+        const double SBO = sum_SBO1 + (1.0 - prod_SBO) * (-delta_ang - ff.pval8 * nlpj);
+        double SBO2 = 0.0, CSBO2 = 0.0;
+        if (SBO > 0.0 && SBO <= 1.0) { SBO2 = pow(SBO, ff.pval9); CSBO2 = ff.pval9 * pow(SBO, ff.pval9 - 1.0); }
+        else if (SBO > 1.0 && SBO <= 2.0) { SBO2 = 2.0 - pow(2.0 - SBO, ff.pval9); CSBO2 = ff.pval9 * pow(2.0 - SBO, ff.pval9 - 1.0); }
+        else if (SBO > 2.0) SBO2 = 2.0;
+        const double ex10 = exp(-ff.pval10 * (2.0 - SBO2));
+        const double theta0 = PI_ - ap.theta00 * (1.0 - ex10);
+        const double theta_diff = theta0 - theta_ijk;
+        const double exp2 = exp(-ap.pval2 * theta_diff * theta_diff);
+        e5 += fn7ij * fn7jk * fn8j * (ap.pval1 - ap.pval1 * exp2);
+        const double Cf7ij = aj.pval3 * ap.pval4 * pow(BOij, ap.pval4 - 1.0) * exp3ij;
+        const double Cf7jk = aj.pval3 * ap.pval4 * pow(BOjk, ap.pval4 - 1.0) * exp3jk;
+        const double Cf8j = (1.0 - aj.pval5) / (trm8 * trm8) * (ff.pval6 * exp6 * trm8 - (2.0 + exp6) * (ff.pval6 * exp6 - ap.pval7 * exp7));
+        const double Ctheta0 = ff.pval10 * ap.theta00 * ex10;
+        const double dSBO1 = -8.0 * prod_SBO * (delta_ang + ff.pval8 * nlpj);
+        const double dSBO2 = (prod_SBO - 1.0) * (1.0 - ff.pval8 * dDj);
+        const double CEval1 = Cf7ij * fn7jk * fn8j * ap.pval1 * (1.0 - exp2);
+        const double CEval2 = fn7ij * Cf7jk * fn8j * ap.pval1 * (1.0 - exp2);
+        const double CEval3 = fn7ij * fn7jk * Cf8j * ap.pval1 * (1.0 - exp2);
+        const double CEval4 = 2.0 * ap.pval1 * ap.pval2 * fn7ij * fn7jk * fn8j * exp2 * theta_diff;
+        const double CEval5 = CEval4 * Ctheta0 * CSBO2;
+        const double CEval6 = CEval5 * dSBO1, CEval7 = CEval5 * dSBO2, CEval8 = CEval4 / sin_ijk;
+        // penalty, pot.F90:460-476
+        const double exp_pen3 = exp(-ff.ppen3 * dlj), exp_pen4 = exp(ff.ppen4 * dlj);
+        const double trm34 = 1.0 + exp_pen3 + exp_pen4;
+        const double fn9 = (2.0 + exp_pen3) / trm34;
+        const double PEpen = ap.ppen1 * fn9 * exp(-ff.ppen2 * (BOij - 2.0) * (BOij - 2.0)) * exp(-ff.ppen2 * (BOjk - 2.0) * (BOjk - 2.0));
+        e6 += PEpen;
+        const double Cf9j = (-ff.ppen3 * exp_pen3 * trm34 - (2.0 + exp_pen3) * (-ff.ppen3 * exp_pen3 + ff.ppen4 * exp_pen4)) / (trm34 * trm34);
+        const double CEpen1 = Cf9j / fn9 * PEpen, CEpen2 = -2.0 * ff.ppen2 * (BOij - 2.0) * PEpen, CEpen3 = -2.0 * ff.ppen2 * (BOjk - 2.0) * PEpen;
+        // three-body conjugation, pot.F90:479-497
+        const double sum_BOi = delta[i] + ff.atom[ti].Val, sum_BOk = delta[k] + ff.atom[tk].Val;
+        const double delta_val = dlj + aj.Val - aj.Valval;
+        const double exp_coa2 = exp(ff.pcoa2 * delta_val);
+        const double ui = -BOij + sum_BOi, uk = -BOjk + sum_BOk;
+        const double PEcoa = ap.pcoa1 / (1.0 + exp_coa2) * exp(-ff.pcoa3 * (ui * ui)) * exp(-ff.pcoa3 * (uk * uk)) *
+                             exp(-ff.pcoa4 * ((BOij - 1.5) * (BOij - 1.5))) * exp(-ff.pcoa4 * ((BOjk - 1.5) * (BOjk - 1.5)));
+        e7 += PEcoa;
+        const double CEcoa1 = -2.0 * ff.pcoa4 * (BOij - 1.5) * PEcoa, CEcoa2 = -2.0 * ff.pcoa4 * (BOjk - 1.5) * PEcoa;
+        const double CEcoa3 = -ff.pcoa2 * exp_coa2 / (1.0 + exp_coa2) * PEcoa;
+        const double CEcoa4 = -2.0 * ff.pcoa3 * ui * PEcoa, CEcoa5 = -2.0 * ff.pcoa3 * uk * PEcoa;
+        // accumulate, pot.F90:509-541
+        cf1[oi] += CEpen2 + CEcoa1 - CEcoa4 + CEval1;      // ForceB on bond i-j
+        cf1[ok] += CEpen3 + CEcoa2 - CEcoa5 + CEval2;      // ForceB on bond j-k
+        S_d1 += CEpen1 + CEcoa3 + CEval3 + CEval7; S_v6 += CEval6; S_v5 += CEval5;
+        cdn[oi] += CEcoa4; cdn[ok] += CEcoa5;              // cdbnd(i), cdbnd(k)
+        V3 fi, fk;
+        angle_forces(CEval8, rij, nij, rjk, njk, fi, fk);
+        fnx[oi] += fi.x; fny[oi] += fi.y; fnz[oi] += fi.z;
+        fnx[ok] += fk.x; fny[ok] += fk.y; fnz[ok] += fk.z;
+        fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z;
+      }
+    }
+    if (S_d1 != 0.0 || S_v6 != 0.0 || S_v5 != 0.0)
+      for (int n1 = 0; n1 < nj; ++n1) {
+        const size_t o = static_cast<size_t>(n1) * NB + j;
+        cf1[o] += S_d1 + S_v6 * ipow7(bo0[o]); cf2[o] += S_v5; cf3[o] += S_v5;
+      }
+    fx[j] += fself.x; fy[j] += fself.y; fz[j] += fself.z;
+  }
+  block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to
+// i,j,k,l.  Here thread j walks ALL its centre bonds; it books the energy, the j-k bond coefficient and the
+// cdbnd terms only when gid(j) < gid(k) (the reference's orientation, which the index-ordered ccbnd rule
+// depends on), the forces on i and on itself and the i-j bond coefficient always.  The k/l side of the same
+// torsion is booked by thread k when it walks k-j.
+__global__ void __launch_bounds__(128) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+                                              const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                              const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
+                                              double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cdn,
+                                              double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
+                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double e8 = 0.0, e9 = 0.0;
+  if (j < N) {
+    const int tj = type[j], nj = nbrcnt[j];
+    const DevAtomP aj = ff.atom[tj];
+    const double xj = x[j], yj = y[j], zj = z[j];
+    const double delta_ang_j = delta[j] + aj.Val - aj.Valangle;
+    const long long jid = gid[j];
+    V3 fself = {0.0, 0.0, 0.0};
+    double cd_self = 0.0;
+    for (int k1 = 0; k1 < nj; ++k1) {
+      const size_t ok = static_cast<size_t>(k1) * NB + j;
+      const double BOjk_f = bo0[ok];
+      if (!(BOjk_f > cutof2_esub)) continue;
+      const double BOjk = BOjk_f - cutof2_esub;
+      const int k = nbr[ok], tk = type[k], nk = nbrcnt[k];
+      const bool own = jid < gid[k];
+      const double delta_ang_jk = own ? (delta_ang_j + (delta[k] + ff.atom[tk].Val - ff.atom[tk].Valangle))
+                                      : ((delta[k] + ff.atom[tk].Val - ff.atom[tk].Valangle) + delta_ang_j);
+      const V3 rjk = {xj - x[k], yj - y[k], zj - z[k]};
+      const double njk = sqrt(dot(rjk, rjk));
+      const double bo2jk = bo2[ok];
+      double cf1_jk = 0.0, cf2_jk = 0.0, cd_k = 0.0;
+      V3 fk_unused = {0, 0, 0}; (void)fk_unused;
+      for (int i1 = 0; i1 < nj; ++i1) {
+        if (i1 == k1) continue;
+        const size_t oi = static_cast<size_t>(i1) * NB + j;
+        const double BOij_f = bo0[oi];
+        if (!(BOij_f > cutof2_esub && BOij_f * BOjk_f > cutof2_esub)) continue;
+        const double BOij = BOij_f - cutof2_esub;
+        const int i = nbr[oi], ti = type[i];
+        if (i == k) continue;
+        const V3 rij = {x[i] - xj, y[i] - yj, z[i] - zj};
+        const double nij = sqrt(dot(rij, rij));
+        double cos_ijk = -dot(rij, rjk) / (nij * njk);
+        if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
+        if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
+        const double sin_ijk = sqrt((1.0 - cos_ijk) * (1.0 + cos_ijk));   // sin(acos(c))
+        const double tan_ijk_i = cos_ijk / sin_ijk;                        // 1/tan(theta)
+        // cross_product(rij, rjk), pot.F90:1524-1543
+        const V3 n1v = {rij.x / nij, rij.y / nij, rij.z / nij}, n2v = {rjk.x / njk, rjk.y / njk, rjk.z / njk};
+        const V3 c1v = {n1v.y * n2v.z - n1v.z * n2v.y, n1v.z * n2v.x - n1v.x * n2v.z, n1v.x * n2v.y - n1v.y * n2v.x};
+        double nc1 = sqrt(dot(c1v, c1v));
+        if (nc1 < NSMALL) nc1 = NSMALL;
+        double cf1_ij = 0.0;
+        V3 fi_acc = {0.0, 0.0, 0.0};
+        for (int l1 = 0; l1 < nk; ++l1) {
+          const size_t ol = static_cast<size_t>(l1) * NB + k;
+          const double BOkl_f = bo0[ol];
+          if (!(BOkl_f > cutof2_esub && BOjk_f * BOkl_f > cutof2_esub)) continue;
+          const int l = nbr[ol];
+          if (l == i || l == j) continue;
+          const int inxn = ff.inxn4[((ti * ff.n1 + tj) * ff.n1 + tk) * ff.n1 + type[l]];
+          if (inxn == 0) continue;
+          if (!(BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0)) continue;
+          const DevTorsP tp = ff.tors[inxn];
+          const double BOkl = BOkl_f - cutof2_esub;
+          const V3 rkl = {x[k] - x[l], y[k] - y[l], z[k] - z[l]};
+          const double nkl = sqrt(dot(rkl, rkl));
+          const double et1 = exp(-ff.ptor2 * BOij), et2 = exp(-ff.ptor2 * BOjk), et3 = exp(-ff.ptor2 * BOkl);
+          const double exp_tor3 = exp(-ff.ptor3 * delta_ang_jk), exp_tor4 = exp(ff.ptor4 * delta_ang_jk);
+          const double exp_tor34_i = 1.0 / (1.0 + exp_tor3 + exp_tor4);
+          const double fn10 = (1.0 - et1) * (1.0 - et2) * (1.0 - et3);
+          const double fn11 = (2.0 + exp_tor3) * exp_tor34_i;
+          const double fn12 = exp(-ff.pcot2 * ((BOij - 1.5) * (BOij - 1.5) + (BOjk - 1.5) * (BOjk - 1.5) + (BOkl - 1.5) * (BOkl - 1.5)));
+          const double btb2 = 2.0 - bo2jk - fn11;
+          const double exp_tor1 = exp(tp.ptor1 * (btb2 * btb2));
+          double cos_jkl = -dot(rjk, rkl) / (njk * nkl);
+          if (cos_jkl > MAXANGLE) cos_jkl = MAXANGLE;
+          if (cos_jkl < MINANGLE) cos_jkl = MINANGLE;
+          const double sin_jkl = sqrt((1.0 - cos_jkl) * (1.0 + cos_jkl));
+          const double tan_jkl_i = cos_jkl / sin_jkl;
+          const V3 n3v = {rkl.x / nkl, rkl.y / nkl, rkl.z / nkl};
+          const V3 c2v = {n2v.y * n3v.z - n2v.z * n3v.y, n2v.z * n3v.x - n2v.x * n3v.z, n2v.x * n3v.y - n2v.y * n3v.x};
+          double nc2 = sqrt(dot(c2v, c2v));
+          if (nc2 < NSMALL) nc2 = NSMALL;
+          double c1 = dot(c1v, c2v) / (nc1 * nc2);
+          if (c1 > MAXANGLE) c1 = MAXANGLE;
+          if (c1 < MINANGLE) c1 = MINANGLE;
+          const double c1sq = c1 * c1;
+          const double cos_2w = 2.0 * c1sq - 1.0;                           // cos(2 acos c)
+          const double c2 = 1.0 - cos_2w, c3 = 1.0 + (4.0 * c1sq - 3.0) * c1;  // 1 + cos(3 acos c)
+          const double vsum = tp.V1 * (1.0 + c1) + tp.V2 * exp_tor1 * c2 + tp.V3 * c3;
+          const double ss = sin_ijk * sin_jkl;
+          const double PEconj = tp.pcot1 * fn12 * (1.0 + (c1sq - 1.0) * ss);
+          if (own) { e8 += 0.5 * fn10 * ss * vsum; e9 += PEconj; }
+          const double CEt1 = 0.5 * ss * vsum;
+          const double CEt2 = -tp.ptor1 * fn10 * ss * tp.V2 * exp_tor1 * btb2 * c2;
+          const double dfn11 = (-ff.ptor3 * exp_tor3 + (ff.ptor3 * exp_tor3 - ff.ptor4 * exp_tor4) * (2.0 + exp_tor3) * exp_tor34_i) * exp_tor34_i;
+          const double CEt3 = CEt2 * dfn11;
+          const double CEt4 = CEt1 * ff.ptor2 * et1 * (1.0 - et2) * (1.0 - et3);
+          const double CEt5 = CEt1 * ff.ptor2 * (1.0 - et1) * et2 * (1.0 - et3);
+          const double cmn = -0.5 * fn10 * vsum;
+          const double CEt7 = cmn * sin_jkl * tan_ijk_i, CEt8 = cmn * sin_ijk * tan_jkl_i;
+          const double CEt9 = fn10 * ss * (0.5 * tp.V1 - 2.0 * tp.V2 * exp_tor1 * c1 + 1.5 * tp.V3 * (cos_2w + 2.0 * c1sq));
+          const double Cconj = -2.0 * ff.pcot2 * PEconj;
+          const double CEc1 = Cconj * (BOij - 1.5), CEc2 = Cconj * (BOjk - 1.5);
+          const double CEc4 = -tp.pcot1 * fn12 * (c1sq - 1.0) * tan_ijk_i * sin_jkl;
+          const double CEc5 = -tp.pcot1 * fn12 * (c1sq - 1.0) * sin_ijk * tan_jkl_i;
+          const double CEc6 = 2.0 * tp.pcot1 * fn12 * c1 * ss;
+          cf1_ij += CEc1 + CEt4;                                            // ForceB(i-j, C4body_b(1)), pot.F90:1185-1186
+          if (own) { cf1_jk += CEc2 + CEt5; cf2_jk += CEt2; cd_self += CEt3; cd_k += CEt3; }   // pot.F90:1178-1194
+          // angle i-j-k (coefficient C4body_a(1)): forces on i and j
+          V3 fi, fk;
+          angle_forces(CEc4 + CEt7, rij, nij, rjk, njk, fi, fk);
+          fi_acc.x += fi.x; fi_acc.y += fi.y; fi_acc.z += fi.z;
+          fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z;
+          // angle j-k-l (coefficient C4body_a(2)): j is the first atom
+          V3 fj2, fl2;
+          angle_forces(CEc5 + CEt8, rjk, njk, rkl, nkl, fj2, fl2);
+          fself.x += fj2.x; fself.y += fj2.y; fself.z += fj2.z;
+          // dihedral (ForceA4, pot.F90:1369-1459): forces on i (fij) and j (-fij + fjk)
+          {
+            const double coeff = CEc6 + CEt9;
+            const double C00 = nij * nij, C01 = dot(rij, rjk), C02 = dot(rij, rkl), C11 = njk * njk, C12 = dot(rjk, rkl), C22 = nkl * nkl;
+            const double D0 = C00 * C11 - C01 * C01, Dm1 = C11 * C22 - C12 * C12;
+            const double coDD = coeff * (1.0 / sqrt(D0 * Dm1));
+            const double com = C01 * C12 - C02 * C11;
+            const double Cwi1 = C11 / D0 * com, Cwi2 = -(C12 + C01 / D0 * com), Cwi3 = C11;
+            const double Cwj1 = -(C12 + (C11 + C01) / D0 * com);
+            const double Cwj2 = -(-C12 - 2 * C02 - C22 / Dm1 * com - (C00 + C01) / D0 * com);
+            const double Cwj3 = -(C01 + C11 + C12 / Dm1 * com);
+            const V3 fij = {coDD * (Cwi1 * rij.x + Cwi2 * rjk.x + Cwi3 * rkl.x), coDD * (Cwi1 * rij.y + Cwi2 * rjk.y + Cwi3 * rkl.y),
+                            coDD * (Cwi1 * rij.z + Cwi2 * rjk.z + Cwi3 * rkl.z)};
+            const V3 fjk = {coDD * ((Cwj1 + Cwi1) * rij.x + (Cwj2 + Cwi2) * rjk.x + (Cwj3 + Cwi3) * rkl.x),
+                            coDD * ((Cwj1 + Cwi1) * rij.y + (Cwj2 + Cwi2) * rjk.y + (Cwj3 + Cwi3) * rkl.y),
+                            coDD * ((Cwj1 + Cwi1) * rij.z + (Cwj2 + Cwi2) * rjk.z + (Cwj3 + Cwi3) * rkl.z)};
+            fi_acc.x += fij.x; fi_acc.y += fij.y; fi_acc.z += fij.z;
+            fself.x += -fij.x + fjk.x; fself.y += -fij.y + fjk.y; fself.z += -fij.z + fjk.z;
+          }
+        }
+        if (cf1_ij != 0.0) cf1[oi] += cf1_ij;
+        if (fi_acc.x != 0.0 || fi_acc.y != 0.0 || fi_acc.z != 0.0) { fnx[oi] += fi_acc.x; fny[oi] += fi_acc.y; fnz[oi] += fi_acc.z; }
+      }
+      if (own) { cf1[ok] += cf1_jk; cf2[ok] += cf2_jk; cdn[ok] += cd_k; }
+    }
+    cds[j] += cd_self;
+    fx[j] += fself.x; fy[j] += fself.y; fz[j] += fself.z;
+  }
+  block_energy_add(e8, pe + 8); block_energy_add(e9, pe + 9);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hydrogen bonds.  One wavefront per donor atom i; lanes sweep i's 10 A row for acceptors k.
+// Hydrogen is atom type 2, hard-coded in the reference (pot.F90:595) and kept.
+__global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+                                              const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                              const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10,
+                                              double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
+                                              double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  double e10 = 0.0;
+  if (i < N) {
+    const int ti = type[i], cnt = nbrcnt[i];
+    bool donor = false;                                  // does any (ti, 2, k) hydrogen-bond row exist?
+    if (ff.nso >= 2)
+      for (int t = 1; t <= ff.nso; ++t) donor |= (ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + t] != 0);
+    if (donor) {
+      const double xi = x[i], yi = y[i], zi = z[i];
+      const int n = n10[i];
+      const size_t row = static_cast<size_t>(i) * S10;
+      for (int s = 0; s < cnt; ++s) {
+        const size_t o = static_cast<size_t>(s) * NB + i;
+        const int j = nbr[o];
+        const double BOij = bo0[o];
+        if (!(type[j] == 2 && BOij > MINBO0)) continue;
+        const V3 rij = {xi - x[j], yi - y[j], zi - z[j]};
+        const double nij = sqrt(dot(rij, rij));
+        double cfs = 0.0, nterm = 0.0;
+        V3 fi_s = {0, 0, 0}, fj_s = {0, 0, 0};
+        for (int kk = lane; kk < n; kk += 64) {
+          const int k = nb10[row + kk];
+          const int inx = ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + type[k]];
+          if (k == j || k == i || inx == 0) continue;
+          const V3 rik = {xi - x[k], yi - y[k], zi - z[k]};
+          if (!(dot(rik, rik) < 100.0)) continue;                          // rchb2, pot.F90:610
+          const DevHbP hp = ff.hb[inx];
+          const V3 rjk = {x[j] - x[k], y[j] - y[k], z[j] - z[k]};
+          const double njk = sqrt(dot(rjk, rjk));
+          double cos_ijk = -dot(rij, rjk) / (nij * njk);
+          if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
+          if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
+          const double sh2 = 0.5 * (1.0 - cos_ijk);                        // sin^2(theta/2)
+          const double sin_xhz4 = sh2 * sh2, cos_xhz1 = 1.0 - cos_ijk;
+          const double exp_hb2 = exp(-hp.phb2 * BOij);
+          const double exp_hb3 = exp(-hp.phb3 * (hp.r0hb / njk + njk / hp.r0hb - 2.0));
+          const double PEhb = hp.phb1 * (1.0 - exp_hb2) * exp_hb3 * sin_xhz4;
+          e10 += PEhb; nterm += 1.0;
+          cfs += hp.phb1 * hp.phb2 * exp_hb2 * exp_hb3 * sin_xhz4;         // CEhb(1) -> ForceB(i,j)
+          const double CEhb2 = -0.5 * hp.phb1 * (1.0 - exp_hb2) * exp_hb3 * cos_xhz1;
+          const double CEhb3 = -PEhb * hp.phb3 * (-hp.r0hb / (njk * njk) + 1.0 / hp.r0hb) * (1.0 / njk);
+          V3 fi, fk;
+          angle_forces(CEhb2, rij, nij, rjk, njk, fi, fk);
+          const V3 ff3 = {CEhb3 * rjk.x, CEhb3 * rjk.y, CEhb3 * rjk.z};   // f(j) -= ff ; f(k) += ff
+          fi_s.x += fi.x; fi_s.y += fi.y; fi_s.z += fi.z;
+          fj_s.x += -(fi.x + fk.x) - ff3.x; fj_s.y += -(fi.y + fk.y) - ff3.y; fj_s.z += -(fi.z + fk.z) - ff3.z;
+          atomicAdd(fx + k, fk.x + ff3.x); atomicAdd(fy + k, fk.y + ff3.y); atomicAdd(fz + k, fk.z + ff3.z);
+        }
+        cfs = wave_sum_b(cfs); nterm = wave_sum_b(nterm);
+        fi_s.x = wave_sum_b(fi_s.x); fi_s.y = wave_sum_b(fi_s.y); fi_s.z = wave_sum_b(fi_s.z);
+        fj_s.x = wave_sum_b(fj_s.x); fj_s.y = wave_sum_b(fj_s.y); fj_s.z = wave_sum_b(fj_s.z);
+        if (lane == 0 && nterm > 0.0) {
+          cf1[o] += cfs;
+          fnx[o] += fj_s.x; fny[o] += fj_s.y; fnz[o] += fj_s.z;
+          atomicAdd(fx + i, fi_s.x); atomicAdd(fy + i, fi_s.y); atomicAdd(fz + i, fi_s.z);
+        }
+      }
+    }
+  }
+  block_energy_add(e10, pe + 10);
+}
+
+void Engine::bonded_energies() {
+  double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
+  k_ebond_elnpr<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, dDlp, cf1, cf2, cf3, cdn, pe_d);
+  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+                                          cds, frc[0], frc[1], frc[2], pe_d);
+  k_e4b<<<nblk(N, 128), 128, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, cf1, cf2, cdn, fnx, fny, fnz,
+                                          cds, frc[0], frc[1], frc[2], pe_d);
+  k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
+}
+
+}  // namespace rxmd

@@ -1,0 +1,392 @@
+// capi.hip -- the extern "C" boundary declared in include/rxmd_hip.h, plus the host front-end helpers
+// (geninit / rxff.bin reader) that a driver needs around the hot path.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+using rxmd::Engine;
+using rxmd::EngineError;
+
+struct rxmd_hip_engine {
+  Engine *e = nullptr;
+  std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+template <class F>
+static int guarded(rxmd_handle h, F &&f) {
+  if (!h || !h->e) return RXMD_E_ARG;
+  try {
+    f(*h->e);
+    return RXMD_OK;
+  } catch (const EngineError &e) {
+    h->err = e.msg;
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    h->err = "host out of memory";
+    return RXMD_E_NBUFFER;
+  } catch (const std::exception &e) {
+    h->err = e.what();
+    return RXMD_E_STATE;
+  }
+}
+
+extern "C" {
+
+void rxmd_hip_default_config(rxmd_config *c) {
+  std::memset(c, 0, sizeof(*c));
+  c->vprocs[0] = c->vprocs[1] = c->vprocs[2] = 1;
+  c->lattice[3] = c->lattice[4] = c->lattice[5] = 90.0;
+  c->isQEq = 1; c->NMAXQEq = 500; c->QEq_tol = 1e-7; c->qstep = 1;   // rxmd.in defaults of examples/1-reaxff
+  c->dt_fs = 0.25; c->Lex_fqs = 1.0; c->Lex_k = 2.0;                  // module.F90:164
+}
+
+int rxmd_hip_has_device_code(void) { return 1; }
+
+int rxmd_hip_create(const rxmd_config *cfg, rxmd_handle *out) {
+  if (!cfg || !out) return RXMD_E_ARG;
+  *out = nullptr;
+  rxmd_hip_engine *h = new (std::nothrow) rxmd_hip_engine;
+  if (!h) return RXMD_E_NBUFFER;
+  try {
+    h->e = new Engine(*cfg);
+  } catch (const EngineError &e) {
+    g_create_error = e.msg;
+    std::fprintf(stderr, "rxmd_hip_create: %s\n", e.msg.c_str());
+    delete h;
+    return e.code;
+  } catch (const std::exception &e) {
+    g_create_error = e.what();
+    delete h;
+    return RXMD_E_STATE;
+  }
+  *out = h;
+  return RXMD_OK;
+}
+
+int rxmd_hip_destroy(rxmd_handle h) {
+  if (!h) return RXMD_E_ARG;
+  delete h->e;
+  delete h;
+  return RXMD_OK;
+}
+
+const char *rxmd_hip_last_error(rxmd_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rxmd_hip_set_atoms_rxff(rxmd_handle h, int natoms, const double *rec10) {
+  if (!rec10) return RXMD_E_ARG;
+  return guarded(h, [&](Engine &e) { e.set_atoms_rxff(natoms, rec10); });
+}
+
+int rxmd_hip_get_atoms_rxff(rxmd_handle h, double *rec10, int capacity) {
+  int n = 0;
+  const int rc = guarded(h, [&](Engine &e) { n = e.get_atoms_rxff(rec10, capacity); });
+  return rc < 0 ? rc : n;
+}
+
+int rxmd_hip_get_atoms(rxmd_handle h, int capacity, long long *gid, int *type, double *pos, double *v, double *f, double *q) {
+  int n = 0;
+  const int rc = guarded(h, [&](Engine &e) {
+    if (!e.atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+    n = e.N;
+    if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity smaller than natoms");
+    RX_HIP(hipStreamSynchronize(e.stream));
+    if (gid) RX_HIP(hipMemcpy(gid, e.gid, sizeof(long long) * n, hipMemcpyDeviceToHost));
+    if (type) RX_HIP(hipMemcpy(type, e.type, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (q) RX_HIP(hipMemcpy(q, e.q, sizeof(double) * n, hipMemcpyDeviceToHost));
+    std::vector<double> tmp(n);
+    auto pull3 = [&](double *const src[3], double *dst) {
+      for (int a = 0; a < 3; ++a) {
+        RX_HIP(hipMemcpy(tmp.data(), src[a], sizeof(double) * n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) dst[3 * static_cast<size_t>(i) + a] = tmp[i];
+      }
+    };
+    if (pos) pull3(e.pos, pos);
+    if (v) pull3(e.vel, v);
+    if (f) pull3(e.frc, f);
+  });
+  return rc < 0 ? rc : n;
+}
+
+int rxmd_hip_set_charges(rxmd_handle h, int natoms, const double *q) {
+  return guarded(h, [&](Engine &e) {
+    if (natoms != e.N || !q) throw EngineError(RXMD_E_ARG, "natoms mismatch");
+    RX_HIP(hipMemcpy(e.q, q, sizeof(double) * natoms, hipMemcpyHostToDevice));
+    e.lists_valid = false;   // ghost charges are refreshed by the next ghost build
+  });
+}
+
+int rxmd_hip_set_velocities(rxmd_handle h, int natoms, const double *v) {
+  return guarded(h, [&](Engine &e) {
+    if (natoms != e.N || !v) throw EngineError(RXMD_E_ARG, "natoms mismatch");
+    std::vector<double> tmp(natoms);
+    for (int a = 0; a < 3; ++a) {
+      for (int i = 0; i < natoms; ++i) tmp[i] = v[3 * static_cast<size_t>(i) + a];
+      RX_HIP(hipMemcpy(e.vel[a], tmp.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+    }
+  });
+}
+
+int rxmd_hip_qeq(rxmd_handle h, int *iters, double *est) {
+  return guarded(h, [&](Engine &e) {
+    e.qeq();
+    if (iters) *iters = e.nstep_qeq;
+    if (est) *est = e.last_est;
+  });
+}
+
+int rxmd_hip_force(rxmd_handle h, double pe[14]) {
+  return guarded(h, [&](Engine &e) {
+    e.force();
+    if (pe) std::memcpy(pe, e.pe, sizeof(double) * 14);
+  });
+}
+
+int rxmd_hip_step(rxmd_handle h, int nsteps) {
+  return guarded(h, [&](Engine &e) {
+    const auto t0 = std::chrono::steady_clock::now();
+    e.step(nsteps);
+    e.st.ms_step_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  });
+}
+
+int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], double astr[6]) {
+  return guarded(h, [&](Engine &e) {
+    if (!e.atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+    const int n = e.N;
+    RX_HIP(hipStreamSynchronize(e.stream));
+    std::vector<double> v[3], q(n);
+    std::vector<int> t(n);
+    for (int a = 0; a < 3; ++a) { v[a].resize(n); RX_HIP(hipMemcpy(v[a].data(), e.vel[a], sizeof(double) * n, hipMemcpyDeviceToHost)); }
+    RX_HIP(hipMemcpy(q.data(), e.q, sizeof(double) * n, hipMemcpyDeviceToHost));
+    RX_HIP(hipMemcpy(t.data(), e.type, sizeof(int) * n, hipMemcpyDeviceToHost));
+    double k = 0.0, qs = 0.0;
+    for (int i = 0; i < n; ++i) { k += e.hmas[t[i]] * (v[0][i] * v[0][i] + v[1][i] * v[1][i] + v[2][i] * v[2][i]); qs += q[i]; }  // main.F90:225-230
+    if (ke) *ke = k;
+    if (qsum) *qsum = qs;
+    if (pe) std::memcpy(pe, e.pe, sizeof(double) * 14);
+    if (astr) std::memcpy(astr, e.astr, sizeof(double) * 6);
+  });
+}
+
+// ---- the reference's own argument shapes (QEq(atype,pos,q) qeq.F90:2 ; FORCE(atype,pos,f,q) pot.F90:2) ----
+static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const double *atype, const double *pos, const double *q) {
+  if (natoms < 1 || nbuffer < natoms) throw EngineError(RXMD_E_ARG, "bad natoms/nbuffer");
+  std::vector<double> rec(10 * static_cast<size_t>(natoms), 0.0);
+  for (int i = 0; i < natoms; ++i) {
+    const double r[3] = {pos[i], pos[static_cast<size_t>(nbuffer) + i], pos[2 * static_cast<size_t>(nbuffer) + i]};   // pos(NBUFFER,3) column-major
+    double *o = rec.data() + 10 * static_cast<size_t>(i);
+    for (int a = 0; a < 3; ++a) o[a] = (e.box.Hi[a][0] * r[0] + e.box.Hi[a][1] * r[1] + e.box.Hi[a][2] * r[2]) - e.box.obox[a];
+    o[6] = q ? q[i] : 0.0;
+    o[7] = atype[i];
+  }
+  e.set_atoms_rxff(natoms, rec.data());
+  // keep the caller's real coordinates bit for bit (the record round trip is only used for sizing/setup)
+  std::vector<double> tmp(natoms);
+  for (int a = 0; a < 3; ++a) {
+    for (int i = 0; i < natoms; ++i) tmp[i] = pos[a * static_cast<size_t>(nbuffer) + i];
+    RX_HIP(hipMemcpy(e.pos[a], tmp.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+  }
+}
+
+int rxmd_hip_QEq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *q) {
+  if (!atype || !pos || !q) return RXMD_E_ARG;
+  return guarded(h, [&](Engine &e) {
+    upload_reference_arrays(e, nbuffer, natoms, atype, pos, q);
+    e.qeq();
+    RX_HIP(hipMemcpy(q, e.q, sizeof(double) * natoms, hipMemcpyDeviceToHost));
+  });
+}
+
+int rxmd_hip_FORCE(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *f, const double *q, double pe[14]) {
+  if (!atype || !pos || !f || !q) return RXMD_E_ARG;
+  return guarded(h, [&](Engine &e) {
+    upload_reference_arrays(e, nbuffer, natoms, atype, pos, q);
+    e.force();
+    std::vector<double> tmp(natoms);
+    for (int a = 0; a < 3; ++a) {
+      RX_HIP(hipMemcpy(tmp.data(), e.frc[a], sizeof(double) * natoms, hipMemcpyDeviceToHost));
+      for (int i = 0; i < natoms; ++i) f[a * static_cast<size_t>(nbuffer) + i] = tmp[i];
+    }
+    if (pe) std::memcpy(pe, e.pe, sizeof(double) * 14);
+  });
+}
+
+// ---- introspection ----
+int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out) {
+  if (!out) return RXMD_E_ARG;
+  return guarded(h, [&](Engine &e) {
+    if (e.atoms_set && e.lists_valid) {
+      RX_HIP(hipStreamSynchronize(e.stream));
+      std::vector<int> n10(e.N), nb(e.G);
+      RX_HIP(hipMemcpy(n10.data(), e.n10, sizeof(int) * e.N, hipMemcpyDeviceToHost));
+      RX_HIP(hipMemcpy(nb.data(), e.nbrcnt, sizeof(int) * e.G, hipMemcpyDeviceToHost));
+      long long s10 = 0, sb = 0; int m10 = 0, mb = 0;
+      for (int v : n10) { s10 += v; m10 = std::max(m10, v); }
+      for (int v : nb) { sb += v; mb = std::max(mb, v); }
+      e.st.nnz10 = s10; e.st.nbonds = sb; e.st.max_n10 = m10; e.st.max_nb = mb;
+    }
+    e.st.natoms = e.N;
+    *out = e.st;
+  });
+}
+
+int rxmd_hip_reset_timers(rxmd_handle h) {
+  return guarded(h, [&](Engine &e) {
+    e.st.ms_qeq = e.st.ms_qeq_list = e.st.ms_qeq_spmv = e.st.ms_force = e.st.ms_lists = e.st.ms_bo = e.st.ms_nonbond = e.st.ms_bonded = e.st.ms_step_total = 0.0;
+    e.st.spmv_launches = 0; e.st.qeq_iters_total = 0; e.st.qeq_calls = 0;
+  });
+}
+
+int rxmd_hip_get_table(rxmd_handle h, int which, double *out, int capacity) {
+  int n = 0;
+  const int rc = guarded(h, [&](Engine &e) {
+    if (!e.tables_ready) throw EngineError(RXMD_E_STATE, "tables are built when atoms are first set");
+    n = e.ff.nboty;
+    if (!out || capacity < n * rxmd::NTABLE) throw EngineError(RXMD_E_ARG, "capacity too small");
+    const std::vector<double> *src[5] = {&e.ff.tblEvdw, &e.ff.tbldEvdw, &e.ff.tblEclmb, &e.ff.tbldEclmb, &e.ff.tblQEq};
+    if (which < 0 || which > 4) throw EngineError(RXMD_E_ARG, "which must be 0..4");
+    for (int r = 1; r <= n; ++r)
+      for (int i = 1; i <= rxmd::NTABLE; ++i) out[static_cast<size_t>(r - 1) * rxmd::NTABLE + (i - 1)] = (*src[which])[static_cast<size_t>(r) * (rxmd::NTABLE + 2) + i];
+  });
+  return rc < 0 ? rc : n;
+}
+
+int rxmd_hip_get_cutoffs(rxmd_handle h, double *rc, int capacity, double *maxrc) {
+  int n = 0;
+  const int r = guarded(h, [&](Engine &e) {
+    if (!e.tables_ready) throw EngineError(RXMD_E_STATE, "cutoffs are computed when atoms are first set");
+    n = e.ff.nboty;
+    if (rc) { if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity too small"); for (int k = 1; k <= n; ++k) rc[k - 1] = e.ff.bond[k].rc; }
+    if (maxrc) *maxrc = e.ff.maxrc;
+  });
+  return r < 0 ? r : n;
+}
+
+int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
+  int n = 0;
+  const int rc = guarded(h, [&](Engine &e) {
+    if (!e.atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+    RX_HIP(hipStreamSynchronize(e.stream));
+    auto pull_d = [&](const double *src, int cnt, int stride, int off) {
+      std::vector<double> t(cnt);
+      RX_HIP(hipMemcpy(t.data(), src, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+      for (int i = 0; i < cnt; ++i) out[static_cast<size_t>(i) * stride + off] = t[i];
+    };
+    const int G = e.G, N = e.N;
+    switch (what) {
+      case 0: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.delta, G, 1, 0); break;
+      case 1: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.deltap, G, 1, 0); break;
+      case 2: { n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); std::vector<int> t(G); RX_HIP(hipMemcpy(t.data(), e.nbrcnt, sizeof(int) * G, hipMemcpyDeviceToHost)); for (int i = 0; i < G; ++i) out[i] = t[i]; break; }
+      case 3: n = G; if (capacity < 3 * n) throw EngineError(RXMD_E_ARG, "capacity"); for (int a = 0; a < 3; ++a) pull_d(e.pos[a], G, 3, a); break;
+      case 4: { n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); std::vector<long long> t(G); RX_HIP(hipMemcpy(t.data(), e.gid, sizeof(long long) * G, hipMemcpyDeviceToHost)); for (int i = 0; i < G; ++i) out[i] = static_cast<double>(t[i]); break; }
+      case 5: { n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); std::vector<int> t(G); RX_HIP(hipMemcpy(t.data(), e.type, sizeof(int) * G, hipMemcpyDeviceToHost)); for (int i = 0; i < G; ++i) out[i] = t[i]; break; }
+      case 6: { n = N; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); std::vector<int> t(N); RX_HIP(hipMemcpy(t.data(), e.n10, sizeof(int) * N, hipMemcpyDeviceToHost)); for (int i = 0; i < N; ++i) out[i] = t[i]; break; }
+      case 7: {
+        n = N; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity");
+        std::vector<int> c(N); RX_HIP(hipMemcpy(c.data(), e.n10, sizeof(int) * N, hipMemcpyDeviceToHost));
+        std::vector<double> row(e.S10);
+        for (int i = 0; i < N; ++i) {
+          RX_HIP(hipMemcpy(row.data(), e.hess + static_cast<size_t>(i) * e.S10, sizeof(double) * c[i], hipMemcpyDeviceToHost));
+          double s = 0; for (int k = 0; k < c[i]; ++k) s += row[k];
+          out[i] = s;
+        }
+        break;
+      }
+      case 8: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.cd, G, 1, 0); break;
+      case 9: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.q, G, 1, 0); break;
+      default: throw EngineError(RXMD_E_ARG, "unknown debug tap");
+    }
+  });
+  return rc < 0 ? rc : n;
+}
+
+int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops) {
+  return guarded(h, [&](Engine &e) {
+    if (!ops) { e.has_comm = false; return; }
+    e.comm = *ops; e.has_comm = true;
+  });
+}
+
+// ---- host front-end helpers ---------------------------------------------------------------------
+// geninit (reference init/geninit.F90:399-575)
+long long rxmd_host_geninit(const char *ffield_path, int natoms0, const char *elem4, const double *frac, const double lattice[6], const int mc[3],
+                            const int vprocs[3], int myid, double *rec10, long long capacity, double lattice_out[6]) {
+  if (!ffield_path || !elem4 || !frac || natoms0 < 1) return RXMD_E_ARG;
+  rxmd::ForceField ff;
+  try { ff.parse(ffield_path); } catch (const std::exception &) { return RXMD_E_FFIELD; }
+  std::vector<int> t0(natoms0, 0);
+  for (int i = 0; i < natoms0; ++i) {
+    std::string nm(elem4 + 4 * static_cast<size_t>(i));
+    for (int t = 1; t <= ff.nso; ++t) if (ff.atom[t].name == nm) { t0[i] = t; break; }
+    if (!t0[i]) return RXMD_E_ARG;
+  }
+  const long long ntot = static_cast<long long>(natoms0) * mc[0] * mc[1] * mc[2];
+  std::vector<double> p(3 * static_cast<size_t>(ntot));
+  double rmin[3] = {1e300, 1e300, 1e300};
+  long long n = 0;
+  for (int ix = 0; ix < mc[0]; ++ix) for (int iy = 0; iy < mc[1]; ++iy) for (int iz = 0; iz < mc[2]; ++iz)
+    for (int i = 0; i < natoms0; ++i, ++n) {                               // geninit.F90:447-462: order defines the global id
+      const double r[3] = {(frac[3 * i] + ix) / mc[0], (frac[3 * i + 1] + iy) / mc[1], (frac[3 * i + 2] + iz) / mc[2]};
+      for (int a = 0; a < 3; ++a) { p[3 * n + a] = r[a]; rmin[a] = std::min(rmin[a], r[a]); }
+    }
+  for (long long k = 0; k < ntot; ++k)
+    for (int a = 0; a < 3; ++a) p[3 * k + a] = std::fmod(p[3 * k + a] - rmin[a], 1.0) + 1e-9;   // geninit.F90:465-478
+  if (lattice_out) { for (int a = 0; a < 3; ++a) lattice_out[a] = lattice[a] * mc[a]; for (int a = 3; a < 6; ++a) lattice_out[a] = lattice[a]; }
+  const double lbox[3] = {1.0 / vprocs[0], 1.0 / vprocs[1], 1.0 / vprocs[2]};
+  const int vi = myid % vprocs[0], vj = (myid / vprocs[0]) % vprocs[1], vk = myid / (vprocs[0] * vprocs[1]);
+  const double obox[3] = {lbox[0] * vi, lbox[1] * vj, lbox[2] * vk};
+  long long cnt = 0;
+  for (long long k = 0; k < ntot; ++k) {
+    const int i = static_cast<int>(p[3 * k] * vprocs[0]), j = static_cast<int>(p[3 * k + 1] * vprocs[1]), l = static_cast<int>(p[3 * k + 2] * vprocs[2]);
+    if (i + j * vprocs[0] + l * vprocs[0] * vprocs[1] != myid) continue;  // geninit.F90:495-500
+    if (rec10) {
+      if (cnt >= capacity) return RXMD_E_NBUFFER;
+      double *o = rec10 + 10 * cnt;
+      for (int a = 0; a < 3; ++a) o[a] = p[3 * k + a] - obox[a];
+      o[3] = o[4] = o[5] = 0.0; o[6] = 0.0;
+      o[7] = t0[k % natoms0] + (k + 1) * 1e-13 + 1e-14;                    // geninit.F90:459
+      o[8] = 0.0; o[9] = 0.0;
+    }
+    ++cnt;
+  }
+  return cnt;
+}
+
+// ReadBIN header + records (reference src/fileio.F90:444-555)
+long long rxmd_host_read_rxff(const char *path, int myid, double lattice_out[6], int vprocs_out[3], double *rec10, long long capacity) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) return RXMD_E_ARG;
+  int head[4];
+  in.read(reinterpret_cast<char *>(head), 16);
+  if (!in || head[0] < 1 || head[0] != head[1] * head[2] * head[3]) return RXMD_E_ARG;
+  const int np = head[0];
+  if (myid < 0 || myid >= np) return RXMD_E_ARG;
+  std::vector<int> nat(np);
+  in.read(reinterpret_cast<char *>(nat.data()), 4 * np);
+  int cur = 0;
+  in.read(reinterpret_cast<char *>(&cur), 4);
+  double lat[6];
+  in.read(reinterpret_cast<char *>(lat), 48);
+  if (!in) return RXMD_E_ARG;
+  if (lattice_out) std::memcpy(lattice_out, lat, 48);
+  if (vprocs_out) { vprocs_out[0] = head[1]; vprocs_out[1] = head[2]; vprocs_out[2] = head[3]; }
+  if (!rec10) return nat[myid];
+  if (capacity < nat[myid]) return RXMD_E_NBUFFER;
+  long long skip = 0;
+  for (int p = 0; p < myid; ++p) skip += nat[p];
+  in.seekg(static_cast<std::streamoff>(skip) * 80, std::ios::cur);
+  in.read(reinterpret_cast<char *>(rec10), static_cast<std::streamsize>(nat[myid]) * 80);
+  return in ? nat[myid] : RXMD_E_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// engine.h -- device-resident state of one rank (= one MI355X) and the kernel-group entry points.
+//
+// Data layout in HBM (all FP64 unless noted; N = residents, G = residents + ghosts, NB = capacity):
+//   per-atom SoA, index = the reference's LOCAL atom index (residents in rxff.bin / arrival order,
+//   then ghosts in exchange-stage order, reference src/comm.F90:414-446,494-518).  The force
+//   semantics depend on this order, so atoms are never physically re-sorted;
+//   spatial sorting exists only as an index permutation for the list builds.
+//   bonded tables are slot-major  [slot * NB + atom]  (coalesced for thread-per-atom kernels)
+//   the 10 A list is row-major ELL [row * S10 + k]    (coalesced for wave-per-row kernels),
+//   S10 a multiple of 64 so that every row starts on a 512-byte boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rxmd_hip.h"
+#include "ffparams.h"
+
+namespace rxmd {
+
+#define RX_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) throw EngineError(RXMD_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct EngineError {
+  int code;
+  std::string msg;
+  EngineError(int c, std::string m) : code(c), msg(std::move(m)) {}
+};
+
+// ---- flattened force field in device memory -------------------------------------------------
+struct DevAtomP { double Val, Valboc, mass, Vale, nlpopt, plp2, povun2, povun5, pval3, pval5, Valangle, Valval, chi, eta; };
+struct DevBondP {
+  double Desig, Depi, Depipi, pbe1, pbe2, povun1, ovc, v13cor;
+  double pbo2, pbo4, pbo6, pboc3, pboc4, pboc5;
+  double cBOp1, cBOp3, cBOp5, pbo2h, pbo4h, pbo6h, sw0, sw1, sw2, rc2;
+};
+struct DevAngleP { double theta00, pval1, pval2, pcoa1, pval7, ppen1, pval4; };
+struct DevTorsP { double V1, V2, V3, ptor1, pcot1; };
+struct DevHbP { double r0hb, phb1, phb2, phb3; };
+struct DevNBTab { double Evdw, dEvdw, Eclmb, dEclmb; };  // one r^2-table node, 32 bytes
+
+struct DevFF {
+  int nso, n1, nboty;
+  const DevAtomP *atom; const DevBondP *bond; const DevAngleP *angle; const DevTorsP *tors; const DevHbP *hb;
+  const int *inxn2, *inxn3, *inxn3hb, *inxn4;
+  const DevNBTab *tabNB;   // [inxn * (NTABLE+2) + i]
+  const double *tabQEq;    // [inxn * (NTABLE+2) + i]
+  double UDR, UDRi, rctap2, cutoff_vpar30, vpar1, vpar2;
+  double plp1, povun3, povun4, povun6, povun7, povun8;
+  double pval6, pval8, pval9, pval10, ppen2, ppen3, ppen4, pcoa2, pcoa3, pcoa4, ptor2, ptor3, ptor4, pcot2;
+};
+
+struct Box {
+  double H[3][3], Hi[3][3];  // GetBoxParams / matinv, reference src/init.F90:610-633, main.F90:557-579
+  double lat[6];
+  double lbox[3];   // normalised local box edge = 1/vprocs          (init.F90:659)
+  double obox[3];   // normalised origin of this rank                (init.F90:665)
+  double volume;
+};
+
+struct Grid {       // the engine's own cell grid over [-shell, L+shell) in normalised local coords
+  int n[3];         // cells per dimension
+  double org[3];    // normalised origin (negative)
+  double inv[3];    // cells per unit of normalised coordinate
+  int ncell;
+};
+
+constexpr int WAVE = 64;
+
+struct Engine {
+  rxmd_config cfg{};
+  std::string ffield_path, err;
+  ForceField ff;
+  Box box{};
+  int vID[3] = {0, 0, 0}, target_node[7] = {0}, nprocs = 1;
+  double dt = 0, Lex_w2 = 0;
+  std::vector<double> dthm, hmas;
+  rxmd_comm_ops comm{};
+  bool has_comm = false, tables_ready = false, atoms_set = false, lists_valid = false, ghosts_valid = false;
+
+  // capacities
+  int NB = 0, MAXNB = 30, S10 = 0, rows10 = 0;
+  int N = 0, G = 0, copyptr[7] = {0};
+  int cc[3] = {1, 1, 1};          // reference bonded cell counts, only to derive the ghost shell (init.F90:656)
+  double shell[3] = {0, 0, 0};    // FORCE ghost shell in normalised units: NMINCELL*lcsize (pot.F90:28)
+  Grid grid{};
+
+  // ---- device memory ----
+  DevFF dff{};
+  void *ffblob = nullptr;
+  double *pos[3] = {}, *vel[3] = {}, *frc[3] = {}, *spos[3] = {};  // real pos, v, f ; normalised-local pos (ghost build)
+  double *q = nullptr, *qsfp = nullptr, *qsfv = nullptr;
+  int *type = nullptr; long long *gid = nullptr;
+  double2 *qst = nullptr, *hst = nullptr, *gst = nullptr;  // (qs,qt) (hs,ht) (gs,gt) interleaved
+  int *gsrc = nullptr, *groot = nullptr;                    // ghost -> source index on sender ; -> resident root (self exchange)
+  int *sendidx = nullptr; int sendoff[8] = {0};             // per-stage send index lists (local indices), concatenated
+  // cell binning
+  int *cellid = nullptr, *cellid_sorted = nullptr, *perm = nullptr, *perm_in = nullptr, *cellstart = nullptr;
+  double4 *sorted_xyzi = nullptr;   // cell-sorted (x,y,z,index-as-bits) copy of real positions
+  void *cubtmp = nullptr; size_t cubtmp_bytes = 0;
+  int *flags = nullptr, *scanout = nullptr;
+  // bonded tables, slot-major
+  int *nbr = nullptr, *nbrcnt = nullptr; unsigned char *nbrindx = nullptr;
+  double *bo0 = nullptr, *bo1 = nullptr, *bo2 = nullptr, *bo3 = nullptr, *dln2 = nullptr, *dln3 = nullptr, *dBOp = nullptr;
+  double *A0 = nullptr, *A1 = nullptr, *A2 = nullptr, *A3 = nullptr;
+  double *cf1 = nullptr, *cf2 = nullptr, *cf3 = nullptr, *cdn = nullptr, *fnx = nullptr, *fny = nullptr, *fnz = nullptr;
+  double *deltap = nullptr, *delta = nullptr, *nlp = nullptr, *dDlp = nullptr, *deltalp = nullptr;
+  double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
+  // 10 A list
+  int *nb10 = nullptr, *n10 = nullptr; double *hess = nullptr;
+  // reductions
+  double *partials = nullptr;  // [nblocks_red * 16]
+  double *scal = nullptr;      // device scalars (CG state)
+  double *h_scal = nullptr;    // pinned host mirror
+  int *d_err = nullptr, *h_err = nullptr;
+  double *xbuf_send = nullptr, *xbuf_recv = nullptr; size_t xbuf_doubles = 0;
+  double pe[14] = {0}, astr[6] = {0};
+
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  rxmd_stats st{};
+  int nstep_qeq = 0; double last_est = 0;
+  long long step_count = 0;
+
+  // ---- host API ----
+  explicit Engine(const rxmd_config &c);
+  ~Engine();
+  void set_atoms_rxff(int natoms, const double *rec10);
+  int get_atoms_rxff(double *rec10, int capacity);
+  void build_ghosts_and_lists();   // COPYATOMS(MODE_COPY) + LINKEDLIST + NEIGHBORLIST + 10 A list/hessian, once per step
+  void qeq();
+  void force();
+  void step(int nsteps);
+  void migrate();                  // COPYATOMS(MODE_MOVE)
+
+  // pieces (each in its own .hip)
+  void setup_after_atoms(const std::vector<long long> &natoms_per_type_global);
+  void upload_ff();
+  void alloc_device();
+  void free_device();
+  void ghost_build();
+  void bin_cells();
+  void build_bonded_list();
+  void build_list10();
+  void halo_refresh(double2 *v2, double *v1);       // QCOPY1/QCOPY2: ghosts <- owners
+  void fold_ghost_forces();                         // CPBK
+  void bond_orders();
+  void bonded_energies();
+  void nonbonded();
+  void assemble_forces();
+  void check_device_error(const char *where);
+  double reduce_partials(int ncomp, int nblocks, double *out);  // host-side helper
+  void tic(int k) { hipEventRecord(ev[k], stream); }
+  double toc(int k0, int k1) { hipEventRecord(ev[k1], stream); hipEventSynchronize(ev[k1]); float ms = 0; hipEventElapsedTime(&ms, ev[k0], ev[k1]); return ms; }
+};
+
+// device error codes written by kernels into Engine::d_err
+enum { DERR_NONE = 0, DERR_MAXNB = 1, DERR_MAXN10 = 2, DERR_GRID = 3, DERR_NBRINDX = 4 };
+
+}  // namespace rxmd

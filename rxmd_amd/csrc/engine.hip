@@ -1,0 +1,543 @@
+// engine.hip -- construction, device memory, atom I/O, ghost-atom build (COPYATOMS MODE_COPY),
+// migration (MODE_MOVE), halo refresh (MODE_QCOPY1/2), ghost-force fold (MODE_CPBK), cell binning.
+// Reference behaviour restated MI355X-first: src/comm.F90 (the six-direction staged exchange),
+// src/main.F90:277-318 (LINKEDLIST), src/init.F90:7-288 (INITSYSTEM derived quantities).
+#include "engine.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace rxmd {
+
+static const double UTIME = 1e3 / 20.455;  // reference src/module.F90:202
+static const int NMINCELL = 4;             // reference src/module.F90:84
+static const int cptridx_[7] = {0, 0, 0, 2, 2, 4, 4};  // comm.F90:61
+
+template <class T>
+static void dmalloc(T *&p, size_t n) {
+  RX_HIP(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)));
+  RX_HIP(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+}
+template <class T>
+static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+static void make_box(Box &b, const double lat[6], const int vprocs[3], const int vID[3]) {
+  // GetBoxParams (reference src/init.F90:610-633)
+  const double pi = std::atan(1.0) * 4.0;
+  const double la = lat[0], lb = lat[1], lc = lat[2];
+  const double lal = lat[3] * pi / 180.0, lbe = lat[4] * pi / 180.0, lga = lat[5] * pi / 180.0;
+  const double hh1 = lc * (std::cos(lal) - std::cos(lbe) * std::cos(lga)) / std::sin(lga);
+  const double hh2 = lc * std::sqrt(1.0 - std::cos(lal) * std::cos(lal) - std::cos(lbe) * std::cos(lbe) - std::cos(lga) * std::cos(lga) +
+                                    2 * std::cos(lal) * std::cos(lbe) * std::cos(lga)) / std::sin(lga);
+  double(*H)[3] = b.H;
+  H[0][0] = la; H[1][0] = 0; H[2][0] = 0;
+  H[0][1] = lb * std::cos(lga); H[1][1] = lb * std::sin(lga); H[2][1] = 0;
+  H[0][2] = lc * std::cos(lbe); H[1][2] = hh1; H[2][2] = hh2;
+  double(*m)[3] = b.Hi;  // matinv (src/main.F90:557-579)
+  m[0][0] = H[1][1] * H[2][2] - H[1][2] * H[2][1]; m[0][1] = H[0][2] * H[2][1] - H[0][1] * H[2][2]; m[0][2] = H[0][1] * H[1][2] - H[0][2] * H[1][1];
+  m[1][0] = H[1][2] * H[2][0] - H[1][0] * H[2][2]; m[1][1] = H[0][0] * H[2][2] - H[0][2] * H[2][0]; m[1][2] = H[0][2] * H[1][0] - H[0][0] * H[1][2];
+  m[2][0] = H[1][0] * H[2][1] - H[1][1] * H[2][0]; m[2][1] = H[0][1] * H[2][0] - H[0][0] * H[2][1]; m[2][2] = H[0][0] * H[1][1] - H[0][1] * H[1][0];
+  const double det = H[0][0] * H[1][1] * H[2][2] + H[0][1] * H[1][2] * H[2][0] + H[0][2] * H[1][0] * H[2][1] -
+                     H[0][2] * H[1][1] * H[2][0] - H[0][1] * H[1][0] * H[2][2] - H[0][0] * H[1][2] * H[2][1];
+  for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) m[a][c] = m[a][c] / det;
+  b.volume = det;
+  for (int a = 0; a < 6; ++a) b.lat[a] = lat[a];
+  for (int a = 0; a < 3; ++a) { b.lbox[a] = 1.0 / vprocs[a]; b.obox[a] = b.lbox[a] * vID[a]; }
+}
+
+Engine::Engine(const rxmd_config &c) : cfg(c) {
+  if (!c.ffield_path) throw EngineError(RXMD_E_ARG, "ffield_path is NULL");
+  ffield_path = c.ffield_path;
+  cfg.ffield_path = ffield_path.c_str();
+  for (int a = 0; a < 3; ++a) if (cfg.vprocs[a] < 1) throw EngineError(RXMD_E_ARG, "vprocs must be >= 1");
+  nprocs = cfg.vprocs[0] * cfg.vprocs[1] * cfg.vprocs[2];
+  if (cfg.myid < 0 || cfg.myid >= nprocs) throw EngineError(RXMD_E_ARG, "myid outside the vprocs grid");
+  if (std::fabs(cfg.lattice[3] - 90.0) > 1e-9 || std::fabs(cfg.lattice[4] - 90.0) > 1e-9 || std::fabs(cfg.lattice[5] - 90.0) > 1e-9)
+    throw EngineError(RXMD_E_ARG, "only orthorhombic boxes are supported by the GPU cell grid (alpha=beta=gamma=90)");
+  try { ff.parse(ffield_path); } catch (const std::exception &e) { throw EngineError(RXMD_E_FFIELD, e.what()); }
+  // rank grid, reference src/init.F90:74-100
+  vID[0] = cfg.myid % cfg.vprocs[0]; vID[1] = (cfg.myid / cfg.vprocs[0]) % cfg.vprocs[1]; vID[2] = cfg.myid / (cfg.vprocs[0] * cfg.vprocs[1]);
+  int k = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 1; j >= -1; j -= 2) {
+      int l[3] = {vID[0], vID[1], vID[2]};
+      l[i] = (vID[i] + j + cfg.vprocs[i]) % cfg.vprocs[i];
+      target_node[++k] = l[0] + l[1] * cfg.vprocs[0] + l[2] * cfg.vprocs[0] * cfg.vprocs[1];
+    }
+  make_box(box, cfg.lattice, cfg.vprocs, vID);
+  dt = cfg.dt_fs / UTIME;                         // init.F90:66
+  Lex_w2 = 2.0 * cfg.Lex_k / dt / dt;             // init.F90:69
+  dthm.assign(ff.nso + 1, 0.0); hmas.assign(ff.nso + 1, 0.0);
+  for (int t = 1; t <= ff.nso; ++t) { dthm[t] = dt * 0.5 / ff.atom[t].mass; hmas[t] = 0.5 * ff.atom[t].mass; }  // init.F90:105-108
+  ff.build_taper(10.0);                           // rctap0, module.F90:281 (no PQEq)
+  MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
+  if (MAXNB > 250) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 250");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw EngineError(RXMD_E_HIP, "no HIP device visible: this engine has no CPU path");
+  RX_HIP(hipSetDevice(cfg.device));
+  RX_HIP(hipStreamCreate(&stream));
+  for (auto &e : ev) RX_HIP(hipEventCreate(&e));
+}
+
+Engine::~Engine() {
+  free_device();
+  for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Engine::check_device_error(const char *where) {
+  RX_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int) * 4, hipMemcpyDeviceToHost, stream));
+  RX_HIP(hipStreamSynchronize(stream));
+  const int e = h_err[0];
+  if (e == DERR_NONE) return;
+  RX_HIP(hipMemsetAsync(d_err, 0, sizeof(int) * 4, stream));
+  const std::string w = std::string(where) + ": ";
+  if (e == DERR_MAXNB) throw EngineError(RXMD_E_MAXNEIGHBS, w + "overflow of max # in neighbor list (MAXNEIGHBS=" + std::to_string(MAXNB) + ", needed " + std::to_string(h_err[1]) + ")");
+  if (e == DERR_MAXN10) throw EngineError(RXMD_E_MAXNEIGHBS10, w + "nbplist greater than MAXNEIGHBS10=" + std::to_string(S10) + " (needed " + std::to_string(h_err[1]) + ")");
+  if (e == DERR_NBRINDX) throw EngineError(RXMD_E_STATE, w + "inconsistency between nbrlist and nbrindx");
+  throw EngineError(RXMD_E_STATE, w + "device error " + std::to_string(e));
+}
+
+// ---------------------------------------------------------------------------------------------
+// derived quantities that need the atoms (INITSYSTEM after ReadBIN, init.F90:141-213)
+void Engine::setup_after_atoms(const std::vector<long long> &npt) {
+  ff.compute_cutoffs(npt);
+  ff.build_tables();
+  const double lreal[3] = {box.lat[0] / cfg.vprocs[0], box.lat[1] / cfg.vprocs[1], box.lat[2] / cfg.vprocs[2]};
+  for (int a = 0; a < 3; ++a) {
+    cc[a] = static_cast<int>(lreal[a] / ff.maxrc);            // UpdateBoxParams, init.F90:656
+    if (cc[a] < 1) throw EngineError(RXMD_E_ARG, "local box smaller than the bond cutoff");
+    shell[a] = NMINCELL * (box.lbox[a] / cc[a]);               // dr of the FORCE ghost copy, pot.F90:28
+  }
+  // the engine's own grid: one cell edge >= max(rctap/2, maxrc); stencil +-2 covers 10 A, +-1 the bonds
+  const double cw = std::max(0.5 * ff.rctap, ff.maxrc) * (1.0 + 1e-9);
+  grid.ncell = 1;
+  for (int a = 0; a < 3; ++a) {
+    const double wn = box.lbox[a] + 2.0 * shell[a];
+    const double wreal = wn * box.lat[a];
+    grid.n[a] = std::max(1, static_cast<int>(wreal / cw));
+    grid.org[a] = -shell[a];
+    grid.inv[a] = grid.n[a] / wn;
+    grid.ncell *= grid.n[a];
+  }
+  tables_ready = true;
+}
+
+void Engine::upload_ff() {
+  // one blob: atom | bond | angle | tors | hb | inxn2 | inxn3 | inxn3hb | inxn4 | tabNB | tabQEq
+  const int n1 = ff.n1();
+  std::vector<DevAtomP> a(ff.nso + 1);
+  for (int t = 1; t <= ff.nso; ++t) {
+    const auto &s = ff.atom[t];
+    a[t] = {s.Val, s.Valboc, s.mass, s.Vale, s.nlpopt, s.plp2, s.povun2, s.povun5, s.pval3, s.pval5, s.Valangle, s.Valval, s.chi, s.eta};
+  }
+  std::vector<DevBondP> b(ff.nboty + 1);
+  for (int r = 1; r <= ff.nboty; ++r) {
+    const auto &s = ff.bond[r];
+    b[r] = {s.Desig, s.Depi, s.Depipi, s.pbe1, s.pbe2, s.povun1, s.ovc, s.v13cor, s.pbo2, s.pbo4, s.pbo6, s.pboc3, s.pboc4, s.pboc5,
+            s.cBOp1, s.cBOp3, s.cBOp5, s.pbo2h, s.pbo4h, s.pbo6h, s.sw[0], s.sw[1], s.sw[2], s.rc2};
+  }
+  std::vector<DevAngleP> an(ff.nvaty + 1);
+  for (int r = 1; r <= ff.nvaty; ++r) { const auto &s = ff.angle[r]; an[r] = {s.theta00, s.pval1, s.pval2, s.pcoa1, s.pval7, s.ppen1, s.pval4}; }
+  std::vector<DevTorsP> to(ff.ntoty + 1);
+  for (int r = 1; r <= ff.ntoty; ++r) { const auto &s = ff.tors[r]; to[r] = {s.V1, s.V2, s.V3, s.ptor1, s.pcot1}; }
+  std::vector<DevHbP> hb(ff.nhbty + 1);
+  for (int r = 1; r <= ff.nhbty; ++r) { const auto &s = ff.hb[r]; hb[r] = {s.r0hb, s.phb1, s.phb2, s.phb3}; }
+  const size_t stride = NTABLE + 2;
+  std::vector<DevNBTab> nb((ff.nboty + 1) * stride);
+  for (size_t i = 0; i < nb.size(); ++i) nb[i] = {ff.tblEvdw[i], ff.tbldEvdw[i], ff.tblEclmb[i], ff.tbldEclmb[i]};
+
+  auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+  size_t off[12], tot = 0;
+  const size_t sz[11] = {a.size() * sizeof(DevAtomP), b.size() * sizeof(DevBondP), an.size() * sizeof(DevAngleP), to.size() * sizeof(DevTorsP),
+                         hb.size() * sizeof(DevHbP), ff.inxn2.size() * 4, ff.inxn3.size() * 4, ff.inxn3hb.size() * 4, ff.inxn4.size() * 4,
+                         nb.size() * sizeof(DevNBTab), ff.tblQEq.size() * 8};
+  const void *src[11] = {a.data(), b.data(), an.data(), to.data(), hb.data(), ff.inxn2.data(), ff.inxn3.data(), ff.inxn3hb.data(), ff.inxn4.data(), nb.data(), ff.tblQEq.data()};
+  for (int i = 0; i < 11; ++i) { off[i] = tot; tot += al(sz[i]); }
+  if (ffblob) { (void)hipFree(ffblob); ffblob = nullptr; }
+  RX_HIP(hipMalloc(&ffblob, tot));
+  for (int i = 0; i < 11; ++i) RX_HIP(hipMemcpy(static_cast<char *>(ffblob) + off[i], src[i], sz[i], hipMemcpyHostToDevice));
+  char *base = static_cast<char *>(ffblob);
+  dff.nso = ff.nso; dff.n1 = n1; dff.nboty = ff.nboty;
+  dff.atom = reinterpret_cast<DevAtomP *>(base + off[0]); dff.bond = reinterpret_cast<DevBondP *>(base + off[1]);
+  dff.angle = reinterpret_cast<DevAngleP *>(base + off[2]); dff.tors = reinterpret_cast<DevTorsP *>(base + off[3]);
+  dff.hb = reinterpret_cast<DevHbP *>(base + off[4]);
+  dff.inxn2 = reinterpret_cast<int *>(base + off[5]); dff.inxn3 = reinterpret_cast<int *>(base + off[6]);
+  dff.inxn3hb = reinterpret_cast<int *>(base + off[7]); dff.inxn4 = reinterpret_cast<int *>(base + off[8]);
+  dff.tabNB = reinterpret_cast<DevNBTab *>(base + off[9]); dff.tabQEq = reinterpret_cast<double *>(base + off[10]);
+  dff.UDR = ff.UDR; dff.UDRi = ff.UDRi; dff.rctap2 = ff.rctap2; dff.cutoff_vpar30 = ff.cutoff_vpar30; dff.vpar1 = ff.vpar1; dff.vpar2 = ff.vpar2;
+  dff.plp1 = ff.plp1; dff.povun3 = ff.povun3; dff.povun4 = ff.povun4; dff.povun6 = ff.povun6; dff.povun7 = ff.povun7; dff.povun8 = ff.povun8;
+  dff.pval6 = ff.pval6; dff.pval8 = ff.pval8; dff.pval9 = ff.pval9; dff.pval10 = ff.pval10; dff.ppen2 = ff.ppen2; dff.ppen3 = ff.ppen3; dff.ppen4 = ff.ppen4;
+  dff.pcoa2 = ff.pcoa2; dff.pcoa3 = ff.pcoa3; dff.pcoa4 = ff.pcoa4; dff.ptor2 = ff.ptor2; dff.ptor3 = ff.ptor3; dff.ptor4 = ff.ptor4; dff.pcot2 = ff.pcot2;
+}
+
+void Engine::alloc_device() {
+  const size_t nb = NB, ns = static_cast<size_t>(NB) * MAXNB;
+  for (int a = 0; a < 3; ++a) { dmalloc(pos[a], nb); dmalloc(vel[a], nb); dmalloc(frc[a], nb); dmalloc(spos[a], nb); }
+  dmalloc(q, nb); dmalloc(qsfp, nb); dmalloc(qsfv, nb); dmalloc(type, nb); dmalloc(gid, nb);
+  dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb);
+  dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb);
+  dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.ncell) + 2);
+  dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1);
+  dmalloc(nbr, ns); dmalloc(nbrcnt, nb); dmalloc(nbrindx, ns);
+  dmalloc(bo0, ns); dmalloc(bo1, ns); dmalloc(bo2, ns); dmalloc(bo3, ns); dmalloc(dln2, ns); dmalloc(dln3, ns); dmalloc(dBOp, ns);
+  dmalloc(A0, ns); dmalloc(A1, ns); dmalloc(A2, ns); dmalloc(A3, ns);
+  dmalloc(cf1, ns); dmalloc(cf2, ns); dmalloc(cf3, ns); dmalloc(cdn, ns); dmalloc(fnx, ns); dmalloc(fny, ns); dmalloc(fnz, ns);
+  dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
+  dmalloc(nb10, static_cast<size_t>(rows10) * S10); dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
+  dmalloc(partials, size_t(4096) * 16); dmalloc(scal, 64);
+  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
+  dmalloc(d_err, 4);
+  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 4 * sizeof(int)));
+  // hipcub scratch sized for the largest scan / sort we issue
+  size_t b1 = 0, b2 = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, b1, flags, scanout, NB + 1, stream);
+  hipcub::DeviceRadixSort::SortPairs(nullptr, b2, cellid, cellid_sorted, perm_in, perm, NB, 0, 32, stream);
+  cubtmp_bytes = std::max(b1, b2) + 256;
+  RX_HIP(hipMalloc(&cubtmp, cubtmp_bytes));
+}
+
+void Engine::free_device() {
+  for (int a = 0; a < 3; ++a) { dfree(pos[a]); dfree(vel[a]); dfree(frc[a]); dfree(spos[a]); }
+  dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst);
+  dfree(gsrc); dfree(groot); dfree(sendidx); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
+  dfree(sorted_xyzi); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
+  dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
+  dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz);
+  dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
+  dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
+  dfree(xbuf_send); dfree(xbuf_recv);
+  if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
+  if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
+  if (cubtmp) { (void)hipFree(cubtmp); cubtmp = nullptr; }
+  if (ffblob) { (void)hipFree(ffblob); ffblob = nullptr; }
+}
+
+// ReadBIN (reference src/fileio.F90:528-552): records -> real coordinates, split atype
+void Engine::set_atoms_rxff(int natoms, const double *rec) {
+  if (natoms < 1) throw EngineError(RXMD_E_ARG, "natoms must be positive");
+  std::vector<double> hx[3], hv[3], hq(natoms), hp(natoms), hw(natoms);
+  std::vector<int> ht(natoms);
+  std::vector<long long> hg(natoms);
+  for (int a = 0; a < 3; ++a) { hx[a].resize(natoms); hv[a].resize(natoms); }
+  std::vector<long long> npt(ff.nso + 2, 0);
+  for (int i = 0; i < natoms; ++i) {
+    const double *r = rec + 10 * static_cast<size_t>(i);
+    const double s[3] = {r[0] + box.obox[0], r[1] + box.obox[1], r[2] + box.obox[2]};
+    for (int a = 0; a < 3; ++a) { hx[a][i] = box.H[a][0] * s[0] + box.H[a][1] * s[1] + box.H[a][2] * s[2]; hv[a][i] = r[3 + a]; }  // xs2xu
+    hq[i] = r[6];
+    const int t = static_cast<int>(std::lround(r[7]));
+    if (t < 1 || t > ff.nso) throw EngineError(RXMD_E_ARG, "atom type outside the ffield");
+    ht[i] = t; hg[i] = std::llround((r[7] - t) * 1e13);                 // l2g, main.F90:582-593
+    hp[i] = r[8]; hw[i] = r[9];
+    npt[t]++;
+  }
+  if (!tables_ready) {
+    if (has_comm && nprocs > 1) {
+      std::vector<double> tmp(ff.nso + 1);
+      for (int t = 0; t <= ff.nso; ++t) tmp[t] = static_cast<double>(npt[t]);
+      if (comm.allreduce_sum(comm.ctx, tmp.data(), ff.nso + 1)) throw EngineError(RXMD_E_COMM, "allreduce failed");
+      for (int t = 0; t <= ff.nso; ++t) npt[t] = std::llround(tmp[t]);
+    }
+    setup_after_atoms(npt);
+    // capacities
+    double fac = 1.0;
+    for (int a = 0; a < 3; ++a) fac *= 1.0 + 2.0 * std::min(shell[a] / box.lbox[a], 1.0);
+    const long long want = static_cast<long long>(natoms * fac * 1.12) + 4096;
+    NB = cfg.nbuffer > 0 ? cfg.nbuffer : static_cast<int>(std::min<long long>(want, 2000000000LL));
+    if (NB <= natoms) throw EngineError(RXMD_E_NBUFFER, "nbuffer smaller than natoms");
+    const double vloc = box.volume / nprocs;
+    const double est10 = natoms / vloc * (4.0 / 3.0) * 3.14159265358979 * ff.rctap * ff.rctap2;
+    int s10 = cfg.maxneighbs10 > 0 ? cfg.maxneighbs10 : static_cast<int>(est10 * 1.35 + 64);
+    S10 = (s10 + 63) / 64 * 64;
+    rows10 = std::min<long long>(NB, static_cast<long long>(natoms) + natoms / 8 + 1024);
+    alloc_device();
+    upload_ff();
+    st.n10_stride = S10; st.nbuffer = NB;
+    for (int a = 0; a < 3; ++a) { st.cells10[a] = grid.n[a]; st.cells3[a] = cc[a]; }
+  }
+  if (natoms > rows10) throw EngineError(RXMD_E_NBUFFER, "more atoms than the engine was sized for");
+  N = natoms; G = natoms;
+  for (int a = 0; a < 3; ++a) {
+    RX_HIP(hipMemcpy(pos[a], hx[a].data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+    RX_HIP(hipMemcpy(vel[a], hv[a].data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+    RX_HIP(hipMemset(frc[a], 0, sizeof(double) * NB));
+  }
+  RX_HIP(hipMemcpy(q, hq.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+  RX_HIP(hipMemcpy(qsfp, hp.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+  RX_HIP(hipMemcpy(qsfv, hw.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+  RX_HIP(hipMemcpy(type, ht.data(), sizeof(int) * natoms, hipMemcpyHostToDevice));
+  RX_HIP(hipMemcpy(gid, hg.data(), sizeof(long long) * natoms, hipMemcpyHostToDevice));
+  atoms_set = true; lists_valid = false; ghosts_valid = false;
+  st.natoms = N;
+}
+
+int Engine::get_atoms_rxff(double *rec, int capacity) {
+  if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+  if (!rec) return N;
+  if (capacity < N) throw EngineError(RXMD_E_ARG, "capacity smaller than natoms");
+  std::vector<double> hx[3], hv[3], hq(N), hp(N), hw(N);
+  std::vector<int> ht(N);
+  std::vector<long long> hg(N);
+  RX_HIP(hipStreamSynchronize(stream));
+  for (int a = 0; a < 3; ++a) {
+    hx[a].resize(N); hv[a].resize(N);
+    RX_HIP(hipMemcpy(hx[a].data(), pos[a], sizeof(double) * N, hipMemcpyDeviceToHost));
+    RX_HIP(hipMemcpy(hv[a].data(), vel[a], sizeof(double) * N, hipMemcpyDeviceToHost));
+  }
+  RX_HIP(hipMemcpy(hq.data(), q, sizeof(double) * N, hipMemcpyDeviceToHost));
+  RX_HIP(hipMemcpy(hp.data(), qsfp, sizeof(double) * N, hipMemcpyDeviceToHost));
+  RX_HIP(hipMemcpy(hw.data(), qsfv, sizeof(double) * N, hipMemcpyDeviceToHost));
+  RX_HIP(hipMemcpy(ht.data(), type, sizeof(int) * N, hipMemcpyDeviceToHost));
+  RX_HIP(hipMemcpy(hg.data(), gid, sizeof(long long) * N, hipMemcpyDeviceToHost));
+  for (int i = 0; i < N; ++i) {
+    double *r = rec + 10 * static_cast<size_t>(i);
+    for (int a = 0; a < 3; ++a) r[a] = (box.Hi[a][0] * hx[0][i] + box.Hi[a][1] * hx[1][i] + box.Hi[a][2] * hx[2][i]) - box.obox[a];  // xu2xs
+    for (int a = 0; a < 3; ++a) r[3 + a] = hv[a][i];
+    r[6] = hq[i]; r[7] = ht[i] + hg[i] * 1e-13; r[8] = hp[i]; r[9] = hw[i];
+  }
+  return N;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: coordinates, slab flags, append, halo
+struct BoxDev { double H[9], Hi[9], obox[3], lbox[3]; };
+static BoxDev boxdev(const Box &b) {
+  BoxDev d;
+  for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) { d.H[3 * a + c] = b.H[a][c]; d.Hi[3 * a + c] = b.Hi[a][c]; }
+  for (int a = 0; a < 3; ++a) { d.obox[a] = b.obox[a]; d.lbox[a] = b.lbox[a]; }
+  return d;
+}
+
+// xu2xs (reference src/main.F90:596-616): normalised local coordinates of atoms [i0,i1)
+__global__ void k_to_normalised(BoxDev B, int i0, int i1, const double *x, const double *y, const double *z, double *sx, double *sy, double *sz) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i1) return;
+  const double r0 = x[i], r1 = y[i], r2 = z[i];
+  sx[i] = (B.Hi[0] * r0 + B.Hi[1] * r1 + B.Hi[2] * r2) - B.obox[0];
+  sy[i] = (B.Hi[3] * r0 + B.Hi[4] * r1 + B.Hi[5] * r2) - B.obox[1];
+  sz[i] = (B.Hi[6] * r0 + B.Hi[7] * r1 + B.Hi[8] * r2) - B.obox[2];
+}
+// xs2xu (reference src/main.F90:641-660)
+__global__ void k_to_real(BoxDev B, int i0, int i1, const double *sx, const double *sy, const double *sz, double *x, double *y, double *z) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i1) return;
+  const double r0 = sx[i] + B.obox[0], r1 = sy[i] + B.obox[1], r2 = sz[i] + B.obox[2];
+  x[i] = B.H[0] * r0 + B.H[1] * r1 + B.H[2] * r2;
+  y[i] = B.H[3] * r0 + B.H[4] * r1 + B.H[5] * r2;
+  z[i] = B.H[6] * r0 + B.H[7] * r1 + B.H[8] * r2;
+}
+
+// inBuffer (reference src/comm.F90:551-576) over the scan range of one exchange stage
+__global__ void k_slab_flags(int nscan, int dflag, double lbox, double dr, const double *s, const int *type, int skip_dead, int *flags) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > nscan) return;
+  int f = 0;
+  if (n < nscan) {
+    const double rr = s[n];
+    f = (dflag & 1) ? (lbox - dr < rr) : (rr <= dr);
+    if (skip_dead && type[n] <= 0) f = 0;
+  }
+  flags[n] = f;   // flags[nscan] = 0 so that scanout[nscan] is the total
+}
+
+// store_atoms + append_atoms for a self-exchange stage of MODE_COPY (reference src/comm.F90:367-453,456-528)
+__global__ void k_append_ghosts(int nscan, int base, int N, int axis, double sft, const int *flags, const int *scanout,
+                                double *sx, double *sy, double *sz, int *type, long long *gid, double *q, int *gsrc, int *groot, int *sendlist) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nscan || !flags[n]) return;
+  const int k = scanout[n], m = base + k;
+  double a = sx[n], b = sy[n], c = sz[n];
+  if (axis == 0) a += sft; else if (axis == 1) b += sft; else c += sft;
+  sx[m] = a; sy[m] = b; sz[m] = c;
+  type[m] = type[n]; gid[m] = gid[n]; q[m] = q[n];
+  gsrc[m] = n; groot[m] = (n < N) ? n : groot[n];
+  sendlist[k] = n;
+}
+
+__global__ void k_refresh2(int N, int G, const int *groot, double2 *v) {
+  const int g = N + blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) v[g] = v[groot[g]];
+}
+__global__ void k_refresh1(int N, int G, const int *groot, double *v) {
+  const int g = N + blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) v[g] = v[groot[g]];
+}
+// append_atoms for MODE_CPBK (reference src/comm.F90:474-482): one stage, sources are unique within a stage
+__global__ void k_fold_stage(int g0, int g1, const int *gsrc, double *fx, double *fy, double *fz) {
+  const int m = g0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= g1) return;
+  const int n = gsrc[m];
+  fx[n] += fx[m]; fy[n] += fy[m]; fz[n] += fz[m];
+}
+
+static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+
+void Engine::ghost_build() {
+  if (has_comm && nprocs > 1) throw EngineError(RXMD_E_COMM, "multi-rank exchange is not wired in this build (vprocs must be 1 1 1)");
+  const BoxDev B = boxdev(box);
+  k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
+  copyptr[0] = N;
+  sendoff[1] = 0;
+  for (int d = 1; d <= 6; ++d) {
+    const int nscan = copyptr[cptridx_[d]], axis = (d - 1) / 2;
+    const double sft = (d & 1) ? -box.lbox[axis] : box.lbox[axis];   // xshift, comm.F90:531-548
+    k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d, box.lbox[axis], shell[axis], spos[axis], type, 0, flags);
+    size_t tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
+    int total = 0;
+    RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipStreamSynchronize(stream));
+    if (static_cast<long long>(copyptr[d - 1]) + total > NB || sendoff[d] + total > NB)
+      throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
+    if (total > 0)
+      k_append_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, copyptr[d - 1], N, axis, sft, flags, scanout, spos[0], spos[1], spos[2], type, gid, q, gsrc, groot, sendidx + sendoff[d]);
+    copyptr[d] = copyptr[d - 1] + total;
+    sendoff[d + 1] = sendoff[d] + total;
+  }
+  G = copyptr[6];
+  if (G > N) k_to_real<<<nblk(G - N, 256), 256, 0, stream>>>(B, N, G, spos[0], spos[1], spos[2], pos[0], pos[1], pos[2]);
+  ghosts_valid = true;
+  st.nghost_force = G - N; st.nghost_qeq = G - N;
+}
+
+void Engine::halo_refresh(double2 *v2, double *v1) {
+  if (G <= N) return;
+  if (v2) k_refresh2<<<nblk(G - N, 256), 256, 0, stream>>>(N, G, groot, v2);
+  if (v1) k_refresh1<<<nblk(G - N, 256), 256, 0, stream>>>(N, G, groot, v1);
+}
+
+void Engine::fold_ghost_forces() {
+  for (int d = 6; d >= 1; --d) {
+    const int g0 = copyptr[d - 1], g1 = copyptr[d];
+    if (g1 > g0) k_fold_stage<<<nblk(g1 - g0, 256), 256, 0, stream>>>(g0, g1, gsrc, frc[0], frc[1], frc[2]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// COPYATOMS(MODE_MOVE) (reference src/comm.F90 with dr = 0): atoms that left [0,lbox) re-enter through
+// the periodic image (or go to the neighbour rank) and are appended after the residents; survivors
+// are compacted in order (comm.F90:238-257).  All positions take the normalise -> real round trip.
+__global__ void k_move_append(int nscan, int base, int axis, double sft, const int *flags, const int *scanout,
+                              double *sx, double *sy, double *sz, double *vx, double *vy, double *vz,
+                              int *type, long long *gid, double *q, double *qsfp, double *qsfv) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nscan || !flags[n]) return;
+  const int m = base + scanout[n];
+  double a = sx[n], b = sy[n], c = sz[n];
+  if (axis == 0) a += sft; else if (axis == 1) b += sft; else c += sft;
+  sx[m] = a; sy[m] = b; sz[m] = c; vx[m] = vx[n]; vy[m] = vy[n]; vz[m] = vz[n];
+  type[m] = type[n]; gid[m] = gid[n]; q[m] = q[n]; qsfp[m] = qsfp[n]; qsfv[m] = qsfv[n];
+  type[n] = -1;   // comm.F90:440
+}
+__global__ void k_alive_flags(int n, const int *type, int *flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) flags[i] = (i < n && type[i] > 0) ? 1 : 0;
+}
+template <class T>
+__global__ void k_compact(int n, const int *flags, const int *scanout, const T *src, T *dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) dst[scanout[i]] = src[i];
+}
+
+void Engine::migrate() {
+  const BoxDev B = boxdev(box);
+  k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
+  int cp[7];
+  cp[0] = N;
+  int moved = 0;
+  for (int d = 1; d <= 6; ++d) {
+    const int nscan = cp[cptridx_[d]], axis = (d - 1) / 2;
+    const double sft = (d & 1) ? -box.lbox[axis] : box.lbox[axis];
+    k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d, box.lbox[axis], 0.0, spos[axis], type, 1, flags);
+    size_t tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
+    int total = 0;
+    RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipStreamSynchronize(stream));
+    if (static_cast<long long>(cp[d - 1]) + total > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
+    if (total > 0)
+      k_move_append<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d - 1], axis, sft, flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
+    cp[d] = cp[d - 1] + total;
+    moved += total;
+  }
+  int newN = N;
+  if (moved > 0) {
+    const int n = cp[6];
+    k_alive_flags<<<nblk(n + 1, 256), 256, 0, stream>>>(n, type, flags);
+    size_t tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, n + 1, stream));
+    RX_HIP(hipMemcpyAsync(&newN, scanout + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipStreamSynchronize(stream));
+    if (newN > rows10) throw EngineError(RXMD_E_NBUFFER, "resident count grew beyond the 10 A list capacity");
+    // scratch: reuse force + bonded scratch arrays as compaction targets (they are recomputed every step)
+    double *tmpd[9] = {frc[0], frc[1], frc[2], cds, cd, cc_, deltap, delta, nlp};
+    double *srcd[9] = {spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], q, qsfp, qsfv};
+    for (int a = 0; a < 9; ++a) {
+      k_compact<double><<<nblk(n, 256), 256, 0, stream>>>(n, flags, scanout, srcd[a], tmpd[a]);
+      RX_HIP(hipMemcpyAsync(srcd[a], tmpd[a], sizeof(double) * newN, hipMemcpyDeviceToDevice, stream));
+    }
+    k_compact<long long><<<nblk(n, 256), 256, 0, stream>>>(n, flags, scanout, gid, reinterpret_cast<long long *>(dDlp));
+    RX_HIP(hipMemcpyAsync(gid, dDlp, sizeof(long long) * newN, hipMemcpyDeviceToDevice, stream));
+    k_compact<int><<<nblk(n, 256), 256, 0, stream>>>(n, flags, scanout, type, perm_in);
+    RX_HIP(hipMemcpyAsync(type, perm_in, sizeof(int) * newN, hipMemcpyDeviceToDevice, stream));
+  }
+  N = newN; G = N;
+  k_to_real<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, spos[0], spos[1], spos[2], pos[0], pos[1], pos[2]);
+  lists_valid = false; ghosts_valid = false;
+  st.natoms = N;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cell binning over residents+ghosts: stable radix sort by cell id, z fastest (LINKEDLIST, main.F90:277-318)
+__global__ void k_cell_ids(int G, Grid g, const double *sx, const double *sy, const double *sz, int *cellid, int *idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G) return;
+  int cx = static_cast<int>(floor((sx[i] - g.org[0]) * g.inv[0]));
+  int cy = static_cast<int>(floor((sy[i] - g.org[1]) * g.inv[1]));
+  int cz = static_cast<int>(floor((sz[i] - g.org[2]) * g.inv[2]));
+  cx = min(max(cx, 0), g.n[0] - 1); cy = min(max(cy, 0), g.n[1] - 1); cz = min(max(cz, 0), g.n[2] - 1);
+  cellid[i] = (cx * g.n[1] + cy) * g.n[2] + cz;
+  idx[i] = i;
+}
+__global__ void k_cell_starts(int G, int ncell, const int *cid_sorted, int *cellstart) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= G) return;
+  const int c = cid_sorted[k], prev = (k == 0) ? -1 : cid_sorted[k - 1];
+  for (int cc = prev + 1; cc <= c; ++cc) cellstart[cc] = k;
+  if (k == G - 1) for (int cc = c + 1; cc <= ncell; ++cc) cellstart[cc] = G;
+}
+__global__ void k_sorted_pos(int G, const int *perm, const double *x, const double *y, const double *z, double4 *out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= G) return;
+  const int i = perm[k];
+  out[k] = make_double4(x[i], y[i], z[i], __longlong_as_double(static_cast<long long>(i)));
+}
+
+void Engine::bin_cells() {
+  // residents need fresh normalised coordinates when ghost_build did not just compute them
+  k_cell_ids<<<nblk(G, 256), 256, 0, stream>>>(G, grid, spos[0], spos[1], spos[2], cellid, perm_in);
+  size_t tb = cubtmp_bytes;
+  int bits = 1;
+  while ((1LL << bits) < grid.ncell + 1 && bits < 31) ++bits;
+  RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, cellid, cellid_sorted, perm_in, perm, G, 0, bits, stream));
+  k_cell_starts<<<nblk(G, 256), 256, 0, stream>>>(G, grid.ncell, cellid_sorted, cellstart);
+  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, perm, pos[0], pos[1], pos[2], sorted_xyzi);
+}
+
+void Engine::build_ghosts_and_lists() {
+  if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+  tic(0);
+  ghost_build();
+  bin_cells();
+  build_bonded_list();
+  build_list10();
+  check_device_error("list build");
+  st.ms_lists += toc(0, 1);
+  lists_valid = true;
+}
+
+}  // namespace rxmd

@@ -1,0 +1,157 @@
+// lists.hip -- bonded (3 A) neighbour list with reverse index, and the 10 A pair list with the QEq
+// "hessian" (shielded-Coulomb matrix) built in the same sweep.
+//   NEIGHBORLIST            reference src/main.F90:321-417   -> k_bonded_list + k_reverse_index
+//   qeq_initialize          reference src/qeq.F90:183-268    \  one sweep: k_list10
+//   GetNonbondingPairList   reference src/main.F90:420-477   /  (the reference walks the stencil twice)
+// Candidates come from the engine's own cell grid (cell edge >= max(5 A, maxrc)), cell-sorted with z
+// fastest, so a (dx,dy) column of the stencil is ONE contiguous range of the sorted array.
+#include "engine.h"
+
+namespace rxmd {
+
+static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+
+// w component of sorted_xyzi: low 32 bits atom index, bits 32.. type
+__global__ void k_pack_type(int G, const int *perm, const int *type, double4 *s) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= G) return;
+  const int i = perm[k];
+  const long long w = (static_cast<long long>(type[i]) << 32) | static_cast<unsigned int>(i);
+  s[k].w = __longlong_as_double(w);
+}
+
+__global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+                                                      const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
+                                                      const double *__restrict__ z, const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G) return;
+  const int c = cellid[i];
+  const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
+  const double xi = x[i], yi = y[i], zi = z[i];
+  const int ti = type[i];
+  const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.n[2] - 1);
+  int cnt = 0;
+  for (int dx = -1; dx <= 1; ++dx) {
+    const int x2 = cx + dx;
+    if (x2 < 0 || x2 >= g.n[0]) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int y2 = cy + dy;
+      if (y2 < 0 || y2 >= g.n[1]) continue;
+      const int cb = (x2 * g.n[1] + y2) * g.n[2];
+      const int k0 = cellstart[cb + z0], k1 = cellstart[cb + z1 + 1];
+      for (int k = k0; k < k1; ++k) {
+        const double4 p = sorted[k];
+        const long long w = __double_as_longlong(p.w);
+        const int j = static_cast<int>(w & 0xffffffffLL);
+        if (j == i) continue;
+        const int tj = static_cast<int>(w >> 32);
+        const int inxn = ff.inxn2[ti * ff.n1 + tj];
+        if (inxn == 0) continue;
+        const double d0 = p.x - xi, d1 = p.y - yi, d2 = p.z - zi;
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        if (r2 < ff.bond[inxn].rc2) {           // dr2 < rc2(inxn), main.F90:366
+          if (cnt < MAXNB) nbr[static_cast<size_t>(cnt) * NB + i] = j;
+          ++cnt;
+        }
+      }
+    }
+  }
+  if (cnt > MAXNB) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXNB); cnt = MAXNB; }  // main.F90:402-407
+  nbrcnt[i] = cnt;
+}
+
+// nbrindx(i,i1) = j1 such that nbrlist(j,j1) == i   (main.F90:383-399)
+__global__ void k_reverse_index(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, unsigned char *__restrict__ nbrindx, int *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G) return;
+  const int ni = nbrcnt[i];
+  for (int s = 0; s < ni; ++s) {
+    const int j = nbr[static_cast<size_t>(s) * NB + i];
+    const int nj = nbrcnt[j];
+    int found = -1;
+    for (int t = 0; t < nj; ++t)
+      if (nbr[static_cast<size_t>(t) * NB + j] == i) found = t;
+    if (found < 0) { atomicCAS(&err[0], DERR_NONE, DERR_NBRINDX); found = 0; }
+    nbrindx[static_cast<size_t>(s) * NB + i] = static_cast<unsigned char>(found);
+  }
+}
+
+// One wavefront per resident row.  Lanes sweep the candidates of a stencil column 64 at a time,
+// the accepted ones are compacted with a ballot so that a row is written as contiguous runs
+// (coalesced 8-byte + 4-byte streams) in a deterministic order.
+__global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+                                                 const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
+                                                 const double *__restrict__ z, const int *__restrict__ type, int *__restrict__ nb10, double *__restrict__ hess,
+                                                 int *__restrict__ n10, int *err) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int c = cellid[i];
+  const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
+  const double xi = x[i], yi = y[i], zi = z[i];
+  const int ti = type[i];
+  const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.n[2] - 1);
+  const size_t row = static_cast<size_t>(i) * S10;
+  int cnt = 0;
+  for (int dx = -2; dx <= 2; ++dx) {
+    const int x2 = cx + dx;
+    if (x2 < 0 || x2 >= g.n[0]) continue;
+    for (int dy = -2; dy <= 2; ++dy) {
+      const int y2 = cy + dy;
+      if (y2 < 0 || y2 >= g.n[1]) continue;
+      const int cb = (x2 * g.n[1] + y2) * g.n[2];
+      const int k0 = cellstart[cb + z0], k1 = cellstart[cb + z1 + 1];
+      for (int kb = k0; kb < k1; kb += 64) {
+        const int k = kb + lane;
+        bool in = false;
+        int j = 0, tj = 0;
+        double r2 = 0.0;
+        if (k < k1) {
+          const double4 p = sorted[k];
+          const long long w = __double_as_longlong(p.w);
+          j = static_cast<int>(w & 0xffffffffLL);
+          tj = static_cast<int>(w >> 32);
+          const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
+          r2 = d0 * d0 + d1 * d1 + d2 * d2;
+          in = (j != i) && (r2 <= ff.rctap2);       // dr2 <= rctap2, main.F90:458
+        }
+        const unsigned long long m = __ballot(in);
+        if (in) {
+          const int slot = cnt + __popcll(m & ((1ULL << lane) - 1ULL));
+          if (slot < S10) {
+            // hessian entry as qeq_initialize computes it: r^2 rounded to REAL(4) first (qeq.F90:191,222-240)
+            const float r2f = static_cast<float>(r2);
+            double h = 0.0;
+            const int inxn = ff.inxn2[ti * ff.n1 + tj];
+            if (static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
+              const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
+              double drtb = static_cast<double>(r2f) - itb * ff.UDR;
+              drtb = drtb * ff.UDRi;
+              const double *T = ff.tabQEq + static_cast<size_t>(inxn) * (NTABLE + 2);
+              h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
+            }
+            nb10[row + slot] = j;
+            hess[row + slot] = h;
+          }
+        }
+        cnt += __popcll(m);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (cnt > S10) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); cnt = S10; }  // qeq.F90:248-252
+    n10[i] = cnt;
+  }
+}
+
+void Engine::build_bonded_list() {
+  k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi);
+  k_bonded_list<<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, nbr, nbrcnt, d_err);
+  k_reverse_index<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, d_err);
+}
+
+void Engine::build_list10() {
+  k_list10<<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, nb10, hess, n10, d_err);
+}
+
+}  // namespace rxmd

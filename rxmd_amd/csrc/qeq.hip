@@ -1,0 +1,231 @@
+// qeq.hip -- two-vector QEq conjugate gradient on the device (reference src/qeq.F90:2-178).
+//   get_hsh      (qeq.F90:271-318) -> k_spmv<MODE_HSH>    matrix pass over (hs,ht)
+//   get_gradient (qeq.F90:321-363) -> k_spmv<MODE_GRAD>   matrix pass over (qs,qt)
+//   driver loop  (qeq.F90:96-166)  -> Engine::qeq()       REAL(4) step lengths kept (qeq.F90:23,133)
+// The matrix is the ELL list built in lists.hip: per row a contiguous FP64 value stream and an INT32
+// column stream (12 bytes per entry, the algorithmic bytes of SURVEY 8d), one wavefront per row.
+// The two right-hand vectors are interleaved (double2) so a column costs ONE 16-byte gather.
+//
+// Est (the convergence quantity, qeq.F90:297-306) is produced by the GRADIENT pass of the previous
+// iteration: sum_j H_ij q_j = sum_j H_ij qs_j - mu sum_j H_ij qt_j, with the reference's
+// "count resident partners twice" rule kept through a second accumulator over ghost columns.
+#include "engine.h"
+
+#include <cmath>
+
+namespace rxmd {
+
+static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+
+enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_COUNT };
+enum { MODE_HSH = 0, MODE_GRAD = 1 };
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int NC>
+__device__ inline void block_store_partials(double (&acc)[NC], double *partials, int ncomp_stride) {
+  // acc holds lane-0-of-wave partials; combine the block's waves in wave order, then one store per component
+  __shared__ double sm[4][NC];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+    for (int c = 0; c < NC; ++c) sm[w][c] = acc[c];
+  __syncthreads();
+  if (threadIdx.x < NC) {
+    double s = 0.0;
+    for (int k = 0; k < 4; ++k) s += sm[k][threadIdx.x];
+    partials[static_cast<size_t>(blockIdx.x) * ncomp_stride + threadIdx.x] = s;
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
+                                               const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
+                                               const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
+                                               const double *__restrict__ scal, double *__restrict__ partials) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int wave0 = blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * wpb;
+  const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int row = wave0; row < N; row += nwaves) {
+    const int n = n10[row];
+    const size_t base = static_cast<size_t>(row) * S10;
+    double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+    for (int k0 = lane; k0 < n; k0 += 256) {
+      int j[4];
+      double h[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 64 * u;
+        const bool ok = k < n;
+        j[u] = ok ? __builtin_nontemporal_load(nb10 + base + k) : 0;
+        h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double2 v = xv[j[u]];
+        as += h[u] * v.x;
+        at += h[u] * v.y;
+        if (MODE == MODE_GRAD && j[u] >= N) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
+      }
+    }
+    as = wave_sum(as); at = wave_sum(at);
+    if (MODE == MODE_GRAD) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+    if (lane == 0) {
+      const DevAtomP ap = ff.atom[type[row]];
+      if (MODE == MODE_HSH) {
+        const double2 hv = hst[row], gv = gst[row];
+        const double ts = ap.eta * hv.x + as, tt = ap.eta * hv.y + at;      // qeq.F90:294-302
+        acc[0] += ts * hv.x; acc[1] += tt * hv.y;                           // hshs_sum, hsht_sum (:309-310)
+        acc[2] += gv.x * hv.x; acc[3] += gv.y * hv.y;                       // g.h (:119,123)
+      } else {
+        const double2 qv = qst[row];
+        const double g1 = -ap.chi - ap.eta * qv.x - as;                     // qeq.F90:349-350
+        const double g2 = -1.0 - ap.eta * qv.y - at;
+        gst[row] = make_double2(g1, g2);
+        acc[0] += g1 * g1; acc[1] += g2 * g2;                               // Gnew (:355-356)
+        const double qi = q[row];
+        const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+        acc[2] += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
+      }
+    }
+  }
+  block_store_partials<4>(acc, partials, 4);
+}
+
+// single-block deterministic reduction of the per-block partials + the scalar algebra between passes
+__device__ inline double block_sum_256(double v, double *sm) {
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double r = sm[0];
+  __syncthreads();
+  return r;
+}
+
+// stage 1: after the HSH pass -> REAL(4) line-minimisation factors (qeq.F90:133)
+// stage 2: after the q update  -> mu = ssum/tsum (qeq.F90:147)
+// stage 3: after the GRAD pass -> Gold<-Gnew, Gnew, Est, beta (qeq.F90:156-161)
+__global__ void __launch_bounds__(256) k_reduce_scalars(int stage, int nblocks, const double *__restrict__ partials, double *__restrict__ scal) {
+  __shared__ double sm[256];
+  double a[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+    for (int c = 0; c < 4; ++c) a[c] += partials[static_cast<size_t>(b) * 4 + c];
+  double r[4];
+  for (int c = 0; c < 4; ++c) r[c] = block_sum_256(a[c], sm);
+  if (threadIdx.x != 0) return;
+  if (stage == 1) {
+    scal[S_HSH_S] = r[0]; scal[S_HSH_T] = r[1]; scal[S_GH_S] = r[2]; scal[S_GH_T] = r[3];
+    const float l1 = static_cast<float>(r[2] / r[0]), l2 = static_cast<float>(r[3] / r[1]);   // real(4) :: lmin(2)
+    scal[S_LMIN_S] = static_cast<double>(l1); scal[S_LMIN_T] = static_cast<double>(l2);
+  } else if (stage == 2) {
+    scal[S_SSUM] = r[0]; scal[S_TSUM] = r[1];
+    scal[S_MU] = r[0] / r[1];
+  } else {
+    const double go_s = scal[S_GNEW_S], go_t = scal[S_GNEW_T];
+    scal[S_GOLD_S] = go_s; scal[S_GOLD_T] = go_t;
+    scal[S_GNEW_S] = r[0]; scal[S_GNEW_T] = r[1]; scal[S_EST] = r[2];
+    scal[S_BETA_S] = r[0] / go_s; scal[S_BETA_T] = r[1] / go_t;
+  }
+}
+
+// qs += lmin1*hs ; qt += lmin2*ht ; partial sums of qs, qt (qeq.F90:136-141)
+__global__ void __launch_bounds__(256) k_update_qst(int N, const double *__restrict__ scal, const double2 *__restrict__ hst, double2 *__restrict__ qst, double *__restrict__ partials) {
+  const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
+  double acc[4] = {0, 0, 0, 0};
+  double s = 0.0, t = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    double2 qv = qst[i];
+    const double2 hv = hst[i];
+    qv.x = qv.x + l1 * hv.x; qv.y = qv.y + l2 * hv.y;
+    qst[i] = qv;
+    s += qv.x; t += qv.y;
+  }
+  s = wave_sum(s); t = wave_sum(t);
+  acc[0] = s; acc[1] = t;
+  block_store_partials<4>(acc, partials, 4);
+}
+// q = qs - mu*qt (qeq.F90:150)
+__global__ void k_apply_q(int N, const double *__restrict__ scal, const double2 *__restrict__ qst, double *__restrict__ q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double2 v = qst[i];
+  q[i] = v.x - scal[S_MU] * v.y;
+}
+// hs = gs + (Gnew1/Gold1)*hs ; ht likewise (qeq.F90:160-161); first = 1: hs = gs (qeq.F90:90-91)
+__global__ void k_direction(int N, int first, const double *__restrict__ scal, const double2 *__restrict__ gst, double2 *__restrict__ hst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double2 g = gst[i];
+  if (first) { hst[i] = g; return; }
+  const double2 h = hst[i];
+  hst[i] = make_double2(g.x + scal[S_BETA_S] * h.x, g.y + scal[S_BETA_T] * h.y);
+}
+// initial vectors (qeq.F90:36-63)
+__global__ void k_qeq_init(int N, int NBcap, int isQEq, double fqs, double *__restrict__ q, double *__restrict__ qsfp, double *__restrict__ qsfv, double2 *__restrict__ qst, double2 *__restrict__ hst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NBcap) return;
+  if (i >= N) { qst[i] = make_double2(0.0, 0.0); hst[i] = make_double2(0.0, 0.0); return; }
+  if (isQEq == 1) { qsfp[i] = q[i]; qsfv[i] = 0.0; qst[i] = make_double2(q[i], 0.0); }
+  else { qst[i] = make_double2(fqs * qsfp[i] + (1.0 - fqs) * q[i], 0.0); }
+}
+
+void Engine::qeq() {
+  if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+  if (cfg.isQEq != 1 && cfg.isQEq != 2) { nstep_qeq = 0; return; }   // qeq.F90:60-61
+  tic(6);
+  if (!lists_valid) build_ghosts_and_lists();
+  const int nmax = (cfg.isQEq == 1) ? cfg.NMAXQEq : 1;
+  const int rb = std::min(nblk(N, 4), 2048);
+  const int vb = std::min(nblk(N, 256), 2048);
+  k_qeq_init<<<nblk(G, 256), 256, 0, stream>>>(N, G, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
+  RX_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 64, stream));
+  halo_refresh(qst, nullptr);                                                                   // QCOPY1, qeq.F90:86
+  k_spmv<MODE_GRAD><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, qst, hst, gst, qst, q, type, scal, partials);
+  k_reduce_scalars<<<1, 256, 0, stream>>>(3, rb, partials, scal);
+  k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
+  halo_refresh(hst, q);                                                                          // QCOPY2, qeq.F90:93
+  RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
+  RX_HIP(hipStreamSynchronize(stream));
+  double GEst2 = 1e99, Est = h_scal[S_EST];
+  int it = 0;
+  float ms = 0;
+  for (it = 0; it <= nmax - 1; ++it) {
+    if (0.5 * (std::fabs(GEst2) + std::fabs(Est)) < cfg.QEq_tol) break;                          // qeq.F90:114
+    if (std::fabs(GEst2) > 0.0 && std::fabs(Est / GEst2 - 1.0) < cfg.QEq_tol) break;            // qeq.F90:115
+    GEst2 = Est;
+    hipEventRecord(ev[2], stream);
+    k_spmv<MODE_HSH><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, hst, hst, gst, qst, q, type, scal, partials);
+    hipEventRecord(ev[3], stream);
+    k_reduce_scalars<<<1, 256, 0, stream>>>(1, rb, partials, scal);
+    k_update_qst<<<vb, 256, 0, stream>>>(N, scal, hst, qst, partials);
+    k_reduce_scalars<<<1, 256, 0, stream>>>(2, vb, partials, scal);
+    k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);
+    halo_refresh(qst, nullptr);                                                                  // QCOPY1, qeq.F90:153
+    hipEventRecord(ev[4], stream);
+    k_spmv<MODE_GRAD><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, qst, hst, gst, qst, q, type, scal, partials);
+    hipEventRecord(ev[5], stream);
+    k_reduce_scalars<<<1, 256, 0, stream>>>(3, rb, partials, scal);
+    k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);
+    halo_refresh(hst, q);                                                                        // QCOPY2, qeq.F90:164
+    RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipStreamSynchronize(stream));
+    Est = h_scal[S_EST];
+    hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
+    hipEventElapsedTime(&ms, ev[4], ev[5]); st.ms_qeq_spmv += ms;
+    st.spmv_launches += 2;
+  }
+  nstep_qeq = it; last_est = Est;
+  st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1;
+  st.ms_qeq += toc(6, 7);
+}
+
+}  // namespace rxmd

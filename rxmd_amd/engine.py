@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference's operator surface for the hot path.
+
+The reference exposes the path as Fortran subroutines `QEq(atype,pos,q)` (src/qeq.F90:2),
+`FORCE(atype,pos,f,q)` (src/pot.F90:2) and the MD loop body (src/main.F90:64-98) working on
+module-global arrays.  `RxmdEngine` keeps those names and argument meanings on top of the C ABI
+(include/rxmd_hip.h); device state lives in the library, numpy arrays are views for the caller.
+Errors that make the reference print + MPI_FINALIZE + stop raise RxmdError with the same text.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import RxmdConfig, RxmdStats
+
+PE_NAMES = ["Esystem", "Ebond", "Elp", "Eover", "Eunder", "Eval", "Epen", "Ecoa", "Etors", "Econj", "Ehbond", "Evdwaals", "Ecoulomb", "Echarge"]
+
+
+class RxmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rxmd_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class RxmdEngine:
+    """One engine = one rank of the vprocs grid = one MI355X."""
+
+    def __init__(self, ffield, lattice, vprocs=(1, 1, 1), myid=0, isQEq=1, NMAXQEq=500, QEq_tol=1e-7, qstep=1, dt_fs=0.25,
+                 nbuffer=0, maxneighbs=0, maxneighbs10=0, device=0, qeq_mode=0, Lex_fqs=1.0, Lex_k=2.0):
+        self.L = _lib.load()
+        cfg = RxmdConfig()
+        self.L.rxmd_hip_default_config(C.byref(cfg))
+        self._ff = str(ffield).encode()
+        cfg.ffield_path = self._ff
+        for i in range(6):
+            cfg.lattice[i] = float(lattice[i])
+        for i in range(3):
+            cfg.vprocs[i] = int(vprocs[i])
+        cfg.myid = myid; cfg.isQEq = isQEq; cfg.NMAXQEq = NMAXQEq; cfg.QEq_tol = QEq_tol; cfg.qstep = qstep; cfg.dt_fs = dt_fs
+        cfg.nbuffer = nbuffer; cfg.maxneighbs = maxneighbs; cfg.maxneighbs10 = maxneighbs10; cfg.device = device; cfg.qeq_mode = qeq_mode
+        cfg.Lex_fqs = Lex_fqs; cfg.Lex_k = Lex_k
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.L.rxmd_hip_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RxmdError(rc, (self.L.rxmd_hip_last_error(None) or b"").decode())
+        self.h = h
+        self.lattice = [float(x) for x in lattice]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rxmd_hip_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RxmdError(rc, self.L.rxmd_hip_last_error(self.h).decode())
+        return rc
+
+    # ---- state ----
+    def set_atoms_rxff(self, rec10):
+        rec10 = np.ascontiguousarray(rec10, np.float64).reshape(-1, 10)
+        self._chk(self.L.rxmd_hip_set_atoms_rxff(self.h, len(rec10), _ptr(rec10)))
+
+    def get_atoms_rxff(self):
+        n = self._chk(self.L.rxmd_hip_get_atoms_rxff(self.h, None, 0))
+        out = np.zeros((n, 10))
+        self._chk(self.L.rxmd_hip_get_atoms_rxff(self.h, _ptr(out), n))
+        return out
+
+    @property
+    def natoms(self):
+        return self._chk(self.L.rxmd_hip_get_atoms_rxff(self.h, None, 0))
+
+    def atoms(self):
+        n = self.natoms
+        gid = np.zeros(n, np.int64); typ = np.zeros(n, np.int32)
+        pos = np.zeros((n, 3)); v = np.zeros((n, 3)); f = np.zeros((n, 3)); q = np.zeros(n)
+        self._chk(self.L.rxmd_hip_get_atoms(self.h, n, _ptr(gid), _ptr(typ), _ptr(pos), _ptr(v), _ptr(f), _ptr(q)))
+        return dict(gid=gid, type=typ, pos=pos, v=v, f=f, q=q)
+
+    def set_charges(self, q):
+        q = np.ascontiguousarray(q, np.float64); self._chk(self.L.rxmd_hip_set_charges(self.h, len(q), _ptr(q)))
+
+    def set_velocities(self, v):
+        v = np.ascontiguousarray(v, np.float64).reshape(-1, 3); self._chk(self.L.rxmd_hip_set_velocities(self.h, len(v), _ptr(v)))
+
+    # ---- the hot path (device resident) ----
+    def QEq(self):
+        """QEq(atype,pos,q), reference src/qeq.F90:2 -> (nstep_qeq, Est)"""
+        it = C.c_int(0); est = C.c_double(0.0)
+        self._chk(self.L.rxmd_hip_qeq(self.h, C.byref(it), C.byref(est)))
+        return it.value, est.value
+
+    def FORCE(self):
+        """FORCE(atype,pos,f,q), reference src/pot.F90:2 -> PE(0:13)"""
+        pe = np.zeros(14)
+        self._chk(self.L.rxmd_hip_force(self.h, _ptr(pe)))
+        return pe
+
+    def step(self, nsteps=1):
+        """nsteps passes of the MD loop body, reference src/main.F90:64-98"""
+        self._chk(self.L.rxmd_hip_step(self.h, int(nsteps)))
+
+    def energy(self):
+        ke = C.c_double(0); qs = C.c_double(0); pe = np.zeros(14); astr = np.zeros(6)
+        self._chk(self.L.rxmd_hip_get_energy(self.h, C.byref(ke), C.byref(qs), _ptr(pe), _ptr(astr)))
+        return dict(KE=ke.value, qsum=qs.value, PE=pe, astr=astr)
+
+    # ---- the reference's own array shapes ----
+    def QEq_arrays(self, atype, pos, q, natoms):
+        """atype(NBUFFER), pos(NBUFFER,3) column-major (Fortran order), q(NBUFFER) updated in place"""
+        nbuf = len(atype)
+        posf = np.asfortranarray(pos, np.float64); atype = np.ascontiguousarray(atype, np.float64)
+        assert q.flags["C_CONTIGUOUS"] and q.dtype == np.float64
+        self._chk(self.L.rxmd_hip_QEq(self.h, nbuf, natoms, _ptr(atype), posf.ctypes.data_as(C.c_void_p), _ptr(q)))
+        return q
+
+    def FORCE_arrays(self, atype, pos, q, natoms):
+        nbuf = len(atype)
+        posf = np.asfortranarray(pos, np.float64); atype = np.ascontiguousarray(atype, np.float64); q = np.ascontiguousarray(q, np.float64)
+        f = np.zeros((nbuf, 3), order="F"); pe = np.zeros(14)
+        self._chk(self.L.rxmd_hip_FORCE(self.h, nbuf, natoms, _ptr(atype), posf.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p), _ptr(q), _ptr(pe)))
+        return f, pe
+
+    # ---- introspection ----
+    def stats(self):
+        s = RxmdStats(); self._chk(self.L.rxmd_hip_get_stats(self.h, C.byref(s))); return s.asdict()
+
+    def reset_timers(self):
+        self._chk(self.L.rxmd_hip_reset_timers(self.h))
+
+    def table(self, which):
+        rc = C.c_double(0)
+        nboty = self._chk(self.L.rxmd_hip_get_cutoffs(self.h, None, 0, C.byref(rc)))
+        out = np.zeros((nboty, 5000))
+        self._chk(self.L.rxmd_hip_get_table(self.h, which, _ptr(out), out.size))
+        return out
+
+    def cutoffs(self):
+        mx = C.c_double(0)
+        n = self._chk(self.L.rxmd_hip_get_cutoffs(self.h, None, 0, C.byref(mx)))
+        rc = np.zeros(n)
+        self._chk(self.L.rxmd_hip_get_cutoffs(self.h, _ptr(rc), n, C.byref(mx)))
+        return rc, mx.value
+
+    def debug(self, what, width=1, cap=None):
+        cap = cap or (self.stats()["nbuffer"] * width)
+        out = np.zeros(cap)
+        n = self._chk(self.L.rxmd_hip_debug_get(self.h, what, _ptr(out), cap))
+        out = out[:n * width]
+        return out.reshape(n, width) if width > 1 else out

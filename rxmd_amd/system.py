@@ -1,0 +1,95 @@
+"""Input-side host helpers that keep the reference's file surface: fractional xyz unit cells,
+`geninit` replication (init/geninit.F90), DAT/rxff.bin (src/fileio.F90:444-653), rxmd.in
+(src/cmdline.F90:255-297).  The replication and the binary reader run in the C++ front-end."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+
+
+def read_xyz(path):
+    """geninit input: line 1 `natoms "note"`, line 2 `a b c alpha beta gamma`, then `Elem x y z` (fractional)"""
+    with open(path) as fh:
+        lines = fh.read().split("\n")
+    n = int(lines[0].split()[0])
+    lattice = [float(x) for x in lines[1].split()[:6]]
+    names, frac = [], []
+    for l in lines[2:2 + n]:
+        t = l.split()
+        names.append(t[0]); frac.append([float(t[1]), float(t[2]), float(t[3])])
+    return names, np.array(frac), lattice
+
+
+def geninit(ffield, names, frac, lattice, mc=(1, 1, 1), vprocs=(1, 1, 1), myid=0):
+    """-> (lattice_super, rec10[natoms_of_rank, 10]) exactly what DAT/rxff.bin would hold for `myid`"""
+    L = _lib.load()
+    n0 = len(names)
+    elem = bytearray(4 * n0)
+    for i, s in enumerate(names):
+        b = s.encode()[:2]
+        elem[4 * i:4 * i + len(b)] = b
+    elem = bytes(elem)
+    frac = np.ascontiguousarray(frac, np.float64)
+    lat = np.array(lattice, np.float64); mcv = np.array(mc, np.int32); vp = np.array(vprocs, np.int32)
+    lat_out = np.zeros(6)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = L.rxmd_host_geninit(str(ffield).encode(), n0, elem, p(frac), p(lat), p(mcv), p(vp), myid, None, 0, p(lat_out))
+    if n < 0:
+        raise RuntimeError("rxmd_host_geninit failed: %d" % n)
+    rec = np.zeros((n, 10))
+    n2 = L.rxmd_host_geninit(str(ffield).encode(), n0, elem, p(frac), p(lat), p(mcv), p(vp), myid, p(rec), n, p(lat_out))
+    assert n2 == n
+    return list(lat_out), rec
+
+
+def read_rxff(path, myid=0):
+    L = _lib.load()
+    lat = np.zeros(6); vp = np.zeros(3, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = L.rxmd_host_read_rxff(str(path).encode(), myid, p(lat), p(vp), None, 0)
+    if n < 0:
+        raise RuntimeError("cannot read %s" % path)
+    rec = np.zeros((n, 10))
+    L.rxmd_host_read_rxff(str(path).encode(), myid, p(lat), p(vp), p(rec), n)
+    return list(lat), [int(x) for x in vp], rec
+
+
+def write_rxff(path, lattice, vprocs, recs, current_step=0):
+    """WriteBIN layout (src/fileio.F90:558-653): int32 nprocs,vprocs[3],natoms[nprocs],step; f64 lattice[6]; records"""
+    with open(path, "wb") as fh:
+        npr = int(np.prod(vprocs))
+        np.array([npr] + list(vprocs) + [len(r) for r in recs] + [current_step], np.int32).tofile(fh)
+        np.array(lattice, np.float64).tofile(fh)
+        for r in recs:
+            np.ascontiguousarray(r, np.float64).tofile(fh)
+
+
+def parse_rxmd_in(path):
+    """keywords of rxmd.in (src/cmdline.F90:255-297); unknown keyword = error, as in the reference"""
+    out = {}
+    keys = {"mdmode": ["mdmode"], "time": ["dt", "ntime_step"], "temperature": ["treq", "vsfact", "sstep"], "io_step": ["fstep", "pstep"],
+            "io_type": ["isBinary", "isBondFile", "isPDB", "isXYZ"], "processors": ["vprocs1", "vprocs2", "vprocs3"],
+            "QEq": ["isQEq", "NMAXQEq", "QEq_tol", "qstep"], "exL": ["Lex_fqs", "Lex_k"], "CG_tol": ["ftol"], "efield": ["eFieldDir", "eFieldStrength"],
+            "PQEqParm": ["PQEqParmPath"]}
+    for line in open(path):
+        t = line.strip()
+        if not t or t.startswith("#"):
+            continue
+        tok = t.split()
+        if tok[0] not in keys:
+            raise ValueError("ERROR: %s is not found" % tok[0])
+        for name, val in zip(keys[tok[0]], tok[1:]):
+            v = val.replace("d", "e").replace("D", "e")
+            if v in (".true.", ".false."):
+                out[name] = v == ".true."
+            else:
+                try:
+                    out[name] = int(v)
+                except ValueError:
+                    try:
+                        out[name] = float(v)
+                    except ValueError:
+                        out[name] = val
+    if "vprocs1" in out:
+        out["vprocs"] = (out.pop("vprocs1"), out.pop("vprocs2"), out.pop("vprocs3"))
+    return out
