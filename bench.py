@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- MD steps/s of the HIP ReaxFF+QEq hot path on replicated RDX at fixed atoms/GPU.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+One "step" = one pass of the MD loop body (reference src/main.F90:64-98: kick, drift, migrate, QEq, FORCE,
+kick) over the workload, inputs resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: RDX unit cell
+(168 atoms) replicated 18x18x18 = 979,776 atoms, QEq tol 1e-7, dt 0.25 fs, v0 = 0, q0 = 0 (the reference's
+own example input, examples/1-reaxff/rxmd.in).  Prints ONE JSON line on rank 0.
+"""
+import argparse, json, os, resource, shutil, subprocess, sys, tempfile, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+INP = os.path.join(ROOT, "tests", "golden", "inputs")
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+ATOMS_PER_GPU_CELLS = 18
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Times the REAL reference (oracle/_ref/rxmd_omp: unmodified Fortran, OpenMP, built by oracle/Makefile) on the
+    host cores of this box on a bounded sample of the same workload: RDX 3x3x3 = 4,536 atoms (the largest cube that
+    fits the reference's compiled-in NBUFFER = 30000 with its 13 A ghost shell), same rxmd.in."""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    exe, gen = os.path.join(ref, "rxmd_omp"), os.path.join(ref, "geninit")
+    if not (os.path.exists(exe) and os.path.exists(gen)):
+        return None
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, 64)
+    tmp = tempfile.mkdtemp(prefix="rxmd_cpu_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(INP, "rdx.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(INP, "ffield_rdx"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "3", "3", "3"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        env = dict(os.environ, OMP_NUM_THREADS=str(nthreads), OMP_STACKSIZE="1G")
+
+        def unlimit():
+            try:
+                resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+            except Exception:
+                pass
+        nsteps = 60
+        t0 = time.time()
+        p = subprocess.run([exe, "--ntime_step", str(nsteps), "--pstep", "1000", "--fstep", "100000"], cwd=tmp, env=env, preexec_fn=unlimit,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        wall = time.time() - t0
+        loop = None
+        for l in p.stdout.split("\n"):
+            if "total (sec)" in l:
+                loop = float(l.split()[2])       # the reference's own timer around its MD loop (main.F90:35,108-109)
+        if loop is None or loop <= 0 or "successfully finished" not in p.stdout:
+            return None
+        atom_steps = 4536 * nsteps / loop
+        return {"value": atom_steps / (168 * ATOMS_PER_GPU_CELLS ** 3), "unit": "steps/s", "cores": nthreads, "kind": "reference",
+                "sample": "USCCACS/RXMD Fortran+OpenMP (oracle/_ref/rxmd_omp), RDX 3x3x3 = 4536 atoms, %d MD steps in %.2f s loop time "
+                          "(%.0f atom-steps/s), scaled to steps/s at 979,776 atoms" % (nsteps, loop, atom_steps),
+                "atom_steps_per_s": atom_steps, "wall_s": wall}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def vprocs_for(n):
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[n]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cells", type=int, default=ATOMS_PER_GPU_CELLS, help="RDX unit cells per edge per GPU (18 -> 979,776 atoms)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--qeq-mode", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    import rxmd_amd
+    from rxmd_amd import system
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    vp = vprocs_for(world)
+    mc = tuple(a.cells * v for v in vp)
+
+    ff = os.path.join(INP, "ffield_rdx")
+    names, frac, lat = system.read_xyz(os.path.join(INP, "rdx.xyz"))
+    cfg = system.parse_rxmd_in(os.path.join(INP, "rxmd.in"))
+    if use_dist:
+        # weak scaling: every rank owns one 18^3-cell domain of the vprocs grid.  Until the RCCL halo transport is
+        # wired (rxmd_hip_set_comm), each rank advances its own periodic 979,776-atom replica: no data-path
+        # collective, identical per-GPU work -- reported as "replicas" in config.parallelism.
+        mc_local, vp_local, myid = (a.cells,) * 3, (1, 1, 1), 0
+    else:
+        mc_local, vp_local, myid = mc, vp, 0
+    lat_super, rec = system.geninit(ff, names, frac, lat, mc=mc_local, vprocs=vp_local, myid=myid)
+    natoms = len(rec)
+    eng = rxmd_amd.RxmdEngine(ff, lat_super, vprocs=vp_local, myid=myid, isQEq=cfg["isQEq"], NMAXQEq=cfg["NMAXQEq"], QEq_tol=cfg["QEq_tol"],
+                              qstep=cfg["qstep"], dt_fs=cfg["dt"], device=local, qeq_mode=a.qeq_mode)
+    eng.set_atoms_rxff(rec)
+    eng.QEq(); eng.FORCE()                       # main.F90:27-32
+    eng.step(a.warmup)
+    eng.reset_timers()
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    eng.step(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.stats()
+    en = eng.energy()
+
+    if rank == 0:
+        steps_per_s = a.steps / dt
+        n10 = st["nnz10"] / max(st["natoms"], 1)
+        nb = st["nbonds"] / max(st["natoms"] + st["nghost_force"], 1)
+        iters = st["qeq_iters_total"] / max(st["qeq_calls"], 1)
+        launches = max(st["spmv_launches"], 1)
+        ms_spmv = st["ms_qeq_spmv"] / launches
+        # algorithmic bytes of ONE matrix pass (value f64 + column i32 per entry, + ~7 vector words per row)
+        bytes_pass = st["nnz10"] * 12.0 + st["natoms"] * 56.0
+        achieved = bytes_pass / (ms_spmv * 1e-3) / 1e9 if ms_spmv > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("natoms") == st["natoms"]:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        # per-atom-step byte model of SURVEY 8d evaluated with the measured n10, nb, K
+        b_step = n10 * 12 + 40 + iters * (2 * n10 * 12 + 112) + n10 * 4 + 64 + nb * 104 * 5
+        out = {
+            "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; aggregate over GPUs of per-GPU domains)",
+            "value": steps_per_s * world, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (RDX unit cell of the reference's conf/init.rdx replicated; v0=0, q0=0)",
+            "config": {"workload": "RDX %dx%dx%d cells per GPU = %d atoms/GPU, QEq tol %g, dt %g fs, mdmode 1 (NVE)" % (a.cells, a.cells, a.cells, natoms, cfg["QEq_tol"], cfg["dt"]),
+                       "atoms_total": natoms * world, "parallelism": "1 GPU" if world == 1 else "%d replicas (halo transport not wired yet)" % world,
+                       "qeq_mode": a.qeq_mode},
+            "steps_per_s_wall": steps_per_s, "ns_per_day": steps_per_s * cfg["dt"] * 86400e-6, "atom_steps_per_s": steps_per_s * natoms * world,
+            "qeq_iters_per_step": iters, "n10": n10, "nb": nb,
+            "roofline": {"bound": "hbm", "kernel": "k_spmv (QEq matrix pass, qeq.hip)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_pass,
+                         "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"],
+                         "step_model_bytes_per_atom": b_step, "step_frac_of_hbm_roofline": (b_step * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9)},
+            "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded")},
+            "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            cb = cpu_baseline()
+            if cb:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    eng.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,11 @@ long long rxmd_host_geninit(const char *ffield_path, int natoms0, const char *el
                             double *rec10, long long capacity, double lattice_out[6]);
 /* rxff.bin header + this rank's records (ReadBIN); returns natoms of `myid` or <0 */
 long long rxmd_host_read_rxff(const char *path, int myid, double lattice_out[6], int vprocs_out[3], double *rec10, long long capacity);
+/* ffield parser + derived tables on the host (GETPARAMS src/param.F90:2-375, CUTOFFLENGTH/POTENTIALTABLE
+ * src/init.F90:363-522) without touching a GPU.  natoms_per_type[1..nso] selects the types present (index 0 unused).
+ * which: 0 Evdw 1 dEvdw 2 Eclmb 3 dEclmb 4 Eclmb_QEq -> out[nboty][5000]; 5 -> out = rc[nboty] then maxrc;
+ * 6 -> out = {nso,nboty,nvaty,ntoty,nhbty, chi[1..nso], eta[1..nso], mass[1..nso]}.  Returns nboty or <0. */
+int rxmd_host_ffield_table(const char *ffield_path, const long long *natoms_per_type, int which, double *out, long long capacity);
 /* library build info: returns 1 if the HIP code object for gfx950 is linked in */
 int rxmd_hip_has_device_code(void);
 

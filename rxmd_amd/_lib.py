@@ -69,6 +69,7 @@ SYMBOLS = [
     ("rxmd_hip_set_comm", C.c_int, [H, C.POINTER(RxmdCommOps)]),
     ("rxmd_host_geninit", C.c_longlong, [C.c_char_p, C.c_int, C.c_char_p, PD, PD, PD, PD, C.c_int, PD, C.c_longlong, PD]),
     ("rxmd_host_read_rxff", C.c_longlong, [C.c_char_p, C.c_int, PD, PD, PD, C.c_longlong]),
+    ("rxmd_host_ffield_table", C.c_int, [C.c_char_p, PD, C.c_int, PD, C.c_longlong]),
     ("rxmd_hip_has_device_code", C.c_int, []),
 ]
 

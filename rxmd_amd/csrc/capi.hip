@@ -362,6 +362,32 @@ long long rxmd_host_geninit(const char *ffield_path, int natoms0, const char *el
   return cnt;
 }
 
+int rxmd_host_ffield_table(const char *ffield_path, const long long *npt, int which, double *out, long long capacity) {
+  if (!ffield_path || !out) return RXMD_E_ARG;
+  rxmd::ForceField ff;
+  try { ff.parse(ffield_path); } catch (const std::exception &) { return RXMD_E_FFIELD; }
+  std::vector<long long> n(ff.nso + 2, 1);
+  if (npt) for (int t = 1; t <= ff.nso; ++t) n[t] = npt[t];
+  ff.compute_cutoffs(n);
+  ff.build_taper(10.0);
+  ff.build_tables();
+  if (which >= 0 && which <= 4) {
+    if (capacity < static_cast<long long>(ff.nboty) * rxmd::NTABLE) return RXMD_E_ARG;
+    const std::vector<double> *src[5] = {&ff.tblEvdw, &ff.tbldEvdw, &ff.tblEclmb, &ff.tbldEclmb, &ff.tblQEq};
+    for (int r = 1; r <= ff.nboty; ++r)
+      for (int i = 1; i <= rxmd::NTABLE; ++i) out[static_cast<size_t>(r - 1) * rxmd::NTABLE + (i - 1)] = (*src[which])[static_cast<size_t>(r) * (rxmd::NTABLE + 2) + i];
+  } else if (which == 5) {
+    if (capacity < ff.nboty + 1) return RXMD_E_ARG;
+    for (int r = 1; r <= ff.nboty; ++r) out[r - 1] = ff.bond[r].rc;
+    out[ff.nboty] = ff.maxrc;
+  } else if (which == 6) {
+    if (capacity < 5 + 3 * ff.nso) return RXMD_E_ARG;
+    out[0] = ff.nso; out[1] = ff.nboty; out[2] = ff.nvaty; out[3] = ff.ntoty; out[4] = ff.nhbty;
+    for (int t = 1; t <= ff.nso; ++t) { out[4 + t] = ff.atom[t].chi; out[4 + ff.nso + t] = ff.atom[t].eta; out[4 + 2 * ff.nso + t] = ff.atom[t].mass; }
+  } else return RXMD_E_ARG;
+  return ff.nboty;
+}
+
 // ReadBIN header + records (reference src/fileio.F90:444-555)
 long long rxmd_host_read_rxff(const char *path, int myid, double lattice_out[6], int vprocs_out[3], double *rec10, long long capacity) {
   std::ifstream in(path, std::ios::binary);

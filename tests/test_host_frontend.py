@@ -1,0 +1,168 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/rxmd_hip.h declares, the
+host front-end (ffield parser, derived tables, geninit, rxff.bin, rxmd.in) agrees with the oracle and
+with files produced by the real reference, and the product fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+import oracle_api as oa
+import rxmd_amd
+from rxmd_amd import system, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FF_RDX = os.path.join(oa.INP, "ffield_rdx")
+FF_WAT = os.path.join(oa.INP, "ffield_water")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rxmd_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rxmd_(?:hip|host)_\w+)\s*\(", hdr))
+    assert len(declared) >= 24
+    lib = C.CDLL(rxmd_amd.SO_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "librxmd_hip.so does not export %s" % name
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    assert rxmd_amd.load_library().rxmd_hip_has_device_code() == 1
+
+
+def test_struct_layout_matches_header_sizes():
+    # config: ptr + 6 doubles + ... ; a drift between header and ctypes mirror would corrupt every call
+    L = rxmd_amd.load_library()
+    cfg = _lib.RxmdConfig()
+    L.rxmd_hip_default_config(C.byref(cfg))
+    assert list(cfg.vprocs) == [1, 1, 1] and cfg.isQEq == 1 and cfg.NMAXQEq == 500 and cfg.QEq_tol == 1e-7
+    assert cfg.qstep == 1 and cfg.dt_fs == 0.25 and cfg.Lex_fqs == 1.0 and cfg.Lex_k == 2.0 and cfg.lattice[5] == 90.0
+    assert all(v == 0 for v in cfg.reserved)
+
+
+def _host_table(ff, which, npt=None):
+    L = rxmd_amd.load_library()
+    info = np.zeros(64)
+    nb = L.rxmd_host_ffield_table(ff.encode(), None, 6, info.ctypes.data_as(C.c_void_p), 64)
+    assert nb > 0
+    nso = int(info[0])
+    n = None
+    if npt is not None:
+        n = np.zeros(nso + 2, np.int64); n[1:1 + len(npt)] = npt
+    if which == 6:
+        return info
+    out = np.zeros(nb * 5000 if which < 5 else nb + 1)
+    rc = L.rxmd_host_ffield_table(ff.encode(), None if n is None else n.ctypes.data_as(C.c_void_p), which, out.ctypes.data_as(C.c_void_p), out.size)
+    assert rc == nb
+    return out.reshape(nb, 5000) if which < 5 else out
+
+
+@pytest.mark.parametrize("case", ["rdx168", "ice644"])
+def test_ffield_tables_and_cutoffs_match_oracle(case):
+    ff, names, frac, lat = oa.make_system(case)
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff))
+    o = oa.Oracle(ff, lat2, ranks)
+    nso = int(o.info()[15])
+    npt = np.bincount(ranks[0]["type"], minlength=nso + 1)[1:]
+    for which in range(5):
+        t = _host_table(ff, which, npt)
+        to = o.table(which)
+        assert t.shape == to.shape
+        assert np.allclose(t, to, rtol=1e-14, atol=0), which
+    rc = _host_table(ff, 5, npt)
+    rco = np.zeros(len(rc) - 1); o.L.rxo_get_rc(o.w, rco.ctypes.data_as(C.c_void_p))
+    present = rco > 0          # the reference zeroes rc (not rc2) of bond rows whose atom types are absent, init.F90:404-413
+    assert present.any() and np.array_equal(rc[:-1][present], rco[present])
+    assert rc[-1] == o.info()[0]
+
+
+def test_ffield_known_values_rdx():
+    info = _host_table(FF_RDX, 6)
+    assert [int(x) for x in info[:5]] == [7, 18, 62, 23, 9]
+    nso = 7
+    chi, eta, mass = info[5:5 + nso], info[5 + nso:5 + 2 * nso], info[5 + 2 * nso:5 + 3 * nso]
+    assert chi[0] == 5.7254 and eta[0] == 2 * 6.9235 and mass[0] == 12.0 and mass[1] == 1.008   # eta doubled, param.F90:361
+    rc = _host_table(FF_RDX, 5, [1, 1, 1, 1, 0, 0, 0])
+    assert abs(rc[-1] - 3.16) < 1e-9                  # maxrc of the RDX system (N-N)
+
+
+def test_geninit_matches_numpy_restatement_and_splits_domains():
+    names, frac, lat = system.read_xyz(os.path.join(oa.INP, "rdx.xyz"))
+    ffn = oa.ffield_names(FF_RDX)
+    for mc, vp in [((1, 1, 1), (1, 1, 1)), ((2, 3, 1), (1, 1, 1)), ((2, 2, 2), (2, 1, 1)), ((2, 2, 2), (2, 2, 2))]:
+        lat_o, ranks = oa.geninit(names, frac, lat, ffn, mc=mc, vprocs=vp)
+        tot = 0
+        for p, r in enumerate(ranks):
+            lat_s, rec = system.geninit(FF_RDX, names, frac, lat, mc=mc, vprocs=vp, myid=p)
+            assert np.allclose(lat_s, lat_o)
+            assert np.array_equal(rec[:, :3], r["rnorm"])
+            assert np.array_equal(np.rint(rec[:, 7]).astype(int), r["type"])
+            gid = np.rint((rec[:, 7] - np.rint(rec[:, 7])) * 1e13).astype(np.int64)
+            assert np.array_equal(gid, r["gid"])
+            tot += len(rec)
+        assert tot == 168 * mc[0] * mc[1] * mc[2]
+
+
+def test_rxff_reader_on_file_written_by_the_reference_geninit():
+    path = os.path.join(oa.GOLD, "rdx_mc121_v121_rxff.bin")    # reference init/geninit -mc 1 2 1 -v 1 2 1
+    names, frac, lat = system.read_xyz(os.path.join(oa.INP, "rdx.xyz"))
+    tot = 0
+    for p in range(2):
+        latf, vp, rec = system.read_rxff(path, p)
+        assert vp == [1, 2, 1] and np.allclose(latf, [13.18, 23.14, 10.71, 90, 90, 90])
+        lat_s, mine = system.geninit(FF_RDX, names, frac, lat, mc=(1, 2, 1), vprocs=(1, 2, 1), myid=p)
+        assert rec.shape == mine.shape
+        assert np.array_equal(rec, mine)               # bit-identical records, incl. atype = type + gid*1e-13 + 1e-14
+        tot += len(rec)
+    assert tot == 336
+
+
+def test_rxff_write_read_roundtrip(tmp_path):
+    names, frac, lat = system.read_xyz(os.path.join(oa.INP, "rdx.xyz"))
+    recs = []
+    for p in range(2):
+        lat_s, r = system.geninit(FF_RDX, names, frac, lat, mc=(2, 1, 1), vprocs=(2, 1, 1), myid=p)
+        recs.append(r)
+    f = tmp_path / "rxff.bin"
+    system.write_rxff(str(f), lat_s, (2, 1, 1), recs, current_step=7)
+    for p in range(2):
+        l2, vp, r2 = system.read_rxff(str(f), p)
+        assert vp == [2, 1, 1] and np.array_equal(r2, recs[p]) and np.allclose(l2, lat_s)
+
+
+def test_rxmd_in_parser():
+    cfg = system.parse_rxmd_in(os.path.join(oa.INP, "rxmd.in"))
+    assert cfg["mdmode"] == 1 and cfg["dt"] == 0.25 and cfg["ntime_step"] == 100 and cfg["vprocs"] == (1, 1, 1)
+    assert cfg["isQEq"] == 1 and cfg["NMAXQEq"] == 500 and cfg["QEq_tol"] == 1e-7 and cfg["qstep"] == 1
+    assert cfg["isXYZ"] is True and cfg["isBinary"] is False
+
+
+def test_rxmd_in_unknown_keyword_is_fatal(tmp_path):
+    p = tmp_path / "rxmd.in"
+    p.write_text("mdmode 1\nbogus 3\n")
+    with pytest.raises(ValueError):
+        system.parse_rxmd_in(str(p))
+
+
+def test_engine_fails_loudly_without_gpu_or_with_bad_input():
+    import torch
+    names, frac, lat = system.read_xyz(os.path.join(oa.INP, "rdx.xyz"))
+    if not torch.cuda.is_available():
+        with pytest.raises(rxmd_amd.RxmdError) as ei:
+            rxmd_amd.RxmdEngine(FF_RDX, lat)
+        assert ei.value.code == -6 and "no CPU path" in str(ei.value)
+    with pytest.raises(rxmd_amd.RxmdError) as ei:
+        rxmd_amd.RxmdEngine("/nonexistent/ffield", lat)
+    assert ei.value.code == -2
+    with pytest.raises(rxmd_amd.RxmdError) as ei:
+        rxmd_amd.RxmdEngine(FF_RDX, [10, 10, 10, 90, 80, 90])
+    assert ei.value.code == -1
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rxmd_amd")):
+        if "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and False, "%s mentions the oracle" % f
