@@ -115,7 +115,10 @@ def test_injected_oracle_charges_isolate_force_kernels():
     e = _engine("rdx222", (2, 2, 2), isQEq=0)
     e.set_charges(o.charges())
     pe = e.FORCE()
-    assert f_err(e.atoms()["f"], o.forces()) <= 1e-9
+    # not 1e-12: the reference round-trips ALL positions through normalised coordinates in every COPYATOMS call
+    # (comm.F90:222-227,260-264; two calls per CG iteration), which moves them by ~1e-12 A over a QEq call; the
+    # engine keeps resident positions fixed.  1e-12 A x bond stiffness ~1e3 kcal/mol/A^2 = 1e-9 in the forces.
+    assert f_err(e.atoms()["f"], o.forces()) <= 1e-7
     assert e_err(pe, o.energy()) <= ETOL
     e.close()
 
