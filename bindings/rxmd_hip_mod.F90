@@ -1,0 +1,166 @@
+!> rxmd_hip_mod -- iso_c_binding interface of the MI355X ReaxFF+QEq engine (include/rxmd_hip.h) and
+!> drop-in replacements for the reference's three entry points of the hot path:
+!>
+!>     QEq(atype,pos,q)      USCCACS/RXMD src/qeq.F90:2      ->  QEq_hip
+!>     FORCE(atype,pos,f,q)  USCCACS/RXMD src/pot.F90:2      ->  FORCE_hip
+!>     MD loop body          USCCACS/RXMD src/main.F90:64-98 ->  rxmd_hip_step (device resident)
+!>
+!> The wrappers take the SAME arguments as the reference subroutines (atype(NBUFFER) packed
+!> type+gid*1e-13, pos/f(NBUFFER,3) column major, q(NBUFFER)), so `call QEq(atype,pos,q)` in
+!> main.F90:30,81 becomes `call QEq_hip(atype,pos,q)` and nothing else changes in the driver.
+!> Build:  amdflang -c bindings/rxmd_hip_mod.F90 ; link with -L rxmd_amd -lrxmd_hip
+module rxmd_hip_mod
+  use iso_c_binding
+  implicit none
+  private
+  public :: rxmd_config, rxmd_hip_init, rxmd_hip_finalize, QEq_hip, FORCE_hip, rxmd_hip_handle
+  public :: rxmd_hip_create, rxmd_hip_destroy, rxmd_hip_qeq, rxmd_hip_force, rxmd_hip_step, rxmd_hip_set_atoms_rxff, &
+            rxmd_hip_get_atoms_rxff, rxmd_hip_last_error, rxmd_hip_default_config, rxmd_hip_qeq_arrays, rxmd_hip_force_arrays
+
+  !> mirrors `struct rxmd_config` (include/rxmd_hip.h)
+  type, bind(c) :: rxmd_config
+     type(c_ptr)    :: ffield_path
+     real(c_double) :: lattice(6)
+     integer(c_int) :: vprocs(3)
+     integer(c_int) :: myid
+     integer(c_int) :: isQEq
+     integer(c_int) :: NMAXQEq
+     real(c_double) :: QEq_tol
+     integer(c_int) :: qstep
+     real(c_double) :: dt_fs
+     real(c_double) :: Lex_fqs, Lex_k
+     integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode
+     integer(c_int) :: reserved(7)
+  end type
+
+  type(c_ptr), save :: rxmd_hip_handle = c_null_ptr
+
+  interface
+     subroutine rxmd_hip_default_config(cfg) bind(c, name='rxmd_hip_default_config')
+       import :: rxmd_config
+       type(rxmd_config), intent(out) :: cfg
+     end subroutine
+     integer(c_int) function rxmd_hip_create(cfg, h) bind(c, name='rxmd_hip_create')
+       import :: rxmd_config, c_ptr, c_int
+       type(rxmd_config), intent(in) :: cfg
+       type(c_ptr), intent(out) :: h
+     end function
+     integer(c_int) function rxmd_hip_destroy(h) bind(c, name='rxmd_hip_destroy')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+     end function
+     type(c_ptr) function rxmd_hip_last_error(h) bind(c, name='rxmd_hip_last_error')
+       import :: c_ptr
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function rxmd_hip_set_atoms_rxff(h, natoms, rec10) bind(c, name='rxmd_hip_set_atoms_rxff')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: natoms
+       real(c_double), intent(in) :: rec10(*)
+     end function
+     integer(c_int) function rxmd_hip_get_atoms_rxff(h, rec10, capacity) bind(c, name='rxmd_hip_get_atoms_rxff')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(out) :: rec10(*)
+       integer(c_int), value :: capacity
+     end function
+     integer(c_int) function rxmd_hip_qeq(h, iters, est) bind(c, name='rxmd_hip_qeq')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), intent(out) :: iters
+       real(c_double), intent(out) :: est
+     end function
+     integer(c_int) function rxmd_hip_force(h, pe) bind(c, name='rxmd_hip_force')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(out) :: pe(0:13)
+     end function
+     integer(c_int) function rxmd_hip_step(h, nsteps) bind(c, name='rxmd_hip_step')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: nsteps
+     end function
+     integer(c_int) function rxmd_hip_qeq_arrays(h, nbuffer, natoms, atype, pos, q) bind(c, name='rxmd_hip_QEq')   ! Fortran is case-blind
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: nbuffer, natoms
+       real(c_double), intent(in) :: atype(*), pos(*)
+       real(c_double), intent(inout) :: q(*)
+     end function
+     integer(c_int) function rxmd_hip_force_arrays(h, nbuffer, natoms, atype, pos, f, q, pe) bind(c, name='rxmd_hip_FORCE')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: nbuffer, natoms
+       real(c_double), intent(in) :: atype(*), pos(*), q(*)
+       real(c_double), intent(out) :: f(*), pe(0:13)
+     end function
+  end interface
+
+contains
+
+  !> call once after GETPARAMS/INITSYSTEM (reference src/main.F90:20-23) with the module-global run parameters
+  subroutine rxmd_hip_init(ffpath, lata, latb, latc, lalpha, lbeta, lgamma, vprocs, myid, isQEq, NMAXQEq, QEq_tol, qstep, dt_fs, device)
+    character(len=*), intent(in) :: ffpath
+    real(8), intent(in) :: lata, latb, latc, lalpha, lbeta, lgamma, QEq_tol, dt_fs
+    integer, intent(in) :: vprocs(3), myid, isQEq, NMAXQEq, qstep, device
+    type(rxmd_config) :: cfg
+    character(kind=c_char, len=:), allocatable, target, save :: cpath
+    integer(c_int) :: rc
+    call rxmd_hip_default_config(cfg)
+    cpath = trim(ffpath)//c_null_char
+    cfg%ffield_path = c_loc(cpath)
+    cfg%lattice = (/lata, latb, latc, lalpha, lbeta, lgamma/)
+    cfg%vprocs = vprocs; cfg%myid = myid
+    cfg%isQEq = isQEq; cfg%NMAXQEq = NMAXQEq; cfg%QEq_tol = QEq_tol; cfg%qstep = qstep; cfg%dt_fs = dt_fs
+    cfg%device = device
+    rc = rxmd_hip_create(cfg, rxmd_hip_handle)
+    if (rc /= 0) call die('rxmd_hip_create', rc)
+  end subroutine
+
+  subroutine rxmd_hip_finalize()
+    integer(c_int) :: rc
+    if (c_associated(rxmd_hip_handle)) rc = rxmd_hip_destroy(rxmd_hip_handle)
+    rxmd_hip_handle = c_null_ptr
+  end subroutine
+
+  !> same arguments as the reference's QEq(atype,pos,q), src/qeq.F90:2,15-16
+  subroutine QEq_hip(atype, pos, q)
+    use atoms, only: NBUFFER, NATOMS
+    real(8), intent(in) :: atype(NBUFFER), pos(NBUFFER,3)
+    real(8), intent(inout) :: q(NBUFFER)
+    integer(c_int) :: rc
+    rc = rxmd_hip_qeq_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, q)
+    if (rc /= 0) call die('QEq', rc)
+  end subroutine
+
+  !> same arguments as the reference's FORCE(atype,pos,f,q), src/pot.F90:2,9-11; fills PE(0:13) of module atoms
+  subroutine FORCE_hip(atype, pos, f, q)
+    use atoms, only: NBUFFER, NATOMS, PE
+    real(8), intent(in) :: atype(NBUFFER), q(NBUFFER), pos(NBUFFER,3)
+    real(8), intent(inout) :: f(NBUFFER,3)
+    integer(c_int) :: rc
+    rc = rxmd_hip_force_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, f, q, PE)
+    if (rc /= 0) call die('FORCE', rc)
+  end subroutine
+
+  !> the reference's error behaviour: message on unit 6, then stop (src/main.F90:402-407)
+  subroutine die(where, rc)
+    character(len=*), intent(in) :: where
+    integer(c_int), intent(in) :: rc
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: n
+    p = rxmd_hip_last_error(rxmd_hip_handle)
+    if (c_associated(p)) then
+       call c_f_pointer(p, msg, (/512/))
+       n = 1
+       do while (n < 512 .and. msg(n) /= c_null_char); n = n + 1; end do
+       write(6,'(a,a,a,i4,a,512a1)') 'ERROR in ', where, ' (rxmd_hip code', rc, '): ', msg(1:n-1)
+    else
+       write(6,'(a,a,a,i4,a)') 'ERROR in ', where, ' (rxmd_hip code', rc, ')'
+    endif
+    stop 1
+  end subroutine
+
+end module rxmd_hip_mod

@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_ebond_elnpr(int N, int NB, DevFF ff, co
                                                       const long long *__restrict__ gid, const double *__restrict__ bo0, const double *__restrict__ bo1,
                                                       const double *__restrict__ bo2, const double *__restrict__ bo3, const double *__restrict__ delta,
                                                       const double *__restrict__ deltalp, const double *__restrict__ dDlp,
-                                                      double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn, double *__restrict__ pe) {
+                                                      double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn, double *__restrict__ ecoa, double *__restrict__ pe) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double e1 = 0.0, e2 = 0.0, e3 = 0.0, e4 = 0.0;
   if (i < N) {
@@ -76,6 +76,10 @@ __global__ void __launch_bounds__(256) k_ebond_elnpr(int N, int NB, DevFF ff, co
       const DevBondP bp = ff.bond[ff.inxn2[ti * ff.n1 + type[j]]];
       sum_ovun1 += bp.povun1 * bp.Desig * bo0[o];                         // pot.F90:223
       sum_ovun2 += (delta[j] - deltalp[j]) * (bo2[o] + bo3[o]);           // pot.F90:224
+      {                                                                   // exp_coa3 * exp_coa4 of this bond as seen from i (pot.F90:484-487)
+        const double bs = bo0[o] - cutof2_esub, u = -bs + (delta[j] + ff.atom[type[j]].Val);
+        ecoa[o] = exp(-ff.pcoa3 * (u * u)) * exp(-ff.pcoa4 * ((bs - 1.5) * (bs - 1.5)));
+      }
       if (gid[j] < iid) {                                                 // Ebond, pot.F90:949
         const double B1 = bo1[o];
         const double pw = pow(B1, bp.pbe2);
@@ -129,6 +133,7 @@ __global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int 
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
                                               const double *__restrict__ delta, const double *__restrict__ nlp, const double *__restrict__ dDlp,
+                                              const double *__restrict__ epen, const double *__restrict__ ecoa,
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
@@ -149,6 +154,14 @@ __global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int 
     const double dlj = delta[j];
     const double delta_ang = dlj + aj.Val - aj.Valangle;
     const double nlpj = nlp[j], dDj = dDlp[j];
+    // per-centre factors of the penalty and conjugation terms (global parameters, pot.F90:460-462,481-483)
+    const double exp_pen3 = exp(-ff.ppen3 * dlj), exp_pen4 = exp(ff.ppen4 * dlj);
+    const double trm34 = 1.0 + exp_pen3 + exp_pen4;
+    const double fn9 = (2.0 + exp_pen3) / trm34;
+    const double Cf9j = (-ff.ppen3 * exp_pen3 * trm34 - (2.0 + exp_pen3) * (-ff.ppen3 * exp_pen3 + ff.ppen4 * exp_pen4)) / (trm34 * trm34);
+    const double delta_val = dlj + aj.Val - aj.Valval;
+    const double exp_coa2 = exp(ff.pcoa2 * delta_val);
+    const double exp6 = exp(ff.pval6 * delta_ang);
     // sums over all angles of the terms that ForceBbo(j,n1,...) applies to EVERY bond of j (pot.F90:526-532)
     double S_d1 = 0.0, S_v6 = 0.0, S_v5 = 0.0;
     V3 fself = {0.0, 0.0, 0.0};
@@ -176,7 +189,7 @@ __global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int 
         const double theta_ijk = acos(cos_ijk), sin_ijk = sin(theta_ijk);
         const double BOij_p4 = pow(BOij, ap.pval4), exp3ij = exp(-aj.pval3 * BOij_p4), fn7ij = 1.0 - exp3ij;
         const double BOjk_p4 = pow(BOjk, ap.pval4), exp3jk = exp(-aj.pval3 * BOjk_p4), fn7jk = 1.0 - exp3jk;
-        const double exp6 = exp(ff.pval6 * delta_ang), exp7 = exp(-ap.pval7 * delta_ang), trm8 = 1.0 + exp6 + exp7;
+        const double exp7 = exp(-ap.pval7 * delta_ang), trm8 = 1.0 + exp6 + exp7;
         const double fn8j = aj.pval5 - (aj.pval5 - 1.0) * (2.0 + exp6) / trm8;
         const double SBO = sum_SBO1 + (1.0 - prod_SBO) * (-delta_ang - ff.pval8 * nlpj);
         double SBO2 = 0.0, CSBO2 = 0.0;
@@ -201,20 +214,13 @@ __global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int 
         const double CEval5 = CEval4 * Ctheta0 * CSBO2;
         const double CEval6 = CEval5 * dSBO1, CEval7 = CEval5 * dSBO2, CEval8 = CEval4 / sin_ijk;
         // penalty, pot.F90:460-476
-        const double exp_pen3 = exp(-ff.ppen3 * dlj), exp_pen4 = exp(ff.ppen4 * dlj);
-        const double trm34 = 1.0 + exp_pen3 + exp_pen4;
-        const double fn9 = (2.0 + exp_pen3) / trm34;
-        const double PEpen = ap.ppen1 * fn9 * exp(-ff.ppen2 * (BOij - 2.0) * (BOij - 2.0)) * exp(-ff.ppen2 * (BOjk - 2.0) * (BOjk - 2.0));
+        const double PEpen = ap.ppen1 * fn9 * epen[oi] * epen[ok];
         e6 += PEpen;
-        const double Cf9j = (-ff.ppen3 * exp_pen3 * trm34 - (2.0 + exp_pen3) * (-ff.ppen3 * exp_pen3 + ff.ppen4 * exp_pen4)) / (trm34 * trm34);
         const double CEpen1 = Cf9j / fn9 * PEpen, CEpen2 = -2.0 * ff.ppen2 * (BOij - 2.0) * PEpen, CEpen3 = -2.0 * ff.ppen2 * (BOjk - 2.0) * PEpen;
         // three-body conjugation, pot.F90:479-497
         const double sum_BOi = delta[i] + ff.atom[ti].Val, sum_BOk = delta[k] + ff.atom[tk].Val;
-        const double delta_val = dlj + aj.Val - aj.Valval;
-        const double exp_coa2 = exp(ff.pcoa2 * delta_val);
         const double ui = -BOij + sum_BOi, uk = -BOjk + sum_BOk;
-        const double PEcoa = ap.pcoa1 / (1.0 + exp_coa2) * exp(-ff.pcoa3 * (ui * ui)) * exp(-ff.pcoa3 * (uk * uk)) *
-                             exp(-ff.pcoa4 * ((BOij - 1.5) * (BOij - 1.5))) * exp(-ff.pcoa4 * ((BOjk - 1.5) * (BOjk - 1.5)));
+        const double PEcoa = ap.pcoa1 / (1.0 + exp_coa2) * ecoa[oi] * ecoa[ok];
         e7 += PEcoa;
         const double CEcoa1 = -2.0 * ff.pcoa4 * (BOij - 1.5) * PEcoa, CEcoa2 = -2.0 * ff.pcoa4 * (BOjk - 1.5) * PEcoa;
         const double CEcoa3 = -ff.pcoa2 * exp_coa2 / (1.0 + exp_coa2) * PEcoa;
@@ -250,6 +256,7 @@ __global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int 
 __global__ void __launch_bounds__(128) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
+                                              const double *__restrict__ etor, const double *__restrict__ econ,
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
@@ -275,6 +282,13 @@ __global__ void __launch_bounds__(128) k_e4b(int N, int NB, DevFF ff, const int 
       const V3 rjk = {xj - x[k], yj - y[k], zj - z[k]};
       const double njk = sqrt(dot(rjk, rjk));
       const double bo2jk = bo2[ok];
+      // factors of the centre bond j-k, shared by every torsion around it (pot.F90:1087,1090-1095)
+      const double et2 = etor[ok], ec2 = econ[ok];
+      const double exp_tor3 = exp(-ff.ptor3 * delta_ang_jk), exp_tor4 = exp(ff.ptor4 * delta_ang_jk);
+      const double exp_tor34_i = 1.0 / (1.0 + exp_tor3 + exp_tor4);
+      const double fn11 = (2.0 + exp_tor3) * exp_tor34_i;
+      const double dfn11 = (-ff.ptor3 * exp_tor3 + (ff.ptor3 * exp_tor3 - ff.ptor4 * exp_tor4) * (2.0 + exp_tor3) * exp_tor34_i) * exp_tor34_i;
+      const double btb2 = 2.0 - bo2jk - fn11;
       double cf1_jk = 0.0, cf2_jk = 0.0, cd_k = 0.0;
       V3 fk_unused = {0, 0, 0}; (void)fk_unused;
       for (int i1 = 0; i1 < nj; ++i1) {
@@ -297,6 +311,7 @@ __global__ void __launch_bounds__(128) k_e4b(int N, int NB, DevFF ff, const int 
         const V3 c1v = {n1v.y * n2v.z - n1v.z * n2v.y, n1v.z * n2v.x - n1v.x * n2v.z, n1v.x * n2v.y - n1v.y * n2v.x};
         double nc1 = sqrt(dot(c1v, c1v));
         if (nc1 < NSMALL) nc1 = NSMALL;
+        const double et1 = etor[oi], ec1 = econ[oi];
         double cf1_ij = 0.0;
         V3 fi_acc = {0.0, 0.0, 0.0};
         for (int l1 = 0; l1 < nk; ++l1) {
@@ -312,13 +327,9 @@ __global__ void __launch_bounds__(128) k_e4b(int N, int NB, DevFF ff, const int 
           const double BOkl = BOkl_f - cutof2_esub;
           const V3 rkl = {x[k] - x[l], y[k] - y[l], z[k] - z[l]};
           const double nkl = sqrt(dot(rkl, rkl));
-          const double et1 = exp(-ff.ptor2 * BOij), et2 = exp(-ff.ptor2 * BOjk), et3 = exp(-ff.ptor2 * BOkl);
-          const double exp_tor3 = exp(-ff.ptor3 * delta_ang_jk), exp_tor4 = exp(ff.ptor4 * delta_ang_jk);
-          const double exp_tor34_i = 1.0 / (1.0 + exp_tor3 + exp_tor4);
+          const double et3 = etor[ol];
           const double fn10 = (1.0 - et1) * (1.0 - et2) * (1.0 - et3);
-          const double fn11 = (2.0 + exp_tor3) * exp_tor34_i;
-          const double fn12 = exp(-ff.pcot2 * ((BOij - 1.5) * (BOij - 1.5) + (BOjk - 1.5) * (BOjk - 1.5) + (BOkl - 1.5) * (BOkl - 1.5)));
-          const double btb2 = 2.0 - bo2jk - fn11;
+          const double fn12 = ec1 * ec2 * econ[ol];
           const double exp_tor1 = exp(tp.ptor1 * (btb2 * btb2));
           double cos_jkl = -dot(rjk, rkl) / (njk * nkl);
           if (cos_jkl > MAXANGLE) cos_jkl = MAXANGLE;
@@ -341,7 +352,6 @@ __global__ void __launch_bounds__(128) k_e4b(int N, int NB, DevFF ff, const int 
           if (own) { e8 += 0.5 * fn10 * ss * vsum; e9 += PEconj; }
           const double CEt1 = 0.5 * ss * vsum;
           const double CEt2 = -tp.ptor1 * fn10 * ss * tp.V2 * exp_tor1 * btb2 * c2;
-          const double dfn11 = (-ff.ptor3 * exp_tor3 + (ff.ptor3 * exp_tor3 - ff.ptor4 * exp_tor4) * (2.0 + exp_tor3) * exp_tor34_i) * exp_tor34_i;
           const double CEt3 = CEt2 * dfn11;
           const double CEt4 = CEt1 * ff.ptor2 * et1 * (1.0 - et2) * (1.0 - et3);
           const double CEt5 = CEt1 * ff.ptor2 * (1.0 - et1) * et2 * (1.0 - et3);
@@ -401,6 +411,7 @@ __global__ void __launch_bounds__(128) k_e4b(int N, int NB, DevFF ff, const int 
 __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10,
+                                              const double4 *__restrict__ pk, const int *__restrict__ perm,
                                               double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
   const int lane = threadIdx.x & 63;
@@ -425,13 +436,17 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
         double cfs = 0.0, nterm = 0.0;
         V3 fi_s = {0, 0, 0}, fj_s = {0, 0, 0};
         for (int kk = lane; kk < n; kk += 64) {
-          const int k = nb10[row + kk];
-          const int inx = ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + type[k]];
-          if (k == j || k == i || inx == 0) continue;
-          const V3 rik = {xi - x[k], yi - y[k], zi - z[k]};
+          const unsigned ent = static_cast<unsigned>(nb10[row + kk]);
+          const int inx = ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + static_cast<int>((ent >> NB10_IDX_BITS) & 15u)];
+          if (inx == 0) continue;
+          const int ks = static_cast<int>(ent & NB10_IDX_MASK);
+          const int k = perm[ks];                                          // list entries are cell-sorted positions
+          if (k == j || k == i) continue;
+          const double4 pk_ = pk[ks];
+          const V3 rik = {xi - pk_.x, yi - pk_.y, zi - pk_.z};
           if (!(dot(rik, rik) < 100.0)) continue;                          // rchb2, pot.F90:610
           const DevHbP hp = ff.hb[inx];
-          const V3 rjk = {x[j] - x[k], y[j] - y[k], z[j] - z[k]};
+          const V3 rjk = {x[j] - pk_.x, y[j] - pk_.y, z[j] - pk_.z};
           const double njk = sqrt(dot(rjk, rjk));
           double cos_ijk = -dot(rij, rjk) / (nij * njk);
           if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
@@ -468,12 +483,12 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
 
 void Engine::bonded_energies() {
   double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
-  k_ebond_elnpr<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, dDlp, cf1, cf2, cf3, cdn, pe_d);
-  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+  k_ebond_elnpr<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, dDlp, cf1, cf2, cf3, cdn, ecoa, pe_d);
+  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
-  k_e4b<<<nblk(N, 128), 128, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, cf1, cf2, cdn, fnx, fny, fnz,
+  k_e4b<<<nblk(N, 128), 128, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
-  k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
+  k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
 }
 
 }  // namespace rxmd

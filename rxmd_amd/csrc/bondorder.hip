@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) k_bo_full(int G, int NB, DevFF ff, const 
                                                   double *__restrict__ A0, double *__restrict__ A1, double *__restrict__ A2, double *__restrict__ A3,
                                                   double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                                   double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
+                                                  double *__restrict__ etor, double *__restrict__ econ, double *__restrict__ epen,
                                                   double *__restrict__ delta, double *__restrict__ nlp, double *__restrict__ dDlp, double *__restrict__ deltalp, double *__restrict__ cds,
                                                   double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,6 +105,11 @@ __global__ void __launch_bounds__(256) k_bo_full(int G, int NB, DevFF ff, const 
     A2[o] = a2v;
     A3[o] = a2v + Cf1i_div1;
     cf1[o] = 0.0; cf2[o] = 0.0; cf3[o] = 0.0; cdn[o] = 0.0; fnx[o] = 0.0; fny[o] = 0.0; fnz[o] = 0.0;
+    // exponentials of this bond that every angle / torsion through it re-uses (global parameters only):
+    const double bs = B0 - 1e-4;                                   // BO - cutof2_esub, pot.F90:372,1022
+    etor[o] = exp(-ff.ptor2 * bs);                                 // exp_tor2, pot.F90:1086-1088
+    econ[o] = exp(-ff.pcot2 * ((bs - 1.5) * (bs - 1.5)));          // factor of fn12, pot.F90:1097-1099
+    epen[o] = exp(-ff.ppen2 * ((bs - 2.0) * (bs - 2.0)));          // exp_pen2, pot.F90:463-464
     sum += B0;
   }
   const double dl = -ai.Val + sum;                     // bo.F90:294
@@ -122,7 +128,7 @@ __global__ void __launch_bounds__(256) k_bo_full(int G, int NB, DevFF ff, const 
 
 void Engine::bond_orders() {
   k_bo_prime<<<nblk(G, 256), 256, 0, stream>>>(G, NB, dff, nbr, nbrcnt, pos[0], pos[1], pos[2], type, bo0, bo2, bo3, dln2, dln3, dBOp, deltap);
-  k_bo_full<<<nblk(G, 256), 256, 0, stream>>>(G, NB, dff, nbr, nbrcnt, type, deltap, bo0, bo1, bo2, bo3, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+  k_bo_full<<<nblk(G, 256), 256, 0, stream>>>(G, NB, dff, nbr, nbrcnt, type, deltap, bo0, bo1, bo2, bo3, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen,
                                               delta, nlp, dDlp, deltalp, cds, frc[0], frc[1], frc[2]);
 }
 

@@ -12,6 +12,7 @@
 
 #include "engine.h"
 
+namespace rxmd { double stream_probe_ms(Engine &e, int blocks); }
 using rxmd::Engine;
 using rxmd::EngineError;
 
@@ -304,6 +305,12 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
       }
       case 8: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.cd, G, 1, 0); break;
       case 9: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.q, G, 1, 0); break;
+      case 100: {   // read-bandwidth probe over the whole value array: out = {ms, bytes} for a few grid sizes
+        n = 4; if (capacity < 8) throw EngineError(RXMD_E_ARG, "capacity");
+        const int grids[4] = {2048, 8192, 32768, 131072};
+        for (int g = 0; g < 4; ++g) { out[2 * g] = rxmd::stream_probe_ms(e, grids[g]); out[2 * g + 1] = static_cast<double>(e.rows10) * e.S10 * 8.0; }
+        n = 8; break;
+      }
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");
     }
   });

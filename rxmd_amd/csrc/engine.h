@@ -41,7 +41,9 @@ struct DevBondP {
 struct DevAngleP { double theta00, pval1, pval2, pcoa1, pval7, ppen1, pval4; };
 struct DevTorsP { double V1, V2, V3, ptor1, pcot1; };
 struct DevHbP { double r0hb, phb1, phb2, phb3; };
-struct DevNBTab { double Evdw, dEvdw, Eclmb, dEclmb; };  // one r^2-table node, 32 bytes
+// one r^2-table node, 64 bytes = one cache-line half: value and (next - this) for the four tabulated functions,
+// so that an interpolation touches ONE node:  f(r2) = v + t * d   (reference lerp, pot.F90:729-743)
+struct DevNBTab { double Evdw, dEvdw_, CEvdw, dCEvdw_, Eclmb, dEclmb_, CEclmb, dCEclmb_; };
 
 struct DevFF {
   int nso, n1, nboty;
@@ -97,6 +99,8 @@ struct Engine {
   int *type = nullptr; long long *gid = nullptr;
   double2 *qst = nullptr, *hst = nullptr, *gst = nullptr;  // (qs,qt) (hs,ht) (gs,gt) interleaved
   int *gsrc = nullptr, *groot = nullptr;                    // ghost -> source index on sender ; -> resident root (self exchange)
+  int *rootperm = nullptr;                                  // cell-sorted position -> resident that owns the value (ghosts resolved)
+  double2 *xs = nullptr;                                    // cell-sorted gather copy of a QEq vector pair (residents+ghosts)
   int *sendidx = nullptr; int sendoff[8] = {0};             // per-stage send index lists (local indices), concatenated
   // cell binning
   int *cellid = nullptr, *cellid_sorted = nullptr, *perm = nullptr, *perm_in = nullptr, *cellstart = nullptr;
@@ -108,6 +112,7 @@ struct Engine {
   double *bo0 = nullptr, *bo1 = nullptr, *bo2 = nullptr, *bo3 = nullptr, *dln2 = nullptr, *dln3 = nullptr, *dBOp = nullptr;
   double *A0 = nullptr, *A1 = nullptr, *A2 = nullptr, *A3 = nullptr;
   double *cf1 = nullptr, *cf2 = nullptr, *cf3 = nullptr, *cdn = nullptr, *fnx = nullptr, *fny = nullptr, *fnz = nullptr;
+  double *etor = nullptr, *econ = nullptr, *epen = nullptr, *ecoa = nullptr;   // per-bond exponentials shared by many angles/torsions
   double *deltap = nullptr, *delta = nullptr, *nlp = nullptr, *dDlp = nullptr, *deltalp = nullptr;
   double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
   // 10 A list
@@ -147,6 +152,7 @@ struct Engine {
   void build_bonded_list();
   void build_list10();
   void halo_refresh(double2 *v2, double *v1);       // QCOPY1/QCOPY2: ghosts <- owners
+  void sorted_copy(const double2 *v);               // QCOPY1/QCOPY2 fused with the cell-sorted gather copy -> xs
   void fold_ghost_forces();                         // CPBK
   void bond_orders();
   void bonded_energies();
@@ -157,6 +163,11 @@ struct Engine {
   void tic(int k) { hipEventRecord(ev[k], stream); }
   double toc(int k0, int k1) { hipEventRecord(ev[k1], stream); hipEventSynchronize(ev[k1]); float ms = 0; hipEventElapsedTime(&ms, ev[k0], ev[k1]); return ms; }
 };
+
+// 10 A list entry: bits 0-25 cell-sorted position of the partner, 26-29 its atom type, 30 ghost, 31 periodic self image
+constexpr int NB10_IDX_BITS = 26;
+constexpr unsigned NB10_IDX_MASK = (1u << NB10_IDX_BITS) - 1u;
+constexpr unsigned NB10_GHOST = 1u << 30, NB10_SELF = 1u << 31;
 
 // device error codes written by kernels into Engine::d_err
 enum { DERR_NONE = 0, DERR_MAXNB = 1, DERR_MAXN10 = 2, DERR_GRID = 3, DERR_NBRINDX = 4 };

@@ -148,7 +148,10 @@ void Engine::upload_ff() {
   for (int r = 1; r <= ff.nhbty; ++r) { const auto &s = ff.hb[r]; hb[r] = {s.r0hb, s.phb1, s.phb2, s.phb3}; }
   const size_t stride = NTABLE + 2;
   std::vector<DevNBTab> nb((ff.nboty + 1) * stride);
-  for (size_t i = 0; i < nb.size(); ++i) nb[i] = {ff.tblEvdw[i], ff.tbldEvdw[i], ff.tblEclmb[i], ff.tbldEclmb[i]};
+  for (size_t i = 0; i + 1 < nb.size(); ++i)
+    nb[i] = {ff.tblEvdw[i], ff.tblEvdw[i + 1] - ff.tblEvdw[i], ff.tbldEvdw[i], ff.tbldEvdw[i + 1] - ff.tbldEvdw[i],
+             ff.tblEclmb[i], ff.tblEclmb[i + 1] - ff.tblEclmb[i], ff.tbldEclmb[i], ff.tbldEclmb[i + 1] - ff.tbldEclmb[i]};
+  nb.back() = DevNBTab{};
 
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
   size_t off[12], tot = 0;
@@ -179,16 +182,17 @@ void Engine::alloc_device() {
   for (int a = 0; a < 3; ++a) { dmalloc(pos[a], nb); dmalloc(vel[a], nb); dmalloc(frc[a], nb); dmalloc(spos[a], nb); }
   dmalloc(q, nb); dmalloc(qsfp, nb); dmalloc(qsfv, nb); dmalloc(type, nb); dmalloc(gid, nb);
   dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb);
-  dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb);
+  dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.ncell) + 2);
   dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1);
   dmalloc(nbr, ns); dmalloc(nbrcnt, nb); dmalloc(nbrindx, ns);
   dmalloc(bo0, ns); dmalloc(bo1, ns); dmalloc(bo2, ns); dmalloc(bo3, ns); dmalloc(dln2, ns); dmalloc(dln3, ns); dmalloc(dBOp, ns);
   dmalloc(A0, ns); dmalloc(A1, ns); dmalloc(A2, ns); dmalloc(A3, ns);
   dmalloc(cf1, ns); dmalloc(cf2, ns); dmalloc(cf3, ns); dmalloc(cdn, ns); dmalloc(fnx, ns); dmalloc(fny, ns); dmalloc(fnz, ns);
+  dmalloc(etor, ns); dmalloc(econ, ns); dmalloc(epen, ns); dmalloc(ecoa, ns);
   dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
   dmalloc(nb10, static_cast<size_t>(rows10) * S10); dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
-  dmalloc(partials, size_t(4096) * 16); dmalloc(scal, 64);
+  dmalloc(partials, std::max<size_t>(size_t(1) << 16, static_cast<size_t>(rows10) + 16384)); dmalloc(scal, 64);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
   dmalloc(d_err, 4);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 4 * sizeof(int)));
@@ -203,10 +207,10 @@ void Engine::alloc_device() {
 void Engine::free_device() {
   for (int a = 0; a < 3; ++a) { dfree(pos[a]); dfree(vel[a]); dfree(frc[a]); dfree(spos[a]); }
   dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst);
-  dfree(gsrc); dfree(groot); dfree(sendidx); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
+  dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(xs); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
   dfree(sorted_xyzi); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
   dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
-  dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz);
+  dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   dfree(xbuf_send); dfree(xbuf_recv);
@@ -254,6 +258,8 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
     int s10 = cfg.maxneighbs10 > 0 ? cfg.maxneighbs10 : static_cast<int>(est10 * 1.35 + 64);
     S10 = (s10 + 63) / 64 * 64;
     rows10 = std::min<long long>(NB, static_cast<long long>(natoms) + natoms / 8 + 1024);
+    if (ff.nso > 15) throw EngineError(RXMD_E_ARG, "more than 15 atom types do not fit the packed 10 A list entry");
+    if (NB >= (1 << NB10_IDX_BITS)) throw EngineError(RXMD_E_NBUFFER, "more than 2^26 atoms+ghosts per GPU do not fit the packed 10 A list entry");
     alloc_device();
     upload_ff();
     st.n10_stride = S10; st.nbuffer = NB;
@@ -510,11 +516,18 @@ __global__ void k_cell_starts(int G, int ncell, const int *cid_sorted, int *cell
   for (int cc = prev + 1; cc <= c; ++cc) cellstart[cc] = k;
   if (k == G - 1) for (int cc = c + 1; cc <= ncell; ++cc) cellstart[cc] = G;
 }
-__global__ void k_sorted_pos(int G, const int *perm, const double *x, const double *y, const double *z, double4 *out) {
+__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, double4 *out, int *rootperm) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= G) return;
   const int i = perm[k];
   out[k] = make_double4(x[i], y[i], z[i], __longlong_as_double(static_cast<long long>(i)));
+  rootperm[k] = (i < N) ? i : groot[i];
+}
+// xs[k] = v[owner of the atom at cell-sorted position k]: the ghost refresh (MODE_QCOPY1/2, comm.F90:187-212) and the
+// spatially sorted gather copy of the vector in one pass
+__global__ void k_sorted_vec(int G, const int *__restrict__ rootperm, const double2 *__restrict__ v, double2 *__restrict__ xs) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < G) xs[k] = v[rootperm[k]];
 }
 
 void Engine::bin_cells() {
@@ -525,8 +538,10 @@ void Engine::bin_cells() {
   while ((1LL << bits) < grid.ncell + 1 && bits < 31) ++bits;
   RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, cellid, cellid_sorted, perm_in, perm, G, 0, bits, stream));
   k_cell_starts<<<nblk(G, 256), 256, 0, stream>>>(G, grid.ncell, cellid_sorted, cellstart);
-  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, perm, pos[0], pos[1], pos[2], sorted_xyzi);
+  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, rootperm);
 }
+
+void Engine::sorted_copy(const double2 *v) { k_sorted_vec<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, v, xs); }
 
 void Engine::build_ghosts_and_lists() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");

@@ -79,10 +79,14 @@ __global__ void k_reverse_index(int G, int NB, const int *__restrict__ nbr, cons
 // One wavefront per resident row.  Lanes sweep the candidates of a stencil column 64 at a time,
 // the accepted ones are compacted with a ballot so that a row is written as contiguous runs
 // (coalesced 8-byte + 4-byte streams) in a deterministic order.
+// A list entry names the partner by its CELL-SORTED position (the loop variable of this sweep), not by atom index:
+// the consumers (QEq matrix passes, ENbond, Ehb) gather from cell-sorted copies, so the 64 lanes of a wavefront hit a
+// handful of cache lines instead of 64 scattered ones.  Bits: see NB10_* in engine.h.
+template <bool SELFCHECK>
 __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
-                                                 const double *__restrict__ z, const int *__restrict__ type, int *__restrict__ nb10, double *__restrict__ hess,
-                                                 int *__restrict__ n10, int *err) {
+                                                 const double *__restrict__ z, const int *__restrict__ type, const long long *__restrict__ gid,
+                                                 int *__restrict__ nb10, double *__restrict__ hess, int *__restrict__ n10, int *err) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
@@ -130,7 +134,9 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
               const double *T = ff.tabQEq + static_cast<size_t>(inxn) * (NTABLE + 2);
               h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
             }
-            nb10[row + slot] = j;
+            unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
+            if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
+            nb10[row + slot] = static_cast<int>(ent);
             hess[row + slot] = h;
           }
         }
@@ -138,10 +144,9 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
       }
     }
   }
-  if (lane == 0) {
-    if (cnt > S10) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); cnt = S10; }  // qeq.F90:248-252
-    n10[i] = cnt;
-  }
+  if (cnt > S10) { if (lane == 0) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); } cnt = S10; }  // qeq.F90:248-252
+  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
+  if (lane == 0) n10[i] = cnt;
 }
 
 void Engine::build_bonded_list() {
@@ -151,7 +156,12 @@ void Engine::build_bonded_list() {
 }
 
 void Engine::build_list10() {
-  k_list10<<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, nb10, hess, n10, d_err);
+  // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
+  const bool selfcheck = (box.lat[0] < 2.0 * ff.rctap + 1.0) || (box.lat[1] < 2.0 * ff.rctap + 1.0) || (box.lat[2] < 2.0 * ff.rctap + 1.0);
+  if (selfcheck)
+    k_list10<true><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, hess, n10, d_err);
+  else
+    k_list10<false><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, hess, n10, d_err);
 }
 
 }  // namespace rxmd

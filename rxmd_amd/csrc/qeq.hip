@@ -4,7 +4,9 @@
 //   driver loop  (qeq.F90:96-166)  -> Engine::qeq()       REAL(4) step lengths kept (qeq.F90:23,133)
 // The matrix is the ELL list built in lists.hip: per row a contiguous FP64 value stream and an INT32
 // column stream (12 bytes per entry, the algorithmic bytes of SURVEY 8d), one wavefront per row.
-// The two right-hand vectors are interleaved (double2) so a column costs ONE 16-byte gather.
+// The two right-hand vectors are interleaved (double2) so a column costs ONE 16-byte gather, and the gather
+// source is a CELL-SORTED copy (ghosts resolved to their owners while copying = the reference's QCOPY halo),
+// so the 64 lanes of a wavefront touch a few cache lines instead of 64.
 //
 // Est (the convergence quantity, qeq.F90:297-306) is produced by the GRADIENT pass of the previous
 // iteration: sum_j H_ij q_j = sum_j H_ij qs_j - mu sum_j H_ij qt_j, with the reference's
@@ -12,6 +14,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace rxmd {
 
@@ -19,6 +22,8 @@ static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1)
 
 enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_COUNT };
 enum { MODE_HSH = 0, MODE_GRAD = 1 };
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int UNR = 8;   // 8 x 64 = 512 entries in flight per wavefront: a whole RDX row (<= 447) in one batch
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -56,22 +61,22 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
     const int n = n10[row];
     const size_t base = static_cast<size_t>(row) * S10;
     double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    for (int k0 = lane; k0 < n; k0 += 256) {
-      int j[4];
-      double h[4];
+    for (int k0 = lane; k0 < n; k0 += 64 * UNR) {
+      unsigned e[UNR];
+      double h[UNR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UNR; ++u) {            // the two coalesced streams of the row: issue every load first
         const int k = k0 + 64 * u;
         const bool ok = k < n;
-        j[u] = ok ? __builtin_nontemporal_load(nb10 + base + k) : 0;
-        h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;
+        e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;   // streamed once: keep it out of
+        h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;                        // the caches that hold the vector
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double2 v = xv[j[u]];
+      for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
+        const double2 v = xv[e[u] & NB10_IDX_MASK];
         as += h[u] * v.x;
         at += h[u] * v.y;
-        if (MODE == MODE_GRAD && j[u] >= N) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
+        if (MODE == MODE_GRAD && (e[u] & NB10_GHOST)) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
       }
     }
     as = wave_sum(as); at = wave_sum(at);
@@ -98,6 +103,27 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
   block_store_partials<4>(acc, partials, 4);
 }
 
+// bandwidth probe (debug tap 100): plain 16-byte-per-lane grid-stride read of the matrix value array; gives the
+// read ceiling of the box the roofline fraction is quoted next to
+__global__ void __launch_bounds__(256) k_stream_probe(size_t n16, const f64x2 *__restrict__ a, double *__restrict__ out) {
+  double s = 0.0;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const f64x2 v = __builtin_nontemporal_load(a + i);
+    s += v.x + v.y;
+  }
+  if (s == 12345.678) out[0] = s;
+}
+double stream_probe_ms(Engine &e, int blocks) {
+  const size_t n16 = static_cast<size_t>(e.rows10) * e.S10 / 2;
+  hipEventRecord(e.ev[2], e.stream);
+  for (int r = 0; r < 5; ++r) k_stream_probe<<<blocks, 256, 0, e.stream>>>(n16, reinterpret_cast<const f64x2 *>(e.hess), e.partials);
+  hipEventRecord(e.ev[3], e.stream);
+  hipEventSynchronize(e.ev[3]);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
+  return ms / 5.0;
+}
+
 // single-block deterministic reduction of the per-block partials + the scalar algebra between passes
 __device__ inline double block_sum_256(double v, double *sm) {
   sm[threadIdx.x] = v;
@@ -109,6 +135,20 @@ __device__ inline double block_sum_256(double v, double *sm) {
   const double r = sm[0];
   __syncthreads();
   return r;
+}
+
+// first level of the two-level deterministic reduction: block b sums its contiguous chunk of the per-workgroup partials
+__global__ void __launch_bounds__(256) k_reduce_level1(int nblocks, const double *__restrict__ partials, double *__restrict__ out) {
+  __shared__ double sm[256];
+  const int per = (nblocks + gridDim.x - 1) / gridDim.x;
+  const int b0 = blockIdx.x * per, b1 = min(nblocks, b0 + per);
+  double a[4] = {0, 0, 0, 0};
+  for (int b = b0 + threadIdx.x; b < b1; b += 256)
+    for (int c = 0; c < 4; ++c) a[c] += partials[static_cast<size_t>(b) * 4 + c];
+  for (int c = 0; c < 4; ++c) {
+    const double r = block_sum_256(a[c], sm);
+    if (threadIdx.x == 0) out[blockIdx.x * 4 + c] = r;
+  }
 }
 
 // stage 1: after the HSH pass -> REAL(4) line-minimisation factors (qeq.F90:133)
@@ -170,10 +210,10 @@ __global__ void k_direction(int N, int first, const double *__restrict__ scal, c
   hst[i] = make_double2(g.x + scal[S_BETA_S] * h.x, g.y + scal[S_BETA_T] * h.y);
 }
 // initial vectors (qeq.F90:36-63)
-__global__ void k_qeq_init(int N, int NBcap, int isQEq, double fqs, double *__restrict__ q, double *__restrict__ qsfp, double *__restrict__ qsfv, double2 *__restrict__ qst, double2 *__restrict__ hst) {
+__global__ void k_qeq_init(int N, int isQEq, double fqs, double *__restrict__ q, double *__restrict__ qsfp, double *__restrict__ qsfv, double2 *__restrict__ qst, double2 *__restrict__ hst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= NBcap) return;
-  if (i >= N) { qst[i] = make_double2(0.0, 0.0); hst[i] = make_double2(0.0, 0.0); return; }
+  if (i >= N) return;
+  hst[i] = make_double2(0.0, 0.0);
   if (isQEq == 1) { qsfp[i] = q[i]; qsfv[i] = 0.0; qst[i] = make_double2(q[i], 0.0); }
   else { qst[i] = make_double2(fqs * qsfp[i] + (1.0 - fqs) * q[i], 0.0); }
 }
@@ -184,15 +224,25 @@ void Engine::qeq() {
   tic(6);
   if (!lists_valid) build_ghosts_and_lists();
   const int nmax = (cfg.isQEq == 1) ? cfg.NMAXQEq : 1;
-  const int rb = std::min(nblk(N, 4), 2048);
+  // one wavefront per row, four rows per workgroup: measured faster than a persistent grid-stride launch (1.10 vs 1.28 ms
+  // per pass at 979,776 rows) -- many short waves overlap each other's load / gather / reduce phases
+  const int rb = nblk(N, 4);
   const int vb = std::min(nblk(N, 256), 2048);
-  k_qeq_init<<<nblk(G, 256), 256, 0, stream>>>(N, G, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
-  RX_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 64, stream));
-  halo_refresh(qst, nullptr);                                                                   // QCOPY1, qeq.F90:86
-  k_spmv<MODE_GRAD><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, qst, hst, gst, qst, q, type, scal, partials);
-  k_reduce_scalars<<<1, 256, 0, stream>>>(3, rb, partials, scal);
+  double *lvl1 = partials + static_cast<size_t>(rb) * 4 + 64;      // 128 x 4 first-level sums live behind the per-workgroup partials
+  auto reduce = [&](int stage, int nb_) {
+    if (nb_ > 1024) {
+      k_reduce_level1<<<128, 256, 0, stream>>>(nb_, partials, lvl1);
+      k_reduce_scalars<<<1, 256, 0, stream>>>(stage, 128, lvl1, scal);
+    } else {
+      k_reduce_scalars<<<1, 256, 0, stream>>>(stage, nb_, partials, scal);
+    }
+  };
+  k_qeq_init<<<nblk(N, 256), 256, 0, stream>>>(N, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
+  RX_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 32, stream));
+  sorted_copy(qst);                                                                             // QCOPY1, qeq.F90:86
+  k_spmv<MODE_GRAD><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials);
+  reduce(3, rb);
   k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
-  halo_refresh(hst, q);                                                                          // QCOPY2, qeq.F90:93
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
   RX_HIP(hipStreamSynchronize(stream));
   double GEst2 = 1e99, Est = h_scal[S_EST];
@@ -202,20 +252,20 @@ void Engine::qeq() {
     if (0.5 * (std::fabs(GEst2) + std::fabs(Est)) < cfg.QEq_tol) break;                          // qeq.F90:114
     if (std::fabs(GEst2) > 0.0 && std::fabs(Est / GEst2 - 1.0) < cfg.QEq_tol) break;            // qeq.F90:115
     GEst2 = Est;
+    sorted_copy(hst);                                                                            // QCOPY2, qeq.F90:93,164
     hipEventRecord(ev[2], stream);
-    k_spmv<MODE_HSH><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, hst, hst, gst, qst, q, type, scal, partials);
+    k_spmv<MODE_HSH><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials);
     hipEventRecord(ev[3], stream);
-    k_reduce_scalars<<<1, 256, 0, stream>>>(1, rb, partials, scal);
+    reduce(1, rb);
     k_update_qst<<<vb, 256, 0, stream>>>(N, scal, hst, qst, partials);
-    k_reduce_scalars<<<1, 256, 0, stream>>>(2, vb, partials, scal);
+    reduce(2, vb);
     k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);
-    halo_refresh(qst, nullptr);                                                                  // QCOPY1, qeq.F90:153
+    sorted_copy(qst);                                                                            // QCOPY1, qeq.F90:153
     hipEventRecord(ev[4], stream);
-    k_spmv<MODE_GRAD><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, qst, hst, gst, qst, q, type, scal, partials);
+    k_spmv<MODE_GRAD><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials);
     hipEventRecord(ev[5], stream);
-    k_reduce_scalars<<<1, 256, 0, stream>>>(3, rb, partials, scal);
+    reduce(3, rb);
     k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);
-    halo_refresh(hst, q);                                                                        // QCOPY2, qeq.F90:164
     RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
     RX_HIP(hipStreamSynchronize(stream));
     Est = h_scal[S_EST];
