@@ -644,10 +644,20 @@ static int nb_pairlist(World *W, Rank *r, int with_hessian) {
   return 0;
 }
 
+/* MPI_ALLREDUCE(SUM) as MPICH evaluates it for a power-of-two communicator (recursive doubling = pairwise tree);
+ * for other sizes: rank order.  Only the rounding of 1e-16-level differs, but the CG exit iteration can feel it. */
+static double allreduce_sum(const double *v, int n) {
+  double t[64];
+  if (n > 64 || (n & (n - 1))) { double s = 0; for (int i = 0; i < n; i++) s += v[i]; return s; }
+  for (int i = 0; i < n; i++) t[i] = v[i];
+  for (int w = 1; w < n; w <<= 1) for (int i = 0; i < n; i += 2 * w) t[i] = t[i] + t[i + w];
+  return t[0];
+}
+
 /* ------------------------------------------------------------------ QEq, src/qeq.F90:2-178 */
 static void get_gradient(World *W, double Gnew[2]) { /* qeq.F90:321-363 */
   const Params *P = &W->P;
-  double gg[2] = {0, 0};
+  double ga[64], gb[64];
   for (int p = 0; p < W->nprocs; p++) {
     Rank *r = &W->R[p];
 #pragma omp parallel for schedule(static)
@@ -664,14 +674,14 @@ static void get_gradient(World *W, double Gnew[2]) { /* qeq.F90:321-363 */
     }
     double a = 0, b = 0;
     for (int i = 1; i <= r->NATOMS; i++) { a += r->gs[i] * r->gs[i]; b += r->gt[i] * r->gt[i]; }
-    gg[0] += a; gg[1] += b;                            /* MPI_ALLREDUCE, :357 */
+    ga[p] = a; gb[p] = b;                              /* MPI_ALLREDUCE, :357 */
   }
-  Gnew[0] = gg[0]; Gnew[1] = gg[1];
+  Gnew[0] = allreduce_sum(ga, W->nprocs); Gnew[1] = allreduce_sum(gb, W->nprocs);
 }
 
 static void get_hsh(World *W, double *Est, double *hshs_sum, double *hsht_sum) { /* qeq.F90:271-318 */
   const Params *P = &W->P;
-  double E = 0, S = 0, T = 0;
+  double Ea[64], Sa[64], Ta[64];
   for (int p = 0; p < W->nprocs; p++) {
     Rank *r = &W->R[p];
     double e = 0.0, s = 0.0, t = 0.0;
@@ -691,9 +701,9 @@ static void get_hsh(World *W, double *Est, double *hshs_sum, double *hsht_sum) {
       s = s + t_hshs * r->hs[i];
       t = t + t_hsht * r->ht[i];
     }
-    E += e; S += s; T += t;
+    Ea[p] = e; Sa[p] = s; Ta[p] = t;
   }
-  *Est = E; *hshs_sum = S; *hsht_sum = T;
+  *Est = allreduce_sum(Ea, W->nprocs); *hshs_sum = allreduce_sum(Sa, W->nprocs); *hsht_sum = allreduce_sum(Ta, W->nprocs);
 }
 
 static void trace_push(World *W, double a, double b, double c) {
@@ -738,24 +748,28 @@ static int QEq(World *W) {
     if (0.5 * (fabs(GEst2) + fabs(GEst1)) < W->QEq_tol) break;                       /* :114 */
     if (fabs(GEst2) > 0.0 && (fabs(GEst1 / GEst2 - 1.0) < W->QEq_tol)) break;        /* :115 */
     GEst2 = GEst1;
-    double g_h[2] = {0, 0};
+    double g_h[2], pa[64], pb[64];
     for (int p = 0; p < W->nprocs; p++) {              /* dot_product per rank then allreduce, :119-131 */
       Rank *r = &W->R[p];
       double a = 0, b = 0;
       for (int i = 1; i <= r->NATOMS; i++) { a += r->gs[i] * r->hs[i]; b += r->gt[i] * r->ht[i]; }
-      g_h[0] += a; g_h[1] += b;
+      pa[p] = a; pb[p] = b;
     }
+    g_h[0] = allreduce_sum(pa, W->nprocs); g_h[1] = allreduce_sum(pb, W->nprocs);
+    {  /* hshs/hsht travel in the same 4-element allreduce (qeq.F90:126-131): they were reduced once in get_hsh already in
+          this restatement, which is what the reference does too (get_hsh returns local sums, the allreduce is here) */ }
     float lmin[2];                                     /* real(4) :: lmin(2), qeq.F90:23,133 */
     lmin[0] = (float)(g_h[0] / hshs_sum); lmin[1] = (float)(g_h[1] / hsht_sum);
-    double ssum = 0, tsum = 0;
+    double ssum, tsum;
     for (int p = 0; p < W->nprocs; p++) {
       Rank *r = &W->R[p];
       double a = 0, b = 0;
       for (int i = 1; i <= r->NATOMS; i++) { r->qs[i] = r->qs[i] + (double)lmin[0] * r->hs[i]; r->qt[i] = r->qt[i] + (double)lmin[1] * r->ht[i]; }
       for (int i = 1; i <= r->NATOMS; i++) a += r->qs[i];
       for (int i = 1; i <= r->NATOMS; i++) b += r->qt[i];
-      ssum += a; tsum += b;
+      pa[p] = a; pb[p] = b;
     }
+    ssum = allreduce_sum(pa, W->nprocs); tsum = allreduce_sum(pb, W->nprocs);
     double mu = ssum / tsum;                            /* :147 */
     for (int p = 0; p < W->nprocs; p++) { Rank *r = &W->R[p]; for (int i = 1; i <= r->NATOMS; i++) r->q[i] = r->qs[i] - mu * r->qt[i]; }
     COPYATOMS(W, MODE_QCOPY1, QCopyDr);                /* :153 */

@@ -46,6 +46,10 @@ CASES = {
     "rdx222_tight":  ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
     "rdx222_md5":    ("rdx.xyz", "ffield_rdx", (2, 2, 2), [], 5),
     "ice644_tight":  ("ICE", "ffield_water", (6, 4, 4), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
+    # multi-rank (real MPI build oracle/_ref/rxmd_mpi, conda MPICH): name: (..., vprocs)
+    "rdx222_v211_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
+    "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),
+    "rdx222_v222_md3":   ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 2, 2)),
 }
 
 
@@ -97,7 +101,35 @@ def parse_mdstep(out):
     return np.array(res)
 
 
+def make_mpi(name):
+    xyz, ff, mc, flags, nsteps, vp = CASES[name]
+    npr = vp[0] * vp[1] * vp[2]
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(INP, xyz), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(INP, ff), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", str(mc[0]), str(mc[1]), str(mc[2]),
+             "-v", str(vp[0]), str(vp[1]), str(vp[2])], tmp)
+        out = run(["/opt/conda/bin/mpiexec", "-np", str(npr), os.path.join(REFBIN, "rxmd_mpi"), "--ntime_step", str(nsteps), "--pstep", "1",
+                   "--fstep", "100000", "--vprocs", str(vp[0]), str(vp[1]), str(vp[2])] + flags, tmp)
+        d = dict(mc=np.array(mc), vprocs=np.array(vp), nsteps=np.array(nsteps), flags=np.array(" ".join(flags)))
+        for r in range(npr):
+            gid, typ, pos, frc, chg = parse_rfdump(os.path.join(tmp, "rfdump%d.txt" % r))
+            d["gid_%d" % r] = gid; d["type_%d" % r] = typ; d["pos_%d" % r] = pos; d["force_%d" % r] = frc; d["charge_%d" % r] = chg
+        traces = parse_trace(out)
+        d["qeq_iters"] = np.array([len(t) - 1 for t in traces])
+        d["mdstep"] = parse_mdstep(out)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, "ranks", npr, "natoms/rank", [len(d["gid_%d" % r]) for r in range(npr)], "qeq_iters", d["qeq_iters"])
+    finally:
+        shutil.rmtree(tmp)
+
+
 def make(name):
+    if len(CASES[name]) == 6:
+        return make_mpi(name)
     xyz, ff, mc, flags, nsteps = CASES[name]
     tmp = tempfile.mkdtemp(prefix="golden_")
     try:

@@ -105,3 +105,22 @@ def test_ice_type_order_and_zero_hbond():
     _compare(g, o, ftol=1e-9)
     assert pe[10] == 0.0          # hydrogen is hard-coded as type 2; water ffield has H = 1  
     _check_energy(g, pe, 2304)
+
+
+@pytest.mark.parametrize("case,steps", [("rdx222_v211_tight", 0), ("rdx222_v222_tight", 0), ("rdx222_v222_md3", 3)])
+def test_multirank_world_vs_real_mpi_reference(case, steps):
+    """the oracle's in-process multi-rank world against the reference run under real MPI (conda MPICH) at the same vprocs"""
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vp = tuple(int(x) for x in g["vprocs"]); mc = tuple(int(x) for x in g["mc"])
+    ff, names, frac, lat = oa.make_system("rdx222")
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=mc, vprocs=vp)
+    o = oa.Oracle(ff, lat2, ranks, vprocs=vp, QEq_tol=1e-12, NMAXQEq=2000)
+    iters = [o.qeq()]; o.force()
+    for _ in range(steps):
+        o.step(1); iters.append(o.L.rxo_qeq_iters(o.w))
+    assert iters == [int(x) for x in g["qeq_iters"]]
+    for r in range(len(ranks)):
+        assert (o.gids(r) == g["gid_%d" % r]).all()
+        assert np.abs(o.charges(r) - g["charge_%d" % r]).max() < 1e-10
+        assert np.abs(o.forces(r) - g["force_%d" % r]).max() < 1e-9
+        assert np.abs(o.pos(r) - g["pos_%d" % r]).max() < 1e-11
