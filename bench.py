@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--cells", type=int, default=ATOMS_PER_GPU_CELLS, help="RDX unit cells per edge per GPU (18 -> 979,776 atoms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--qeq-mode", type=int, default=0)
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent periodic replicas instead of one decomposed box")
     a = ap.parse_args()
 
     import torch
@@ -92,17 +93,38 @@ def main():
     ff = os.path.join(INP, "ffield_rdx")
     names, frac, lat = system.read_xyz(os.path.join(INP, "rdx.xyz"))
     cfg = system.parse_rxmd_in(os.path.join(INP, "rxmd.in"))
-    if use_dist:
-        # weak scaling: every rank owns one 18^3-cell domain of the vprocs grid.  Until the RCCL halo transport is
-        # wired (rxmd_hip_set_comm), each rank advances its own periodic 979,776-atom replica: no data-path
-        # collective, identical per-GPU work -- reported as "replicas" in config.parallelism.
-        mc_local, vp_local, myid = (a.cells,) * 3, (1, 1, 1), 0
+    # weak scaling (BASELINE configs[3]): the box is a.cells*vprocs unit cells per edge, every rank owns one 18^3-cell
+    # domain of the reference's vprocs grid; ghost atoms, QEq vector halos, force return and migration travel through the
+    # engine's six-stage exchange over RCCL (torch.distributed "nccl"), scalars through small all-reduces.
+    transport_mode = None
+    if use_dist and not a.replicas:
+        mc_local, vp_local, myid = mc, vp, rank
     else:
-        mc_local, vp_local, myid = mc, vp, 0
+        mc_local, vp_local, myid = (a.cells,) * 3, (1, 1, 1), 0
     lat_super, rec = system.geninit(ff, names, frac, lat, mc=mc_local, vprocs=vp_local, myid=myid)
     natoms = len(rec)
     eng = rxmd_amd.RxmdEngine(ff, lat_super, vprocs=vp_local, myid=myid, isQEq=cfg["isQEq"], NMAXQEq=cfg["NMAXQEq"], QEq_tol=cfg["QEq_tol"],
                               qstep=cfg["qstep"], dt_fs=cfg["dt"], device=local, qeq_mode=a.qeq_mode)
+    if use_dist and not a.replicas:
+        from rxmd_amd.comm import TorchTransport
+        dev = torch.device("cuda", local)
+        cap = int(natoms * 0.45 * 6) + (1 << 20)          # widest message: the 13 A ghost shell of one stage, 6 doubles per atom
+        tr = TorchTransport(mode="device", device=dev, capacity_doubles=cap)
+        ok = torch.ones(1, device=dev)
+        try:                                               # one ring round on the device path before trusting it
+            peer_to, peer_from = (rank + 1) % world, (rank - 1) % world
+            tr.send_t[:8] = float(rank)
+            n = tr._exchange(None, peer_to, 0, 8, peer_from, 0, cap)
+            if n != 8 or float(tr.recv_t[0].item()) != float(peer_from):
+                ok[0] = 0
+        except Exception:
+            ok[0] = 0
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 1:                                  # fall back to host-staged messages over gloo
+            gl = dist.new_group(backend="gloo")
+            tr = TorchTransport(mode="staged", group=gl, device=dev, capacity_doubles=cap)
+        transport_mode = tr.mode
+        tr.attach(eng)
     eng.set_atoms_rxff(rec)
     eng.QEq(); eng.FORCE()                       # main.F90:27-32
     eng.step(a.warmup)
@@ -152,7 +174,8 @@ def main():
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (RDX unit cell of the reference's conf/init.rdx replicated; v0=0, q0=0)",
             "config": {"workload": "RDX %dx%dx%d cells per GPU = %d atoms/GPU, QEq tol %g, dt %g fs, mdmode 1 (NVE)" % (a.cells, a.cells, a.cells, natoms, cfg["QEq_tol"], cfg["dt"]),
-                       "atoms_total": natoms * world, "parallelism": "1 GPU" if world == 1 else "%d replicas (halo transport not wired yet)" % world,
+                       "atoms_total": natoms * world, "parallelism": "1 GPU" if world == 1 else ("%d independent replicas" % world if a.replicas else
+                                       "vprocs %dx%dx%d domain decomposition, six-stage halo over RCCL (%s)" % (vp[0], vp[1], vp[2], transport_mode)),
                        "qeq_mode": a.qeq_mode},
             "steps_per_s_wall": steps_per_s, "ns_per_day": steps_per_s * cfg["dt"] * 86400e-6, "atom_steps_per_s": steps_per_s * natoms * world,
             "qeq_iters_per_step": iters, "n10": n10, "nb": nb,

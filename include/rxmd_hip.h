@@ -132,8 +132,17 @@ typedef struct rxmd_comm_ops {
   void *ctx;
   long long (*exchange)(void *ctx, int to, const double *send, long long nsend, int from, double *recv, long long cap);
   int (*allreduce_sum)(void *ctx, double *buf, int n);
+  /* optional (may be NULL): the same as `exchange` when the receiver already knows it will get exactly `nrecv` doubles
+   * (vector halos and force returns re-use the index lists of the ghost build), so no size message is needed */
+  long long (*exchange_known)(void *ctx, int to, const double *send, long long nsend, int from, double *recv, long long nrecv);
 } rxmd_comm_ops;
 int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops);
+/* Optional: let the host own the two message buffers (device memory, `ndoubles` each) that `exchange` is called
+ * with -- e.g. torch tensors, so that torch.distributed can send them without wrapping foreign pointers. */
+int rxmd_hip_set_exchange_buffers(rxmd_handle h, double *send, double *recv, long long ndoubles);
+/* Transport self-test with HOST buffers (no GPU needed): every rank sends a pattern round the ring of `nprocs` ranks in
+ * both directions with different lengths and all-reduces a vector; returns 0 if the callbacks honour the contract. */
+int rxmd_host_comm_selftest(const rxmd_comm_ops *ops, int myid, int nprocs);
 
 /* ---- host front-end helpers (no GPU needed) ------------------------------------------------- */
 /* geninit (reference init/geninit.F90:399-575): replicate a fractional-coordinate unit cell mc times,

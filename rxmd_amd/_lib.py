@@ -39,7 +39,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 
 class RxmdCommOps(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN)]
+    _fields_ = [("ctx", C.c_void_p), ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN), ("exchange_known", EXCHANGE_FN)]
 
 
 # every symbol include/rxmd_hip.h declares: (name, restype, argtypes)
@@ -67,6 +67,8 @@ SYMBOLS = [
     ("rxmd_hip_get_cutoffs", C.c_int, [H, PD, C.c_int, C.POINTER(C.c_double)]),
     ("rxmd_hip_debug_get", C.c_int, [H, C.c_int, PD, C.c_int]),
     ("rxmd_hip_set_comm", C.c_int, [H, C.POINTER(RxmdCommOps)]),
+    ("rxmd_hip_set_exchange_buffers", C.c_int, [H, PD, PD, C.c_longlong]),
+    ("rxmd_host_comm_selftest", C.c_int, [C.POINTER(RxmdCommOps), C.c_int, C.c_int]),
     ("rxmd_host_geninit", C.c_longlong, [C.c_char_p, C.c_int, C.c_char_p, PD, PD, PD, PD, C.c_int, PD, C.c_longlong, PD]),
     ("rxmd_host_read_rxff", C.c_longlong, [C.c_char_p, C.c_int, PD, PD, PD, C.c_longlong]),
     ("rxmd_host_ffield_table", C.c_int, [C.c_char_p, PD, C.c_int, PD, C.c_longlong]),

@@ -324,6 +324,40 @@ int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops) {
   });
 }
 
+int rxmd_hip_set_exchange_buffers(rxmd_handle h, double *send, double *recv, long long ndoubles) {
+  return guarded(h, [&](Engine &e) {
+    if (!send || !recv || ndoubles < 1024) throw EngineError(RXMD_E_ARG, "bad exchange buffers");
+    if (e.xbuf_owned) { (void)hipFree(e.xbuf_send); (void)hipFree(e.xbuf_recv); }
+    e.xbuf_send = send; e.xbuf_recv = recv; e.xbuf_doubles = static_cast<size_t>(ndoubles); e.xbuf_owned = false;
+  });
+}
+
+int rxmd_host_comm_selftest(const rxmd_comm_ops *ops, int myid, int nprocs) {
+  if (!ops || !ops->exchange || !ops->allreduce_sum || nprocs < 1 || myid < 0 || myid >= nprocs) return RXMD_E_ARG;
+  const int right = (myid + 1) % nprocs, left = (myid + nprocs - 1) % nprocs;
+  std::vector<double> snd(4096), rcv(4096);
+  for (int dir = 0; dir < 2; ++dir) {
+    const int to = dir ? left : right, from = dir ? right : left;
+    const long long ns = 7 + 13 * myid + dir;                 // ragged lengths, different per rank
+    for (long long k = 0; k < ns; ++k) snd[k] = 1000.0 * myid + k + 0.5 * dir;
+    const long long nr = ops->exchange(ops->ctx, to, snd.data(), ns, from, rcv.data(), 4096);
+    if (nr != 7 + 13 * from + dir) return RXMD_E_COMM;
+    for (long long k = 0; k < nr; ++k) if (rcv[k] != 1000.0 * from + k + 0.5 * dir) return RXMD_E_COMM;
+    const long long nz = ops->exchange(ops->ctx, to, snd.data(), 0, from, rcv.data(), 4096);   // empty message (comm.F90:321-327)
+    if (nz != 0) return RXMD_E_COMM;
+    if (ops->exchange_known) {                                  // size known to the receiver: payload only
+      const long long nk = ops->exchange_known(ops->ctx, to, snd.data(), ns, from, rcv.data(), 7 + 13 * from + dir);
+      if (nk != 7 + 13 * from + dir) return RXMD_E_COMM;
+      for (long long k = 0; k < nk; ++k) if (rcv[k] != 1000.0 * from + k + 0.5 * dir) return RXMD_E_COMM;
+    }
+  }
+  double v[3] = {1.0 * (myid + 1), 0.25, -2.0 * myid};
+  if (ops->allreduce_sum(ops->ctx, v, 3)) return RXMD_E_COMM;
+  const double n = nprocs;
+  if (v[0] != n * (n + 1) / 2 || v[1] != 0.25 * n || v[2] != -n * (n - 1)) return RXMD_E_COMM;
+  return RXMD_OK;
+}
+
 // ---- host front-end helpers ---------------------------------------------------------------------
 // geninit (reference init/geninit.F90:399-575)
 long long rxmd_host_geninit(const char *ffield_path, int natoms0, const char *elem4, const double *frac, const double lattice[6], const int mc[3],

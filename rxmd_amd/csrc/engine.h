@@ -122,7 +122,7 @@ struct Engine {
   double *scal = nullptr;      // device scalars (CG state)
   double *h_scal = nullptr;    // pinned host mirror
   int *d_err = nullptr, *h_err = nullptr;
-  double *xbuf_send = nullptr, *xbuf_recv = nullptr; size_t xbuf_doubles = 0;
+  double *xbuf_send = nullptr, *xbuf_recv = nullptr; size_t xbuf_doubles = 0; bool xbuf_owned = false;   // staged-exchange message buffers
   double pe[14] = {0}, astr[6] = {0};
 
   hipStream_t stream = nullptr;
@@ -151,7 +151,13 @@ struct Engine {
   void bin_cells();
   void build_bonded_list();
   void build_list10();
-  void halo_refresh(double2 *v2, double *v1);       // QCOPY1/QCOPY2: ghosts <- owners
+  void halo_refresh(double2 *v2, double *v1);       // QCOPY1/QCOPY2: ghosts <- owners (self exchange, resolved roots)
+  void halo_staged(double *v, int ncomp);           // the same through the six-stage exchange (multi-rank)
+  long long exchange_stage(int d, bool reverse, long long nsend, long long known_nrecv = -1);  // one send_recv of comm.F90:291-364; returns #doubles received
+  void ensure_xbuf(size_t doubles);
+  bool multi() const { return nprocs > 1; }
+  void ghost_build_staged();
+  void migrate_staged();
   void sorted_copy(const double2 *v);               // QCOPY1/QCOPY2 fused with the cell-sorted gather copy -> xs
   void fold_ghost_forces();                         // CPBK
   void bond_orders();

@@ -15,6 +15,7 @@ namespace rxmd {
 static const double UTIME = 1e3 / 20.455;  // reference src/module.F90:202
 static const int NMINCELL = 4;             // reference src/module.F90:84
 static const int cptridx_[7] = {0, 0, 0, 2, 2, 4, 4};  // comm.F90:61
+static const int dinv_[7] = {0, 2, 1, 4, 3, 6, 5};     // comm.F90:60
 
 template <class T>
 static void dmalloc(T *&p, size_t n) {
@@ -213,7 +214,7 @@ void Engine::free_device() {
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
-  dfree(xbuf_send); dfree(xbuf_recv);
+  if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
   if (cubtmp) { (void)hipFree(cubtmp); cubtmp = nullptr; }
@@ -383,7 +384,7 @@ __global__ void k_fold_stage(int g0, int g1, const int *gsrc, double *fx, double
 static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
 
 void Engine::ghost_build() {
-  if (has_comm && nprocs > 1) throw EngineError(RXMD_E_COMM, "multi-rank exchange is not wired in this build (vprocs must be 1 1 1)");
+  if (multi()) { ghost_build_staged(); return; }
   const BoxDev B = boxdev(box);
   k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
   copyptr[0] = N;
@@ -411,12 +412,138 @@ void Engine::ghost_build() {
 }
 
 void Engine::halo_refresh(double2 *v2, double *v1) {
+  if (multi()) { if (v2) halo_staged(reinterpret_cast<double *>(v2), 2); if (v1) halo_staged(v1, 1); return; }
   if (G <= N) return;
   if (v2) k_refresh2<<<nblk(G - N, 256), 256, 0, stream>>>(N, G, groot, v2);
   if (v1) k_refresh1<<<nblk(G - N, 256), 256, 0, stream>>>(N, G, groot, v1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// multi-rank: the same six stages with pack -> send_recv -> unpack (reference src/comm.F90:68-86).  A stage whose
+// partner is this rank (vprocs(axis) == 1) is a device copy; otherwise the host-supplied transport moves the bytes.
+__global__ void k_pack_ghosts(int nscan, int axis, double sft, const int *flags, const int *scanout, const double *sx, const double *sy, const double *sz,
+                              const int *type, const long long *gid, const double *q, double *buf, int *sendlist) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nscan || !flags[n]) return;
+  const int k = scanout[n];
+  double a = sx[n], b = sy[n], c = sz[n];
+  if (axis == 0) a += sft; else if (axis == 1) b += sft; else c += sft;
+  double *o = buf + 6 * static_cast<size_t>(k);
+  o[0] = a; o[1] = b; o[2] = c; o[3] = static_cast<double>(type[n]); o[4] = static_cast<double>(gid[n]); o[5] = q[n];
+  sendlist[k] = n;
+}
+__global__ void k_unpack_ghosts(int cnt, int base, const double *buf, double *sx, double *sy, double *sz, int *type, long long *gid, double *q, int *gsrc) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const double *o = buf + 6 * static_cast<size_t>(k);
+  const int m = base + k;
+  sx[m] = o[0]; sy[m] = o[1]; sz[m] = o[2]; type[m] = static_cast<int>(llrint(o[3])); gid[m] = llrint(o[4]); q[m] = o[5];
+  gsrc[m] = -1;
+}
+__global__ void k_pack_vec(int cnt, int ncomp, const int *sendlist, const double *v, double *buf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const int n = sendlist[k];
+  for (int c = 0; c < ncomp; ++c) buf[static_cast<size_t>(k) * ncomp + c] = v[static_cast<size_t>(n) * ncomp + c];
+}
+__global__ void k_unpack_vec(int cnt, int ncomp, int base, const double *buf, double *v) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  for (int c = 0; c < ncomp; ++c) v[static_cast<size_t>(base + k) * ncomp + c] = buf[static_cast<size_t>(k) * ncomp + c];
+}
+__global__ void k_pack_force(int g0, int cnt, const double *fx, const double *fy, const double *fz, double *buf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  buf[3 * static_cast<size_t>(k)] = fx[g0 + k]; buf[3 * static_cast<size_t>(k) + 1] = fy[g0 + k]; buf[3 * static_cast<size_t>(k) + 2] = fz[g0 + k];
+}
+__global__ void k_add_force(int cnt, const int *sendlist, const double *buf, double *fx, double *fy, double *fz) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const int n = sendlist[k];      // unique within a stage
+  fx[n] += buf[3 * static_cast<size_t>(k)]; fy[n] += buf[3 * static_cast<size_t>(k) + 1]; fz[n] += buf[3 * static_cast<size_t>(k) + 2];
+}
+
+void Engine::ensure_xbuf(size_t doubles) {
+  if (doubles <= xbuf_doubles) return;
+  if (!xbuf_owned && xbuf_doubles > 0) throw EngineError(RXMD_E_COMM, "host-supplied exchange buffers are too small");
+  dfree(xbuf_send); dfree(xbuf_recv);
+  xbuf_doubles = doubles + doubles / 4 + 4096;
+  dmalloc(xbuf_send, xbuf_doubles); dmalloc(xbuf_recv, xbuf_doubles);
+  xbuf_owned = true;
+}
+
+long long Engine::exchange_stage(int d, bool reverse, long long nsend, long long known_nrecv) {
+  const int to = reverse ? target_node[dinv_[d]] : target_node[d];
+  const int from = reverse ? target_node[d] : target_node[dinv_[d]];
+  if (to == cfg.myid && from == cfg.myid) {                    // comm.F90:305-315
+    if (nsend > 0) RX_HIP(hipMemcpyAsync(xbuf_recv, xbuf_send, sizeof(double) * nsend, hipMemcpyDeviceToDevice, stream));
+    return nsend;
+  }
+  if (!has_comm || !comm.exchange) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
+  RX_HIP(hipStreamSynchronize(stream));                        // the message must be packed before the transport reads it
+  const long long nr = (known_nrecv >= 0 && comm.exchange_known)
+                           ? comm.exchange_known(comm.ctx, to, xbuf_send, nsend, from, xbuf_recv, known_nrecv)
+                           : comm.exchange(comm.ctx, to, xbuf_send, nsend, from, xbuf_recv, static_cast<long long>(xbuf_doubles));
+  if (nr < 0) throw EngineError(RXMD_E_COMM, "exchange callback failed");
+  return nr;
+}
+
+void Engine::ghost_build_staged() {
+  const BoxDev B = boxdev(box);
+  ensure_xbuf(static_cast<size_t>(NB) * 6);
+  k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
+  copyptr[0] = N;
+  sendoff[1] = 0;
+  for (int d = 1; d <= 6; ++d) {
+    const int nscan = copyptr[cptridx_[d]], axis = (d - 1) / 2;
+    const double sft = (d & 1) ? -box.lbox[axis] : box.lbox[axis];
+    k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d, box.lbox[axis], shell[axis], spos[axis], type, 0, flags);
+    size_t tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
+    int total = 0;
+    RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipStreamSynchronize(stream));
+    if (sendoff[d] + total > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
+    if (total > 0)
+      k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, sft, flags, scanout, spos[0], spos[1], spos[2], type, gid, q, xbuf_send, sendidx + sendoff[d]);
+    sendoff[d + 1] = sendoff[d] + total;
+    const long long nr = exchange_stage(d, false, 6LL * total);
+    const int cnt = static_cast<int>(nr / 6);
+    if (static_cast<long long>(copyptr[d - 1]) + cnt > NB)
+      throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
+    if (cnt > 0) k_unpack_ghosts<<<nblk(cnt, 256), 256, 0, stream>>>(cnt, copyptr[d - 1], xbuf_recv, spos[0], spos[1], spos[2], type, gid, q, gsrc);
+    copyptr[d] = copyptr[d - 1] + cnt;
+  }
+  G = copyptr[6];
+  if (G > N) k_to_real<<<nblk(G - N, 256), 256, 0, stream>>>(B, N, G, spos[0], spos[1], spos[2], pos[0], pos[1], pos[2]);
+  ghosts_valid = true;
+  st.nghost_force = G - N; st.nghost_qeq = G - N;
+}
+
+// MODE_QCOPY1 / MODE_QCOPY2 (comm.F90:187-212): ghost slots of an ncomp-interleaved vector, stage by stage
+void Engine::halo_staged(double *v, int ncomp) {
+  for (int d = 1; d <= 6; ++d) {
+    const int ns = sendoff[d + 1] - sendoff[d];
+    if (ns > 0) k_pack_vec<<<nblk(ns, 256), 256, 0, stream>>>(ns, ncomp, sendidx + sendoff[d], v, xbuf_send);
+    const int cnt = copyptr[d] - copyptr[d - 1];
+    const long long nr = exchange_stage(d, false, static_cast<long long>(ns) * ncomp, static_cast<long long>(cnt) * ncomp);
+    if (nr != static_cast<long long>(cnt) * ncomp) throw EngineError(RXMD_E_COMM, "halo size changed between the ghost build and a vector exchange");
+    if (cnt > 0) k_unpack_vec<<<nblk(cnt, 256), 256, 0, stream>>>(cnt, ncomp, copyptr[d - 1], xbuf_recv, v);
+  }
+}
+
 void Engine::fold_ghost_forces() {
+  if (multi()) {                                               // MODE_CPBK, reversed stage order (comm.F90:74-78,385-396,474-482)
+    for (int d = 6; d >= 1; --d) {
+      const int g0 = copyptr[d - 1], cnt = copyptr[d] - copyptr[d - 1];
+      if (cnt > 0) k_pack_force<<<nblk(cnt, 256), 256, 0, stream>>>(g0, cnt, frc[0], frc[1], frc[2], xbuf_send);
+      const int ns = sendoff[d + 1] - sendoff[d];
+      const long long nr = exchange_stage(d, true, 3LL * cnt, 3LL * ns);
+      if (nr != 3LL * ns) throw EngineError(RXMD_E_COMM, "returned force count does not match the stage send list");
+      if (ns > 0) k_add_force<<<nblk(ns, 256), 256, 0, stream>>>(ns, sendidx + sendoff[d], xbuf_recv, frc[0], frc[1], frc[2]);
+    }
+    return;
+  }
   for (int d = 6; d >= 1; --d) {
     const int g0 = copyptr[d - 1], g1 = copyptr[d];
     if (g1 > g0) k_fold_stage<<<nblk(g1 - g0, 256), 256, 0, stream>>>(g0, g1, gsrc, frc[0], frc[1], frc[2]);
@@ -449,6 +576,28 @@ __global__ void k_compact(int n, const int *flags, const int *scanout, const T *
   if (i < n && flags[i]) dst[scanout[i]] = src[i];
 }
 
+__global__ void k_pack_move(int nscan, int axis, double sft, const int *flags, const int *scanout, const double *sx, const double *sy, const double *sz,
+                            const double *vx, const double *vy, const double *vz, int *type, const long long *gid, const double *q,
+                            const double *qsfp, const double *qsfv, double *buf) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nscan || !flags[n]) return;
+  double a = sx[n], b = sy[n], c = sz[n];
+  if (axis == 0) a += sft; else if (axis == 1) b += sft; else c += sft;
+  double *o = buf + 11 * static_cast<size_t>(scanout[n]);
+  o[0] = a; o[1] = b; o[2] = c; o[3] = vx[n]; o[4] = vy[n]; o[5] = vz[n];
+  o[6] = static_cast<double>(type[n]); o[7] = static_cast<double>(gid[n]); o[8] = q[n]; o[9] = qsfp[n]; o[10] = qsfv[n];
+  type[n] = -1;   // comm.F90:440
+}
+__global__ void k_unpack_move(int cnt, int base, const double *buf, double *sx, double *sy, double *sz, double *vx, double *vy, double *vz,
+                              int *type, long long *gid, double *q, double *qsfp, double *qsfv) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const double *o = buf + 11 * static_cast<size_t>(k);
+  const int m = base + k;
+  sx[m] = o[0]; sy[m] = o[1]; sz[m] = o[2]; vx[m] = o[3]; vy[m] = o[4]; vz[m] = o[5];
+  type[m] = static_cast<int>(llrint(o[6])); gid[m] = llrint(o[7]); q[m] = o[8]; qsfp[m] = o[9]; qsfv[m] = o[10];
+}
+
 void Engine::migrate() {
   const BoxDev B = boxdev(box);
   k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
@@ -464,6 +613,19 @@ void Engine::migrate() {
     int total = 0;
     RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
     RX_HIP(hipStreamSynchronize(stream));
+    if (multi()) {
+      ensure_xbuf(static_cast<size_t>(std::max(total, 1)) * 11 + 4096);
+      if (total > 0)
+        k_pack_move<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, sft, flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv, xbuf_send);
+      const long long nr = exchange_stage(d, false, 11LL * total);
+      const int cnt = static_cast<int>(nr / 11);
+      if (static_cast<long long>(cp[d - 1]) + cnt > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
+      if (cnt > 0)
+        k_unpack_move<<<nblk(cnt, 256), 256, 0, stream>>>(cnt, cp[d - 1], xbuf_recv, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
+      cp[d] = cp[d - 1] + cnt;
+      moved += total + cnt;
+      continue;
+    }
     if (static_cast<long long>(cp[d - 1]) + total > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
     if (total > 0)
       k_move_append<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d - 1], axis, sft, flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
@@ -541,7 +703,14 @@ void Engine::bin_cells() {
   k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, rootperm);
 }
 
-void Engine::sorted_copy(const double2 *v) { k_sorted_vec<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, v, xs); }
+void Engine::sorted_copy(const double2 *v) {
+  if (multi()) {   // ghost slots first (six-stage exchange), then the plain permuted copy
+    halo_staged(reinterpret_cast<double *>(const_cast<double2 *>(v)), 2);
+    k_sorted_vec<<<nblk(G, 256), 256, 0, stream>>>(G, perm, v, xs);
+    return;
+  }
+  k_sorted_vec<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, v, xs);
+}
 
 void Engine::build_ghosts_and_lists() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");

@@ -84,7 +84,11 @@ __global__ void __launch_bounds__(256) k_nonbond(int N, int S10, DevFF ff, const
 }
 
 void Engine::nonbonded() {
-  k_sorted_charge<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, q, sorted_xyzi);
+  if (multi()) {                                    // ghost charges through the staged exchange, then the plain permuted copy
+    halo_staged(q, 1);
+    k_sorted_charge<<<nblk(G, 256), 256, 0, stream>>>(G, perm, q, sorted_xyzi);
+  } else
+    k_sorted_charge<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, q, sorted_xyzi);
   k_nonbond<<<nblk(N, 4), 256, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, pos[0], pos[1], pos[2], q, type, frc[0], frc[1], frc[2], scal + 32);
 }
 

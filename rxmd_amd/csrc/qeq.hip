@@ -20,7 +20,7 @@ namespace rxmd {
 
 static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
 
-enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_COUNT };
+enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_RAW0, S_RAW1, S_RAW2, S_RAW3, S_COUNT };
 enum { MODE_HSH = 0, MODE_GRAD = 1 };
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int UNR = 8;   // 8 x 64 = 512 entries in flight per wavefront: a whole RDX row (<= 447) in one batch
@@ -151,17 +151,24 @@ __global__ void __launch_bounds__(256) k_reduce_level1(int nblocks, const double
   }
 }
 
-// stage 1: after the HSH pass -> REAL(4) line-minimisation factors (qeq.F90:133)
-// stage 2: after the q update  -> mu = ssum/tsum (qeq.F90:147)
-// stage 3: after the GRAD pass -> Gold<-Gnew, Gnew, Est, beta (qeq.F90:156-161)
-__global__ void __launch_bounds__(256) k_reduce_scalars(int stage, int nblocks, const double *__restrict__ partials, double *__restrict__ scal) {
+// rank-local sums of the four partial columns -> scal[S_RAW0..3]
+__global__ void __launch_bounds__(256) k_reduce_scalars(int nblocks, const double *__restrict__ partials, double *__restrict__ scal) {
   __shared__ double sm[256];
   double a[4] = {0, 0, 0, 0};
   for (int b = threadIdx.x; b < nblocks; b += 256)
     for (int c = 0; c < 4; ++c) a[c] += partials[static_cast<size_t>(b) * 4 + c];
-  double r[4];
-  for (int c = 0; c < 4; ++c) r[c] = block_sum_256(a[c], sm);
-  if (threadIdx.x != 0) return;
+  for (int c = 0; c < 4; ++c) {
+    const double r = block_sum_256(a[c], sm);
+    if (threadIdx.x == 0) scal[S_RAW0 + c] = r;
+  }
+}
+// the scalar algebra between the passes, on the (all-reduced, MPI_ALLREDUCE qeq.F90:107,129,144,357) sums:
+// stage 1: after the HSH pass -> REAL(4) line-minimisation factors (qeq.F90:133)
+// stage 2: after the q update  -> mu = ssum/tsum (qeq.F90:147)
+// stage 3: after the GRAD pass -> Gold<-Gnew, Gnew, Est, beta (qeq.F90:156-161)
+__global__ void k_scalar_algebra(int stage, double *__restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double r[4] = {scal[S_RAW0], scal[S_RAW1], scal[S_RAW2], scal[S_RAW3]};
   if (stage == 1) {
     scal[S_HSH_S] = r[0]; scal[S_HSH_T] = r[1]; scal[S_GH_S] = r[2]; scal[S_GH_T] = r[3];
     const float l1 = static_cast<float>(r[2] / r[0]), l2 = static_cast<float>(r[3] / r[1]);   // real(4) :: lmin(2)
@@ -232,10 +239,18 @@ void Engine::qeq() {
   auto reduce = [&](int stage, int nb_) {
     if (nb_ > 1024) {
       k_reduce_level1<<<128, 256, 0, stream>>>(nb_, partials, lvl1);
-      k_reduce_scalars<<<1, 256, 0, stream>>>(stage, 128, lvl1, scal);
+      k_reduce_scalars<<<1, 256, 0, stream>>>(128, lvl1, scal);
     } else {
-      k_reduce_scalars<<<1, 256, 0, stream>>>(stage, nb_, partials, scal);
+      k_reduce_scalars<<<1, 256, 0, stream>>>(nb_, partials, scal);
     }
+    if (multi()) {                               // MPI_ALLREDUCE of the rank-local sums through the host transport
+      if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
+      RX_HIP(hipMemcpyAsync(h_scal + 48, scal + S_RAW0, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipStreamSynchronize(stream));
+      if (comm.allreduce_sum(comm.ctx, h_scal + 48, 4)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
+      RX_HIP(hipMemcpyAsync(scal + S_RAW0, h_scal + 48, sizeof(double) * 4, hipMemcpyHostToDevice, stream));
+    }
+    k_scalar_algebra<<<1, 64, 0, stream>>>(stage, scal);
   };
   k_qeq_init<<<nblk(N, 256), 256, 0, stream>>>(N, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
   RX_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 32, stream));

@@ -1,0 +1,55 @@
+"""worker functions for the multi-process tests (spawned by torch.multiprocessing)"""
+import os, sys, traceback
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def transport_selftest(rank, world, port, out):
+    try:
+        dist = _init(rank, world, port)
+        from rxmd_amd.comm import TorchTransport
+        t = TorchTransport(mode="host")
+        rc = t.selftest()
+        out[rank] = (rc, t.n_exchange, t.n_allreduce, repr(t.error))
+        dist.barrier(); dist.destroy_process_group()
+    except Exception:
+        out[rank] = (-99, 0, 0, traceback.format_exc())
+
+
+def engine_rank(rank, world, port, case, vp, steps, out):
+    """one rank of a vprocs run; all ranks share GPU 0, messages are staged through the host over gloo"""
+    try:
+        dist = _init(rank, world, port)
+        import torch
+        import oracle_api as oa
+        import rxmd_amd
+        from rxmd_amd import system
+        from rxmd_amd.comm import TorchTransport
+        g = np.load(os.path.join(oa.GOLD, case + ".npz"))
+        mc = tuple(int(x) for x in g["mc"])
+        ff, names, frac, lat = oa.make_system("rdx222")
+        lat_s, rec = system.geninit(ff, names, frac, lat, mc=mc, vprocs=vp, myid=rank)
+        e = rxmd_amd.RxmdEngine(ff, lat_s, vprocs=vp, myid=rank, QEq_tol=1e-12, NMAXQEq=2000, device=0)
+        tr = TorchTransport(mode="staged", device=torch.device("cuda", 0), capacity_doubles=1 << 20)
+        tr.attach(e)
+        e.set_atoms_rxff(rec)
+        it, est = e.QEq()
+        pe = e.FORCE()
+        if steps:
+            e.step(steps)
+        a = e.atoms()
+        st = e.stats()
+        out[rank] = dict(gid=a["gid"], q=a["q"], f=a["f"], pos=a["pos"], iters=st["qeq_iters_last"], pe=pe, nex=tr.n_exchange, nar=tr.n_allreduce, err=repr(tr.error))
+        e.close()
+        dist.barrier(); dist.destroy_process_group()
+    except Exception:
+        out[rank] = dict(error=traceback.format_exc())
