@@ -83,10 +83,16 @@ def main():
     if a.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     use_dist = world > 1
+    backend = os.environ.get("RXMD_BENCH_BACKEND", "nccl")       # "gloo": host-staged messages (several ranks on one GPU, debugging)
+    if "RXMD_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["RXMD_BENCH_DEVICE"])
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     vp = vprocs_for(world)
     mc = tuple(a.cells * v for v in vp)
 
@@ -109,20 +115,23 @@ def main():
         from rxmd_amd.comm import TorchTransport
         dev = torch.device("cuda", local)
         cap = int(natoms * 0.45 * 6) + (1 << 20)          # widest message: the 13 A ghost shell of one stage, 6 doubles per atom
-        tr = TorchTransport(mode="device", device=dev, capacity_doubles=cap)
-        ok = torch.ones(1, device=dev)
-        try:                                               # one ring round on the device path before trusting it
-            peer_to, peer_from = (rank + 1) % world, (rank - 1) % world
-            tr.send_t[:8] = float(rank)
-            n = tr._exchange(None, peer_to, 0, 8, peer_from, 0, cap)
-            if n != 8 or float(tr.recv_t[0].item()) != float(peer_from):
+        if backend == "nccl":
+            tr = TorchTransport(mode="device", device=dev, capacity_doubles=cap)
+            ok = torch.ones(1, device=dev)
+            try:                                           # one ring round on the device path before trusting it
+                peer_to, peer_from = (rank + 1) % world, (rank - 1) % world
+                tr.send_t[:8] = float(rank)
+                n = tr._exchange(None, peer_to, 0, 8, peer_from, 0, cap)
+                if n != 8 or float(tr.recv_t[0].item()) != float(peer_from):
+                    ok[0] = 0
+            except Exception:
                 ok[0] = 0
-        except Exception:
-            ok[0] = 0
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() < 1:                                  # fall back to host-staged messages over gloo
-            gl = dist.new_group(backend="gloo")
-            tr = TorchTransport(mode="staged", group=gl, device=dev, capacity_doubles=cap)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1:                              # fall back to host-staged messages over gloo
+                gl = dist.new_group(backend="gloo")
+                tr = TorchTransport(mode="staged", group=gl, device=dev, capacity_doubles=cap)
+        else:
+            tr = TorchTransport(mode="staged", device=dev, capacity_doubles=cap)
         transport_mode = tr.mode
         tr.attach(eng)
     eng.set_atoms_rxff(rec)
@@ -141,7 +150,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = eng.stats()

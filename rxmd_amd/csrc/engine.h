@@ -98,6 +98,7 @@ struct Engine {
   double *q = nullptr, *qsfp = nullptr, *qsfv = nullptr;
   int *type = nullptr; long long *gid = nullptr;
   double2 *qst = nullptr, *hst = nullptr, *gst = nullptr;  // (qs,qt) (hs,ht) (gs,gt) interleaved
+  double2 *sall = nullptr, *sgh = nullptr, *wall = nullptr, *wgh = nullptr;  // qeq_mode 1: row sums H.(qs,qt), H.(hs,ht): all columns / ghost columns
   int *gsrc = nullptr, *groot = nullptr;                    // ghost -> source index on sender ; -> resident root (self exchange)
   int *rootperm = nullptr;                                  // cell-sorted position -> resident that owns the value (ghosts resolved)
   double2 *xs = nullptr;                                    // cell-sorted gather copy of a QEq vector pair (residents+ghosts)

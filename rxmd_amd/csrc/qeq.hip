@@ -46,11 +46,14 @@ __device__ inline void block_store_partials(double (&acc)[NC], double *partials,
   }
 }
 
-template <int MODE>
+// STORE (qeq_mode 1): additionally keep the raw row sums (all columns / ghost columns) so that the next gradient and Est
+// follow from  H.(q + l h) = H.q + l H.h  with N-sized vector kernels instead of a second matrix pass.
+template <int MODE, bool STORE>
 __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
-                                               const double *__restrict__ scal, double *__restrict__ partials) {
+                                               const double *__restrict__ scal, double *__restrict__ partials,
+                                               double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int wave0 = blockIdx.x * wpb + (threadIdx.x >> 6);
@@ -76,12 +79,13 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
         const double2 v = xv[e[u] & NB10_IDX_MASK];
         as += h[u] * v.x;
         at += h[u] * v.y;
-        if (MODE == MODE_GRAD && (e[u] & NB10_GHOST)) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
+        if ((MODE == MODE_GRAD || STORE) && (e[u] & NB10_GHOST)) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
       }
     }
     as = wave_sum(as); at = wave_sum(at);
-    if (MODE == MODE_GRAD) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+    if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
     if (lane == 0) {
+      if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
       const DevAtomP ap = ff.atom[type[row]];
       if (MODE == MODE_HSH) {
         const double2 hv = hst[row], gv = gst[row];
@@ -200,6 +204,52 @@ __global__ void __launch_bounds__(256) k_update_qst(int N, const double *__restr
   acc[0] = s; acc[1] = t;
   block_store_partials<4>(acc, partials, 4);
 }
+// ---- qeq_mode 1 ---------------------------------------------------------------------------------
+// qs += l1 hs, qt += l2 ht and the same update of the stored row sums: H.qs += l1 H.hs, H.qt += l2 H.ht
+__global__ void __launch_bounds__(256) k_update_qst_sums(int N, const double *__restrict__ scal, const double2 *__restrict__ hst, double2 *__restrict__ qst,
+                                                          const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
+                                                          double *__restrict__ partials) {
+  const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
+  double acc[4] = {0, 0, 0, 0};
+  double s = 0.0, t = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    double2 qv = qst[i];
+    const double2 hv = hst[i];
+    qv.x = qv.x + l1 * hv.x; qv.y = qv.y + l2 * hv.y;
+    qst[i] = qv;
+    double2 a = sall[i], g = sgh[i];
+    const double2 wa = wall[i], wg = wgh[i];
+    a.x += l1 * wa.x; a.y += l2 * wa.y; g.x += l1 * wg.x; g.y += l2 * wg.y;
+    sall[i] = a; sgh[i] = g;
+    s += qv.x; t += qv.y;
+  }
+  s = wave_sum(s); t = wave_sum(t);
+  acc[0] = s; acc[1] = t;
+  block_store_partials<4>(acc, partials, 4);
+}
+// gradient, q, Gnew and Est from the stored row sums (the arithmetic of get_gradient / get_hsh, qeq.F90:297-306,349-356)
+__global__ void __launch_bounds__(256) k_grad_from_sums(int N, DevFF ff, const double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ qst,
+                                                         const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double2 *__restrict__ gst, double *__restrict__ q,
+                                                         double *__restrict__ partials) {
+  const double mu = scal[S_MU];
+  double acc[4] = {0, 0, 0, 0};
+  double g1s = 0.0, g2s = 0.0, es = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const DevAtomP ap = ff.atom[type[i]];
+    const double2 qv = qst[i], a = sall[i], g = sgh[i];
+    const double g1 = -ap.chi - ap.eta * qv.x - a.x, g2 = -1.0 - ap.eta * qv.y - a.y;
+    gst[i] = make_double2(g1, g2);
+    const double qi = qv.x - mu * qv.y;
+    q[i] = qi;
+    const double hq_all = a.x - mu * a.y, hq_res = (a.x - g.x) - mu * (a.y - g.y);
+    g1s += g1 * g1; g2s += g2 * g2;
+    es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
+  }
+  g1s = wave_sum(g1s); g2s = wave_sum(g2s); es = wave_sum(es);
+  acc[0] = g1s; acc[1] = g2s; acc[2] = es;
+  block_store_partials<4>(acc, partials, 4);
+}
+
 // q = qs - mu*qt (qeq.F90:150)
 __global__ void k_apply_q(int N, const double *__restrict__ scal, const double2 *__restrict__ qst, double *__restrict__ q) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,7 +305,9 @@ void Engine::qeq() {
   k_qeq_init<<<nblk(N, 256), 256, 0, stream>>>(N, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
   RX_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 32, stream));
   sorted_copy(qst);                                                                             // QCOPY1, qeq.F90:86
-  k_spmv<MODE_GRAD><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials);
+  const bool onepass = (cfg.qeq_mode == 1);
+  if (onepass) k_spmv<MODE_GRAD, true><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, sall, sgh);
+  else k_spmv<MODE_GRAD, false><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, nullptr, nullptr);
   reduce(3, rb);
   k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
@@ -269,15 +321,29 @@ void Engine::qeq() {
     GEst2 = Est;
     sorted_copy(hst);                                                                            // QCOPY2, qeq.F90:93,164
     hipEventRecord(ev[2], stream);
-    k_spmv<MODE_HSH><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials);
+    if (onepass) k_spmv<MODE_HSH, true><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, wall, wgh);
+    else k_spmv<MODE_HSH, false><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, nullptr, nullptr);
     hipEventRecord(ev[3], stream);
     reduce(1, rb);
+    if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
+      k_update_qst_sums<<<vb, 256, 0, stream>>>(N, scal, hst, qst, wall, wgh, sall, sgh, partials);
+      reduce(2, vb);
+      k_grad_from_sums<<<vb, 256, 0, stream>>>(N, dff, scal, type, qst, sall, sgh, gst, q, partials);
+      reduce(3, vb);
+      k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);
+      RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipStreamSynchronize(stream));
+      Est = h_scal[S_EST];
+      hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
+      st.spmv_launches += 1;
+      continue;
+    }
     k_update_qst<<<vb, 256, 0, stream>>>(N, scal, hst, qst, partials);
     reduce(2, vb);
     k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);
     sorted_copy(qst);                                                                            // QCOPY1, qeq.F90:153
     hipEventRecord(ev[4], stream);
-    k_spmv<MODE_GRAD><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials);
+    k_spmv<MODE_GRAD, false><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, nullptr, nullptr);
     hipEventRecord(ev[5], stream);
     reduce(3, rb);
     k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);

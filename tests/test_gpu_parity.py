@@ -235,3 +235,19 @@ def test_full_size_properties_rdx_1m():
     st = e.stats()
     assert st["max_n10"] == 447 and st["max_nb"] == 12          # RDX crystal statistics
     e.close()
+
+
+@pytest.mark.parametrize("case,mc", [("rdx168", (1, 1, 1)), ("rdx222", (2, 2, 2))])
+def test_one_pass_qeq_mode_reaches_the_same_fixed_point(case, mc):
+    """qeq_mode=1 (one matrix pass per CG iteration, gradient/Est by recurrence on stored row sums) is an opt-in
+    re-association of the reference algebra: at tight tolerance it must land on the reference's charges and forces."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    o = _oracle(case, mc, **kw); o.qeq(); o.force()
+    e = _engine(case, mc, qeq_mode=1, **kw)
+    it, est = e.QEq(); pe = e.FORCE(); a = e.atoms()
+    assert q_err(a["q"], o.charges()) <= QTOL
+    assert f_err(a["f"], o.forces()) <= FTOL
+    assert e_err(pe, o.energy()) <= ETOL
+    assert abs(est - o.trace()[-1, 0]) <= 1e-9 * abs(est)
+    assert e.stats()["spmv_launches"] == it          # one pass per iteration
+    e.close()
