@@ -75,7 +75,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   for (int t = 1; t <= ff.nso; ++t) { dthm[t] = dt * 0.5 / ff.atom[t].mass; hmas[t] = 0.5 * ff.atom[t].mass; }  // init.F90:105-108
   ff.build_taper(10.0);                           // rctap0, module.F90:281 (no PQEq)
   MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
-  if (MAXNB > 250) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 250");
+  if (MAXNB > 31) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 31 (the wavefront-per-centre kernels stage the bond slots of two atoms in one 64-lane wavefront; the reference uses 30)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw EngineError(RXMD_E_HIP, "no HIP device visible: this engine has no CPU path");
   RX_HIP(hipSetDevice(cfg.device));
