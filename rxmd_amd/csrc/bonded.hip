@@ -1,7 +1,8 @@
 // bonded.hip -- bonded energy terms of FORCE (reference src/pot.F90) as own-slot accumulation kernels.
 //   Ebond (pot.F90:926-977) + Elnpr (pot.F90:148-316) -> k_ebond_elnpr
-//   E3b   (pot.F90:319-557)                           -> k_e3b
-//   E4b   (pot.F90:980-1227)                          -> k_e4b   (every torsion visited from both ends)
+//   E3b   (pot.F90:319-557)                           -> k_e3b   (thread per centre atom)
+//   E4b   (pot.F90:980-1227)                          -> k_e4b   (wavefront per two centre atoms, ballot-compacted work queue;
+//                                                                  every torsion visited from both ends)
 //   Ehb   (pot.F90:559-673)                           -> k_ehb   (one wavefront per donor atom)
 // The reference scatters every derivative at once with atomics (ForceB/ForceBbo/ForceA3/ForceA4,
 // pot.F90:1276-1521).  Here a thread owns one centre atom and accumulates ONLY into that atom's own
@@ -139,12 +140,6 @@ __device__ inline void wave_lds_sync() {
 constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages in LDS (MAXNEIGHBS = 30; slot 31 = the centre atom itself)
 
 // ------------------------------------------------------------------------------------------------
-// Valence angle + penalty + three-body conjugation.  One wavefront owns TWO consecutive centre atoms j, lane t = (g<<5|slot)
-// owns the accumulators of bond `slot` of atom g (slot 31: the centre atom itself).  Phase A enumerates the neighbour pairs
-// (i1 < k1), applies the reference's cut-offs (pot.F90:372-386,401-402) and compacts the survivors into an LDS queue with a
-// ballot; phase B evaluates 64 surviving angles at a time; every owner lane then adds the results that name its bond, in
-// queue order (no atomics, scheduling independent).  The terms ForceBbo applies to EVERY bond of j (pot.F90:526-532) are
-// linear in their coefficients, so they are summed over the angles first and applied once per bond.
 __global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
@@ -153,192 +148,114 @@ __global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int 
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
-  __shared__ double s_bo[4][64], s_ep[4][64], s_eco[4][64], s_sbo[4][64], s_rx[4][64], s_ry[4][64], s_rz[4][64], s_rn[4][64];
-  __shared__ int s_ty[4][64];
-  __shared__ int s_q[4][128];                    // surviving angles: g<<10 | i1<<5 | k1
-  __shared__ double s_out[4][64][16];            // i-side (cf1, cdn, fx, fy, fz), k-side (same), centre (S_d1, S_v6, S_v5, fx, fy, fz)
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int jbase = (blockIdx.x * 4 + w) * 2;
-  if (jbase >= N) return;
-  const int g_me = lane >> 5, sl_me = lane & 31;
-  const int j_me = jbase + g_me;
-  const bool has_me = j_me < N;
-  const int nj_me = has_me ? min(nbrcnt[j_me], WSLOT) : 0;
-  const int tj_me = has_me ? type[j_me] : 1;
-  const DevAtomP aj = ff.atom[tj_me];
-  const double xj = has_me ? x[j_me] : 0.0, yj = has_me ? y[j_me] : 0.0, zj = has_me ? z[j_me] : 0.0;
-  double b8 = 0.0, sb1 = 0.0, bme = 0.0;
-  if (sl_me < nj_me) {
-    const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
-    const int i = nbr[o], ti = type[i];
-    const double rx = x[i] - xj, ry = y[i] - yj, rz = z[i] - zj;      // r_i - r_j
-    bme = bo0[o];
-    s_ty[w][lane] = ti; s_bo[w][lane] = bme; s_ep[w][lane] = epen[o]; s_eco[w][lane] = ecoa[o];
-    s_sbo[w][lane] = delta[i] + ff.atom[ti].Val;                       // sum_BOi, pot.F90:479-480
-    s_rx[w][lane] = rx; s_ry[w][lane] = ry; s_rz[w][lane] = rz; s_rn[w][lane] = sqrt(rx * rx + ry * ry + rz * rz);
-    const double b2 = bme * bme, b4 = b2 * b2;
-    b8 = b4 * b4;                                                      // BO**8, pot.F90:362
-    sb1 = bo2[o] + bo3[o];
-  }
-  // sums over the slots of one atom = over one 32-lane half, in a fixed butterfly order
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) { b8 += __shfl_xor(b8, o, 64); sb1 += __shfl_xor(sb1, o, 64); }
-  wave_lds_sync();
-  // per-centre quantities (every lane of the half computes the same values)
-  const double dlj = has_me ? delta[j_me] : 0.0, nlpj = has_me ? nlp[j_me] : 0.0, dDj = has_me ? dDlp[j_me] : 0.0;
-  const double prod_SBO = exp(-b8);
-  const double sum_SBO1 = sb1;
-  const double delta_ang = dlj + aj.Val - aj.Valangle;
-  const double exp_pen3 = exp(-ff.ppen3 * dlj), exp_pen4 = exp(ff.ppen4 * dlj);
-  const double trm34 = 1.0 + exp_pen3 + exp_pen4;
-  const double fn9 = (2.0 + exp_pen3) / trm34;
-  const double Cf9j = (-ff.ppen3 * exp_pen3 * trm34 - (2.0 + exp_pen3) * (-ff.ppen3 * exp_pen3 + ff.ppen4 * exp_pen4)) / (trm34 * trm34);
-  const double delta_val = dlj + aj.Val - aj.Valval;
-  const double exp_coa2 = exp(ff.pcoa2 * delta_val);
-  const double exp6 = exp(ff.pval6 * delta_ang);
-  const int njg[2] = {__shfl(nj_me, 0, 64), __shfl(nj_me, 32, 64)};
-  const int tjg[2] = {__shfl(tj_me, 0, 64), __shfl(tj_me, 32, 64)};
-
-  // per-centre scalars of both atoms, visible to every lane
-  const double cv[9] = {delta_ang, prod_SBO, sum_SBO1, nlpj, dDj, fn9, Cf9j, exp_coa2, exp6};
-  double cb[9][2];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) { cb[c][0] = __shfl(cv[c], 0, 64); cb[c][1] = __shfl(cv[c], 32, 64); }
-
-  double a_cf = 0.0, a_cd = 0.0, a_fx = 0.0, a_fy = 0.0, a_fz = 0.0;   // bond owner sums; lane slot 31: a_cf=S_d1, a_cd=S_v6, a_v5, force
-  double a_v5 = 0.0;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
-  int qn = 0;
-
-  auto evaluate = [&](int cnt) {
-    double o[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) o[c] = 0.0;
-    if (lane < cnt) {
-      const int key = s_q[w][lane];
-      const int g = key >> 10, i1 = (key >> 5) & 31, k1 = key & 31;
-      const int si = g * 32 + i1, sk = g * 32 + k1;
-      // the centre's scalars were broadcast from lane 0 / lane 32 above (shuffles must not sit in a divergent branch)
-      const double c_delta_ang = g ? cb[0][1] : cb[0][0], c_prod = g ? cb[1][1] : cb[1][0], c_sbo1 = g ? cb[2][1] : cb[2][0];
-      const double c_nlp = g ? cb[3][1] : cb[3][0], c_dD = g ? cb[4][1] : cb[4][0], c_fn9 = g ? cb[5][1] : cb[5][0], c_Cf9 = g ? cb[6][1] : cb[6][0];
-      const double c_coa2 = g ? cb[7][1] : cb[7][0], c_exp6 = g ? cb[8][1] : cb[8][0];
-      const DevAtomP ac = ff.atom[tjg[g]];
-      const double BOij_f = s_bo[w][si], BOjk_f = s_bo[w][sk];
-      const double BOij = BOij_f - cutof2_esub, BOjk = BOjk_f - cutof2_esub;
-      const int inxn = ff.inxn3[(s_ty[w][si] * ff.n1 + tjg[g]) * ff.n1 + s_ty[w][sk]];
-      const DevAngleP ap = ff.angle[inxn];
-      const V3 rij = {s_rx[w][si], s_ry[w][si], s_rz[w][si]};             // r_i - r_j
-      const V3 rjk = {-s_rx[w][sk], -s_ry[w][sk], -s_rz[w][sk]};          // r_j - r_k
-      const double nij = s_rn[w][si], njk = s_rn[w][sk];
-      double cos_ijk = -dot(rij, rjk) / (nij * njk);
-      if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
-      if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
-      const double theta_ijk = acos(cos_ijk), sin_ijk = sqrt((1.0 - cos_ijk) * (1.0 + cos_ijk));
-      const double BOij_p4 = pow(BOij, ap.pval4), exp3ij = exp(-ac.pval3 * BOij_p4), fn7ij = 1.0 - exp3ij;
-      const double BOjk_p4 = pow(BOjk, ap.pval4), exp3jk = exp(-ac.pval3 * BOjk_p4), fn7jk = 1.0 - exp3jk;
-      const double exp7 = exp(-ap.pval7 * c_delta_ang), trm8 = 1.0 + c_exp6 + exp7;
-      const double fn8j = ac.pval5 - (ac.pval5 - 1.0) * (2.0 + c_exp6) / trm8;
-      const double SBO = c_sbo1 + (1.0 - c_prod) * (-c_delta_ang - ff.pval8 * c_nlp);
-      double SBO2 = 0.0, CSBO2 = 0.0;
-      if (SBO > 0.0 && SBO <= 1.0) { SBO2 = pow(SBO, ff.pval9); CSBO2 = ff.pval9 * pow(SBO, ff.pval9 - 1.0); }
-      else if (SBO > 1.0 && SBO <= 2.0) { SBO2 = 2.0 - pow(2.0 - SBO, ff.pval9); CSBO2 = ff.pval9 * pow(2.0 - SBO, ff.pval9 - 1.0); }
-      else if (SBO > 2.0) SBO2 = 2.0;
-      const double ex10 = exp(-ff.pval10 * (2.0 - SBO2));
-      const double theta0 = PI_ - ap.theta00 * (1.0 - ex10);
-      const double theta_diff = theta0 - theta_ijk;
-      const double exp2 = exp(-ap.pval2 * theta_diff * theta_diff);
-      e5 += fn7ij * fn7jk * fn8j * (ap.pval1 - ap.pval1 * exp2);
-      const double Cf7ij = ac.pval3 * ap.pval4 * (BOij_p4 / BOij) * exp3ij;                 // BO**(pval4-1) = BO**pval4 / BO
-      const double Cf7jk = ac.pval3 * ap.pval4 * (BOjk_p4 / BOjk) * exp3jk;
-      const double Cf8j = (1.0 - ac.pval5) / (trm8 * trm8) * (ff.pval6 * c_exp6 * trm8 - (2.0 + c_exp6) * (ff.pval6 * c_exp6 - ap.pval7 * exp7));
-      const double Ctheta0 = ff.pval10 * ap.theta00 * ex10;
-      const double dSBO1 = -8.0 * c_prod * (c_delta_ang + ff.pval8 * c_nlp);
-      const double dSBO2 = (c_prod - 1.0) * (1.0 - ff.pval8 * c_dD);
-      const double CEval1 = Cf7ij * fn7jk * fn8j * ap.pval1 * (1.0 - exp2);
-      const double CEval2 = fn7ij * Cf7jk * fn8j * ap.pval1 * (1.0 - exp2);
-      const double CEval3 = fn7ij * fn7jk * Cf8j * ap.pval1 * (1.0 - exp2);
-      const double CEval4 = 2.0 * ap.pval1 * ap.pval2 * fn7ij * fn7jk * fn8j * exp2 * theta_diff;
-      const double CEval5 = CEval4 * Ctheta0 * CSBO2;
-      const double CEval6 = CEval5 * dSBO1, CEval7 = CEval5 * dSBO2, CEval8 = CEval4 / sin_ijk;
-      const double PEpen = ap.ppen1 * c_fn9 * s_ep[w][si] * s_ep[w][sk];                   // pot.F90:460-466
-      e6 += PEpen;
-      const double CEpen1 = c_Cf9 / c_fn9 * PEpen, CEpen2 = -2.0 * ff.ppen2 * (BOij - 2.0) * PEpen, CEpen3 = -2.0 * ff.ppen2 * (BOjk - 2.0) * PEpen;
-      const double ui = -BOij + s_sbo[w][si], uk = -BOjk + s_sbo[w][sk];
-      const double PEcoa = ap.pcoa1 / (1.0 + c_coa2) * s_eco[w][si] * s_eco[w][sk];       // pot.F90:479-489
-      e7 += PEcoa;
-      const double CEcoa1 = -2.0 * ff.pcoa4 * (BOij - 1.5) * PEcoa, CEcoa2 = -2.0 * ff.pcoa4 * (BOjk - 1.5) * PEcoa;
-      const double CEcoa3 = -ff.pcoa2 * c_coa2 / (1.0 + c_coa2) * PEcoa;
-      const double CEcoa4 = -2.0 * ff.pcoa3 * ui * PEcoa, CEcoa5 = -2.0 * ff.pcoa3 * uk * PEcoa;
-      V3 fi, fk;
-      angle_forces(CEval8, rij, nij, rjk, njk, fi, fk);
-      o[0] = CEpen2 + CEcoa1 - CEcoa4 + CEval1; o[1] = CEcoa4; o[2] = fi.x; o[3] = fi.y; o[4] = fi.z;       // bond i-j, cdbnd(i), f(i)
-      o[5] = CEpen3 + CEcoa2 - CEcoa5 + CEval2; o[6] = CEcoa5; o[7] = fk.x; o[8] = fk.y; o[9] = fk.z;       // bond j-k, cdbnd(k), f(k)
-      o[10] = CEpen1 + CEcoa3 + CEval3 + CEval7; o[11] = CEval6; o[12] = CEval5;                             // every bond of j
-      o[13] = -(fi.x + fk.x); o[14] = -(fi.y + fk.y); o[15] = -(fi.z + fk.z);                                // f(j)
+  if (j < N) {
+    const int tj = type[j], nj = nbrcnt[j];
+    const DevAtomP aj = ff.atom[tj];
+    const double xj = x[j], yj = y[j], zj = z[j];
+    double sum_BO8 = 0.0, sum_SBO1 = 0.0;
+    for (int n1 = 0; n1 < nj; ++n1) {
+      const size_t o = static_cast<size_t>(n1) * NB + j;
+      const double b = bo0[o], b2 = b * b, b4 = b2 * b2;
+      sum_BO8 -= b4 * b4;                                                  // BO**8, pot.F90:362
+      sum_SBO1 += bo2[o] + bo3[o];
     }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) s_out[w][lane][c] = o[c];
-    wave_lds_sync();
-    for (int e = 0; e < cnt; ++e) {
-      const int ke = s_q[w][e];
-      if ((ke >> 10) != g_me) continue;
-      if (sl_me == 31) { a_cf += s_out[w][e][10]; a_cd += s_out[w][e][11]; a_v5 += s_out[w][e][12]; a_fx += s_out[w][e][13]; a_fy += s_out[w][e][14]; a_fz += s_out[w][e][15]; continue; }
-      if (((ke >> 5) & 31) == sl_me) { a_cf += s_out[w][e][0]; a_cd += s_out[w][e][1]; a_fx += s_out[w][e][2]; a_fy += s_out[w][e][3]; a_fz += s_out[w][e][4]; }
-      if ((ke & 31) == sl_me) { a_cf += s_out[w][e][5]; a_cd += s_out[w][e][6]; a_fx += s_out[w][e][7]; a_fy += s_out[w][e][8]; a_fz += s_out[w][e][9]; }
-    }
-    wave_lds_sync();
-  };
-
-  for (int g = 0; g < 2; ++g) {
-    const int nj = njg[g];
-    const int total = nj * nj;
-    for (int c0 = 0; c0 < total; c0 += 64) {
-      const int c = c0 + lane;
-      bool go = false;
-      int i1 = 0, k1 = 0;
-      if (c < total) {
-        i1 = c / nj; k1 = c - i1 * nj;
-        if (i1 < k1) {
-          const double bi = s_bo[w][g * 32 + i1], bk = s_bo[w][g * 32 + k1];
-          go = (bi - cutof2_esub > 0.0) && (bk - cutof2_esub > 0.0) && (bi * bk > cutof2_esub) &&
-               (ff.inxn3[(s_ty[w][g * 32 + i1] * ff.n1 + tjg[g]) * ff.n1 + s_ty[w][g * 32 + k1]] != 0);
-        }
-      }
-      const unsigned long long m = __ballot(go);
-      if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = (g << 10) | (i1 << 5) | k1;
-      qn += __popcll(m);
-      wave_lds_sync();
-      if (qn >= 64) {
-        evaluate(64);
-        const int rest = qn - 64;
-        const int v = (lane < rest) ? s_q[w][64 + lane] : 0;
-        wave_lds_sync();
-        if (lane < rest) s_q[w][lane] = v;
-        wave_lds_sync();
-        qn = rest;
+    const double prod_SBO = exp(sum_BO8);
+    const double dlj = delta[j];
+    const double delta_ang = dlj + aj.Val - aj.Valangle;
+    const double nlpj = nlp[j], dDj = dDlp[j];
+    // per-centre factors of the penalty and conjugation terms (global parameters, pot.F90:460-462,481-483)
+    const double exp_pen3 = exp(-ff.ppen3 * dlj), exp_pen4 = exp(ff.ppen4 * dlj);
+    const double trm34 = 1.0 + exp_pen3 + exp_pen4;
+    const double fn9 = (2.0 + exp_pen3) / trm34;
+    const double Cf9j = (-ff.ppen3 * exp_pen3 * trm34 - (2.0 + exp_pen3) * (-ff.ppen3 * exp_pen3 + ff.ppen4 * exp_pen4)) / (trm34 * trm34);
+    const double delta_val = dlj + aj.Val - aj.Valval;
+    const double exp_coa2 = exp(ff.pcoa2 * delta_val);
+    const double exp6 = exp(ff.pval6 * delta_ang);
+    // sums over all angles of the terms that ForceBbo(j,n1,...) applies to EVERY bond of j (pot.F90:526-532)
+    double S_d1 = 0.0, S_v6 = 0.0, S_v5 = 0.0;
+    V3 fself = {0.0, 0.0, 0.0};
+    for (int i1 = 0; i1 < nj - 1; ++i1) {
+      const size_t oi = static_cast<size_t>(i1) * NB + j;
+      const double BOij_f = bo0[oi], BOij = BOij_f - cutof2_esub;
+      if (!(BOij > 0.0)) continue;
+      const int i = nbr[oi], ti = type[i];
+      const V3 rij = {x[i] - xj, y[i] - yj, z[i] - zj};
+      const double nij = sqrt(dot(rij, rij));
+      for (int k1 = i1 + 1; k1 < nj; ++k1) {
+        const size_t ok = static_cast<size_t>(k1) * NB + j;
+        const double BOjk_f = bo0[ok], BOjk = BOjk_f - cutof2_esub;
+        if (!(BOjk > 0.0)) continue;
+        if (!(BOij_f * BOjk_f > cutof2_esub)) continue;
+        const int k = nbr[ok], tk = type[k];
+        const int inxn = ff.inxn3[(ti * ff.n1 + tj) * ff.n1 + tk];
+        if (inxn == 0) continue;
+        const DevAngleP ap = ff.angle[inxn];
+        const V3 rjk = {xj - x[k], yj - y[k], zj - z[k]};
+        const double njk = sqrt(dot(rjk, rjk));
+        double cos_ijk = -dot(rij, rjk) / (nij * njk);
+        if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
+        if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
+        const double theta_ijk = acos(cos_ijk), sin_ijk = sin(theta_ijk);
+        const double BOij_p4 = pow(BOij, ap.pval4), exp3ij = exp(-aj.pval3 * BOij_p4), fn7ij = 1.0 - exp3ij;
+        const double BOjk_p4 = pow(BOjk, ap.pval4), exp3jk = exp(-aj.pval3 * BOjk_p4), fn7jk = 1.0 - exp3jk;
+        const double exp7 = exp(-ap.pval7 * delta_ang), trm8 = 1.0 + exp6 + exp7;
+        const double fn8j = aj.pval5 - (aj.pval5 - 1.0) * (2.0 + exp6) / trm8;
+        const double SBO = sum_SBO1 + (1.0 - prod_SBO) * (-delta_ang - ff.pval8 * nlpj);
+        double SBO2 = 0.0, CSBO2 = 0.0;
+        if (SBO > 0.0 && SBO <= 1.0) { SBO2 = pow(SBO, ff.pval9); CSBO2 = ff.pval9 * pow(SBO, ff.pval9 - 1.0); }
+        else if (SBO > 1.0 && SBO <= 2.0) { SBO2 = 2.0 - pow(2.0 - SBO, ff.pval9); CSBO2 = ff.pval9 * pow(2.0 - SBO, ff.pval9 - 1.0); }
+        else if (SBO > 2.0) SBO2 = 2.0;
+        const double ex10 = exp(-ff.pval10 * (2.0 - SBO2));
+        const double theta0 = PI_ - ap.theta00 * (1.0 - ex10);
+        const double theta_diff = theta0 - theta_ijk;
+        const double exp2 = exp(-ap.pval2 * theta_diff * theta_diff);
+        e5 += fn7ij * fn7jk * fn8j * (ap.pval1 - ap.pval1 * exp2);
+        const double Cf7ij = aj.pval3 * ap.pval4 * pow(BOij, ap.pval4 - 1.0) * exp3ij;
+        const double Cf7jk = aj.pval3 * ap.pval4 * pow(BOjk, ap.pval4 - 1.0) * exp3jk;
+        const double Cf8j = (1.0 - aj.pval5) / (trm8 * trm8) * (ff.pval6 * exp6 * trm8 - (2.0 + exp6) * (ff.pval6 * exp6 - ap.pval7 * exp7));
+        const double Ctheta0 = ff.pval10 * ap.theta00 * ex10;
+        const double dSBO1 = -8.0 * prod_SBO * (delta_ang + ff.pval8 * nlpj);
+        const double dSBO2 = (prod_SBO - 1.0) * (1.0 - ff.pval8 * dDj);
+        const double CEval1 = Cf7ij * fn7jk * fn8j * ap.pval1 * (1.0 - exp2);
+        const double CEval2 = fn7ij * Cf7jk * fn8j * ap.pval1 * (1.0 - exp2);
+        const double CEval3 = fn7ij * fn7jk * Cf8j * ap.pval1 * (1.0 - exp2);
+        const double CEval4 = 2.0 * ap.pval1 * ap.pval2 * fn7ij * fn7jk * fn8j * exp2 * theta_diff;
+        const double CEval5 = CEval4 * Ctheta0 * CSBO2;
+        const double CEval6 = CEval5 * dSBO1, CEval7 = CEval5 * dSBO2, CEval8 = CEval4 / sin_ijk;
+        // penalty, pot.F90:460-476
+        const double PEpen = ap.ppen1 * fn9 * epen[oi] * epen[ok];
+        e6 += PEpen;
+        const double CEpen1 = Cf9j / fn9 * PEpen, CEpen2 = -2.0 * ff.ppen2 * (BOij - 2.0) * PEpen, CEpen3 = -2.0 * ff.ppen2 * (BOjk - 2.0) * PEpen;
+        // three-body conjugation, pot.F90:479-497
+        const double sum_BOi = delta[i] + ff.atom[ti].Val, sum_BOk = delta[k] + ff.atom[tk].Val;
+        const double ui = -BOij + sum_BOi, uk = -BOjk + sum_BOk;
+        const double PEcoa = ap.pcoa1 / (1.0 + exp_coa2) * ecoa[oi] * ecoa[ok];
+        e7 += PEcoa;
+        const double CEcoa1 = -2.0 * ff.pcoa4 * (BOij - 1.5) * PEcoa, CEcoa2 = -2.0 * ff.pcoa4 * (BOjk - 1.5) * PEcoa;
+        const double CEcoa3 = -ff.pcoa2 * exp_coa2 / (1.0 + exp_coa2) * PEcoa;
+        const double CEcoa4 = -2.0 * ff.pcoa3 * ui * PEcoa, CEcoa5 = -2.0 * ff.pcoa3 * uk * PEcoa;
+        // accumulate, pot.F90:509-541
+        cf1[oi] += CEpen2 + CEcoa1 - CEcoa4 + CEval1;      // ForceB on bond i-j
+        cf1[ok] += CEpen3 + CEcoa2 - CEcoa5 + CEval2;      // ForceB on bond j-k
+        S_d1 += CEpen1 + CEcoa3 + CEval3 + CEval7; S_v6 += CEval6; S_v5 += CEval5;
+        cdn[oi] += CEcoa4; cdn[ok] += CEcoa5;              // cdbnd(i), cdbnd(k)
+        V3 fi, fk;
+        angle_forces(CEval8, rij, nij, rjk, njk, fi, fk);
+        fnx[oi] += fi.x; fny[oi] += fi.y; fnz[oi] += fi.z;
+        fnx[ok] += fk.x; fny[ok] += fk.y; fnz[ok] += fk.z;
+        fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z;
       }
     }
+    if (S_d1 != 0.0 || S_v6 != 0.0 || S_v5 != 0.0)
+      for (int n1 = 0; n1 < nj; ++n1) {
+        const size_t o = static_cast<size_t>(n1) * NB + j;
+        cf1[o] += S_d1 + S_v6 * ipow7(bo0[o]); cf2[o] += S_v5; cf3[o] += S_v5;
+      }
+    fx[j] += fself.x; fy[j] += fself.y; fz[j] += fself.z;
   }
-  if (qn > 0) evaluate(qn);
-
-  // the per-centre sums sit in lane slot 31 of each half
-  const int csrc = g_me * 32 + 31;
-  const double S_d1 = __shfl(a_cf, csrc, 64), S_v6 = __shfl(a_cd, csrc, 64), S_v5 = __shfl(a_v5, csrc, 64);
-  if (sl_me < nj_me) {
-    const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
-    const double extra = S_d1 + S_v6 * ipow7(bme);
-    if (a_cf != 0.0 || extra != 0.0) cf1[o] += a_cf + extra;
-    if (S_v5 != 0.0) { cf2[o] += S_v5; cf3[o] += S_v5; }
-    if (a_cd != 0.0) cdn[o] += a_cd;
-    if (a_fx != 0.0 || a_fy != 0.0 || a_fz != 0.0) { fnx[o] += a_fx; fny[o] += a_fy; fnz[o] += a_fz; }
-  }
-  if (sl_me == 31 && has_me) { fx[j_me] += a_fx; fy[j_me] += a_fy; fz[j_me] += a_fz; }
-  e5 = wave_sum_b(e5); e6 = wave_sum_b(e6); e7 = wave_sum_b(e7);
-  if (lane == 0) {
-    if (e5 != 0.0) atomicAdd(pe + 5, e5);
-    if (e6 != 0.0) atomicAdd(pe + 6, e6);
-    if (e7 != 0.0) atomicAdd(pe + 7, e7);
-  }
+  block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
 }
 
 // Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to i,j,k,l.
@@ -661,7 +578,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
 void Engine::bonded_energies() {
   double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
   k_ebond_elnpr<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, dDlp, cf1, cf2, cf3, cdn, ecoa, pe_d);
-  k_e3b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
   k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
