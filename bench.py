@@ -71,7 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=ATOMS_PER_GPU_CELLS, help="RDX unit cells per edge per GPU (18 -> 979,776 atoms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--qeq-mode", type=int, default=0)
+    ap.add_argument("--qeq-mode", type=int, default=1, help="1: one matrix pass per CG iteration (gradient by recurrence; default), 0: the reference's two passes")
+    ap.add_argument("--alt-steps", type=int, default=3, help="after the timed region, time this many steps in the other qeq_mode and report them under \"alt\" (0 = skip)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent periodic replicas instead of one decomposed box")
     a = ap.parse_args()
 
@@ -155,6 +156,18 @@ def main():
         dt = float(t.item())
     st = eng.stats()
     en = eng.energy()
+    alt = None
+    if a.alt_steps > 0 and world == 1:           # the other QEq algebra on the same trajectory, reported beside the headline
+        eng.set_qeq_mode(1 - a.qeq_mode)
+        eng.step(1)
+        eng.reset_timers()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        eng.step(a.alt_steps)
+        torch.cuda.synchronize(); dta = time.perf_counter() - t1
+        sa = eng.stats()                          # the reference's exit test makes the iteration count jump from step to step: quote it
+        alt = {"qeq_mode": 1 - a.qeq_mode, "steps": a.alt_steps, "ms_per_step": 1e3 * dta / a.alt_steps, "steps_per_s": a.alt_steps / dta,
+               "qeq_iters_per_step": sa["qeq_iters_total"] / max(sa["qeq_calls"], 1), "ms_qeq_per_iter": sa["ms_qeq"] / max(sa["qeq_iters_total"], 1)}
+        eng.set_qeq_mode(a.qeq_mode)
 
     if rank == 0:
         steps_per_s = a.steps / dt
@@ -187,7 +200,7 @@ def main():
                                        "vprocs %dx%dx%d domain decomposition, six-stage halo over RCCL (%s)" % (vp[0], vp[1], vp[2], transport_mode)),
                        "qeq_mode": a.qeq_mode},
             "steps_per_s_wall": steps_per_s, "ns_per_day": steps_per_s * cfg["dt"] * 86400e-6, "atom_steps_per_s": steps_per_s * natoms * world,
-            "qeq_iters_per_step": iters, "n10": n10, "nb": nb,
+            "qeq_iters_per_step": iters, "ms_qeq_per_iter": st["ms_qeq"] / max(st["qeq_iters_total"], 1), "n10": n10, "nb": nb,
             "roofline": {"bound": "hbm", "kernel": "k_spmv (QEq matrix pass, qeq.hip)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_pass,
                          "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"],
@@ -195,6 +208,8 @@ def main():
             "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded")},
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
         }
+        if alt:
+            out["alt"] = alt
         if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline()
             if cb:

@@ -111,6 +111,8 @@ typedef struct rxmd_stats {
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);
+/* switch rxmd_config.qeq_mode (0|1) between calls; both modes share every buffer */
+int rxmd_hip_set_qeq_mode(rxmd_handle h, int mode);
 
 /* host-side derived tables for unit tests (CUTOFFLENGTH/POTENTIALTABLE, src/init.F90:363-522):
  * which: 0 Evdw 1 dEvdw 2 Eclmb 3 dEclmb 4 Eclmb_QEq  -> out[nboty][5000]; returns nboty */

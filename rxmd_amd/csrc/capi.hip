@@ -248,6 +248,13 @@ int rxmd_hip_reset_timers(rxmd_handle h) {
   });
 }
 
+int rxmd_hip_set_qeq_mode(rxmd_handle h, int mode) {
+  return guarded(h, [&](Engine &e) {
+    if (mode != 0 && mode != 1) throw EngineError(RXMD_E_ARG, "qeq_mode must be 0 or 1");
+    e.cfg.qeq_mode = mode;
+  });
+}
+
 int rxmd_hip_get_table(rxmd_handle h, int which, double *out, int capacity) {
   int n = 0;
   const int rc = guarded(h, [&](Engine &e) {

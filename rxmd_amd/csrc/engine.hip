@@ -183,7 +183,7 @@ void Engine::alloc_device() {
   for (int a = 0; a < 3; ++a) { dmalloc(pos[a], nb); dmalloc(vel[a], nb); dmalloc(frc[a], nb); dmalloc(spos[a], nb); }
   dmalloc(q, nb); dmalloc(qsfp, nb); dmalloc(qsfv, nb); dmalloc(type, nb); dmalloc(gid, nb);
   dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb);
-  if (cfg.qeq_mode == 1) { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
+  { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.ncell) + 2);
   dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1);

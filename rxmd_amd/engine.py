@@ -138,6 +138,9 @@ class RxmdEngine:
     def reset_timers(self):
         self._chk(self.L.rxmd_hip_reset_timers(self.h))
 
+    def set_qeq_mode(self, mode):
+        self._chk(self.L.rxmd_hip_set_qeq_mode(self.h, int(mode)))
+
     def table(self, which):
         rc = C.c_double(0)
         nboty = self._chk(self.L.rxmd_hip_get_cutoffs(self.h, None, 0, C.byref(rc)))
