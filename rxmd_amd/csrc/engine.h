@@ -98,6 +98,8 @@ struct Engine {
   double *q = nullptr, *qsfp = nullptr, *qsfv = nullptr;
   int *type = nullptr; long long *gid = nullptr;
   double2 *qst = nullptr, *hst = nullptr, *gst = nullptr;  // (qs,qt) (hs,ht) (gs,gt) interleaved
+  double2 *hst2 = nullptr;     // second (hs,ht) buffer: the fused direction kernel reads the old and writes the new one (qeq.hip)
+  unsigned *tickets = nullptr; // arrival counters of the in-kernel final reductions (qeq.hip, block_finish)
   double2 *sall = nullptr, *sgh = nullptr, *wall = nullptr, *wgh = nullptr;  // qeq_mode 1: row sums H.(qs,qt), H.(hs,ht): all columns / ghost columns
   int *gsrc = nullptr, *groot = nullptr;                    // ghost -> source index on sender ; -> resident root (self exchange)
   int *rootperm = nullptr;                                  // cell-sorted position -> resident that owns the value (ghosts resolved)
@@ -118,6 +120,10 @@ struct Engine {
   double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
   // 10 A list
   int *nb10 = nullptr, *n10 = nullptr; double *hess = nullptr;
+  unsigned short *nb10s = nullptr;   // same list, partner named by its position inside the row's 5x5x5-cell neighbourhood (bit 15: ghost): k_spmv_cell
+  size_t partials_cap = 0; bool cell_attr_set = false;
+  bool spmv_cell = false;            // env RXMD_SPMV_CELL=1: build nb10s and run the cell-tiled matrix pass
+  int nbhd_max = 0;                  // largest neighbourhood population of a resident's cell (sizes the LDS stage of k_spmv_cell)
   // reductions
   double *partials = nullptr;  // [nblocks_red * 16]
   double *scal = nullptr;      // device scalars (CG state)

@@ -3,6 +3,7 @@
 // Reference behaviour restated MI355X-first: src/comm.F90 (the six-direction staged exchange),
 // src/main.F90:277-318 (LINKEDLIST), src/init.F90:7-288 (INITSYSTEM derived quantities).
 #include "engine.h"
+#include <cstdlib>
 
 #include <hipcub/hipcub.hpp>
 
@@ -182,7 +183,7 @@ void Engine::alloc_device() {
   const size_t nb = NB, ns = static_cast<size_t>(NB) * MAXNB;
   for (int a = 0; a < 3; ++a) { dmalloc(pos[a], nb); dmalloc(vel[a], nb); dmalloc(frc[a], nb); dmalloc(spos[a], nb); }
   dmalloc(q, nb); dmalloc(qsfp, nb); dmalloc(qsfv, nb); dmalloc(type, nb); dmalloc(gid, nb);
-  dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb);
+  dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb); dmalloc(hst2, nb); dmalloc(tickets, 16);
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.ncell) + 2);
@@ -193,8 +194,11 @@ void Engine::alloc_device() {
   dmalloc(cf1, ns); dmalloc(cf2, ns); dmalloc(cf3, ns); dmalloc(cdn, ns); dmalloc(fnx, ns); dmalloc(fny, ns); dmalloc(fnz, ns);
   dmalloc(etor, ns); dmalloc(econ, ns); dmalloc(epen, ns); dmalloc(ecoa, ns);
   dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
-  dmalloc(nb10, static_cast<size_t>(rows10) * S10); dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
-  dmalloc(partials, std::max<size_t>(size_t(1) << 16, static_cast<size_t>(rows10) + 16384)); dmalloc(scal, 64);
+  dmalloc(nb10, static_cast<size_t>(rows10) * S10);
+  spmv_cell = (std::getenv("RXMD_SPMV_CELL") != nullptr);
+  if (spmv_cell) dmalloc(nb10s, static_cast<size_t>(rows10) * S10); dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
+  partials_cap = std::max<size_t>(size_t(1) << 16, static_cast<size_t>(rows10) + 16384);
+  dmalloc(partials, partials_cap); dmalloc(scal, 64);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
   dmalloc(d_err, 4);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 4 * sizeof(int)));
@@ -208,13 +212,13 @@ void Engine::alloc_device() {
 
 void Engine::free_device() {
   for (int a = 0; a < 3; ++a) { dfree(pos[a]); dfree(vel[a]); dfree(frc[a]); dfree(spos[a]); }
-  dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst); dfree(sall); dfree(sgh); dfree(wall); dfree(wgh);
+  dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst); dfree(hst2); dfree(tickets); dfree(sall); dfree(sgh); dfree(wall); dfree(wgh);
   dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(xs); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
   dfree(sorted_xyzi); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
   dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
-  dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
+  dfree(nb10); dfree(nb10s); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
@@ -721,6 +725,7 @@ void Engine::build_ghosts_and_lists() {
   build_bonded_list();
   build_list10();
   check_device_error("list build");
+  nbhd_max = h_err[2];
   st.ms_lists += toc(0, 1);
   lists_valid = true;
 }

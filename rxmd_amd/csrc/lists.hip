@@ -86,10 +86,12 @@ template <bool SELFCHECK>
 __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
                                                  const double *__restrict__ z, const int *__restrict__ type, const long long *__restrict__ gid,
-                                                 int *__restrict__ nb10, double *__restrict__ hess, int *__restrict__ n10, int *err) {
+                                                 int *__restrict__ nb10, unsigned short *__restrict__ nb10s, double *__restrict__ hess, int *__restrict__ n10, int *err) {
+  extern __shared__ unsigned short srow_all[];       // [4][S10]: the wavefront's row of 16-bit entries, written out as 4-byte words
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
+  unsigned short *srow = srow_all + static_cast<size_t>(threadIdx.x >> 6) * S10;
   const int c = cellid[i];
   const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
@@ -97,6 +99,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.n[2] - 1);
   const size_t row = static_cast<size_t>(i) * S10;
   int cnt = 0;
+  int loff = 0;     // candidates in the stencil columns already swept = position of this column inside the neighbourhood
   for (int dx = -2; dx <= 2; ++dx) {
     const int x2 = cx + dx;
     if (x2 < 0 || x2 >= g.n[0]) continue;
@@ -105,6 +108,8 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
       if (y2 < 0 || y2 >= g.n[1]) continue;
       const int cb = (x2 * g.n[1] + y2) * g.n[2];
       const int k0 = cellstart[cb + z0], k1 = cellstart[cb + z1 + 1];
+      const int lbase = loff - k0;
+      loff += k1 - k0;
       for (int kb = k0; kb < k1; kb += 64) {
         const int k = kb + lane;
         bool in = false;
@@ -137,6 +142,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
             unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
             if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
             nb10[row + slot] = static_cast<int>(ent);
+            if (nb10s) srow[slot] = static_cast<unsigned short>(((lbase + k) & 0x7fff) | (j >= N ? 0x8000 : 0));
             hess[row + slot] = h;
           }
         }
@@ -145,8 +151,15 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
     }
   }
   if (cnt > S10) { if (lane == 0) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); } cnt = S10; }  // qeq.F90:248-252
-  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
-  if (lane == 0) n10[i] = cnt;
+  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; if (nb10s) srow[cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
+  if (nb10s) {
+    const int nw = ((cnt + 3) & ~3) >> 1;            // the wavefront's own LDS row: no barrier needed beyond the wave's program order
+    const unsigned *sw = reinterpret_cast<const unsigned *>(srow);
+    unsigned *dw = reinterpret_cast<unsigned *>(nb10s + row);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int t = lane; t < nw; t += 64) dw[t] = sw[t];
+  }
+  if (lane == 0) { n10[i] = cnt; if (loff > __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&err[2], loff); }
 }
 
 void Engine::build_bonded_list() {
@@ -157,11 +170,12 @@ void Engine::build_bonded_list() {
 
 void Engine::build_list10() {
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
+  RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
   const bool selfcheck = (box.lat[0] < 2.0 * ff.rctap + 1.0) || (box.lat[1] < 2.0 * ff.rctap + 1.0) || (box.lat[2] < 2.0 * ff.rctap + 1.0);
   if (selfcheck)
-    k_list10<true><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, hess, n10, d_err);
+    k_list10<true><<<nblk(N, 4), 256, static_cast<size_t>(S10) * 4 * sizeof(unsigned short), stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, hess, n10, d_err);
   else
-    k_list10<false><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, hess, n10, d_err);
+    k_list10<false><<<nblk(N, 4), 256, static_cast<size_t>(S10) * 4 * sizeof(unsigned short), stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, hess, n10, d_err);
 }
 
 }  // namespace rxmd

@@ -34,15 +34,40 @@ __device__ inline double wave_sum(double v) {
 template <int NC>
 __device__ inline void block_store_partials(double (&acc)[NC], double *partials, int ncomp_stride) {
   // acc holds lane-0-of-wave partials; combine the block's waves in wave order, then one store per component
-  __shared__ double sm[4][NC];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ double sm[16][NC];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   if (lane == 0)
     for (int c = 0; c < NC; ++c) sm[w][c] = acc[c];
   __syncthreads();
   if (threadIdx.x < NC) {
     double s = 0.0;
-    for (int k = 0; k < 4; ++k) s += sm[k][threadIdx.x];
-    partials[static_cast<size_t>(blockIdx.x) * ncomp_stride + threadIdx.x] = s;
+    for (int k = 0; k < nw; ++k) s += sm[k][threadIdx.x];
+    // device-scope store: written through to the coherence point, so the in-kernel tail (block_finish) needs no L2 write-back
+    __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * ncomp_stride + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// per-row tail of a matrix pass (lane 0 of the row's wavefront): the arithmetic of get_hsh / get_gradient around the row sums
+template <int MODE, bool STORE>
+__device__ inline void row_epilogue(int row, double as, double at, double gs_, double gt_, double mu, const DevFF &ff, const double2 *__restrict__ hst, double2 *__restrict__ gst,
+                                    const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
+                                    double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh, double (&acc)[4]) {
+  if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+  const DevAtomP ap = ff.atom[type[row]];
+  if (MODE == MODE_HSH) {
+    const double2 hv = hst[row], gv = gst[row];
+    const double ts = ap.eta * hv.x + as, tt = ap.eta * hv.y + at;      // qeq.F90:294-302
+    acc[0] += ts * hv.x; acc[1] += tt * hv.y;                           // hshs_sum, hsht_sum (:309-310)
+    acc[2] += gv.x * hv.x; acc[3] += gv.y * hv.y;                       // g.h (:119,123)
+  } else {
+    const double2 qv = qst[row];
+    const double g1 = -ap.chi - ap.eta * qv.x - as;                     // qeq.F90:349-350
+    const double g2 = -1.0 - ap.eta * qv.y - at;
+    gst[row] = make_double2(g1, g2);
+    acc[0] += g1 * g1; acc[1] += g2 * g2;                               // Gnew (:355-356)
+    const double qi = q[row];
+    const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+    acc[2] += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
   }
 }
 
@@ -84,25 +109,96 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
     }
     as = wave_sum(as); at = wave_sum(at);
     if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-    if (lane == 0) {
-      if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
-      const DevAtomP ap = ff.atom[type[row]];
-      if (MODE == MODE_HSH) {
-        const double2 hv = hst[row], gv = gst[row];
-        const double ts = ap.eta * hv.x + as, tt = ap.eta * hv.y + at;      // qeq.F90:294-302
-        acc[0] += ts * hv.x; acc[1] += tt * hv.y;                           // hshs_sum, hsht_sum (:309-310)
-        acc[2] += gv.x * hv.x; acc[3] += gv.y * hv.y;                       // g.h (:119,123)
-      } else {
-        const double2 qv = qst[row];
-        const double g1 = -ap.chi - ap.eta * qv.x - as;                     // qeq.F90:349-350
-        const double g2 = -1.0 - ap.eta * qv.y - at;
-        gst[row] = make_double2(g1, g2);
-        acc[0] += g1 * g1; acc[1] += g2 * g2;                               // Gnew (:355-356)
-        const double qi = q[row];
-        const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
-        acc[2] += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
+    if (lane == 0) row_epilogue<MODE, STORE>(row, as, at, gs_, gt_, mu, ff, hst, gst, qst, q, type, rs_all, rs_gh, acc);
+  }
+  block_store_partials<4>(acc, partials, 4);
+}
+
+// ---- cell-tiled matrix pass ------------------------------------------------------------------------------------
+// One workgroup per cell of the engine's grid.  Every row of the cell draws its partners from the same 5x5x5-cell
+// neighbourhood = 25 contiguous runs of the cell-sorted vector copy, so the workgroup stages that neighbourhood of (xs,xt)
+// in LDS once (coalesced, ~26 KB for RDX) and the per-entry gathers become ds_read_b128.  The list names a partner by its
+// position inside the neighbourhood (lists.hip, nb10s: 15 bits + ghost flag), which halves the index stream: a row entry
+// costs 8 + 2 bytes of HBM instead of 8 + 4 and no L1 gather.
+constexpr int UNRC = 4;   // 4 x 64 lanes x 2 entries = 512 entries in flight per wavefront
+template <int MODE, bool STORE>
+__global__ void __launch_bounds__(1024) k_spmv_cell(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellstart, const int *__restrict__ perm,
+                                                    const unsigned short *__restrict__ nb10s, const double *__restrict__ hess, const int *__restrict__ n10,
+                                                    const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
+                                                    const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
+                                                    const double *__restrict__ scal, double *__restrict__ partials,
+                                                    double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh) {
+  extern __shared__ double2 xl[];
+  __shared__ int s_k0[25], s_len[25], s_off[26];
+  __shared__ int s_any;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const int c = blockIdx.x;
+  const int r0 = cellstart[c], r1 = cellstart[c + 1];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  for (int k = r0 + threadIdx.x; k < r1; k += blockDim.x)
+    if (perm[k] < N) s_any = 1;
+  if (threadIdx.x < 25) {       // the stencil columns in the order k_list10 swept them
+    const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
+    const int x2 = cx + threadIdx.x / 5 - 2, y2 = cy + threadIdx.x % 5 - 2;
+    int k0 = 0, len = 0;
+    if (x2 >= 0 && x2 < g.n[0] && y2 >= 0 && y2 < g.n[1]) {
+      const int cb = (x2 * g.n[1] + y2) * g.n[2];
+      k0 = cellstart[cb + max(cz - 2, 0)];
+      len = cellstart[cb + min(cz + 2, g.n[2] - 1) + 1] - k0;
+    }
+    s_k0[threadIdx.x] = k0; s_len[threadIdx.x] = len;
+  }
+  __syncthreads();
+  if (!s_any) {                 // a cell of the ghost shell: nothing to do
+    if (threadIdx.x < 4) __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * 4 + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (threadIdx.x == 0) {
+    int o = 0;
+    for (int t = 0; t < 25; ++t) { s_off[t] = o; o += s_len[t]; }
+    s_off[25] = o;
+  }
+  __syncthreads();
+  for (int col = w; col < 25; col += nwv) {     // a wavefront per column: coalesced 16-byte loads
+    const int k0 = s_k0[col], len = s_len[col], o = s_off[col];
+    for (int t = lane; t < len; t += 64) xl[o + t] = xv[k0 + t];
+  }
+  __syncthreads();
+  const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
+  for (int k = r0 + w; k < r1; k += nwv) {
+    const int row = perm[k];
+    if (row >= N) continue;
+    const int npair = (n10[row] + 3) >> 2 << 1;                     // rows are zero-padded to a multiple of 4 entries
+    const size_t base = static_cast<size_t>(row) * S10;
+    const unsigned *ep = reinterpret_cast<const unsigned *>(nb10s + base);
+    const f64x2 *hp = reinterpret_cast<const f64x2 *>(hess + base);
+    double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+    for (int p0 = lane; p0 < npair; p0 += 64 * UNRC) {
+      unsigned e[UNRC];
+      f64x2 h[UNRC];
+#pragma unroll
+      for (int u = 0; u < UNRC; ++u) {
+        const int p = p0 + 64 * u;
+        const bool ok = p < npair;
+        e[u] = ok ? __builtin_nontemporal_load(ep + p) : 0u;
+        h[u] = ok ? __builtin_nontemporal_load(hp + p) : f64x2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < UNRC; ++u) {
+        const double2 v0 = xl[e[u] & 0x7fffu], v1 = xl[(e[u] >> 16) & 0x7fffu];
+        as += h[u].x * v0.x; at += h[u].x * v0.y;
+        as += h[u].y * v1.x; at += h[u].y * v1.y;
+        if (MODE == MODE_GRAD || STORE) {
+          if (e[u] & 0x8000u) { gs_ += h[u].x * v0.x; gt_ += h[u].x * v0.y; }
+          if (e[u] & 0x80000000u) { gs_ += h[u].y * v1.x; gt_ += h[u].y * v1.y; }
+        }
       }
     }
+    as = wave_sum(as); at = wave_sum(at);
+    if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+    if (lane == 0) row_epilogue<MODE, STORE>(row, as, at, gs_, gt_, mu, ff, hst, gst, qst, q, type, rs_all, rs_gh, acc);
   }
   block_store_partials<4>(acc, partials, 4);
 }
@@ -170,8 +266,8 @@ __global__ void __launch_bounds__(256) k_reduce_scalars(int nblocks, const doubl
 // stage 1: after the HSH pass -> REAL(4) line-minimisation factors (qeq.F90:133)
 // stage 2: after the q update  -> mu = ssum/tsum (qeq.F90:147)
 // stage 3: after the GRAD pass -> Gold<-Gnew, Gnew, Est, beta (qeq.F90:156-161)
-__global__ void k_scalar_algebra(int stage, double *__restrict__ scal) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// stage 4 (qeq_mode 1, fused loop): sums (qs, qt, gs.gs, gt.gt) -> mu, Gold<-Gnew, Gnew, beta;  stage 5: Est
+__device__ inline void scalar_algebra(int stage, double *__restrict__ scal) {
   const double r[4] = {scal[S_RAW0], scal[S_RAW1], scal[S_RAW2], scal[S_RAW3]};
   if (stage == 1) {
     scal[S_HSH_S] = r[0]; scal[S_HSH_T] = r[1]; scal[S_GH_S] = r[2]; scal[S_GH_T] = r[3];
@@ -180,12 +276,69 @@ __global__ void k_scalar_algebra(int stage, double *__restrict__ scal) {
   } else if (stage == 2) {
     scal[S_SSUM] = r[0]; scal[S_TSUM] = r[1];
     scal[S_MU] = r[0] / r[1];
-  } else {
+  } else if (stage == 3) {
     const double go_s = scal[S_GNEW_S], go_t = scal[S_GNEW_T];
     scal[S_GOLD_S] = go_s; scal[S_GOLD_T] = go_t;
     scal[S_GNEW_S] = r[0]; scal[S_GNEW_T] = r[1]; scal[S_EST] = r[2];
     scal[S_BETA_S] = r[0] / go_s; scal[S_BETA_T] = r[1] / go_t;
+  } else if (stage == 4) {
+    scal[S_SSUM] = r[0]; scal[S_TSUM] = r[1];
+    scal[S_MU] = r[0] / r[1];
+    const double go_s = scal[S_GNEW_S], go_t = scal[S_GNEW_T];
+    scal[S_GOLD_S] = go_s; scal[S_GOLD_T] = go_t;
+    scal[S_GNEW_S] = r[2]; scal[S_GNEW_T] = r[3];
+    scal[S_BETA_S] = r[2] / go_s; scal[S_BETA_T] = r[3] / go_t;
+  } else {
+    scal[S_EST] = r[0];
   }
+}
+__global__ void k_scalar_algebra(int stage, double *__restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  scalar_algebra(stage, scal);
+}
+
+// In-kernel tail of a deterministic reduction: every workgroup has stored its four partial sums; the LAST one to arrive
+// (arrival counter) adds all of them in a fixed order (thread t takes partials t, t+256, ...; then the fixed LDS tree), writes
+// scal[S_RAW0..3] and, single rank only, runs the scalar algebra of `stage` -- so a reduction costs no extra launch.
+// The result does not depend on which workgroup happens to be last.
+__device__ inline void block_finish(int nblocks, double *partials, unsigned *ticket, int stage, double *scal) {
+  __shared__ double smf[256];
+  __shared__ bool last;
+  // The partials were stored with device-scope atomics (write-through); waiting for those stores to complete is all the
+  // release this needs.  A full __threadfence() here would write back the L2's dirty lines of the whole kernel from every
+  // workgroup (measured: +0.25 ms per launch on the 160 MB vector kernels).
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nblocks - 1));
+  __syncthreads();
+  if (!last) return;
+  double a[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+    for (int c = 0; c < 4; ++c) a[c] += __hip_atomic_load(partials + static_cast<size_t>(b) * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int c = 0; c < 4; ++c) {
+    const double r = block_sum_256(a[c], smf);
+    if (threadIdx.x == 0) scal[S_RAW0 + c] = r;
+  }
+  if (threadIdx.x == 0) {
+    *ticket = 0u;                                    // ready for the next launch (stream order)
+    if (stage > 0) scalar_algebra(stage, scal);
+  }
+}
+
+// the matrix pass leaves one partial per workgroup (245k at 979,776 rows): 128 workgroups sum contiguous chunks,
+// the last of them finishes (replaces k_reduce_level1 + k_reduce_scalars + k_scalar_algebra: one launch instead of three)
+__global__ void __launch_bounds__(256) k_reduce_fused(int nblocks, const double *__restrict__ partials, double *__restrict__ lvl1, unsigned *ticket, int stage, double *__restrict__ scal) {
+  __shared__ double sm[256];
+  const int per = (nblocks + gridDim.x - 1) / gridDim.x;
+  const int b0 = blockIdx.x * per, b1 = min(nblocks, b0 + per);
+  double a[4] = {0, 0, 0, 0};
+  for (int b = b0 + threadIdx.x; b < b1; b += 256)
+    for (int c = 0; c < 4; ++c) a[c] += partials[static_cast<size_t>(b) * 4 + c];
+  for (int c = 0; c < 4; ++c) {
+    const double r = block_sum_256(a[c], sm);
+    if (threadIdx.x == 0) __hip_atomic_store(lvl1 + blockIdx.x * 4 + c, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  block_finish(gridDim.x, lvl1, ticket, stage, scal);
 }
 
 // qs += lmin1*hs ; qt += lmin2*ht ; partial sums of qs, qt (qeq.F90:136-141)
@@ -250,6 +403,61 @@ __global__ void __launch_bounds__(256) k_grad_from_sums(int N, DevFF ff, const d
   block_store_partials<4>(acc, partials, 4);
 }
 
+// ---- qeq_mode 1, single rank: the whole vector algebra of one CG iteration in two launches ---------------------
+// A: qs,qt += lmin (hs,ht); stored row sums += lmin H.(hs,ht); new gradient (no mu needed); sums (qs, qt, gs.gs, gt.gt)
+//    -> tail: mu, Gnew, beta                                                    (qeq.F90:136-147,349-356,160-161)
+__global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ hst, double2 *__restrict__ qst,
+                                                    const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
+                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket) {
+  const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
+  double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    double2 qv = qst[i];
+    const double2 hv = hst[i];
+    qv.x = qv.x + l1 * hv.x; qv.y = qv.y + l2 * hv.y;
+    qst[i] = qv;
+    double2 a = sall[i], g = sgh[i];
+    const double2 wa = wall[i], wg = wgh[i];
+    a.x += l1 * wa.x; a.y += l2 * wa.y; g.x += l1 * wg.x; g.y += l2 * wg.y;
+    sall[i] = a; sgh[i] = g;
+    const DevAtomP ap = ff.atom[type[i]];
+    const double g1 = -ap.chi - ap.eta * qv.x - a.x, g2 = -1.0 - ap.eta * qv.y - a.y;
+    gst[i] = make_double2(g1, g2);
+    s += qv.x; t += qv.y; g1s += g1 * g1; g2s += g2 * g2;
+  }
+  double acc[4] = {wave_sum(s), wave_sum(t), wave_sum(g1s), wave_sum(g2s)};
+  block_store_partials<4>(acc, partials, 4);
+  block_finish(gridDim.x, partials, ticket, 4, scal);
+}
+// B: over the cell-sorted positions k (residents and their periodic images): new direction h = g + beta h written to the
+//    other (hs,ht) buffer and, as the QCOPY2 halo + sorted gather copy, to xs[k]; at the resident itself also
+//    q = qs - mu qt and the Est term (qeq.F90:150,160-164,297-306) -> tail: Est
+__global__ void __launch_bounds__(256) k_cg_direction(int G, int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ perm, const int *__restrict__ rootperm, const int *__restrict__ type,
+                                                       const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new, double2 *__restrict__ xs,
+                                                       const double2 *__restrict__ qst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double *__restrict__ q,
+                                                       double *__restrict__ partials, unsigned *ticket) {
+  const double mu = scal[S_MU], b1 = scal[S_BETA_S], b2 = scal[S_BETA_T];
+  double es = 0.0;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < G; k += gridDim.x * blockDim.x) {
+    const int i = rootperm[k];
+    const double2 g = gst[i], h = hst[i];
+    const double2 hn = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
+    xs[k] = hn;
+    if (perm[k] == i) {                              // the resident itself, not one of its images
+      hst_new[i] = hn;
+      const DevAtomP ap = ff.atom[type[i]];
+      const double2 qv = qst[i], a = sall[i], gh = sgh[i];
+      const double qi = qv.x - mu * qv.y;
+      q[i] = qi;
+      const double hq_all = a.x - mu * a.y, hq_res = (a.x - gh.x) - mu * (a.y - gh.y);
+      es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
+    }
+  }
+  double acc[4] = {wave_sum(es), 0.0, 0.0, 0.0};
+  block_store_partials<4>(acc, partials, 4);
+  block_finish(gridDim.x, partials, ticket, 5, scal);
+}
+
 // q = qs - mu*qt (qeq.F90:150)
 __global__ void k_apply_q(int N, const double *__restrict__ scal, const double2 *__restrict__ qst, double *__restrict__ q) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,15 +493,45 @@ void Engine::qeq() {
   // per pass at 979,776 rows) -- many short waves overlap each other's load / gather / reduce phases
   const int rb = nblk(N, 4);
   const int vb = std::min(nblk(N, 256), 2048);
-  double *lvl1 = partials + static_cast<size_t>(rb) * 4 + 64;      // 128 x 4 first-level sums live behind the per-workgroup partials
+  // cell-tiled pass (k_spmv_cell) whenever the neighbourhood of a cell fits the 15-bit local index and the LDS stage
+  const size_t lds_bytes = (static_cast<size_t>(nbhd_max) + 64) / 64 * 64 * sizeof(double2);
+  // (opt-in: measured 1.21 ms against 1.13 ms per pass for the row kernel at 979,776 rows, see DESIGN.md "matrix pass variants")
+  const bool use_cell = spmv_cell && nbhd_max > 0 && nbhd_max < 32768 && lds_bytes <= 128 * 1024 &&
+                        static_cast<size_t>(std::max(rb, grid.ncell)) * 4 + 1024 <= partials_cap;
+  if (use_cell && lds_bytes > 48 * 1024 && !cell_attr_set) {
+    const int lim = 128 * 1024;
+    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_cell<MODE_HSH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_cell<MODE_HSH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_cell<MODE_GRAD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_cell<MODE_GRAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    cell_attr_set = true;
+  }
+  const int cell_bs = 512;
+  const int nred = use_cell ? grid.ncell : rb;                                      // partials one matrix pass leaves
+  double *lvl1 = partials + static_cast<size_t>(std::max(rb, grid.ncell)) * 4 + 64; // 128 x 4 first-level sums live behind the per-workgroup partials
+  auto pass = [&](int mode, bool store, double2 *ra, double2 *rg) {
+#define RX_PASS(M, S)                                                                                                                        \
+  do {                                                                                                                                       \
+    if (use_cell) k_spmv_cell<M, S><<<grid.ncell, cell_bs, lds_bytes, stream>>>(N, S10, grid, dff, cellstart, perm, nb10s, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg); \
+    else k_spmv<M, S><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg);            \
+  } while (0)
+    if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
+    else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }
+#undef RX_PASS
+  };
   auto reduce = [&](int stage, int nb_) {
+    if (!multi()) {                              // single rank: level-1 sums, final sum and scalar algebra in one launch
+      if (nb_ > 1024) k_reduce_fused<<<128, 256, 0, stream>>>(nb_, partials, lvl1, tickets, stage, scal);
+      else k_reduce_fused<<<1, 256, 0, stream>>>(nb_, partials, lvl1, tickets, stage, scal);
+      return;
+    }
     if (nb_ > 1024) {
       k_reduce_level1<<<128, 256, 0, stream>>>(nb_, partials, lvl1);
       k_reduce_scalars<<<1, 256, 0, stream>>>(128, lvl1, scal);
     } else {
       k_reduce_scalars<<<1, 256, 0, stream>>>(nb_, partials, scal);
     }
-    if (multi()) {                               // MPI_ALLREDUCE of the rank-local sums through the host transport
+    {                                            // MPI_ALLREDUCE of the rank-local sums through the host transport
       if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
       RX_HIP(hipMemcpyAsync(h_scal + 48, scal + S_RAW0, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
       RX_HIP(hipStreamSynchronize(stream));
@@ -306,25 +544,38 @@ void Engine::qeq() {
   RX_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 32, stream));
   sorted_copy(qst);                                                                             // QCOPY1, qeq.F90:86
   const bool onepass = (cfg.qeq_mode == 1);
-  if (onepass) k_spmv<MODE_GRAD, true><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, sall, sgh);
-  else k_spmv<MODE_GRAD, false><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, nullptr, nullptr);
-  reduce(3, rb);
+  pass(MODE_GRAD, onepass, onepass ? sall : nullptr, onepass ? sgh : nullptr);
+  reduce(3, nred);
   k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
   RX_HIP(hipStreamSynchronize(stream));
   double GEst2 = 1e99, Est = h_scal[S_EST];
   int it = 0;
   float ms = 0;
+  bool xs_current = false;       // the fused direction kernel leaves the sorted copy of the new (hs,ht) in xs
   for (it = 0; it <= nmax - 1; ++it) {
     if (0.5 * (std::fabs(GEst2) + std::fabs(Est)) < cfg.QEq_tol) break;                          // qeq.F90:114
     if (std::fabs(GEst2) > 0.0 && std::fabs(Est / GEst2 - 1.0) < cfg.QEq_tol) break;            // qeq.F90:115
     GEst2 = Est;
-    sorted_copy(hst);                                                                            // QCOPY2, qeq.F90:93,164
+    if (!xs_current) sorted_copy(hst);                                                           // QCOPY2, qeq.F90:93,164
+    xs_current = false;
     hipEventRecord(ev[2], stream);
-    if (onepass) k_spmv<MODE_HSH, true><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, wall, wgh);
-    else k_spmv<MODE_HSH, false><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, nullptr, nullptr);
+    pass(MODE_HSH, onepass, onepass ? wall : nullptr, onepass ? wgh : nullptr);
     hipEventRecord(ev[3], stream);
-    reduce(1, rb);
+    reduce(1, nred);
+    if (onepass && !multi()) {   // qeq_mode 1, single rank: matrix pass + three launches, every reduction finished in-kernel
+      const int gb = std::min(nblk(G, 256), 2048);
+      k_cg_update<<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1);
+      k_cg_direction<<<gb, 256, 0, stream>>>(G, N, dff, scal, perm, rootperm, type, gst, hst, hst2, xs, qst, sall, sgh, q, partials, tickets + 2);
+      std::swap(hst, hst2);
+      xs_current = true;
+      RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipStreamSynchronize(stream));
+      Est = h_scal[S_EST];
+      hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
+      st.spmv_launches += 1;
+      continue;
+    }
     if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
       k_update_qst_sums<<<vb, 256, 0, stream>>>(N, scal, hst, qst, wall, wgh, sall, sgh, partials);
       reduce(2, vb);
@@ -343,9 +594,9 @@ void Engine::qeq() {
     k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);
     sorted_copy(qst);                                                                            // QCOPY1, qeq.F90:153
     hipEventRecord(ev[4], stream);
-    k_spmv<MODE_GRAD, false><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, nullptr, nullptr);
+    pass(MODE_GRAD, false, nullptr, nullptr);
     hipEventRecord(ev[5], stream);
-    reduce(3, rb);
+    reduce(3, nred);
     k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);
     RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
     RX_HIP(hipStreamSynchronize(stream));

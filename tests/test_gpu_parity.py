@@ -251,3 +251,18 @@ def test_one_pass_qeq_mode_reaches_the_same_fixed_point(case, mc):
     assert abs(est - o.trace()[-1, 0]) <= 1e-9 * abs(est)
     assert e.stats()["spmv_launches"] == it          # one pass per iteration
     e.close()
+
+
+@pytest.mark.parametrize("qeq_mode", [0, 1])
+def test_cell_tiled_matrix_pass_is_the_same_operator(qeq_mode, monkeypatch):
+    """RXMD_SPMV_CELL=1 switches the QEq matrix pass to the LDS-staged, 16-bit-index kernel (k_spmv_cell): another
+    summation order of the same rows, so the tight-tolerance fixed point must not move."""
+    monkeypatch.setenv("RXMD_SPMV_CELL", "1")
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    o = _oracle("rdx222", (2, 2, 2), **kw); o.qeq(); o.force()
+    e = _engine("rdx222", (2, 2, 2), qeq_mode=qeq_mode, **kw)
+    it, est = e.QEq(); pe = e.FORCE(); a = e.atoms()
+    assert q_err(a["q"], o.charges()) <= QTOL
+    assert f_err(a["f"], o.forces()) <= FTOL
+    assert abs(est - o.trace()[-1, 0]) <= 1e-9 * abs(est)
+    e.close()
