@@ -30,7 +30,9 @@ module rxmd_hip_mod
      real(c_double) :: dt_fs
      real(c_double) :: Lex_fqs, Lex_k
      integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode
-     integer(c_int) :: reserved(7)
+     integer(c_int) :: reserved0
+     type(c_ptr)    :: pqeq_path
+     integer(c_int) :: reserved(4)
   end type
 
   type(c_ptr), save :: rxmd_hip_handle = c_null_ptr

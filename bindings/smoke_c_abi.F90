@@ -11,7 +11,9 @@ program smoke_c_abi
      real(c_double) :: QEq_tol
      integer(c_int) :: qstep
      real(c_double) :: dt_fs, Lex_fqs, Lex_k
-     integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode, reserved(7)
+     integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode, reserved0
+     type(c_ptr) :: pqeq_path
+     integer(c_int) :: reserved(4)
   end type
   interface
      subroutine rxmd_hip_default_config(cfg) bind(c, name='rxmd_hip_default_config')

@@ -56,7 +56,10 @@ typedef struct rxmd_config {
   int device;              /* HIP device ordinal */
   int qeq_mode;            /* 0 = reference algebra (two matrix passes per CG iteration, qeq.F90:96-166)
                               1 = one pass per iteration (gradient by recurrence); same fixed point */
-  int reserved[7];
+  int reserved0;
+  const char *pqeq_path;   /* --pqeq / rxmd.in PQEqParm (cmdline.F90:112-128,291-293): NULL = plain QEq.  Switches the charge solver to
+                              PQEq (pqeq.F90), the nonbonded term to ENbond_PQEq (pot.F90:784-923) and the taper cutoff to 12.5 A */
+  int reserved[4];
 } rxmd_config;
 
 void rxmd_hip_default_config(rxmd_config *cfg);
@@ -77,6 +80,10 @@ int rxmd_hip_get_atoms_rxff(rxmd_handle h, double *rec10, int capacity);
 int rxmd_hip_get_atoms(rxmd_handle h, int capacity, long long *gid, int *type, double *pos, double *v, double *f, double *q);
 int rxmd_hip_set_charges(rxmd_handle h, int natoms, const double *q);
 int rxmd_hip_set_velocities(rxmd_handle h, int natoms, const double *v);
+/* PQEq shell displacements spos(natoms,3) of the residents, real units (module.F90:286; written by WriteXYZ, fileio.F90:332-333).
+ * get returns natoms; both fail with RXMD_E_STATE when the engine was created without pqeq_path */
+int rxmd_hip_get_shells(rxmd_handle h, double *spos3, int capacity);
+int rxmd_hip_set_shells(rxmd_handle h, int natoms, const double *spos3);
 
 /* ---- the hot path, device resident ---------------------------------------------------------- */
 /* QEq(atype,pos,q), src/qeq.F90:2-178.  iters = nstep_qeq, est = last GEst1. */

@@ -73,6 +73,11 @@ typedef struct {
   double *rc, *rc2, maxrc, cutoff_vpar30;
   double *TBL_Eclmb, *TBL_Evdw, *TBL_Eclmb_QEq; /* [inxn][i][0:1], [inxn][i] ; i in 0..NTABLE+1 */
   double UDR, UDRi, rctap, rctap2, CTap[8];
+  /* PQEq (module.F90:286-303, cmdline.F90:160-235): per type 1..ntype_pqeq; pair arrays [(ity)*(ntype_pqeq+1)+jty] */
+  int isPQEq, ntype_pqeq, *isPolarizable, *inxnpqeq;
+  int pq_clean;   /* 0 = the reference's behaviour beyond the cutoff (outputs keep the previous pair's values); 1 = outputs zeroed */
+  double *X0pqeq, *J0pqeq, *Zpqeq, *Rcpqeq, *Rspqeq, *Kspqeq, *alphacc, *alphasc, *alphass;
+  double *TBL_Eclmb_pcc, *TBL_Eclmb_psc, *TBL_Eclmb_pss;   /* [inxn][i][0:1], i in 0..NTABLE+1 (i = 0 is outside the Fortran array) */
 } Params;
 
 #define T2(p, a, b) ((p)[(a) * (P->nso + 1) + (b)])
@@ -333,6 +338,7 @@ typedef struct {
   int *ity; long long *gid;            /* atype = type + gid*1e-13, kept split */
   double *pos, *v, *f;                 /* SoA: x[k*NBUFFER + i], i 1-based */
   double *q, *qs, *qt, *gs, *gt, *hs, *ht, *qsfp, *qsfv;
+  double *spos, *fpqeq, *hshs, *hsht;  /* PQEq: shell displacement (SoA like pos), field term, H.h products */
   int *frcindx;
   int *header, *llist, *nacell, *nbheader, *nbllist, *nbnacell;
   int *nbrlist, *nbrindx;              /* [i*(MAXNEIGHBS+1)+k] */
@@ -355,12 +361,14 @@ typedef struct {
   Rank *R;
   double *trace; int ntrace, trace_cap;      /* per-iteration (Est, Gnew1, Gnew2) of the last QEq call */
   int qeq_iters_total;
+  long long pq_stale;                        /* PQEq lookups that fell outside the cutoff and left stale outputs behind (see pq_coulomb) */
   char err[256];
 } World;
 
 #define POS(r, i, k) ((r)->pos[(size_t)(k) * (r)->NBUFFER + (i)])
 #define VEL(r, i, k) ((r)->v[(size_t)(k) * (r)->NBUFFER + (i)])
 #define FRC(r, i, k) ((r)->f[(size_t)(k) * (r)->NBUFFER + (i)])
+#define SPOS(r, i, k) ((r)->spos[(size_t)(k) * (r)->NBUFFER + (i)])
 #define NBR(r, i, k) ((r)->nbrlist[(size_t)(i) * (MAXNEIGHBS + 1) + (k)])
 #define NBX(r, i, k) ((r)->nbrindx[(size_t)(i) * (MAXNEIGHBS + 1) + (k)])
 #define SL(r, i, k) ((size_t)(i) * (MAXNEIGHBS + 1) + (k))
@@ -428,7 +436,9 @@ static int inBuffer(const World *W, int dflag, const double dr[3], double rr) { 
 static void ensure(double **buf, size_t *cap, size_t n) { if (n > *cap) { *cap = 2 * n + 64; *buf = (double *)realloc(*buf, *cap * sizeof(double)); } }
 
 /* field lists per mode (comm.F90:118-220): positions first (shifted), then 1-d arrays */
-static int mode_ne(int imode) { /* atype travels as (type,gid): 11 and 13 instead of 10 and 12 */ return imode == MODE_COPY ? 11 : imode == MODE_MOVE ? 13 : imode == MODE_QCOPY1 ? 2 : imode == MODE_QCOPY2 ? 3 : 4; }
+static int mode_ne_(int imode) { /* atype travels as (type,gid): 11 and 13 instead of 10 and 12 */ return imode == MODE_COPY ? 11 : imode == MODE_MOVE ? 13 : imode == MODE_QCOPY1 ? 2 : imode == MODE_QCOPY2 ? 3 : 4; }
+/* PQEq adds the (unshifted) shell displacement spos to the COPY and MOVE messages, comm.F90:122,129-131,153,165-167 */
+#define mode_ne(imode) (mode_ne_(imode) + ((W->P.isPQEq && ((imode) == MODE_COPY || (imode) == MODE_MOVE)) ? 3 : 0))
 
 static void store_atoms(World *W, Rank *r, int dflag, int imode, const double dr[3]) { /* comm.F90:273-287, 367-453 */
   int ne = mode_ne(imode);
@@ -459,6 +469,7 @@ static void store_atoms(World *W, Rank *r, int dflag, int imode, const double dr
       s[o++] = r->q[n]; s[o++] = r->qs[n]; s[o++] = r->qt[n];
       if (imode == MODE_COPY) { s[o++] = r->hs[n]; s[o++] = r->ht[n]; s[o++] = (double)n; }
       else { s[o++] = r->qsfp[n]; s[o++] = r->qsfv[n]; }
+      if (W->P.isPQEq) { s[o++] = SPOS(r, n, 0); s[o++] = SPOS(r, n, 1); s[o++] = SPOS(r, n, 2); }
     } else if (imode == MODE_QCOPY1) { s[0] = r->qs[n]; s[1] = r->qt[n]; o = 2; }
     else { s[0] = r->hs[n]; s[1] = r->ht[n]; s[2] = r->q[n]; o = 3; }
     if (imode == MODE_MOVE) r->ity[n] = -1;          /* comm.F90:440 */
@@ -468,7 +479,6 @@ static void store_atoms(World *W, Rank *r, int dflag, int imode, const double dr
 }
 
 static int append_atoms(World *W, Rank *r, int dflag, int imode) { /* comm.F90:456-528 */
-  (void)W;
   int ne = mode_ne(imode);
   if (imode == MODE_CPBK) {
     for (int i = 0; i < r->nr / ne; i++) {
@@ -491,6 +501,7 @@ static int append_atoms(World *W, Rank *r, int dflag, int imode) { /* comm.F90:4
       r->q[m] = b[o++]; r->qs[m] = b[o++]; r->qt[m] = b[o++];
       if (imode == MODE_COPY) { r->hs[m] = b[o++]; r->ht[m] = b[o++]; r->frcindx[m] = (int)lround(b[o++]); }
       else { r->qsfp[m] = b[o++]; r->qsfv[m] = b[o++]; }
+      if (W->P.isPQEq) { SPOS(r, m, 0) = b[o++]; SPOS(r, m, 1) = b[o++]; SPOS(r, m, 2) = b[o++]; }
     } else if (imode == MODE_QCOPY1) { r->qs[m] = b[0]; r->qt[m] = b[1]; }
     else { r->hs[m] = b[0]; r->ht[m] = b[1]; r->q[m] = b[2]; }
   }
@@ -523,7 +534,7 @@ static int COPYATOMS(World *W, int imode, const double dr[3]) { /* comm.F90:2-10
       int ni = 0;
       for (int i = 1; i <= r->copyptr[6]; i++) if (r->ity[i] > 0) {
         ni++;
-        for (int k = 0; k < 3; k++) { POS(r, ni, k) = POS(r, i, k); VEL(r, ni, k) = VEL(r, i, k); }
+        for (int k = 0; k < 3; k++) { POS(r, ni, k) = POS(r, i, k); VEL(r, ni, k) = VEL(r, i, k); if (W->P.isPQEq) SPOS(r, ni, k) = SPOS(r, i, k); }
         r->ity[ni] = r->ity[i]; r->gid[ni] = r->gid[i]; r->q[ni] = r->q[i]; r->qs[ni] = r->qs[i]; r->qt[ni] = r->qt[i];
         r->qsfp[ni] = r->qsfp[i]; r->qsfv[ni] = r->qsfv[i];
       }
@@ -786,6 +797,318 @@ static int QEq(World *W) {
   return 0;
 }
 
+
+/* ================================================================== PQEq, src/pqeq.F90 + module.F90:386-611 */
+#define PQ2(a, i, j) ((a)[(i) * (P->ntype_pqeq + 1) + (j)])
+#define PQT(T, inxn, i, d) ((T)[((size_t)(inxn) * (NTABLE + 2) + (i)) * 2 + (d)])
+static const double lambda_pqeq = 0.462770;                         /* module.F90:298 */
+static const double rctap0_pqeq = 12.5;                             /* module.F90:282 */
+
+/* get_pqeq_parms, src/cmdline.F90:160-235: '#' lines skipped; "NPARMS n"; then per line  name flag X0 J0 Z Rc Rs Ks
+ * (the flag token is read and ignored: every listed type is polarizable, :217) */
+static int read_pqeq(Params *P, const char *path) {
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  char line[512]; int n = 0;
+  P->ntype_pqeq = 0;
+  while (fgets(line, sizeof line, f)) {
+    char *t = line; while (*t == ' ' || *t == '\t') t++;
+    if (*t == '#' || *t == '\n' || *t == 0) continue;     /* cmdline.F90:185 tests the first column only; blank lines do not occur in the inputs */
+    if (strstr(line, "NPARMS")) {
+      int np = 0; sscanf(strstr(line, "NPARMS") + 6, "%d", &np);
+      P->ntype_pqeq = np;
+      size_t m = (size_t)np + 1;
+      P->isPolarizable = ialloc(m); P->X0pqeq = dalloc(m); P->J0pqeq = dalloc(m); P->Zpqeq = dalloc(m); P->Rcpqeq = dalloc(m); P->Rspqeq = dalloc(m); P->Kspqeq = dalloc(m);
+      P->alphacc = dalloc(m * m); P->alphasc = dalloc(m * m); P->alphass = dalloc(m * m); P->inxnpqeq = ialloc(m * m);
+      continue;
+    }
+    if (!P->ntype_pqeq || n >= P->ntype_pqeq) continue;
+    char nm[16]; int flag; double x0, j0, z, rc, rs, ks;
+    if (sscanf(line, "%15s %d %lf %lf %lf %lf %lf %lf", nm, &flag, &x0, &j0, &z, &rc, &rs, &ks) != 8) continue;
+    n++;
+    P->isPolarizable[n] = 1; P->X0pqeq[n] = x0; P->J0pqeq[n] = j0; P->Zpqeq[n] = z; P->Rcpqeq[n] = rc; P->Rspqeq[n] = rs; P->Kspqeq[n] = ks;
+  }
+  fclose(f);
+  return (P->ntype_pqeq > 0 && n == P->ntype_pqeq) ? 0 : -2;
+}
+
+/* set_alphaij_pqeq + initialize_pqeq, src/module.F90:448-611 (needs rctap, CTap) */
+static void initialize_pqeq(Params *P) {
+  int nt = P->ntype_pqeq;
+  for (int ity = 1; ity <= nt; ity++) {
+    double alpha_ci = 0.5 * lambda_pqeq / (P->Rcpqeq[ity] * P->Rcpqeq[ity]), alpha_si = 0.5 * lambda_pqeq / (P->Rspqeq[ity] * P->Rspqeq[ity]);
+    for (int jty = 1; jty <= nt; jty++) {
+      double alpha_cj = 0.5 * lambda_pqeq / (P->Rcpqeq[jty] * P->Rcpqeq[jty]), alpha_sj = 0.5 * lambda_pqeq / (P->Rspqeq[jty] * P->Rspqeq[jty]);
+      PQ2(P->alphacc, ity, jty) = sqrt((alpha_ci * alpha_cj) / (alpha_ci + alpha_cj));
+      if (P->isPolarizable[ity] && P->isPolarizable[jty]) PQ2(P->alphass, ity, jty) = sqrt((alpha_si * alpha_sj) / (alpha_si + alpha_sj));
+      if (P->isPolarizable[ity]) PQ2(P->alphasc, ity, jty) = sqrt((alpha_si * alpha_cj) / (alpha_si + alpha_cj));
+    }
+  }
+  for (int ity = 1; ity <= nt; ity++) {                 /* module.F90:501-519 */
+    if (!P->isPolarizable[ity]) { P->Zpqeq[ity] = 0.0; P->Kspqeq[ity] = 0.0; }
+    else { P->chi[ity] = P->X0pqeq[ity]; P->eta[ity] = P->J0pqeq[ity]; }
+  }
+  for (int ity = 1; ity <= nt; ity++) P->eta[ity] = 2.0 * P->eta[ity];   /* :522 (eta(:) has ntype_pqeq elements in this routine) */
+  int icounter = 0;
+  for (int ity = 1; ity <= nt; ity++) for (int jty = ity; jty <= nt; jty++) { icounter++; PQ2(P->inxnpqeq, ity, jty) = icounter; PQ2(P->inxnpqeq, jty, ity) = icounter; }
+  size_t tsz = (size_t)(nt * nt + 1) * (NTABLE + 2) * 2;
+  P->TBL_Eclmb_pcc = dalloc(tsz); P->TBL_Eclmb_psc = dalloc(tsz); P->TBL_Eclmb_pss = dalloc(tsz);
+  const double sqrtpi_inv = 1.0 / sqrt(3.14159265358979);             /* module.F90:90-91 */
+  double UDR = P->rctap2 / NTABLE;
+  for (int ity = 1; ity <= nt; ity++) for (int jty = ity; jty <= nt; jty++) {
+    double A[3] = {PQ2(P->alphacc, ity, jty), PQ2(P->alphasc, ity, jty), PQ2(P->alphass, ity, jty)};
+    double *T[3] = {P->TBL_Eclmb_pcc, P->TBL_Eclmb_psc, P->TBL_Eclmb_pss};
+    int inxn = PQ2(P->inxnpqeq, ity, jty);
+    for (int i = 1; i <= NTABLE; i++) {
+      double dr2 = UDR * i, dr1 = sqrt(dr2);
+      double dr3 = dr1 * dr2, dr4 = dr2 * dr2, dr5 = dr1 * dr2 * dr2, dr6 = dr2 * dr2 * dr2, dr7 = dr1 * dr2 * dr2 * dr2;
+      double Tap = P->CTap[7] * dr7 + P->CTap[6] * dr6 + P->CTap[5] * dr5 + P->CTap[4] * dr4 + P->CTap[0];
+      double dTap = 7.0 * P->CTap[7] * dr5 + 6.0 * P->CTap[6] * dr4 + 5.0 * P->CTap[5] * dr3 + 4.0 * P->CTap[4] * dr2;
+      double dr1i = 1.0 / dr1, clmb = dr1i, dclmb = -dr1i * dr1i * dr1i;
+      for (int k = 0; k < 3; k++) {
+        double screen = erf(A[k] * dr1), dscreen = 2.0 * A[k] * sqrtpi_inv * exp(-A[k] * A[k] * dr2) * dr1i;
+        PQT(T[k], inxn, i, 0) = clmb * screen * Tap;
+        PQT(T[k], inxn, i, 1) = dclmb * screen * Tap + clmb * dscreen * Tap + clmb * screen * dTap;
+      }
+    }
+  }
+}
+
+/* get_coulomb_and_dcoulomb_pqeq, src/module.F90:386-445 (the live part, :401-418).  Beyond the cutoff the routine RETURNS
+ * WITHOUT TOUCHING ITS OUTPUTS: callers that do not reset them see the previous pair's values (qeq_initialize,
+ * update_shell_positions).  Kept: returns 0 in that case, 1 otherwise. */
+static int pq_coulomb(const Params *P, const double rr[3], int inxn, const double *TBL, double *Eclmb, double ff[3]) {
+  double dr2 = rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2];
+  if (dr2 > P->rctap2) { if (P->pq_clean) { *Eclmb = 0.0; ff[0] = ff[1] = ff[2] = 0.0; } return 0; }
+  int itb = (int)(dr2 * P->UDRi), itb1 = itb + 1;
+  double drtb = dr2 - itb * P->UDR; drtb = drtb * P->UDRi;
+  double drtb1 = 1.0 - drtb;
+  *Eclmb = drtb1 * PQT(TBL, inxn, itb, 0) + drtb * PQT(TBL, inxn, itb1, 0);
+  double dEclmb = drtb1 * PQT(TBL, inxn, itb, 1) + drtb * PQT(TBL, inxn, itb1, 1);
+  for (int k = 0; k < 3; k++) ff[k] = dEclmb * rr[k];
+  return 1;
+}
+
+/* qeq_initialize of PQEq, src/pqeq.F90:262-353: list + core-core hessian + field term fpqeq (Eq. 30).  Serial on purpose:
+ * pqeqc / pqeqs / ff are routine-scope variables that keep the previous pair's value when a lookup falls outside the cutoff. */
+static int pq_initialize(World *W, Rank *r, long long *nstale) {
+  const Params *P = &W->P; const int *nbcc = W->nbcc;
+  double pqeqc = 0.0, pqeqs = 0.0, ff[3] = {0, 0, 0};
+  for (int i = 0; i <= r->NATOMS; i++) NBP(r, i, 0) = 0;
+  for (int c1 = 0; c1 < nbcc[0]; c1++) for (int c2 = 0; c2 < nbcc[1]; c2++) for (int c3 = 0; c3 < nbcc[2]; c3++) {
+    size_t c = CIDX(c1, c2, c3, nbcc, MAXLAYERS_NB);
+    int i = r->nbheader[c];
+    for (int m = 1; m <= r->nbnacell[c]; m++) {
+      if (i > r->NATOMS) { i = r->nbllist[i]; continue; }
+      int ity = r->ity[i], cnt = 0;
+      r->fpqeq[i] = 0.0;
+      for (int mn = 0; mn < W->nbnmesh; mn++) {
+        size_t cn = CIDX(c1 + W->nbmesh[3 * mn], c2 + W->nbmesh[3 * mn + 1], c3 + W->nbmesh[3 * mn + 2], nbcc, MAXLAYERS_NB);
+        int j = r->nbheader[cn];
+        for (int n = 1; n <= r->nbnacell[cn]; n++) {
+          if (i != j) {
+            double dr[3] = {POS(r, i, 0) - POS(r, j, 0), POS(r, i, 1) - POS(r, j, 1), POS(r, i, 2) - POS(r, j, 2)};
+            float dr2 = (float)(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);      /* real(4) :: dr2, pqeq.F90:271,305 */
+            if ((double)dr2 < P->rctap2) {
+              int jty = r->ity[j];
+              if (cnt >= r->maxn10) { snprintf(W->err, 256, "nbplist greater than MAXNEIGHBS10=%d", r->maxn10); return -1; }
+              cnt++;
+              NBP(r, i, cnt) = j;
+              if (!pq_coulomb(P, dr, PQ2(P->inxnpqeq, ity, jty), P->TBL_Eclmb_pcc, &pqeqc, ff)) (*nstale)++;
+              HES(r, i, cnt) = Cclmb0_qeq * pqeqc;
+              r->fpqeq[i] = r->fpqeq[i] + Cclmb0_qeq * pqeqc * P->Zpqeq[jty];
+              if (P->isPolarizable[jty]) {
+                double d2[3] = {POS(r, i, 0) - POS(r, j, 0) - SPOS(r, j, 0), POS(r, i, 1) - POS(r, j, 1) - SPOS(r, j, 1), POS(r, i, 2) - POS(r, j, 2) - SPOS(r, j, 2)};
+                if (!pq_coulomb(P, d2, PQ2(P->inxnpqeq, jty, ity), P->TBL_Eclmb_psc, &pqeqs, ff)) (*nstale)++;
+                r->fpqeq[i] = r->fpqeq[i] - Cclmb0_qeq * pqeqs * P->Zpqeq[jty];
+              }
+            }
+          }
+          j = r->nbllist[j];
+        }
+      }
+      NBP(r, i, 0) = cnt;
+      i = r->nbllist[i];
+    }
+  }
+  return 0;
+}
+
+static void pq_get_gradient(World *W, double Gnew[2]) { /* pqeq.F90:432-478 */
+  const Params *P = &W->P;
+  double ga[64], gb[64];
+  for (int p = 0; p < W->nprocs; p++) {
+    Rank *r = &W->R[p];
+    for (int i = 1; i <= r->NATOMS; i++) {
+      double gssum = 0.0, gtsum = 0.0;
+      for (int j1 = 1; j1 <= NBP(r, i, 0); j1++) {
+        int j = NBP(r, i, j1);
+        gssum = gssum + HES(r, i, j1) * r->qs[j];
+        gtsum = gtsum + HES(r, i, j1) * r->qt[j];
+      }
+      double eta_ity = P->eta[r->ity[i]];
+      r->gs[i] = -P->chi[r->ity[i]] - eta_ity * r->qs[i] - gssum - r->fpqeq[i];
+      r->gt[i] = -1.0 - eta_ity * r->qt[i] - gtsum;
+    }
+    double a = 0, b = 0;
+    for (int i = 1; i <= r->NATOMS; i++) a += r->gs[i] * r->gs[i];
+    for (int i = 1; i <= r->NATOMS; i++) b += r->gt[i] * r->gt[i];
+    ga[p] = a; gb[p] = b;
+  }
+  Gnew[0] = allreduce_sum(ga, W->nprocs); Gnew[1] = allreduce_sum(gb, W->nprocs);
+}
+
+static double pq_get_hsh(World *W) { /* pqeq.F90:356-429 -- Est with the shell terms, no doubling for resident partners */
+  const Params *P = &W->P;
+  double Ea[64];
+  for (int p = 0; p < W->nprocs; p++) {
+    Rank *r = &W->R[p];
+    double Est = 0.0;
+    for (int i = 1; i <= r->NATOMS; i++) {
+      int ity = r->ity[i];
+      double eta_ity = P->eta[ity];
+      r->hshs[i] = eta_ity * r->hs[i];
+      r->hsht[i] = eta_ity * r->ht[i];
+      double qic = r->q[i] + P->Zpqeq[ity];
+      double shelli[3] = {POS(r, i, 0) + SPOS(r, i, 0), POS(r, i, 1) + SPOS(r, i, 1), POS(r, i, 2) + SPOS(r, i, 2)};
+      Est = Est + P->chi[ity] * r->q[i] + 0.5 * eta_ity * r->q[i] * r->q[i];
+      for (int j1 = 1; j1 <= NBP(r, i, 0); j1++) {
+        int j = NBP(r, i, j1), jty = r->ity[j];
+        double qjc = r->q[j] + P->Zpqeq[jty];
+        double shellj[3] = {POS(r, j, 0) + SPOS(r, j, 0), POS(r, j, 1) + SPOS(r, j, 1), POS(r, j, 2) + SPOS(r, j, 2)};
+        double Ccicj = 0.0, Csicj = 0.0, Csisj = 0.0, ff[3];
+        Ccicj = HES(r, i, j1) * qic * qjc;
+        if (P->isPolarizable[ity]) {
+          double d[3] = {shelli[0] - POS(r, j, 0), shelli[1] - POS(r, j, 1), shelli[2] - POS(r, j, 2)};
+          pq_coulomb(P, d, PQ2(P->inxnpqeq, ity, jty), P->TBL_Eclmb_psc, &Csicj, ff);
+          Csicj = -Cclmb0_qeq * Csicj * qjc * P->Zpqeq[ity];
+          if (P->isPolarizable[jty]) {
+            double d2[3] = {shelli[0] - shellj[0], shelli[1] - shellj[1], shelli[2] - shellj[2]};
+            pq_coulomb(P, d2, PQ2(P->inxnpqeq, ity, jty), P->TBL_Eclmb_pss, &Csisj, ff);
+            Csisj = Cclmb0_qeq * Csisj * P->Zpqeq[ity] * P->Zpqeq[jty];
+          }
+        }
+        r->hshs[i] = r->hshs[i] + HES(r, i, j1) * r->hs[j];
+        r->hsht[i] = r->hsht[i] + HES(r, i, j1) * r->ht[j];
+        double Est1 = 0.5 * (Ccicj + Csisj);
+        Est = Est + Est1 + Csicj;
+      }
+    }
+    Ea[p] = Est;
+  }
+  return allreduce_sum(Ea, W->nprocs);
+}
+
+/* update_shell_positions, src/pqeq.F90:184-259 (Eqs. 37-39); sf / Esc / Ess are routine-scope (stale beyond the cutoff) */
+static void pq_update_shells(World *W, Rank *r, long long *nstale) {
+  const Params *P = &W->P;
+  const double MAX_SHELL_DISPLACEMENT = 1e-3;
+  int n = r->NATOMS;
+  double *sforce = dalloc(3 * (size_t)(n + 1));
+  double sf[3] = {0, 0, 0}, Esc = 0.0, Ess = 0.0;
+  for (int i = 1; i <= n; i++) {
+    int ity = r->ity[i];
+    if (!P->isPolarizable[ity]) continue;
+    for (int k = 0; k < 3; k++) sforce[3 * i + k] = sforce[3 * i + k] - P->Kspqeq[ity] * SPOS(r, i, k);
+    double shelli[3] = {POS(r, i, 0) + SPOS(r, i, 0), POS(r, i, 1) + SPOS(r, i, 1), POS(r, i, 2) + SPOS(r, i, 2)};
+    for (int j1 = 1; j1 <= NBP(r, i, 0); j1++) {
+      int j = NBP(r, i, j1), jty = r->ity[j];
+      double qjc = r->q[j] + P->Zpqeq[jty];
+      double shellj[3] = {POS(r, j, 0) + SPOS(r, j, 0), POS(r, j, 1) + SPOS(r, j, 1), POS(r, j, 2) + SPOS(r, j, 2)};
+      double d[3] = {shelli[0] - POS(r, j, 0), shelli[1] - POS(r, j, 1), shelli[2] - POS(r, j, 2)};
+      if (!pq_coulomb(P, d, PQ2(P->inxnpqeq, ity, jty), P->TBL_Eclmb_psc, &Esc, sf)) (*nstale)++;
+      for (int k = 0; k < 3; k++) { double ff = -Cclmb0 * sf[k] * qjc * P->Zpqeq[ity]; sforce[3 * i + k] = sforce[3 * i + k] - ff; }
+      if (P->isPolarizable[jty]) {
+        double d2[3] = {shelli[0] - shellj[0], shelli[1] - shellj[1], shelli[2] - shellj[2]};
+        if (!pq_coulomb(P, d2, PQ2(P->inxnpqeq, ity, jty), P->TBL_Eclmb_pss, &Ess, sf)) (*nstale)++;
+        for (int k = 0; k < 3; k++) { double ff = Cclmb0 * sf[k] * P->Zpqeq[ity] * P->Zpqeq[jty]; sforce[3 * i + k] = sforce[3 * i + k] - ff; }
+      }
+    }
+  }
+  for (int i = 1; i <= n; i++) {
+    int ity = r->ity[i];
+    double dr[3] = {sforce[3 * i] / P->Kspqeq[ity], sforce[3 * i + 1] / P->Kspqeq[ity], sforce[3 * i + 2] / P->Kspqeq[ity]};
+    double ddr = sqrt(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
+    if (ddr > MAX_SHELL_DISPLACEMENT) for (int k = 0; k < 3; k++) dr[k] = dr[k] / ddr * MAX_SHELL_DISPLACEMENT;
+    if (P->isPolarizable[ity]) for (int k = 0; k < 3; k++) SPOS(r, i, k) = SPOS(r, i, k) + dr[k];
+  }
+  free(sforce);
+}
+
+static int PQEq(World *W) { /* pqeq.F90:2-178: the QEq driver with the PQEq list / products, then the shell update */
+  const Params *P = &W->P;
+  int nmax;
+  double QCopyDr[3] = {P->rctap / W->lata, P->rctap / W->latb, P->rctap / W->latc};
+  for (int p = 0; p < W->nprocs; p++) {
+    Rank *r = &W->R[p];
+    if (W->isQEq == 1) {
+      for (int i = 1; i <= r->NATOMS; i++) { r->qsfp[i] = r->q[i]; r->qsfv[i] = 0.0; }
+      for (int i = 0; i < r->NBUFFER; i++) { r->qs[i] = 0.0; r->qt[i] = 0.0; }
+      for (int i = 1; i <= r->NATOMS; i++) r->qs[i] = r->q[i];
+    } else if (W->isQEq == 2) {
+      for (int i = 1; i <= r->NATOMS; i++) { r->qs[i] = W->Lex_fqs * r->qsfp[i] + (1.0 - W->Lex_fqs) * r->q[i]; r->qt[i] = 0.0; }
+    }
+  }
+  if (W->isQEq == 1) nmax = W->NMAXQEq; else if (W->isQEq == 2) nmax = 1; else return 0;
+  W->ntrace = 0;
+  if (COPYATOMS(W, MODE_COPY, QCopyDr)) return -1;
+  for (int p = 0; p < W->nprocs; p++) {
+    Rank *r = &W->R[p];
+    if (LINKEDLIST(W, r, W->nblcsize, r->nbheader, r->nbllist, r->nbnacell, W->nbcc, MAXLAYERS_NB)) { snprintf(W->err, 256, "atom outside the cell grid (NB)"); return -1; }
+    if (pq_initialize(W, r, &W->pq_stale)) return -1;
+  }
+  double Gnew[2], Gold[2];
+  COPYATOMS(W, MODE_QCOPY1, QCopyDr);
+  pq_get_gradient(W, Gnew);
+  for (int p = 0; p < W->nprocs; p++) { Rank *r = &W->R[p]; for (int i = 1; i <= r->NATOMS; i++) { r->hs[i] = r->gs[i]; r->ht[i] = r->gt[i]; } }
+  COPYATOMS(W, MODE_QCOPY2, QCopyDr);
+  double GEst2 = 1e99, GEst1 = 0;
+  int it;
+  for (it = 0; it <= nmax - 1; it++) {
+    GEst1 = pq_get_hsh(W);
+    trace_push(W, GEst1, Gnew[0], Gnew[1]);
+    if (0.5 * (fabs(GEst2) + fabs(GEst1)) < W->QEq_tol) break;
+    if (fabs(GEst2) > 0.0 && (fabs(GEst1 / GEst2 - 1.0) < W->QEq_tol)) break;
+    GEst2 = GEst1;
+    double pa[64], pb[64], pc[64], pd[64];
+    for (int p = 0; p < W->nprocs; p++) {              /* four dot_products then one allreduce, pqeq.F90:118-131 */
+      Rank *r = &W->R[p];
+      double a = 0, b = 0, c = 0, d = 0;
+      for (int i = 1; i <= r->NATOMS; i++) a += r->gs[i] * r->hs[i];
+      for (int i = 1; i <= r->NATOMS; i++) c += r->hs[i] * r->hshs[i];
+      for (int i = 1; i <= r->NATOMS; i++) b += r->gt[i] * r->ht[i];
+      for (int i = 1; i <= r->NATOMS; i++) d += r->ht[i] * r->hsht[i];
+      pa[p] = a; pb[p] = b; pc[p] = c; pd[p] = d;
+    }
+    double g_h[2] = {allreduce_sum(pa, W->nprocs), allreduce_sum(pb, W->nprocs)}, h_hsh[2] = {allreduce_sum(pc, W->nprocs), allreduce_sum(pd, W->nprocs)};
+    float lmin[2];
+    lmin[0] = (float)(g_h[0] / h_hsh[0]); lmin[1] = (float)(g_h[1] / h_hsh[1]);
+    for (int p = 0; p < W->nprocs; p++) {
+      Rank *r = &W->R[p];
+      double a = 0, b = 0;
+      for (int i = 1; i <= r->NATOMS; i++) { r->qs[i] = r->qs[i] + (double)lmin[0] * r->hs[i]; r->qt[i] = r->qt[i] + (double)lmin[1] * r->ht[i]; }
+      for (int i = 1; i <= r->NATOMS; i++) a += r->qs[i];
+      for (int i = 1; i <= r->NATOMS; i++) b += r->qt[i];
+      pa[p] = a; pb[p] = b;
+    }
+    double ssum = allreduce_sum(pa, W->nprocs), tsum = allreduce_sum(pb, W->nprocs);
+    double mu = ssum / tsum;
+    for (int p = 0; p < W->nprocs; p++) { Rank *r = &W->R[p]; for (int i = 1; i <= r->NATOMS; i++) r->q[i] = r->qs[i] - mu * r->qt[i]; }
+    COPYATOMS(W, MODE_QCOPY1, QCopyDr);
+    Gold[0] = Gnew[0]; Gold[1] = Gnew[1];
+    pq_get_gradient(W, Gnew);
+    for (int p = 0; p < W->nprocs; p++) {
+      Rank *r = &W->R[p];
+      for (int i = 1; i <= r->NATOMS; i++) { r->hs[i] = r->gs[i] + (Gnew[0] / Gold[0]) * r->hs[i]; r->ht[i] = r->gt[i] + (Gnew[1] / Gold[1]) * r->ht[i]; }
+    }
+    COPYATOMS(W, MODE_QCOPY2, QCopyDr);
+  }
+  for (int p = 0; p < W->nprocs; p++) pq_update_shells(W, &W->R[p], &W->pq_stale);     /* pqeq.F90:169 */
+  W->nstep_qeq = it;
+  W->qeq_iters_total += it;
+  return 0;
+}
+
 /* ------------------------------------------------------------------ BOCALC, src/bo.F90 */
 static void BOPRIM(World *W, Rank *r) { /* bo.F90:28-118 */
   const Params *P = &W->P;
@@ -980,6 +1303,58 @@ static void ENbond(World *W, Rank *r) { /* pot.F90:676-781 */
       double CEclmb = drtb1 * Tc[2 * itb + 1] + drtb * Tc[2 * itb1 + 1]; CEclmb = CEclmb * qij;
       r->PE[11] += PEvdw; r->PE[12] += PEclmb;
       for (int k = 0; k < 3; k++) { double ff = (CEvdw + CEclmb) * d[k]; FRC(r, i, k) -= ff; FRC(r, j, k) += ff; }
+    }
+  }
+}
+
+static void ENbond_PQEq(World *W, Rank *r) { /* pot.F90:784-923 */
+  const Params *P = &W->P;
+  for (int i = 1; i <= r->NATOMS; i++) {
+    int ity = r->ity[i]; long long iid = r->gid[i];
+    double Eshell = 0.0;
+    if (P->isPolarizable[ity]) {
+      double dr2 = SPOS(r, i, 0) * SPOS(r, i, 0) + SPOS(r, i, 1) * SPOS(r, i, 1) + SPOS(r, i, 2) * SPOS(r, i, 2);
+      Eshell = 0.5 * P->Kspqeq[ity] * dr2;
+    }
+    r->PE[13] = r->PE[13] + CEchrge * (P->chi[ity] * r->q[i] + 0.5 * P->eta[ity] * r->q[i] * r->q[i]) + Eshell;
+    double qic = r->q[i] + P->Zpqeq[ity];
+    for (int j1 = 1; j1 <= NBP(r, i, 0); j1++) {
+      int j = NBP(r, i, j1);
+      if (!(iid < r->gid[j])) continue;                 /* if(iid<jid), :830 -- the opposite half of ENbond's rule */
+      double dr[3] = {POS(r, i, 0) - POS(r, j, 0), POS(r, i, 1) - POS(r, j, 1), POS(r, i, 2) - POS(r, j, 2)};
+      double dr2 = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
+      int jty = r->ity[j], inxn = T2(P->inxn2, ity, jty);
+      int itb = (int)(dr2 * P->UDRi), itb1 = itb + 1;
+      double drtb = dr2 - itb * P->UDR; drtb = drtb * P->UDRi;
+      double drtb1 = 1.0 - drtb;
+      const double *Tv = P->TBL_Evdw + (size_t)inxn * (NTABLE + 2) * 2;
+      double PEvdw = drtb1 * Tv[2 * itb] + drtb * Tv[2 * itb1], CEvdw = drtb1 * Tv[2 * itb + 1] + drtb * Tv[2 * itb1 + 1];
+      double qjc = r->q[j] + P->Zpqeq[jty], qij = qic * qjc;
+      double Ecc = 0, Esc = 0, Ecs = 0, Ess = 0, fcc[3] = {0, 0, 0}, fsc[3] = {0, 0, 0}, fcs[3] = {0, 0, 0}, fss[3] = {0, 0, 0};
+      pq_coulomb(P, dr, PQ2(P->inxnpqeq, ity, jty), P->TBL_Eclmb_pcc, &Ecc, fcc);
+      for (int k = 0; k < 3; k++) fcc[k] = Cclmb0 * qij * fcc[k];
+      Ecc = Cclmb0 * Ecc * qij;
+      if (P->isPolarizable[ity]) {
+        double d[3] = {dr[0] + SPOS(r, i, 0), dr[1] + SPOS(r, i, 1), dr[2] + SPOS(r, i, 2)};
+        pq_coulomb(P, d, PQ2(P->inxnpqeq, ity, jty), P->TBL_Eclmb_psc, &Esc, fsc);
+        for (int k = 0; k < 3; k++) fsc[k] = -Cclmb0 * P->Zpqeq[ity] * qjc * fsc[k];
+        Esc = -Cclmb0 * Esc * P->Zpqeq[ity] * qjc;
+      }
+      if (P->isPolarizable[jty]) {
+        double d[3] = {dr[0] - SPOS(r, j, 0), dr[1] - SPOS(r, j, 1), dr[2] - SPOS(r, j, 2)};
+        pq_coulomb(P, d, PQ2(P->inxnpqeq, jty, ity), P->TBL_Eclmb_psc, &Ecs, fcs);
+        for (int k = 0; k < 3; k++) fcs[k] = -Cclmb0 * P->Zpqeq[jty] * qic * fcs[k];
+        Ecs = -Cclmb0 * Ecs * qic * P->Zpqeq[jty];
+      }
+      if (P->isPolarizable[ity] && P->isPolarizable[jty]) {
+        double d[3] = {dr[0] + SPOS(r, i, 0) - SPOS(r, j, 0), dr[1] + SPOS(r, i, 1) - SPOS(r, j, 1), dr[2] + SPOS(r, i, 2) - SPOS(r, j, 2)};
+        pq_coulomb(P, d, PQ2(P->inxnpqeq, ity, jty), P->TBL_Eclmb_pss, &Ess, fss);
+        for (int k = 0; k < 3; k++) fss[k] = Cclmb0 * P->Zpqeq[ity] * P->Zpqeq[jty] * fss[k];
+        Ess = Cclmb0 * Ess * P->Zpqeq[ity] * P->Zpqeq[jty];
+      }
+      double PEclmb = Ecc + Esc + Ecs + Ess;
+      r->PE[11] += PEvdw; r->PE[12] += PEclmb;
+      for (int k = 0; k < 3; k++) { double ff = CEvdw * dr[k] + fcc[k] + fcs[k] + fsc[k] + fss[k]; FRC(r, i, k) -= ff; FRC(r, j, k) += ff; }
     }
   }
 }
@@ -1320,7 +1695,8 @@ static int FORCE(World *W) { /* pot.F90:2-90 */
     if (NEIGHBORLIST(W, r, NMINCELL)) return -1;
     if (nb_pairlist(W, r, 0)) return -1;               /* GetNonbondingPairList */
     BOPRIM(W, r); BOFULL(W, r);
-    ENbond(W, r); Ebond(W, r); Elnpr(W, r); Ehb(W, r); E3b(W, r); E4b(W, r);
+    if (W->P.isPQEq) ENbond_PQEq(W, r); else ENbond(W, r);      /* pot.F90:48-52 */
+    Ebond(W, r); Elnpr(W, r); Ehb(W, r); E3b(W, r); E4b(W, r);
     ForceBondedTerms(r);
     for (int i = 1; i < r->NBUFFER; i++) {             /* virial, pot.F90:65-72 */
       r->astr[0] += POS(r, i, 0) * FRC(r, i, 0); r->astr[1] += POS(r, i, 1) * FRC(r, i, 1); r->astr[2] += POS(r, i, 2) * FRC(r, i, 2);
@@ -1343,7 +1719,7 @@ static int md_step(World *W) {
   }
   double z[3] = {0, 0, 0};
   if (COPYATOMS(W, MODE_MOVE, z)) return -1;
-  if (QEq(W)) return -1;                               /* qstep = 1 */
+  if (W->P.isPQEq ? PQEq(W) : QEq(W)) return -1;       /* qstep = 1; main.F90:77-83 */
   if (FORCE(W)) return -1;
   for (int p = 0; p < W->nprocs; p++) {
     Rank *r = &W->R[p];
@@ -1375,6 +1751,7 @@ static void alloc_rank(World *W, Rank *r, int p, int NBUFFER) {
   r->pos = dalloc(3 * NB); r->v = dalloc(3 * NB); r->f = dalloc(3 * NB);
   r->q = dalloc(NB); r->qs = dalloc(NB); r->qt = dalloc(NB); r->gs = dalloc(NB); r->gt = dalloc(NB); r->hs = dalloc(NB); r->ht = dalloc(NB);
   r->qsfp = dalloc(NB); r->qsfv = dalloc(NB);
+  r->spos = dalloc(3 * NB); r->fpqeq = dalloc(NB); r->hshs = dalloc(NB); r->hsht = dalloc(NB);   /* init.F90:117-120 */
   r->llist = ialloc(NB); r->nbllist = ialloc(NB);
   r->nbrlist = ialloc(NB * (MAXNEIGHBS + 1)); r->nbrindx = ialloc(NB * (MAXNEIGHBS + 1));
   size_t ns = NB * (MAXNEIGHBS + 1);
@@ -1409,6 +1786,26 @@ void *rxo_create(const char *ffield, const double lattice[6], const int vprocs[3
   }
   return W;
 }
+
+/* --pqeq <path> / rxmd.in PQEqParm (cmdline.F90:112-128,291-293): call between rxo_create and rxo_init.
+ * Switches the taper cutoff to rctap0_pqeq and replaces chi / eta (init.F90:28-43). */
+int rxo_enable_pqeq(void *w, const char *pqeq_path) {
+  World *W = (World *)w; Params *P = &W->P;
+  int rc = read_pqeq(P, pqeq_path);
+  if (rc) { snprintf(W->err, 256, "cannot read PQEq parameters from %s (%d)", pqeq_path, rc); return rc; }
+  if (P->ntype_pqeq < P->nso) { snprintf(W->err, 256, "PQEq parameter file lists %d types, the ffield %d", P->ntype_pqeq, P->nso); return -3; }
+  P->isPQEq = 1;
+  P->rctap = rctap0_pqeq; P->rctap2 = P->rctap * P->rctap;
+  double rc_ = P->rctap;
+  P->CTap[0] = 1.0; P->CTap[1] = P->CTap[2] = P->CTap[3] = 0.0;
+  P->CTap[4] = -35.0 / powi(rc_, 4); P->CTap[5] = 84.0 / powi(rc_, 5); P->CTap[6] = -70.0 / powi(rc_, 6); P->CTap[7] = 20.0 / powi(rc_, 7);
+  P->UDR = P->rctap2 / NTABLE; P->UDRi = 1.0 / P->UDR;
+  initialize_pqeq(P);
+  return 0;
+}
+long long rxo_pqeq_stale(void *w) { return ((World *)w)->pq_stale; }
+/* clean = 1: a lookup beyond the cutoff yields zero (what the HIP engine does) instead of the previous pair's values */
+void rxo_set_pqeq_clean(void *w, int clean) { ((World *)w)->P.pq_clean = clean; }
 
 /* rxff.bin record -> state (ReadBIN, src/fileio.F90:444-555): rnorm are normalised LOCAL coordinates */
 int rxo_set_atoms(void *w, int rank, int n, const double *rnorm, const double *v, const double *q, const int *type, const long long *gid) {
@@ -1463,7 +1860,7 @@ int rxo_init(void *w) { /* the rest of INITSYSTEM: cutoffs, cells, tables, 10 A 
   return 0;
 }
 
-int rxo_qeq(void *w) { return QEq((World *)w); }
+int rxo_qeq(void *w) { World *W = (World *)w; return W->P.isPQEq ? PQEq(W) : QEq(W); }   /* main.F90:27-31 */
 int rxo_force(void *w) { return FORCE((World *)w); }
 int rxo_step(void *w, int nsteps) { for (int s = 0; s < nsteps; s++) if (md_step((World *)w)) return -1; return 0; }
 const char *rxo_error(void *w) { return ((World *)w)->err; }
@@ -1513,6 +1910,8 @@ int rxo_get(void *w, int rank, int what, double *out) {
     case 5: for (int i = 1; i <= n; i++) out[i - 1] = (double)r->gid[i]; return n;
     case 6: for (int i = 1; i <= n; i++) out[i - 1] = r->qs[i]; return n;
     case 7: for (int i = 1; i <= n; i++) out[i - 1] = r->qt[i]; return n;
+    case 8: for (int i = 1; i <= n; i++) for (int k = 0; k < 3; k++) out[3 * (i - 1) + k] = SPOS(r, i, k); return n;
+    case 9: for (int i = 1; i <= n; i++) out[i - 1] = r->fpqeq[i]; return n;
     case 100: for (int i = 1; i <= G; i++) for (int k = 0; k < 3; k++) out[3 * (i - 1) + k] = POS(r, i, k); return G;
     case 101: for (int i = 1; i <= G; i++) out[i - 1] = r->delta[i]; return G;
     case 102: for (int i = 1; i <= G; i++) out[i - 1] = r->deltap[2 * i]; return G;

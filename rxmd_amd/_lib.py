@@ -14,7 +14,8 @@ class RxmdConfig(C.Structure):
     _fields_ = [("ffield_path", C.c_char_p), ("lattice", C.c_double * 6), ("vprocs", C.c_int * 3), ("myid", C.c_int),
                 ("isQEq", C.c_int), ("NMAXQEq", C.c_int), ("QEq_tol", C.c_double), ("qstep", C.c_int), ("dt_fs", C.c_double),
                 ("Lex_fqs", C.c_double), ("Lex_k", C.c_double), ("nbuffer", C.c_int), ("maxneighbs", C.c_int),
-                ("maxneighbs10", C.c_int), ("device", C.c_int), ("qeq_mode", C.c_int), ("reserved", C.c_int * 7)]
+                ("maxneighbs10", C.c_int), ("device", C.c_int), ("qeq_mode", C.c_int), ("reserved0", C.c_int),
+                ("pqeq_path", C.c_char_p), ("reserved", C.c_int * 4)]
 
 
 class RxmdStats(C.Structure):
@@ -55,6 +56,8 @@ SYMBOLS = [
     ("rxmd_hip_get_atoms", C.c_int, [H, C.c_int, PD, PD, PD, PD, PD, PD]),
     ("rxmd_hip_set_charges", C.c_int, [H, C.c_int, PD]),
     ("rxmd_hip_set_velocities", C.c_int, [H, C.c_int, PD]),
+    ("rxmd_hip_get_shells", C.c_int, [H, PD, C.c_int]),
+    ("rxmd_hip_set_shells", C.c_int, [H, C.c_int, PD]),
     ("rxmd_hip_qeq", C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("rxmd_hip_force", C.c_int, [H, PD]),
     ("rxmd_hip_step", C.c_int, [H, C.c_int]),

@@ -107,7 +107,7 @@ void Engine::force() {
   hipEventRecord(ev[2], stream);
   bond_orders();
   hipEventRecord(ev[3], stream);
-  nonbonded();
+  if (ff.pqeq) nonbonded_pqeq(); else nonbonded();     // pot.F90:48-52
   hipEventRecord(ev[4], stream);
   bonded_energies();
   assemble_forces();

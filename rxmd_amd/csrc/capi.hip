@@ -137,6 +137,35 @@ int rxmd_hip_set_velocities(rxmd_handle h, int natoms, const double *v) {
   });
 }
 
+int rxmd_hip_get_shells(rxmd_handle h, double *spos3, int capacity) {
+  int n = 0;
+  const int rc = guarded(h, [&](Engine &e) {
+    if (!e.ff.pqeq) throw EngineError(RXMD_E_STATE, "the engine was created without a PQEq parameter file");
+    if (!spos3 || capacity < e.N) throw EngineError(RXMD_E_ARG, "capacity smaller than natoms");
+    RX_HIP(hipStreamSynchronize(e.stream));
+    std::vector<double> tmp(e.N);
+    for (int a = 0; a < 3; ++a) {
+      RX_HIP(hipMemcpy(tmp.data(), e.shl[a], sizeof(double) * e.N, hipMemcpyDeviceToHost));
+      for (int i = 0; i < e.N; ++i) spos3[3 * static_cast<size_t>(i) + a] = tmp[i];
+    }
+    n = e.N;
+  });
+  return rc ? rc : n;
+}
+
+int rxmd_hip_set_shells(rxmd_handle h, int natoms, const double *spos3) {
+  return guarded(h, [&](Engine &e) {
+    if (!e.ff.pqeq) throw EngineError(RXMD_E_STATE, "the engine was created without a PQEq parameter file");
+    if (natoms != e.N || !spos3) throw EngineError(RXMD_E_ARG, "natoms mismatch");
+    std::vector<double> tmp(natoms);
+    for (int a = 0; a < 3; ++a) {
+      for (int i = 0; i < natoms; ++i) tmp[i] = spos3[3 * static_cast<size_t>(i) + a];
+      RX_HIP(hipMemcpy(e.shl[a], tmp.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+    }
+    e.lists_valid = false;
+  });
+}
+
 int rxmd_hip_qeq(rxmd_handle h, int *iters, double *est) {
   return guarded(h, [&](Engine &e) {
     e.qeq();

@@ -54,6 +54,12 @@ struct DevFF {
   double UDR, UDRi, rctap2, cutoff_vpar30, vpar1, vpar2;
   double plp1, povun3, povun4, povun6, povun7, povun8;
   double pval6, pval8, pval9, pval10, ppen2, ppen3, ppen4, pcoa2, pcoa3, pcoa4, ptor2, ptor3, ptor4, pcot2;
+  // PQEq (pqeq != 0): per-type core charge Z and shell spring K, pair rows, and the three screened-Coulomb tables
+  // (core-core, shell-core, shell-shell) as nodes (E, E_next - E, F, F_next - F), F = (1/r) dE/dr   (module.F90:537-611)
+  int pqeq, npq1;
+  const double *Zpq, *Kspq;
+  const int *inxnpq;            // [a * npq1 + b]
+  const double4 *tabPcc, *tabPsc, *tabPss;   // [row * (NTABLE+2) + i]
 };
 
 struct Box {
@@ -75,7 +81,7 @@ constexpr int WAVE = 64;
 
 struct Engine {
   rxmd_config cfg{};
-  std::string ffield_path, err;
+  std::string ffield_path, pqeq_path, err;
   ForceField ff;
   Box box{};
   int vID[3] = {0, 0, 0}, target_node[7] = {0}, nprocs = 1;
@@ -93,9 +99,12 @@ struct Engine {
 
   // ---- device memory ----
   DevFF dff{};
-  void *ffblob = nullptr;
+  void *ffblob = nullptr, *pqblob = nullptr;
   double *pos[3] = {}, *vel[3] = {}, *frc[3] = {}, *spos[3] = {};  // real pos, v, f ; normalised-local pos (ghost build)
   double *q = nullptr, *qsfp = nullptr, *qsfv = nullptr;
+  // PQEq: shell displacement of every atom (reference spos, module.F90:286; real units, travels with the atom), its cell-sorted
+  // copy, the shell-core matrix values of the 10 A list and per-row constants (fpqeq, sum H Z, sum Hsc Z, shell-shell energy)
+  double *shl[3] = {}; double4 *sorted_shl = nullptr; double *hsc = nullptr; double4 *pqrow = nullptr;
   int *type = nullptr; long long *gid = nullptr;
   double2 *qst = nullptr, *hst = nullptr, *gst = nullptr;  // (qs,qt) (hs,ht) (gs,gt) interleaved
   double2 *hst2 = nullptr;     // second (hs,ht) buffer: the fused direction kernel reads the old and writes the new one (qeq.hip)
@@ -170,6 +179,9 @@ struct Engine {
   void bond_orders();
   void bonded_energies();
   void nonbonded();
+  void pqeq_sorted_shells();      // ghost shells <- owners, cell-sorted copy (MODE_COPY payload of spos, comm.F90:129-131)
+  void pqeq_update_shells();      // update_shell_positions, pqeq.F90:184-259
+  void nonbonded_pqeq();          // ENbond_PQEq, pot.F90:784-923
   void assemble_forces();
   void check_device_error(const char *where);
   double reduce_partials(int ncomp, int nblocks, double *out);  // host-side helper

@@ -74,7 +74,14 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   Lex_w2 = 2.0 * cfg.Lex_k / dt / dt;             // init.F90:69
   dthm.assign(ff.nso + 1, 0.0); hmas.assign(ff.nso + 1, 0.0);
   for (int t = 1; t <= ff.nso; ++t) { dthm[t] = dt * 0.5 / ff.atom[t].mass; hmas[t] = 0.5 * ff.atom[t].mass; }  // init.F90:105-108
-  ff.build_taper(10.0);                           // rctap0, module.F90:281 (no PQEq)
+  if (cfg.pqeq_path && cfg.pqeq_path[0]) {          // --pqeq: chi/eta replaced, taper cutoff 12.5 A (init.F90:28-43, module.F90:282)
+    pqeq_path = cfg.pqeq_path; cfg.pqeq_path = pqeq_path.c_str();
+    try { ff.parse_pqeq(pqeq_path); } catch (const std::exception &e) { throw EngineError(RXMD_E_FFIELD, e.what()); }
+    ff.build_taper(12.5);
+  } else {
+    cfg.pqeq_path = nullptr;
+    ff.build_taper(10.0);                         // rctap0, module.F90:281
+  }
   MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
   if (MAXNB > 31) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 31 (the wavefront-per-centre kernels stage the bond slots of two atoms in one 64-lane wavefront; the reference uses 30)");
   int ndev = 0;
@@ -108,6 +115,7 @@ void Engine::check_device_error(const char *where) {
 void Engine::setup_after_atoms(const std::vector<long long> &npt) {
   ff.compute_cutoffs(npt);
   ff.build_tables();
+  if (ff.pqeq) ff.build_pqeq_tables();
   const double lreal[3] = {box.lat[0] / cfg.vprocs[0], box.lat[1] / cfg.vprocs[1], box.lat[2] / cfg.vprocs[2]};
   for (int a = 0; a < 3; ++a) {
     cc[a] = static_cast<int>(lreal[a] / ff.maxrc);            // UpdateBoxParams, init.F90:656
@@ -155,6 +163,20 @@ void Engine::upload_ff() {
              ff.tblEclmb[i], ff.tblEclmb[i + 1] - ff.tblEclmb[i], ff.tbldEclmb[i], ff.tbldEclmb[i + 1] - ff.tbldEclmb[i]};
   nb.back() = DevNBTab{};
 
+  // PQEq tables as (E, dE, F, dF) nodes
+  std::vector<double4> pt[3];
+  std::vector<double> zk;
+  if (ff.pqeq) {
+    const std::vector<double> *T[3] = {&ff.tblPcc, &ff.tblPsc, &ff.tblPss};
+    for (int k = 0; k < 3; ++k) {
+      const size_t nn = T[k]->size() / 2;
+      pt[k].assign(nn, make_double4(0, 0, 0, 0));
+      for (size_t i = 0; i + 1 < nn; ++i)
+        pt[k][i] = make_double4((*T[k])[2 * i], (*T[k])[2 * (i + 1)] - (*T[k])[2 * i], (*T[k])[2 * i + 1], (*T[k])[2 * (i + 1) + 1] - (*T[k])[2 * i + 1]);
+    }
+    zk.assign(2 * (ff.npq + 1), 0.0);
+    for (int t = 1; t <= ff.npq; ++t) { zk[t] = ff.Zpq[t]; zk[ff.npq + 1 + t] = ff.Kspq[t]; }
+  }
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
   size_t off[12], tot = 0;
   const size_t sz[11] = {a.size() * sizeof(DevAtomP), b.size() * sizeof(DevBondP), an.size() * sizeof(DevAngleP), to.size() * sizeof(DevTorsP),
@@ -177,12 +199,29 @@ void Engine::upload_ff() {
   dff.plp1 = ff.plp1; dff.povun3 = ff.povun3; dff.povun4 = ff.povun4; dff.povun6 = ff.povun6; dff.povun7 = ff.povun7; dff.povun8 = ff.povun8;
   dff.pval6 = ff.pval6; dff.pval8 = ff.pval8; dff.pval9 = ff.pval9; dff.pval10 = ff.pval10; dff.ppen2 = ff.ppen2; dff.ppen3 = ff.ppen3; dff.ppen4 = ff.ppen4;
   dff.pcoa2 = ff.pcoa2; dff.pcoa3 = ff.pcoa3; dff.pcoa4 = ff.pcoa4; dff.ptor2 = ff.ptor2; dff.ptor3 = ff.ptor3; dff.ptor4 = ff.ptor4; dff.pcot2 = ff.pcot2;
+  dff.pqeq = ff.pqeq ? 1 : 0; dff.npq1 = ff.npq + 1;
+  if (ff.pqeq) {
+    const size_t b0 = al(zk.size() * 8), b1 = al(ff.inxnpq.size() * 4), bt = al(pt[0].size() * sizeof(double4));
+    if (pqblob) { (void)hipFree(pqblob); pqblob = nullptr; }
+    RX_HIP(hipMalloc(&pqblob, b0 + b1 + 3 * bt));
+    char *pb = static_cast<char *>(pqblob);
+    RX_HIP(hipMemcpy(pb, zk.data(), zk.size() * 8, hipMemcpyHostToDevice));
+    RX_HIP(hipMemcpy(pb + b0, ff.inxnpq.data(), ff.inxnpq.size() * 4, hipMemcpyHostToDevice));
+    for (int k = 0; k < 3; ++k) RX_HIP(hipMemcpy(pb + b0 + b1 + k * bt, pt[k].data(), pt[k].size() * sizeof(double4), hipMemcpyHostToDevice));
+    dff.Zpq = reinterpret_cast<double *>(pb); dff.Kspq = dff.Zpq + (ff.npq + 1);
+    dff.inxnpq = reinterpret_cast<int *>(pb + b0);
+    dff.tabPcc = reinterpret_cast<double4 *>(pb + b0 + b1); dff.tabPsc = reinterpret_cast<double4 *>(pb + b0 + b1 + bt); dff.tabPss = reinterpret_cast<double4 *>(pb + b0 + b1 + 2 * bt);
+  }
 }
 
 void Engine::alloc_device() {
   const size_t nb = NB, ns = static_cast<size_t>(NB) * MAXNB;
   for (int a = 0; a < 3; ++a) { dmalloc(pos[a], nb); dmalloc(vel[a], nb); dmalloc(frc[a], nb); dmalloc(spos[a], nb); }
   dmalloc(q, nb); dmalloc(qsfp, nb); dmalloc(qsfv, nb); dmalloc(type, nb); dmalloc(gid, nb);
+  if (ff.pqeq) {
+    for (int a = 0; a < 3; ++a) dmalloc(shl[a], nb);
+    dmalloc(sorted_shl, nb); dmalloc(hsc, static_cast<size_t>(rows10) * S10); dmalloc(pqrow, static_cast<size_t>(rows10));
+  }
   dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb); dmalloc(hst2, nb); dmalloc(tickets, 16);
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(xs, nb);
@@ -196,7 +235,8 @@ void Engine::alloc_device() {
   dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   spmv_cell = (std::getenv("RXMD_SPMV_CELL") != nullptr);
-  if (spmv_cell) dmalloc(nb10s, static_cast<size_t>(rows10) * S10); dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
+  if (spmv_cell) dmalloc(nb10s, static_cast<size_t>(rows10) * S10);
+  dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
   partials_cap = std::max<size_t>(size_t(1) << 16, static_cast<size_t>(rows10) + 16384);
   dmalloc(partials, partials_cap); dmalloc(scal, 64);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
@@ -212,6 +252,9 @@ void Engine::alloc_device() {
 
 void Engine::free_device() {
   for (int a = 0; a < 3; ++a) { dfree(pos[a]); dfree(vel[a]); dfree(frc[a]); dfree(spos[a]); }
+  for (int a = 0; a < 3; ++a) dfree(shl[a]);
+  dfree(sorted_shl); dfree(hsc); dfree(pqrow);
+  if (pqblob) { (void)hipFree(pqblob); pqblob = nullptr; }
   dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst); dfree(hst2); dfree(tickets); dfree(sall); dfree(sgh); dfree(wall); dfree(wgh);
   dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(xs); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
   dfree(sorted_xyzi); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
@@ -278,6 +321,7 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
     RX_HIP(hipMemcpy(vel[a], hv[a].data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
     RX_HIP(hipMemset(frc[a], 0, sizeof(double) * NB));
   }
+  if (ff.pqeq) for (int a = 0; a < 3; ++a) RX_HIP(hipMemset(shl[a], 0, sizeof(double) * NB));      // spos(:,:)=0, init.F90:117-120
   RX_HIP(hipMemcpy(q, hq.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
   RX_HIP(hipMemcpy(qsfp, hp.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
   RX_HIP(hipMemcpy(qsfv, hw.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
@@ -571,6 +615,24 @@ __global__ void k_move_append(int nscan, int base, int axis, double sft, const i
   type[m] = type[n]; gid[m] = gid[n]; q[m] = q[n]; qsfp[m] = qsfp[n]; qsfv[m] = qsfv[n];
   type[n] = -1;   // comm.F90:440
 }
+// the same append for one more per-atom array (PQEq shell displacement, unshifted: comm.F90:165-167); runs before k_move_append
+__global__ void k_move_append_extra(int nscan, int base, const int *flags, const int *scanout, double *a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nscan || !flags[n]) return;
+  a[base + scanout[n]] = a[n];
+}
+__global__ void k_pack_extra3(int nscan, const int *flags, const int *scanout, int W, int o, const double *a0, const double *a1, const double *a2, double *buf) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nscan || !flags[n]) return;
+  double *p = buf + static_cast<size_t>(W) * scanout[n] + o;
+  p[0] = a0[n]; p[1] = a1[n]; p[2] = a2[n];
+}
+__global__ void k_unpack_extra3(int cnt, int base, int W, int o, const double *buf, double *a0, double *a1, double *a2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const double *p = buf + static_cast<size_t>(W) * k + o;
+  a0[base + k] = p[0]; a1[base + k] = p[1]; a2[base + k] = p[2];
+}
 __global__ void k_alive_flags(int n, const int *type, int *flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n) flags[i] = (i < n && type[i] > 0) ? 1 : 0;
@@ -583,21 +645,21 @@ __global__ void k_compact(int n, const int *flags, const int *scanout, const T *
 
 __global__ void k_pack_move(int nscan, int axis, double sft, const int *flags, const int *scanout, const double *sx, const double *sy, const double *sz,
                             const double *vx, const double *vy, const double *vz, int *type, const long long *gid, const double *q,
-                            const double *qsfp, const double *qsfv, double *buf) {
+                            const double *qsfp, const double *qsfv, double *buf, int W) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= nscan || !flags[n]) return;
   double a = sx[n], b = sy[n], c = sz[n];
   if (axis == 0) a += sft; else if (axis == 1) b += sft; else c += sft;
-  double *o = buf + 11 * static_cast<size_t>(scanout[n]);
+  double *o = buf + static_cast<size_t>(W) * scanout[n];
   o[0] = a; o[1] = b; o[2] = c; o[3] = vx[n]; o[4] = vy[n]; o[5] = vz[n];
   o[6] = static_cast<double>(type[n]); o[7] = static_cast<double>(gid[n]); o[8] = q[n]; o[9] = qsfp[n]; o[10] = qsfv[n];
   type[n] = -1;   // comm.F90:440
 }
 __global__ void k_unpack_move(int cnt, int base, const double *buf, double *sx, double *sy, double *sz, double *vx, double *vy, double *vz,
-                              int *type, long long *gid, double *q, double *qsfp, double *qsfv) {
+                              int *type, long long *gid, double *q, double *qsfp, double *qsfv, int W) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= cnt) return;
-  const double *o = buf + 11 * static_cast<size_t>(k);
+  const double *o = buf + static_cast<size_t>(W) * k;
   const int m = base + k;
   sx[m] = o[0]; sy[m] = o[1]; sz[m] = o[2]; vx[m] = o[3]; vy[m] = o[4]; vz[m] = o[5];
   type[m] = static_cast<int>(llrint(o[6])); gid[m] = llrint(o[7]); q[m] = o[8]; qsfp[m] = o[9]; qsfv[m] = o[10];
@@ -619,19 +681,26 @@ void Engine::migrate() {
     RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
     RX_HIP(hipStreamSynchronize(stream));
     if (multi()) {
-      ensure_xbuf(static_cast<size_t>(std::max(total, 1)) * 11 + 4096);
-      if (total > 0)
-        k_pack_move<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, sft, flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv, xbuf_send);
-      const long long nr = exchange_stage(d, false, 11LL * total);
-      const int cnt = static_cast<int>(nr / 11);
+      const int W = ff.pqeq ? 14 : 11;             // + shell displacement (comm.F90:153,165-167)
+      ensure_xbuf(static_cast<size_t>(std::max(total, 1)) * W + 4096);
+      if (total > 0) {
+        if (ff.pqeq) k_pack_extra3<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, flags, scanout, W, 11, shl[0], shl[1], shl[2], xbuf_send);
+        k_pack_move<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, sft, flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv, xbuf_send, W);
+      }
+      const long long nr = exchange_stage(d, false, static_cast<long long>(W) * total);
+      const int cnt = static_cast<int>(nr / W);
       if (static_cast<long long>(cp[d - 1]) + cnt > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
-      if (cnt > 0)
-        k_unpack_move<<<nblk(cnt, 256), 256, 0, stream>>>(cnt, cp[d - 1], xbuf_recv, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
+      if (cnt > 0) {
+        k_unpack_move<<<nblk(cnt, 256), 256, 0, stream>>>(cnt, cp[d - 1], xbuf_recv, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv, W);
+        if (ff.pqeq) k_unpack_extra3<<<nblk(cnt, 256), 256, 0, stream>>>(cnt, cp[d - 1], W, 11, xbuf_recv, shl[0], shl[1], shl[2]);
+      }
       cp[d] = cp[d - 1] + cnt;
       moved += total + cnt;
       continue;
     }
     if (static_cast<long long>(cp[d - 1]) + total > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
+    if (total > 0 && ff.pqeq)
+      for (int a = 0; a < 3; ++a) k_move_append_extra<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d - 1], flags, scanout, shl[a]);
     if (total > 0)
       k_move_append<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d - 1], axis, sft, flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
     cp[d] = cp[d - 1] + total;
@@ -652,6 +721,13 @@ void Engine::migrate() {
     for (int a = 0; a < 9; ++a) {
       k_compact<double><<<nblk(n, 256), 256, 0, stream>>>(n, flags, scanout, srcd[a], tmpd[a]);
       RX_HIP(hipMemcpyAsync(srcd[a], tmpd[a], sizeof(double) * newN, hipMemcpyDeviceToDevice, stream));
+    }
+    if (ff.pqeq) {
+      double *ts[3] = {A0, A1, A2};
+      for (int a = 0; a < 3; ++a) {
+        k_compact<double><<<nblk(n, 256), 256, 0, stream>>>(n, flags, scanout, shl[a], ts[a]);
+        RX_HIP(hipMemcpyAsync(shl[a], ts[a], sizeof(double) * newN, hipMemcpyDeviceToDevice, stream));
+      }
     }
     k_compact<long long><<<nblk(n, 256), 256, 0, stream>>>(n, flags, scanout, gid, reinterpret_cast<long long *>(dDlp));
     RX_HIP(hipMemcpyAsync(gid, dDlp, sizeof(long long) * newN, hipMemcpyDeviceToDevice, stream));
@@ -706,6 +782,7 @@ void Engine::bin_cells() {
   RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, cellid, cellid_sorted, perm_in, perm, G, 0, bits, stream));
   k_cell_starts<<<nblk(G, 256), 256, 0, stream>>>(G, grid.ncell, cellid_sorted, cellstart);
   k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, rootperm);
+  if (ff.pqeq) pqeq_sorted_shells();
 }
 
 void Engine::sorted_copy(const double2 *v) {

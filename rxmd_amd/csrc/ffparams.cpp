@@ -1,5 +1,6 @@
 // ffparams.cpp -- see ffparams.h.  Host only (no HIP).
 #include "ffparams.h"
+#include <sstream>
 
 #include <cctype>
 #include <cmath>
@@ -278,6 +279,72 @@ void ForceField::build_tables() {
         const double dfn13 = std::pow(rv + gw, pvdW1inv - 1.0) * std::pow(dr2, pvdW1h - 1.0);
         tbldEvdw[o] = Dij[k] * (dTap * (e1 - 2.0 * e2) - Tap * (alpij[k] / rvdW[k]) * (e1 - e2) * dfn13);
         tbldEclmb[o] = Cclmb0 * g3 * (dTap - (g3 * g3 * g3) * Tap * dr1);
+      }
+    }
+}
+
+// ---- PQEq -------------------------------------------------------------------------------------------------------
+// parameter file (reference src/cmdline.F90:160-235): '#' comment lines, "NPARMS n", then n lines
+//   name  flag  X0  J0  Z  Rc  Rs  Ks      (the flag column is read and ignored there: every listed type is polarizable, :217)
+void ForceField::parse_pqeq(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) throw std::runtime_error("cannot open PQEq parameter file " + path);
+  std::string line;
+  int n = 0;
+  npq = 0;
+  while (std::getline(f, line)) {
+    size_t p0 = line.find_first_not_of(" \t");
+    if (p0 == std::string::npos || line[p0] == '#') continue;
+    const size_t pn = line.find("NPARMS");
+    if (pn != std::string::npos) {
+      npq = std::atoi(line.c_str() + pn + 6);
+      if (npq < 1) throw std::runtime_error("PQEq: bad NPARMS line");
+      X0pq.assign(npq + 1, 0.0); J0pq = Zpq = Rcpq = Rspq = Kspq = X0pq;
+      continue;
+    }
+    if (!npq || n >= npq) continue;
+    std::istringstream is(line);
+    std::string nm; int flag; double x0, j0, z, rc, rs, ks;
+    if (!(is >> nm >> flag >> x0 >> j0 >> z >> rc >> rs >> ks)) continue;
+    ++n;
+    X0pq[n] = x0; J0pq[n] = j0; Zpq[n] = z; Rcpq[n] = rc; Rspq[n] = rs; Kspq[n] = ks;
+  }
+  if (npq < 1 || n != npq) throw std::runtime_error("PQEq: parameter file " + path + " is incomplete");
+  if (npq < nso) throw std::runtime_error("PQEq: fewer parameter rows than ffield atom types");
+  // initialize_pqeq, module.F90:501-522: chi <- X0, eta <- 2*J0 for every (polarizable) type
+  for (int t = 1; t <= nso; ++t) { atom[t].chi = X0pq[t]; atom[t].eta = 2.0 * J0pq[t]; }
+  inxnpq.assign((npq + 1) * (npq + 1), 0);
+  int c = 0;
+  for (int a = 1; a <= npq; ++a) for (int b = a; b <= npq; ++b) { ++c; inxnpq[a * (npq + 1) + b] = c; inxnpq[b * (npq + 1) + a] = c; }
+  pqeq = true;
+}
+
+void ForceField::build_pqeq_tables() {
+  const double lambda = 0.462770;                                  // module.F90:298
+  const double sqrtpi_inv = 1.0 / std::sqrt(3.14159265358979);    // module.F90:90-91
+  const size_t stride = NTABLE + 2;
+  const int nrow = npq * (npq + 1) / 2;
+  tblPcc.assign((nrow + 1) * stride * 2, 0.0); tblPsc = tblPss = tblPcc;
+  UDR = rctap2 / NTABLE; UDRi = 1.0 / UDR;
+  for (int a = 1; a <= npq; ++a)
+    for (int b = a; b <= npq; ++b) {
+      const double aci = 0.5 * lambda / (Rcpq[a] * Rcpq[a]), asi = 0.5 * lambda / (Rspq[a] * Rspq[a]);
+      const double acj = 0.5 * lambda / (Rcpq[b] * Rcpq[b]), asj = 0.5 * lambda / (Rspq[b] * Rspq[b]);
+      // set_alphaij_pqeq, module.F90:448-485; the tables are filled from alpha(ity,jty) with ity <= jty (:541-547)
+      const double A[3] = {std::sqrt((aci * acj) / (aci + acj)), std::sqrt((asi * acj) / (asi + acj)), std::sqrt((asi * asj) / (asi + asj))};
+      std::vector<double> *T[3] = {&tblPcc, &tblPsc, &tblPss};
+      const int row = ipq(a, b);
+      for (int i = 1; i <= NTABLE; ++i) {
+        const double dr2 = UDR * i, dr1 = std::sqrt(dr2);
+        const double dr3 = dr1 * dr2, dr4 = dr2 * dr2, dr5 = dr1 * dr2 * dr2, dr6 = dr2 * dr2 * dr2, dr7 = dr1 * dr2 * dr2 * dr2;
+        const double Tap = CTap[7] * dr7 + CTap[6] * dr6 + CTap[5] * dr5 + CTap[4] * dr4 + CTap[0];
+        const double dTap = 7.0 * CTap[7] * dr5 + 6.0 * CTap[6] * dr4 + 5.0 * CTap[5] * dr3 + 4.0 * CTap[4] * dr2;
+        const double dr1i = 1.0 / dr1, clmb = dr1i, dclmb = -dr1i * dr1i * dr1i;
+        for (int k = 0; k < 3; ++k) {
+          const double screen = std::erf(A[k] * dr1), dscreen = 2.0 * A[k] * sqrtpi_inv * std::exp(-A[k] * A[k] * dr2) * dr1i;
+          (*T[k])[(row * stride + i) * 2] = clmb * screen * Tap;
+          (*T[k])[(row * stride + i) * 2 + 1] = dclmb * screen * Tap + clmb * dscreen * Tap + clmb * screen * dTap;
+        }
       }
     }
 }

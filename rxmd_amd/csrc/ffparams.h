@@ -57,6 +57,16 @@ struct ForceField {
   int pair(int a, int b) const { return a * n1() + b; }
   int ix2(int a, int b) const { return inxn2[pair(a, b)]; }
 
+  // PQEq (reference src/cmdline.F90:160-235 get_pqeq_parms, src/module.F90:448-611): per type 1..npq, pair index ipq(a,b)
+  bool pqeq = false;
+  int npq = 0;
+  std::vector<double> X0pq, J0pq, Zpq, Rcpq, Rspq, Kspq;   // [0..npq]
+  std::vector<int> inxnpq;                                  // [(npq+1)^2]: 1-based pair row, symmetric
+  std::vector<double> tblPcc, tblPsc, tblPss;               // [row][i][0:1]: energy kernel and (1/r) derivative, i = 0..NTABLE+1
+  int ipq(int a, int b) const { return inxnpq[a * (npq + 1) + b]; }
+  void parse_pqeq(const std::string &path);                 // also replaces chi / eta (module.F90:501-522); call before build_tables
+  void build_pqeq_tables();                                 // needs the taper of rctap0_pqeq
+
   // throws std::runtime_error with a message on malformed input
   void parse(const std::string &path);
   // bond-order cutoffs per bond row; types with zero atoms are ignored for maxrc (init.F90:404-413)

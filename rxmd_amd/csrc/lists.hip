@@ -76,17 +76,39 @@ __global__ void k_reverse_index(int G, int NB, const int *__restrict__ nbr, cons
   }
 }
 
+// get_coulomb_and_dcoulomb_pqeq (reference src/module.F90:401-418): energy kernel and (1/r) dE/dr at squared distance r2.
+// Beyond the taper cutoff the reference returns without touching its outputs (callers then see the previous pair's
+// values); here such a lookup contributes nothing -- see DESIGN.md "PQEq beyond-cutoff lookups".
+__device__ inline bool pq_lookup(const DevFF &ff, const double4 *__restrict__ tab, int row, double r2, double &E, double &F) {
+  if (r2 > ff.rctap2) { E = 0.0; F = 0.0; return false; }
+  const int itb = static_cast<int>(r2 * ff.UDRi);
+  double t = r2 - itb * ff.UDR;
+  t = t * ff.UDRi;
+  const double4 nd = tab[static_cast<size_t>(row) * (NTABLE + 2) + itb];
+  E = nd.x + t * nd.y; F = nd.z + t * nd.w;
+  return true;
+}
+__device__ inline double wave_sum_l(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // One wavefront per resident row.  Lanes sweep the candidates of a stencil column 64 at a time,
 // the accepted ones are compacted with a ballot so that a row is written as contiguous runs
 // (coalesced 8-byte + 4-byte streams) in a deterministic order.
 // A list entry names the partner by its CELL-SORTED position (the loop variable of this sweep), not by atom index:
 // the consumers (QEq matrix passes, ENbond, Ehb) gather from cell-sorted copies, so the 64 lanes of a wavefront hit a
 // handful of cache lines instead of 64 scattered ones.  Bits: see NB10_* in engine.h.
-template <bool SELFCHECK>
+// PQ: PQEq variant of qeq_initialize (pqeq.F90:262-353): core-core hessian from the pcc table, the shell-core matrix hsc of
+// get_hsh's Csicj term, and per row (fpqeq Eq. 30, sum_j H Z_j, sum_j hsc Z_j, shell-shell energy) -> pqrow
+template <bool SELFCHECK, bool PQ>
 __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
                                                  const double *__restrict__ z, const int *__restrict__ type, const long long *__restrict__ gid,
-                                                 int *__restrict__ nb10, unsigned short *__restrict__ nb10s, double *__restrict__ hess, int *__restrict__ n10, int *err) {
+                                                 int *__restrict__ nb10, unsigned short *__restrict__ nb10s, double *__restrict__ hess, int *__restrict__ n10, int *err,
+                                                 const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
+                                                 double *__restrict__ hsc, double4 *__restrict__ pqrow) {
   extern __shared__ unsigned short srow_all[];       // [4][S10]: the wavefront's row of 16-bit entries, written out as 4-byte words
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -98,6 +120,8 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   const int ti = type[i];
   const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.n[2] - 1);
   const size_t row = static_cast<size_t>(i) * S10;
+  double sxi = 0.0, syi = 0.0, szi = 0.0, Zi = 0.0, p_f = 0.0, p_hz = 0.0, p_bz = 0.0, p_ss = 0.0;
+  if (PQ) { sxi = shx[i]; syi = shy[i]; szi = shz[i]; Zi = ff.Zpq[ti]; }
   int cnt = 0;
   int loff = 0;     // candidates in the stencil columns already swept = position of this column inside the neighbourhood
   for (int dx = -2; dx <= 2; ++dx) {
@@ -132,7 +156,35 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
             const float r2f = static_cast<float>(r2);
             double h = 0.0;
             const int inxn = ff.inxn2[ti * ff.n1 + tj];
-            if (static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
+            if (PQ) {
+              double c = 0.0;
+              if (static_cast<double>(r2f) < ff.rctap2) {                  // the pair is in PQEq's own list (real(4) test, pqeq.F90:305)
+                const double C0q = 14.4;                                   // Cclmb0_qeq, module.F90:682
+                const double4 sj = sorted_shl[k];
+                const double Zj = ff.Zpq[tj];
+                const int prow = ff.inxnpq[ti * ff.npq1 + tj];
+                const double4 p = sorted[k];
+                const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
+                double E, F;
+                pq_lookup(ff, ff.tabPcc, prow, r2, E, F);                  // core(i)-core(j)
+                h = C0q * E;
+                p_hz += h * Zj;
+                // Eq. 30: field of core(j) minus field of shell(j) at core(i); table row (jty,ity), pqeq.F90:328-334
+                double e0 = d0 - sj.x, e1 = d1 - sj.y, e2 = d2 - sj.z;
+                pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+                p_f += h * Zj - C0q * E * Zj;
+                // shell(i)-core(j): Csicj = -hsc * (q_j + Z_j), pqeq.F90:392-395
+                e0 = d0 + sxi; e1 = d1 + syi; e2 = d2 + szi;
+                pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+                c = C0q * E * Zi;
+                p_bz += c * Zj;
+                // shell(i)-shell(j): Csisj, pqeq.F90:397-401 (half of it per row, :409)
+                e0 -= sj.x; e1 -= sj.y; e2 -= sj.z;
+                pq_lookup(ff, ff.tabPss, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+                p_ss += 0.5 * C0q * E * Zi * Zj;
+              }
+              hsc[row + slot] = c;
+            } else if (static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
               const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
               double drtb = static_cast<double>(r2f) - itb * ff.UDR;
               drtb = drtb * ff.UDRi;
@@ -159,6 +211,11 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     for (int t = lane; t < nw; t += 64) dw[t] = sw[t];
   }
+  if (PQ) {
+    p_f = wave_sum_l(p_f); p_hz = wave_sum_l(p_hz); p_bz = wave_sum_l(p_bz); p_ss = wave_sum_l(p_ss);
+    if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) hsc[row + cnt + lane] = 0.0;
+    if (lane == 0) pqrow[i] = make_double4(p_f, p_hz, p_bz, p_ss);
+  }
   if (lane == 0) { n10[i] = cnt; if (loff > __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&err[2], loff); }
 }
 
@@ -172,10 +229,13 @@ void Engine::build_list10() {
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
   const bool selfcheck = (box.lat[0] < 2.0 * ff.rctap + 1.0) || (box.lat[1] < 2.0 * ff.rctap + 1.0) || (box.lat[2] < 2.0 * ff.rctap + 1.0);
-  if (selfcheck)
-    k_list10<true><<<nblk(N, 4), 256, static_cast<size_t>(S10) * 4 * sizeof(unsigned short), stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, hess, n10, d_err);
-  else
-    k_list10<false><<<nblk(N, 4), 256, static_cast<size_t>(S10) * 4 * sizeof(unsigned short), stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, hess, n10, d_err);
+  const size_t lds = static_cast<size_t>(S10) * 4 * sizeof(unsigned short);
+#define RX_LIST10(SC, PQF)                                                                                                                     \
+  k_list10<SC, PQF><<<nblk(N, 4), 256, lds, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, \
+                                                      hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow)
+  if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
+  else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
+#undef RX_LIST10
 }
 
 }  // namespace rxmd

@@ -48,12 +48,28 @@ __device__ inline void block_store_partials(double (&acc)[NC], double *partials,
 }
 
 // per-row tail of a matrix pass (lane 0 of the row's wavefront): the arithmetic of get_hsh / get_gradient around the row sums
+// PQEq (pqrow != nullptr): the second pair of sums (gs_,gt_) is over the shell-core matrix hsc instead of the ghost columns;
+// gradient gets the field term fpqeq (pqeq.F90:466), Est the core/shell terms of pqeq.F90:381-411 without the resident doubling
+__device__ inline double pq_est_row(const DevAtomP &ap, double Zi, const double4 &pr, double qi, double hq, double bq) {
+  return ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * (qi + Zi) * (hq + pr.y) + pr.w - (bq + pr.z);
+}
 template <int MODE, bool STORE>
 __device__ inline void row_epilogue(int row, double as, double at, double gs_, double gt_, double mu, const DevFF &ff, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                     const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
-                                    double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh, double (&acc)[4]) {
+                                    double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh, double (&acc)[4], const double4 *__restrict__ pqrow) {
   if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
-  const DevAtomP ap = ff.atom[type[row]];
+  const int ti = type[row];
+  const DevAtomP ap = ff.atom[ti];
+  if (MODE == MODE_GRAD && pqrow) {
+    const double4 pr = pqrow[row];
+    const double2 qv = qst[row];
+    const double g1 = -ap.chi - ap.eta * qv.x - as - pr.x;
+    const double g2 = -1.0 - ap.eta * qv.y - at;
+    gst[row] = make_double2(g1, g2);
+    acc[0] += g1 * g1; acc[1] += g2 * g2;
+    acc[2] += pq_est_row(ap, ff.Zpq[ti], pr, q[row], as - mu * at, gs_ - mu * gt_);
+    return;
+  }
   if (MODE == MODE_HSH) {
     const double2 hv = hst[row], gv = gst[row];
     const double ts = ap.eta * hv.x + as, tt = ap.eta * hv.y + at;      // qeq.F90:294-302
@@ -78,7 +94,8 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
                                                const double *__restrict__ scal, double *__restrict__ partials,
-                                               double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh) {
+                                               double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
+                                               const double *__restrict__ hsc, const double4 *__restrict__ pqrow) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int wave0 = blockIdx.x * wpb + (threadIdx.x >> 6);
@@ -104,12 +121,19 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
         const double2 v = xv[e[u] & NB10_IDX_MASK];
         as += h[u] * v.x;
         at += h[u] * v.y;
-        if ((MODE == MODE_GRAD || STORE) && (e[u] & NB10_GHOST)) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
+        if ((MODE == MODE_GRAD || STORE) && !hsc && (e[u] & NB10_GHOST)) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
+      }
+      if ((MODE == MODE_GRAD || STORE) && hsc) {     // PQEq: second matrix (shell-core) over the same columns
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int k = k0 + 64 * u;
+          if (k < n) { const double c = __builtin_nontemporal_load(hsc + base + k); const double2 v = xv[e[u] & NB10_IDX_MASK]; gs_ += c * v.x; gt_ += c * v.y; }
+        }
       }
     }
     as = wave_sum(as); at = wave_sum(at);
     if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-    if (lane == 0) row_epilogue<MODE, STORE>(row, as, at, gs_, gt_, mu, ff, hst, gst, qst, q, type, rs_all, rs_gh, acc);
+    if (lane == 0) row_epilogue<MODE, STORE>(row, as, at, gs_, gt_, mu, ff, hst, gst, qst, q, type, rs_all, rs_gh, acc, pqrow);
   }
   block_store_partials<4>(acc, partials, 4);
 }
@@ -198,7 +222,7 @@ __global__ void __launch_bounds__(1024) k_spmv_cell(int N, int S10, Grid g, DevF
     }
     as = wave_sum(as); at = wave_sum(at);
     if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-    if (lane == 0) row_epilogue<MODE, STORE>(row, as, at, gs_, gt_, mu, ff, hst, gst, qst, q, type, rs_all, rs_gh, acc);
+    if (lane == 0) row_epilogue<MODE, STORE>(row, as, at, gs_, gt_, mu, ff, hst, gst, qst, q, type, rs_all, rs_gh, acc, nullptr);
   }
   block_store_partials<4>(acc, partials, 4);
 }
@@ -383,20 +407,21 @@ __global__ void __launch_bounds__(256) k_update_qst_sums(int N, const double *__
 // gradient, q, Gnew and Est from the stored row sums (the arithmetic of get_gradient / get_hsh, qeq.F90:297-306,349-356)
 __global__ void __launch_bounds__(256) k_grad_from_sums(int N, DevFF ff, const double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ qst,
                                                          const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double2 *__restrict__ gst, double *__restrict__ q,
-                                                         double *__restrict__ partials) {
+                                                         double *__restrict__ partials, const double4 *__restrict__ pqrow) {
   const double mu = scal[S_MU];
   double acc[4] = {0, 0, 0, 0};
   double g1s = 0.0, g2s = 0.0, es = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     const DevAtomP ap = ff.atom[type[i]];
     const double2 qv = qst[i], a = sall[i], g = sgh[i];
-    const double g1 = -ap.chi - ap.eta * qv.x - a.x, g2 = -1.0 - ap.eta * qv.y - a.y;
+    const double g1 = -ap.chi - ap.eta * qv.x - a.x - (pqrow ? pqrow[i].x : 0.0), g2 = -1.0 - ap.eta * qv.y - a.y;
     gst[i] = make_double2(g1, g2);
     const double qi = qv.x - mu * qv.y;
     q[i] = qi;
     const double hq_all = a.x - mu * a.y, hq_res = (a.x - g.x) - mu * (a.y - g.y);
     g1s += g1 * g1; g2s += g2 * g2;
-    es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
+    if (pqrow) es += pq_est_row(ap, ff.Zpq[type[i]], pqrow[i], qi, hq_all, g.x - mu * g.y);
+    else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
   }
   g1s = wave_sum(g1s); g2s = wave_sum(g2s); es = wave_sum(es);
   acc[0] = g1s; acc[1] = g2s; acc[2] = es;
@@ -408,7 +433,7 @@ __global__ void __launch_bounds__(256) k_grad_from_sums(int N, DevFF ff, const d
 //    -> tail: mu, Gnew, beta                                                    (qeq.F90:136-147,349-356,160-161)
 __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ hst, double2 *__restrict__ qst,
                                                     const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
-                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket) {
+                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow) {
   const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
   double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
@@ -421,7 +446,7 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
     a.x += l1 * wa.x; a.y += l2 * wa.y; g.x += l1 * wg.x; g.y += l2 * wg.y;
     sall[i] = a; sgh[i] = g;
     const DevAtomP ap = ff.atom[type[i]];
-    const double g1 = -ap.chi - ap.eta * qv.x - a.x, g2 = -1.0 - ap.eta * qv.y - a.y;
+    const double g1 = -ap.chi - ap.eta * qv.x - a.x - (pqrow ? pqrow[i].x : 0.0), g2 = -1.0 - ap.eta * qv.y - a.y;
     gst[i] = make_double2(g1, g2);
     s += qv.x; t += qv.y; g1s += g1 * g1; g2s += g2 * g2;
   }
@@ -435,7 +460,7 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
 __global__ void __launch_bounds__(256) k_cg_direction(int G, int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ perm, const int *__restrict__ rootperm, const int *__restrict__ type,
                                                        const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new, double2 *__restrict__ xs,
                                                        const double2 *__restrict__ qst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double *__restrict__ q,
-                                                       double *__restrict__ partials, unsigned *ticket) {
+                                                       double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow) {
   const double mu = scal[S_MU], b1 = scal[S_BETA_S], b2 = scal[S_BETA_T];
   double es = 0.0;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < G; k += gridDim.x * blockDim.x) {
@@ -450,7 +475,8 @@ __global__ void __launch_bounds__(256) k_cg_direction(int G, int N, DevFF ff, do
       const double qi = qv.x - mu * qv.y;
       q[i] = qi;
       const double hq_all = a.x - mu * a.y, hq_res = (a.x - gh.x) - mu * (a.y - gh.y);
-      es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
+      if (pqrow) es += pq_est_row(ap, ff.Zpq[type[i]], pqrow[i], qi, hq_all, gh.x - mu * gh.y);
+      else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
     }
   }
   double acc[4] = {wave_sum(es), 0.0, 0.0, 0.0};
@@ -496,7 +522,7 @@ void Engine::qeq() {
   // cell-tiled pass (k_spmv_cell) whenever the neighbourhood of a cell fits the 15-bit local index and the LDS stage
   const size_t lds_bytes = (static_cast<size_t>(nbhd_max) + 64) / 64 * 64 * sizeof(double2);
   // (opt-in: measured 1.21 ms against 1.13 ms per pass for the row kernel at 979,776 rows, see DESIGN.md "matrix pass variants")
-  const bool use_cell = spmv_cell && nbhd_max > 0 && nbhd_max < 32768 && lds_bytes <= 128 * 1024 &&
+  const bool use_cell = spmv_cell && !ff.pqeq && nbhd_max > 0 && nbhd_max < 32768 && lds_bytes <= 128 * 1024 &&
                         static_cast<size_t>(std::max(rb, grid.ncell)) * 4 + 1024 <= partials_cap;
   if (use_cell && lds_bytes > 48 * 1024 && !cell_attr_set) {
     const int lim = 128 * 1024;
@@ -513,7 +539,7 @@ void Engine::qeq() {
 #define RX_PASS(M, S)                                                                                                                        \
   do {                                                                                                                                       \
     if (use_cell) k_spmv_cell<M, S><<<grid.ncell, cell_bs, lds_bytes, stream>>>(N, S10, grid, dff, cellstart, perm, nb10s, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg); \
-    else k_spmv<M, S><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg);            \
+    else k_spmv<M, S><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow);  \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }
@@ -565,8 +591,8 @@ void Engine::qeq() {
     reduce(1, nred);
     if (onepass && !multi()) {   // qeq_mode 1, single rank: matrix pass + three launches, every reduction finished in-kernel
       const int gb = std::min(nblk(G, 256), 2048);
-      k_cg_update<<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1);
-      k_cg_direction<<<gb, 256, 0, stream>>>(G, N, dff, scal, perm, rootperm, type, gst, hst, hst2, xs, qst, sall, sgh, q, partials, tickets + 2);
+      k_cg_update<<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow);
+      k_cg_direction<<<gb, 256, 0, stream>>>(G, N, dff, scal, perm, rootperm, type, gst, hst, hst2, xs, qst, sall, sgh, q, partials, tickets + 2, pqrow);
       std::swap(hst, hst2);
       xs_current = true;
       RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
@@ -579,7 +605,7 @@ void Engine::qeq() {
     if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
       k_update_qst_sums<<<vb, 256, 0, stream>>>(N, scal, hst, qst, wall, wgh, sall, sgh, partials);
       reduce(2, vb);
-      k_grad_from_sums<<<vb, 256, 0, stream>>>(N, dff, scal, type, qst, sall, sgh, gst, q, partials);
+      k_grad_from_sums<<<vb, 256, 0, stream>>>(N, dff, scal, type, qst, sall, sgh, gst, q, partials, pqrow);
       reduce(3, vb);
       k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);
       RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
@@ -605,6 +631,7 @@ void Engine::qeq() {
     hipEventElapsedTime(&ms, ev[4], ev[5]); st.ms_qeq_spmv += ms;
     st.spmv_launches += 2;
   }
+  if (ff.pqeq) pqeq_update_shells();                  // pqeq.F90:169
   nstep_qeq = it; last_est = Est;
   st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1;
   st.ms_qeq += toc(6, 7);

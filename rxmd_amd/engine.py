@@ -29,7 +29,7 @@ class RxmdEngine:
     """One engine = one rank of the vprocs grid = one MI355X."""
 
     def __init__(self, ffield, lattice, vprocs=(1, 1, 1), myid=0, isQEq=1, NMAXQEq=500, QEq_tol=1e-7, qstep=1, dt_fs=0.25,
-                 nbuffer=0, maxneighbs=0, maxneighbs10=0, device=0, qeq_mode=0, Lex_fqs=1.0, Lex_k=2.0):
+                 nbuffer=0, maxneighbs=0, maxneighbs10=0, device=0, qeq_mode=0, Lex_fqs=1.0, Lex_k=2.0, pqeq=None):
         self.L = _lib.load()
         cfg = RxmdConfig()
         self.L.rxmd_hip_default_config(C.byref(cfg))
@@ -42,6 +42,8 @@ class RxmdEngine:
         cfg.myid = myid; cfg.isQEq = isQEq; cfg.NMAXQEq = NMAXQEq; cfg.QEq_tol = QEq_tol; cfg.qstep = qstep; cfg.dt_fs = dt_fs
         cfg.nbuffer = nbuffer; cfg.maxneighbs = maxneighbs; cfg.maxneighbs10 = maxneighbs10; cfg.device = device; cfg.qeq_mode = qeq_mode
         cfg.Lex_fqs = Lex_fqs; cfg.Lex_k = Lex_k
+        self._pq = str(pqeq).encode() if pqeq else None       # --pqeq <file> (cmdline.F90:112-128): PQEq instead of QEq
+        cfg.pqeq_path = self._pq
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.L.rxmd_hip_create(C.byref(cfg), C.byref(h))
@@ -92,6 +94,17 @@ class RxmdEngine:
 
     def set_velocities(self, v):
         v = np.ascontiguousarray(v, np.float64).reshape(-1, 3); self._chk(self.L.rxmd_hip_set_velocities(self.h, len(v), _ptr(v)))
+
+    def shells(self):
+        """PQEq shell displacements spos(natoms,3)"""
+        n = self.natoms
+        out = np.zeros((n, 3)); rc = self.L.rxmd_hip_get_shells(self.h, _ptr(out), n)
+        if rc < 0:
+            self._chk(rc)
+        return out[:rc]
+
+    def set_shells(self, s):
+        s = np.ascontiguousarray(s, np.float64).reshape(-1, 3); self._chk(self.L.rxmd_hip_set_shells(self.h, len(s), _ptr(s)))
 
     # ---- the hot path (device resident) ----
     def QEq(self):

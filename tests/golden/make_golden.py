@@ -46,6 +46,10 @@ CASES = {
     "rdx222_tight":  ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
     "rdx222_md5":    ("rdx.xyz", "ffield_rdx", (2, 2, 2), [], 5),
     "ice644_tight":  ("ICE", "ffield_water", (6, 4, 4), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
+    # PQEq (pqeq.F90): SiC nanoparticle in O2, conf/init.sicnp, polarizable shells; the --pqeq file is copied next to the run
+    "sicnp547_pqeq_tol7":  ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in"], 0),
+    "sicnp547_pqeq_tight": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
+    "sicnp547_pqeq_md5":   ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in"], 5),
     # multi-rank (real MPI build oracle/_ref/rxmd_mpi, conda MPICH): name: (..., vprocs)
     "rdx222_v211_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
     "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),
@@ -140,6 +144,7 @@ def make(name):
             shutil.copy(os.path.join(INP, xyz), os.path.join(tmp, "input.xyz"))
         shutil.copy(os.path.join(INP, ff), os.path.join(tmp, "ffield"))
         shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        shutil.copy(os.path.join(INP, "pqeq_sicnp.in"), os.path.join(tmp, "pqeq.in"))
         run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT",
              "-mc", str(mc[0]), str(mc[1]), str(mc[2])], tmp)
         rxffbin = open(os.path.join(tmp, "DAT", "rxff.bin"), "rb").read()

@@ -84,7 +84,7 @@ def geninit(names, frac, lattice, ffnames, mc=(1, 1, 1), vprocs=(1, 1, 1)):
 
 class Oracle:
     def __init__(self, ffield, lattice, ranks, vprocs=(1, 1, 1), isQEq=1, NMAXQEq=500, QEq_tol=1e-7, dt_fs=0.25,
-                 nbuffer=None, maxn10=1500, q0=None, v0=None):
+                 nbuffer=None, maxn10=1500, q0=None, v0=None, pqeq=None):
         L = lib()
         self.L = L
         nmax = max(len(r["type"]) for r in ranks)
@@ -95,6 +95,9 @@ class Oracle:
         self.w = L.rxo_create(ffield.encode(), lat, vp, isQEq, NMAXQEq, QEq_tol, dt_fs, nbuffer, maxn10)
         assert self.w, "rxo_create failed"
         self.w = C.c_void_p(self.w)
+        if pqeq:                                      # --pqeq <file>: before the tables are built (init.F90:28-43)
+            L.rxo_enable_pqeq.restype = C.c_int; L.rxo_enable_pqeq.argtypes = [C.c_void_p, C.c_char_p]
+            self._chk(L.rxo_enable_pqeq(self.w, pqeq.encode()))
         self.nranks = len(ranks)
         for p, r in enumerate(ranks):
             n = len(r["type"])
@@ -134,6 +137,13 @@ class Oracle:
     def vel(self, rank=0): return self.get(1, rank, 3)
     def forces(self, rank=0): return self.get(2, rank, 3)
     def charges(self, rank=0): return self.get(3, rank)
+    def spos(self, rank=0): return self.get(8, rank, 3)
+    def set_pqeq_clean(self, flag=1):
+        self.L.rxo_set_pqeq_clean.argtypes = [C.c_void_p, C.c_int]; self.L.rxo_set_pqeq_clean(self.w, int(flag))
+
+    def pqeq_stale(self):
+        self.L.rxo_pqeq_stale.restype = C.c_longlong; self.L.rxo_pqeq_stale.argtypes = [C.c_void_p]
+        return int(self.L.rxo_pqeq_stale(self.w))
     def types(self, rank=0): return self.get(4, rank).astype(np.int32)
     def gids(self, rank=0): return self.get(5, rank).astype(np.int64)
 
@@ -172,6 +182,12 @@ def make_system(case):
         ff = os.path.join(INP, "ffield_water")
         g = np.load(os.path.join(GOLD, "ice644_tight.npz"))
         names, frac, lat = read_xyz(str(g["input_xyz"]))
+    elif case.startswith("sicnp"):
+        ff = os.path.join(INP, "ffield_sicnp")
+        names, frac, lat = read_xyz(os.path.join(INP, "sicnp.xyz"))
     else:
         raise KeyError(case)
     return ff, names, frac, lat
+
+
+PQEQ_SICNP = os.path.join(INP, "pqeq_sicnp.in")
