@@ -94,7 +94,10 @@ int rxmd_hip_force(rxmd_handle h, double pe[14]);
  * QEq every qstep, FORCE, vkick); mdmode 1 (NVE).  Call rxmd_hip_qeq + rxmd_hip_force once before
  * the first step, as main.F90:27-32 does. */
 int rxmd_hip_step(rxmd_handle h, int nsteps);
-/* PRINTE reductions (src/main.F90:210-274) for this rank: ke = sum hmas*v^2, qsum, pe[14], astr[6]. */
+/* PRINTE reductions (src/main.F90:210-274) for this rank: ke = sum hmas*v^2, qsum, pe[14], and the stress accumulators
+ * astr[6] = (xx,yy,zz,yz,zx,xy): virial sum over residents+ghosts of pos*f before the fold (pot.F90:65-72) plus m*v*v of every
+ * step (main.F90:86-94), raw sums since the previous read -- passing astr != NULL resets them, as PRINTE does (main.F90:270).
+ * Pressure as printed: sum(astr[0..2])/3 / MDBOX * 6.94728103 / pstep  [GPa] (main.F90:233,252). */
 int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], double astr[6]);
 
 /* ---- the same path behind the reference's own argument shapes ------------------------------- */

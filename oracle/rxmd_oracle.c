@@ -1891,6 +1891,14 @@ void rxo_get_energy(void *w, double *pe14) { /* sum over ranks, PE(0) = sum(PE(1
   for (int p = 0; p < W->nprocs; p++) for (int k = 1; k < 14; k++) pe14[k] += W->R[p].PE[k];
   for (int k = 1; k < 14; k++) pe14[0] += pe14[k];
 }
+/* astr(1:6) summed over ranks as PRINTE's allreduce (main.F90:241-246); reset != 0 zeroes the accumulators as PRINTE does (:270).
+ * Printed pressure: ss = sum(astr(1:3))/3 / MDBOX * USTRS / pstep, USTRS = 6.94728103 (module.F90:200). */
+void rxo_get_astr(void *w, double *out6, int reset) {
+  World *W = (World *)w;
+  for (int k = 0; k < 6; k++) out6[k] = 0.0;
+  for (int p = 0; p < W->nprocs; p++) for (int k = 0; k < 6; k++) { out6[k] += W->R[p].astr[k]; if (reset) W->R[p].astr[k] = 0.0; }
+}
+double rxo_mdbox(void *w) { return ((World *)w)->MDBOX; }
 double rxo_kinetic(void *w) { /* PRINTE, main.F90:225-229 */
   World *W = (World *)w; double KE = 0;
   for (int p = 0; p < W->nprocs; p++) { Rank *r = &W->R[p]; for (int i = 1; i <= r->NATOMS; i++) KE += W->hmas[r->ity[i]] * (VEL(r, i, 0) * VEL(r, i, 0) + VEL(r, i, 1) * VEL(r, i, 1) + VEL(r, i, 2) * VEL(r, i, 2)); }

@@ -98,6 +98,44 @@ void Engine::assemble_forces() {
                                                   fnx, fny, fnz, cd, cc_, frc[0], frc[1], frc[2]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// stress accumulators astr(1:6) = (xx, yy, zz, yz, zx, xy):  sum_i a_i b_i^T [* mass_i]
+//   virial  : a = local position of residents AND ghosts, b = their force before the CPBK fold  (pot.F90:65-72)
+//   kinetic : a = b = velocity of residents, weighted by the mass                                (main.F90:86-94)
+// fixed grid + fixed-order final sum: the result does not depend on scheduling
+__global__ void __launch_bounds__(256) k_stress_partial(int n, const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az,
+                                                         const double *__restrict__ bx, const double *__restrict__ by, const double *__restrict__ bz,
+                                                         const int *__restrict__ type, DevFF ff, int use_mass, double *__restrict__ partials) {
+  __shared__ double sm[256];
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double w = use_mass ? ff.atom[type[i]].mass : 1.0;
+    const double p0 = ax[i], p1 = ay[i], p2 = az[i], f0 = bx[i] * w, f1 = by[i] * w, f2 = bz[i] * w;
+    a[0] += p0 * f0; a[1] += p1 * f1; a[2] += p2 * f2; a[3] += p1 * f2; a[4] += p2 * f0; a[5] += p0 * f1;
+  }
+  for (int c = 0; c < 6; ++c) {
+    sm[threadIdx.x] = a[c];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) partials[blockIdx.x * 6 + c] = sm[0];
+    __syncthreads();
+  }
+}
+__global__ void k_stress_final(int nblocks, const double *__restrict__ partials, double *__restrict__ acc6) {
+  const int c = threadIdx.x;
+  if (c >= 6) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partials[b * 6 + c];
+  acc6[c] += s;
+}
+
+void Engine::accumulate_stress(bool kinetic) {
+  const int n = kinetic ? N : G, nb = 240;
+  if (kinetic) k_stress_partial<<<nb, 256, 0, stream>>>(n, vel[0], vel[1], vel[2], vel[0], vel[1], vel[2], type, dff, 1, partials);
+  else k_stress_partial<<<nb, 256, 0, stream>>>(n, pos[0], pos[1], pos[2], frc[0], frc[1], frc[2], type, dff, 0, partials);
+  k_stress_final<<<1, 64, 0, stream>>>(nb, partials, scal + 48);
+}
+
 void Engine::force() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   tic(6);
@@ -111,6 +149,7 @@ void Engine::force() {
   hipEventRecord(ev[4], stream);
   bonded_energies();
   assemble_forces();
+  accumulate_stress(false);                            // pot.F90:65-72, before the ghost forces are folded back
   fold_ghost_forces();
   hipEventRecord(ev[5], stream);
   RX_HIP(hipMemcpyAsync(h_scal + 32, pe_d, sizeof(double) * 16, hipMemcpyDeviceToHost, stream));
@@ -163,6 +202,7 @@ void Engine::step(int nsteps) {
     const int qs = cfg.qstep > 0 ? cfg.qstep : 1;
     if (step_count % qs == 0) qeq();                                     // main.F90:77-83
     force();                                                             // main.F90:84
+    accumulate_stress(true);                                             // main.F90:86-94
     k_kick<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], q, qsfp, qsfv);
     ++step_count;
   }

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, 3) k_e4b(int N, int NB, DevFF ff, const i
                                               const double *__restrict__ etor, const double *__restrict__ econ,
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, double3 boxl) {
   // per (atom g, slot): the bond as seen from the centre
   __shared__ double s_bo[4][64], s_et[4][64], s_ec[4][64], s_rx[4][64], s_ry[4][64], s_rz[4][64], s_rn[4][64];
   __shared__ int s_nb[4][64], s_ty[4][64];
@@ -419,6 +419,20 @@ __global__ void __launch_bounds__(256, 3) k_e4b(int N, int NB, DevFF ff, const i
                         coDD * ((Cwj1 + Cwi1) * rij.z + (Cwj2 + Cwi2) * rjk.z + (Cwj3 + Cwi3) * rkl.z)};
         o[1] += fij.x; o[2] += fij.y; o[3] += fij.z;
         fself.x += -fij.x + fjk.x; fself.y += -fij.y + fjk.y; fself.z += -fij.z + fjk.z;
+      }
+      // stress: this visit books f_i and f_j in the frame of centre j; f_k and f_l are booked by the visit whose centre is the
+      // OWNER of k.  When k is an image beyond the periodic box that owner sits one lattice vector T away, and the virial
+      // sum_a pos_a f_a (pot.F90:65-72) would hold T (f_k + f_l) = -T (f_i + f_j) too much.  The owner's visit sees j as an
+      // image at -T and finds the same product, so each of the two visits takes out half (rare lanes only).
+      {
+        const double xk = x[k], yk = y[k], zk = z[k];
+        const double t0 = -boxl.x * floor(xk / boxl.x), t1 = -boxl.y * floor(yk / boxl.y), t2 = -boxl.z * floor(zk / boxl.z);
+        if (t0 != 0.0 || t1 != 0.0 || t2 != 0.0) {
+          const double F0 = 0.5 * (o[1] + fself.x), F1 = 0.5 * (o[2] + fself.y), F2 = 0.5 * (o[3] + fself.z);
+          if (t0 != 0.0) { atomicAdd(pe + 16, t0 * F0); atomicAdd(pe + 21, t0 * F1); }     // xx, xy
+          if (t1 != 0.0) { atomicAdd(pe + 17, t1 * F1); atomicAdd(pe + 19, t1 * F2); }     // yy, yz
+          if (t2 != 0.0) { atomicAdd(pe + 18, t2 * F2); atomicAdd(pe + 20, t2 * F0); }     // zz, zx
+        }
       }
     }
 #pragma unroll
@@ -581,7 +595,7 @@ void Engine::bonded_energies() {
   k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
   k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                          cds, frc[0], frc[1], frc[2], pe_d);
+                                          cds, frc[0], frc[1], frc[2], pe_d, make_double3(box.lat[0], box.lat[1], box.lat[2]));
   k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
 }
 

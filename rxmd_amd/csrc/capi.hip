@@ -204,7 +204,11 @@ int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], 
     if (ke) *ke = k;
     if (qsum) *qsum = qs;
     if (pe) std::memcpy(pe, e.pe, sizeof(double) * 14);
-    if (astr) std::memcpy(astr, e.astr, sizeof(double) * 6);
+    if (astr) {     // accumulated since the previous read; reading resets the accumulators as PRINTE does (main.F90:270)
+      RX_HIP(hipMemcpy(e.astr, e.scal + 48, sizeof(double) * 6, hipMemcpyDeviceToHost));
+      RX_HIP(hipMemset(e.scal + 48, 0, sizeof(double) * 6));
+      std::memcpy(astr, e.astr, sizeof(double) * 6);
+    }
   });
 }
 

@@ -183,6 +183,7 @@ struct Engine {
   void pqeq_update_shells();      // update_shell_positions, pqeq.F90:184-259
   void nonbonded_pqeq();          // ENbond_PQEq, pot.F90:784-923
   void assemble_forces();
+  void accumulate_stress(bool kinetic);   // astr(1:6) on the device (scal[48..53])
   void check_device_error(const char *where);
   double reduce_partials(int ncomp, int nblocks, double *out);  // host-side helper
   void tic(int k) { hipEventRecord(ev[k], stream); }

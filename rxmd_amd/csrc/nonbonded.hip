@@ -28,8 +28,10 @@ __global__ void __launch_bounds__(256) k_nonbond(int N, int S10, DevFF ff, const
                                                   const double4 *__restrict__ pk, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                   const double *__restrict__ q, const int *__restrict__ type,
                                                   double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
-  __shared__ double sm[4][3];
+  __shared__ double sm[4][3], sv[4][6];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < 24) sv[threadIdx.x / 6][threadIdx.x % 6] = 0.0;
+  __syncthreads();
   const int i = blockIdx.x * (blockDim.x >> 6) + w;
   double e11 = 0.0, e12 = 0.0, e13 = 0.0;
   if (i < N) {
@@ -39,6 +41,7 @@ __global__ void __launch_bounds__(256) k_nonbond(int N, int S10, DevFF ff, const
     const size_t row = static_cast<size_t>(i) * S10;
     const int *ix2 = ff.inxn2 + ti * ff.n1;
     double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;   // pair virial, see the stress note at the end of the row
     for (int k0 = lane; k0 < n; k0 += 256) {
       unsigned ee[4];
 #pragma unroll
@@ -64,13 +67,20 @@ __global__ void __launch_bounds__(256) k_nonbond(int N, int S10, DevFF ff, const
         e12 += 0.5 * (nd.Eclmb + t * nd.dEclmb_) * qij;
         const double c = CEvdw + CEclmb;
         f0 -= c * d0; f1 -= c * d1; f2 -= c * d2;
+        const double hc = -0.5 * c;
+        v0 += hc * d0 * d0; v1 += hc * d1 * d1; v2 += hc * d2 * d2; v3 += hc * d1 * d2; v4 += hc * d2 * d0; v5 += hc * d0 * d1;
       }
     }
     f0 = wave_sum_n(f0); f1 = wave_sum_n(f1); f2 = wave_sum_n(f2);
+    // stress: the reference scatters -ff to i and +ff to its partner (possibly a ghost image), so its virial sum_a pos_a f_a
+    // (pot.F90:65-72) holds (pos_i - pos_j) f_ij once per pair.  This row gathered all of f_i at pos_i instead: add the
+    // difference  1/2 sum_j dr_ij f_ij - pos_i f_i  to the accumulators so that Engine::accumulate_stress sees the reference's sum
+    v0 = wave_sum_n(v0); v1 = wave_sum_n(v1); v2 = wave_sum_n(v2); v3 = wave_sum_n(v3); v4 = wave_sum_n(v4); v5 = wave_sum_n(v5);
     if (lane == 0) {
       fx[i] += f0; fy[i] += f1; fz[i] += f2;
       const DevAtomP ap = ff.atom[ti];
       e13 = CEchrge * (ap.chi * qi + 0.5 * ap.eta * qi * qi);           // pot.F90:708
+      sv[w][0] = v0 - xi * f0; sv[w][1] = v1 - yi * f1; sv[w][2] = v2 - zi * f2; sv[w][3] = v3 - yi * f2; sv[w][4] = v4 - zi * f0; sv[w][5] = v5 - xi * f1;
     }
   }
   e11 = wave_sum_n(e11); e12 = wave_sum_n(e12); e13 = wave_sum_n(e13);
@@ -80,6 +90,11 @@ __global__ void __launch_bounds__(256) k_nonbond(int N, int S10, DevFF ff, const
     double s = 0.0;
     for (int k = 0; k < 4; ++k) s += sm[k][threadIdx.x];
     if (s != 0.0) atomicAdd(pe + 11 + threadIdx.x, s);
+  }
+  if (threadIdx.x >= 64 && threadIdx.x < 70) {      // pe = scal + 32: the stress accumulators sit at scal + 48
+    const int c = threadIdx.x - 64;
+    const double s = sv[0][c] + sv[1][c] + sv[2][c] + sv[3][c];
+    if (s != 0.0) atomicAdd(pe + 16 + c, s);
   }
 }
 

@@ -118,8 +118,10 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
                                                        const double *__restrict__ q, const int *__restrict__ type,
                                                        const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
                                                        double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
-  __shared__ double sm[4][3];
+  __shared__ double sm[4][3], sv[4][6];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < 24) sv[threadIdx.x / 6][threadIdx.x % 6] = 0.0;
+  __syncthreads();
   const int i = blockIdx.x * (blockDim.x >> 6) + w;
   double e11 = 0.0, e12 = 0.0, e13 = 0.0;
   if (i < N) {
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
     const size_t row = static_cast<size_t>(i) * S10;
     const int *ix2 = ff.inxn2 + ti * ff.n1;
     double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;   // pair virial (stress note in nonbonded.hip)
     for (int k = lane; k < n; k += 64) {
       const unsigned e = static_cast<unsigned>(nb10[row + k]);
       if (e & NB10_SELF) continue;
@@ -163,9 +166,12 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
       c = Cclmb0 * Zi * Zj; ec += c * E; g0 += c * F * a0; g1 += c * F * a1; g2 += c * F * a2;
       e12 += 0.5 * ec;
       f0 -= g0; f1 -= g1; f2 -= g2;
+      v0 -= 0.5 * d0 * g0; v1 -= 0.5 * d1 * g1; v2 -= 0.5 * d2 * g2; v3 -= 0.5 * d1 * g2; v4 -= 0.5 * d2 * g0; v5 -= 0.5 * d0 * g1;
     }
     f0 = wave_sum_p(f0); f1 = wave_sum_p(f1); f2 = wave_sum_p(f2);
+    v0 = wave_sum_p(v0); v1 = wave_sum_p(v1); v2 = wave_sum_p(v2); v3 = wave_sum_p(v3); v4 = wave_sum_p(v4); v5 = wave_sum_p(v5);
     if (lane == 0) {
+      sv[w][0] = v0 - xi * f0; sv[w][1] = v1 - yi * f1; sv[w][2] = v2 - zi * f2; sv[w][3] = v3 - yi * f2; sv[w][4] = v4 - zi * f0; sv[w][5] = v5 - xi * f1;
       fx[i] += f0; fy[i] += f1; fz[i] += f2;
       const DevAtomP ap = ff.atom[ti];
       e13 = CEchrge * (ap.chi * qi + 0.5 * ap.eta * qi * qi) + 0.5 * ff.Kspq[ti] * (s0 * s0 + s1 * s1 + s2 * s2);   // pot.F90:818-824
@@ -178,6 +184,11 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
     double s = 0.0;
     for (int k = 0; k < 4; ++k) s += sm[k][threadIdx.x];
     if (s != 0.0) atomicAdd(pe + 11 + threadIdx.x, s);
+  }
+  if (threadIdx.x >= 64 && threadIdx.x < 70) {      // pe = scal + 32: the stress accumulators sit at scal + 48
+    const int c = threadIdx.x - 64;
+    const double s = sv[0][c] + sv[1][c] + sv[2][c] + sv[3][c];
+    if (s != 0.0) atomicAdd(pe + 16 + c, s);
   }
 }
 

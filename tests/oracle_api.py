@@ -152,6 +152,14 @@ class Oracle:
 
     def kinetic(self): return self.L.rxo_kinetic(self.w)
 
+    def astr(self, reset=True):
+        """stress accumulators astr(1:6) (pot.F90:65-72 virial + main.F90:86-94 kinetic), reset like PRINTE"""
+        a = np.zeros(6); self.L.rxo_get_astr.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.L.rxo_get_astr(self.w, a.ctypes.data_as(C.c_void_p), int(reset)); return a
+
+    def mdbox(self):
+        self.L.rxo_mdbox.restype = C.c_double; self.L.rxo_mdbox.argtypes = [C.c_void_p]; return self.L.rxo_mdbox(self.w)
+
     def trace(self):
         n = self.L.rxo_ntrace(self.w); t = np.zeros((n, 3)); self.L.rxo_get_trace(self.w, t.ctypes.data_as(C.c_void_p)); return t
 

@@ -131,7 +131,7 @@ def test_benchmark_tolerance_report():
     e = _engine("rdx168", (1, 1, 1))
     it, est = e.QEq()
     a = e.atoms()
-    assert abs(it - int(g["qeq_iters"][0])) <= 10
+    assert abs(it - int(g["qeq_iters"][0])) <= 0.4 * int(g["qeq_iters"][0])     # chance exit on REAL(4) step-length noise, see the module docstring
     assert np.abs(a["q"] - g["charge"]).max() <= 1e-4
     assert np.abs(a["q"] - gt["charge"]).max() <= 1e-4            # no further from the converged charges than the reference is
     assert abs(est - g["qeq_trace_last"][-1, 3]) <= 1e-5 * abs(est)
@@ -310,5 +310,23 @@ def test_pqeq_md_against_the_clean_oracle():
     # shells move by (small net force)/K per call, clipped to 1e-3 A: measured difference 2e-8 A after 6 calls, it follows the
     # 1e-7 relative CG noise of the charges at this tolerance
     assert np.abs(e.shells()[ie] - o.spos()[io]).max() <= 1e-7
-    assert e_err(e.energy()["PE"], o.energy()) <= 1e-8
+    # the Coulomb term PE(12) = 69 kcal/mol is what is left of +-1e5 kcal/mol of core/shell sums and moves with the shells
+    # (2e-8 A apart, above): gate every term on the scale of the total energy instead of its own
+    pe_e, pe_o = e.energy()["PE"], o.energy()
+    assert np.abs(pe_e - pe_o).max() <= 1e-9 * abs(pe_o[0])
+    e.close()
+
+
+def test_stress_accumulators_match_the_oracle():
+    """astr(1:6): virial over residents+ghosts before the fold (pot.F90:65-72) + kinetic part per step (main.F90:86-94),
+    accumulated between reads like PRINTE; the oracle's values are pinned to the reference's printed pressure column"""
+    e = _engine("rdx222", (2, 2, 2), QEq_tol=1e-12, NMAXQEq=2000)
+    o = _oracle("rdx222", (2, 2, 2), QEq_tol=1e-12, NMAXQEq=2000)
+    e.QEq(); e.FORCE(); o.qeq(); o.force()
+    a0, b0 = e.energy()["astr"], o.astr(reset=True)
+    assert np.abs(a0 - b0).max() <= 1e-8 * np.abs(b0).max()
+    e.step(3); o.step(3)
+    a1, b1 = e.energy()["astr"], o.astr(reset=True)
+    assert np.abs(a1 - b1).max() <= 1e-8 * np.abs(b1).max()
+    assert np.abs(e.energy()["astr"]).max() == 0.0      # reading resets
     e.close()

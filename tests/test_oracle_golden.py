@@ -141,3 +141,19 @@ def test_pqeq_sicnp_against_reference(case, steps):
     # inside.  Once shells move it happens (170 times in these 5 steps) and the reference then re-uses the previous pair's value
     # (module.F90:401 returns without touching its outputs); the oracle restates that, which is why the trajectory still matches.
     assert (o.pqeq_stale() == 0) == (steps == 0)
+
+
+def test_pressure_column_of_the_mdstep_line():
+    """ss of the reference's MDstep line (main.F90:233,252,261; f8.2) = sum(astr(1:3))/3/MDBOX*USTRS: pins the virial
+    (pot.F90:65-72, positions of residents AND ghosts times their pre-fold forces) and the kinetic part (main.F90:86-94)"""
+    USTRS = 6.94728103
+    g = np.load(os.path.join(GOLD, "rdx168_md10.npz"))
+    ff, names, frac, lat = oa.make_system("rdx168")
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff))
+    o = oa.Oracle(ff, lat2, ranks)
+    o.qeq(); o.force()
+    for row in range(len(g["mdstep"])):
+        a = o.astr(reset=True)
+        ss = a[:3].sum() / 3.0 / o.mdbox() * USTRS
+        assert abs(ss - g["mdstep"][row][11]) <= 0.0051, (row, ss, g["mdstep"][row][11])
+        o.step(1)
