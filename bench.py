@@ -83,7 +83,7 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
-    use_dist = world > 1
+    use_dist = world > 1 or "RXMD_BENCH_FORCE_DIST" in os.environ     # the latter: drive the N > 1 code path with one rank (tests)
     backend = os.environ.get("RXMD_BENCH_BACKEND", "nccl")       # "gloo": host-staged messages (several ranks on one GPU, debugging)
     if "RXMD_BENCH_DEVICE" in os.environ:
         local = int(os.environ["RXMD_BENCH_DEVICE"])
@@ -116,7 +116,28 @@ def main():
         from rxmd_amd.comm import TorchTransport
         dev = torch.device("cuda", local)
         cap = int(natoms * 0.45 * 6) + (1 << 20)          # widest message: the 13 A ghost shell of one stage, 6 doubles per atom
-        if backend == "nccl":
+        tr = None
+        if backend == "nccl" and os.environ.get("RXMD_BENCH_TRANSPORT", "native") == "native":
+            # native transport: the engine's own RCCL communicator (ncclSend/ncclRecv/ncclAllReduce on its stream, rccl_comm.hip);
+            # torch.distributed only carries the 128-byte unique id
+            ok = torch.ones(1, device=dev)
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(eng.rccl_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                eng.init_rccl(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                transport_mode = "native RCCL send/recv on the engine stream"
+            except Exception as ex:
+                sys.stderr.write("rank %d: native RCCL transport unavailable (%s)\n" % (rank, ex))
+                ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            native_ok = ok.item() >= 1
+        else:
+            native_ok = False
+        if native_ok:
+            pass
+        elif backend == "nccl":
             tr = TorchTransport(mode="device", device=dev, capacity_doubles=cap)
             ok = torch.ones(1, device=dev)
             try:                                           # one ring round on the device path before trusting it
@@ -133,12 +154,15 @@ def main():
                 tr = TorchTransport(mode="staged", group=gl, device=dev, capacity_doubles=cap)
         else:
             tr = TorchTransport(mode="staged", device=dev, capacity_doubles=cap)
-        transport_mode = tr.mode
-        tr.attach(eng)
+        if tr is not None:
+            transport_mode = "torch.distributed " + tr.mode
+            tr.attach(eng)
     eng.set_atoms_rxff(rec)
     eng.QEq(); eng.FORCE()                       # main.F90:27-32
     eng.step(a.warmup)
     eng.reset_timers()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)              # every rank: push out what RCCL / the runtime wrote to C stdout during set-up
 
     def barrier():
         if use_dist:
@@ -197,7 +221,7 @@ def main():
             "data": "synthetic (RDX unit cell of the reference's conf/init.rdx replicated; v0=0, q0=0)",
             "config": {"workload": "RDX %dx%dx%d cells per GPU = %d atoms/GPU, QEq tol %g, dt %g fs, mdmode 1 (NVE)" % (a.cells, a.cells, a.cells, natoms, cfg["QEq_tol"], cfg["dt"]),
                        "atoms_total": natoms * world, "parallelism": "1 GPU" if world == 1 else ("%d independent replicas" % world if a.replicas else
-                                       "vprocs %dx%dx%d domain decomposition, six-stage halo over RCCL (%s)" % (vp[0], vp[1], vp[2], transport_mode)),
+                                       "vprocs %dx%dx%d domain decomposition, six-stage halo, %s" % (vp[0], vp[1], vp[2], transport_mode)),
                        "qeq_mode": a.qeq_mode},
             "steps_per_s_wall": steps_per_s, "ns_per_day": steps_per_s * cfg["dt"] * 86400e-6, "atom_steps_per_s": steps_per_s * natoms * world,
             "qeq_iters_per_step": iters, "ms_qeq_per_iter": st["ms_qeq"] / max(st["qeq_iters_total"], 1), "n10": n10, "nb": nb,
@@ -214,7 +238,10 @@ def main():
             cb = cpu_baseline()
             if cb:
                 out["cpu_baseline"] = cb
-        print(json.dumps(out))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # C-level stdout first (RCCL prints a version banner there): the JSON line stays last
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -149,6 +149,11 @@ typedef struct rxmd_comm_ops {
   long long (*exchange_known)(void *ctx, int to, const double *send, long long nsend, int from, double *recv, long long nrecv);
 } rxmd_comm_ops;
 int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops);
+/* Native transport: RCCL send/recv + all-reduce on the engine's own stream (rccl_comm.hip), one communicator per engine.
+ * Rank 0 obtains a 128-byte id with rxmd_hip_rccl_unique_id, the host distributes it (MPI_Bcast, torch.distributed, a file)
+ * and every rank calls rxmd_hip_comm_init_rccl(h, id, myid, nprocs); a collective call.  Takes precedence over rxmd_comm_ops. */
+int rxmd_hip_rccl_unique_id(unsigned char out128[128]);
+int rxmd_hip_comm_init_rccl(rxmd_handle h, const unsigned char id128[128], int rank, int world);
 /* Optional: let the host own the two message buffers (device memory, `ndoubles` each) that `exchange` is called
  * with -- e.g. torch tensors, so that torch.distributed can send them without wrapping foreign pointers. */
 int rxmd_hip_set_exchange_buffers(rxmd_handle h, double *send, double *recv, long long ndoubles);

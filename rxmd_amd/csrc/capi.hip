@@ -364,6 +364,13 @@ int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops) {
   });
 }
 
+int rxmd_hip_comm_init_rccl(rxmd_handle h, const unsigned char id128[128], int rank, int world) {
+  return guarded(h, [&](Engine &e) {
+    if (!id128) throw EngineError(RXMD_E_ARG, "NULL unique id");
+    e.rccl_init(id128, rank, world);
+  });
+}
+
 int rxmd_hip_set_exchange_buffers(rxmd_handle h, double *send, double *recv, long long ndoubles) {
   return guarded(h, [&](Engine &e) {
     if (!send || !recv || ndoubles < 1024) throw EngineError(RXMD_E_ARG, "bad exchange buffers");

@@ -171,7 +171,16 @@ struct Engine {
   void halo_staged(double *v, int ncomp);           // the same through the six-stage exchange (multi-rank)
   long long exchange_stage(int d, bool reverse, long long nsend, long long known_nrecv = -1);  // one send_recv of comm.F90:291-364; returns #doubles received
   void ensure_xbuf(size_t doubles);
-  bool multi() const { return nprocs > 1; }
+  bool multi() const { return nprocs > 1 || force_staged; }
+  // native RCCL transport (rccl_comm.hip); force_staged / force_remote (env RXMD_FORCE_STAGED / RXMD_FORCE_REMOTE) push a
+  // single rank through the staged exchange and through RCCL self send/recv: how the multi-GPU code path runs on ONE GPU in the tests
+  void *nccl = nullptr; double *cnt_dev = nullptr, *cnt_host = nullptr; bool force_staged = false, force_remote = false;
+  void rccl_init(const unsigned char id128[128], int rank, int world);
+  void rccl_destroy();
+  long long rccl_exchange(int to, int from, long long nsend, long long known_nrecv);
+  void rccl_allreduce_dev(double *dev, int n);
+  void allreduce_scal4();                          // MPI_ALLREDUCE of scal[S_RAW0..3] (qeq.hip)
+  void allreduce_host(double *buf, int n);         // the same for a host vector (setup paths)
   void ghost_build_staged();
   void migrate_staged();
   void sorted_copy(const double2 *v);               // QCOPY1/QCOPY2 fused with the cell-sorted gather copy -> xs

@@ -82,6 +82,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
     cfg.pqeq_path = nullptr;
     ff.build_taper(10.0);                         // rctap0, module.F90:281
   }
+  force_staged = std::getenv("RXMD_FORCE_STAGED") != nullptr; force_remote = std::getenv("RXMD_FORCE_REMOTE") != nullptr;
   MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
   if (MAXNB > 31) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 31 (the wavefront-per-centre kernels stage the bond slots of two atoms in one 64-lane wavefront; the reference uses 30)");
   int ndev = 0;
@@ -92,9 +93,25 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
 }
 
 Engine::~Engine() {
+  rccl_destroy();
   free_device();
   for (auto &e : ev) if (e) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Engine::allreduce_host(double *buf, int n) {
+  if (nccl) {
+    double *d = nullptr;
+    RX_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * n));
+    RX_HIP(hipMemcpyAsync(d, buf, sizeof(double) * n, hipMemcpyHostToDevice, stream));
+    rccl_allreduce_dev(d, n);
+    RX_HIP(hipMemcpyAsync(buf, d, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(d);
+    return;
+  }
+  if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm or rxmd_hip_comm_init_rccl first");
+  if (comm.allreduce_sum(comm.ctx, buf, n)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
 }
 
 void Engine::check_device_error(const char *where) {
@@ -289,10 +306,10 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
     npt[t]++;
   }
   if (!tables_ready) {
-    if (has_comm && nprocs > 1) {
+    if (nprocs > 1) {
       std::vector<double> tmp(ff.nso + 1);
       for (int t = 0; t <= ff.nso; ++t) tmp[t] = static_cast<double>(npt[t]);
-      if (comm.allreduce_sum(comm.ctx, tmp.data(), ff.nso + 1)) throw EngineError(RXMD_E_COMM, "allreduce failed");
+      allreduce_host(tmp.data(), ff.nso + 1);
       for (int t = 0; t <= ff.nso; ++t) npt[t] = std::llround(tmp[t]);
     }
     setup_after_atoms(npt);
@@ -524,10 +541,11 @@ void Engine::ensure_xbuf(size_t doubles) {
 long long Engine::exchange_stage(int d, bool reverse, long long nsend, long long known_nrecv) {
   const int to = reverse ? target_node[dinv_[d]] : target_node[d];
   const int from = reverse ? target_node[d] : target_node[dinv_[d]];
-  if (to == cfg.myid && from == cfg.myid) {                    // comm.F90:305-315
+  if (to == cfg.myid && from == cfg.myid && !(force_remote && nccl)) {                    // comm.F90:305-315
     if (nsend > 0) RX_HIP(hipMemcpyAsync(xbuf_recv, xbuf_send, sizeof(double) * nsend, hipMemcpyDeviceToDevice, stream));
     return nsend;
   }
+  if (nccl) return rccl_exchange(to, from, nsend, known_nrecv);       // native: stays in stream order
   if (!has_comm || !comm.exchange) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
   RX_HIP(hipStreamSynchronize(stream));                        // the message must be packed before the transport reads it
   const long long nr = (known_nrecv >= 0 && comm.exchange_known)

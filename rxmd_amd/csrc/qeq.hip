@@ -381,59 +381,12 @@ __global__ void __launch_bounds__(256) k_update_qst(int N, const double *__restr
   acc[0] = s; acc[1] = t;
   block_store_partials<4>(acc, partials, 4);
 }
-// ---- qeq_mode 1 ---------------------------------------------------------------------------------
-// qs += l1 hs, qt += l2 ht and the same update of the stored row sums: H.qs += l1 H.hs, H.qt += l2 H.ht
-__global__ void __launch_bounds__(256) k_update_qst_sums(int N, const double *__restrict__ scal, const double2 *__restrict__ hst, double2 *__restrict__ qst,
-                                                          const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
-                                                          double *__restrict__ partials) {
-  const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
-  double acc[4] = {0, 0, 0, 0};
-  double s = 0.0, t = 0.0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    double2 qv = qst[i];
-    const double2 hv = hst[i];
-    qv.x = qv.x + l1 * hv.x; qv.y = qv.y + l2 * hv.y;
-    qst[i] = qv;
-    double2 a = sall[i], g = sgh[i];
-    const double2 wa = wall[i], wg = wgh[i];
-    a.x += l1 * wa.x; a.y += l2 * wa.y; g.x += l1 * wg.x; g.y += l2 * wg.y;
-    sall[i] = a; sgh[i] = g;
-    s += qv.x; t += qv.y;
-  }
-  s = wave_sum(s); t = wave_sum(t);
-  acc[0] = s; acc[1] = t;
-  block_store_partials<4>(acc, partials, 4);
-}
-// gradient, q, Gnew and Est from the stored row sums (the arithmetic of get_gradient / get_hsh, qeq.F90:297-306,349-356)
-__global__ void __launch_bounds__(256) k_grad_from_sums(int N, DevFF ff, const double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ qst,
-                                                         const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double2 *__restrict__ gst, double *__restrict__ q,
-                                                         double *__restrict__ partials, const double4 *__restrict__ pqrow) {
-  const double mu = scal[S_MU];
-  double acc[4] = {0, 0, 0, 0};
-  double g1s = 0.0, g2s = 0.0, es = 0.0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    const DevAtomP ap = ff.atom[type[i]];
-    const double2 qv = qst[i], a = sall[i], g = sgh[i];
-    const double g1 = -ap.chi - ap.eta * qv.x - a.x - (pqrow ? pqrow[i].x : 0.0), g2 = -1.0 - ap.eta * qv.y - a.y;
-    gst[i] = make_double2(g1, g2);
-    const double qi = qv.x - mu * qv.y;
-    q[i] = qi;
-    const double hq_all = a.x - mu * a.y, hq_res = (a.x - g.x) - mu * (a.y - g.y);
-    g1s += g1 * g1; g2s += g2 * g2;
-    if (pqrow) es += pq_est_row(ap, ff.Zpq[type[i]], pqrow[i], qi, hq_all, g.x - mu * g.y);
-    else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
-  }
-  g1s = wave_sum(g1s); g2s = wave_sum(g2s); es = wave_sum(es);
-  acc[0] = g1s; acc[1] = g2s; acc[2] = es;
-  block_store_partials<4>(acc, partials, 4);
-}
-
-// ---- qeq_mode 1, single rank: the whole vector algebra of one CG iteration in two launches ---------------------
+// ---- qeq_mode 1: the whole vector algebra of one CG iteration in two launches -----------------------------------
 // A: qs,qt += lmin (hs,ht); stored row sums += lmin H.(hs,ht); new gradient (no mu needed); sums (qs, qt, gs.gs, gt.gt)
 //    -> tail: mu, Gnew, beta                                                    (qeq.F90:136-147,349-356,160-161)
 __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ hst, double2 *__restrict__ qst,
                                                     const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
-                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow) {
+                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage) {
   const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
   double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
@@ -452,7 +405,7 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
   }
   double acc[4] = {wave_sum(s), wave_sum(t), wave_sum(g1s), wave_sum(g2s)};
   block_store_partials<4>(acc, partials, 4);
-  block_finish(gridDim.x, partials, ticket, 4, scal);
+  block_finish(gridDim.x, partials, ticket, stage, scal);     // stage 4, or 0 = sums only (the all-reduce of a multi-rank run comes first)
 }
 // B: over the cell-sorted positions k (residents and their periodic images): new direction h = g + beta h written to the
 //    other (hs,ht) buffer and, as the QCOPY2 halo + sorted gather copy, to xs[k]; at the resident itself also
@@ -460,15 +413,15 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
 __global__ void __launch_bounds__(256) k_cg_direction(int G, int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ perm, const int *__restrict__ rootperm, const int *__restrict__ type,
                                                        const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new, double2 *__restrict__ xs,
                                                        const double2 *__restrict__ qst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double *__restrict__ q,
-                                                       double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow) {
+                                                       double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage) {
   const double mu = scal[S_MU], b1 = scal[S_BETA_S], b2 = scal[S_BETA_T];
   double es = 0.0;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < G; k += gridDim.x * blockDim.x) {
-    const int i = rootperm[k];
+    const int i = rootperm ? rootperm[k] : k;        // rootperm == nullptr: residents only, k is the atom (multi-rank: the halo + sorted copy follow)
     const double2 g = gst[i], h = hst[i];
     const double2 hn = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
-    xs[k] = hn;
-    if (perm[k] == i) {                              // the resident itself, not one of its images
+    if (xs) xs[k] = hn;
+    if (!perm || perm[k] == i) {                              // the resident itself, not one of its images
       hst_new[i] = hn;
       const DevAtomP ap = ff.atom[type[i]];
       const double2 qv = qst[i], a = sall[i], gh = sgh[i];
@@ -481,7 +434,7 @@ __global__ void __launch_bounds__(256) k_cg_direction(int G, int N, DevFF ff, do
   }
   double acc[4] = {wave_sum(es), 0.0, 0.0, 0.0};
   block_store_partials<4>(acc, partials, 4);
-  block_finish(gridDim.x, partials, ticket, 5, scal);
+  block_finish(gridDim.x, partials, ticket, stage, scal);     // stage 5 or 0
 }
 
 // q = qs - mu*qt (qeq.F90:150)
@@ -507,6 +460,16 @@ __global__ void k_qeq_init(int N, int isQEq, double fqs, double *__restrict__ q,
   hst[i] = make_double2(0.0, 0.0);
   if (isQEq == 1) { qsfp[i] = q[i]; qsfv[i] = 0.0; qst[i] = make_double2(q[i], 0.0); }
   else { qst[i] = make_double2(fqs * qsfp[i] + (1.0 - fqs) * q[i], 0.0); }
+}
+
+void Engine::allreduce_scal4() {
+  if (nprocs == 1 && !nccl) return;              // forced staged mode of a single rank without a communicator: nothing to add
+  if (nccl) { rccl_allreduce_dev(scal + S_RAW0, 4); return; }      // in stream order, no host round trip
+  if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm or rxmd_hip_comm_init_rccl first");
+  RX_HIP(hipMemcpyAsync(h_scal + 48, scal + S_RAW0, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
+  RX_HIP(hipStreamSynchronize(stream));
+  if (comm.allreduce_sum(comm.ctx, h_scal + 48, 4)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
+  RX_HIP(hipMemcpyAsync(scal + S_RAW0, h_scal + 48, sizeof(double) * 4, hipMemcpyHostToDevice, stream));
 }
 
 void Engine::qeq() {
@@ -557,13 +520,7 @@ void Engine::qeq() {
     } else {
       k_reduce_scalars<<<1, 256, 0, stream>>>(nb_, partials, scal);
     }
-    {                                            // MPI_ALLREDUCE of the rank-local sums through the host transport
-      if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
-      RX_HIP(hipMemcpyAsync(h_scal + 48, scal + S_RAW0, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipStreamSynchronize(stream));
-      if (comm.allreduce_sum(comm.ctx, h_scal + 48, 4)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
-      RX_HIP(hipMemcpyAsync(scal + S_RAW0, h_scal + 48, sizeof(double) * 4, hipMemcpyHostToDevice, stream));
-    }
+    allreduce_scal4();                           // MPI_ALLREDUCE of the rank-local sums
     k_scalar_algebra<<<1, 64, 0, stream>>>(stage, scal);
   };
   k_qeq_init<<<nblk(N, 256), 256, 0, stream>>>(N, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
@@ -589,25 +546,19 @@ void Engine::qeq() {
     pass(MODE_HSH, onepass, onepass ? wall : nullptr, onepass ? wgh : nullptr);
     hipEventRecord(ev[3], stream);
     reduce(1, nred);
-    if (onepass && !multi()) {   // qeq_mode 1, single rank: matrix pass + three launches, every reduction finished in-kernel
-      const int gb = std::min(nblk(G, 256), 2048);
-      k_cg_update<<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow);
-      k_cg_direction<<<gb, 256, 0, stream>>>(G, N, dff, scal, perm, rootperm, type, gst, hst, hst2, xs, qst, sall, sgh, q, partials, tickets + 2, pqrow);
-      std::swap(hst, hst2);
-      xs_current = true;
-      RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipStreamSynchronize(stream));
-      Est = h_scal[S_EST];
-      hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
-      st.spmv_launches += 1;
-      continue;
-    }
     if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
-      k_update_qst_sums<<<vb, 256, 0, stream>>>(N, scal, hst, qst, wall, wgh, sall, sgh, partials);
-      reduce(2, vb);
-      k_grad_from_sums<<<vb, 256, 0, stream>>>(N, dff, scal, type, qst, sall, sgh, gst, q, partials, pqrow);
-      reduce(3, vb);
-      k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);
+      const bool fuse = !multi();                  // single rank: every reduction finishes in-kernel; multi: sums, all-reduce, algebra
+      k_cg_update<<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
+      if (!fuse) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(4, scal); }
+      if (fuse) {
+        const int gb = std::min(nblk(G, 256), 2048);
+        k_cg_direction<<<gb, 256, 0, stream>>>(G, N, dff, scal, perm, rootperm, type, gst, hst, hst2, xs, qst, sall, sgh, q, partials, tickets + 2, pqrow, 5);
+      } else {
+        k_cg_direction<<<vb, 256, 0, stream>>>(N, N, dff, scal, nullptr, nullptr, type, gst, hst, hst2, nullptr, qst, sall, sgh, q, partials, tickets + 2, pqrow, 0);
+        allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal);
+      }
+      std::swap(hst, hst2);
+      xs_current = fuse;                           // multi-rank: the (hs,ht) halo and the sorted copy run at the top of the next iteration
       RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
       RX_HIP(hipStreamSynchronize(stream));
       Est = h_scal[S_EST];

@@ -1,0 +1,79 @@
+// rccl_comm.hip -- native transport of the six-stage exchange: RCCL point-to-point and all-reduce enqueued on the engine's
+// own HIP stream (reference: the MPI_Send/MPI_Recv pairs of send_recv, src/comm.F90:291-364, and the MPI_ALLREDUCE call
+// sites of src/qeq.F90:107,129,144,357).  One communicator per engine = per GPU; between two MI355X of a node the bytes
+// go over the xGMI link that joins them.  Nothing here synchronises the host except the size message of a stage whose
+// receive count is not known in advance (ghost build, migration: 12 per step); vector halos, the force fold and the CG
+// scalars stay in stream order with the kernels that pack, unpack and consume them.
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "engine.h"
+
+namespace rxmd {
+
+#define RX_NCCL(call)                                                                                          \
+  do {                                                                                                         \
+    ncclResult_t r_ = (call);                                                                                  \
+    if (r_ != ncclSuccess) throw EngineError(RXMD_E_COMM, std::string(#call) + ": " + ncclGetErrorString(r_)); \
+  } while (0)
+
+static inline ncclComm_t C(void *p) { return static_cast<ncclComm_t>(p); }
+
+void Engine::rccl_init(const unsigned char id128[128], int rank, int world) {
+  if (world != nprocs && !(force_staged && world == 1)) throw EngineError(RXMD_E_ARG, "RCCL world size does not match vprocs");
+  if (rank != cfg.myid) throw EngineError(RXMD_E_ARG, "RCCL rank does not match myid");
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(&id, id128, 128);
+  RX_HIP(hipSetDevice(cfg.device));
+  ncclComm_t c;
+  RX_NCCL(ncclCommInitRank(&c, world, id, rank));
+  nccl = c;
+  if (!cnt_dev) { RX_HIP(hipMalloc(reinterpret_cast<void **>(&cnt_dev), 4 * sizeof(double))); RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&cnt_host), 4 * sizeof(double))); }
+}
+
+void Engine::rccl_destroy() {
+  if (nccl) { (void)ncclCommDestroy(C(nccl)); nccl = nullptr; }
+  if (cnt_dev) { (void)hipFree(cnt_dev); cnt_dev = nullptr; }
+  if (cnt_host) { (void)hipHostFree(cnt_host); cnt_host = nullptr; }
+}
+
+// one send_recv: nsend doubles of xbuf_send to `to`, the message of `from` into xbuf_recv; returns the doubles received
+long long Engine::rccl_exchange(int to, int from, long long nsend, long long known_nrecv) {
+  ncclComm_t c = C(nccl);
+  long long nrecv = known_nrecv;
+  if (nrecv < 0) {                                        // size message first (the reference sends the size inside MPI_Probe, comm.F90:329-341)
+    cnt_host[0] = static_cast<double>(nsend);
+    RX_HIP(hipMemcpyAsync(cnt_dev, cnt_host, sizeof(double), hipMemcpyHostToDevice, stream));
+    RX_NCCL(ncclGroupStart());
+    RX_NCCL(ncclSend(cnt_dev, 1, ncclDouble, to, c, stream));
+    RX_NCCL(ncclRecv(cnt_dev + 1, 1, ncclDouble, from, c, stream));
+    RX_NCCL(ncclGroupEnd());
+    RX_HIP(hipMemcpyAsync(cnt_host + 1, cnt_dev + 1, sizeof(double), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipStreamSynchronize(stream));
+    nrecv = static_cast<long long>(cnt_host[1]);
+    if (nrecv > static_cast<long long>(xbuf_doubles)) throw EngineError(RXMD_E_NBUFFER, "incoming message larger than the exchange buffer");
+  }
+  if (nsend > 0 || nrecv > 0) {
+    RX_NCCL(ncclGroupStart());
+    if (nsend > 0) RX_NCCL(ncclSend(xbuf_send, static_cast<size_t>(nsend), ncclDouble, to, c, stream));
+    if (nrecv > 0) RX_NCCL(ncclRecv(xbuf_recv, static_cast<size_t>(nrecv), ncclDouble, from, c, stream));
+    RX_NCCL(ncclGroupEnd());
+  }
+  return nrecv;
+}
+
+// MPI_ALLREDUCE(SUM) of n device doubles, in place, in stream order
+void Engine::rccl_allreduce_dev(double *dev, int n) {
+  RX_NCCL(ncclAllReduce(dev, dev, static_cast<size_t>(n), ncclDouble, ncclSum, C(nccl), stream));
+}
+
+}  // namespace rxmd
+
+extern "C" int rxmd_hip_rccl_unique_id(unsigned char out128[128]) {
+  ncclUniqueId id;
+  if (!out128 || ncclGetUniqueId(&id) != ncclSuccess) return RXMD_E_COMM;
+  std::memcpy(out128, &id, 128);
+  return RXMD_OK;
+}

@@ -95,6 +95,14 @@ class RxmdEngine:
     def set_velocities(self, v):
         v = np.ascontiguousarray(v, np.float64).reshape(-1, 3); self._chk(self.L.rxmd_hip_set_velocities(self.h, len(v), _ptr(v)))
 
+    # ---- native multi-GPU transport (include/rxmd_hip.h: rxmd_hip_comm_init_rccl) ----
+    def rccl_unique_id(self):
+        buf = C.create_string_buffer(128); self._chk(self.L.rxmd_hip_rccl_unique_id(buf)); return buf.raw
+
+    def init_rccl(self, unique_id, rank, world):
+        """collective: every rank of the vprocs grid calls it with the id rank 0 generated"""
+        self._chk(self.L.rxmd_hip_comm_init_rccl(self.h, C.c_char_p(bytes(unique_id)), int(rank), int(world)))
+
     def shells(self):
         """PQEq shell displacements spos(natoms,3)"""
         n = self.natoms

@@ -43,3 +43,29 @@ def test_vprocs_parity_vs_mpi_reference(case, steps):
         # re-ordering): same neighbourhood, not the same count; charges and forces above are the gate
         assert abs(o["iters"] - int(g["qeq_iters"][-1])) <= 0.25 * int(g["qeq_iters"][-1])
         assert o["nex"] > 0 and o["nar"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qeq_mode", [0, 1])
+def test_native_rccl_transport_self_loop(qeq_mode, monkeypatch):
+    """The native transport (rccl_comm.hip: ncclSend/ncclRecv/ncclAllReduce on the engine's stream) on ONE GPU: a single rank is
+    pushed through the staged six-stage exchange (RXMD_FORCE_STAGED) and every message through RCCL send/recv to itself
+    (RXMD_FORCE_REMOTE) -- the code path of vprocs > 1 minus the wire.  Must reproduce the single-rank oracle trajectory."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_api as oa
+    from test_gpu_parity import _engine, _oracle, q_err, f_err
+    monkeypatch.setenv("RXMD_FORCE_STAGED", "1")
+    monkeypatch.setenv("RXMD_FORCE_REMOTE", "1")
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    e = _engine("rdx222", (2, 2, 2), qeq_mode=qeq_mode, **kw)
+    e.init_rccl(e.rccl_unique_id(), 0, 1)
+    o = _oracle("rdx222", (2, 2, 2), **kw)
+    e.QEq(); e.FORCE(); o.qeq(); o.force()
+    e.step(3); o.step(3)
+    a = e.atoms()
+    assert np.array_equal(a["gid"], o.gids())
+    assert q_err(a["q"], o.charges()) <= 1e-6
+    assert f_err(a["f"], o.forces()) <= 1e-6
+    assert np.abs(a["pos"] - o.pos()).max() <= 1e-9
+    e.close()
