@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--qeq-mode", type=int, default=1, help="1: one matrix pass per CG iteration (gradient by recurrence; default), 0: the reference's two passes")
     ap.add_argument("--alt-steps", type=int, default=3, help="after the timed region, time this many steps in the other qeq_mode and report them under \"alt\" (0 = skip)")
+    ap.add_argument("--workload", default="rdx", choices=["rdx", "water", "sicnp"],
+                    help="rdx: BASELINE configs[1]/[3] (headline); water: configs[2], perturbed ice Ih 60x35x40 = 2,016,000 atoms; "
+                         "sicnp: configs[4], SiC nanoparticle + O2 with PQEq, 547-atom cell replicated --cells (default 12) per edge")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent periodic replicas instead of one decomposed box")
     a = ap.parse_args()
 
@@ -95,23 +98,50 @@ def main():
         else:
             dist.init_process_group(backend)
     vp = vprocs_for(world)
-    mc = tuple(a.cells * v for v in vp)
 
-    ff = os.path.join(INP, "ffield_rdx")
-    names, frac, lat = system.read_xyz(os.path.join(INP, "rdx.xyz"))
+    pqeq = None
+    if a.workload == "rdx":
+        ff = os.path.join(INP, "ffield_rdx")
+        names, frac, lat = system.read_xyz(os.path.join(INP, "rdx.xyz"))
+        cells = (a.cells,) * 3
+        wname = "RDX %dx%dx%d cells per GPU" % cells
+    elif a.workload == "water":
+        # BASELINE configs[2] / SURVEY 8d C3: conf/init.water/ice-1h.xyz holds REAL coordinates with exactly collinear
+        # O-H...O triples (NaN in the reference): Gaussian kick sigma 0.02 A, numpy default_rng(12345)
+        import numpy as np
+        ff = os.path.join(INP, "ffield_water")
+        lines = open(os.path.join(INP, "ice-1h_real.xyz")).read().split("\n")
+        n0 = int(lines[0].split()[0]); lat = [float(x) for x in lines[1].split()[:6]]
+        rng = np.random.default_rng(12345)
+        names, frac = [], []
+        for l in lines[2:2 + n0]:
+            e, x, y, z = l.split()[:4]
+            r = np.array([float(x), float(y), float(z)]) + rng.normal(0.0, 0.02, 3)
+            names.append(e); frac.append(r / np.array(lat[:3]))
+        frac = np.array(frac)
+        cells = (60, 35, 40) if a.cells == ATOMS_PER_GPU_CELLS else (a.cells,) * 3
+        wname = "perturbed ice Ih %dx%dx%d cells per GPU" % cells
+    else:
+        ff = os.path.join(INP, "ffield_sicnp")
+        names, frac, lat = system.read_xyz(os.path.join(INP, "sicnp.xyz"))
+        pqeq = os.path.join(INP, "pqeq_sicnp.in")
+        c = 12 if a.cells == ATOMS_PER_GPU_CELLS else a.cells
+        cells = (c, c, c)
+        wname = "SiC nanoparticle + O2 (conf/init.sicnp) %dx%dx%d cells per GPU, PQEq" % cells
+    mc = tuple(cells[i] * vp[i] for i in range(3))
     cfg = system.parse_rxmd_in(os.path.join(INP, "rxmd.in"))
-    # weak scaling (BASELINE configs[3]): the box is a.cells*vprocs unit cells per edge, every rank owns one 18^3-cell
-    # domain of the reference's vprocs grid; ghost atoms, QEq vector halos, force return and migration travel through the
-    # engine's six-stage exchange over RCCL (torch.distributed "nccl"), scalars through small all-reduces.
+    # weak scaling (BASELINE configs[3]): the box is cells*vprocs unit cells per edge, every rank owns one domain of the
+    # reference's vprocs grid; ghost atoms, QEq vector halos, force return and migration travel through the engine's
+    # six-stage exchange, scalars through small all-reduces.
     transport_mode = None
     if use_dist and not a.replicas:
         mc_local, vp_local, myid = mc, vp, rank
     else:
-        mc_local, vp_local, myid = (a.cells,) * 3, (1, 1, 1), 0
+        mc_local, vp_local, myid = cells, (1, 1, 1), 0
     lat_super, rec = system.geninit(ff, names, frac, lat, mc=mc_local, vprocs=vp_local, myid=myid)
     natoms = len(rec)
     eng = rxmd_amd.RxmdEngine(ff, lat_super, vprocs=vp_local, myid=myid, isQEq=cfg["isQEq"], NMAXQEq=cfg["NMAXQEq"], QEq_tol=cfg["QEq_tol"],
-                              qstep=cfg["qstep"], dt_fs=cfg["dt"], device=local, qeq_mode=a.qeq_mode)
+                              qstep=cfg["qstep"], dt_fs=cfg["dt"], device=local, qeq_mode=a.qeq_mode, pqeq=pqeq)
     if use_dist and not a.replicas:
         from rxmd_amd.comm import TorchTransport
         dev = torch.device("cuda", local)
@@ -215,11 +245,12 @@ def main():
         # per-atom-step byte model of SURVEY 8d evaluated with the measured n10, nb, K
         b_step = n10 * 12 + 40 + iters * (2 * n10 * 12 + 112) + n10 * 4 + 64 + nb * 104 * 5
         out = {
-            "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; aggregate over GPUs of per-GPU domains)",
+            "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; aggregate over GPUs of per-GPU domains)" if a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS
+                      else "MD steps/sec (%s, %d atoms/GPU; aggregate over GPUs of per-GPU domains)" % (a.workload, natoms),
             "value": steps_per_s * world, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (RDX unit cell of the reference's conf/init.rdx replicated; v0=0, q0=0)",
-            "config": {"workload": "RDX %dx%dx%d cells per GPU = %d atoms/GPU, QEq tol %g, dt %g fs, mdmode 1 (NVE)" % (a.cells, a.cells, a.cells, natoms, cfg["QEq_tol"], cfg["dt"]),
+            "data": "synthetic (unit cell of the reference's conf/init.%s replicated; v0=0, q0=0)" % ("rdx" if a.workload == "rdx" else a.workload),
+            "config": {"workload": "%s = %d atoms/GPU, QEq tol %g, dt %g fs, mdmode 1 (NVE)" % (wname, natoms, cfg["QEq_tol"], cfg["dt"]),
                        "atoms_total": natoms * world, "parallelism": "1 GPU" if world == 1 else ("%d independent replicas" % world if a.replicas else
                                        "vprocs %dx%dx%d domain decomposition, six-stage halo, %s" % (vp[0], vp[1], vp[2], transport_mode)),
                        "qeq_mode": a.qeq_mode},
@@ -234,7 +265,7 @@ def main():
         }
         if alt:
             out["alt"] = alt
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.workload == "rdx":
             cb = cpu_baseline()
             if cb:
                 out["cpu_baseline"] = cb
