@@ -44,6 +44,8 @@ CASES = {
     "rdx168_noqeq":  ("rdx.xyz", "ffield_rdx", (1, 1, 1), ["--isQEq", "0"], 0),
     "rdx168_md10":   ("rdx.xyz", "ffield_rdx", (1, 1, 1), [], 10),
     "rdx222_tight":  ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
+    # extended-Lagrangian charges (isQEq 2: one CG step per MD step from the fictitious charges, qeq.F90:51-57, main.F90:67-68,98)
+    "rdx168_lex_md10": ("rdx.xyz", "ffield_rdx", (1, 1, 1), ["--isQEq", "2"], 10),
     "rdx222_md5":    ("rdx.xyz", "ffield_rdx", (2, 2, 2), [], 5),
     "ice644_tight":  ("ICE", "ffield_water", (6, 4, 4), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
     # PQEq (pqeq.F90): SiC nanoparticle in O2, conf/init.sicnp, polarizable shells; the --pqeq file is copied next to the run

@@ -330,3 +330,18 @@ def test_stress_accumulators_match_the_oracle():
     assert np.abs(a1 - b1).max() <= 1e-8 * np.abs(b1).max()
     assert np.abs(e.energy()["astr"]).max() == 0.0      # reading resets
     e.close()
+
+
+@pytest.mark.parametrize("qeq_mode", [0, 1])
+def test_extended_lagrangian_charges_isQEq2(qeq_mode):
+    """isQEq = 2: one CG step per MD step from qs = fqs*qsfp + (1-fqs)*q (qeq.F90:51-57); the fictitious charges are
+    integrated with the atoms (main.F90:67-68,98).  10 steps against the real reference's dump."""
+    g = np.load(os.path.join(oa.GOLD, "rdx168_lex_md10.npz"))
+    e = _engine("rdx168", (1, 1, 1), isQEq=2, qeq_mode=qeq_mode)
+    e.QEq(); e.FORCE(); e.step(10)
+    a = e.atoms()
+    o = np.argsort(a["gid"]); go = np.argsort(g["gid"])
+    assert np.abs(a["pos"][o] - g["pos"][go]).max() <= 1e-9
+    assert q_err(a["q"][o], g["charge"][go]) <= QTOL
+    assert f_err(a["f"][o], g["force"][go]) <= FTOL
+    e.close()

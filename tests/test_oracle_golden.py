@@ -157,3 +157,10 @@ def test_pressure_column_of_the_mdstep_line():
         ss = a[:3].sum() / 3.0 / o.mdbox() * USTRS
         assert abs(ss - g["mdstep"][row][11]) <= 0.0051, (row, ss, g["mdstep"][row][11])
         o.step(1)
+
+
+def test_extended_lagrangian_charges_isQEq2():
+    """isQEq = 2 (qeq.F90:51-57,66; main.F90:67-68,98): one CG step per call from the mixed fictitious charges"""
+    g, o, iters, pe = _run("rdx168_lex_md10", (1, 1, 1), steps=10, isQEq=2)
+    _compare(g, o, ftol=1e-9, qtol=1e-10)
+    assert all(i <= 1 for i in iters)
