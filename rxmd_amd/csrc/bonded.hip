@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
                                               double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   double e10 = 0.0;
   if (i < N) {
     const int ti = type[i], cnt = nbrcnt[i];

@@ -79,6 +79,14 @@ struct Grid {       // the engine's own cell grid over [-shell, L+shell) in norm
 
 constexpr int WAVE = 64;
 
+// XCD-aware workgroup order: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2),
+// so without a remap every L2 sees rows from all over the box and re-fetches the whole gather vector.  With it the
+// workgroups that share an XCD own one contiguous eighth of the rows = one compact region of space (bijective for any grid).
+__device__ inline int xcd_swizzle(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 struct Engine {
   rxmd_config cfg{};
   std::string ffield_path, pqeq_path, err;

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow) {
   extern __shared__ unsigned short srow_all[];       // [4][S10]: the wavefront's row of 16-bit entries, written out as 4-byte words
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
   unsigned short *srow = srow_all + static_cast<size_t>(threadIdx.x >> 6) * S10;
   const int c = cellid[i];

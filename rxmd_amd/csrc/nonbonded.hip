@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_nonbond(int N, int S10, DevFF ff, const
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x < 24) sv[threadIdx.x / 6][threadIdx.x % 6] = 0.0;
   __syncthreads();
-  const int i = blockIdx.x * (blockDim.x >> 6) + w;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
   double e11 = 0.0, e12 = 0.0, e13 = 0.0;
   if (i < N) {
     const double xi = x[i], yi = y[i], zi = z[i], qi = q[i];

@@ -95,10 +95,10 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
                                                const double *__restrict__ scal, double *__restrict__ partials,
                                                double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
-                                               const double *__restrict__ hsc, const double4 *__restrict__ pqrow) {
+                                               const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
-  const int wave0 = blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int wave0 = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * wpb;
   const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -498,11 +498,12 @@ void Engine::qeq() {
   const int cell_bs = 512;
   const int nred = use_cell ? grid.ncell : rb;                                      // partials one matrix pass leaves
   double *lvl1 = partials + static_cast<size_t>(std::max(rb, grid.ncell)) * 4 + 64; // 128 x 4 first-level sums live behind the per-workgroup partials
+  static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg) {
 #define RX_PASS(M, S)                                                                                                                        \
   do {                                                                                                                                       \
     if (use_cell) k_spmv_cell<M, S><<<grid.ncell, cell_bs, lds_bytes, stream>>>(N, S10, grid, dff, cellstart, perm, nb10s, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg); \
-    else k_spmv<M, S><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow);  \
+    else k_spmv<M, S><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }
