@@ -95,6 +95,21 @@ class RxmdEngine:
     def set_velocities(self, v):
         v = np.ascontiguousarray(v, np.float64).reshape(-1, 3); self._chk(self.L.rxmd_hip_set_velocities(self.h, len(v), _ptr(v)))
 
+    def write_xyz(self, path, natoms_total=None):
+        """trajectory frame in the reference's WriteXYZ layout (fileio.F90:241-355); with several ranks every rank writes its part
+        (natoms_total = global count on rank 0, -1 on the others) and the parts are concatenated in rank order"""
+        from . import system
+        a = self.atoms()
+        txt = system.format_xyz(self.lattice, system.ffield_type_names(self._ff.decode()), a["gid"], a["type"], a["pos"], a["q"],
+                                self.shells() if self._pq else None, natoms_total)
+        with open(path, "w") as f:
+            f.write(txt)
+
+    def write_rxff(self, path, current_step=0):
+        """checkpoint in the reference's WriteBIN layout (fileio.F90:558-653), single rank"""
+        from . import system
+        system.write_rxff(path, self.lattice, (1, 1, 1), [self.get_atoms_rxff()], current_step)
+
     # ---- native multi-GPU transport (include/rxmd_hip.h: rxmd_hip_comm_init_rccl) ----
     def rccl_unique_id(self):
         buf = C.create_string_buffer(128); self._chk(self.L.rxmd_hip_rccl_unique_id(buf)); return buf.raw

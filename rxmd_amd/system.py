@@ -64,6 +64,46 @@ def write_rxff(path, lattice, vprocs, recs, current_step=0):
             np.ascontiguousarray(r, np.float64).tofile(fh)
 
 
+def format_xyz(lattice, type_names, gid, types, pos, q, shells=None, natoms_total=None):
+    """One trajectory frame exactly as the reference's WriteXYZ lays it out (src/fileio.F90:241-355): `i9` atom count, the
+    lattice as `3f12.5,3f8.3`, then per atom `a3` name, position, charge, `i9` global id -- `3f12.5` + `f8.3`, or with PQEq
+    `3es20.12` + `es20.12` and the shell displacement `3es20.12` -- so util/ and analysis tools of rxmd read it unchanged.
+    type_names[t] is the ffield element name of type t (1-based).  Returns the text; ranks concatenate in rank order."""
+    n = len(gid) if natoms_total is None else natoms_total
+    out = []
+    if natoms_total is None or natoms_total >= 0:
+        out.append("%9d\n" % n)
+        out.append("%12.5f%12.5f%12.5f%8.3f%8.3f%8.3f\n" % tuple(lattice[:6]))
+    for i in range(len(gid)):
+        nm = " " + type_names[int(types[i])][:2].ljust(2)            # a3 of a character(2) name: right-justified
+        if shells is None:
+            out.append("%s%12.5f%12.5f%12.5f%8.3f%9d\n" % (nm, pos[i][0], pos[i][1], pos[i][2], q[i], gid[i]))
+        else:
+            out.append("%s%20.12E%20.12E%20.12E%20.12E%9d%20.12E%20.12E%20.12E\n" % (nm, pos[i][0], pos[i][1], pos[i][2], q[i], gid[i],
+                                                                                   shells[i][0], shells[i][1], shells[i][2]))
+    return "".join(out)
+
+
+def ffield_type_names(ffield):
+    """element names of the ffield atom types, 1-based list (index 0 unused) -- the reference's atmname (param.F90:103)"""
+    L = _lib.load()
+    out = np.zeros(4096)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = L.rxmd_host_ffield_table(str(ffield).encode(), None, 6, p(out), len(out))
+    if rc < 0:
+        raise RuntimeError("cannot parse %s" % ffield)
+    nso = int(out[0])
+    names = [""]
+    lines = open(ffield).read().split("\n")
+    npar = int(lines[1].split()[0])
+    base = 2 + npar
+    nso2 = int(lines[base].split()[0])
+    assert nso2 == nso
+    for t in range(nso):
+        names.append(lines[base + 4 + 4 * t].split()[0])
+    return names
+
+
 def parse_rxmd_in(path):
     """keywords of rxmd.in (src/cmdline.F90:255-297); unknown keyword = error, as in the reference"""
     out = {}

@@ -178,6 +178,10 @@ def make(name):
         d["mdstep"] = parse_mdstep(outB)
         if name.startswith("ice"):
             d["input_xyz"] = np.array(open(os.path.join(tmp, "input.xyz")).read())
+        if name in ("rdx168_md10", "sicnp547_pqeq_md5"):
+            # the reference's own trajectory frame of the last step (OUTPUT -> WriteXYZ, fileio.F90:241-355): output data, kept as text
+            outC = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(nsteps), "--pstep", "1", "--fstep", str(nsteps)] + flags, tmp)
+            d["xyz_last"] = np.array(open(os.path.join(tmp, "DAT", "%09d.xyz" % nsteps)).read())
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         print(name, "natoms", len(gid), "qeq_iters", d.get("qeq_iters"), "PE/atom", d["mdstep"][0][2] if len(d["mdstep"]) else None)
     finally:

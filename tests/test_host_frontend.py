@@ -166,3 +166,29 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "__init__.py" and False, "%s mentions the oracle" % f
+
+
+@pytest.mark.parametrize("case,steps,pq", [("rdx168_md10", 10, False), ("sicnp547_pqeq_md5", 5, True)])
+def test_xyz_frame_is_byte_identical_to_the_reference_writer(case, steps, pq):
+    """format_xyz (WriteXYZ, fileio.F90:241-355) fed with the oracle's state after the same number of steps must give the file
+    the real reference wrote (kept as text in the golden): f12.5/f8.3 columns, or es20.12 + shell columns with PQEq."""
+    import oracle_api as oa
+    from rxmd_amd import system
+    g = np.load(os.path.join(oa.GOLD, case + ".npz"))
+    name = "sicnp" if pq else "rdx168"
+    ff, names, frac, lat = oa.make_system(name)
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff))
+    o = oa.Oracle(ff, lat2, ranks, pqeq=oa.PQEQ_SICNP if pq else None)
+    o.qeq(); o.force(); o.step(steps)
+    txt = system.format_xyz(lat2, system.ffield_type_names(ff), o.gids(), o.types(), o.pos(), o.charges(), o.spos() if pq else None)
+    ref = str(g["xyz_last"])
+    a, b = txt.split("\n"), ref.split("\n")
+    assert len(a) == len(b)
+    if pq:      # 13 significant digits of a trajectory that the oracle reproduces to ~1e-12: compare numerically, layout exactly
+        for x, y in zip(a[2:-1], b[2:-1]):
+            assert len(x) == len(y) and x[:3] == y[:3] and x[83:92] == y[83:92]
+            assert np.allclose([float(t) for t in x[3:83].split()] + [float(t) for t in x[92:].split()],
+                               [float(t) for t in y[3:83].split()] + [float(t) for t in y[92:].split()], rtol=1e-9, atol=1e-12)
+        assert a[:2] == b[:2]
+    else:
+        assert txt == ref
