@@ -94,6 +94,12 @@ int rxmd_hip_force(rxmd_handle h, double pe[14]);
  * QEq every qstep, FORCE, vkick); mdmode 1 (NVE).  Call rxmd_hip_qeq + rxmd_hip_force once before
  * the first step, as main.F90:27-32 does. */
 int rxmd_hip_step(rxmd_handle h, int nsteps);
+/* The velocity scaling the reference's MD loop applies at its head when mod(nstep,sstep)==0 (src/main.F90:45-61), on the
+ * device: mdmode 4 (v *= vsfact), 5 (rescale to treq_K; gke_per_atom = kinetic energy per atom of the last PRINTE, <= 0: the
+ * current one), 7 (per element, ScaleTemperature :722-763), 8 (only beyond 5 %, AdjustTemperature :684-719); 7 and 8 remove the
+ * centre-of-mass momentum afterwards (LinearMomentum :766-797).  The caller keeps the sstep cadence:
+ *   for (n = 0; n < nsteps; n += sstep) { rxmd_hip_thermostat(h, mdmode, treq, vsfact, -1); rxmd_hip_step(h, sstep); } */
+int rxmd_hip_thermostat(rxmd_handle h, int mdmode, double treq_K, double vsfact, double gke_per_atom);
 /* PRINTE reductions (src/main.F90:210-274) for this rank: ke = sum hmas*v^2, qsum, pe[14], and the stress accumulators
  * astr[6] = (xx,yy,zz,yz,zx,xy): virial sum over residents+ghosts of pos*f before the fold (pot.F90:65-72) plus m*v*v of every
  * step (main.F90:86-94), raw sums since the previous read -- passing astr != NULL resets them, as PRINTE does (main.F90:270).

@@ -1734,6 +1734,69 @@ static int md_step(World *W) {
   return 0;
 }
 
+/* ------------------------------------------------------------------ velocity scaling of the MD loop head, src/main.F90:45-61 */
+static const double UTEMP0 = 503.398008, UTEMP = 503.398008 * 2.0 / 3.0;                 /* module.F90:198-199 */
+static void LinearMomentum(World *W) { /* main.F90:766-797 */
+  const Params *P = &W->P;
+  double sb[4][64];
+  for (int p = 0; p < W->nprocs; p++) {
+    Rank *r = &W->R[p];
+    double mm = 0, v0 = 0, v1 = 0, v2 = 0;
+    for (int i = 1; i <= r->NATOMS; i++) { double m = P->mass[r->ity[i]]; v0 += m * VEL(r, i, 0); v1 += m * VEL(r, i, 1); v2 += m * VEL(r, i, 2); mm += m; }
+    sb[0][p] = mm; sb[1][p] = v0; sb[2][p] = v1; sb[3][p] = v2;
+  }
+  double mm = allreduce_sum(sb[0], W->nprocs), vc[3] = {allreduce_sum(sb[1], W->nprocs), allreduce_sum(sb[2], W->nprocs), allreduce_sum(sb[3], W->nprocs)};
+  for (int k = 0; k < 3; k++) vc[k] = vc[k] / mm;
+  for (int p = 0; p < W->nprocs; p++) { Rank *r = &W->R[p]; for (int i = 1; i <= r->NATOMS; i++) for (int k = 0; k < 3; k++) VEL(r, i, k) = VEL(r, i, k) - vc[k]; }
+}
+/* what the loop head does when mod(nstep,sstep)==0: mdmode 4 (v *= vsfact), 5 (rescale to treq; gke = kinetic energy per atom of
+ * the last PRINTE, main.F90:49), 7 (ScaleTemperature :722-763, per element), 8 (AdjustTemperature :684-719, only beyond 5 %).
+ * mdmode 0/6 (INITVELOCITY, random) are not restated. */
+int rxo_thermostat(void *w, int mdmode, double treq_K, double vsfact, double gke) {
+  World *W = (World *)w; const Params *P = &W->P;
+  const double treq = treq_K / UTEMP0;                 /* init.F90:72: the requested temperature is kept in energy units */
+  if (mdmode == 4 || mdmode == 5) {
+    double c = mdmode == 4 ? vsfact : sqrt((treq * UTEMP0) / (gke * UTEMP));
+    for (int p = 0; p < W->nprocs; p++) { Rank *r = &W->R[p]; for (int i = 1; i <= r->NATOMS; i++) for (int k = 0; k < 3; k++) VEL(r, i, k) = c * VEL(r, i, k); }
+    return 0;
+  }
+  if (mdmode == 8) {
+    double ea[64];
+    for (int p = 0; p < W->nprocs; p++) {
+      Rank *r = &W->R[p]; double e = 0;
+      for (int i = 1; i <= r->NATOMS; i++) e = e + 0.5 * P->mass[r->ity[i]] * (VEL(r, i, 0) * VEL(r, i, 0) + VEL(r, i, 1) * VEL(r, i, 1) + VEL(r, i, 2) * VEL(r, i, 2));
+      ea[p] = e;
+    }
+    double Ek = allreduce_sum(ea, W->nprocs) / (double)W->GNATOMS;
+    double c = sqrt((treq * UTEMP0) / (Ek * UTEMP));
+    if (fabs(c - 1.0) > 0.05) {
+      for (int p = 0; p < W->nprocs; p++) { Rank *r = &W->R[p]; for (int i = 1; i <= r->NATOMS; i++) for (int k = 0; k < 3; k++) VEL(r, i, k) = c * VEL(r, i, k); }
+      LinearMomentum(W);
+    }
+    return 0;
+  }
+  if (mdmode == 7) {
+    double cnt[21][64], ek[21][64], c[21];
+    memset(cnt, 0, sizeof cnt); memset(ek, 0, sizeof ek);
+    for (int p = 0; p < W->nprocs; p++) {
+      Rank *r = &W->R[p];
+      for (int i = 1; i <= r->NATOMS; i++) {
+        int t = r->ity[i];
+        cnt[t][p] += 1.0;
+        ek[t][p] += 0.5 * P->mass[t] * (VEL(r, i, 0) * VEL(r, i, 0) + VEL(r, i, 1) * VEL(r, i, 1) + VEL(r, i, 2) * VEL(r, i, 2));
+      }
+    }
+    for (int t = 1; t <= 20; t++) {
+      double n = allreduce_sum(cnt[t], W->nprocs), e = allreduce_sum(ek[t], W->nprocs);
+      if (n > 1.0) { c[t] = e / n; c[t] = sqrt((treq * UTEMP0) / (c[t] * UTEMP)); } else c[t] = 0.0;
+    }
+    for (int p = 0; p < W->nprocs; p++) { Rank *r = &W->R[p]; for (int i = 1; i <= r->NATOMS; i++) for (int k = 0; k < 3; k++) VEL(r, i, k) = c[r->ity[i]] * VEL(r, i, k); }
+    LinearMomentum(W);
+    return 0;
+  }
+  return -1;
+}
+
 /* ------------------------------------------------------------------ setup (INITSYSTEM, src/init.F90:7-288) + C API for the tests */
 static void alloc_rank(World *W, Rank *r, int p, int NBUFFER) {
   memset(r, 0, sizeof(*r));
@@ -1940,6 +2003,8 @@ int rxo_get_bonds(void *w, int rank, int *nbr, double *bo0) {
   }
   return G;
 }
+/* qsfp / qsfv of a restart file (rxff.bin record columns 9-10, fileio.F90:536-537) */
+void rxo_set_lex(void *w, int rank, const double *qsfp, const double *qsfv) { World *W = (World *)w; Rank *r = &W->R[rank]; for (int i = 1; i <= r->NATOMS; i++) { r->qsfp[i] = qsfp[i - 1]; r->qsfv[i] = qsfv[i - 1]; } }
 void rxo_set_charges(void *w, int rank, const double *q) { World *W = (World *)w; Rank *r = &W->R[rank]; for (int i = 1; i <= r->NATOMS; i++) r->q[i] = q[i - 1]; }
 void rxo_set_qeq(void *w, int isQEq, int NMAXQEq, double tol) { World *W = (World *)w; W->isQEq = isQEq; W->NMAXQEq = NMAXQEq; W->QEq_tol = tol; }
 void rxo_destroy(void *w) { (void)w; /* test processes are short-lived; leak on purpose */ }

@@ -17,6 +17,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <vector>
 
 namespace rxmd {
 
@@ -190,6 +191,91 @@ __global__ void k_kick(int N, DevFF ff, double dt, double lex_w2, const int *__r
   const double dthm = dt * 0.5 / ff.atom[type[i]].mass;
   vx[i] = vx[i] + 1.0 * dthm * fx[i]; vy[i] = vy[i] + 1.0 * dthm * fy[i]; vz[i] = vz[i] + 1.0 * dthm * fz[i];
   qsfv[i] = qsfv[i] + 0.5 * dt * lex_w2 * (q[i] - qsfp[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// velocity scaling of the MD loop head (main.F90:45-61; ScaleTemperature :722-763, AdjustTemperature :684-719,
+// LinearMomentum :766-797).  Rare (every sstep steps): per type one masked reduction (count, kinetic energy, momentum, mass)
+// in a fixed order, factors on the host, one scaling kernel.
+__global__ void __launch_bounds__(256) k_type_sums(int n, int tsel, const int *__restrict__ type, DevFF ff, const double *__restrict__ vx, const double *__restrict__ vy,
+                                                    const double *__restrict__ vz, double *__restrict__ partials) {
+  __shared__ double sm[256];
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (type[i] != tsel) continue;
+    const double m = ff.atom[tsel].mass, v0 = vx[i], v1 = vy[i], v2 = vz[i];
+    a[0] += 1.0; a[1] += 0.5 * m * (v0 * v0 + v1 * v1 + v2 * v2); a[2] += m * v0; a[3] += m * v1; a[4] += m * v2; a[5] += m;
+  }
+  for (int c = 0; c < 6; ++c) {
+    sm[threadIdx.x] = a[c];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) partials[blockIdx.x * 6 + c] = sm[0];
+    __syncthreads();
+  }
+}
+__global__ void k_sum6(int nblocks, const double *__restrict__ partials, double *__restrict__ out6) {
+  const int c = threadIdx.x;
+  if (c >= 6) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partials[b * 6 + c];
+  out6[c] = s;
+}
+struct ScaleArgs { double c[16]; double vcm[3]; };
+__global__ void k_scale_velocities(int n, ScaleArgs a, const int *__restrict__ type, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double c = a.c[type[i]];
+  vx[i] = c * vx[i] - a.vcm[0]; vy[i] = c * vy[i] - a.vcm[1]; vz[i] = c * vz[i] - a.vcm[2];
+}
+
+void Engine::thermostat(int mdmode, double treq_K, double vsfact, double gke) {
+  if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
+  if (ff.nso > 15) throw EngineError(RXMD_E_ARG, "more than 15 atom types");
+  const double UTEMP0 = 503.398008, UTEMP = UTEMP0 * 2.0 / 3.0;      // module.F90:198-199
+  const double treq = treq_K / UTEMP0;                               // init.F90:72
+  ScaleArgs sa{};
+  std::vector<double> sums(6 * (ff.nso + 1), 0.0);
+  const bool need_sums = (mdmode == 7 || mdmode == 8 || (mdmode == 5 && gke <= 0.0));
+  if (need_sums) {
+    const int nb = 240;
+    for (int t = 1; t <= ff.nso; ++t) {
+      k_type_sums<<<nb, 256, 0, stream>>>(N, t, type, dff, vel[0], vel[1], vel[2], partials);
+      k_sum6<<<1, 64, 0, stream>>>(nb, partials, scal + 56);
+      RX_HIP(hipMemcpyAsync(sums.data() + 6 * t, scal + 56, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipStreamSynchronize(stream));
+    }
+    if (nprocs > 1) allreduce_host(sums.data(), static_cast<int>(sums.size()));      // MPI_ALLREDUCE, main.F90:699,738,783
+  }
+  double ntot = 0, ektot = 0, mtot = 0;
+  for (int t = 1; t <= ff.nso; ++t) { ntot += sums[6 * t]; ektot += sums[6 * t + 1]; mtot += sums[6 * t + 5]; }
+  bool remove_momentum = false;
+  if (mdmode == 4) { for (int t = 0; t < 16; ++t) sa.c[t] = vsfact; }
+  else if (mdmode == 5) {
+    const double g = gke > 0.0 ? gke : ektot / ntot;                 // GKE of the last PRINTE, main.F90:49,250
+    const double c = std::sqrt((treq * UTEMP0) / (g * UTEMP));
+    for (int t = 0; t < 16; ++t) sa.c[t] = c;
+  } else if (mdmode == 8) {
+    const double c = std::sqrt((treq * UTEMP0) / (ektot / ntot * UTEMP));
+    if (!(std::fabs(c - 1.0) > 0.05)) return;                        // within 5 %: leave the velocities alone (main.F90:704-705)
+    for (int t = 0; t < 16; ++t) sa.c[t] = c;
+    remove_momentum = true;
+  } else if (mdmode == 7) {
+    for (int t = 1; t <= ff.nso; ++t) {
+      const double n = sums[6 * t];
+      sa.c[t] = n > 1.0 ? std::sqrt((treq * UTEMP0) / (sums[6 * t + 1] / n * UTEMP)) : 0.0;   // main.F90:742-751
+    }
+    remove_momentum = true;
+  } else {
+    throw EngineError(RXMD_E_ARG, "thermostat: mdmode must be 4, 5, 7 or 8 (0/6 draw random velocities on the host side)");
+  }
+  if (remove_momentum)                                               // LinearMomentum of the scaled velocities
+    for (int a = 0; a < 3; ++a) {
+      double p = 0.0;
+      for (int t = 1; t <= ff.nso; ++t) p += sa.c[t] * sums[6 * t + 2 + a];
+      sa.vcm[a] = p / mtot;
+    }
+  k_scale_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, sa, type, vel[0], vel[1], vel[2]);
 }
 
 void Engine::step(int nsteps) {

@@ -189,6 +189,10 @@ int rxmd_hip_step(rxmd_handle h, int nsteps) {
   });
 }
 
+int rxmd_hip_thermostat(rxmd_handle h, int mdmode, double treq_K, double vsfact, double gke_per_atom) {
+  return guarded(h, [&](Engine &e) { e.thermostat(mdmode, treq_K, vsfact, gke_per_atom); });
+}
+
 int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], double astr[6]) {
   return guarded(h, [&](Engine &e) {
     if (!e.atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");

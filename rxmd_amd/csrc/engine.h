@@ -165,6 +165,7 @@ struct Engine {
   void force();
   void step(int nsteps);
   void migrate();                  // COPYATOMS(MODE_MOVE)
+  void thermostat(int mdmode, double treq_K, double vsfact, double gke);   // velocity scaling of the MD loop head (assemble.hip)
 
   // pieces (each in its own .hip)
   void setup_after_atoms(const std::vector<long long> &natoms_per_type_global);

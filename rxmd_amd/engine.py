@@ -95,6 +95,10 @@ class RxmdEngine:
     def set_velocities(self, v):
         v = np.ascontiguousarray(v, np.float64).reshape(-1, 3); self._chk(self.L.rxmd_hip_set_velocities(self.h, len(v), _ptr(v)))
 
+    def thermostat(self, mdmode, treq=300.0, vsfact=1.0, gke=-1.0):
+        """velocity scaling of the MD loop head, main.F90:45-61 (mdmode 4, 5, 7, 8); call every sstep steps"""
+        self._chk(self.L.rxmd_hip_thermostat(self.h, int(mdmode), float(treq), float(vsfact), float(gke)))
+
     def write_xyz(self, path, natoms_total=None):
         """trajectory frame in the reference's WriteXYZ layout (fileio.F90:241-355); with several ranks every rank writes its part
         (natoms_total = global count on rank 0, -1 on the others) and the parts are concatenated in rank order"""

@@ -188,6 +188,43 @@ def make(name):
         shutil.rmtree(tmp)
 
 
+THERMO = {   # name: rxmd flags of the restart run (7 steps, thermostat action every 3rd step, PRINTE every step so that GKE is current)
+    "rdx168_thermo4": ["--mdmode", "4", "--vsfact", "0.9"],
+    "rdx168_thermo5": ["--mdmode", "5", "--treq", "300"],
+    "rdx168_thermo7": ["--mdmode", "7", "--treq", "300"],
+    "rdx168_thermo8": ["--mdmode", "8", "--treq", "300"],
+}
+
+
+def make_thermo():
+    """velocity-scaling modes of the MD loop head (main.F90:45-61): 20 NVE steps from rest produce a restart file with
+    velocities (the reference's own DAT/rxff.bin), every mode then continues from it for 7 steps with sstep 3."""
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(INP, "rdx.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(INP, "ffield_rdx"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "1", "1", "1"], tmp)
+        # --isBinary: WriteBIN returns early without it (fileio.F90:585); the real-MPI build on one rank does the file I/O
+        mpi = ["/opt/conda/bin/mpiexec", "-np", "1", os.path.join(REFBIN, "rxmd_mpi")]
+        tight = ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"]     # converged charges: the trajectory is then reproducible to 1e-9
+        run(mpi + ["--ntime_step", "20", "--pstep", "1", "--fstep", "100000", "--isBinary"] + tight, tmp)
+        restart = open(os.path.join(tmp, "DAT", "rxff.bin"), "rb").read()
+        for name, flags in THERMO.items():
+            open(os.path.join(tmp, "DAT", "rxff.bin"), "wb").write(restart)
+            run(mpi + ["--ntime_step", "7", "--pstep", "1", "--fstep", "100000", "--sstep", "3", "--isBinary"] + tight + flags, tmp)
+            gid, typ, pos, frc, chg = parse_rfdump(os.path.join(tmp, "rfdump0.txt"))
+            final = np.frombuffer(open(os.path.join(tmp, "DAT", "rxff.bin"), "rb").read(), np.uint8)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), gid=gid, type=typ, pos=pos, force=frc, charge=chg, flags=np.array(" ".join(flags)),
+                                restart_rxff=np.frombuffer(restart, np.uint8), final_rxff=final)
+            print(name, "natoms", len(gid))
+    finally:
+        shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["thermo"]:
+        make_thermo(); sys.exit(0)
     for n in (sys.argv[1:] or list(CASES)):
         make(n)

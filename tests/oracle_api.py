@@ -152,6 +152,11 @@ class Oracle:
 
     def kinetic(self): return self.L.rxo_kinetic(self.w)
 
+    def thermostat(self, mdmode, treq=300.0, vsfact=1.0, gke=0.0):
+        """the velocity scaling the MD loop head applies when mod(nstep,sstep)==0 (main.F90:45-61); gke = KE per atom of the last PRINTE"""
+        self.L.rxo_thermostat.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        assert self.L.rxo_thermostat(self.w, int(mdmode), float(treq), float(vsfact), float(gke)) == 0
+
     def astr(self, reset=True):
         """stress accumulators astr(1:6) (pot.F90:65-72 virial + main.F90:86-94 kinetic), reset like PRINTE"""
         a = np.zeros(6); self.L.rxo_get_astr.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -179,6 +184,36 @@ class Oracle:
         nbr = np.zeros((G, 30), np.int32); bo = np.zeros((G, 30))
         self.L.rxo_get_bonds(self.w, rank, nbr.ctypes.data_as(C.c_void_p), bo.ctypes.data_as(C.c_void_p))
         return nbr, bo
+
+
+def parse_rxff(buf):
+    """rxff.bin bytes (WriteBIN, src/fileio.F90:558-653) -> (lattice, vprocs, step, [records (n,10) per rank])"""
+    b = bytes(buf)
+    npr = int(np.frombuffer(b[:4], np.int32)[0])
+    head = np.frombuffer(b[:4 * (4 + npr + 1)], np.int32)
+    vp = tuple(int(x) for x in head[1:4]); nat = [int(x) for x in head[4:4 + npr]]; step = int(head[4 + npr])
+    o = 4 * (4 + npr + 1)
+    lat = [float(x) for x in np.frombuffer(b[o:o + 48], np.float64)]; o += 48
+    recs = []
+    for n in nat:
+        recs.append(np.frombuffer(b[o:o + 80 * n], np.float64).reshape(n, 10).copy()); o += 80 * n
+    return lat, vp, step, recs
+
+
+def oracle_from_rxff(ffield, buf, **kw):
+    """an Oracle started from a restart file exactly as ReadBIN would (src/fileio.F90:444-555)"""
+    lat, vp, step, recs = parse_rxff(buf)
+    ranks, q0, v0 = [], [], []
+    for r in recs:
+        ty = np.rint(r[:, 7]).astype(np.int32)
+        gid = np.rint((r[:, 7] - ty) * 1e13).astype(np.int64)
+        ranks.append(dict(rnorm=r[:, 0:3].copy(), type=ty, gid=gid)); q0.append(r[:, 6].copy()); v0.append(r[:, 3:6].copy())
+    o = Oracle(ffield, lat, ranks, vprocs=vp, q0=q0, v0=v0, **kw)
+    o.L.rxo_set_lex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    for p, r in enumerate(recs):
+        a = np.ascontiguousarray(r[:, 8]); b = np.ascontiguousarray(r[:, 9])
+        o.L.rxo_set_lex(o.w, p, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+    return o, recs, lat
 
 
 def make_system(case):

@@ -345,3 +345,26 @@ def test_extended_lagrangian_charges_isQEq2(qeq_mode):
     assert q_err(a["q"][o], g["charge"][go]) <= QTOL
     assert f_err(a["f"][o], g["force"][go]) <= FTOL
     e.close()
+
+
+@pytest.mark.parametrize("mode,kw", [(4, dict(vsfact=0.9)), (5, dict(treq=300.0)), (7, dict(treq=300.0)), (8, dict(treq=300.0))])
+def test_velocity_scaling_modes_from_a_restart_file(mode, kw):
+    """mdmode 4/5/7/8 on the device (rxmd_hip_thermostat) continued from the reference's own restart file (rxff.bin after 20 NVE
+    steps, loaded with set_atoms_rxff), 7 steps with sstep 3, against the reference's dump of the last step"""
+    import rxmd_amd
+    g = np.load(os.path.join(oa.GOLD, "rdx168_thermo%d.npz" % mode))
+    ff = oa.make_system("rdx168")[0]
+    lat, vp, step, recs = oa.parse_rxff(g["restart_rxff"])
+    e = rxmd_amd.RxmdEngine(ff, lat, QEq_tol=1e-12, NMAXQEq=2000)
+    e.set_atoms_rxff(recs[0])
+    e.QEq(); e.FORCE()
+    for nstep in range(7):
+        if nstep % 3 == 0:
+            e.thermostat(mode, **kw)
+        e.step(1)
+    a = e.atoms()
+    o = np.argsort(a["gid"]); go = np.argsort(g["gid"])
+    assert np.abs(a["pos"][o] - g["pos"][go]).max() <= 1e-9
+    assert q_err(a["q"][o], g["charge"][go]) <= QTOL
+    assert f_err(a["f"][o], g["force"][go]) <= FTOL
+    e.close()

@@ -164,3 +164,19 @@ def test_extended_lagrangian_charges_isQEq2():
     g, o, iters, pe = _run("rdx168_lex_md10", (1, 1, 1), steps=10, isQEq=2)
     _compare(g, o, ftol=1e-9, qtol=1e-10)
     assert all(i <= 1 for i in iters)
+
+
+@pytest.mark.parametrize("mode,kw", [(4, dict(vsfact=0.9)), (5, dict(treq=300.0)), (7, dict(treq=300.0)), (8, dict(treq=300.0))])
+def test_velocity_scaling_modes_from_a_restart_file(mode, kw):
+    """mdmode 4/5/7/8 (main.F90:45-61, ScaleTemperature, AdjustTemperature, LinearMomentum): 7 steps with sstep 3 continued from the
+    reference's own restart file (20 NVE steps), against the reference's dump of the last step"""
+    g = np.load(os.path.join(GOLD, "rdx168_thermo%d.npz" % mode))
+    ff = oa.make_system("rdx168")[0]
+    o, recs, lat = oa.oracle_from_rxff(ff, g["restart_rxff"], QEq_tol=1e-12, NMAXQEq=2000)
+    o.qeq(); o.force()
+    n = len(recs[0])
+    for nstep in range(7):
+        if nstep % 3 == 0:
+            o.thermostat(mode, gke=o.kinetic() / n, **kw)
+        o.step(1)
+    _compare(g, o, ftol=1e-8, qtol=1e-10)
