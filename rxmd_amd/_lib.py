@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "librxmd_hip.so")
+SO_PATH = os.environ.get("RXMD_HIP_LIB") or os.path.join(HERE, "librxmd_hip.so")     # RXMD_HIP_LIB: A/B builds of the same library
 
 
 class RxmdConfig(C.Structure):

@@ -140,7 +140,16 @@ __device__ inline void wave_lds_sync() {
 constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages in LDS (MAXNEIGHBS = 30; slot 31 = the centre atom itself)
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+// occupancy knobs, measured on MI355X (bonded section of the step, ms): E3b at 1/2/3/4 workgroups per CU = 22.5/20.4/22.4/22.9
+// (256 VGPRs + 3 AGPRs miss the 2-wave budget by three registers without the hint; beyond 2 the spills cost more than
+// the occupancy buys), E4b at 2/3 = 21.3/20.4
+#ifndef E3B_MINB
+#define E3B_MINB 2
+#endif
+#ifndef E4B_MINB
+#define E4B_MINB 3
+#endif
+__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
                                               const double *__restrict__ delta, const double *__restrict__ nlp, const double *__restrict__ dDlp,
@@ -267,7 +276,7 @@ __global__ void __launch_bounds__(256) k_e3b(int N, int NB, DevFF ff, const int 
 // gid(j) < gid(k) (the reference's orientation, which the index-ordered ccbnd rule depends on), the forces on i and j and
 // the i-j bond coefficient always; the k/l side is booked when atom k is the centre.  Per-bond sums are formed by each
 // owner lane scanning the 64 results in queue order: no atomics, scheduling-independent.
-__global__ void __launch_bounds__(256, 3) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+__global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
                                               const double *__restrict__ etor, const double *__restrict__ econ,
