@@ -32,7 +32,8 @@ module rxmd_hip_mod
      integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode
      integer(c_int) :: reserved0
      type(c_ptr)    :: pqeq_path
-     integer(c_int) :: reserved(4)
+     integer(c_int) :: efield_dir, reserved1
+     real(c_double) :: efield_strength
   end type
 
   type(c_ptr), save :: rxmd_hip_handle = c_null_ptr

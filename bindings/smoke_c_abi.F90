@@ -13,7 +13,8 @@ program smoke_c_abi
      real(c_double) :: dt_fs, Lex_fqs, Lex_k
      integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode, reserved0
      type(c_ptr) :: pqeq_path
-     integer(c_int) :: reserved(4)
+     integer(c_int) :: efield_dir, reserved1
+     real(c_double) :: efield_strength
   end type
   interface
      subroutine rxmd_hip_default_config(cfg) bind(c, name='rxmd_hip_default_config')

@@ -59,7 +59,12 @@ typedef struct rxmd_config {
   int reserved0;
   const char *pqeq_path;   /* --pqeq / rxmd.in PQEqParm (cmdline.F90:112-128,291-293): NULL = plain QEq.  Switches the charge solver to
                               PQEq (pqeq.F90), the nonbonded term to ENbond_PQEq (pot.F90:784-923) and the taper cutoff to 12.5 A */
-  int reserved[4];
+  int efield_dir;          /* rxmd.in `efield <dir> <strength>` / --efield (cmdline.F90:131-137,286-289): 0 = off, 1..3 = x,y,z; PQEq only */
+  int reserved1;
+  double efield_strength;  /* [V/A]: force -(q_i + Z_i) E Eev_kcal on every core (module.F90:359-383), -Z_i E Eev_kcal on every shell (pqeq.F90:205),
+                              centre-of-mass momentum removed every step (main.F90:70-71).  NOTE the reference's EEfield addresses
+                              its force array with the wrong leading extent, so for dir > 1 it pushes the x component of ghost slots;
+                              the engine applies the field to atom i along dir, which equals the reference for dir = 1 */
 } rxmd_config;
 
 void rxmd_hip_default_config(rxmd_config *cfg);

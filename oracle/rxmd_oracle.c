@@ -75,6 +75,7 @@ typedef struct {
   double UDR, UDRi, rctap, rctap2, CTap[8];
   /* PQEq (module.F90:286-303, cmdline.F90:160-235): per type 1..ntype_pqeq; pair arrays [(ity)*(ntype_pqeq+1)+jty] */
   int isPQEq, ntype_pqeq, *isPolarizable, *inxnpqeq;
+  int isEfield, eFieldDir; double eFieldStrength;    /* --efield dir strength (cmdline.F90:131-137); used with PQEq (needs Zpqeq) */
   int pq_clean;   /* 0 = the reference's behaviour beyond the cutoff (outputs keep the previous pair's values); 1 = outputs zeroed */
   double *X0pqeq, *J0pqeq, *Zpqeq, *Rcpqeq, *Rspqeq, *Kspqeq, *alphacc, *alphasc, *alphass;
   double *TBL_Eclmb_pcc, *TBL_Eclmb_psc, *TBL_Eclmb_pss;   /* [inxn][i][0:1], i in 0..NTABLE+1 (i = 0 is outside the Fortran array) */
@@ -801,6 +802,7 @@ static int QEq(World *W) {
 /* ================================================================== PQEq, src/pqeq.F90 + module.F90:386-611 */
 #define PQ2(a, i, j) ((a)[(i) * (P->ntype_pqeq + 1) + (j)])
 #define PQT(T, inxn, i, d) ((T)[((size_t)(inxn) * (NTABLE + 2) + (i)) * 2 + (d)])
+static const double Eev_kcal = 23.060538;                           /* module.F90:191 */
 static const double lambda_pqeq = 0.462770;                         /* module.F90:298 */
 static const double rctap0_pqeq = 12.5;                             /* module.F90:282 */
 
@@ -1009,6 +1011,7 @@ static void pq_update_shells(World *W, Rank *r, long long *nstale) {
   for (int i = 1; i <= n; i++) {
     int ity = r->ity[i];
     if (!P->isPolarizable[ity]) continue;
+    if (P->isEfield) sforce[3 * i + P->eFieldDir - 1] = sforce[3 * i + P->eFieldDir - 1] - P->Zpqeq[ity] * P->eFieldStrength * Eev_kcal;   /* pqeq.F90:205 */
     for (int k = 0; k < 3; k++) sforce[3 * i + k] = sforce[3 * i + k] - P->Kspqeq[ity] * SPOS(r, i, k);
     double shelli[3] = {POS(r, i, 0) + SPOS(r, i, 0), POS(r, i, 1) + SPOS(r, i, 1), POS(r, i, 2) + SPOS(r, i, 2)};
     for (int j1 = 1; j1 <= NBP(r, i, 0); j1++) {
@@ -1697,6 +1700,18 @@ static int FORCE(World *W) { /* pot.F90:2-90 */
     BOPRIM(W, r); BOFULL(W, r);
     if (W->P.isPQEq) ENbond_PQEq(W, r); else ENbond(W, r);      /* pot.F90:48-52 */
     Ebond(W, r); Elnpr(W, r); Ehb(W, r); E3b(W, r); E4b(W, r);
+    if (W->P.isEfield)                                 /* EEfield, module.F90:359-383, pot.F90:61 */
+      for (int i = 1; i <= r->NATOMS; i++) {
+        double qic = r->q[i] + W->P.Zpqeq[r->ity[i]];
+        double Eforce = -qic * W->P.eFieldStrength * Eev_kcal;
+        if (W->P.pq_clean) { FRC(r, i, W->P.eFieldDir - 1) += Eforce; continue; }
+        /* EEfield declares f(NATOMS,3) but receives f(NBUFFER,3) (module.F90:363 vs pot.F90:61): by sequence association its
+         * f(i,dir) is element (dir-1)*NATOMS + i of the caller's storage, i.e. for dir > 1 the x component of a GHOST slot,
+         * which the CPBK fold then adds to that ghost's owner.  Restated as it executes. */
+        size_t lin = (size_t)(W->P.eFieldDir - 1) * r->NATOMS + (i - 1);          /* 0-based offset in f(NBUFFER,3) of the caller */
+        size_t NBf = (size_t)r->NBUFFER;                                          /* the caller's first extent (create the oracle with the reference's NBUFFER, module.F90:80) */
+        FRC(r, (int)(lin % NBf) + 1, (int)(lin / NBf)) += Eforce;
+      }
     ForceBondedTerms(r);
     for (int i = 1; i < r->NBUFFER; i++) {             /* virial, pot.F90:65-72 */
       r->astr[0] += POS(r, i, 0) * FRC(r, i, 0); r->astr[1] += POS(r, i, 1) * FRC(r, i, 1); r->astr[2] += POS(r, i, 2) * FRC(r, i, 2);
@@ -1707,6 +1722,7 @@ static int FORCE(World *W) { /* pot.F90:2-90 */
   return COPYATOMS(W, MODE_CPBK, z);
 }
 
+static void LinearMomentum(World *W);
 /* one pass of the MD loop body, src/main.F90:64-98 (mdmode 1 = NVE; thermostats are out of the path) */
 static int md_step(World *W) {
   const Params *P = &W->P;
@@ -1715,6 +1731,10 @@ static int md_step(World *W) {
     for (int i = 1; i <= r->NATOMS; i++) for (int k = 0; k < 3; k++) VEL(r, i, k) = VEL(r, i, k) + 1.0 * W->dthm[r->ity[i]] * FRC(r, i, k); /* vkick, :192-207 */
     for (int i = 1; i <= r->NATOMS; i++) r->qsfv[i] = r->qsfv[i] + 0.5 * W->dt * W->Lex_w2 * (r->q[i] - r->qsfp[i]);
     for (int i = 1; i <= r->NATOMS; i++) r->qsfp[i] = r->qsfp[i] + W->dt * r->qsfv[i];
+  }
+  if (P->isEfield) LinearMomentum(W);                  /* main.F90:70-71 */
+  for (int p = 0; p < W->nprocs; p++) {
+    Rank *r = &W->R[p];
     for (int i = 1; i <= r->NATOMS; i++) for (int k = 0; k < 3; k++) POS(r, i, k) = POS(r, i, k) + W->dt * VEL(r, i, k);
   }
   double z[3] = {0, 0, 0};
@@ -1866,6 +1886,8 @@ int rxo_enable_pqeq(void *w, const char *pqeq_path) {
   initialize_pqeq(P);
   return 0;
 }
+/* --efield dir strength [V/A] (cmdline.F90:131-137); dir = 1,2,3 */
+void rxo_set_efield(void *w, int dir, double strength) { World *W = (World *)w; W->P.isEfield = 1; W->P.eFieldDir = dir; W->P.eFieldStrength = strength; }
 long long rxo_pqeq_stale(void *w) { return ((World *)w)->pq_stale; }
 /* clean = 1: a lookup beyond the cutoff yields zero (what the HIP engine does) instead of the previous pair's values */
 void rxo_set_pqeq_clean(void *w, int clean) { ((World *)w)->P.pq_clean = clean; }

@@ -15,7 +15,7 @@ class RxmdConfig(C.Structure):
                 ("isQEq", C.c_int), ("NMAXQEq", C.c_int), ("QEq_tol", C.c_double), ("qstep", C.c_int), ("dt_fs", C.c_double),
                 ("Lex_fqs", C.c_double), ("Lex_k", C.c_double), ("nbuffer", C.c_int), ("maxneighbs", C.c_int),
                 ("maxneighbs10", C.c_int), ("device", C.c_int), ("qeq_mode", C.c_int), ("reserved0", C.c_int),
-                ("pqeq_path", C.c_char_p), ("reserved", C.c_int * 4)]
+                ("pqeq_path", C.c_char_p), ("efield_dir", C.c_int), ("reserved1", C.c_int), ("efield_strength", C.c_double)]
 
 
 class RxmdStats(C.Structure):

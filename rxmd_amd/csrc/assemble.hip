@@ -149,6 +149,7 @@ void Engine::force() {
   if (ff.pqeq) nonbonded_pqeq(); else nonbonded();     // pot.F90:48-52
   hipEventRecord(ev[4], stream);
   bonded_energies();
+  if (ff.pqeq) efield_force();                         // pot.F90:61, before ForceBondedTerms
   assemble_forces();
   accumulate_stress(false);                            // pot.F90:65-72, before the ghost forces are folded back
   fold_ghost_forces();
@@ -278,12 +279,47 @@ void Engine::thermostat(int mdmode, double treq_K, double vsfact, double gke) {
   k_scale_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, sa, type, vel[0], vel[1], vel[2]);
 }
 
+__global__ void k_drift(int N, double dt, const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ vz,
+                        double *__restrict__ x, double *__restrict__ y, double *__restrict__ z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  x[i] = x[i] + dt * vx[i]; y[i] = y[i] + dt * vy[i]; z[i] = z[i] + dt * vz[i];
+}
+__global__ void k_lex_drift(int N, double dt, double *__restrict__ qsfp, const double *__restrict__ qsfv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) qsfp[i] = qsfp[i] + dt * qsfv[i];
+}
+
+void Engine::remove_momentum() {
+  ScaleArgs sa{};
+  std::vector<double> sums(6 * (ff.nso + 1), 0.0);
+  const int nb = 240;
+  for (int t = 1; t <= ff.nso; ++t) {
+    k_type_sums<<<nb, 256, 0, stream>>>(N, t, type, dff, vel[0], vel[1], vel[2], partials);
+    k_sum6<<<1, 64, 0, stream>>>(nb, partials, scal + 56);
+    RX_HIP(hipMemcpyAsync(sums.data() + 6 * t, scal + 56, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipStreamSynchronize(stream));
+  }
+  if (nprocs > 1) allreduce_host(sums.data(), static_cast<int>(sums.size()));
+  double mtot = 0.0, p[3] = {0, 0, 0};
+  for (int t = 1; t <= ff.nso; ++t) { mtot += sums[6 * t + 5]; for (int a = 0; a < 3; ++a) p[a] += sums[6 * t + 2 + a]; }
+  for (int t = 0; t < 16; ++t) sa.c[t] = 1.0;
+  for (int a = 0; a < 3; ++a) sa.vcm[a] = p[a] / mtot;
+  k_scale_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, sa, type, vel[0], vel[1], vel[2]);
+}
+
 void Engine::step(int nsteps) {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   for (int s = 0; s < nsteps; ++s) {
     tic(0);
     hipEventRecord(ev[0], stream);
-    k_kick_drift<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], pos[0], pos[1], pos[2], q, qsfp, qsfv);
+    if (cfg.efield_dir != 0) {             // always correct the linear momentum when an electric field is applied (main.F90:70-71)
+      k_kick<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], q, qsfp, qsfv);
+      k_lex_drift<<<nblk(N, 256), 256, 0, stream>>>(N, dt, qsfp, qsfv);
+      remove_momentum();
+      k_drift<<<nblk(N, 256), 256, 0, stream>>>(N, dt, vel[0], vel[1], vel[2], pos[0], pos[1], pos[2]);
+    } else
+      k_kick_drift<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], pos[0], pos[1], pos[2], q, qsfp, qsfv);
     migrate();                                                           // main.F90:75
     const int qs = cfg.qstep > 0 ? cfg.qstep : 1;
     if (step_count % qs == 0) qeq();                                     // main.F90:77-83

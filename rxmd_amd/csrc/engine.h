@@ -200,6 +200,8 @@ struct Engine {
   void pqeq_sorted_shells();      // ghost shells <- owners, cell-sorted copy (MODE_COPY payload of spos, comm.F90:129-131)
   void pqeq_update_shells();      // update_shell_positions, pqeq.F90:184-259
   void nonbonded_pqeq();          // ENbond_PQEq, pot.F90:784-923
+  void efield_force();            // EEfield, module.F90:359-383
+  void remove_momentum();         // LinearMomentum, main.F90:766-797
   void assemble_forces();
   void accumulate_stress(bool kinetic);   // astr(1:6) on the device (scal[48..53])
   void check_device_error(const char *where);

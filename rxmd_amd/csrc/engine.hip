@@ -82,6 +82,8 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
     cfg.pqeq_path = nullptr;
     ff.build_taper(10.0);                         // rctap0, module.F90:281
   }
+  if (cfg.efield_dir != 0 && (!ff.pqeq || cfg.efield_dir < 1 || cfg.efield_dir > 3))
+    throw EngineError(RXMD_E_ARG, "efield needs a PQEq parameter file (core charges Z) and a direction 1..3");
   force_staged = std::getenv("RXMD_FORCE_STAGED") != nullptr; force_remote = std::getenv("RXMD_FORCE_REMOTE") != nullptr;
   MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
   if (MAXNB > 31) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 31 (the wavefront-per-centre kernels stage the bond slots of two atoms in one 64-lane wavefront; the reference uses 30)");

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_shell_update(int N, int S10, DevFF ff, 
                                                        const double4 *__restrict__ pk, const double4 *__restrict__ sorted_shl,
                                                        const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, const int *__restrict__ type,
                                                        const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
-                                                       double *__restrict__ nx, double *__restrict__ ny, double *__restrict__ nz) {
+                                                       double *__restrict__ nx, double *__restrict__ ny, double *__restrict__ nz, int edir, double efield) {
   const int lane = threadIdx.x & 63;
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(256) k_shell_update(int N, int S10, DevFF ff, 
   f0 = wave_sum_p(f0); f1 = wave_sum_p(f1); f2 = wave_sum_p(f2);
   if (lane == 0) {
     f0 -= Ki * s0; f1 -= Ki * s1; f2 -= Ki * s2;                     // Eq. 37
+    if (edir == 1) f0 -= Zi * efield; else if (edir == 2) f1 -= Zi * efield; else if (edir == 3) f2 -= Zi * efield;   // pqeq.F90:205 (efield = E*Eev_kcal)
     double r0 = f0 / Ki, r1 = f1 / Ki, r2 = f2 / Ki;
     const double ddr = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
     if (ddr > 1e-3) { r0 = r0 / ddr * 1e-3; r1 = r1 / ddr * 1e-3; r2 = r2 / ddr * 1e-3; }
@@ -103,7 +104,8 @@ void Engine::pqeq_update_shells() {
   if (multi()) { halo_staged(q, 1); k_sorted_charge_p<<<nblk(G, 256), 256, 0, stream>>>(G, perm, q, sorted_xyzi); }
   else k_sorted_charge_p<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, q, sorted_xyzi);
   // new shells into scratch (every row reads its partners' old shells), then copy back
-  k_shell_update<<<nblk(N, 4), 256, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, sorted_shl, pos[0], pos[1], pos[2], type, shl[0], shl[1], shl[2], cds, cd, cc_);
+  k_shell_update<<<nblk(N, 4), 256, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, sorted_shl, pos[0], pos[1], pos[2], type, shl[0], shl[1], shl[2], cds, cd, cc_,
+                                                cfg.efield_dir, cfg.efield_strength * 23.060538);
   double *tmp[3] = {cds, cd, cc_};
   for (int a = 0; a < 3; ++a) RX_HIP(hipMemcpyAsync(shl[a], tmp[a], sizeof(double) * N, hipMemcpyDeviceToDevice, stream));
   pqeq_sorted_shells();            // FORCE's MODE_COPY carries the moved shells to the ghosts (pot.F90:28)
@@ -190,6 +192,16 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
     const double s = sv[0][c] + sv[1][c] + sv[2][c] + sv[3][c];
     if (s != 0.0) atomicAdd(pe + 16 + c, s);
   }
+}
+
+// EEfield (module.F90:359-383, called at pot.F90:61): force -(q_i + Z_i) E Eev_kcal on the core of every resident along the field
+__global__ void k_efield(int N, DevFF ff, const int *__restrict__ type, const double *__restrict__ q, double ev, double *__restrict__ f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) f[i] += -(q[i] + ff.Zpq[type[i]]) * ev;
+}
+void Engine::efield_force() {
+  if (cfg.efield_dir < 1 || cfg.efield_dir > 3) return;
+  k_efield<<<nblk(N, 256), 256, 0, stream>>>(N, dff, type, q, cfg.efield_strength * 23.060538, frc[cfg.efield_dir - 1]);
 }
 
 void Engine::nonbonded_pqeq() {

@@ -52,6 +52,10 @@ CASES = {
     "sicnp547_pqeq_tol7":  ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in"], 0),
     "sicnp547_pqeq_tight": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
     "sicnp547_pqeq_md5":   ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in"], 5),
+    # external electric field on cores and shells (EEfield module.F90:359-383, pqeq.F90:205, momentum removal main.F90:70-71)
+    "sicnp547_pqeq_efieldx_0": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 1 0.05"], 0),
+    "sicnp547_pqeq_efieldx_md3": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 1 0.05"], 3),
+    "sicnp547_pqeq_efield_md3": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 3 0.05"], 3),
     # multi-rank (real MPI build oracle/_ref/rxmd_mpi, conda MPICH): name: (..., vprocs)
     "rdx222_v211_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
     "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),
@@ -137,6 +141,8 @@ def make(name):
     if len(CASES[name]) == 6:
         return make_mpi(name)
     xyz, ff, mc, flags, nsteps = CASES[name]
+    extra_in = [f[7:] for f in flags if f.startswith("RXMDIN:")]     # extra rxmd.in lines (the --efield command-line form does not parse under flang)
+    flags = [f for f in flags if not f.startswith("RXMDIN:")]
     tmp = tempfile.mkdtemp(prefix="golden_")
     try:
         os.makedirs(os.path.join(tmp, "DAT"))
@@ -147,6 +153,9 @@ def make(name):
         shutil.copy(os.path.join(INP, ff), os.path.join(tmp, "ffield"))
         shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
         shutil.copy(os.path.join(INP, "pqeq_sicnp.in"), os.path.join(tmp, "pqeq.in"))
+        if extra_in:
+            with open(os.path.join(tmp, "rxmd.in"), "a") as f:
+                f.write("\n".join(extra_in) + "\n")
         run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT",
              "-mc", str(mc[0]), str(mc[1]), str(mc[2])], tmp)
         rxffbin = open(os.path.join(tmp, "DAT", "rxff.bin"), "rb").read()

@@ -138,6 +138,9 @@ class Oracle:
     def forces(self, rank=0): return self.get(2, rank, 3)
     def charges(self, rank=0): return self.get(3, rank)
     def spos(self, rank=0): return self.get(8, rank, 3)
+    def set_efield(self, direction, strength):
+        self.L.rxo_set_efield.argtypes = [C.c_void_p, C.c_int, C.c_double]; self.L.rxo_set_efield(self.w, int(direction), float(strength))
+
     def set_pqeq_clean(self, flag=1):
         self.L.rxo_set_pqeq_clean.argtypes = [C.c_void_p, C.c_int]; self.L.rxo_set_pqeq_clean(self.w, int(flag))
 

@@ -368,3 +368,32 @@ def test_velocity_scaling_modes_from_a_restart_file(mode, kw):
     assert q_err(a["q"][o], g["charge"][go]) <= QTOL
     assert f_err(a["f"][o], g["force"][go]) <= FTOL
     e.close()
+
+
+def test_pqeq_electric_field_step0_against_the_reference():
+    """rxmd.in `efield 1 0.05`: field force on the cores (EEfield) on top of the PQEq forces, against the real reference (x direction:
+    the one the reference's EEfield addresses correctly, see include/rxmd_hip.h)"""
+    g = np.load(os.path.join(oa.GOLD, "sicnp547_pqeq_efieldx_0.npz"))
+    e = _engine("sicnp", (1, 1, 1), pqeq=oa.PQEQ_SICNP, efield=(1, 0.05), QEq_tol=1e-12, NMAXQEq=2000)
+    e.QEq(); e.FORCE(); a = e.atoms()
+    o = np.argsort(a["gid"]); go = np.argsort(g["gid"])
+    assert q_err(a["q"][o], g["charge"][go]) <= QTOL
+    assert f_err(a["f"][o], g["force"][go]) <= FTOL
+    e.close()
+
+
+def test_pqeq_electric_field_md_against_the_clean_oracle():
+    """field along z, 3 MD steps: core and shell field forces, momentum removal between kick and drift (main.F90:70-71).  Oracle in
+    clean mode = field applied to atom i along dir and no stale table values (the reference-faithful mode is pinned on CPU)."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    e = _engine("sicnp", (1, 1, 1), pqeq=oa.PQEQ_SICNP, efield=(3, 0.05), **kw)
+    o = _oracle("sicnp", (1, 1, 1), pqeq=oa.PQEQ_SICNP, **kw); o.set_efield(3, 0.05); o.set_pqeq_clean(1)
+    e.QEq(); e.FORCE(); o.qeq(); o.force()
+    e.step(3); o.step(3)
+    a = e.atoms()
+    ie = np.argsort(a["gid"]); io = np.argsort(o.gids())
+    assert np.abs(a["pos"][ie] - o.pos()[io]).max() <= 1e-9
+    assert q_err(a["q"][ie], o.charges()[io]) <= QTOL
+    assert f_err(a["f"][ie], o.forces()[io]) <= FTOL
+    assert np.abs(e.shells()[ie] - o.spos()[io]).max() <= 1e-7
+    e.close()

@@ -180,3 +180,15 @@ def test_velocity_scaling_modes_from_a_restart_file(mode, kw):
             o.thermostat(mode, gke=o.kinetic() / n, **kw)
         o.step(1)
     _compare(g, o, ftol=1e-8, qtol=1e-10)
+
+
+def test_pqeq_with_electric_field():
+    """--efield 3 0.05: field force on cores (EEfield, module.F90:359-383), on shells (pqeq.F90:205) and the momentum removal of
+    every step (main.F90:70-71), 3 MD steps against the reference"""
+    g = np.load(os.path.join(GOLD, "sicnp547_pqeq_efield_md3.npz"))
+    ff, names, frac, lat = oa.make_system("sicnp")
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff))
+    o = oa.Oracle(ff, lat2, ranks, pqeq=oa.PQEQ_SICNP, QEq_tol=1e-12, NMAXQEq=2000)
+    o.set_efield(3, 0.05)
+    o.qeq(); o.force(); o.step(3)
+    _compare(g, o, ftol=1e-9, qtol=1e-10)
