@@ -36,7 +36,8 @@ def test_struct_layout_matches_header_sizes():
     L.rxmd_hip_default_config(C.byref(cfg))
     assert list(cfg.vprocs) == [1, 1, 1] and cfg.isQEq == 1 and cfg.NMAXQEq == 500 and cfg.QEq_tol == 1e-7
     assert cfg.qstep == 1 and cfg.dt_fs == 0.25 and cfg.Lex_fqs == 1.0 and cfg.Lex_k == 2.0 and cfg.lattice[5] == 90.0
-    assert all(v == 0 for v in cfg.reserved)
+    assert cfg.reserved0 == 0 and cfg.pqeq_path is None and cfg.efield_dir == 0 and cfg.reserved1 == 0 and cfg.efield_strength == 0.0
+    assert C.sizeof(cfg) == 168 and _lib.RxmdConfig.pqeq_path.offset == 144 and _lib.RxmdConfig.efield_strength.offset == 160   # = gcc's layout of include/rxmd_hip.h
 
 
 def _host_table(ff, which, npt=None):
