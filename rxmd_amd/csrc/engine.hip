@@ -821,7 +821,23 @@ void Engine::build_ghosts_and_lists() {
   bin_cells();
   build_bonded_list();
   build_list10();
-  check_device_error("list build");
+  try {
+    check_device_error("list build");
+  } catch (const EngineError &er) {
+    // The row stride of the 10 A list is sized from the MEAN density; a dense region inside a sparse box (a nanoparticle in
+    // vacuum) can need more.  The reference stops (fixed MAXNEIGHBS10 = 1500, qeq.F90:248-252); here the list grows once to
+    // what the sweep reported -- unless the caller fixed the stride (cfg.maxneighbs10), which keeps the reference's trap.
+    if (er.code != RXMD_E_MAXNEIGHBS10 || cfg.maxneighbs10 > 0) throw;
+    const int need = h_err[1];
+    S10 = (static_cast<int>(need * 1.1) + 64 + 63) / 64 * 64;
+    const size_t n = static_cast<size_t>(rows10) * S10;
+    dfree(nb10); dfree(hess); dmalloc(nb10, n); dmalloc(hess, n);
+    if (spmv_cell) { dfree(nb10s); dmalloc(nb10s, n); }
+    if (ff.pqeq) { dfree(hsc); dmalloc(hsc, n); }
+    st.n10_stride = S10;
+    build_list10();
+    check_device_error("list build");
+  }
   nbhd_max = h_err[2];
   st.ms_lists += toc(0, 1);
   lists_valid = true;

@@ -397,3 +397,28 @@ def test_pqeq_electric_field_md_against_the_clean_oracle():
     assert f_err(a["f"][ie], o.forces()[io]) <= FTOL
     assert np.abs(e.shells()[ie] - o.spos()[io]).max() <= 1e-7
     e.close()
+
+
+def test_row_stride_of_the_10A_list_grows_when_the_density_estimate_is_too_low():
+    """The list stride is sized from the mean density; a tiny explicit hint (maxneighbs10) keeps the reference's overflow trap,
+    the automatic sizing must recover by growing to what the sweep reports."""
+    import rxmd_amd
+    from rxmd_amd import system
+    ff, names, frac, lat = oa.make_system("sicnp")
+    lat3, rec = system.geninit(ff, names, frac, lat, mc=(1, 1, 1))
+    e = rxmd_amd.RxmdEngine(ff, lat3, maxneighbs10=64)
+    e.set_atoms_rxff(rec)
+    with pytest.raises(rxmd_amd.RxmdError) as ex:
+        e.QEq()
+    assert ex.value.code == -5 and "MAXNEIGHBS10" in str(ex.value)      # RXMD_E_MAXNEIGHBS10, qeq.F90:248-252
+    e.close()
+    # a box that is mostly vacuum: widen it so that the mean density underestimates the rows of the particle
+    lat_wide = list(lat3); lat_wide[0] *= 3.0
+    rec2 = rec.copy(); rec2[:, 0] = rec2[:, 0] / 3.0
+    e = rxmd_amd.RxmdEngine(ff, lat_wide)
+    e.set_atoms_rxff(rec2)
+    s0 = e.stats()["n10_stride"]
+    e.QEq(); e.FORCE()
+    s1 = e.stats()
+    assert s1["n10_stride"] > s0 and s1["max_n10"] <= s1["n10_stride"]
+    e.close()
