@@ -160,7 +160,9 @@ struct Engine {
   ~Engine();
   void set_atoms_rxff(int natoms, const double *rec10);
   int get_atoms_rxff(double *rec10, int capacity);
-  void build_ghosts_and_lists();   // COPYATOMS(MODE_COPY) + LINKEDLIST + NEIGHBORLIST + 10 A list/hessian, once per step
+  void build_ghosts_and_lists(bool qeq_prepass = false);   // COPYATOMS(MODE_COPY) + LINKEDLIST + NEIGHBORLIST + 10 A list/hessian, once per step
+  void qeq_start_vectors();        // qs, qt, hs, ht of qeq.F90:36-63 and their cell-sorted copy (before the list sweep that uses them)
+  bool sums_from_list = false;     // the list sweep left H.(qs,qt) of the CG start vector in sall / sgh
   void qeq();
   void force();
   void step(int nsteps);

@@ -814,12 +814,14 @@ void Engine::sorted_copy(const double2 *v) {
   k_sorted_vec<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, v, xs);
 }
 
-void Engine::build_ghosts_and_lists() {
+void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   tic(0);
   ghost_build();
   bin_cells();
   build_bonded_list();
+  sums_from_list = qeq_prepass;
+  if (qeq_prepass) qeq_start_vectors();             // the sweep below also forms H.(qs,qt) of the CG start vector
   build_list10();
   try {
     check_device_error("list build");

@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
                                                  const double *__restrict__ z, const int *__restrict__ type, const long long *__restrict__ gid,
                                                  int *__restrict__ nb10, unsigned short *__restrict__ nb10s, double *__restrict__ hess, int *__restrict__ n10, int *err,
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
-                                                 double *__restrict__ hsc, double4 *__restrict__ pqrow) {
+                                                 double *__restrict__ hsc, double4 *__restrict__ pqrow,
+                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh) {
   extern __shared__ unsigned short srow_all[];       // [4][S10]: the wavefront's row of 16-bit entries, written out as 4-byte words
   const int lane = threadIdx.x & 63;
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -122,6 +123,9 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   const size_t row = static_cast<size_t>(i) * S10;
   double sxi = 0.0, syi = 0.0, szi = 0.0, Zi = 0.0, p_f = 0.0, p_hz = 0.0, p_bz = 0.0, p_ss = 0.0;
   if (PQ) { sxi = shx[i]; syi = shy[i]; szi = shz[i]; Zi = ff.Zpq[ti]; }
+  // xs0 != nullptr: the sweep also forms the row sums H.(qs,qt) of the CG start vector (qt = 0) -- the matrix pass that
+  // get_gradient would need before the first iteration (qeq.F90:87) comes for free while the entries are in registers
+  double ra = 0.0, rg = 0.0;
   int cnt = 0;
   int loff = 0;     // candidates in the stencil columns already swept = position of this column inside the neighbourhood
   for (int dx = -2; dx <= 2; ++dx) {
@@ -193,6 +197,11 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
             }
             unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
             if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
+            if (xs0) {
+              const double qsj = xs0[k].x;
+              ra += h * qsj;
+              if (PQ) rg += hsc[row + slot] * qsj; else if (j >= N) rg += h * qsj;
+            }
             nb10[row + slot] = static_cast<int>(ent);
             if (nb10s) srow[slot] = static_cast<unsigned short>(((lbase + k) & 0x7fff) | (j >= N ? 0x8000 : 0));
             hess[row + slot] = h;
@@ -210,6 +219,10 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
     unsigned *dw = reinterpret_cast<unsigned *>(nb10s + row);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     for (int t = lane; t < nw; t += 64) dw[t] = sw[t];
+  }
+  if (xs0) {
+    ra = wave_sum_l(ra); rg = wave_sum_l(rg);
+    if (lane == 0) { s_all[i] = make_double2(ra, 0.0); s_gh[i] = make_double2(rg, 0.0); }
   }
   if (PQ) {
     p_f = wave_sum_l(p_f); p_hz = wave_sum_l(p_hz); p_bz = wave_sum_l(p_bz); p_ss = wave_sum_l(p_ss);
@@ -232,7 +245,8 @@ void Engine::build_list10() {
   const size_t lds = static_cast<size_t>(S10) * 4 * sizeof(unsigned short);
 #define RX_LIST10(SC, PQF)                                                                                                                     \
   k_list10<SC, PQF><<<nblk(N, 4), 256, lds, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, \
-                                                      hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow)
+                                                      hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, \
+                                                      sums_from_list ? xs : nullptr, sall, sgh)
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
 #undef RX_LIST10

@@ -462,6 +462,32 @@ __global__ void k_qeq_init(int N, int isQEq, double fqs, double *__restrict__ q,
   else { qst[i] = make_double2(fqs * qsfp[i] + (1.0 - fqs) * q[i], 0.0); }
 }
 
+// gradient, Gnew and Est of the CG start vector from the row sums the list sweep left behind (qt = 0, mu = 0): the
+// arithmetic of the MODE_GRAD epilogue without the matrix pass (qeq.F90:87, 349-356, 297-306)
+__global__ void __launch_bounds__(256) k_grad_start(int N, DevFF ff, const int *__restrict__ type, const double2 *__restrict__ qst, const double *__restrict__ q,
+                                                     const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double2 *__restrict__ gst,
+                                                     double *__restrict__ partials, const double4 *__restrict__ pqrow) {
+  double g1s = 0.0, g2s = 0.0, es = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const int ti = type[i];
+    const DevAtomP ap = ff.atom[ti];
+    const double2 qv = qst[i], a = sall[i], g = sgh[i];
+    const double g1 = -ap.chi - ap.eta * qv.x - a.x - (pqrow ? pqrow[i].x : 0.0), g2 = -1.0 - ap.eta * qv.y - a.y;
+    gst[i] = make_double2(g1, g2);
+    const double qi = q[i];
+    g1s += g1 * g1; g2s += g2 * g2;
+    if (pqrow) es += pq_est_row(ap, ff.Zpq[ti], pqrow[i], qi, a.x, g.x);
+    else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (a.x + (a.x - g.x));
+  }
+  double acc[4] = {wave_sum(g1s), wave_sum(g2s), wave_sum(es), 0.0};
+  block_store_partials<4>(acc, partials, 4);
+}
+
+void Engine::qeq_start_vectors() {
+  k_qeq_init<<<nblk(N, 256), 256, 0, stream>>>(N, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
+  sorted_copy(qst);                                                                             // QCOPY1, qeq.F90:86
+}
+
 void Engine::allreduce_scal4() {
   if (nprocs == 1 && !nccl) return;              // forced staged mode of a single rank without a communicator: nothing to add
   if (nccl) { rccl_allreduce_dev(scal + S_RAW0, 4); return; }      // in stream order, no host round trip
@@ -476,7 +502,10 @@ void Engine::qeq() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   if (cfg.isQEq != 1 && cfg.isQEq != 2) { nstep_qeq = 0; return; }   // qeq.F90:60-61
   tic(6);
-  if (!lists_valid) build_ghosts_and_lists();
+  // the list sweep of this step can form the row sums of the start vector on the way (saves the matrix pass of qeq.F90:87)
+  static const bool prepass_on = (std::getenv("RXMD_QEQ_NO_PREPASS") == nullptr);
+  sums_from_list = false;
+  if (!lists_valid) build_ghosts_and_lists(prepass_on);
   const int nmax = (cfg.isQEq == 1) ? cfg.NMAXQEq : 1;
   // one wavefront per row, four rows per workgroup: measured faster than a persistent grid-stride launch (1.10 vs 1.28 ms
   // per pass at 979,776 rows) -- many short waves overlap each other's load / gather / reduce phases
@@ -524,12 +553,16 @@ void Engine::qeq() {
     allreduce_scal4();                           // MPI_ALLREDUCE of the rank-local sums
     k_scalar_algebra<<<1, 64, 0, stream>>>(stage, scal);
   };
-  k_qeq_init<<<nblk(N, 256), 256, 0, stream>>>(N, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
   RX_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 32, stream));
-  sorted_copy(qst);                                                                             // QCOPY1, qeq.F90:86
   const bool onepass = (cfg.qeq_mode == 1);
-  pass(MODE_GRAD, onepass, onepass ? sall : nullptr, onepass ? sgh : nullptr);
-  reduce(3, nred);
+  if (sums_from_list) {
+    k_grad_start<<<vb, 256, 0, stream>>>(N, dff, type, qst, q, sall, sgh, gst, partials, pqrow);
+    reduce(3, vb);
+  } else {
+    qeq_start_vectors();
+    pass(MODE_GRAD, onepass, onepass ? sall : nullptr, onepass ? sgh : nullptr);
+    reduce(3, nred);
+  }
   k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
   RX_HIP(hipStreamSynchronize(stream));
