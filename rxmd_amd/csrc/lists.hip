@@ -110,11 +110,13 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
                                                  const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh) {
-  extern __shared__ unsigned short srow_all[];       // [4][S10]: the wavefront's row of 16-bit entries, written out as 4-byte words
-  const int lane = threadIdx.x & 63;
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // dynamic LDS: [4][128] queue of accepted candidates (sorted position, neighbourhood position), then [4][S10] 16-bit rows
+  extern __shared__ int lds_all[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
   if (i >= N) return;
-  unsigned short *srow = srow_all + static_cast<size_t>(threadIdx.x >> 6) * S10;
+  int2 *sq = reinterpret_cast<int2 *>(lds_all) + w * 128;
+  unsigned short *srow = reinterpret_cast<unsigned short *>(lds_all + 4 * 128 * 2) + static_cast<size_t>(w) * S10;
   const int c = cellid[i];
   const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
@@ -126,8 +128,73 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   // xs0 != nullptr: the sweep also forms the row sums H.(qs,qt) of the CG start vector (qt = 0) -- the matrix pass that
   // get_gradient would need before the first iteration (qeq.F90:87) comes for free while the entries are in registers
   double ra = 0.0, rg = 0.0;
-  int cnt = 0;
+  int cnt = 0;      // entries written so far
+  int qn = 0;       // accepted candidates waiting in the queue
   int loff = 0;     // candidates in the stencil columns already swept = position of this column inside the neighbourhood
+
+  // Phase 2, dense: one queued candidate per lane -> table interpolation, list entry, hessian value.  Only ~27 % of the
+  // candidates of a chunk pass the distance test, so doing this work on compacted batches keeps every lane busy.
+  auto emit = [&](int nproc) {
+    if (lane < nproc) {
+      const int2 qe = sq[lane];
+      const int k = qe.x, slot = cnt + lane;
+      if (slot < S10) {
+        const double4 p = sorted[k];
+        const long long wv = __double_as_longlong(p.w);
+        const int j = static_cast<int>(wv & 0xffffffffLL), tj = static_cast<int>(wv >> 32);
+        const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        // hessian entry as qeq_initialize computes it: r^2 rounded to REAL(4) first (qeq.F90:191,222-240)
+        const float r2f = static_cast<float>(r2);
+        double h = 0.0, hc = 0.0;
+        const int inxn = ff.inxn2[ti * ff.n1 + tj];
+        if (PQ) {
+          if (static_cast<double>(r2f) < ff.rctap2) {                  // the pair is in PQEq's own list (real(4) test, pqeq.F90:305)
+            const double C0q = 14.4;                                   // Cclmb0_qeq, module.F90:682
+            const double4 sj = sorted_shl[k];
+            const double Zj = ff.Zpq[tj];
+            const int prow = ff.inxnpq[ti * ff.npq1 + tj];
+            double E, F;
+            pq_lookup(ff, ff.tabPcc, prow, r2, E, F);                  // core(i)-core(j)
+            h = C0q * E;
+            p_hz += h * Zj;
+            // Eq. 30: field of core(j) minus field of shell(j) at core(i); table row (jty,ity), pqeq.F90:328-334
+            double e0 = d0 - sj.x, e1 = d1 - sj.y, e2 = d2 - sj.z;
+            pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+            p_f += h * Zj - C0q * E * Zj;
+            // shell(i)-core(j): Csicj = -hsc * (q_j + Z_j), pqeq.F90:392-395
+            e0 = d0 + sxi; e1 = d1 + syi; e2 = d2 + szi;
+            pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+            hc = C0q * E * Zi;
+            p_bz += hc * Zj;
+            // shell(i)-shell(j): Csisj, pqeq.F90:397-401 (half of it per row, :409)
+            e0 -= sj.x; e1 -= sj.y; e2 -= sj.z;
+            pq_lookup(ff, ff.tabPss, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+            p_ss += 0.5 * C0q * E * Zi * Zj;
+          }
+          hsc[row + slot] = hc;
+        } else if (static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
+          const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
+          double drtb = static_cast<double>(r2f) - itb * ff.UDR;
+          drtb = drtb * ff.UDRi;
+          const double *T = ff.tabQEq + static_cast<size_t>(inxn) * (NTABLE + 2);
+          h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
+        }
+        unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
+        if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
+        if (xs0) {
+          const double qsj = xs0[k].x;
+          ra += h * qsj;
+          if (PQ) rg += hc * qsj; else if (j >= N) rg += h * qsj;
+        }
+        nb10[row + slot] = static_cast<int>(ent);
+        if (nb10s) srow[slot] = static_cast<unsigned short>((qe.y & 0x7fff) | (j >= N ? 0x8000 : 0));
+        hess[row + slot] = h;
+      }
+    }
+    cnt += nproc;
+  };
+
   for (int dx = -2; dx <= 2; ++dx) {
     const int x2 = cx + dx;
     if (x2 < 0 || x2 >= g.n[0]) continue;
@@ -139,78 +206,34 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
       const int lbase = loff - k0;
       loff += k1 - k0;
       for (int kb = k0; kb < k1; kb += 64) {
+        // Phase 1, sparse: distance test of 64 candidates, survivors appended to the queue in candidate order
         const int k = kb + lane;
         bool in = false;
-        int j = 0, tj = 0;
-        double r2 = 0.0;
         if (k < k1) {
           const double4 p = sorted[k];
-          const long long w = __double_as_longlong(p.w);
-          j = static_cast<int>(w & 0xffffffffLL);
-          tj = static_cast<int>(w >> 32);
+          const int j = static_cast<int>(__double_as_longlong(p.w) & 0xffffffffLL);
           const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
-          r2 = d0 * d0 + d1 * d1 + d2 * d2;
+          const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
           in = (j != i) && (r2 <= ff.rctap2);       // dr2 <= rctap2, main.F90:458
         }
         const unsigned long long m = __ballot(in);
-        if (in) {
-          const int slot = cnt + __popcll(m & ((1ULL << lane) - 1ULL));
-          if (slot < S10) {
-            // hessian entry as qeq_initialize computes it: r^2 rounded to REAL(4) first (qeq.F90:191,222-240)
-            const float r2f = static_cast<float>(r2);
-            double h = 0.0;
-            const int inxn = ff.inxn2[ti * ff.n1 + tj];
-            if (PQ) {
-              double c = 0.0;
-              if (static_cast<double>(r2f) < ff.rctap2) {                  // the pair is in PQEq's own list (real(4) test, pqeq.F90:305)
-                const double C0q = 14.4;                                   // Cclmb0_qeq, module.F90:682
-                const double4 sj = sorted_shl[k];
-                const double Zj = ff.Zpq[tj];
-                const int prow = ff.inxnpq[ti * ff.npq1 + tj];
-                const double4 p = sorted[k];
-                const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
-                double E, F;
-                pq_lookup(ff, ff.tabPcc, prow, r2, E, F);                  // core(i)-core(j)
-                h = C0q * E;
-                p_hz += h * Zj;
-                // Eq. 30: field of core(j) minus field of shell(j) at core(i); table row (jty,ity), pqeq.F90:328-334
-                double e0 = d0 - sj.x, e1 = d1 - sj.y, e2 = d2 - sj.z;
-                pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
-                p_f += h * Zj - C0q * E * Zj;
-                // shell(i)-core(j): Csicj = -hsc * (q_j + Z_j), pqeq.F90:392-395
-                e0 = d0 + sxi; e1 = d1 + syi; e2 = d2 + szi;
-                pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
-                c = C0q * E * Zi;
-                p_bz += c * Zj;
-                // shell(i)-shell(j): Csisj, pqeq.F90:397-401 (half of it per row, :409)
-                e0 -= sj.x; e1 -= sj.y; e2 -= sj.z;
-                pq_lookup(ff, ff.tabPss, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
-                p_ss += 0.5 * C0q * E * Zi * Zj;
-              }
-              hsc[row + slot] = c;
-            } else if (static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
-              const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
-              double drtb = static_cast<double>(r2f) - itb * ff.UDR;
-              drtb = drtb * ff.UDRi;
-              const double *T = ff.tabQEq + static_cast<size_t>(inxn) * (NTABLE + 2);
-              h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
-            }
-            unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
-            if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
-            if (xs0) {
-              const double qsj = xs0[k].x;
-              ra += h * qsj;
-              if (PQ) rg += hsc[row + slot] * qsj; else if (j >= N) rg += h * qsj;
-            }
-            nb10[row + slot] = static_cast<int>(ent);
-            if (nb10s) srow[slot] = static_cast<unsigned short>(((lbase + k) & 0x7fff) | (j >= N ? 0x8000 : 0));
-            hess[row + slot] = h;
-          }
+        if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(k, lbase + k);
+        qn += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (qn >= 64) {
+          emit(64);
+          const int rest = qn - 64;
+          int2 v = make_int2(0, 0);
+          if (lane < rest) v = sq[64 + lane];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          if (lane < rest) sq[lane] = v;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          qn = rest;
         }
-        cnt += __popcll(m);
       }
     }
   }
+  if (qn > 0) emit(qn);
   if (cnt > S10) { if (lane == 0) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); } cnt = S10; }  // qeq.F90:248-252
   if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; if (nb10s) srow[cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
   if (nb10s) {
@@ -242,7 +265,7 @@ void Engine::build_list10() {
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
   const bool selfcheck = (box.lat[0] < 2.0 * ff.rctap + 1.0) || (box.lat[1] < 2.0 * ff.rctap + 1.0) || (box.lat[2] < 2.0 * ff.rctap + 1.0);
-  const size_t lds = static_cast<size_t>(S10) * 4 * sizeof(unsigned short);
+  const size_t lds = 4 * 128 * sizeof(int2) + static_cast<size_t>(S10) * 4 * sizeof(unsigned short);
 #define RX_LIST10(SC, PQF)                                                                                                                     \
   k_list10<SC, PQF><<<nblk(N, 4), 256, lds, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, \
                                                       hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, \
