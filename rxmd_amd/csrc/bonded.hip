@@ -142,7 +142,7 @@ constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages
 // ------------------------------------------------------------------------------------------------
 // occupancy knobs, measured on MI355X (bonded section of the step, ms): E3b at 1/2/3/4 workgroups per CU = 22.5/20.4/22.4/22.9
 // (256 VGPRs + 3 AGPRs miss the 2-wave budget by three registers without the hint; beyond 2 the spills cost more than
-// the occupancy buys), E4b at 2/3 = 21.3/20.4
+// the occupancy buys), E4b at 2/3 = 21.3/20.4 (before its LDS-atomic accumulators; with them 3 stays best: 15.2, at 4: 18.9)
 #ifndef E3B_MINB
 #define E3B_MINB 2
 #endif
@@ -275,7 +275,8 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
 // A torsion is visited from both ends: a lane books the energy, the j-k bond coefficient and the cdbnd terms only when
 // gid(j) < gid(k) (the reference's orientation, which the index-ordered ccbnd rule depends on), the forces on i and j and
 // the i-j bond coefficient always; the k/l side is booked when atom k is the centre.  Per-bond sums are formed by each
-// owner lane scanning the 64 results in queue order: no atomics, scheduling-independent.
+// evaluating lane adding its results to the (atom, slot) accumulators in LDS (ds_add_f64): no global atomics, and the order of the
+// additions is fixed by the queue order and the lane order inside one LDS instruction.
 __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
@@ -290,7 +291,11 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   __shared__ double s_btb2[4][64], s_dfn11[4][64];
   __shared__ int s_nk[4][64], s_own[4][64];
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
-  __shared__ double s_out[4][64][11];            // per evaluated torsion: i-side (cf1, fx, fy, fz), centre-bond side (cf1, cf2, cd), centre atom (fx, fy, fz, cd)
+  // per (atom g, slot) accumulators, updated with LDS atomics by the lanes that evaluate torsions: [0] cf1 and [1..3] force of the
+  // i-j bond / its neighbour, [4] cf1, [5] cf2, [6] cdbnd of the centre bond; slot 31 (never a bond) holds the centre atom's own
+  // force in [1..3] and cdbnd in [6].  (An earlier version wrote 11 results per torsion to LDS and let every owner lane scan all 64
+  // of them: that scan cost about as many instructions as the torsion itself.)
+  __shared__ double s_acc[4][64][7];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int jbase = (blockIdx.x * 4 + w) * 2;
   if (jbase >= N) return;                        // whole wavefront leaves together; no block-level barrier below
@@ -321,10 +326,11 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
       s_own[w][lane] = gid[j_me] < gid[i] ? 1 : 0;
     }
   }
+#pragma unroll
+  for (int c = 0; c < 7; ++c) s_acc[w][lane][c] = 0.0;
   wave_lds_sync();
   const int njg[2] = {__shfl(nj_me, 0, 64), __shfl(nj_me, 32, 64)};
   const int tjg[2] = {__shfl(tj_me, 0, 64), __shfl(tj_me, 32, 64)};
-  double a_cf = 0.0, a_fx = 0.0, a_fy = 0.0, a_fz = 0.0, a_cjk1 = 0.0, a_cjk2 = 0.0, a_cdk = 0.0;   // owner-lane sums
   double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
   int qn = 0;                                     // (slot 31 is never a bond: its lane accumulates the centre atom's own force and cdbnd)
 
@@ -444,17 +450,12 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
         }
       }
     }
-#pragma unroll
-    for (int c = 0; c < 7; ++c) s_out[w][lane][c] = o[c];
-    s_out[w][lane][7] = fself.x; s_out[w][lane][8] = fself.y; s_out[w][lane][9] = fself.z; s_out[w][lane][10] = cd_self;
-    wave_lds_sync();
-    // owner lane (g_me, sl_me): add the results that name its bond as the i-j bond or as the centre bond, in queue order
-    for (int e = 0; e < cnt; ++e) {
-      const int ke = s_q[w][e];
-      if ((ke >> 15) != g_me) continue;
-      if (sl_me == 31) { a_fx += s_out[w][e][7]; a_fy += s_out[w][e][8]; a_fz += s_out[w][e][9]; a_cdk += s_out[w][e][10]; continue; }
-      if (((ke >> 5) & 31) == sl_me) { a_cf += s_out[w][e][0]; a_fx += s_out[w][e][1]; a_fy += s_out[w][e][2]; a_fz += s_out[w][e][3]; }
-      if (((ke >> 10) & 31) == sl_me) { a_cjk1 += s_out[w][e][4]; a_cjk2 += s_out[w][e][5]; a_cdk += s_out[w][e][6]; }
+    if (key >= 0) {
+      const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31;
+      double *ai = &s_acc[w][g * 32 + i1][0], *ak = &s_acc[w][g * 32 + k1][0], *as = &s_acc[w][g * 32 + 31][0];
+      atomicAdd(ai + 0, o[0]); atomicAdd(ai + 1, o[1]); atomicAdd(ai + 2, o[2]); atomicAdd(ai + 3, o[3]);
+      atomicAdd(ak + 4, o[4]); atomicAdd(ak + 5, o[5]); atomicAdd(ak + 6, o[6]);
+      atomicAdd(as + 1, fself.x); atomicAdd(as + 2, fself.y); atomicAdd(as + 3, fself.z); atomicAdd(as + 6, cd_self);
     }
     wave_lds_sync();
   };
@@ -504,6 +505,9 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   }
   if (qn > 0) evaluate(qn);
 
+  wave_lds_sync();
+  const double a_cf = s_acc[w][lane][0], a_fx = s_acc[w][lane][1], a_fy = s_acc[w][lane][2], a_fz = s_acc[w][lane][3];
+  const double a_cjk1 = s_acc[w][lane][4], a_cjk2 = s_acc[w][lane][5], a_cdk = s_acc[w][lane][6];
   if (sl_me < nj_me) {
     const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
     if (a_cf != 0.0 || a_cjk1 != 0.0) cf1[o] += a_cf + a_cjk1;
