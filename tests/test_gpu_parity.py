@@ -422,3 +422,22 @@ def test_row_stride_of_the_10A_list_grows_when_the_density_estimate_is_too_low()
     s1 = e.stats()
     assert s1["n10_stride"] > s0 and s1["max_n10"] <= s1["n10_stride"]
     e.close()
+
+
+def test_forces_and_charges_are_bitwise_reproducible_run_to_run():
+    """no result may depend on scheduling: partial sums are combined in fixed orders, the torsion accumulators use LDS atomics whose
+    order is fixed by queue and lane order; only the 14 energy scalars and the hydrogen-bond acceptor forces take global atomics.
+    RDX 2x2x2 (H-bond acceptor atomics present): charges bitwise, forces to 1e-13 relative; the ice case (Ehb == 0): forces bitwise."""
+    res = []
+    for rep in range(2):
+        e = _engine("rdx222", (2, 2, 2), QEq_tol=1e-12, NMAXQEq=2000)
+        e.QEq(); e.FORCE(); e.step(2)
+        a = e.atoms(); res.append((a["q"].copy(), a["f"].copy())); e.close()
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-13 * np.abs(res[0][1]).max()
+    res = []
+    for rep in range(2):
+        e = _engine("ice644", (6, 4, 4), QEq_tol=1e-12, NMAXQEq=2000)
+        e.QEq(); e.FORCE()
+        a = e.atoms(); res.append((a["q"].copy(), a["f"].copy())); e.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
