@@ -23,7 +23,10 @@ static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1)
 enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_RAW0, S_RAW1, S_RAW2, S_RAW3, S_COUNT };
 enum { MODE_HSH = 0, MODE_GRAD = 1 };
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-constexpr int UNR = 8;   // 8 x 64 = 512 entries in flight per wavefront: a whole RDX row (<= 447) in one batch
+#ifndef SPMV_UNR
+#define SPMV_UNR 4
+#endif
+constexpr int UNR = SPMV_UNR;   // 4 x 64 = 256 entries in flight per wavefront and pass of the row loop (see k_spmv)
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -89,7 +92,13 @@ __device__ inline void row_epilogue(int row, double as, double at, double gs_, d
 
 // STORE (qeq_mode 1): additionally keep the raw row sums (all columns / ghost columns) so that the next gradient and Est
 // follow from  H.(q + l h) = H.q + l H.h  with N-sized vector kernels instead of a second matrix pass.
-template <int MODE, bool STORE>
+// One wavefront = one row (the launch covers the rows exactly: nblk(N, 4) workgroups of 4 wavefronts).  The pass is bound by
+// LATENCY x occupancy, not by instruction issue: a wavefront lives for a chain of dependent memory round trips (row length ->
+// the two streams -> the gathers -> the operands of the tail), so (a) the tail operands are requested first, next to the row
+// length, (b) four batches of 64 entries are in flight instead of eight, which brings the kernel from 99 to <= 80 VGPRs and from
+// 4 to 6 wavefronts per SIMD (measured on one box: 1.276 ms -> 1.21 with (a), 1.157 with (b), 1.06-1.12 with both), (c) PQEq is
+// a template parameter so that the plain kernel does not carry its code.
+template <int MODE, bool STORE, bool PQ>
 __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
@@ -98,12 +107,15 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
                                                const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
-  const int wave0 = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * wpb;
-  const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
+  const int row = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + (threadIdx.x >> 6);
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int row = wave0; row < N; row += nwaves) {
+  if (row < N) {
     const int n = n10[row];
+    // operands of the row tail, requested before the streams so that they are not a further dependent round trip after the reduction
+    const int pf_t = type[row];
+    const double2 pf_a = (MODE == MODE_HSH) ? hst[row] : qst[row];
+    const double2 pf_b = (MODE == MODE_HSH) ? gst[row] : make_double2(q[row], 0.0);
+    const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
     const size_t base = static_cast<size_t>(row) * S10;
     double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
     for (int k0 = lane; k0 < n; k0 += 64 * UNR) {
@@ -121,19 +133,35 @@ __global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const in
         const double2 v = xv[e[u] & NB10_IDX_MASK];
         as += h[u] * v.x;
         at += h[u] * v.y;
-        if ((MODE == MODE_GRAD || STORE) && !hsc && (e[u] & NB10_GHOST)) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
-      }
-      if ((MODE == MODE_GRAD || STORE) && hsc) {     // PQEq: second matrix (shell-core) over the same columns
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        if ((MODE == MODE_GRAD || STORE) && !PQ && (e[u] & NB10_GHOST)) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
+        if ((MODE == MODE_GRAD || STORE) && PQ) {      // PQEq: second matrix (shell-core) over the same columns
           const int k = k0 + 64 * u;
-          if (k < n) { const double c = __builtin_nontemporal_load(hsc + base + k); const double2 v = xv[e[u] & NB10_IDX_MASK]; gs_ += c * v.x; gt_ += c * v.y; }
+          const double c = (k < n) ? __builtin_nontemporal_load(hsc + base + k) : 0.0;
+          gs_ += c * v.x; gt_ += c * v.y;
         }
       }
     }
     as = wave_sum(as); at = wave_sum(at);
     if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-    if (lane == 0) row_epilogue<MODE, STORE>(row, as, at, gs_, gt_, mu, ff, hst, gst, qst, q, type, rs_all, rs_gh, acc, pqrow);
+    if (lane == 0) {
+      if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+      const DevAtomP ap = ff.atom[pf_t];
+      if (MODE == MODE_HSH) {
+        const double ts = ap.eta * pf_a.x + as, tt = ap.eta * pf_a.y + at;      // qeq.F90:294-302
+        acc[0] = ts * pf_a.x; acc[1] = tt * pf_a.y;                             // hshs_sum, hsht_sum (:309-310)
+        acc[2] = pf_b.x * pf_a.x; acc[3] = pf_b.y * pf_a.y;                     // g.h (:119,123)
+      } else {
+        const double fpq = PQ ? pqrow[row].x : 0.0;
+        const double g1 = -ap.chi - ap.eta * pf_a.x - as - fpq;                 // qeq.F90:349-350 (pqeq.F90:466)
+        const double g2 = -1.0 - ap.eta * pf_a.y - at;
+        gst[row] = make_double2(g1, g2);
+        acc[0] = g1 * g1; acc[1] = g2 * g2;                                     // Gnew (:355-356)
+        const double qi = pf_b.x;
+        const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+        if (PQ) acc[2] = pq_est_row(ap, ff.Zpq[pf_t], pqrow[row], qi, hq_all, gs_ - mu * gt_);
+        else acc[2] = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
+      }
+    }
   }
   block_store_partials<4>(acc, partials, 4);
 }
@@ -532,7 +560,8 @@ void Engine::qeq() {
 #define RX_PASS(M, S)                                                                                                                        \
   do {                                                                                                                                       \
     if (use_cell) k_spmv_cell<M, S><<<grid.ncell, cell_bs, lds_bytes, stream>>>(N, S10, grid, dff, cellstart, perm, nb10s, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg); \
-    else k_spmv<M, S><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
+    else if (ff.pqeq) k_spmv<M, S, true><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
+    else k_spmv<M, S, false><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }

@@ -226,7 +226,9 @@ def test_full_size_properties_rdx_1m():
     ncell = mc[0] * mc[1] * mc[2]
     assert len(a["q"]) == 168 * ncell
     q = a["q"].reshape(ncell, 168); f = a["f"].reshape(ncell, 168, 3)
-    assert np.abs(q - a1["q"][None]).max() <= 1e-8
+    # two CG runs that stop on a 1e-12 relative energy change agree to ~1e-7 in the charges (the exit iteration differs with
+    # the summation order, see the module docstring); the parity tolerance is 1e-6 relative
+    assert q_err(q.reshape(-1), np.tile(a1["q"], ncell)) <= 5e-7
     # the index-ordered ccbnd rule makes bonded forces depend on which neighbours are ghosts: compare only cells
     # whose ghost pattern equals the unit cell's (none do exactly), so use invariants instead of per-atom equality
     assert abs(a["q"].sum()) <= 1e-6
