@@ -110,13 +110,16 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
                                                  const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh) {
-  // dynamic LDS: [4][128] queue of accepted candidates (sorted position, neighbourhood position), then [4][S10] 16-bit rows
+  // dynamic LDS: [4][128] queue of accepted candidates (sorted position, neighbourhood position), [4][128] chunk table, then [4][S10] 16-bit rows
   extern __shared__ int lds_all[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
   if (i >= N) return;
+  constexpr int MAXCH = 128;                     // chunks of one row (RDX: 26-50)
   int2 *sq = reinterpret_cast<int2 *>(lds_all) + w * 128;
-  unsigned short *srow = reinterpret_cast<unsigned short *>(lds_all + 4 * 128 * 2) + static_cast<size_t>(w) * S10;
+  int4 *ck = reinterpret_cast<int4 *>(lds_all + 4 * 128 * 2) + w * MAXCH;
+  unsigned short *srow = reinterpret_cast<unsigned short *>(lds_all + 4 * 128 * 2 + 4 * MAXCH * 4) + static_cast<size_t>(w) * S10;
+  int nchunk = 0;
   const int c = cellid[i];
   const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
@@ -195,41 +198,69 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
     cnt += nproc;
   };
 
-  for (int dx = -2; dx <= 2; ++dx) {
-    const int x2 = cx + dx;
-    if (x2 < 0 || x2 >= g.n[0]) continue;
-    for (int dy = -2; dy <= 2; ++dy) {
-      const int y2 = cy + dy;
-      if (y2 < 0 || y2 >= g.n[1]) continue;
-      const int cb = (x2 * g.n[1] + y2) * g.n[2];
-      const int k0 = cellstart[cb + z0], k1 = cellstart[cb + z1 + 1];
-      const int lbase = loff - k0;
-      loff += k1 - k0;
-      for (int kb = k0; kb < k1; kb += 64) {
-        // Phase 1, sparse: distance test of 64 candidates, survivors appended to the queue in candidate order
-        const int k = kb + lane;
-        bool in = false;
-        if (k < k1) {
-          const double4 p = sorted[k];
-          const int j = static_cast<int>(__double_as_longlong(p.w) & 0xffffffffLL);
-          const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
-          const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-          in = (j != i) && (r2 <= ff.rctap2);       // dr2 <= rctap2, main.F90:458
-        }
-        const unsigned long long m = __ballot(in);
-        if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(k, lbase + k);
-        qn += __popcll(m);
+  // chunk table of the row: the 25 stencil columns (contiguous runs of the sorted array) cut into 64-candidate chunks, in sweep
+  // order.  Lane t < 25 owns column t; an exclusive scan over the lanes places its chunks.  The sweep is bound by the latency of
+  // the candidate loads (26 dependent round trips per row when done one chunk at a time), so four chunks are loaded at once.
+  {
+    int k0 = 0, len = 0;
+    if (lane < 25) {
+      const int x2 = cx + lane / 5 - 2, y2 = cy + lane % 5 - 2;
+      if (x2 >= 0 && x2 < g.n[0] && y2 >= 0 && y2 < g.n[1]) {
+        const int cb = (x2 * g.n[1] + y2) * g.n[2];
+        k0 = cellstart[cb + z0];
+        len = cellstart[cb + z1 + 1] - k0;
+      }
+    }
+    int nch = (len + 63) >> 6, cpre = nch, lpre = len;      // inclusive scans over lanes 0..24 (chunks, candidates)
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int c2 = __shfl_up(cpre, o, 64), l2 = __shfl_up(lpre, o, 64);
+      if (lane >= o) { cpre += c2; lpre += l2; }
+    }
+    const int cfirst = cpre - nch, lfirst = lpre - len;
+    for (int t = 0; t < nch && cfirst + t < MAXCH; ++t) ck[cfirst + t] = make_int4(k0 + 64 * t, k0 + len, lfirst - k0, 0);
+    loff = __shfl(lpre, 24, 64);
+    nchunk = __shfl(cpre, 24, 64);
+    if (nchunk > MAXCH) { if (lane == 0) atomicCAS(&err[0], DERR_NONE, DERR_GRID); nchunk = MAXCH; }   // > 8192 candidates around one atom
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
+    double4 p[4];
+    int kk[4], lb[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ok[u] = false; kk[u] = 0; lb[u] = 0;
+      if (c0 + u < nchunk) {
+        const int4 ce = ck[c0 + u];
+        kk[u] = ce.x + lane; lb[u] = ce.z;
+        ok[u] = kk[u] < ce.y;
+      }
+      p[u] = ok[u] ? sorted[kk[u]] : make_double4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bool in = false;
+      if (ok[u]) {
+        const int j = static_cast<int>(__double_as_longlong(p[u].w) & 0xffffffffLL);
+        const double d0 = xi - p[u].x, d1 = yi - p[u].y, d2 = zi - p[u].z;
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        in = (j != i) && (r2 <= ff.rctap2);       // dr2 <= rctap2, main.F90:458
+      }
+      const unsigned long long m = __ballot(in);
+      if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(kk[u], lb[u] + kk[u]);
+      qn += __popcll(m);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if (qn >= 64) {
+        emit(64);
+        const int rest = qn - 64;
+        int2 v = make_int2(0, 0);
+        if (lane < rest) v = sq[64 + lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (qn >= 64) {
-          emit(64);
-          const int rest = qn - 64;
-          int2 v = make_int2(0, 0);
-          if (lane < rest) v = sq[64 + lane];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          if (lane < rest) sq[lane] = v;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          qn = rest;
-        }
+        if (lane < rest) sq[lane] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        qn = rest;
       }
     }
   }
@@ -265,7 +296,7 @@ void Engine::build_list10() {
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
   const bool selfcheck = (box.lat[0] < 2.0 * ff.rctap + 1.0) || (box.lat[1] < 2.0 * ff.rctap + 1.0) || (box.lat[2] < 2.0 * ff.rctap + 1.0);
-  const size_t lds = 4 * 128 * sizeof(int2) + static_cast<size_t>(S10) * 4 * sizeof(unsigned short);
+  const size_t lds = 4 * 128 * sizeof(int2) + 4 * 128 * sizeof(int4) + static_cast<size_t>(S10) * 4 * sizeof(unsigned short);
 #define RX_LIST10(SC, PQF)                                                                                                                     \
   k_list10<SC, PQF><<<nblk(N, 4), 256, lds, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, \
                                                       hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, \
