@@ -182,6 +182,15 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
     const double delta_val = dlj + aj.Val - aj.Valval;
     const double exp_coa2 = exp(ff.pcoa2 * delta_val);
     const double exp6 = exp(ff.pval6 * delta_ang);
+    // SBO, SBO2, its derivative factor and exp(-pval10 (2 - SBO2)) depend on the centre only (pot.F90:415-437): once per atom
+    const double SBO = sum_SBO1 + (1.0 - prod_SBO) * (-delta_ang - ff.pval8 * nlpj);
+    double SBO2 = 0.0, CSBO2 = 0.0;
+    if (SBO > 0.0 && SBO <= 1.0) { SBO2 = pow(SBO, ff.pval9); CSBO2 = ff.pval9 * pow(SBO, ff.pval9 - 1.0); }
+    else if (SBO > 1.0 && SBO <= 2.0) { SBO2 = 2.0 - pow(2.0 - SBO, ff.pval9); CSBO2 = ff.pval9 * pow(2.0 - SBO, ff.pval9 - 1.0); }
+    else if (SBO > 2.0) SBO2 = 2.0;
+    const double ex10 = exp(-ff.pval10 * (2.0 - SBO2));
+    const double dSBO1 = -8.0 * prod_SBO * (delta_ang + ff.pval8 * nlpj);
+    const double dSBO2 = (prod_SBO - 1.0) * (1.0 - ff.pval8 * dDj);
     // sums over all angles of the terms that ForceBbo(j,n1,...) applies to EVERY bond of j (pot.F90:526-532)
     double S_d1 = 0.0, S_v6 = 0.0, S_v5 = 0.0;
     V3 fself = {0.0, 0.0, 0.0};
@@ -192,6 +201,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
       const int i = nbr[oi], ti = type[i];
       const V3 rij = {x[i] - xj, y[i] - yj, z[i] - zj};
       const double nij = sqrt(dot(rij, rij));
+      double ai_cf = 0.0, ai_cd = 0.0, ai_fx = 0.0, ai_fy = 0.0, ai_fz = 0.0;      // the i-j bond's own sums over k1: one write after the loop
       for (int k1 = i1 + 1; k1 < nj; ++k1) {
         const size_t ok = static_cast<size_t>(k1) * NB + j;
         const double BOjk_f = bo0[ok], BOjk = BOjk_f - cutof2_esub;
@@ -206,27 +216,19 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
         double cos_ijk = -dot(rij, rjk) / (nij * njk);
         if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
         if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
-        const double theta_ijk = acos(cos_ijk), sin_ijk = sin(theta_ijk);
+        const double theta_ijk = acos(cos_ijk), sin_ijk = sqrt((1.0 - cos_ijk) * (1.0 + cos_ijk));   // sin(acos(c))
         const double BOij_p4 = pow(BOij, ap.pval4), exp3ij = exp(-aj.pval3 * BOij_p4), fn7ij = 1.0 - exp3ij;
         const double BOjk_p4 = pow(BOjk, ap.pval4), exp3jk = exp(-aj.pval3 * BOjk_p4), fn7jk = 1.0 - exp3jk;
         const double exp7 = exp(-ap.pval7 * delta_ang), trm8 = 1.0 + exp6 + exp7;
         const double fn8j = aj.pval5 - (aj.pval5 - 1.0) * (2.0 + exp6) / trm8;
-        const double SBO = sum_SBO1 + (1.0 - prod_SBO) * (-delta_ang - ff.pval8 * nlpj);
-        double SBO2 = 0.0, CSBO2 = 0.0;
-        if (SBO > 0.0 && SBO <= 1.0) { SBO2 = pow(SBO, ff.pval9); CSBO2 = ff.pval9 * pow(SBO, ff.pval9 - 1.0); }
-        else if (SBO > 1.0 && SBO <= 2.0) { SBO2 = 2.0 - pow(2.0 - SBO, ff.pval9); CSBO2 = ff.pval9 * pow(2.0 - SBO, ff.pval9 - 1.0); }
-        else if (SBO > 2.0) SBO2 = 2.0;
-        const double ex10 = exp(-ff.pval10 * (2.0 - SBO2));
         const double theta0 = PI_ - ap.theta00 * (1.0 - ex10);
         const double theta_diff = theta0 - theta_ijk;
         const double exp2 = exp(-ap.pval2 * theta_diff * theta_diff);
         e5 += fn7ij * fn7jk * fn8j * (ap.pval1 - ap.pval1 * exp2);
-        const double Cf7ij = aj.pval3 * ap.pval4 * pow(BOij, ap.pval4 - 1.0) * exp3ij;
-        const double Cf7jk = aj.pval3 * ap.pval4 * pow(BOjk, ap.pval4 - 1.0) * exp3jk;
+        const double Cf7ij = aj.pval3 * ap.pval4 * (BOij_p4 / BOij) * exp3ij;                 // BO**(pval4-1) = BO**pval4 / BO
+        const double Cf7jk = aj.pval3 * ap.pval4 * (BOjk_p4 / BOjk) * exp3jk;
         const double Cf8j = (1.0 - aj.pval5) / (trm8 * trm8) * (ff.pval6 * exp6 * trm8 - (2.0 + exp6) * (ff.pval6 * exp6 - ap.pval7 * exp7));
         const double Ctheta0 = ff.pval10 * ap.theta00 * ex10;
-        const double dSBO1 = -8.0 * prod_SBO * (delta_ang + ff.pval8 * nlpj);
-        const double dSBO2 = (prod_SBO - 1.0) * (1.0 - ff.pval8 * dDj);
         const double CEval1 = Cf7ij * fn7jk * fn8j * ap.pval1 * (1.0 - exp2);
         const double CEval2 = fn7ij * Cf7jk * fn8j * ap.pval1 * (1.0 - exp2);
         const double CEval3 = fn7ij * fn7jk * Cf8j * ap.pval1 * (1.0 - exp2);
@@ -246,16 +248,19 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
         const double CEcoa3 = -ff.pcoa2 * exp_coa2 / (1.0 + exp_coa2) * PEcoa;
         const double CEcoa4 = -2.0 * ff.pcoa3 * ui * PEcoa, CEcoa5 = -2.0 * ff.pcoa3 * uk * PEcoa;
         // accumulate, pot.F90:509-541
-        cf1[oi] += CEpen2 + CEcoa1 - CEcoa4 + CEval1;      // ForceB on bond i-j
+        ai_cf += CEpen2 + CEcoa1 - CEcoa4 + CEval1;        // ForceB on bond i-j
         cf1[ok] += CEpen3 + CEcoa2 - CEcoa5 + CEval2;      // ForceB on bond j-k
         S_d1 += CEpen1 + CEcoa3 + CEval3 + CEval7; S_v6 += CEval6; S_v5 += CEval5;
-        cdn[oi] += CEcoa4; cdn[ok] += CEcoa5;              // cdbnd(i), cdbnd(k)
+        ai_cd += CEcoa4; cdn[ok] += CEcoa5;                // cdbnd(i), cdbnd(k)
         V3 fi, fk;
         angle_forces(CEval8, rij, nij, rjk, njk, fi, fk);
-        fnx[oi] += fi.x; fny[oi] += fi.y; fnz[oi] += fi.z;
+        ai_fx += fi.x; ai_fy += fi.y; ai_fz += fi.z;
         fnx[ok] += fk.x; fny[ok] += fk.y; fnz[ok] += fk.z;
         fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z;
       }
+      if (ai_cf != 0.0) cf1[oi] += ai_cf;
+      if (ai_cd != 0.0) cdn[oi] += ai_cd;
+      if (ai_fx != 0.0 || ai_fy != 0.0 || ai_fz != 0.0) { fnx[oi] += ai_fx; fny[oi] += ai_fy; fnz[oi] += ai_fz; }
     }
     if (S_d1 != 0.0 || S_v6 != 0.0 || S_v5 != 0.0)
       for (int n1 = 0; n1 < nj; ++n1) {
