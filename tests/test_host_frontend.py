@@ -193,3 +193,17 @@ def test_xyz_frame_is_byte_identical_to_the_reference_writer(case, steps, pq):
         assert a[:2] == b[:2]
     else:
         assert txt == ref
+
+
+def test_fortran_binding_module_compiles_against_the_reference_modules(tmp_path):
+    """bindings/rxmd_hip_mod.F90 (QEq_hip / FORCE_hip in the reference's argument shapes) must compile against the reference's own
+    `atoms` module; needs amdflang and the module files of the oracle/_ref serial build (this container only)"""
+    import shutil, subprocess
+    flang = "/opt/rocm/bin/amdflang"
+    mods = os.path.join(ROOT, "oracle", "_ref", "build_ser")
+    if not (os.path.exists(flang) and os.path.exists(os.path.join(mods, "atoms.mod"))):
+        pytest.skip("amdflang or the reference module files are not here")
+    for src in ("rxmd_hip_mod.F90", "smoke_c_abi.F90"):
+        r = subprocess.run([flang, "-cpp", "-DNOMPI", "-I" + mods, "-c", os.path.join(ROOT, "bindings", src), "-o", str(tmp_path / (src + ".o")),
+                            "-module-dir", str(tmp_path)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
