@@ -98,6 +98,15 @@ module rxmd_hip_mod
        real(c_double), intent(in) :: atype(*), pos(*), q(*)
        real(c_double), intent(out) :: f(*), pe(0:13)
      end function
+     integer(c_int) function rxmd_hip_last_qeq_iters(h) bind(c, name='rxmd_hip_last_qeq_iters')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+     end function
+     integer(c_int) function rxmd_hip_get_energy(h, ke, qsum, pe, astr6) bind(c, name='rxmd_hip_get_energy')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(out) :: ke, qsum, pe(0:13), astr6(6)
+     end function
   end interface
 
 contains
@@ -129,22 +138,26 @@ contains
 
   !> same arguments as the reference's QEq(atype,pos,q), src/qeq.F90:2,15-16
   subroutine QEq_hip(atype, pos, q)
-    use atoms, only: NBUFFER, NATOMS
+    use atoms, only: NBUFFER, NATOMS, nstep_qeq
     real(8), intent(in) :: atype(NBUFFER), pos(NBUFFER,3)
     real(8), intent(inout) :: q(NBUFFER)
     integer(c_int) :: rc
     rc = rxmd_hip_qeq_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, q)
     if (rc /= 0) call die('QEq', rc)
+    nstep_qeq = rxmd_hip_last_qeq_iters(rxmd_hip_handle)        ! printed by PRINTE, src/main.F90:261
   end subroutine
 
   !> same arguments as the reference's FORCE(atype,pos,f,q), src/pot.F90:2,9-11; fills PE(0:13) of module atoms
   subroutine FORCE_hip(atype, pos, f, q)
-    use atoms, only: NBUFFER, NATOMS, PE
+    use atoms, only: NBUFFER, NATOMS, PE, astr
     real(8), intent(in) :: atype(NBUFFER), q(NBUFFER), pos(NBUFFER,3)
     real(8), intent(inout) :: f(NBUFFER,3)
     integer(c_int) :: rc
+    real(c_double) :: ke, qsum, pe2(0:13), a6(6)
     rc = rxmd_hip_force_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, f, q, PE)
     if (rc /= 0) call die('FORCE', rc)
+    rc = rxmd_hip_get_energy(rxmd_hip_handle, ke, qsum, pe2, a6)   ! the virial this FORCE call added (src/pot.F90:65-72); reading resets it
+    astr(1:6) = astr(1:6) + a6(1:6)
   end subroutine
 
   !> the reference's error behaviour: message on unit 6, then stop (src/main.F90:402-407)

@@ -99,6 +99,8 @@ int rxmd_hip_force(rxmd_handle h, double pe[14]);
  * QEq every qstep, FORCE, vkick); mdmode 1 (NVE).  Call rxmd_hip_qeq + rxmd_hip_force once before
  * the first step, as main.F90:27-32 does. */
 int rxmd_hip_step(rxmd_handle h, int nsteps);
+/* nstep_qeq of the last QEq call (printed in the MDstep line, src/main.F90:261); negative = error */
+int rxmd_hip_last_qeq_iters(rxmd_handle h);
 /* The velocity scaling the reference's MD loop applies at its head when mod(nstep,sstep)==0 (src/main.F90:45-61), on the
  * device: mdmode 4 (v *= vsfact), 5 (rescale to treq_K; gke_per_atom = kinetic energy per atom of the last PRINTE, <= 0: the
  * current one), 7 (per element, ScaleTemperature :722-763), 8 (only beyond 5 %, AdjustTemperature :684-719); 7 and 8 remove the

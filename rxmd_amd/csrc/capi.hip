@@ -189,6 +189,12 @@ int rxmd_hip_step(rxmd_handle h, int nsteps) {
   });
 }
 
+int rxmd_hip_last_qeq_iters(rxmd_handle h) {
+  int n = 0;
+  const int rc = guarded(h, [&](Engine &e) { n = e.nstep_qeq; });
+  return rc ? rc : n;
+}
+
 int rxmd_hip_thermostat(rxmd_handle h, int mdmode, double treq_K, double vsfact, double gke_per_atom) {
   return guarded(h, [&](Engine &e) { e.thermostat(mdmode, treq_K, vsfact, gke_per_atom); });
 }

@@ -1,0 +1,45 @@
+"""Drop-in level 1 of INTEGRATION.md, end to end: the REFERENCE'S OWN driver (src/main.F90 and every other object of the serial
+build, unmodified) with its QEq / FORCE calls redirected through bindings/rxmd_hip_mod.F90 to librxmd_hip.so.  oracle/Makefile
+builds it as oracle/_ref/rxmd_hipdrv in the container that has the reference sources; here it runs on the GPU box like the
+reference would: geninit -> rxmd.in / ffield / DAT/rxff.bin -> MD loop -> MDstep lines and the xyz frame."""
+import os, shutil, subprocess, tempfile
+import numpy as np
+import pytest
+import oracle_api as oa
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def test_reference_driver_runs_on_the_hip_library():
+    drv, gen = os.path.join(REF, "rxmd_hipdrv"), os.path.join(REF, "geninit")
+    if not (os.path.exists(drv) and os.path.exists(gen)):
+        pytest.skip("oracle/_ref/rxmd_hipdrv was not built (needs the reference sources + amdflang: make -C oracle ref)")
+    g = np.load(os.path.join(oa.GOLD, "rdx168_md10.npz"))
+    tmp = tempfile.mkdtemp(prefix="dropin_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(oa.INP, "rdx.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(oa.INP, "ffield_rdx"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(oa.INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "1", "1", "1"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        p = subprocess.run([drv, "--ntime_step", "10", "--pstep", "1", "--fstep", "10"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert "successfully finished" in p.stdout, p.stdout[-3000:]
+        rows = [[float(x) for x in l.split()[1:13]] for l in p.stdout.split("\n") if l.startswith("MDstep:")]
+        rows = np.array(rows); ref = g["mdstep"][:len(rows), :12]
+        assert len(rows) == 10
+        # MDstep: step, total / potential / kinetic energy per atom (es13.5), six energy groups (es11.3), temperature, pressure (f8.2)
+        assert np.allclose(rows[:, 1:3], ref[:, 1:3], rtol=2e-6)
+        assert np.allclose(rows[:, 3], ref[:, 3], rtol=2e-3, atol=1e-9)            # kinetic energy: 6 digits of a 1e-4 number
+        assert np.allclose(rows[:, 4:10], ref[:, 4:10], rtol=2e-3, atol=1e-6)
+        assert np.allclose(rows[:, 11], ref[:, 11], atol=0.011)                     # pressure [GPa]: the virial came from the engine
+        # the trajectory frame the driver wrote after 10 steps against the one the unmodified reference wrote
+        mine = open(os.path.join(tmp, "DAT", "000000010.xyz")).read().split("\n")
+        theirs = str(g["xyz_last"]).split("\n")
+        assert mine[:2] == theirs[:2] and len(mine) == len(theirs)
+        for a, b in zip(mine[2:-1], theirs[2:-1]):
+            assert a[:3] == b[:3] and a[47:] == b[47:]                              # element, global id
+            assert np.allclose([float(x) for x in a[3:47].split()], [float(x) for x in b[3:47].split()], atol=2.1e-5, rtol=0)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
