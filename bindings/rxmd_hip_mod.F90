@@ -13,7 +13,7 @@ module rxmd_hip_mod
   use iso_c_binding
   implicit none
   private
-  public :: rxmd_config, rxmd_hip_init, rxmd_hip_finalize, QEq_hip, FORCE_hip, rxmd_hip_handle
+  public :: rxmd_config, rxmd_hip_init, rxmd_hip_finalize, QEq_hip, PQEq_hip, FORCE_hip, rxmd_hip_handle
   public :: rxmd_hip_create, rxmd_hip_destroy, rxmd_hip_qeq, rxmd_hip_force, rxmd_hip_step, rxmd_hip_set_atoms_rxff, &
             rxmd_hip_get_atoms_rxff, rxmd_hip_last_error, rxmd_hip_default_config, rxmd_hip_qeq_arrays, rxmd_hip_force_arrays
 
@@ -98,6 +98,20 @@ module rxmd_hip_mod
        real(c_double), intent(in) :: atype(*), pos(*), q(*)
        real(c_double), intent(out) :: f(*), pe(0:13)
      end function
+     integer(c_int) function rxmd_hip_pqeq_arrays(h, nbuffer, natoms, atype, pos, q, spos) bind(c, name='rxmd_hip_PQEq')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: nbuffer, natoms
+       real(c_double), intent(in) :: atype(*), pos(*)
+       real(c_double), intent(inout) :: q(*), spos(*)
+     end function
+     integer(c_int) function rxmd_hip_force_pqeq_arrays(h, nbuffer, natoms, atype, pos, f, q, spos, pe) bind(c, name='rxmd_hip_FORCE_pqeq')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: nbuffer, natoms
+       real(c_double), intent(in) :: atype(*), pos(*), q(*), spos(*)
+       real(c_double), intent(out) :: f(*), pe(0:13)
+     end function
      integer(c_int) function rxmd_hip_last_qeq_iters(h) bind(c, name='rxmd_hip_last_qeq_iters')
        import :: c_ptr, c_int
        type(c_ptr), value :: h
@@ -112,8 +126,10 @@ module rxmd_hip_mod
 contains
 
   !> call once after GETPARAMS/INITSYSTEM (reference src/main.F90:20-23) with the module-global run parameters
-  subroutine rxmd_hip_init(ffpath, lata, latb, latc, lalpha, lbeta, lgamma, vprocs, myid, isQEq, NMAXQEq, QEq_tol, qstep, dt_fs, device)
+  subroutine rxmd_hip_init(ffpath, lata, latb, latc, lalpha, lbeta, lgamma, vprocs, myid, isQEq, NMAXQEq, QEq_tol, qstep, dt_fs, device, pqeqpath)
     character(len=*), intent(in) :: ffpath
+    character(len=*), intent(in), optional :: pqeqpath          ! PQEqParmPath when isPQEq (cmdline.F90:112-128)
+    character(kind=c_char, len=:), allocatable, target, save :: cpq
     real(8), intent(in) :: lata, latb, latc, lalpha, lbeta, lgamma, QEq_tol, dt_fs
     integer, intent(in) :: vprocs(3), myid, isQEq, NMAXQEq, qstep, device
     type(rxmd_config) :: cfg
@@ -126,6 +142,12 @@ contains
     cfg%vprocs = vprocs; cfg%myid = myid
     cfg%isQEq = isQEq; cfg%NMAXQEq = NMAXQEq; cfg%QEq_tol = QEq_tol; cfg%qstep = qstep; cfg%dt_fs = dt_fs
     cfg%device = device
+    if (present(pqeqpath)) then
+       if (len_trim(pqeqpath) > 0) then
+          cpq = trim(pqeqpath)//c_null_char
+          cfg%pqeq_path = c_loc(cpq)
+       endif
+    endif
     rc = rxmd_hip_create(cfg, rxmd_hip_handle)
     if (rc /= 0) call die('rxmd_hip_create', rc)
   end subroutine
@@ -147,14 +169,29 @@ contains
     nstep_qeq = rxmd_hip_last_qeq_iters(rxmd_hip_handle)        ! printed by PRINTE, src/main.F90:261
   end subroutine
 
+  !> same arguments as the reference's PQEq(atype,pos,q), src/pqeq.F90:2; the shell displacements are module atoms' spos
+  subroutine PQEq_hip(atype, pos, q)
+    use atoms, only: NBUFFER, NATOMS, nstep_qeq, spos
+    real(8), intent(in) :: atype(NBUFFER), pos(NBUFFER,3)
+    real(8), intent(inout) :: q(NBUFFER)
+    integer(c_int) :: rc
+    rc = rxmd_hip_pqeq_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, q, spos)
+    if (rc /= 0) call die('PQEq', rc)
+    nstep_qeq = rxmd_hip_last_qeq_iters(rxmd_hip_handle)
+  end subroutine
+
   !> same arguments as the reference's FORCE(atype,pos,f,q), src/pot.F90:2,9-11; fills PE(0:13) of module atoms
   subroutine FORCE_hip(atype, pos, f, q)
-    use atoms, only: NBUFFER, NATOMS, PE, astr
+    use atoms, only: NBUFFER, NATOMS, PE, astr, isPQEq, spos
     real(8), intent(in) :: atype(NBUFFER), q(NBUFFER), pos(NBUFFER,3)
     real(8), intent(inout) :: f(NBUFFER,3)
     integer(c_int) :: rc
     real(c_double) :: ke, qsum, pe2(0:13), a6(6)
-    rc = rxmd_hip_force_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, f, q, PE)
+    if (isPQEq) then
+       rc = rxmd_hip_force_pqeq_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, f, q, spos, PE)
+    else
+       rc = rxmd_hip_force_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, f, q, PE)
+    endif
     if (rc /= 0) call die('FORCE', rc)
     rc = rxmd_hip_get_energy(rxmd_hip_handle, ke, qsum, pe2, a6)   ! the virial this FORCE call added (src/pot.F90:65-72); reading resets it
     astr(1:6) = astr(1:6) + a6(1:6)

@@ -119,6 +119,10 @@ int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], 
  * download; they are what a Fortran `QEq`/`FORCE` shim calls (bindings/rxmd_hip_mod.F90). */
 int rxmd_hip_QEq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *q);
 int rxmd_hip_FORCE(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *f, const double *q, double pe[14]);
+/* the same for `subroutine PQEq(atype,pos,q)` (src/pqeq.F90:2) and FORCE with isPQEq: the shell displacements spos(NBUFFER,3)
+ * of module atoms (module.F90:286) go in, PQEq returns them moved (update_shell_positions, pqeq.F90:184-259) */
+int rxmd_hip_PQEq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *q, double *spos);
+int rxmd_hip_FORCE_pqeq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *f, const double *q, const double *spos, double pe[14]);
 
 /* ---- introspection for tests, roofline accounting and the timers table (main.F90:135-182) ---- */
 typedef struct rxmd_stats {

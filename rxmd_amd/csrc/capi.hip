@@ -265,6 +265,37 @@ int rxmd_hip_FORCE(rxmd_handle h, int nbuffer, int natoms, const double *atype, 
   });
 }
 
+// PQEq in the reference's shapes: spos(NBUFFER,3) column-major travels with the call (the reference keeps it in module atoms and
+// moves it with the atoms in COPYATOMS, comm.F90:122-167)
+static void upload_shells(Engine &e, int nbuffer, int natoms, const double *spos) {
+  if (!e.ff.pqeq) throw EngineError(RXMD_E_STATE, "the engine was created without a PQEq parameter file");
+  for (int a = 0; a < 3; ++a) RX_HIP(hipMemcpy(e.shl[a], spos + a * static_cast<size_t>(nbuffer), sizeof(double) * natoms, hipMemcpyHostToDevice));
+}
+int rxmd_hip_PQEq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *q, double *spos) {
+  if (!atype || !pos || !q || !spos) return RXMD_E_ARG;
+  return guarded(h, [&](Engine &e) {
+    upload_reference_arrays(e, nbuffer, natoms, atype, pos, q);
+    upload_shells(e, nbuffer, natoms, spos);
+    e.qeq();
+    RX_HIP(hipMemcpy(q, e.q, sizeof(double) * natoms, hipMemcpyDeviceToHost));
+    for (int a = 0; a < 3; ++a) RX_HIP(hipMemcpy(spos + a * static_cast<size_t>(nbuffer), e.shl[a], sizeof(double) * natoms, hipMemcpyDeviceToHost));
+  });
+}
+int rxmd_hip_FORCE_pqeq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *f, const double *q, const double *spos, double pe[14]) {
+  if (!atype || !pos || !f || !q || !spos) return RXMD_E_ARG;
+  return guarded(h, [&](Engine &e) {
+    upload_reference_arrays(e, nbuffer, natoms, atype, pos, q);
+    upload_shells(e, nbuffer, natoms, spos);
+    e.force();
+    std::vector<double> tmp(natoms);
+    for (int a = 0; a < 3; ++a) {
+      RX_HIP(hipMemcpy(tmp.data(), e.frc[a], sizeof(double) * natoms, hipMemcpyDeviceToHost));
+      for (int i = 0; i < natoms; ++i) f[a * static_cast<size_t>(nbuffer) + i] = tmp[i];
+    }
+    if (pe) std::memcpy(pe, e.pe, sizeof(double) * 14);
+  });
+}
+
 // ---- introspection ----
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out) {
   if (!out) return RXMD_E_ARG;

@@ -43,3 +43,39 @@ def test_reference_driver_runs_on_the_hip_library():
             assert np.allclose([float(x) for x in a[3:47].split()], [float(x) for x in b[3:47].split()], atol=2.1e-5, rtol=0)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_reference_driver_with_pqeq_on_the_hip_library():
+    """the same with --pqeq: PQEq(atype,pos,q) -> PQEq_hip, FORCE -> FORCE_hip carrying module atoms' spos in and out"""
+    drv, gen = os.path.join(REF, "rxmd_hipdrv"), os.path.join(REF, "geninit")
+    if not (os.path.exists(drv) and os.path.exists(gen)):
+        pytest.skip("oracle/_ref/rxmd_hipdrv was not built (needs the reference sources + amdflang: make -C oracle ref)")
+    g = np.load(os.path.join(oa.GOLD, "sicnp547_pqeq_md5.npz"))
+    tmp = tempfile.mkdtemp(prefix="dropin_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(oa.INP, "sicnp.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(oa.INP, "ffield_sicnp"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(oa.INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        shutil.copy(oa.PQEQ_SICNP, os.path.join(tmp, "pqeq.in"))
+        subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "1", "1", "1"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        p = subprocess.run([drv, "--ntime_step", "5", "--pstep", "1", "--fstep", "5", "--pqeq", "pqeq.in"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600)
+        assert "successfully finished" in p.stdout, p.stdout[-3000:]
+        rows = np.array([[float(x) for x in l.split()[1:13]] for l in p.stdout.split("\n") if l.startswith("MDstep:")])
+        ref = g["mdstep"][:len(rows), :12]
+        assert len(rows) == 5
+        assert np.allclose(rows[0, 1:3], ref[0, 1:3], rtol=2e-6)            # step 0: shells on the cores, no beyond-cutoff lookups (DESIGN 5b)
+        assert np.allclose(rows[:, 1:3], ref[:, 1:3], rtol=2e-5)            # later steps: the reference's stale-value artefact is inside this
+        assert np.allclose(rows[:, 4:10], ref[:, 4:10], rtol=5e-3, atol=1e-5)
+        mine = open(os.path.join(tmp, "DAT", "000000005.xyz")).read().split("\n")
+        theirs = str(g["xyz_last"]).split("\n")
+        assert mine[:2] == theirs[:2] and len(mine) == len(theirs)
+        for a, b in zip(mine[2:-1], theirs[2:-1]):
+            assert len(a) == len(b) and a[:3] == b[:3] and a[83:92] == b[83:92]
+            va = np.array([float(t) for t in a[3:83].split()] + [float(t) for t in a[92:].split()])
+            vb = np.array([float(t) for t in b[3:83].split()] + [float(t) for t in b[92:].split()])
+            assert np.abs(va[:3] - vb[:3]).max() <= 1e-5                    # positions after 5 steps at the run tolerance 1e-7
+            assert abs(va[3] - vb[3]) <= 1e-2 and np.abs(va[4:] - vb[4:]).max() <= 1e-3   # charge, shell displacement (artefact-sized bounds)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
