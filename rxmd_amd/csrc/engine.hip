@@ -256,7 +256,7 @@ void Engine::alloc_device() {
   spmv_cell = (std::getenv("RXMD_SPMV_CELL") != nullptr);
   if (spmv_cell) dmalloc(nb10s, static_cast<size_t>(rows10) * S10);
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
-  partials_cap = std::max<size_t>(size_t(1) << 16, static_cast<size_t>(rows10) + 16384);
+  partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap); dmalloc(scal, 64);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
   dmalloc(d_err, 4);

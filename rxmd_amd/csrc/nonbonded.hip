@@ -27,13 +27,16 @@ __device__ inline double wave_sum_n(double v) {
 #ifndef NB_UNR
 #define NB_UNR 8      // entries per lane and pass: a whole RDX row in one pass (measured 4.83 / 4.59 / 4.45 / 4.10 ms at 1 / 2 / 4 / 8)
 #endif
-__global__ void __launch_bounds__(256) k_nonbond(int N, int S10, DevFF ff, const int *__restrict__ nb10, const int *__restrict__ n10,
+#ifndef NB_WPB
+#define NB_WPB 8      // rows per workgroup (measured 4.08 / 3.73 / 4.35 ms at 4 / 8 / 16)
+#endif
+__global__ void __launch_bounds__(64 * NB_WPB) k_nonbond(int N, int S10, DevFF ff, const int *__restrict__ nb10, const int *__restrict__ n10,
                                                   const double4 *__restrict__ pk, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                   const double *__restrict__ q, const int *__restrict__ type,
                                                   double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
-  __shared__ double sm[4][3], sv[4][6];
+  __shared__ double sm[NB_WPB][3], sv[NB_WPB][6];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x < 24) sv[threadIdx.x / 6][threadIdx.x % 6] = 0.0;
+  if (threadIdx.x < 6 * NB_WPB) sv[threadIdx.x / 6][threadIdx.x % 6] = 0.0;
   __syncthreads();
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
   double e11 = 0.0, e12 = 0.0, e13 = 0.0;
@@ -91,12 +94,13 @@ __global__ void __launch_bounds__(256) k_nonbond(int N, int S10, DevFF ff, const
   __syncthreads();
   if (threadIdx.x < 3) {
     double s = 0.0;
-    for (int k = 0; k < 4; ++k) s += sm[k][threadIdx.x];
+    for (int k = 0; k < NB_WPB; ++k) s += sm[k][threadIdx.x];
     if (s != 0.0) atomicAdd(pe + 11 + threadIdx.x, s);
   }
   if (threadIdx.x >= 64 && threadIdx.x < 70) {      // pe = scal + 32: the stress accumulators sit at scal + 48
     const int c = threadIdx.x - 64;
-    const double s = sv[0][c] + sv[1][c] + sv[2][c] + sv[3][c];
+    double s = 0.0;
+    for (int k = 0; k < NB_WPB; ++k) s += sv[k][c];
     if (s != 0.0) atomicAdd(pe + 16 + c, s);
   }
 }
@@ -107,7 +111,7 @@ void Engine::nonbonded() {
     k_sorted_charge<<<nblk(G, 256), 256, 0, stream>>>(G, perm, q, sorted_xyzi);
   } else
     k_sorted_charge<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, q, sorted_xyzi);
-  k_nonbond<<<nblk(N, 4), 256, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, pos[0], pos[1], pos[2], q, type, frc[0], frc[1], frc[2], scal + 32);
+  k_nonbond<<<nblk(N, NB_WPB), 64 * NB_WPB, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, pos[0], pos[1], pos[2], q, type, frc[0], frc[1], frc[2], scal + 32);
 }
 
 }  // namespace rxmd

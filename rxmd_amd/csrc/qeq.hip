@@ -92,14 +92,16 @@ __device__ inline void row_epilogue(int row, double as, double at, double gs_, d
 
 // STORE (qeq_mode 1): additionally keep the raw row sums (all columns / ghost columns) so that the next gradient and Est
 // follow from  H.(q + l h) = H.q + l H.h  with N-sized vector kernels instead of a second matrix pass.
-// One wavefront = one row (the launch covers the rows exactly: nblk(N, 4) workgroups of 4 wavefronts).  The pass is bound by
+// One wavefront = one row (the launch covers the rows exactly), 16 rows per workgroup: workgroup dispatch is not free at a million
+// wavefronts per pass (measured 1.25 / 1.24 / 1.15-1.19 / 1.13 / 1.08-1.11 ms at 1 / 2 / 4 / 8 / 16 wavefronts per workgroup; splitting
+// a row over 2 or 4 wavefronts instead: 1.22 / 2.19 ms).  The pass is bound by
 // LATENCY x occupancy, not by instruction issue: a wavefront lives for a chain of dependent memory round trips (row length ->
 // the two streams -> the gathers -> the operands of the tail), so (a) the tail operands are requested first, next to the row
 // length, (b) four batches of 64 entries are in flight instead of eight, which brings the kernel from 99 to <= 80 VGPRs and from
 // 4 to 6 wavefronts per SIMD (measured on one box: 1.276 ms -> 1.21 with (a), 1.157 with (b), 1.06-1.12 with both), (c) PQEq is
 // a template parameter so that the plain kernel does not carry its code.
 template <int MODE, bool STORE, bool PQ>
-__global__ void __launch_bounds__(256) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
+__global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
                                                const double *__restrict__ scal, double *__restrict__ partials,
@@ -537,7 +539,8 @@ void Engine::qeq() {
   const int nmax = (cfg.isQEq == 1) ? cfg.NMAXQEq : 1;
   // one wavefront per row, four rows per workgroup: measured faster than a persistent grid-stride launch (1.10 vs 1.28 ms
   // per pass at 979,776 rows) -- many short waves overlap each other's load / gather / reduce phases
-  const int rb = nblk(N, 4);
+  constexpr int SPMV_WPB = 16;                   // wavefronts (= rows) per workgroup of the matrix pass
+  const int rb = nblk(N, SPMV_WPB);
   const int vb = std::min(nblk(N, 256), 2048);
   // cell-tiled pass (k_spmv_cell) whenever the neighbourhood of a cell fits the 15-bit local index and the LDS stage
   const size_t lds_bytes = (static_cast<size_t>(nbhd_max) + 64) / 64 * 64 * sizeof(double2);
@@ -560,8 +563,8 @@ void Engine::qeq() {
 #define RX_PASS(M, S)                                                                                                                        \
   do {                                                                                                                                       \
     if (use_cell) k_spmv_cell<M, S><<<grid.ncell, cell_bs, lds_bytes, stream>>>(N, S10, grid, dff, cellstart, perm, nb10s, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg); \
-    else if (ff.pqeq) k_spmv<M, S, true><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
-    else k_spmv<M, S, false><<<rb, 256, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
+    else if (ff.pqeq) k_spmv<M, S, true><<<rb, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
+    else k_spmv<M, S, false><<<rb, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }

@@ -40,7 +40,8 @@ def test_reference_driver_runs_on_the_hip_library():
         assert mine[:2] == theirs[:2] and len(mine) == len(theirs)
         for a, b in zip(mine[2:-1], theirs[2:-1]):
             assert a[:3] == b[:3] and a[47:] == b[47:]                              # element, global id
-            assert np.allclose([float(x) for x in a[3:47].split()], [float(x) for x in b[3:47].split()], atol=2.1e-5, rtol=0)
+            assert np.allclose([float(x) for x in a[3:39].split()], [float(x) for x in b[3:39].split()], atol=2.1e-5, rtol=0)   # positions, f12.5
+            assert abs(float(a[39:47]) - float(b[39:47])) <= 1.1e-3                                                              # charge, f8.3
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
