@@ -232,7 +232,33 @@ def make_thermo():
         shutil.rmtree(tmp)
 
 
+def make_minimiser():
+    """mdmode 10: the reference's geometry minimiser (src/cg.F90: bracket, golden-section line minimisation, Polak-Ribiere) on
+    RDX-168; it calls QEq + FORCE some sixty times and writes DAT/000000000.xyz when the energy has converged."""
+    import resource
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(INP, "rdx.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(INP, "ffield_rdx"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        with open(os.path.join(tmp, "rxmd.in"), "a") as f:
+            f.write("CG_tol 1.d-5\n")
+        run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "1", "1", "1"], tmp)
+        p = subprocess.run([os.path.join(REFBIN, "rxmd"), "--mdmode", "10", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], cwd=tmp,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY)))
+        assert "successfully finished structural optimization" in p.stdout, p.stdout[-2000:]
+        xyz = open(os.path.join(tmp, "DAT", "000000000.xyz")).read()
+        np.savez_compressed(os.path.join(HERE, "rdx168_minimiser.npz"), xyz=np.array(xyz), stdout_tail=np.array(p.stdout[-1500:]))
+        print("rdx168_minimiser", len(xyz))
+    finally:
+        shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["minimiser"]:
+        make_minimiser(); sys.exit(0)
     if sys.argv[1:] == ["thermo"]:
         make_thermo(); sys.exit(0)
     for n in (sys.argv[1:] or list(CASES)):

@@ -80,3 +80,35 @@ def test_reference_driver_with_pqeq_on_the_hip_library():
             assert abs(va[3] - vb[3]) <= 1e-2 and np.abs(va[4:] - vb[4:]).max() <= 1e-3   # charge, shell displacement (artefact-sized bounds)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_reference_minimiser_runs_on_the_hip_library():
+    """mdmode 10: the reference's own geometry minimiser (src/cg.F90, unmodified algorithm: bracket, golden section, Polak-Ribiere)
+    with its QEq / FORCE calls redirected to the HIP library; the minimised structure must be the one the reference finds"""
+    import resource
+    drv, gen = os.path.join(REF, "rxmd_hipdrv"), os.path.join(REF, "geninit")
+    if not (os.path.exists(drv) and os.path.exists(gen)):
+        pytest.skip("oracle/_ref/rxmd_hipdrv was not built (needs the reference sources + amdflang: make -C oracle ref)")
+    g = np.load(os.path.join(oa.GOLD, "rdx168_minimiser.npz"))
+    tmp = tempfile.mkdtemp(prefix="dropin_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(oa.INP, "rdx.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(oa.INP, "ffield_rdx"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(oa.INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        with open(os.path.join(tmp, "rxmd.in"), "a") as f:
+            f.write("CG_tol 1.d-5\n")
+        subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "1", "1", "1"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        p = subprocess.run([drv, "--mdmode", "10", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=900, preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY)))
+        assert "successfully finished structural optimization" in p.stdout, p.stdout[-3000:]
+        mine = open(os.path.join(tmp, "DAT", "000000000.xyz")).read().split("\n")
+        theirs = str(g["xyz"]).split("\n")
+        assert mine[:2] == theirs[:2] and len(mine) == len(theirs)
+        for a, b in zip(mine[2:-1], theirs[2:-1]):
+            assert a[:3] == b[:3] and a[47:] == b[47:]
+            # the golden-section search stops at a relative step tolerance of 1e-6 (cg.F90:16): the two minima agree to ~1e-4 A
+            assert np.allclose([float(x) for x in a[3:39].split()], [float(x) for x in b[3:39].split()], atol=3e-4, rtol=0)
+            assert abs(float(a[39:47]) - float(b[39:47])) <= 1.1e-3
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
