@@ -225,6 +225,17 @@ int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], 
 // ---- the reference's own argument shapes (QEq(atype,pos,q) qeq.F90:2 ; FORCE(atype,pos,f,q) pot.F90:2) ----
 static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const double *atype, const double *pos, const double *q) {
   if (natoms < 1 || nbuffer < natoms) throw EngineError(RXMD_E_ARG, "bad natoms/nbuffer");
+  // FORCE right after QEq (src/main.F90:77-84) hands over the same atoms: keep ghosts, cells and both lists, refresh the charges only
+  if (e.atoms_set && e.lists_valid && natoms == e.N && e.last_atype.size() == static_cast<size_t>(natoms)) {
+    bool same = std::memcmp(e.last_atype.data(), atype, sizeof(double) * natoms) == 0;
+    for (int a = 0; a < 3 && same; ++a) same = std::memcmp(e.last_pos[a].data(), pos + a * static_cast<size_t>(nbuffer), sizeof(double) * natoms) == 0;
+    if (same) {
+      if (q) RX_HIP(hipMemcpy(e.q, q, sizeof(double) * natoms, hipMemcpyHostToDevice));
+      return;
+    }
+  }
+  e.last_atype.assign(atype, atype + natoms);
+  for (int a = 0; a < 3; ++a) e.last_pos[a].assign(pos + a * static_cast<size_t>(nbuffer), pos + a * static_cast<size_t>(nbuffer) + natoms);
   std::vector<double> rec(10 * static_cast<size_t>(natoms), 0.0);
   for (int i = 0; i < natoms; ++i) {
     const double r[3] = {pos[i], pos[static_cast<size_t>(nbuffer) + i], pos[2 * static_cast<size_t>(nbuffer) + i]};   // pos(NBUFFER,3) column-major

@@ -151,6 +151,7 @@ struct Engine {
 
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
+  std::vector<double> last_atype, last_pos[3];    // what the array-shaped entry points uploaded last (capi.hip)
   rxmd_stats st{};
   int nstep_qeq = 0; double last_est = 0;
   long long step_count = 0;
