@@ -144,8 +144,12 @@ void Engine::force() {
   double *pe_d = scal + 32;
   RX_HIP(hipMemsetAsync(pe_d, 0, sizeof(double) * 16, stream));
   hipEventRecord(ev[2], stream);
+  // the ghost-charge halo needs nothing from the bond orders and they need no charges: on a multi-rank run the exchange goes to
+  // the second stream and meets the main stream again in front of the nonbonded kernel
+  if (multi()) on_comm_stream([&] { charge_halo(); }); else charge_halo();
   bond_orders();
   hipEventRecord(ev[3], stream);
+  if (multi()) join_comm_stream();
   if (ff.pqeq) nonbonded_pqeq(); else nonbonded();     // pot.F90:48-52
   hipEventRecord(ev[4], stream);
   bonded_energies();

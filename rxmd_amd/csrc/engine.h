@@ -150,6 +150,18 @@ struct Engine {
   double pe[14] = {0}, astr[6] = {0};
 
   hipStream_t stream = nullptr;
+  // second stream for the halo exchanges that overlap with compute (multi-rank): pack / RCCL send-recv / unpack run here while
+  // the main stream works on what does not need the ghosts yet; events order the two (engine.hip: on_comm_stream)
+  hipStream_t comm_stream = nullptr; hipEvent_t ev_main = nullptr, ev_comm = nullptr;
+  template <class F> void on_comm_stream(F &&body) {          // body runs with `stream` == comm_stream, after everything queued on the main stream so far
+    RX_HIP(hipEventRecord(ev_main, stream));
+    RX_HIP(hipStreamWaitEvent(comm_stream, ev_main, 0));
+    std::swap(stream, comm_stream);
+    try { body(); } catch (...) { std::swap(stream, comm_stream); throw; }
+    std::swap(stream, comm_stream);
+    RX_HIP(hipEventRecord(ev_comm, comm_stream));
+  }
+  void join_comm_stream() { RX_HIP(hipStreamWaitEvent(stream, ev_comm, 0)); }   // main stream waits for what on_comm_stream queued
   hipEvent_t ev[8] = {};
   std::vector<double> last_atype, last_pos[3];    // what the array-shaped entry points uploaded last (capi.hip)
   rxmd_stats st{};
@@ -163,6 +175,8 @@ struct Engine {
   int get_atoms_rxff(double *rec10, int capacity);
   void build_ghosts_and_lists(bool qeq_prepass = false);   // COPYATOMS(MODE_COPY) + LINKEDLIST + NEIGHBORLIST + 10 A list/hessian, once per step
   void qeq_start_vectors();        // qs, qt, hs, ht of qeq.F90:36-63 and their cell-sorted copy (before the list sweep that uses them)
+  int *rows_int = nullptr, *rows_bnd = nullptr; int n_bnd = 0; bool rows_split_pending = false;   // interior / boundary rows (multi-rank)
+  bool rows_split_pending_invalid() const { return n_bnd < 0 || n_bnd > N; }
   bool sums_from_list = false;     // the list sweep left H.(qs,qt) of the CG start vector in sall / sgh
   void qeq();
   void force();
@@ -199,6 +213,7 @@ struct Engine {
   void fold_ghost_forces();                         // CPBK
   void bond_orders();
   void bonded_energies();
+  void charge_halo();
   void nonbonded();
   void pqeq_sorted_shells();      // ghost shells <- owners, cell-sorted copy (MODE_COPY payload of spos, comm.F90:129-131)
   void pqeq_update_shells();      // update_shell_positions, pqeq.F90:184-259

@@ -91,6 +91,8 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw EngineError(RXMD_E_HIP, "no HIP device visible: this engine has no CPU path");
   RX_HIP(hipSetDevice(cfg.device));
   RX_HIP(hipStreamCreate(&stream));
+  RX_HIP(hipStreamCreate(&comm_stream));
+  RX_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   for (auto &e : ev) RX_HIP(hipEventCreate(&e));
 }
 
@@ -98,6 +100,9 @@ Engine::~Engine() {
   rccl_destroy();
   free_device();
   for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+  if (ev_main) (void)hipEventDestroy(ev_main);
+  if (ev_comm) (void)hipEventDestroy(ev_comm);
+  if (comm_stream) (void)hipStreamDestroy(comm_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -253,6 +258,7 @@ void Engine::alloc_device() {
   dmalloc(etor, ns); dmalloc(econ, ns); dmalloc(epen, ns); dmalloc(ecoa, ns);
   dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
+  dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
   spmv_cell = (std::getenv("RXMD_SPMV_CELL") != nullptr);
   if (spmv_cell) dmalloc(nb10s, static_cast<size_t>(rows10) * S10);
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
@@ -280,6 +286,7 @@ void Engine::free_device() {
   dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
+  dfree(rows_int); dfree(rows_bnd);
   dfree(nb10); dfree(nb10s); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }

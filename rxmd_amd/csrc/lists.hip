@@ -7,6 +7,8 @@
 // fastest, so a (dx,dy) column of the stencil is ONE contiguous range of the sorted array.
 #include "engine.h"
 
+#include <hipcub/hipcub.hpp>
+
 namespace rxmd {
 
 static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
                                                  int *__restrict__ nb10, unsigned short *__restrict__ nb10s, double *__restrict__ hess, int *__restrict__ n10, int *err,
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
-                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh) {
+                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag) {
   // dynamic LDS: [4][128] queue of accepted candidates (sorted position, neighbourhood position), [4][128] chunk table, then [4][S10] 16-bit rows
   extern __shared__ int lds_all[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   // xs0 != nullptr: the sweep also forms the row sums H.(qs,qt) of the CG start vector (qt = 0) -- the matrix pass that
   // get_gradient would need before the first iteration (qeq.F90:87) comes for free while the entries are in registers
   double ra = 0.0, rg = 0.0;
+  bool anyghost = false;                          // does the row have a ghost partner (boundary row of the domain)?
   int cnt = 0;      // entries written so far
   int qn = 0;       // accepted candidates waiting in the queue
   int loff = 0;     // candidates in the stencil columns already swept = position of this column inside the neighbourhood
@@ -190,6 +193,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
           ra += h * qsj;
           if (PQ) rg += hc * qsj; else if (j >= N) rg += h * qsj;
         }
+        anyghost |= (j >= N);
         nb10[row + slot] = static_cast<int>(ent);
         if (nb10s) srow[slot] = static_cast<unsigned short>((qe.y & 0x7fff) | (j >= N ? 0x8000 : 0));
         hess[row + slot] = h;
@@ -283,7 +287,15 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
     if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) hsc[row + cnt + lane] = 0.0;
     if (lane == 0) pqrow[i] = make_double4(p_f, p_hz, p_bz, p_ss);
   }
+  { const unsigned long long mg = __ballot(anyghost); if (lane == 0 && rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0; }
   if (lane == 0) { n10[i] = cnt; if (loff > __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&err[2], loff); }
+}
+
+// boundary rows keep their order, interior rows too: index lists for the two launches of the matrix pass
+__global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__restrict__ scan, int *__restrict__ rows_int, int *__restrict__ rows_bnd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (flag[i]) rows_bnd[scan[i]] = i; else rows_int[i - scan[i]] = i;
 }
 
 void Engine::build_bonded_list() {
@@ -300,10 +312,18 @@ void Engine::build_list10() {
 #define RX_LIST10(SC, PQF)                                                                                                                     \
   k_list10<SC, PQF><<<nblk(N, 4), 256, lds, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, \
                                                       hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, \
-                                                      sums_from_list ? xs : nullptr, sall, sgh)
+                                                      sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
 #undef RX_LIST10
+  if (multi()) {     // interior rows (no ghost partner) and boundary rows: the matrix pass does the former while the vector halo is in flight
+    RX_HIP(hipMemsetAsync(flags + N, 0, sizeof(int), stream));
+    size_t tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, N + 1, stream));
+    k_split_rows<<<nblk(N, 256), 256, 0, stream>>>(N, flags, scanout, rows_int, rows_bnd);
+    RX_HIP(hipMemcpyAsync(&n_bnd, scanout + N, sizeof(int), hipMemcpyDeviceToHost, stream));
+    rows_split_pending = true;          // n_bnd is valid after the next stream synchronisation (check_device_error of the list build)
+  }
 }
 
 }  // namespace rxmd

@@ -105,12 +105,16 @@ __global__ void __launch_bounds__(64 * NB_WPB) k_nonbond(int N, int S10, DevFF f
   }
 }
 
-void Engine::nonbonded() {
-  if (multi()) {                                    // ghost charges through the staged exchange, then the plain permuted copy
+// ghost charges (MODE_COPY payload, comm.F90:135) and their cell-sorted copy; multi-rank: through the staged exchange
+void Engine::charge_halo() {
+  if (multi()) {
     halo_staged(q, 1);
     k_sorted_charge<<<nblk(G, 256), 256, 0, stream>>>(G, perm, q, sorted_xyzi);
   } else
     k_sorted_charge<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, q, sorted_xyzi);
+}
+
+void Engine::nonbonded() {
   k_nonbond<<<nblk(N, NB_WPB), 64 * NB_WPB, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, pos[0], pos[1], pos[2], q, type, frc[0], frc[1], frc[2], scal + 32);
 }
 

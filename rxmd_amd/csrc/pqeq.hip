@@ -205,8 +205,6 @@ void Engine::efield_force() {
 }
 
 void Engine::nonbonded_pqeq() {
-  if (multi()) { halo_staged(q, 1); k_sorted_charge_p<<<nblk(G, 256), 256, 0, stream>>>(G, perm, q, sorted_xyzi); }
-  else k_sorted_charge_p<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, q, sorted_xyzi);
   k_nonbond_pqeq<<<nblk(N, 4), 256, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, sorted_shl, pos[0], pos[1], pos[2], q, type, shl[0], shl[1], shl[2],
                                                 frc[0], frc[1], frc[2], scal + 32);
 }

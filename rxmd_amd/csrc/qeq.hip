@@ -106,10 +106,14 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
                                                const double *__restrict__ scal, double *__restrict__ partials,
                                                double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
-                                               const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz) {
+                                               const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
+                                               const int *__restrict__ rowlist, int nrows, int pbase) {
+  // rowlist != nullptr: this launch covers nrows rows named by the list (interior or boundary rows of a multi-rank domain);
+  // its workgroups write their partial sums behind the pbase workgroups of the other launch
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
-  const int row = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + (threadIdx.x >> 6);
+  const int widx = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + (threadIdx.x >> 6);
+  const int row = rowlist ? (widx < nrows ? rowlist[widx] : N) : widx;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (row < N) {
     const int n = n10[row];
@@ -165,7 +169,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
       }
     }
   }
-  block_store_partials<4>(acc, partials, 4);
+  block_store_partials<4>(acc, partials + static_cast<size_t>(pbase) * 4, 4);
 }
 
 // ---- cell-tiled matrix pass ------------------------------------------------------------------------------------
@@ -513,6 +517,15 @@ __global__ void __launch_bounds__(256) k_grad_start(int N, DevFF ff, const int *
   block_store_partials<4>(acc, partials, 4);
 }
 
+// the cell-sorted copy of a vector in two parts (multi-rank overlap): resident positions as soon as the vector exists, ghost
+// positions when the halo has delivered them
+__global__ void k_sorted_part(int G, int N, const int *__restrict__ perm, const double2 *__restrict__ v, double2 *__restrict__ xs, int ghosts) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= G) return;
+  const int i = perm[k];
+  if ((i >= N) == (ghosts != 0)) xs[k] = v[i];
+}
+
 void Engine::qeq_start_vectors() {
   k_qeq_init<<<nblk(N, 256), 256, 0, stream>>>(N, cfg.isQEq, cfg.Lex_fqs, q, qsfp, qsfv, qst, hst);
   sorted_copy(qst);                                                                             // QCOPY1, qeq.F90:86
@@ -559,12 +572,14 @@ void Engine::qeq() {
   const int nred = use_cell ? grid.ncell : rb;                                      // partials one matrix pass leaves
   double *lvl1 = partials + static_cast<size_t>(std::max(rb, grid.ncell)) * 4 + 64; // 128 x 4 first-level sums live behind the per-workgroup partials
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
-  auto pass = [&](int mode, bool store, double2 *ra, double2 *rg) {
+  auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) {
+    const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
+    if (rbl == 0) return;
 #define RX_PASS(M, S)                                                                                                                        \
   do {                                                                                                                                       \
     if (use_cell) k_spmv_cell<M, S><<<grid.ncell, cell_bs, lds_bytes, stream>>>(N, S10, grid, dff, cellstart, perm, nb10s, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg); \
-    else if (ff.pqeq) k_spmv<M, S, true><<<rb, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
-    else k_spmv<M, S, false><<<rb, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz);  \
+    else if (ff.pqeq) k_spmv<M, S, true><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase);  \
+    else k_spmv<M, S, false><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase);  \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }
@@ -602,16 +617,32 @@ void Engine::qeq() {
   int it = 0;
   float ms = 0;
   bool xs_current = false;       // the fused direction kernel leaves the sorted copy of the new (hs,ht) in xs
+  const bool overlap_on = (std::getenv("RXMD_NO_HALO_OVERLAP") == nullptr);     // read per call: the tests switch it
+  const bool overlap = overlap_on && multi() && onepass && !use_cell && !rows_split_pending_invalid();
+  bool halo_in_flight = false;
   for (it = 0; it <= nmax - 1; ++it) {
     if (0.5 * (std::fabs(GEst2) + std::fabs(Est)) < cfg.QEq_tol) break;                          // qeq.F90:114
     if (std::fabs(GEst2) > 0.0 && std::fabs(Est / GEst2 - 1.0) < cfg.QEq_tol) break;            // qeq.F90:115
     GEst2 = Est;
-    if (!xs_current) sorted_copy(hst);                                                           // QCOPY2, qeq.F90:93,164
-    xs_current = false;
-    hipEventRecord(ev[2], stream);
-    pass(MODE_HSH, onepass, onepass ? wall : nullptr, onepass ? wgh : nullptr);
-    hipEventRecord(ev[3], stream);
-    reduce(1, nred);
+    if (halo_in_flight) {
+      // multi-rank overlap: the (hs,ht) halo of this iteration was started on the second stream right after the direction update;
+      // rows without a ghost partner do not need it
+      const int n_int = N - n_bnd, nb_int = nblk(n_int, SPMV_WPB);
+      hipEventRecord(ev[2], stream);
+      pass(MODE_HSH, onepass, wall, wgh, rows_int, n_int, 0);
+      join_comm_stream();
+      pass(MODE_HSH, onepass, wall, wgh, rows_bnd, n_bnd, nb_int);
+      hipEventRecord(ev[3], stream);
+      reduce(1, nb_int + nblk(n_bnd, SPMV_WPB));
+      halo_in_flight = false;
+    } else {
+      if (!xs_current) sorted_copy(hst);                                                         // QCOPY2, qeq.F90:93,164
+      xs_current = false;
+      hipEventRecord(ev[2], stream);
+      pass(MODE_HSH, onepass, onepass ? wall : nullptr, onepass ? wgh : nullptr);
+      hipEventRecord(ev[3], stream);
+      reduce(1, nred);
+    }
     if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
       const bool fuse = !multi();                  // single rank: every reduction finishes in-kernel; multi: sums, all-reduce, algebra
       k_cg_update<<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
@@ -624,7 +655,15 @@ void Engine::qeq() {
         allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal);
       }
       std::swap(hst, hst2);
-      xs_current = fuse;                           // multi-rank: the (hs,ht) halo and the sorted copy run at the top of the next iteration
+      xs_current = fuse;                           // multi-rank: the (hs,ht) halo and the sorted copy come with the next pass ...
+      if (overlap && it + 1 <= nmax - 1) {         // ... or, overlapped: residents' part of the sorted copy now, halo + ghosts' part on the second stream
+        k_sorted_part<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, hst, xs, 0);
+        on_comm_stream([&] {
+          halo_staged(reinterpret_cast<double *>(hst), 2);
+          k_sorted_part<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, hst, xs, 1);
+        });
+        halo_in_flight = true;
+      }
       RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
       RX_HIP(hipStreamSynchronize(stream));
       Est = h_scal[S_EST];
@@ -648,6 +687,7 @@ void Engine::qeq() {
     hipEventElapsedTime(&ms, ev[4], ev[5]); st.ms_qeq_spmv += ms;
     st.spmv_launches += 2;
   }
+  if (halo_in_flight) join_comm_stream();             // the loop ended while a halo it will not use was still in flight
   if (ff.pqeq) pqeq_update_shells();                  // pqeq.F90:169
   nstep_qeq = it; last_est = Est;
   st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1;

@@ -46,8 +46,8 @@ def test_vprocs_parity_vs_mpi_reference(case, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("qeq_mode", [0, 1])
-def test_native_rccl_transport_self_loop(qeq_mode, monkeypatch):
+@pytest.mark.parametrize("qeq_mode,overlap", [(0, True), (1, True), (1, False)])
+def test_native_rccl_transport_self_loop(qeq_mode, overlap, monkeypatch):
     """The native transport (rccl_comm.hip: ncclSend/ncclRecv/ncclAllReduce on the engine's stream) on ONE GPU: a single rank is
     pushed through the staged six-stage exchange (RXMD_FORCE_STAGED) and every message through RCCL send/recv to itself
     (RXMD_FORCE_REMOTE) -- the code path of vprocs > 1 minus the wire.  Must reproduce the single-rank oracle trajectory."""
@@ -57,6 +57,8 @@ def test_native_rccl_transport_self_loop(qeq_mode, monkeypatch):
     from test_gpu_parity import _engine, _oracle, q_err, f_err
     monkeypatch.setenv("RXMD_FORCE_STAGED", "1")
     monkeypatch.setenv("RXMD_FORCE_REMOTE", "1")
+    if not overlap:          # default: the (hs,ht) halo runs on a second stream under the interior rows of the matrix pass (qeq_mode 1)
+        monkeypatch.setenv("RXMD_NO_HALO_OVERLAP", "1")
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
     e = _engine("rdx222", (2, 2, 2), qeq_mode=qeq_mode, **kw)
     e.init_rccl(e.rccl_unique_id(), 0, 1)
