@@ -443,3 +443,19 @@ def test_forces_and_charges_are_bitwise_reproducible_run_to_run():
         e.QEq(); e.FORCE()
         a = e.atoms(); res.append((a["q"].copy(), a["f"].copy())); e.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_full_size_nve_trajectory_conserves_energy():
+    """BASELINE configs[1] size, 20 MD steps (dt 0.25 fs, QEq tol 1e-7 as in the bench): total energy per atom stays where the
+    reference keeps it (its own RDX-168 run moves by 2e-4 kcal/mol/atom over 15 steps), net charge stays zero, no atom is lost"""
+    e = _engine("rdx168", (18, 18, 18))
+    e.QEq(); pe = e.FORCE()
+    n = e.natoms
+    en0 = e.energy(); te0 = (en0["PE"][0] + en0["KE"]) / n
+    e.step(20)
+    en1 = e.energy(); te1 = (en1["PE"][0] + en1["KE"]) / n
+    assert e.natoms == n
+    assert abs(te1 - te0) <= 1e-3
+    assert en1["KE"] / n > 1e-5                      # the crystal started at rest and is moving now
+    assert abs(en1["qsum"]) <= 1e-6
+    e.close()
