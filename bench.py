@@ -210,6 +210,14 @@ def main():
         dt = float(t.item())
     st = eng.stats()
     en = eng.energy()
+    probe = None
+    if world == 1:                               # plain 16-B/lane read of the matrix value array on this very box: the ceiling the pass is quoted next to
+        try:
+            pr = eng.debug(100, cap=16)
+            rates = [pr[2 * g + 1] / (pr[2 * g] * 1e-3) / 1e9 for g in range(4) if pr[2 * g] > 0]
+            probe = max(rates) if rates else None
+        except Exception:
+            probe = None
     alt = None
     if a.alt_steps > 0 and world == 1:           # the other QEq algebra on the same trajectory, reported beside the headline
         eng.set_qeq_mode(1 - a.qeq_mode)
@@ -259,6 +267,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_spmv (QEq matrix pass, qeq.hip)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_pass,
                          "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"],
+                         "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,
                          "step_model_bytes_per_atom": b_step, "step_frac_of_hbm_roofline": (b_step * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9)},
             "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded")},
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
