@@ -91,7 +91,8 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw EngineError(RXMD_E_HIP, "no HIP device visible: this engine has no CPU path");
   RX_HIP(hipSetDevice(cfg.device));
   RX_HIP(hipStreamCreate(&stream));
-  RX_HIP(hipStreamCreate(&comm_stream));
+  if (std::getenv("RXMD_SINGLE_STREAM")) comm_stream = stream;   // diagnostic: the halo work queues on the main stream (no second hardware queue)
+  else RX_HIP(hipStreamCreate(&comm_stream));
   RX_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   for (auto &e : ev) RX_HIP(hipEventCreate(&e));
 }
@@ -102,7 +103,7 @@ Engine::~Engine() {
   for (auto &e : ev) if (e) (void)hipEventDestroy(e);
   if (ev_main) (void)hipEventDestroy(ev_main);
   if (ev_comm) (void)hipEventDestroy(ev_comm);
-  if (comm_stream) (void)hipStreamDestroy(comm_stream);
+  if (comm_stream && comm_stream != stream) (void)hipStreamDestroy(comm_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
