@@ -30,7 +30,7 @@ module rxmd_hip_mod
      real(c_double) :: dt_fs
      real(c_double) :: Lex_fqs, Lex_k
      integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode
-     integer(c_int) :: reserved0
+     integer(c_int) :: lg
      type(c_ptr)    :: pqeq_path
      integer(c_int) :: efield_dir, reserved1
      real(c_double) :: efield_strength
@@ -127,6 +127,7 @@ contains
 
   !> call once after GETPARAMS/INITSYSTEM (reference src/main.F90:20-23) with the module-global run parameters
   subroutine rxmd_hip_init(ffpath, lata, latb, latc, lalpha, lbeta, lgamma, vprocs, myid, isQEq, NMAXQEq, QEq_tol, qstep, dt_fs, device, pqeqpath)
+    use atoms, only: isLG                                       ! --lg (cmdline.F90:148-151): the ffield format and the vdW tables
     character(len=*), intent(in) :: ffpath
     character(len=*), intent(in), optional :: pqeqpath          ! PQEqParmPath when isPQEq (cmdline.F90:112-128)
     character(kind=c_char, len=:), allocatable, target, save :: cpq
@@ -142,6 +143,7 @@ contains
     cfg%vprocs = vprocs; cfg%myid = myid
     cfg%isQEq = isQEq; cfg%NMAXQEq = NMAXQEq; cfg%QEq_tol = QEq_tol; cfg%qstep = qstep; cfg%dt_fs = dt_fs
     cfg%device = device
+    if (isLG) cfg%lg = 1
     if (present(pqeqpath)) then
        if (len_trim(pqeqpath) > 0) then
           cpq = trim(pqeqpath)//c_null_char

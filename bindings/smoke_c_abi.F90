@@ -11,7 +11,7 @@ program smoke_c_abi
      real(c_double) :: QEq_tol
      integer(c_int) :: qstep
      real(c_double) :: dt_fs, Lex_fqs, Lex_k
-     integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode, reserved0
+     integer(c_int) :: nbuffer, maxneighbs, maxneighbs10, device, qeq_mode, lg
      type(c_ptr) :: pqeq_path
      integer(c_int) :: efield_dir, reserved1
      real(c_double) :: efield_strength

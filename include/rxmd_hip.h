@@ -56,7 +56,8 @@ typedef struct rxmd_config {
   int device;              /* HIP device ordinal */
   int qeq_mode;            /* 0 = reference algebra (two matrix passes per CG iteration, qeq.F90:96-166)
                               1 = one pass per iteration (gradient by recurrence); same fixed point */
-  int reserved0;
+  int lg;                  /* --lg (cmdline.F90:148-151): the ffield is in the low-gradient format (five-line atom blocks, C_lg column;
+                              param.F90:83-86,107-109,197-200) and the vdW table carries the LG + core terms (init.F90:496-514) */
   const char *pqeq_path;   /* --pqeq / rxmd.in PQEqParm (cmdline.F90:112-128,291-293): NULL = plain QEq.  Switches the charge solver to
                               PQEq (pqeq.F90), the nonbonded term to ENbond_PQEq (pot.F90:784-923) and the taper cutoff to 12.5 A */
   int efield_dir;          /* rxmd.in `efield <dir> <strength>` / --efield (cmdline.F90:131-137,286-289): 0 = off, 1..3 = x,y,z; PQEq only */
@@ -193,6 +194,10 @@ long long rxmd_host_read_rxff(const char *path, int myid, double lattice_out[6],
  * which: 0 Evdw 1 dEvdw 2 Eclmb 3 dEclmb 4 Eclmb_QEq -> out[nboty][5000]; 5 -> out = rc[nboty] then maxrc;
  * 6 -> out = {nso,nboty,nvaty,ntoty,nhbty, chi[1..nso], eta[1..nso], mass[1..nso]}.  Returns nboty or <0. */
 int rxmd_host_ffield_table(const char *ffield_path, const long long *natoms_per_type, int which, double *out, long long capacity);
+/* geninit's `-lg` / rxmd's `--lg` for the host helpers above (geninit, ffield_table): nonzero = they read ffields in the
+ * low-gradient format (init/geninit.F90:233,347).  Process-wide like the reference's module variable; returns the previous value.
+ * The engine itself takes the switch per handle (rxmd_config.lg). */
+int rxmd_host_ffield_lg(int on);
 /* library build info: returns 1 if the HIP code object for gfx950 is linked in */
 int rxmd_hip_has_device_code(void);
 

@@ -71,6 +71,7 @@ typedef struct {
   double pvdW1, pvdW1h, pvdW1inv, vpar30, vpar1, vpar2;
   /* derived, init.F90 */
   double *rc, *rc2, maxrc, cutoff_vpar30;
+  int isLG; double *C_lg, *Re_lg, *rcore2, *ecore2, *acore2, *rcore, *ecore, *acore; /* --lg, param.F90:82-86 */
   double *TBL_Eclmb, *TBL_Evdw, *TBL_Eclmb_QEq; /* [inxn][i][0:1], [inxn][i] ; i in 0..NTABLE+1 */
   double UDR, UDRi, rctap, rctap2, CTap[8];
   /* PQEq (module.F90:286-303, cmdline.F90:160-235): per type 1..ntype_pqeq; pair arrays [(ity)*(ntype_pqeq+1)+jty] */
@@ -135,6 +136,8 @@ static int read_ffield(Params *P, const char *path) {
 #undef A1
 #define A2(x) P->x = dalloc(n1 * n1)
   A2(r0s); A2(r0p); A2(r0pp); A2(rvdW); A2(Dij); A2(alpij); A2(gamW); A2(gamij);
+  if (P->isLG) { A2(C_lg); A2(rcore); A2(ecore); A2(acore); P->Re_lg = dalloc(n1); P->rcore2 = dalloc(n1); P->ecore2 = dalloc(n1); P->acore2 = dalloc(n1); }
+  /* the reference leaves the C_lg pairs no off-diagonal row names unset (allocate without a fill, :83); zero here */
 #undef A2
   P->inxn2 = ialloc(n1 * n1); P->inxn3 = ialloc(n1 * n1 * n1); P->inxn3hb = ialloc(n1 * n1 * n1); P->inxn4 = ialloc(n1 * n1 * n1 * n1);
   for (int i = 1; i <= nso; i++) {                   /* :90-95 */
@@ -157,6 +160,11 @@ static int read_ffield(Params *P, const char *path) {
     rdline(fp, L, 512);
     P->povun2[i] = ffield_f(L, 3, 9, 4); P->pval3[i] = ffield_f(L, 12, 9, 4);
     P->Valval[i] = ffield_f(L, 30, 9, 4); P->pval5[i] = ffield_f(L, 39, 9, 4);
+    if (P->isLG) {                                   /* :107-109: three more fields on line 4 and a fifth line */
+      P->rcore2[i] = ffield_f(L, 48, 9, 4); P->ecore2[i] = ffield_f(L, 57, 9, 4); P->acore2[i] = ffield_f(L, 66, 9, 4);
+      rdline(fp, L, 512);
+      T2(P->C_lg, i, i) = ffield_f(L, 3, 9, 4); P->Re_lg[i] = ffield_f(L, 12, 9, 4);
+    }
   }
   for (int i = 1; i <= nso; i++) if (P->mass[i] < 21.0 && P->Valboc[i] != P->Valval[i]) P->Valboc[i] = P->Valval[i]; /* :117-119 */
   for (int i = 1; i <= nso; i++) { P->nlpopt[i] = 0.5 * (P->Vale[i] - P->Val[i]); P->Valangle[i] = P->Valboc[i]; } /* :121-123 */
@@ -169,6 +177,11 @@ static int read_ffield(Params *P, const char *path) {
     T2(P->alpij, i, j) = sqrt(P->alf[i] * P->alf[j]);
     T2(P->gamW, i, j) = sqrt(P->vop[i] * P->vop[j]);
     T2(P->gamij, i, j) = pow(P->gam[i] * P->gam[j], -1.5);
+    if (P->isLG) {                                   /* :140-145 */
+      T2(P->rcore, i, j) = sqrt(P->rcore2[i] * P->rcore2[j]);
+      T2(P->ecore, i, j) = sqrt(P->ecore2[i] * P->ecore2[j]);
+      T2(P->acore, i, j) = sqrt(P->acore2[i] * P->acore2[j]);
+    }
   }
   rdline(fp, L, 512); P->nboty = ffield_i(L, 0, 3);  /* :151 */
   int nb1 = P->nboty + 1;
@@ -203,6 +216,7 @@ static int read_ffield(Params *P, const char *path) {
     int a = ffield_i(L, 0, 3), b = ffield_i(L, 3, 3);
     double deodmh = ffield_f(L, 6, 9, 4), rodmh = ffield_f(L, 15, 9, 4), godmh = ffield_f(L, 24, 9, 4);
     double rsig = ffield_f(L, 33, 9, 4), rpi = ffield_f(L, 42, 9, 4), rpi2 = ffield_f(L, 51, 9, 4);
+    if (P->isLG) { double c = ffield_f(L, 60, 9, 4); T2(P->C_lg, a, b) = c; T2(P->C_lg, b, a) = c; } /* :197-200 */
     if (rsig > 0) { T2(P->r0s, a, b) = rsig; T2(P->r0s, b, a) = rsig; }
     if (rpi > 0) { T2(P->r0p, a, b) = rpi; T2(P->r0p, b, a) = rpi; }
     if (rpi2 > 0) { T2(P->r0pp, a, b) = rpi2; T2(P->r0pp, b, a) = rpi2; }
@@ -294,7 +308,8 @@ static void cutofflength(Params *P, const long long *natoms_per_type) {
   for (int x = 1; x <= P->nboty; x++) if (P->rc[x] > P->maxrc) P->maxrc = P->rc[x];
 }
 
-/* restates POTENTIALTABLE, src/init.F90:421-522 (isLG = false) */
+static double powi_lg(double a) { double a2 = a * a; return a2 * a2 * a2; }   /* dr_lg**6 as repeated squaring evaluates it: a^2, a^4, a^2*a^4 */
+/* restates POTENTIALTABLE, src/init.F90:421-522 (the LG branch :496-514 included) */
 static void potentialtable(Params *P) {
   size_t nb1 = P->nboty + 1;
   P->TBL_Eclmb = dalloc(nb1 * (NTABLE + 2) * 2); P->TBL_Evdw = dalloc(nb1 * (NTABLE + 2) * 2); P->TBL_Eclmb_QEq = dalloc(nb1 * (NTABLE + 2));
@@ -321,6 +336,17 @@ static void potentialtable(Params *P) {
       double dfn13 = pow(rij_vd1 + gamwinvp, P->pvdW1inv - 1.0) * pow(dr2, P->pvdW1h - 1.0);
       P->TBL_Evdw[2 * k + 1] = Dij0 * (dTap * (exp1 - 2.0 * exp2) - Tap * (alphaij / rvdW0) * (exp1 - exp2) * dfn13);
       P->TBL_Eclmb[2 * k + 1] = Cclmb0 * dr3gamij * (dTap - (dr3gamij * dr3gamij * dr3gamij) * Tap * dr1);
+      if (P->isLG && ity <= 4 && jty <= 4) {         /* :496-514: low-gradient dispersion + core repulsion, C H O N only (:499) */
+        double dr_lg = 2 * sqrt(P->Re_lg[ity] * P->Re_lg[jty]);
+        double dr6_lg = powi_lg(dr_lg);
+        double Clg = T2(P->C_lg, ity, jty), rco = T2(P->rcore, ity, jty), eco = T2(P->ecore, ity, jty), aco = T2(P->acore, ity, jty);
+        double Elg = -Clg / (dr6 + dr6_lg);
+        double E_core = eco * exp(aco * (1.0 - (dr1 / rco)));
+        double dElg = Clg * (6.0 * dr5) / ((dr6 + dr6_lg) * (dr6 + dr6_lg)) / dr1;
+        double dE_core = -aco * E_core / rco / dr1;
+        P->TBL_Evdw[2 * k] = P->TBL_Evdw[2 * k] + Tap * (Elg + E_core);
+        P->TBL_Evdw[2 * k + 1] = P->TBL_Evdw[2 * k + 1] + dTap * Elg + Tap * dElg + dTap * E_core + Tap * dE_core;
+      }
     }
   }
 }
@@ -1843,8 +1869,14 @@ static void alloc_rank(World *W, Rank *r, int p, int NBUFFER) {
   r->commflag = (char *)calloc(NB, 1);
 }
 
+/* --lg (cmdline.F90:148-151): a process-wide switch like the reference's module variable; set before rxo_create because it
+ * changes the ffield FORMAT (param.F90:83-86,107-109,197-200). */
+static int g_isLG = 0;
+void rxo_global_lg(int on) { g_isLG = on; }
+
 void *rxo_create(const char *ffield, const double lattice[6], const int vprocs[3], int isQEq, int NMAXQEq, double QEq_tol, double dt_fs, int NBUFFER, int maxn10) {
   World *W = (World *)calloc(1, sizeof(World));
+  W->P.isLG = g_isLG;
   if (read_ffield(&W->P, ffield)) { free(W); return NULL; }
   W->lata = lattice[0]; W->latb = lattice[1]; W->latc = lattice[2]; W->lalpha = lattice[3]; W->lbeta = lattice[4]; W->lgamma = lattice[5];
   for (int a = 0; a < 3; a++) W->vprocs[a] = vprocs[a];

@@ -14,7 +14,7 @@ class RxmdConfig(C.Structure):
     _fields_ = [("ffield_path", C.c_char_p), ("lattice", C.c_double * 6), ("vprocs", C.c_int * 3), ("myid", C.c_int),
                 ("isQEq", C.c_int), ("NMAXQEq", C.c_int), ("QEq_tol", C.c_double), ("qstep", C.c_int), ("dt_fs", C.c_double),
                 ("Lex_fqs", C.c_double), ("Lex_k", C.c_double), ("nbuffer", C.c_int), ("maxneighbs", C.c_int),
-                ("maxneighbs10", C.c_int), ("device", C.c_int), ("qeq_mode", C.c_int), ("reserved0", C.c_int),
+                ("maxneighbs10", C.c_int), ("device", C.c_int), ("qeq_mode", C.c_int), ("lg", C.c_int),
                 ("pqeq_path", C.c_char_p), ("efield_dir", C.c_int), ("reserved1", C.c_int), ("efield_strength", C.c_double)]
 
 
@@ -82,6 +82,7 @@ SYMBOLS = [
     ("rxmd_host_geninit", C.c_longlong, [C.c_char_p, C.c_int, C.c_char_p, PD, PD, PD, PD, C.c_int, PD, C.c_longlong, PD]),
     ("rxmd_host_read_rxff", C.c_longlong, [C.c_char_p, C.c_int, PD, PD, PD, C.c_longlong]),
     ("rxmd_host_ffield_table", C.c_int, [C.c_char_p, PD, C.c_int, PD, C.c_longlong]),
+    ("rxmd_host_ffield_lg", C.c_int, [C.c_int]),
     ("rxmd_hip_has_device_code", C.c_int, []),
 ]
 

@@ -458,12 +458,14 @@ int rxmd_host_comm_selftest(const rxmd_comm_ops *ops, int myid, int nprocs) {
 }
 
 // ---- host front-end helpers ---------------------------------------------------------------------
+static int g_host_lg = 0;
+int rxmd_host_ffield_lg(int on) { const int was = g_host_lg; g_host_lg = on != 0; return was; }
 // geninit (reference init/geninit.F90:399-575)
 long long rxmd_host_geninit(const char *ffield_path, int natoms0, const char *elem4, const double *frac, const double lattice[6], const int mc[3],
                             const int vprocs[3], int myid, double *rec10, long long capacity, double lattice_out[6]) {
   if (!ffield_path || !elem4 || !frac || natoms0 < 1) return RXMD_E_ARG;
   rxmd::ForceField ff;
-  try { ff.parse(ffield_path); } catch (const std::exception &) { return RXMD_E_FFIELD; }
+  try { ff.parse(ffield_path, g_host_lg != 0); } catch (const std::exception &) { return RXMD_E_FFIELD; }
   std::vector<int> t0(natoms0, 0);
   for (int i = 0; i < natoms0; ++i) {
     std::string nm(elem4 + 4 * static_cast<size_t>(i));
@@ -505,7 +507,7 @@ long long rxmd_host_geninit(const char *ffield_path, int natoms0, const char *el
 int rxmd_host_ffield_table(const char *ffield_path, const long long *npt, int which, double *out, long long capacity) {
   if (!ffield_path || !out) return RXMD_E_ARG;
   rxmd::ForceField ff;
-  try { ff.parse(ffield_path); } catch (const std::exception &) { return RXMD_E_FFIELD; }
+  try { ff.parse(ffield_path, g_host_lg != 0); } catch (const std::exception &) { return RXMD_E_FFIELD; }
   std::vector<long long> n(ff.nso + 2, 1);
   if (npt) for (int t = 1; t <= ff.nso; ++t) n[t] = npt[t];
   ff.compute_cutoffs(n);

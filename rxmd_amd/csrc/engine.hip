@@ -59,7 +59,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   if (cfg.myid < 0 || cfg.myid >= nprocs) throw EngineError(RXMD_E_ARG, "myid outside the vprocs grid");
   if (std::fabs(cfg.lattice[3] - 90.0) > 1e-9 || std::fabs(cfg.lattice[4] - 90.0) > 1e-9 || std::fabs(cfg.lattice[5] - 90.0) > 1e-9)
     throw EngineError(RXMD_E_ARG, "only orthorhombic boxes are supported by the GPU cell grid (alpha=beta=gamma=90)");
-  try { ff.parse(ffield_path); } catch (const std::exception &e) { throw EngineError(RXMD_E_FFIELD, e.what()); }
+  try { ff.parse(ffield_path, cfg.lg != 0); } catch (const std::exception &e) { throw EngineError(RXMD_E_FFIELD, e.what()); }
   // rank grid, reference src/init.F90:74-100
   vID[0] = cfg.myid % cfg.vprocs[0]; vID[1] = (cfg.myid / cfg.vprocs[0]) % cfg.vprocs[1]; vID[2] = cfg.myid / (cfg.vprocs[0] * cfg.vprocs[1]);
   int k = 0;

@@ -61,7 +61,8 @@ std::string next_line(std::ifstream &in, const std::string &path) {
 
 }  // namespace
 
-void ForceField::parse(const std::string &path) {
+void ForceField::parse(const std::string &path, bool lg_format) {
+  lg = lg_format;
   std::ifstream in(path);
   if (!in) throw std::runtime_error("cannot open ffield '" + path + "'");
   header = next_line(in, path);
@@ -75,6 +76,7 @@ void ForceField::parse(const std::string &path) {
   ppen2 = vpar[20]; ppen3 = vpar[21]; ppen4 = vpar[22]; pcoa2 = vpar[3]; pcoa3 = vpar[39]; pcoa4 = vpar[31];
   ptor2 = vpar[24]; ptor3 = vpar[25]; ptor4 = vpar[26]; pcot2 = vpar[28];
 
+  std::vector<double> lg_diag;
   nso = FixedLine(next_line(in, path)).integer(3);
   if (nso < 1 || nso > 30) throw std::runtime_error("ffield: bad number of atom types");
   for (int k = 0; k < 3; ++k) next_line(in, path);
@@ -93,6 +95,11 @@ void ForceField::parse(const std::string &path) {
     a.bo131 = l3.real(9, 4); a.bo132 = l3.real(9, 4); a.bo133 = l3.real(9, 4);
     FixedLine l4(next_line(in, path));
     l4.skip(3); a.povun2 = l4.real(9, 4); a.pval3 = l4.real(9, 4); l4.skip(9); a.Valval = l4.real(9, 4); a.pval5 = l4.real(9, 4);
+    if (lg) {                                              // param.F90:107-109
+      a.rcore2 = l4.real(9, 4); a.ecore2 = l4.real(9, 4); a.acore2 = l4.real(9, 4);
+      FixedLine l5(next_line(in, path));
+      l5.skip(3); lg_diag.push_back(l5.real(9, 4)); a.Re_lg = l5.real(9, 4);
+    }
   }
   for (int t = 1; t <= nso; ++t) {
     AtomTypeParams &a = atom[t];
@@ -114,6 +121,18 @@ void ForceField::parse(const std::string &path) {
       gamW[k] = std::sqrt(atom[a].vop * atom[b].vop);
       gamij[k] = std::pow(atom[a].gam * atom[b].gam, -1.5);
     }
+  if (lg) {                                                // param.F90:140-145; C_lg pairs no row names stay 0 (unset in the reference, :83)
+    C_lg.assign(n * n, 0); rcore = ecore = acore = C_lg;
+    for (int a = 1; a <= nso; ++a) {
+      C_lg[pair(a, a)] = lg_diag[a - 1];
+      for (int b = 1; b <= nso; ++b) {
+        const int k = pair(a, b);
+        rcore[k] = std::sqrt(atom[a].rcore2 * atom[b].rcore2);
+        ecore[k] = std::sqrt(atom[a].ecore2 * atom[b].ecore2);
+        acore[k] = std::sqrt(atom[a].acore2 * atom[b].acore2);
+      }
+    }
+  }
 
   nboty = FixedLine(next_line(in, path)).integer(3);
   if (nboty < 1 || nboty > 1000) throw std::runtime_error("ffield: bad number of bond types");
@@ -147,6 +166,7 @@ void ForceField::parse(const std::string &path) {
     double de = l.real(9, 4), ro = l.real(9, 4), go = l.real(9, 4), rs = l.real(9, 4), rp = l.real(9, 4), rpp = l.real(9, 4);
     if (a < 1 || a > nso || b < 1 || b > nso) throw std::runtime_error("ffield: off-diagonal row names an unknown atom type");
     auto put = [&](std::vector<double> &v, double x) { v[pair(a, b)] = x; v[pair(b, a)] = x; };
+    if (lg) put(C_lg, l.real(9, 4));                       // param.F90:197-200
     if (rs > 0) put(r0s, rs);
     if (rp > 0) put(r0p, rp);
     if (rpp > 0) put(r0pp, rpp);
@@ -279,6 +299,16 @@ void ForceField::build_tables() {
         const double dfn13 = std::pow(rv + gw, pvdW1inv - 1.0) * std::pow(dr2, pvdW1h - 1.0);
         tbldEvdw[o] = Dij[k] * (dTap * (e1 - 2.0 * e2) - Tap * (alpij[k] / rvdW[k]) * (e1 - e2) * dfn13);
         tbldEclmb[o] = Cclmb0 * g3 * (dTap - (g3 * g3 * g3) * Tap * dr1);
+        if (lg && a <= 4 && b <= 4) {                      // init.F90:496-514: low-gradient dispersion + core repulsion, C H O N only (:499)
+          const double dr_lg = 2 * std::sqrt(atom[a].Re_lg * atom[b].Re_lg);
+          const double d2 = dr_lg * dr_lg, dr6_lg = d2 * (d2 * d2);
+          const double Elg = -C_lg[k] / (dr6 + dr6_lg);
+          const double Ecore = ecore[k] * std::exp(acore[k] * (1.0 - (dr1 / rcore[k])));
+          const double dElg = C_lg[k] * (6.0 * dr5) / ((dr6 + dr6_lg) * (dr6 + dr6_lg)) / dr1;
+          const double dEcore = -acore[k] * Ecore / rcore[k] / dr1;
+          tblEvdw[o] = tblEvdw[o] + Tap * (Elg + Ecore);
+          tbldEvdw[o] = tbldEvdw[o] + dTap * Elg + Tap * dElg + dTap * Ecore + Tap * dEcore;
+        }
       }
     }
 }

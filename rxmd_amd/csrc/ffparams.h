@@ -18,6 +18,7 @@ struct AtomTypeParams {
   double vnq, plp2, bo131, bo132, bo133;                   // line 3 (:105)
   double povun2, pval3, Valval, pval5;                     // line 4 (:111)
   double nlpopt, Valangle;                                 // derived (:121-123)
+  double rcore2 = 0, ecore2 = 0, acore2 = 0, Re_lg = 0;    // --lg: line 4 fields 6-8 and line 5 (:107-109)
 };
 struct BondTypeParams {
   double Desig, Depi, Depipi, pbe1, pbo5, v13cor, pbo6, povun1;  // bond line 1 (:166)
@@ -68,7 +69,10 @@ struct ForceField {
   void build_pqeq_tables();                                 // needs the taper of rctap0_pqeq
 
   // throws std::runtime_error with a message on malformed input
-  void parse(const std::string &path);
+  // lg: the low-gradient format (--lg, cmdline.F90:148-151): five-line atom blocks and a C_lg column on the off-diagonal rows
+  void parse(const std::string &path, bool lg = false);
+  bool lg = false;
+  std::vector<double> C_lg, rcore, ecore, acore;            // [(nso+1)^2] (param.F90:83-86,140-145,197-200)
   // bond-order cutoffs per bond row; types with zero atoms are ignored for maxrc (init.F90:404-413)
   void compute_cutoffs(const std::vector<long long> &natoms_per_type);
   void build_taper(double rc);

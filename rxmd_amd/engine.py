@@ -29,7 +29,7 @@ class RxmdEngine:
     """One engine = one rank of the vprocs grid = one MI355X."""
 
     def __init__(self, ffield, lattice, vprocs=(1, 1, 1), myid=0, isQEq=1, NMAXQEq=500, QEq_tol=1e-7, qstep=1, dt_fs=0.25,
-                 nbuffer=0, maxneighbs=0, maxneighbs10=0, device=0, qeq_mode=0, Lex_fqs=1.0, Lex_k=2.0, pqeq=None, efield=None):
+                 nbuffer=0, maxneighbs=0, maxneighbs10=0, device=0, qeq_mode=0, Lex_fqs=1.0, Lex_k=2.0, pqeq=None, efield=None, lg=False):
         self.L = _lib.load()
         cfg = RxmdConfig()
         self.L.rxmd_hip_default_config(C.byref(cfg))
@@ -44,6 +44,7 @@ class RxmdEngine:
         cfg.Lex_fqs = Lex_fqs; cfg.Lex_k = Lex_k
         self._pq = str(pqeq).encode() if pqeq else None       # --pqeq <file> (cmdline.F90:112-128): PQEq instead of QEq
         cfg.pqeq_path = self._pq
+        cfg.lg = 1 if lg else 0                                # --lg: LG ffield format + low-gradient dispersion tables
         if efield:                                             # (dir 1..3, strength V/A): rxmd.in `efield`
             cfg.efield_dir = int(efield[0]); cfg.efield_strength = float(efield[1])
         self.cfg = cfg

@@ -20,9 +20,17 @@ def read_xyz(path):
     return names, np.array(frac), lattice
 
 
-def geninit(ffield, names, frac, lattice, mc=(1, 1, 1), vprocs=(1, 1, 1), myid=0):
-    """-> (lattice_super, rec10[natoms_of_rank, 10]) exactly what DAT/rxff.bin would hold for `myid`"""
+def geninit(ffield, names, frac, lattice, mc=(1, 1, 1), vprocs=(1, 1, 1), myid=0, lg=False):
+    """-> (lattice_super, rec10[natoms_of_rank, 10]) exactly what DAT/rxff.bin would hold for `myid`; lg = geninit's -lg (LG ffield format)"""
     L = _lib.load()
+    was = L.rxmd_host_ffield_lg(1 if lg else 0)
+    try:
+        return _geninit(L, ffield, names, frac, lattice, mc, vprocs, myid)
+    finally:
+        L.rxmd_host_ffield_lg(was)
+
+
+def _geninit(L, ffield, names, frac, lattice, mc, vprocs, myid):
     n0 = len(names)
     elem = bytearray(4 * n0)
     for i, s in enumerate(names):
@@ -84,12 +92,14 @@ def format_xyz(lattice, type_names, gid, types, pos, q, shells=None, natoms_tota
     return "".join(out)
 
 
-def ffield_type_names(ffield):
+def ffield_type_names(ffield, lg=False):
     """element names of the ffield atom types, 1-based list (index 0 unused) -- the reference's atmname (param.F90:103)"""
     L = _lib.load()
     out = np.zeros(4096)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
+    was = L.rxmd_host_ffield_lg(1 if lg else 0)
     rc = L.rxmd_host_ffield_table(str(ffield).encode(), None, 6, p(out), len(out))
+    L.rxmd_host_ffield_lg(was)
     if rc < 0:
         raise RuntimeError("cannot parse %s" % ffield)
     nso = int(out[0])
@@ -100,7 +110,7 @@ def ffield_type_names(ffield):
     nso2 = int(lines[base].split()[0])
     assert nso2 == nso
     for t in range(nso):
-        names.append(lines[base + 4 + 4 * t].split()[0])
+        names.append(lines[base + 4 + (5 if lg else 4) * t].split()[0])
     return names
 
 

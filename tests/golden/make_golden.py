@@ -56,6 +56,10 @@ CASES = {
     "sicnp547_pqeq_efieldx_0": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 1 0.05"], 0),
     "sicnp547_pqeq_efieldx_md3": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 1 0.05"], 3),
     "sicnp547_pqeq_efield_md3": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 3 0.05"], 3),
+    # low-gradient dispersion correction (--lg: five-line atom blocks and a C_lg column in the ffield, param.F90:83-86,107-109,197-200;
+    # table terms init.F90:496-514); conf/init.rdx.lg/{input.xyz,ffield}
+    "rdx168_lg_tight": ("rdx_lg.xyz", "ffield_rdx_lg", (1, 1, 1), ["--lg", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
+    "rdx168_lg_md5":   ("rdx_lg.xyz", "ffield_rdx_lg", (1, 1, 1), ["--lg"], 5),
     # multi-rank (real MPI build oracle/_ref/rxmd_mpi, conda MPICH): name: (..., vprocs)
     "rdx222_v211_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
     "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),
@@ -157,7 +161,7 @@ def make(name):
             with open(os.path.join(tmp, "rxmd.in"), "a") as f:
                 f.write("\n".join(extra_in) + "\n")
         run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT",
-             "-mc", str(mc[0]), str(mc[1]), str(mc[2])], tmp)
+             "-mc", str(mc[0]), str(mc[1]), str(mc[2])] + (["-lg"] if "--lg" in flags else []), tmp)
         rxffbin = open(os.path.join(tmp, "DAT", "rxff.bin"), "rb").read()
         # run A: the dump run
         out = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(nsteps), "--pstep", "1",

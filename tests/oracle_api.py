@@ -35,13 +35,13 @@ def lib():
     return _lib
 
 
-def ffield_names(path):
-    """atom names in ffield order (geninit.F90 getAtomNames)"""
+def ffield_names(path, lg=False):
+    """atom names in ffield order (geninit.F90 getAtomNames; -lg: five lines per atom block, geninit.F90:233)"""
     lines = open(path).read().split("\n")
     npar = int(lines[1].split()[0])
     nso = int(lines[2 + npar].split()[0])
     base = 2 + npar + 4
-    return [lines[base + 4 * i][1:3].strip() for i in range(nso)]
+    return [lines[base + (5 if lg else 4) * i][1:3].strip() for i in range(nso)]
 
 
 def read_xyz(path_or_text):
@@ -84,7 +84,7 @@ def geninit(names, frac, lattice, ffnames, mc=(1, 1, 1), vprocs=(1, 1, 1)):
 
 class Oracle:
     def __init__(self, ffield, lattice, ranks, vprocs=(1, 1, 1), isQEq=1, NMAXQEq=500, QEq_tol=1e-7, dt_fs=0.25,
-                 nbuffer=None, maxn10=1500, q0=None, v0=None, pqeq=None):
+                 nbuffer=None, maxn10=1500, q0=None, v0=None, pqeq=None, lg=False):
         L = lib()
         self.L = L
         nmax = max(len(r["type"]) for r in ranks)
@@ -92,7 +92,9 @@ class Oracle:
             nbuffer = max(30000, 8 * nmax)
         lat = (C.c_double * 6)(*lattice)
         vp = (C.c_int * 3)(*vprocs)
+        L.rxo_global_lg(1 if lg else 0)               # --lg changes the ffield format: known before the file is read
         self.w = L.rxo_create(ffield.encode(), lat, vp, isQEq, NMAXQEq, QEq_tol, dt_fs, nbuffer, maxn10)
+        L.rxo_global_lg(0)
         assert self.w, "rxo_create failed"
         self.w = C.c_void_p(self.w)
         if pqeq:                                      # --pqeq <file>: before the tables are built (init.F90:28-43)
@@ -221,7 +223,10 @@ def oracle_from_rxff(ffield, buf, **kw):
 
 def make_system(case):
     """(ffield_path, lattice, ranks) for the named golden case family"""
-    if case.startswith("rdx"):
+    if case.startswith("rdx168_lg"):
+        ff = os.path.join(INP, "ffield_rdx_lg")
+        names, frac, lat = read_xyz(os.path.join(INP, "rdx_lg.xyz"))
+    elif case.startswith("rdx"):
         ff = os.path.join(INP, "ffield_rdx")
         names, frac, lat = read_xyz(os.path.join(INP, "rdx.xyz"))
     elif case.startswith("ice"):

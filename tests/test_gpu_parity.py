@@ -26,7 +26,7 @@ def _engine(case, mc, **kw):
     import rxmd_amd
     from rxmd_amd import system
     ff, names, frac, lat = oa.make_system(case)
-    lat3, rec = system.geninit(ff, names, frac, lat, mc=mc)
+    lat3, rec = system.geninit(ff, names, frac, lat, mc=mc, lg=kw.get("lg", False))
     e = rxmd_amd.RxmdEngine(ff, lat3, **kw)
     e.set_atoms_rxff(rec)
     return e
@@ -34,7 +34,7 @@ def _engine(case, mc, **kw):
 
 def _oracle(case, mc, **kw):
     ff, names, frac, lat = oa.make_system(case)
-    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=mc)
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff, lg=kw.get("lg", False)), mc=mc)
     return oa.Oracle(ff, lat2, ranks, **kw)
 
 
@@ -398,6 +398,26 @@ def test_pqeq_electric_field_md_against_the_clean_oracle():
     assert q_err(a["q"][ie], o.charges()[io]) <= QTOL
     assert f_err(a["f"][ie], o.forces()[io]) <= FTOL
     assert np.abs(e.shells()[ie] - o.spos()[io]).max() <= 1e-7
+    e.close()
+
+
+def test_low_gradient_dispersion_against_the_reference_and_the_oracle():
+    """--lg on the reference's conf/init.rdx.lg input: LG ffield format, low-gradient + core terms in the vdW table (init.F90:496-514).
+    Step 0 against the real reference, then 5 MD steps against the oracle (itself pinned on that trajectory on CPU)."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000, lg=True)
+    g = np.load(os.path.join(oa.GOLD, "rdx168_lg_tight.npz"))
+    e = _engine("rdx168_lg", (1, 1, 1), **kw)
+    e.QEq(); pe = e.FORCE(); a = e.atoms()
+    assert (a["gid"] == g["gid"]).all()
+    assert q_err(a["q"], g["charge"]) <= QTOL
+    assert f_err(a["f"], g["force"]) <= FTOL
+    assert abs(pe[0] / 168 - g["mdstep"][0][2]) <= 1e-5 * abs(g["mdstep"][0][2])
+    o = _oracle("rdx168_lg", (1, 1, 1), **kw); o.qeq(); o.force()
+    assert e_err(pe, o.energy()) <= ETOL
+    e.step(5); o.step(5); a = e.atoms()
+    assert np.abs(a["pos"] - o.pos()).max() <= 1e-9
+    assert q_err(a["q"], o.charges()) <= QTOL
+    assert f_err(a["f"], o.forces()) <= FTOL
     e.close()
 
 

@@ -36,7 +36,7 @@ def test_struct_layout_matches_header_sizes():
     L.rxmd_hip_default_config(C.byref(cfg))
     assert list(cfg.vprocs) == [1, 1, 1] and cfg.isQEq == 1 and cfg.NMAXQEq == 500 and cfg.QEq_tol == 1e-7
     assert cfg.qstep == 1 and cfg.dt_fs == 0.25 and cfg.Lex_fqs == 1.0 and cfg.Lex_k == 2.0 and cfg.lattice[5] == 90.0
-    assert cfg.reserved0 == 0 and cfg.pqeq_path is None and cfg.efield_dir == 0 and cfg.reserved1 == 0 and cfg.efield_strength == 0.0
+    assert cfg.lg == 0 and cfg.pqeq_path is None and cfg.efield_dir == 0 and cfg.reserved1 == 0 and cfg.efield_strength == 0.0
     assert C.sizeof(cfg) == 168 and _lib.RxmdConfig.pqeq_path.offset == 144 and _lib.RxmdConfig.efield_strength.offset == 160   # = gcc's layout of include/rxmd_hip.h
 
 
@@ -57,11 +57,25 @@ def _host_table(ff, which, npt=None):
     return out.reshape(nb, 5000) if which < 5 else out
 
 
-@pytest.mark.parametrize("case", ["rdx168", "ice644"])
+@pytest.mark.parametrize("case", ["rdx168", "ice644", "rdx168_lg"])
 def test_ffield_tables_and_cutoffs_match_oracle(case):
     ff, names, frac, lat = oa.make_system(case)
-    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff))
-    o = oa.Oracle(ff, lat2, ranks)
+    lg = case.endswith("_lg")                      # --lg: LG ffield format, low-gradient terms in the vdW table (init.F90:496-514)
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff, lg=lg))
+    o = oa.Oracle(ff, lat2, ranks, lg=lg)
+    was = rxmd_amd.load_library().rxmd_host_ffield_lg(1 if lg else 0)
+    try:
+        _tables_and_cutoffs(o, ff, ranks)
+    finally:
+        rxmd_amd.load_library().rxmd_host_ffield_lg(was)
+    if lg:
+        from rxmd_amd import system
+        assert system.ffield_type_names(ff, lg=True)[1:5] == ["C", "H", "O", "N"]
+        lat3, rec = system.geninit(ff, names, frac, lat, lg=True)
+        assert np.array_equal(np.floor(rec[:, 7]).astype(int), ranks[0]["type"]) and np.allclose(rec[:, :3], ranks[0]["rnorm"], rtol=0, atol=1e-15)
+
+
+def _tables_and_cutoffs(o, ff, ranks):
     nso = int(o.info()[15])
     npt = np.bincount(ranks[0]["type"], minlength=nso + 1)[1:]
     for which in range(5):

@@ -14,7 +14,7 @@ GOLD = oa.GOLD
 def _run(case, mc, steps=0, **kw):
     g = np.load(os.path.join(GOLD, case + ".npz"))
     ff, names, frac, lat = oa.make_system(case)
-    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=mc)
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff, lg=kw.get("lg", False)), mc=mc)
     o = oa.Oracle(ff, lat2, ranks, **kw)
     iters = [o.qeq()]
     o.force()
@@ -191,4 +191,18 @@ def test_pqeq_with_electric_field():
     o = oa.Oracle(ff, lat2, ranks, pqeq=oa.PQEQ_SICNP, QEq_tol=1e-12, NMAXQEq=2000)
     o.set_efield(3, 0.05)
     o.qeq(); o.force(); o.step(3)
+    _compare(g, o, ftol=1e-9, qtol=1e-10)
+
+
+def test_low_gradient_dispersion_tables():
+    """--lg: the LG ffield format (param.F90:83-86,107-109,197-200) and the table terms of init.F90:496-514, on the reference's own
+    conf/init.rdx.lg input; step 0 at the tight tolerance, then the 5-step trajectory with its iteration counts"""
+    g, o, iters, pe = _run("rdx168_lg_tight", (1, 1, 1), QEq_tol=1e-12, NMAXQEq=2000, lg=True)
+    assert iters[0] == int(g["qeq_iters"][0])
+    _compare(g, o)
+    _check_energy(g, pe, 168)
+    g0 = np.load(os.path.join(GOLD, "rdx168_tight.npz"))
+    assert abs(g["mdstep"][0][2] - g0["mdstep"][0][2]) > 1e-3       # not the plain RDX answer: the correction is really on
+    g, o, iters, pe = _run("rdx168_lg_md5", (1, 1, 1), steps=5, lg=True)
+    assert iters == [int(x) for x in g["qeq_iters"]]
     _compare(g, o, ftol=1e-9, qtol=1e-10)
