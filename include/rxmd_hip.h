@@ -163,7 +163,9 @@ typedef struct rxmd_comm_ops {
   long long (*exchange)(void *ctx, int to, const double *send, long long nsend, int from, double *recv, long long cap);
   int (*allreduce_sum)(void *ctx, double *buf, int n);
   /* optional (may be NULL): the same as `exchange` when the receiver already knows it will get exactly `nrecv` doubles
-   * (vector halos and force returns re-use the index lists of the ghost build), so no size message is needed */
+   * (vector halos and force returns re-use the index lists of the ghost build), so no size message is needed.  `send` and
+   * `recv` may point INSIDE the exchange buffers: the two stages of an axis are packed back to back and handed over as two
+   * consecutive calls (RXMD_NO_STAGE_PAIRS=1 restores one message per buffer) */
   long long (*exchange_known)(void *ctx, int to, const double *send, long long nsend, int from, double *recv, long long nrecv);
 } rxmd_comm_ops;
 int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops);

@@ -196,6 +196,9 @@ struct Engine {
   void halo_refresh(double2 *v2, double *v1);       // QCOPY1/QCOPY2: ghosts <- owners (self exchange, resolved roots)
   void halo_staged(double *v, int ncomp);           // the same through the six-stage exchange (multi-rank)
   long long exchange_stage(int d, bool reverse, long long nsend, long long known_nrecv = -1);  // one send_recv of comm.F90:291-364; returns #doubles received
+  void exchange_pair(int d0, bool reverse, long long n0, long long r0, long long n1, long long r1);  // stages d0 and d0+1 (one axis) in one round, counts known
+  void rccl_exchange_pair(int to0, int from0, long long n0, long long r0, int to1, int from1, long long n1, long long r1);
+  bool stage_pairs = true;                          // RXMD_NO_STAGE_PAIRS=1: one round per stage as the reference does (six per halo)
   void ensure_xbuf(size_t doubles);
   bool multi() const { return nprocs > 1 || force_staged; }
   // native RCCL transport (rccl_comm.hip); force_staged / force_remote (env RXMD_FORCE_STAGED / RXMD_FORCE_REMOTE) push a

@@ -84,6 +84,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   }
   if (cfg.efield_dir != 0 && (!ff.pqeq || cfg.efield_dir < 1 || cfg.efield_dir > 3))
     throw EngineError(RXMD_E_ARG, "efield needs a PQEq parameter file (core charges Z) and a direction 1..3");
+  stage_pairs = std::getenv("RXMD_NO_STAGE_PAIRS") == nullptr;
   force_staged = std::getenv("RXMD_FORCE_STAGED") != nullptr; force_remote = std::getenv("RXMD_FORCE_REMOTE") != nullptr;
   MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
   if (MAXNB > 31) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 31 (the wavefront-per-centre kernels stage the bond slots of two atoms in one 64-lane wavefront; the reference uses 30)");
@@ -597,8 +598,38 @@ void Engine::ghost_build_staged() {
   st.nghost_force = G - N; st.nghost_qeq = G - N;
 }
 
-// MODE_QCOPY1 / MODE_QCOPY2 (comm.F90:187-212): ghost slots of an ncomp-interleaved vector, stage by stage
+// The + and - stage of one axis are independent (both scan residents and the ghosts of EARLIER axes only, comm.F90:55-66), and
+// their send lists, ghost slots and messages lie back to back: one pack, one exchange round with both messages in flight, one
+// unpack -- three rounds per halo instead of six.  xbuf_send = [message of d0 | message of d0+1], xbuf_recv likewise.
+void Engine::exchange_pair(int d0, bool reverse, long long n0, long long r0, long long n1, long long r1) {
+  const int d1 = d0 + 1;
+  const int to0 = reverse ? target_node[dinv_[d0]] : target_node[d0], from0 = reverse ? target_node[d0] : target_node[dinv_[d0]];
+  const int to1 = reverse ? target_node[dinv_[d1]] : target_node[d1], from1 = reverse ? target_node[d1] : target_node[dinv_[d1]];
+  if (to0 == cfg.myid && from0 == cfg.myid && !(force_remote && nccl)) {                  // the axis is not split: both partners are this rank
+    if (n0 != r0 || n1 != r1) throw EngineError(RXMD_E_COMM, "self exchange with unequal send and receive counts");
+    if (n0 + n1 > 0) RX_HIP(hipMemcpyAsync(xbuf_recv, xbuf_send, sizeof(double) * (n0 + n1), hipMemcpyDeviceToDevice, stream));
+    return;
+  }
+  if (nccl) { rccl_exchange_pair(to0, from0, n0, r0, to1, from1, n1, r1); return; }
+  if (!has_comm || !comm.exchange_known) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
+  RX_HIP(hipStreamSynchronize(stream));
+  if (comm.exchange_known(comm.ctx, to0, xbuf_send, n0, from0, xbuf_recv, r0) != r0 ||
+      comm.exchange_known(comm.ctx, to1, xbuf_send + n0, n1, from1, xbuf_recv + r0, r1) != r1)
+    throw EngineError(RXMD_E_COMM, "halo size changed between the ghost build and a vector exchange");
+}
+
+// MODE_QCOPY1 / MODE_QCOPY2 (comm.F90:187-212): ghost slots of an ncomp-interleaved vector, axis by axis
 void Engine::halo_staged(double *v, int ncomp) {
+  if (stage_pairs && (nccl || (has_comm && comm.exchange_known))) {
+    for (int d0 = 1; d0 <= 5; d0 += 2) {
+      const int ns0 = sendoff[d0 + 1] - sendoff[d0], ns1 = sendoff[d0 + 2] - sendoff[d0 + 1];
+      const int cnt0 = copyptr[d0] - copyptr[d0 - 1], cnt1 = copyptr[d0 + 1] - copyptr[d0];
+      if (ns0 + ns1 > 0) k_pack_vec<<<nblk(ns0 + ns1, 256), 256, 0, stream>>>(ns0 + ns1, ncomp, sendidx + sendoff[d0], v, xbuf_send);
+      exchange_pair(d0, false, static_cast<long long>(ns0) * ncomp, static_cast<long long>(cnt0) * ncomp, static_cast<long long>(ns1) * ncomp, static_cast<long long>(cnt1) * ncomp);
+      if (cnt0 + cnt1 > 0) k_unpack_vec<<<nblk(cnt0 + cnt1, 256), 256, 0, stream>>>(cnt0 + cnt1, ncomp, copyptr[d0 - 1], xbuf_recv, v);
+    }
+    return;
+  }
   for (int d = 1; d <= 6; ++d) {
     const int ns = sendoff[d + 1] - sendoff[d];
     if (ns > 0) k_pack_vec<<<nblk(ns, 256), 256, 0, stream>>>(ns, ncomp, sendidx + sendoff[d], v, xbuf_send);
@@ -610,6 +641,17 @@ void Engine::halo_staged(double *v, int ncomp) {
 }
 
 void Engine::fold_ghost_forces() {
+  if (multi() && stage_pairs && (nccl || (has_comm && comm.exchange_known))) {   // MODE_CPBK by axis, z first; within an axis the + stage's sums land first (6 then 5)
+    for (int d0 = 5; d0 >= 1; d0 -= 2) {
+      const int g0 = copyptr[d0 - 1], cnt0 = copyptr[d0] - copyptr[d0 - 1], cnt1 = copyptr[d0 + 1] - copyptr[d0];
+      const int ns0 = sendoff[d0 + 1] - sendoff[d0], ns1 = sendoff[d0 + 2] - sendoff[d0 + 1];
+      if (cnt0 + cnt1 > 0) k_pack_force<<<nblk(cnt0 + cnt1, 256), 256, 0, stream>>>(g0, cnt0 + cnt1, frc[0], frc[1], frc[2], xbuf_send);
+      exchange_pair(d0, true, 3LL * cnt0, 3LL * ns0, 3LL * cnt1, 3LL * ns1);
+      if (ns1 > 0) k_add_force<<<nblk(ns1, 256), 256, 0, stream>>>(ns1, sendidx + sendoff[d0 + 1], xbuf_recv + 3LL * ns0, frc[0], frc[1], frc[2]);
+      if (ns0 > 0) k_add_force<<<nblk(ns0, 256), 256, 0, stream>>>(ns0, sendidx + sendoff[d0], xbuf_recv, frc[0], frc[1], frc[2]);
+    }
+    return;
+  }
   if (multi()) {                                               // MODE_CPBK, reversed stage order (comm.F90:74-78,385-396,474-482)
     for (int d = 6; d >= 1; --d) {
       const int g0 = copyptr[d - 1], cnt = copyptr[d] - copyptr[d - 1];

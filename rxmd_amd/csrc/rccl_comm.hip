@@ -64,6 +64,20 @@ long long Engine::rccl_exchange(int to, int from, long long nsend, long long kno
   return nrecv;
 }
 
+// both send_recv of one axis in one group: four point-to-point operations in flight at once.  Two messages to the same peer
+// (an axis split in two: the + and the - neighbour are the same rank) are matched in the order they were issued, which is the
+// order the peer posts its receives in (its own stage d0 message first).
+void Engine::rccl_exchange_pair(int to0, int from0, long long n0, long long r0, int to1, int from1, long long n1, long long r1) {
+  ncclComm_t c = C(nccl);
+  if (n0 + n1 + r0 + r1 == 0) return;
+  RX_NCCL(ncclGroupStart());
+  if (n0 > 0) RX_NCCL(ncclSend(xbuf_send, static_cast<size_t>(n0), ncclDouble, to0, c, stream));
+  if (r0 > 0) RX_NCCL(ncclRecv(xbuf_recv, static_cast<size_t>(r0), ncclDouble, from0, c, stream));
+  if (n1 > 0) RX_NCCL(ncclSend(xbuf_send + n0, static_cast<size_t>(n1), ncclDouble, to1, c, stream));
+  if (r1 > 0) RX_NCCL(ncclRecv(xbuf_recv + r0, static_cast<size_t>(r1), ncclDouble, from1, c, stream));
+  RX_NCCL(ncclGroupEnd());
+}
+
 // MPI_ALLREDUCE(SUM) of n device doubles, in place, in stream order
 void Engine::rccl_allreduce_dev(double *dev, int n) {
   RX_NCCL(ncclAllReduce(dev, dev, static_cast<size_t>(n), ncclDouble, ncclSum, C(nccl), stream));
