@@ -208,7 +208,7 @@ struct Engine {
   void rccl_destroy();
   long long rccl_exchange(int to, int from, long long nsend, long long known_nrecv);
   void rccl_allreduce_dev(double *dev, int n);
-  void allreduce_scal4();                          // MPI_ALLREDUCE of scal[S_RAW0..3] (qeq.hip)
+  void allreduce_scal4(int n = 4);                 // MPI_ALLREDUCE of scal[S_RAW0..n-1] (qeq.hip)
   void allreduce_host(double *buf, int n);         // the same for a host vector (setup paths)
   void ghost_build_staged();
   void migrate_staged();

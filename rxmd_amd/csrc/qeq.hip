@@ -20,7 +20,7 @@ namespace rxmd {
 
 static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
 
-enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_RAW0, S_RAW1, S_RAW2, S_RAW3, S_COUNT };
+enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_RAW0, S_RAW1, S_RAW2, S_RAW3, S_RAW4, S_RAW5, S_RAW6, S_RAW7, S_COUNT };
 enum { MODE_HSH = 0, MODE_GRAD = 1 };
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef SPMV_UNR
@@ -295,36 +295,13 @@ __device__ inline double block_sum_256(double v, double *sm) {
   return r;
 }
 
-// first level of the two-level deterministic reduction: block b sums its contiguous chunk of the per-workgroup partials
-__global__ void __launch_bounds__(256) k_reduce_level1(int nblocks, const double *__restrict__ partials, double *__restrict__ out) {
-  __shared__ double sm[256];
-  const int per = (nblocks + gridDim.x - 1) / gridDim.x;
-  const int b0 = blockIdx.x * per, b1 = min(nblocks, b0 + per);
-  double a[4] = {0, 0, 0, 0};
-  for (int b = b0 + threadIdx.x; b < b1; b += 256)
-    for (int c = 0; c < 4; ++c) a[c] += partials[static_cast<size_t>(b) * 4 + c];
-  for (int c = 0; c < 4; ++c) {
-    const double r = block_sum_256(a[c], sm);
-    if (threadIdx.x == 0) out[blockIdx.x * 4 + c] = r;
-  }
-}
-
-// rank-local sums of the four partial columns -> scal[S_RAW0..3]
-__global__ void __launch_bounds__(256) k_reduce_scalars(int nblocks, const double *__restrict__ partials, double *__restrict__ scal) {
-  __shared__ double sm[256];
-  double a[4] = {0, 0, 0, 0};
-  for (int b = threadIdx.x; b < nblocks; b += 256)
-    for (int c = 0; c < 4; ++c) a[c] += partials[static_cast<size_t>(b) * 4 + c];
-  for (int c = 0; c < 4; ++c) {
-    const double r = block_sum_256(a[c], sm);
-    if (threadIdx.x == 0) scal[S_RAW0 + c] = r;
-  }
-}
 // the scalar algebra between the passes, on the (all-reduced, MPI_ALLREDUCE qeq.F90:107,129,144,357) sums:
 // stage 1: after the HSH pass -> REAL(4) line-minimisation factors (qeq.F90:133)
 // stage 2: after the q update  -> mu = ssum/tsum (qeq.F90:147)
 // stage 3: after the GRAD pass -> Gold<-Gnew, Gnew, Est, beta (qeq.F90:156-161)
 // stage 4 (qeq_mode 1, fused loop): sums (qs, qt, gs.gs, gt.gt) -> mu, Gold<-Gnew, Gnew, beta;  stage 5: Est
+// stage 6 (qeq_mode 1, multi-rank): stage 4 and Est in one -- Est is a quadratic in mu whose three coefficients are sums the
+//          update kernel can form before mu exists (k_cg_update<true>), so the iteration needs two all-reduces instead of three
 __device__ inline void scalar_algebra(int stage, double *__restrict__ scal) {
   const double r[4] = {scal[S_RAW0], scal[S_RAW1], scal[S_RAW2], scal[S_RAW3]};
   if (stage == 1) {
@@ -339,13 +316,15 @@ __device__ inline void scalar_algebra(int stage, double *__restrict__ scal) {
     scal[S_GOLD_S] = go_s; scal[S_GOLD_T] = go_t;
     scal[S_GNEW_S] = r[0]; scal[S_GNEW_T] = r[1]; scal[S_EST] = r[2];
     scal[S_BETA_S] = r[0] / go_s; scal[S_BETA_T] = r[1] / go_t;
-  } else if (stage == 4) {
+  } else if (stage == 4 || stage == 6) {
     scal[S_SSUM] = r[0]; scal[S_TSUM] = r[1];
-    scal[S_MU] = r[0] / r[1];
+    const double mu = r[0] / r[1];
+    scal[S_MU] = mu;
     const double go_s = scal[S_GNEW_S], go_t = scal[S_GNEW_T];
     scal[S_GOLD_S] = go_s; scal[S_GOLD_T] = go_t;
     scal[S_GNEW_S] = r[2]; scal[S_GNEW_T] = r[3];
     scal[S_BETA_S] = r[2] / go_s; scal[S_BETA_T] = r[3] / go_t;
+    if (stage == 6) scal[S_EST] = scal[S_RAW4] - mu * scal[S_RAW5] + mu * mu * scal[S_RAW6];
   } else {
     scal[S_EST] = r[0];
   }
@@ -359,7 +338,7 @@ __global__ void k_scalar_algebra(int stage, double *__restrict__ scal) {
 // (arrival counter) adds all of them in a fixed order (thread t takes partials t, t+256, ...; then the fixed LDS tree), writes
 // scal[S_RAW0..3] and, single rank only, runs the scalar algebra of `stage` -- so a reduction costs no extra launch.
 // The result does not depend on which workgroup happens to be last.
-__device__ inline void block_finish(int nblocks, double *partials, unsigned *ticket, int stage, double *scal) {
+__device__ inline void block_finish(int nblocks, double *partials, unsigned *ticket, int stage, double *scal, int nsets = 1) {
   __shared__ double smf[256];
   __shared__ bool last;
   // The partials were stored with device-scope atomics (write-through); waiting for those stores to complete is all the
@@ -370,12 +349,15 @@ __device__ inline void block_finish(int nblocks, double *partials, unsigned *tic
   if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nblocks - 1));
   __syncthreads();
   if (!last) return;
-  double a[4] = {0, 0, 0, 0};
-  for (int b = threadIdx.x; b < nblocks; b += 256)
-    for (int c = 0; c < 4; ++c) a[c] += __hip_atomic_load(partials + static_cast<size_t>(b) * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int c = 0; c < 4; ++c) {
-    const double r = block_sum_256(a[c], smf);
-    if (threadIdx.x == 0) scal[S_RAW0 + c] = r;
+  for (int set = 0; set < nsets; ++set) {            // set k: nblocks x 4 partials behind those of set k-1 -> scal[S_RAW0 + 4k ..]
+    const double *ps = partials + static_cast<size_t>(set) * nblocks * 4;
+    double a[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+      for (int c = 0; c < 4; ++c) a[c] += __hip_atomic_load(ps + static_cast<size_t>(b) * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = 0; c < 4; ++c) {
+      const double r = block_sum_256(a[c], smf);
+      if (threadIdx.x == 0) scal[S_RAW0 + 4 * set + c] = r;
+    }
   }
   if (threadIdx.x == 0) {
     *ticket = 0u;                                    // ready for the next launch (stream order)
@@ -384,7 +366,7 @@ __device__ inline void block_finish(int nblocks, double *partials, unsigned *tic
 }
 
 // the matrix pass leaves one partial per workgroup (245k at 979,776 rows): 128 workgroups sum contiguous chunks,
-// the last of them finishes (replaces k_reduce_level1 + k_reduce_scalars + k_scalar_algebra: one launch instead of three)
+// the last of them finishes (one launch for level-1 sums, final sum and scalar algebra)
 __global__ void __launch_bounds__(256) k_reduce_fused(int nblocks, const double *__restrict__ partials, double *__restrict__ lvl1, unsigned *ticket, int stage, double *__restrict__ scal) {
   __shared__ double sm[256];
   const int per = (nblocks + gridDim.x - 1) / gridDim.x;
@@ -418,11 +400,14 @@ __global__ void __launch_bounds__(256) k_update_qst(int N, const double *__restr
 // ---- qeq_mode 1: the whole vector algebra of one CG iteration in two launches -----------------------------------
 // A: qs,qt += lmin (hs,ht); stored row sums += lmin H.(hs,ht); new gradient (no mu needed); sums (qs, qt, gs.gs, gt.gt)
 //    -> tail: mu, Gnew, beta                                                    (qeq.F90:136-147,349-356,160-161)
+//    EST3: also the three coefficients of Est(mu) = E0 - mu E1 + mu^2 E2 (the per-row term of k_cg_direction expanded in mu,
+//    qeq.F90:297-306 with q = qs - mu qt) as a second set of partials -> scal[S_RAW4..6]
+template <bool EST3>
 __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ hst, double2 *__restrict__ qst,
                                                     const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
                                                     double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage) {
   const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
-  double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0;
+  double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     double2 qv = qst[i];
     const double2 hv = hst[i];
@@ -436,10 +421,21 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
     const double g1 = -ap.chi - ap.eta * qv.x - a.x - (pqrow ? pqrow[i].x : 0.0), g2 = -1.0 - ap.eta * qv.y - a.y;
     gst[i] = make_double2(g1, g2);
     s += qv.x; t += qv.y; g1s += g1 * g1; g2s += g2 * g2;
+    if (EST3) {        // chi q + eta q^2/2 + q (Hq_all + Hq_res)/2 with q = s - mu t, Hq_all + Hq_res = A - mu B
+      const double A = 2.0 * a.x - g.x, B = 2.0 * a.y - g.y;
+      e0 += ap.chi * qv.x + 0.5 * ap.eta * qv.x * qv.x + 0.5 * qv.x * A;
+      e1 += ap.chi * qv.y + ap.eta * qv.x * qv.y + 0.5 * (qv.x * B + qv.y * A);
+      e2 += 0.5 * ap.eta * qv.y * qv.y + 0.5 * qv.y * B;
+    }
   }
   double acc[4] = {wave_sum(s), wave_sum(t), wave_sum(g1s), wave_sum(g2s)};
   block_store_partials<4>(acc, partials, 4);
-  block_finish(gridDim.x, partials, ticket, stage, scal);     // stage 4, or 0 = sums only (the all-reduce of a multi-rank run comes first)
+  if (EST3) {
+    __syncthreads();                                           // block_store_partials stages through one LDS array
+    double acc2[4] = {wave_sum(e0), wave_sum(e1), wave_sum(e2), 0.0};
+    block_store_partials<4>(acc2, partials + static_cast<size_t>(gridDim.x) * 4, 4);
+  }
+  block_finish(gridDim.x, partials, ticket, stage, scal, EST3 ? 2 : 1);   // stage 4, or 0 = sums only (the all-reduce of a multi-rank run comes first)
 }
 // B: over the cell-sorted positions k (residents and their periodic images): new direction h = g + beta h written to the
 //    other (hs,ht) buffer and, as the QCOPY2 halo + sorted gather copy, to xs[k]; at the resident itself also
@@ -466,6 +462,7 @@ __global__ void __launch_bounds__(256) k_cg_direction(int G, int N, DevFF ff, do
       else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
     }
   }
+  if (stage < 0) return;                                      // Est came with the update kernel's sums (scalar_algebra stage 6)
   double acc[4] = {wave_sum(es), 0.0, 0.0, 0.0};
   block_store_partials<4>(acc, partials, 4);
   block_finish(gridDim.x, partials, ticket, stage, scal);     // stage 5 or 0
@@ -531,14 +528,14 @@ void Engine::qeq_start_vectors() {
   sorted_copy(qst);                                                                             // QCOPY1, qeq.F90:86
 }
 
-void Engine::allreduce_scal4() {
+void Engine::allreduce_scal4(int n) {
   if (nprocs == 1 && !nccl) return;              // forced staged mode of a single rank without a communicator: nothing to add
-  if (nccl) { rccl_allreduce_dev(scal + S_RAW0, 4); return; }      // in stream order, no host round trip
+  if (nccl) { rccl_allreduce_dev(scal + S_RAW0, n); return; }      // in stream order, no host round trip
   if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm or rxmd_hip_comm_init_rccl first");
-  RX_HIP(hipMemcpyAsync(h_scal + 48, scal + S_RAW0, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
+  RX_HIP(hipMemcpyAsync(h_scal + 48, scal + S_RAW0, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
   RX_HIP(hipStreamSynchronize(stream));
-  if (comm.allreduce_sum(comm.ctx, h_scal + 48, 4)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
-  RX_HIP(hipMemcpyAsync(scal + S_RAW0, h_scal + 48, sizeof(double) * 4, hipMemcpyHostToDevice, stream));
+  if (comm.allreduce_sum(comm.ctx, h_scal + 48, n)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
+  RX_HIP(hipMemcpyAsync(scal + S_RAW0, h_scal + 48, sizeof(double) * n, hipMemcpyHostToDevice, stream));
 }
 
 void Engine::qeq() {
@@ -591,12 +588,8 @@ void Engine::qeq() {
       else k_reduce_fused<<<1, 256, 0, stream>>>(nb_, partials, lvl1, tickets, stage, scal);
       return;
     }
-    if (nb_ > 1024) {
-      k_reduce_level1<<<128, 256, 0, stream>>>(nb_, partials, lvl1);
-      k_reduce_scalars<<<1, 256, 0, stream>>>(128, lvl1, scal);
-    } else {
-      k_reduce_scalars<<<1, 256, 0, stream>>>(nb_, partials, scal);
-    }
+    if (nb_ > 1024) k_reduce_fused<<<128, 256, 0, stream>>>(nb_, partials, lvl1, tickets, 0, scal);   // stage 0: rank-local sums only
+    else k_reduce_fused<<<1, 256, 0, stream>>>(nb_, partials, lvl1, tickets, 0, scal);
     allreduce_scal4();                           // MPI_ALLREDUCE of the rank-local sums
     k_scalar_algebra<<<1, 64, 0, stream>>>(stage, scal);
   };
@@ -618,6 +611,7 @@ void Engine::qeq() {
   float ms = 0;
   bool xs_current = false;       // the fused direction kernel leaves the sorted copy of the new (hs,ht) in xs
   const bool overlap_on = (std::getenv("RXMD_NO_HALO_OVERLAP") == nullptr);     // read per call: the tests switch it
+  const bool est_with_update = (std::getenv("RXMD_EST_SEPARATE") == nullptr);
   const bool overlap = overlap_on && multi() && onepass && !use_cell && !rows_split_pending_invalid();
   bool halo_in_flight = false;
   for (it = 0; it <= nmax - 1; ++it) {
@@ -645,14 +639,16 @@ void Engine::qeq() {
     }
     if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
       const bool fuse = !multi();                  // single rank: every reduction finishes in-kernel; multi: sums, all-reduce, algebra
-      k_cg_update<<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
-      if (!fuse) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(4, scal); }
+      const bool est3 = !fuse && !ff.pqeq && est_with_update;   // multi-rank: Est rides on the update kernel's all-reduce (two per iteration, not three)
+      if (est3) k_cg_update<true><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 0);
+      else k_cg_update<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
+      if (!fuse) { allreduce_scal4(est3 ? 8 : 4); k_scalar_algebra<<<1, 64, 0, stream>>>(est3 ? 6 : 4, scal); }
       if (fuse) {
         const int gb = std::min(nblk(G, 256), 2048);
         k_cg_direction<<<gb, 256, 0, stream>>>(G, N, dff, scal, perm, rootperm, type, gst, hst, hst2, xs, qst, sall, sgh, q, partials, tickets + 2, pqrow, 5);
       } else {
-        k_cg_direction<<<vb, 256, 0, stream>>>(N, N, dff, scal, nullptr, nullptr, type, gst, hst, hst2, nullptr, qst, sall, sgh, q, partials, tickets + 2, pqrow, 0);
-        allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal);
+        k_cg_direction<<<vb, 256, 0, stream>>>(N, N, dff, scal, nullptr, nullptr, type, gst, hst, hst2, nullptr, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : 0);
+        if (!est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
       }
       std::swap(hst, hst2);
       xs_current = fuse;                           // multi-rank: the (hs,ht) halo and the sorted copy come with the next pass ...
