@@ -21,7 +21,7 @@
 
 namespace rxmd {
 
-static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
 __global__ void __launch_bounds__(256) k_cd_gather(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
                                                     const double *__restrict__ cds, const double *__restrict__ cdn, double *__restrict__ cd) {

@@ -18,7 +18,7 @@
 
 namespace rxmd {
 
-static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
 static constexpr double MINBO0 = 1e-4, cutof2_esub = 1e-4;                                        // module.F90:61-62
 static constexpr double MAXANGLE = 0.999999999999, MINANGLE = -0.999999999999, NSMALL = 1e-10;   // module.F90:85-87

@@ -9,7 +9,7 @@
 
 namespace rxmd {
 
-static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
 __global__ void __launch_bounds__(256) k_bo_prime(int G, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt,
                                                    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, const int *__restrict__ type,

@@ -224,7 +224,7 @@ int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], 
 
 // ---- the reference's own argument shapes (QEq(atype,pos,q) qeq.F90:2 ; FORCE(atype,pos,f,q) pot.F90:2) ----
 static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const double *atype, const double *pos, const double *q) {
-  if (natoms < 1 || nbuffer < natoms) throw EngineError(RXMD_E_ARG, "bad natoms/nbuffer");
+  if (natoms < 0 || (natoms == 0 && e.nprocs == 1) || nbuffer < natoms) throw EngineError(RXMD_E_ARG, "bad natoms/nbuffer");
   // FORCE right after QEq (src/main.F90:77-84) hands over the same atoms: keep ghosts, cells and both lists, refresh the charges only
   if (e.atoms_set && e.lists_valid && natoms == e.N && e.last_atype.size() == static_cast<size_t>(natoms)) {
     bool same = std::memcmp(e.last_atype.data(), atype, sizeof(double) * natoms) == 0;

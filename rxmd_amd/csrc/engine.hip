@@ -299,7 +299,7 @@ void Engine::free_device() {
 
 // ReadBIN (reference src/fileio.F90:528-552): records -> real coordinates, split atype
 void Engine::set_atoms_rxff(int natoms, const double *rec) {
-  if (natoms < 1) throw EngineError(RXMD_E_ARG, "natoms must be positive");
+  if (natoms < 0 || (natoms == 0 && nprocs == 1)) throw EngineError(RXMD_E_ARG, "natoms must be positive");   // a rank of a decomposed box may own nothing
   std::vector<double> hx[3], hv[3], hq(natoms), hp(natoms), hw(natoms);
   std::vector<int> ht(natoms);
   std::vector<long long> hg(natoms);
@@ -324,17 +324,20 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
       for (int t = 0; t <= ff.nso; ++t) npt[t] = std::llround(tmp[t]);
     }
     setup_after_atoms(npt);
-    // capacities
+    // capacities: sized from this rank's atoms, but never below the mean share (a sparse or empty domain can fill up by migration)
+    long long ntot = 0;
+    for (int t = 1; t <= ff.nso; ++t) ntot += npt[t];
+    const long long nsize = std::max<long long>(natoms, ntot / nprocs);
     double fac = 1.0;
     for (int a = 0; a < 3; ++a) fac *= 1.0 + 2.0 * std::min(shell[a] / box.lbox[a], 1.0);
-    const long long want = static_cast<long long>(natoms * fac * 1.12) + 4096;
+    const long long want = static_cast<long long>(nsize * fac * 1.12) + 4096;
     NB = cfg.nbuffer > 0 ? cfg.nbuffer : static_cast<int>(std::min<long long>(want, 2000000000LL));
     if (NB <= natoms) throw EngineError(RXMD_E_NBUFFER, "nbuffer smaller than natoms");
     const double vloc = box.volume / nprocs;
-    const double est10 = natoms / vloc * (4.0 / 3.0) * 3.14159265358979 * ff.rctap * ff.rctap2;
+    const double est10 = nsize / vloc * (4.0 / 3.0) * 3.14159265358979 * ff.rctap * ff.rctap2;
     int s10 = cfg.maxneighbs10 > 0 ? cfg.maxneighbs10 : static_cast<int>(est10 * 1.35 + 64);
     S10 = (s10 + 63) / 64 * 64;
-    rows10 = std::min<long long>(NB, static_cast<long long>(natoms) + natoms / 8 + 1024);
+    rows10 = std::min<long long>(NB, nsize + nsize / 8 + 1024);
     if (ff.nso > 15) throw EngineError(RXMD_E_ARG, "more than 15 atom types do not fit the packed 10 A list entry");
     if (NB >= (1 << NB10_IDX_BITS)) throw EngineError(RXMD_E_NBUFFER, "more than 2^26 atoms+ghosts per GPU do not fit the packed 10 A list entry");
     alloc_device();
@@ -458,7 +461,7 @@ __global__ void k_fold_stage(int g0, int g1, const int *gsrc, double *fx, double
   fx[n] += fx[m]; fy[n] += fy[m]; fz[n] += fz[m];
 }
 
-static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
 void Engine::ghost_build() {
   if (multi()) { ghost_build_staged(); return; }

@@ -11,7 +11,7 @@
 
 namespace rxmd {
 
-static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
 // w component of sorted_xyzi: low 32 bits atom index, bits 32.. type
 __global__ void k_pack_type(int G, const int *perm, const int *type, double4 *s) {

@@ -9,7 +9,7 @@
 
 namespace rxmd {
 
-static inline int nblk(long long n, int b) { return static_cast<int>((n + b - 1) / b); }
+static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 static constexpr double CEchrge = 23.02;   // module.F90:683
 
 // w of the cell-sorted position array becomes the charge of the atom's owner (ghost charges = MODE_COPY payload, comm.F90:135)

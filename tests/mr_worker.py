@@ -53,3 +53,39 @@ def engine_rank(rank, world, port, case, vp, steps, out):
         dist.barrier(); dist.destroy_process_group()
     except Exception:
         out[rank] = dict(error=traceback.format_exc())
+
+
+def slab_system():
+    """RDX-168 squeezed into the lower 44 % of a box 1/0.35 times as long in x: at vprocs 2x1x1 rank 1 owns NO atom"""
+    import oracle_api as oa
+    ff, names, frac, lat = oa.make_system("rdx168")
+    frac2 = frac.copy(); frac2[:, 0] = frac2[:, 0] * 0.35
+    lat2 = list(lat); lat2[0] = lat[0] / 0.35
+    return ff, names, frac2, lat2
+
+
+def engine_rank_empty(rank, world, port, steps, qeq_mode, out):
+    """2x1x1 with an EMPTY second rank: it still takes part in every exchange round and all-reduce"""
+    try:
+        dist = _init(rank, world, port)
+        import torch
+        import rxmd_amd
+        from rxmd_amd import system
+        from rxmd_amd.comm import TorchTransport
+        ff, names, frac, lat = slab_system()
+        vp = (2, 1, 1)
+        lat_s, rec = system.geninit(ff, names, frac, lat, vprocs=vp, myid=rank)
+        e = rxmd_amd.RxmdEngine(ff, lat_s, vprocs=vp, myid=rank, QEq_tol=1e-12, NMAXQEq=2000, device=0, qeq_mode=qeq_mode, nbuffer=20000)
+        tr = TorchTransport(mode="staged", device=torch.device("cuda", 0), capacity_doubles=1 << 20)
+        tr.attach(e)
+        e.set_atoms_rxff(rec)
+        n0 = len(rec)
+        e.QEq(); pe = e.FORCE()
+        if steps:
+            e.step(steps)
+        a = e.atoms()
+        out[rank] = dict(n0=n0, gid=a["gid"], q=a["q"], f=a["f"], pos=a["pos"], pe=pe, err=repr(tr.error))
+        e.close()
+        dist.barrier(); dist.destroy_process_group()
+    except Exception:
+        out[rank] = dict(error=traceback.format_exc())

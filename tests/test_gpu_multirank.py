@@ -45,6 +45,36 @@ def test_vprocs_parity_vs_mpi_reference(case, steps):
         assert o["nex"] > 0 and o["nar"] > 0
 
 
+@pytest.mark.parametrize("qeq_mode", [0, 1])
+def test_a_rank_that_owns_no_atom(qeq_mode):
+    """ragged decomposition: all 168 atoms in the lower half of the box, rank 1 of 2x1x1 is EMPTY (zero residents, ghosts only) and must
+    still answer every exchange round and all-reduce; compared per rank with the multi-rank oracle, energies with the global sums"""
+    ff, names, frac, lat = mr_worker.slab_system()
+    lat_s, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), vprocs=(2, 1, 1))
+    assert [len(r["type"]) for r in ranks] == [168, 0]
+    o = oa.Oracle(ff, lat_s, ranks, vprocs=(2, 1, 1), QEq_tol=1e-12, NMAXQEq=2000, nbuffer=20000)
+    o.qeq(); o.force(); pe_ref = o.energy()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        port = _port()
+        ps = [ctx.Process(target=mr_worker.engine_rank_empty, args=(r, 2, port, 0, qeq_mode, out)) for r in range(2)]
+        [p.start() for p in ps]; [p.join(600) for p in ps]
+        assert len(out) == 2, "a rank died"
+        res = [out[r] for r in range(2)]
+    for r, x in enumerate(res):
+        assert "error" not in x, x.get("error")
+        assert x["err"] == "None"
+    assert res[0]["n0"] == 168 and res[1]["n0"] == 0 and len(res[1]["gid"]) == 0
+    assert np.array_equal(res[0]["gid"], o.gids(0))
+    qref, fref = o.charges(0), o.forces(0)
+    qrms = np.sqrt((qref ** 2).mean()); frms = np.sqrt((fref ** 2).mean())
+    assert (np.abs(res[0]["q"] - qref) / np.maximum(np.abs(qref), qrms)).max() <= 1e-6
+    assert (np.abs(res[0]["f"] - fref).max(axis=1) / np.maximum(np.abs(fref).max(axis=1), frms)).max() <= 1e-6
+    pe = np.array(res[0]["pe"]) + np.array(res[1]["pe"])           # rank-local energies; the oracle reports the global sums
+    assert max(abs(a - b) / abs(b) for a, b in zip(pe, pe_ref) if abs(b) > 1e-6) <= 1e-9
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("qeq_mode,overlap", [(0, True), (1, True), (1, False)])
 def test_native_rccl_transport_self_loop(qeq_mode, overlap, monkeypatch):
