@@ -101,3 +101,25 @@ def test_native_rccl_transport_self_loop(qeq_mode, overlap, monkeypatch):
     assert f_err(a["f"], o.forces()) <= 1e-6
     assert np.abs(a["pos"] - o.pos()).max() <= 1e-9
     e.close()
+
+
+@pytest.mark.gpu
+def test_pqeq_through_the_multi_rank_path_self_loop(monkeypatch):
+    """PQEq on the vprocs > 1 code path (staged exchange + RCCL self send/recv): shell positions and charges travel as halos,
+    the shell displacement migrates with its atom (14 doubles per record, comm.F90:153,165-167); against the clean oracle"""
+    from test_gpu_parity import _engine, _oracle, q_err, f_err
+    monkeypatch.setenv("RXMD_FORCE_STAGED", "1")
+    monkeypatch.setenv("RXMD_FORCE_REMOTE", "1")
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    e = _engine("sicnp", (1, 1, 1), pqeq=oa.PQEQ_SICNP, qeq_mode=1, **kw)
+    e.init_rccl(e.rccl_unique_id(), 0, 1)
+    o = _oracle("sicnp", (1, 1, 1), pqeq=oa.PQEQ_SICNP, **kw); o.set_pqeq_clean(1)
+    e.QEq(); e.FORCE(); o.qeq(); o.force()
+    e.step(3); o.step(3)
+    a = e.atoms()
+    ie = np.argsort(a["gid"]); io = np.argsort(o.gids())
+    assert np.abs(a["pos"][ie] - o.pos()[io]).max() <= 1e-9
+    assert q_err(a["q"][ie], o.charges()[io]) <= 1e-6
+    assert f_err(a["f"][ie], o.forces()[io]) <= 1e-6
+    assert np.abs(e.shells()[ie] - o.spos()[io]).max() <= 1e-7
+    e.close()
