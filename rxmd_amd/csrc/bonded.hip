@@ -552,19 +552,31 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
       const double xi = x[i], yi = y[i], zi = z[i];
       const int n = n10[i];
       const size_t row = static_cast<size_t>(i) * S10;
-      for (int s = 0; s < cnt; ++s) {
+      const int inx_l = (lane >= 1 && lane <= ff.nso) ? ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + lane] : 0;
+      // the lanes test the bond slots side by side (one round trip instead of cnt dependent ones: three atoms in four have no
+      // hydrogen partner and leave here); the surviving slots are then visited in slot order
+      int jl = 0; double bl = 0.0; bool hq = false;
+      if (lane < cnt) {
+        const size_t ol = static_cast<size_t>(lane) * NB + i;
+        jl = nbr[ol]; bl = bo0[ol];
+        hq = (type[jl] == 2 && bl > MINBO0);
+      }
+      unsigned long long hmask = __ballot(hq);
+      while (hmask) {
+        const int s = __ffsll(static_cast<long long>(hmask)) - 1;
+        hmask &= hmask - 1;
         const size_t o = static_cast<size_t>(s) * NB + i;
-        const int j = nbr[o];
-        const double BOij = bo0[o];
-        if (!(type[j] == 2 && BOij > MINBO0)) continue;
+        const int j = __shfl(jl, s, 64);
+        const double BOij = __shfl(bl, s, 64);
         const V3 rij = {xi - x[j], yi - y[j], zi - z[j]};
         const double nij = sqrt(dot(rij, rij));
         double cfs = 0.0, nterm = 0.0;
         V3 fi_s = {0, 0, 0}, fj_s = {0, 0, 0};
-        for (int kk = lane; kk < n; kk += 64) {
-          const unsigned ent = static_cast<unsigned>(nb10[row + kk]);
-          const int inx = ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + static_cast<int>((ent >> NB10_IDX_BITS) & 15u)];
-          if (inx == 0) continue;
+        for (int k0 = 0; k0 < n; k0 += 64) {                                // wave-uniform trip count: the shuffle below needs every lane
+          const int kk = k0 + lane;
+          const unsigned ent = kk < n ? static_cast<unsigned>(nb10[row + kk]) : 0u;
+          const int inx = __shfl(inx_l, static_cast<int>((ent >> NB10_IDX_BITS) & 15u), 64);   // (ti, H, type k) row, held by lane = type k
+          if (kk >= n || inx == 0) continue;
           const int ks = static_cast<int>(ent & NB10_IDX_MASK);
           const int k = perm[ks];                                          // list entries are cell-sorted positions
           if (k == j || k == i) continue;
