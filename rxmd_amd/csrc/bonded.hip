@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   // force in [1..3] and cdbnd in [6].  (An earlier version wrote 11 results per torsion to LDS and let every owner lane scan all 64
   // of them: that scan cost about as many instructions as the torsion itself.)
   __shared__ double s_acc[4][64][7];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
   const int jbase = (blockIdx.x * 4 + w) * 2;
   if (jbase >= N) return;                        // whole wavefront leaves together; no block-level barrier below
   const int g_me = lane >> 5, sl_me = lane & 31;
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
                                               double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
   const int lane = threadIdx.x & 63;
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
   double e10 = 0.0;
   if (i < N) {
     const int ti = type[i], cnt = nbrcnt[i];

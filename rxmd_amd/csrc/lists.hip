@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
                                                  const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag) {
   // dynamic LDS: [4][128] queue of accepted candidates (sorted position, neighbourhood position), [4][128] chunk table, then [4][S10] 16-bit rows
   extern __shared__ int lds_all[];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
   if (i >= N) return;
   constexpr int MAXCH = 128;                     // chunks of one row (RDX: 26-50)

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(64 * NB_WPB) k_nonbond(int N, int S10, DevFF f
                                                   const double *__restrict__ q, const int *__restrict__ type,
                                                   double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
   __shared__ double sm[NB_WPB][3], sv[NB_WPB][6];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
   if (threadIdx.x < 6 * NB_WPB) sv[threadIdx.x / 6][threadIdx.x % 6] = 0.0;
   __syncthreads();
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) k_shell_update(int N, int S10, DevFF ff, 
                                                        const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
                                                        double *__restrict__ nx, double *__restrict__ ny, double *__restrict__ nz, int edir, double efield) {
   const int lane = threadIdx.x & 63;
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   if (i >= N) return;
   const int ti = type[i];
   const double s0 = sx[i], s1 = sy[i], s2 = sz[i];
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
                                                        const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
                                                        double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
   __shared__ double sm[4][3], sv[4][6];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   if (threadIdx.x < 24) sv[threadIdx.x / 6][threadIdx.x % 6] = 0.0;
   __syncthreads();
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
