@@ -239,6 +239,34 @@ def test_full_size_properties_rdx_1m():
     e.close()
 
 
+@pytest.mark.parametrize("case,mc_small,mc_full,natoms", [("ice644", (6, 4, 4), (60, 35, 40), 2016000), ("sicnp", (1, 1, 1), (12, 12, 12), 945216)])
+def test_full_size_properties_water_and_sicnp(case, mc_small, mc_full, natoms):
+    """BASELINE configs[2] (perturbed ice Ih, 2,016,000 atoms) and configs[4] (SiC nanoparticle + O2 with PQEq, 945,216 atoms) at full
+    size, by the same size-independent property as the RDX case: both are replications of a unit cell, so per-atom charges repeat
+    those of a small replication of the same cell, every energy term scales with the cell count and the net charge vanishes.
+    Water additionally keeps the reference's quirk that no hydrogen bond is ever found (type 2 is O in this ffield)."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    if case == "sicnp":
+        kw["pqeq"] = oa.PQEQ_SICNP
+    e1 = _engine(case, mc_small, **kw); e1.QEq(); pe1 = e1.FORCE(); a1 = e1.atoms(); e1.close()
+    e = _engine(case, mc_full, qeq_mode=1, **kw)
+    e.QEq(); pe = e.FORCE(); a = e.atoms()
+    assert len(a["q"]) == natoms
+    n0 = len(a1["q"]) // (mc_small[0] * mc_small[1] * mc_small[2])          # atoms of the unit cell
+    ratio = natoms // len(a1["q"])
+    # charges: atom t of every unit cell carries the charge of atom t of the small system's first cell (gid order: cell-major)
+    o1 = np.argsort(a1["gid"]); o = np.argsort(a["gid"])
+    q_cell = a1["q"][o1][:n0]
+    assert q_err(a["q"][o], np.tile(q_cell, natoms // n0)) <= 5e-7
+    assert abs(a["q"].sum()) <= 1e-6 * np.abs(a["q"]).sum()
+    scale = abs(ratio * pe1[0])
+    for k in range(1, 14):
+        assert abs(pe[k] - ratio * pe1[k]) <= 1e-7 * abs(ratio * pe1[k]) + 1e-9 * scale      # second term: PQEq's PE(12) is a small difference of large sums
+    if case == "ice644":
+        assert pe[10] == 0.0
+    e.close()
+
+
 @pytest.mark.parametrize("case,mc", [("rdx168", (1, 1, 1)), ("rdx222", (2, 2, 2))])
 def test_one_pass_qeq_mode_reaches_the_same_fixed_point(case, mc):
     """qeq_mode=1 (one matrix pass per CG iteration, gradient/Est by recurrence on stored row sums) is an opt-in
