@@ -439,32 +439,26 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
   }
   block_finish(gridDim.x, partials, ticket, stage, scal, EST3 ? 2 : 1);   // stage 4, or 0 = sums only (the all-reduce of a multi-rank run comes first)
 }
-// B: over the cell-sorted positions k (residents and their periodic images): new direction h = g + beta h written to the
-//    other (hs,ht) buffer and, as the QCOPY2 halo + sorted gather copy, to xs[k]; at the resident itself also
-//    q = qs - mu qt and the Est term (qeq.F90:150,160-164,297-306) -> tail: Est
-__global__ void __launch_bounds__(256) k_cg_direction(int G, int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ perm, const int *__restrict__ rootperm, const int *__restrict__ type,
-                                                       const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new, double2 *__restrict__ xs,
+// B: new direction h = g + beta h written to the other (hs,ht) buffer; q = qs - mu qt and the Est term (qeq.F90:150,160-164,297-306)
+//    -> tail: Est (stage 5), sums only (0) or no reduction at all (-1: Est came with the update kernel's sums)
+__global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type,
+                                                       const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new,
                                                        const double2 *__restrict__ qst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double *__restrict__ q,
                                                        double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage) {
   const double mu = scal[S_MU], b1 = scal[S_BETA_S], b2 = scal[S_BETA_T];
   double es = 0.0;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < G; k += gridDim.x * blockDim.x) {
-    const int i = rootperm ? rootperm[k] : k;        // rootperm == nullptr: residents only, k is the atom (multi-rank: the halo + sorted copy follow)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     const double2 g = gst[i], h = hst[i];
-    const double2 hn = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
-    if (xs) xs[k] = hn;
-    if (!perm || perm[k] == i) {                              // the resident itself, not one of its images
-      hst_new[i] = hn;
-      const DevAtomP ap = ff.atom[type[i]];
-      const double2 qv = qst[i], a = sall[i], gh = sgh[i];
-      const double qi = qv.x - mu * qv.y;
-      q[i] = qi;
-      const double hq_all = a.x - mu * a.y, hq_res = (a.x - gh.x) - mu * (a.y - gh.y);
-      if (pqrow) es += pq_est_row(ap, ff.Zpq[type[i]], pqrow[i], qi, hq_all, gh.x - mu * gh.y);
-      else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
-    }
+    hst_new[i] = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
+    const DevAtomP ap = ff.atom[type[i]];
+    const double2 qv = qst[i], a = sall[i], gh = sgh[i];
+    const double qi = qv.x - mu * qv.y;
+    q[i] = qi;
+    const double hq_all = a.x - mu * a.y, hq_res = (a.x - gh.x) - mu * (a.y - gh.y);
+    if (pqrow) es += pq_est_row(ap, ff.Zpq[type[i]], pqrow[i], qi, hq_all, gh.x - mu * gh.y);
+    else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
   }
-  if (stage < 0) return;                                      // Est came with the update kernel's sums (scalar_algebra stage 6)
+  if (stage < 0) return;
   double acc[4] = {wave_sum(es), 0.0, 0.0, 0.0};
   block_store_partials<4>(acc, partials, 4);
   block_finish(gridDim.x, partials, ticket, stage, scal);     // stage 5 or 0
@@ -645,16 +639,18 @@ void Engine::qeq() {
       if (est3) k_cg_update<true><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 0);
       else k_cg_update<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
       if (!fuse) { allreduce_scal4(est3 ? 8 : 4); k_scalar_algebra<<<1, 64, 0, stream>>>(est3 ? 6 : 4, scal); }
-      if (fuse) {
-        const int gb = std::min(nblk(G, 256), 2048);
-        k_cg_direction<<<gb, 256, 0, stream>>>(G, N, dff, scal, perm, rootperm, type, gst, hst, hst2, xs, qst, sall, sgh, q, partials, tickets + 2, pqrow, 5);
-      } else {
-        k_cg_direction<<<vb, 256, 0, stream>>>(N, N, dff, scal, nullptr, nullptr, type, gst, hst, hst2, nullptr, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : 0);
-        if (!est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
-      }
+      // the direction update runs over the residents in atom order (every access coalesced); the cell-sorted copy with the images
+      // is one gather pass at the head of the next iteration (sorted_copy).  Doing both in one kernel over the sorted positions
+      // (five random 16-byte accesses per atom) was 0.4 ms per step slower.
+      k_cg_direction<<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, fuse ? 5 : (est3 ? -1 : 0));
+      if (!fuse && !est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
       std::swap(hst, hst2);
-      xs_current = fuse;                           // multi-rank: the (hs,ht) halo and the sorted copy come with the next pass ...
-      if (overlap && it + 1 <= nmax - 1) {         // ... or, overlapped: residents' part of the sorted copy now, halo + ghosts' part on the second stream
+      xs_current = false;
+      if (!overlap && it + 1 <= nmax - 1) {        // sorted copy (multi-rank: after the (hs,ht) halo) queued before the host waits for Est
+        sorted_copy(hst);
+        xs_current = true;
+      }
+      if (overlap && it + 1 <= nmax - 1) {         // overlapped: residents' part of the sorted copy now, halo + ghosts' part on the second stream
         k_sorted_part<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, hst, xs, 0);
         on_comm_stream([&] {
           halo_staged(reinterpret_cast<double *>(hst), 2);
