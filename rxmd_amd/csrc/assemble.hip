@@ -25,7 +25,7 @@ static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n 
 
 __global__ void __launch_bounds__(256) k_cd_gather(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
                                                     const double *__restrict__ cds, const double *__restrict__ cdn, double *__restrict__ cd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int cnt = nbrcnt[i];
   double s = cds[i];
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_ccbnd(int G, int NB, const int *__restr
                                                 const double *__restrict__ A2, const double *__restrict__ A3,
                                                 const double *__restrict__ cf1, const double *__restrict__ cf2, const double *__restrict__ cf3,
                                                 const double *__restrict__ cd, double *__restrict__ cc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int cnt = nbrcnt[i];
   const double cdi = cd[i];
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_bond_forces(int G, int NB, const int *_
                                                       const double *__restrict__ fnx, const double *__restrict__ fny, const double *__restrict__ fnz,
                                                       const double *__restrict__ cd, const double *__restrict__ cc,
                                                       double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int cnt = nbrcnt[i];
   const double xi = x[i], yi = y[i], zi = z[i], cdi = cd[i], cci = cc[i];

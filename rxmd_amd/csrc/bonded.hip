@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_ebond_elnpr(int N, int NB, DevFF ff, co
                                                       const double *__restrict__ bo2, const double *__restrict__ bo3, const double *__restrict__ delta,
                                                       const double *__restrict__ deltalp, const double *__restrict__ dDlp,
                                                       double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn, double *__restrict__ ecoa, double *__restrict__ pe) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   double e1 = 0.0, e2 = 0.0, e3 = 0.0, e4 = 0.0;
   if (i < N) {
     const int ti = type[i], cnt = nbrcnt[i];
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
   if (j < N) {
     const int tj = type[j], nj = nbrcnt[j];

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) k_bo_prime(int G, int NB, DevFF ff, const
                                                    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, const int *__restrict__ type,
                                                    double *__restrict__ bo0, double *__restrict__ bo2, double *__restrict__ bo3,
                                                    double *__restrict__ dln2, double *__restrict__ dln3, double *__restrict__ dBOp, double *__restrict__ deltap) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int ti = type[i], cnt = nbrcnt[i];
   const double xi = x[i], yi = y[i], zi = z[i];
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) k_bo_full(int G, int NB, DevFF ff, const 
                                                   double *__restrict__ etor, double *__restrict__ econ, double *__restrict__ epen,
                                                   double *__restrict__ delta, double *__restrict__ nlp, double *__restrict__ dDlp, double *__restrict__ deltalp, double *__restrict__ cds,
                                                   double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int ti = type[i], cnt = nbrcnt[i];
   const DevAtomP ai = ff.atom[ti];

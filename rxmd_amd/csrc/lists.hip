@@ -25,7 +25,7 @@ __global__ void k_pack_type(int G, const int *perm, const int *type, double4 *s)
 __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                       const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ z, const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int c = cellid[i];
   const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
 
 // nbrindx(i,i1) = j1 such that nbrlist(j,j1) == i   (main.F90:383-399)
 __global__ void k_reverse_index(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, unsigned char *__restrict__ nbrindx, int *err) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int ni = nbrcnt[i];
   for (int s = 0; s < ni; ++s) {
