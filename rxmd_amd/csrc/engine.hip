@@ -93,7 +93,11 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   RX_HIP(hipSetDevice(cfg.device));
   RX_HIP(hipStreamCreate(&stream));
   if (std::getenv("RXMD_SINGLE_STREAM")) comm_stream = stream;   // diagnostic: the halo work queues on the main stream (no second hardware queue)
-  else RX_HIP(hipStreamCreate(&comm_stream));
+  else {                                         // highest priority: pack / send-recv / unpack kernels of a halo go ahead of the queued compute workgroups
+    int lo = 0, hi = 0;
+    RX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    RX_HIP(hipStreamCreateWithPriority(&comm_stream, hipStreamDefault, hi));
+  }
   RX_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   for (auto &e : ev) RX_HIP(hipEventCreate(&e));
 }
