@@ -25,12 +25,18 @@ __global__ void k_pack_type(int G, const int *perm, const int *type, double4 *s)
 __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                       const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ z, const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {
+  // squared bond cut-off of every type pair in LDS (0 = the pair has no bond row): one LDS read per candidate instead of two
+  // dependent global look-ups (inxn2, then bond[inxn].rc2)
+  __shared__ double s_rc2[256];
+  for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) { const int ix = ff.inxn2[t]; s_rc2[t] = ix ? ff.bond[ix].rc2 : 0.0; }
+  __syncthreads();
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int c = cellid[i];
   const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
   const int ti = type[i];
+  const double *rc2row = s_rc2 + ti * ff.n1;
   const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.n[2] - 1);
   int cnt = 0;
   for (int dx = -1; dx <= 1; ++dx) {
@@ -47,11 +53,9 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
         const int j = static_cast<int>(w & 0xffffffffLL);
         if (j == i) continue;
         const int tj = static_cast<int>(w >> 32);
-        const int inxn = ff.inxn2[ti * ff.n1 + tj];
-        if (inxn == 0) continue;
         const double d0 = p.x - xi, d1 = p.y - yi, d2 = p.z - zi;
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-        if (r2 < ff.bond[inxn].rc2) {           // dr2 < rc2(inxn), main.F90:366
+        if (r2 < rc2row[tj]) {                  // dr2 < rc2(inxn), main.F90:366 (no bond row: cut-off 0)
           if (cnt < MAXNB) nbr[static_cast<size_t>(cnt) * NB + i] = j;
           ++cnt;
         }
