@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
         const double2 v = xv[e[u] & NB10_IDX_MASK];
         as += h[u] * v.x;
         at += h[u] * v.y;
-        if ((MODE == MODE_GRAD || STORE) && !PQ && (e[u] & NB10_GHOST)) { gs_ += h[u] * v.x; gt_ += h[u] * v.y; }
+        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
         if ((MODE == MODE_GRAD || STORE) && PQ) {      // PQEq: second matrix (shell-core) over the same columns
           const int k = k0 + 64 * u;
           const double c = (k < n) ? __builtin_nontemporal_load(hsc + base + k) : 0.0;
