@@ -446,7 +446,10 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
       // image at -T and finds the same product, so each of the two visits takes out half (rare lanes only).
       {
         const double xk = x[k], yk = y[k], zk = z[k];
-        const double t0 = -boxl.x * floor(xk / boxl.x), t1 = -boxl.y * floor(yk / boxl.y), t2 = -boxl.z * floor(zk / boxl.z);
+        // k is bonded to a resident: it lies inside the box or in the first image layer, so comparisons name the lattice vector
+        // (floor(x / L) costs three FP64 divisions per torsion)
+        const double t0 = xk < 0.0 ? boxl.x : (xk >= boxl.x ? -boxl.x : 0.0), t1 = yk < 0.0 ? boxl.y : (yk >= boxl.y ? -boxl.y : 0.0),
+                     t2 = zk < 0.0 ? boxl.z : (zk >= boxl.z ? -boxl.z : 0.0);
         if (t0 != 0.0 || t1 != 0.0 || t2 != 0.0) {
           const double F0 = 0.5 * (o[1] + fself.x), F1 = 0.5 * (o[2] + fself.y), F2 = 0.5 * (o[3] + fself.z);
           if (t0 != 0.0) { atomicAdd(pe + 16, t0 * F0); atomicAdd(pe + 21, t0 * F1); }     // xx, xy
