@@ -99,6 +99,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
     RX_HIP(hipStreamCreateWithPriority(&comm_stream, hipStreamDefault, hi));
   }
   RX_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
+  RX_HIP(hipEventCreateWithFlags(&ev_est, hipEventDisableTiming));
   for (auto &e : ev) RX_HIP(hipEventCreate(&e));
 }
 
@@ -108,6 +109,7 @@ Engine::~Engine() {
   for (auto &e : ev) if (e) (void)hipEventDestroy(e);
   if (ev_main) (void)hipEventDestroy(ev_main);
   if (ev_comm) (void)hipEventDestroy(ev_comm);
+  if (ev_est) (void)hipEventDestroy(ev_est);
   if (comm_stream && comm_stream != stream) (void)hipStreamDestroy(comm_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }

@@ -644,6 +644,10 @@ void Engine::qeq() {
       // (five random 16-byte accesses per atom) was 0.4 ms per step slower.
       k_cg_direction<<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, fuse ? 5 : (est3 ? -1 : 0));
       if (!fuse && !est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
+      // Est is final here: send it to the host now and let the host wait for THIS copy only (an event), so that it evaluates the
+      // exit test and queues the next matrix pass while the sorted copy / the halo of the next iteration are still running
+      RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipEventRecord(ev_est, stream));
       std::swap(hst, hst2);
       xs_current = false;
       if (!overlap && it + 1 <= nmax - 1) {        // sorted copy (multi-rank: after the (hs,ht) halo) queued before the host waits for Est
@@ -658,8 +662,7 @@ void Engine::qeq() {
         });
         halo_in_flight = true;
       }
-      RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipStreamSynchronize(stream));
+      RX_HIP(hipEventSynchronize(ev_est));
       Est = h_scal[S_EST];
       hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
       st.spmv_launches += 1;
