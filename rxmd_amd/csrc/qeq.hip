@@ -635,19 +635,23 @@ void Engine::qeq() {
     }
     if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
       const bool fuse = !multi();                  // single rank: every reduction finishes in-kernel; multi: sums, all-reduce, algebra
-      const bool est3 = !fuse && !ff.pqeq && est_with_update;   // multi-rank: Est rides on the update kernel's all-reduce (two per iteration, not three)
-      if (est3) k_cg_update<true><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 0);
+      // plain QEq: Est rides on the update kernel's sums (quadratic in mu, scalar_algebra stage 6) -- multi-rank: two all-reduces per
+      // iteration instead of three; any rank count: Est is final BEFORE the direction kernel, so its copy to the host, the host's exit
+      // test and the launch of the next matrix pass all run underneath the direction update and the sorted copy / halo
+      const bool est3 = !ff.pqeq && est_with_update;
+      if (est3) k_cg_update<true><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 6 : 0);
       else k_cg_update<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
       if (!fuse) { allreduce_scal4(est3 ? 8 : 4); k_scalar_algebra<<<1, 64, 0, stream>>>(est3 ? 6 : 4, scal); }
+      if (est3) { RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream)); RX_HIP(hipEventRecord(ev_est, stream)); }
       // the direction update runs over the residents in atom order (every access coalesced); the cell-sorted copy with the images
-      // is one gather pass at the head of the next iteration (sorted_copy).  Doing both in one kernel over the sorted positions
+      // is one gather pass queued behind it (sorted_copy).  Doing both in one kernel over the sorted positions
       // (five random 16-byte accesses per atom) was 0.4 ms per step slower.
-      k_cg_direction<<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, fuse ? 5 : (est3 ? -1 : 0));
+      k_cg_direction<<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : (fuse ? 5 : 0));
       if (!fuse && !est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
-      // Est is final here: send it to the host now and let the host wait for THIS copy only (an event), so that it evaluates the
-      // exit test and queues the next matrix pass while the sorted copy / the halo of the next iteration are still running
-      RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipEventRecord(ev_est, stream));
+      if (!est3) {       // PQEq: Est comes out of the direction kernel; the host still waits for this copy only, not for the sorted copy behind it
+        RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
+        RX_HIP(hipEventRecord(ev_est, stream));
+      }
       std::swap(hst, hst2);
       xs_current = false;
       if (!overlap && it + 1 <= nmax - 1) {        // sorted copy (multi-rank: after the (hs,ht) halo) queued before the host waits for Est
