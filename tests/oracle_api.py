@@ -242,3 +242,19 @@ def make_system(case):
 
 
 PQEQ_SICNP = os.path.join(INP, "pqeq_sicnp.in")
+
+
+# The reference's own published known answer: README.md:157, step-0 line of the 168-atom RDX sample run (per-atom energies as PRINTE
+# prints them: GPE es13.5, the groups es11.3).  (value, half a unit of the last printed digit)
+README_KNOWN_ANSWER = {
+    "GPE": (-9.82464E+01, 0.5e-4), "Ebond": (-1.369E+02, 0.5e-1), "lp+ov+un": (1.287E+00, 0.5e-3), "val+pen+coa": (-1.362E+00, 0.5e-3),
+    "tors+conj": (5.208E-01, 0.5e-4), "Ehb": (-1.398E-03, 0.5e-6), "vdW+Clmb+chg": (3.821E+01, 0.5e-2),
+}
+
+
+def check_readme_known_answer(pe, natoms=168):
+    """pe = PE(0:13) of the whole system after the pre-loop QEq + FORCE (default rxmd.in: QEq tol 1e-7, q0 = 0)"""
+    got = {"GPE": pe[0], "Ebond": pe[1], "lp+ov+un": pe[2:5].sum(), "val+pen+coa": pe[5:8].sum(), "tors+conj": pe[8:10].sum(),
+           "Ehb": pe[10], "vdW+Clmb+chg": pe[11:14].sum()}
+    for k, (ref, half) in README_KNOWN_ANSWER.items():
+        assert abs(got[k] / natoms - ref) <= half * 1.02, (k, got[k] / natoms, ref)

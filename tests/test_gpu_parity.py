@@ -94,6 +94,16 @@ def test_tight_tolerance_parity_vs_reference_golden(case, npz):
     e.close()
 
 
+def test_step0_energies_match_the_references_published_sample_output():
+    """README.md:157 of the reference: per-atom energies of the 168-atom RDX sample at step 0 (default rxmd.in, QEq tol 1e-7, q0 = 0),
+    to the digits it prints -- through the C ABI, both QEq modes"""
+    for mode in (0, 1):
+        e = _engine("rdx168", (1, 1, 1), qeq_mode=mode)
+        e.QEq(); pe = e.FORCE()
+        oa.check_readme_known_answer(np.asarray(pe))
+        e.close()
+
+
 def test_forces_only_no_qeq_vs_reference_golden():
     g = np.load(os.path.join(oa.GOLD, "rdx168_noqeq.npz"))
     e = _engine("rdx168", (1, 1, 1), isQEq=0)

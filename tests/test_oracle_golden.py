@@ -61,6 +61,12 @@ def test_rdx168_default_tolerance_bitpath():
     assert abs(tr[-1, 0] - (-1.260035970464605E+02)) < 1e-10
 
 
+def test_rdx168_step0_energies_match_the_references_published_sample_output():
+    """the only known answer the reference itself publishes: README.md:157 (168-atom RDX, default rxmd.in)"""
+    g, o, iters, pe = _run("rdx168_tol7", (1, 1, 1))
+    oa.check_readme_known_answer(np.asarray(pe))
+
+
 def test_rdx168_tight():
     g, o, iters, pe = _run("rdx168_tight", (1, 1, 1), QEq_tol=1e-12, NMAXQEq=2000)
     assert iters[0] == int(g["qeq_iters"][0])
