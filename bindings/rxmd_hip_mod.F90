@@ -127,7 +127,7 @@ contains
 
   !> call once after GETPARAMS/INITSYSTEM (reference src/main.F90:20-23) with the module-global run parameters
   subroutine rxmd_hip_init(ffpath, lata, latb, latc, lalpha, lbeta, lgamma, vprocs, myid, isQEq, NMAXQEq, QEq_tol, qstep, dt_fs, device, pqeqpath)
-    use atoms, only: isLG                                       ! --lg (cmdline.F90:148-151): the ffield format and the vdW tables
+    use atoms, only: isLG, isEfield, eFieldDir, eFieldStrength   ! --lg (cmdline.F90:148-151); rxmd.in `efield` (cmdline.F90:131-137,286-289)
     character(len=*), intent(in) :: ffpath
     character(len=*), intent(in), optional :: pqeqpath          ! PQEqParmPath when isPQEq (cmdline.F90:112-128)
     character(kind=c_char, len=:), allocatable, target, save :: cpq
@@ -144,6 +144,9 @@ contains
     cfg%isQEq = isQEq; cfg%NMAXQEq = NMAXQEq; cfg%QEq_tol = QEq_tol; cfg%qstep = qstep; cfg%dt_fs = dt_fs
     cfg%device = device
     if (isLG) cfg%lg = 1
+    if (isEfield) then                                          ! field force on cores and shells inside FORCE / PQEq (pot.F90:61, pqeq.F90:205)
+       cfg%efield_dir = eFieldDir; cfg%efield_strength = eFieldStrength
+    endif
     if (present(pqeqpath)) then
        if (len_trim(pqeqpath) > 0) then
           cpq = trim(pqeqpath)//c_null_char

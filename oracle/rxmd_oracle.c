@@ -874,9 +874,9 @@ static void initialize_pqeq(Params *P) {
   }
   for (int ity = 1; ity <= nt; ity++) {                 /* module.F90:501-519 */
     if (!P->isPolarizable[ity]) { P->Zpqeq[ity] = 0.0; P->Kspqeq[ity] = 0.0; }
-    else { P->chi[ity] = P->X0pqeq[ity]; P->eta[ity] = P->J0pqeq[ity]; }
+    else if (ity <= P->nso) { P->chi[ity] = P->X0pqeq[ity]; P->eta[ity] = P->J0pqeq[ity]; }
   }
-  for (int ity = 1; ity <= nt; ity++) P->eta[ity] = 2.0 * P->eta[ity];   /* :522 (eta(:) has ntype_pqeq elements in this routine) */
+  for (int ity = 1; ity <= P->nso; ity++) P->eta[ity] = 2.0 * P->eta[ity];   /* :522, eta(:) = every ffield type: types the file does not list are doubled a second time */
   int icounter = 0;
   for (int ity = 1; ity <= nt; ity++) for (int jty = ity; jty <= nt; jty++) { icounter++; PQ2(P->inxnpqeq, ity, jty) = icounter; PQ2(P->inxnpqeq, jty, ity) = icounter; }
   size_t tsz = (size_t)(nt * nt + 1) * (NTABLE + 2) * 2;
@@ -1908,7 +1908,7 @@ int rxo_enable_pqeq(void *w, const char *pqeq_path) {
   World *W = (World *)w; Params *P = &W->P;
   int rc = read_pqeq(P, pqeq_path);
   if (rc) { snprintf(W->err, 256, "cannot read PQEq parameters from %s (%d)", pqeq_path, rc); return rc; }
-  if (P->ntype_pqeq < P->nso) { snprintf(W->err, 256, "PQEq parameter file lists %d types, the ffield %d", P->ntype_pqeq, P->nso); return -3; }
+  /* fewer rows than ffield types is legal (examples/3-reaxpq+): the loops of initialize_pqeq run over ntype_pqeq, module.F90:501-522 */
   P->isPQEq = 1;
   P->rctap = rctap0_pqeq; P->rctap2 = P->rctap * P->rctap;
   double rc_ = P->rctap;

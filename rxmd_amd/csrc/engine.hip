@@ -145,6 +145,9 @@ void Engine::check_device_error(const char *where) {
 // ---------------------------------------------------------------------------------------------
 // derived quantities that need the atoms (INITSYSTEM after ReadBIN, init.F90:141-213)
 void Engine::setup_after_atoms(const std::vector<long long> &npt) {
+  if (ff.pqeq)
+    for (int t = ff.npq + 1; t <= ff.nso; ++t)
+      if (npt[t] > 0) throw EngineError(RXMD_E_FFIELD, "PQEq: atoms of ffield type " + std::to_string(t) + " (" + ff.atom[t].name + ") have no row in the PQEq parameter file");
   ff.compute_cutoffs(npt);
   ff.build_tables();
   if (ff.pqeq) ff.build_pqeq_tables();

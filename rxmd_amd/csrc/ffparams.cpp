@@ -340,9 +340,12 @@ void ForceField::parse_pqeq(const std::string &path) {
     X0pq[n] = x0; J0pq[n] = j0; Zpq[n] = z; Rcpq[n] = rc; Rspq[n] = rs; Kspq[n] = ks;
   }
   if (npq < 1 || n != npq) throw std::runtime_error("PQEq: parameter file " + path + " is incomplete");
-  if (npq < nso) throw std::runtime_error("PQEq: fewer parameter rows than ffield atom types");
-  // initialize_pqeq, module.F90:501-522: chi <- X0, eta <- 2*J0 for every (polarizable) type
-  for (int t = 1; t <= nso; ++t) { atom[t].chi = X0pq[t]; atom[t].eta = 2.0 * J0pq[t]; }
+  // initialize_pqeq, module.F90:501-522: chi <- X0, eta <- 2*J0 for every listed (polarizable) type.  The file may list fewer types
+  // than the ffield (the reference's examples/3-reaxpq+ lists C and H only): the remaining types keep their ffield values, their
+  // eta takes the second doubling of module.F90:522, and atoms of such a type are refused when the atoms are set (the reference
+  // would index its parameter arrays out of bounds).
+  for (int t = 1; t <= nso && t <= npq; ++t) { atom[t].chi = X0pq[t]; atom[t].eta = 2.0 * J0pq[t]; }
+  for (int t = npq + 1; t <= nso; ++t) atom[t].eta *= 2.0;
   inxnpq.assign((npq + 1) * (npq + 1), 0);
   int c = 0;
   for (int a = 1; a <= npq; ++a) for (int b = a; b <= npq; ++b) { ++c; inxnpq[a * (npq + 1) + b] = c; inxnpq[b * (npq + 1) + a] = c; }

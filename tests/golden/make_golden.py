@@ -260,7 +260,31 @@ def make_minimiser():
         shutil.rmtree(tmp)
 
 
+def make_examples():
+    """The reference's own example workflows as shipped (examples/1-reaxff and examples/3-reaxpq+: polyethylene, geninit -mc 2 3 5,
+    their rxmd.in; example 3 adds PQEq (pqeq1.par) and an electric field along x), shortened to 20 steps: MDstep rows and the last frame"""
+    for ex, extra in (("example1", []), ("example3", ["pqeq1.par"])):
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        try:
+            os.makedirs(os.path.join(tmp, "DAT"))
+            for f in ("input.xyz", "ffield"):
+                shutil.copy(os.path.join(INP, "example1", f), os.path.join(tmp, f))
+            shutil.copy(os.path.join(INP, ex, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+            for f in extra:
+                shutil.copy(os.path.join(INP, ex, f), os.path.join(tmp, f))
+            run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "2", "3", "5"], tmp)
+            out = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", "20", "--pstep", "5", "--fstep", "20"], tmp)
+            md = parse_mdstep(out)
+            xyz = open(os.path.join(tmp, "DAT", "%09d.xyz" % 20)).read()
+            np.savez_compressed(os.path.join(HERE, ex + ".npz"), mdstep=md, xyz_last=np.array(xyz))
+            print(ex, "rows", len(md), "PE/atom", md[0][2])
+        finally:
+            shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["examples"]:
+        make_examples(); sys.exit(0)
     if sys.argv[1:] == ["minimiser"]:
         make_minimiser(); sys.exit(0)
     if sys.argv[1:] == ["thermo"]:

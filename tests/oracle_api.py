@@ -223,6 +223,10 @@ def oracle_from_rxff(ffield, buf, **kw):
 
 def make_system(case):
     """(ffield_path, lattice, ranks) for the named golden case family"""
+    if case.startswith("example"):                 # the reference's examples/1-reaxff and 3-reaxpq+: polyethylene, geninit -mc 2 3 5
+        ff = os.path.join(INP, "example1", "ffield")
+        names, frac, lat = read_xyz(os.path.join(INP, "example1", "input.xyz"))
+        return ff, names, frac, lat
     if case.startswith("rdx168_lg"):
         ff = os.path.join(INP, "ffield_rdx_lg")
         names, frac, lat = read_xyz(os.path.join(INP, "rdx_lg.xyz"))
@@ -242,6 +246,7 @@ def make_system(case):
 
 
 PQEQ_SICNP = os.path.join(INP, "pqeq_sicnp.in")
+PQEQ_EXAMPLE3 = os.path.join(INP, "example3", "pqeq1.par")
 
 
 # The reference's own published known answer: README.md:157, step-0 line of the 168-atom RDX sample run (per-atom energies as PRINTE

@@ -459,6 +459,24 @@ def test_low_gradient_dispersion_against_the_reference_and_the_oracle():
     e.close()
 
 
+def test_reference_example3_small_box_pqeq_with_field_against_the_clean_oracle():
+    """the system of the reference's examples/3-reaxpq+ (polyethylene 2x3x5: a 14.8 x 14.8 x 12.7 A box under the 12.5 A PQEq cut-off,
+    parameter file listing only C and H, field along x), 5 MD steps at tight tolerance against the oracle in clean mode; the oracle's
+    reference-faithful mode is pinned to the real reference's frame of this example on CPU (tests/test_oracle_golden.py)"""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    e = _engine("example3", (2, 3, 5), pqeq=oa.PQEQ_EXAMPLE3, efield=(1, 0.01), **kw)
+    o = _oracle("example3", (2, 3, 5), pqeq=oa.PQEQ_EXAMPLE3, **kw); o.set_efield(1, 0.01); o.set_pqeq_clean(1)
+    e.QEq(); e.FORCE(); o.qeq(); o.force()
+    e.step(5); o.step(5)
+    a = e.atoms()
+    ie = np.argsort(a["gid"]); io = np.argsort(o.gids())
+    assert np.abs(a["pos"][ie] - o.pos()[io]).max() <= 1e-9
+    assert q_err(a["q"][ie], o.charges()[io]) <= QTOL
+    assert f_err(a["f"][ie], o.forces()[io]) <= FTOL
+    assert np.abs(e.shells()[ie] - o.spos()[io]).max() <= 1e-7
+    e.close()
+
+
 def test_row_stride_of_the_10A_list_grows_when_the_density_estimate_is_too_low():
     """The list stride is sized from the mean density; a tiny explicit hint (maxneighbs10) keeps the reference's overflow trap,
     the automatic sizing must recover by growing to what the sweep reports."""

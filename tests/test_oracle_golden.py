@@ -212,3 +212,28 @@ def test_low_gradient_dispersion_tables():
     g, o, iters, pe = _run("rdx168_lg_md5", (1, 1, 1), steps=5, lg=True)
     assert iters == [int(x) for x in g["qeq_iters"]]
     _compare(g, o, ftol=1e-9, qtol=1e-10)
+
+
+def test_reference_example3_frame_including_its_stale_lookup_artefact():
+    """examples/3-reaxpq+ as shipped (polyethylene 2x3x5, PQEq with a parameter file that lists only C and H, field along x): in this
+    12.7 A box the 12.5 A PQEq cut-off makes the reference re-use the previous pair's table values on ~1,500 lookups beyond the
+    cut-off (module.F90:401).  The reference-faithful oracle mode reproduces the reference's frame after 20 steps to dump precision;
+    the clean mode (what the HIP engine computes) differs from it by exactly the artefact: single charges by ~1e-2, shells by the clip."""
+    g = np.load(os.path.join(GOLD, "example3.npz"))
+    ff, names, frac, lat = oa.make_system("example3")
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=(2, 3, 5))
+    t = str(g["xyz_last"]).split("\n")[2:-1]
+    ref = np.array([[float(x) for x in l[3:83].split()] + [float(x) for x in l[92:].split()] for l in t])
+    ids = np.array([int(l[83:92]) for l in t])
+    out = {}
+    for clean in (0, 1):
+        o = oa.Oracle(ff, lat2, ranks, pqeq=oa.PQEQ_EXAMPLE3)
+        o.set_efield(1, 0.01); o.set_pqeq_clean(clean)
+        o.qeq(); o.force()
+        assert abs(o.energy()[0] / 360 - g["mdstep"][0][2]) <= 1e-5 * abs(g["mdstep"][0][2])
+        o.step(20)
+        order = np.argsort(o.gids())
+        q = o.charges()[order][ids - 1]; sp = o.spos()[order][ids - 1]; pos = o.pos()[order][ids - 1]
+        out[clean] = (np.abs(pos - ref[:, :3]).max(), np.abs(q - ref[:, 3]).max(), np.abs(sp - ref[:, 4:]).max(), o.pqeq_stale())
+    assert out[0][0] <= 1e-10 and out[0][1] <= 1e-12 and out[0][2] <= 1e-12 and out[0][3] > 1000
+    assert out[1][0] <= 1e-5 and 1e-3 < out[1][1] <= 3e-2 and out[1][2] <= 2.5e-3
