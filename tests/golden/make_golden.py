@@ -64,6 +64,8 @@ CASES = {
     "rdx222_v211_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
     "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),
     "rdx222_v222_md3":   ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 2, 2)),
+    # the reference's examples/2-reaxff-dc: polyethylene, geninit -mc 4 3 5 -v 2 1 1, mpirun -np 2
+    "example2_v211_md3": ("example1/input.xyz", "example1/ffield", (4, 3, 5), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 1, 1)),
 }
 
 

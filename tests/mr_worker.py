@@ -36,7 +36,7 @@ def engine_rank(rank, world, port, case, vp, steps, out):
         from rxmd_amd.comm import TorchTransport
         g = np.load(os.path.join(oa.GOLD, case + ".npz"))
         mc = tuple(int(x) for x in g["mc"])
-        ff, names, frac, lat = oa.make_system("rdx222")
+        ff, names, frac, lat = oa.make_system(case)
         lat_s, rec = system.geninit(ff, names, frac, lat, mc=mc, vprocs=vp, myid=rank)
         e = rxmd_amd.RxmdEngine(ff, lat_s, vprocs=vp, myid=rank, QEq_tol=1e-12, NMAXQEq=2000, device=0)
         tr = TorchTransport(mode="staged", device=torch.device("cuda", 0), capacity_doubles=1 << 20)

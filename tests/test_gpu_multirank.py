@@ -18,7 +18,8 @@ def _port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("case,steps", [("rdx222_v211_tight", 0), ("rdx222_v222_tight", 0), ("rdx222_v222_md3", 3)])
+@pytest.mark.parametrize("case,steps", [("rdx222_v211_tight", 0), ("rdx222_v222_tight", 0), ("rdx222_v222_md3", 3),
+                                        ("example2_v211_md3", 3)])        # the last: the reference's examples/2-reaxff-dc (mc 4 3 5, -v 2 1 1, 2 ranks)
 def test_vprocs_parity_vs_mpi_reference(case, steps):
     g = np.load(os.path.join(oa.GOLD, case + ".npz"))
     vp = tuple(int(x) for x in g["vprocs"]); world = vp[0] * vp[1] * vp[2]

@@ -113,12 +113,13 @@ def test_ice_type_order_and_zero_hbond():
     _check_energy(g, pe, 2304)
 
 
-@pytest.mark.parametrize("case,steps", [("rdx222_v211_tight", 0), ("rdx222_v222_tight", 0), ("rdx222_v222_md3", 3)])
+@pytest.mark.parametrize("case,steps", [("rdx222_v211_tight", 0), ("rdx222_v222_tight", 0), ("rdx222_v222_md3", 3),
+                                        ("example2_v211_md3", 3)])        # the last: the reference's examples/2-reaxff-dc under mpirun -np 2
 def test_multirank_world_vs_real_mpi_reference(case, steps):
     """the oracle's in-process multi-rank world against the reference run under real MPI (conda MPICH) at the same vprocs"""
     g = np.load(os.path.join(GOLD, case + ".npz"))
     vp = tuple(int(x) for x in g["vprocs"]); mc = tuple(int(x) for x in g["mc"])
-    ff, names, frac, lat = oa.make_system("rdx222")
+    ff, names, frac, lat = oa.make_system(case)
     lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=mc, vprocs=vp)
     o = oa.Oracle(ff, lat2, ranks, vprocs=vp, QEq_tol=1e-12, NMAXQEq=2000)
     iters = [o.qeq()]; o.force()
