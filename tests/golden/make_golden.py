@@ -60,6 +60,11 @@ CASES = {
     # table terms init.F90:496-514); conf/init.rdx.lg/{input.xyz,ffield}
     "rdx168_lg_tight": ("rdx_lg.xyz", "ffield_rdx_lg", (1, 1, 1), ["--lg", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
     "rdx168_lg_md5":   ("rdx_lg.xyz", "ffield_rdx_lg", (1, 1, 1), ["--lg"], 5),
+    # other systems and force fields the reference ships under conf/ (10-, 4-, 7- and 5-type ffields), 3 MD steps at tight tolerance
+    "fes576_md3":     ("conf/fes.xyz", "conf/ffield_fes", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
+    "mos2_216_md3":   ("conf/mos2_ortho.xyz", "conf/ffield_mos2", (2, 1, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
+    "sic512_md3":     ("conf/sic.xyz", "ffield_sicnp", (4, 4, 4), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
+    "aloslab180_md3": ("conf/aloslab.xyz", "conf/ffield_aloslab", (3, 2, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
     # multi-rank (real MPI build oracle/_ref/rxmd_mpi, conda MPICH): name: (..., vprocs)
     "rdx222_v211_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
     "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),

@@ -227,6 +227,12 @@ def make_system(case):
         ff = os.path.join(INP, "example1", "ffield")
         names, frac, lat = read_xyz(os.path.join(INP, "example1", "input.xyz"))
         return ff, names, frac, lat
+    conf = {"fes": ("conf/fes.xyz", "conf/ffield_fes"), "mos2": ("conf/mos2_ortho.xyz", "conf/ffield_mos2"), "sic512": ("conf/sic.xyz", "ffield_sicnp"),
+            "aloslab": ("conf/aloslab.xyz", "conf/ffield_aloslab")}            # more of the reference's conf/ systems
+    for k, (x, f) in conf.items():
+        if case.startswith(k):
+            names, frac, lat = read_xyz(os.path.join(INP, x))
+            return os.path.join(INP, f), names, frac, lat
     if case.startswith("rdx168_lg"):
         ff = os.path.join(INP, "ffield_rdx_lg")
         names, frac, lat = read_xyz(os.path.join(INP, "rdx_lg.xyz"))

@@ -477,6 +477,23 @@ def test_reference_example3_small_box_pqeq_with_field_against_the_clean_oracle()
     e.close()
 
 
+@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "sic512_md3", "aloslab180_md3"])
+@pytest.mark.parametrize("qeq_mode", [0, 1])
+def test_other_force_fields_and_systems_the_reference_ships(case, qeq_mode):
+    """pyrite (10-type ffield), MoS2, zinc-blende SiC and an alumina slab from the reference's conf/: 3 MD steps at tight tolerance
+    against the goldens of the real reference (state after the third step: positions, charges, forces)"""
+    g = np.load(os.path.join(oa.GOLD, case + ".npz"))
+    e = _engine(case, tuple(int(x) for x in g["mc"]), QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=qeq_mode)
+    e.QEq(); e.FORCE(); e.step(3)
+    a = e.atoms()
+    o = np.argsort(a["gid"]); go = np.argsort(g["gid"])
+    assert (a["gid"][o] == g["gid"][go]).all()
+    assert np.abs(a["pos"][o] - g["pos"][go]).max() <= 1e-9
+    assert q_err(a["q"][o], g["charge"][go]) <= QTOL
+    assert f_err(a["f"][o], g["force"][go]) <= FTOL
+    e.close()
+
+
 def test_row_stride_of_the_10A_list_grows_when_the_density_estimate_is_too_low():
     """The list stride is sized from the mean density; a tiny explicit hint (maxneighbs10) keeps the reference's overflow trap,
     the automatic sizing must recover by growing to what the sweep reports."""
