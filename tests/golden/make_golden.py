@@ -37,6 +37,17 @@ def perturbed_ice_fractional(path, seed=12345, sigma=0.02):
     open(path, "w").write("\n".join(out) + "\n")
 
 
+def real_to_fractional(src, dst):
+    """conf/init.a-polys/*.xyz hold REAL coordinates of an orthorhombic box: fractional = r / (a, b, c), 12 decimals"""
+    lines = open(src).read().split("\n")
+    n = int(lines[0].split()[0]); lat = [float(x) for x in lines[1].split()[:6]]
+    out = [lines[0], lines[1]]
+    for l in lines[2:2 + n]:
+        e, x, y, z = l.split()[:4]
+        out.append("%s %.12f %.12f %.12f" % (e, float(x) / lat[0], float(y) / lat[1], float(z) / lat[2]))
+    open(dst, "w").write("\n".join(out) + "\n")
+
+
 CASES = {
     # name: (xyz, ffield, mc, extra rxmd flags, nsteps for the dump run)
     "rdx168_tol7":   ("rdx.xyz", "ffield_rdx", (1, 1, 1), [], 0),
@@ -65,6 +76,9 @@ CASES = {
     "mos2_216_md3":   ("conf/mos2_ortho.xyz", "conf/ffield_mos2", (2, 1, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
     "sic512_md3":     ("conf/sic.xyz", "ffield_sicnp", (4, 4, 4), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
     "aloslab180_md3": ("conf/aloslab.xyz", "conf/ffield_aloslab", (3, 2, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
+    # an amorphous polymer cell of the reference's conf/init.a-polys (poly(butylene terephthalate), 2,272 atoms, real coordinates -> fractional
+    # by real_to_fractional above) with the top-level ffield: aromatic rings, esters -- every bonded term on a disordered structure
+    "pbt2272_md2":    ("PBT", "ffield_rdx", (1, 1, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 2),
     # multi-rank (real MPI build oracle/_ref/rxmd_mpi, conda MPICH): name: (..., vprocs)
     "rdx222_v211_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
     "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),
@@ -159,6 +173,8 @@ def make(name):
         os.makedirs(os.path.join(tmp, "DAT"))
         if xyz == "ICE":
             perturbed_ice_fractional(os.path.join(tmp, "input.xyz"))
+        elif xyz == "PBT":
+            real_to_fractional(os.path.join(INP, "conf", "PBT_real.xyz"), os.path.join(tmp, "input.xyz"))
         else:
             shutil.copy(os.path.join(INP, xyz), os.path.join(tmp, "input.xyz"))
         shutil.copy(os.path.join(INP, ff), os.path.join(tmp, "ffield"))
@@ -196,7 +212,7 @@ def make(name):
         outB = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(max(nsteps, 1)), "--pstep", "1",
                     "--fstep", "100000"] + flags, tmp)
         d["mdstep"] = parse_mdstep(outB)
-        if name.startswith("ice"):
+        if name.startswith("ice") or name.startswith("pbt"):
             d["input_xyz"] = np.array(open(os.path.join(tmp, "input.xyz")).read())
         if name in ("rdx168_md10", "sicnp547_pqeq_md5"):
             # the reference's own trajectory frame of the last step (OUTPUT -> WriteXYZ, fileio.F90:241-355): output data, kept as text

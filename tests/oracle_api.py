@@ -233,6 +233,10 @@ def make_system(case):
         if case.startswith(k):
             names, frac, lat = read_xyz(os.path.join(INP, x))
             return os.path.join(INP, f), names, frac, lat
+    if case.startswith("pbt"):                     # the fractional input the golden was generated from travels inside the fixture
+        g = np.load(os.path.join(GOLD, "pbt2272_md2.npz"))
+        names, frac, lat = read_xyz(str(g["input_xyz"]))
+        return os.path.join(INP, "ffield_rdx"), names, frac, lat
     if case.startswith("rdx168_lg"):
         ff = os.path.join(INP, "ffield_rdx_lg")
         names, frac, lat = read_xyz(os.path.join(INP, "rdx_lg.xyz"))

@@ -477,14 +477,14 @@ def test_reference_example3_small_box_pqeq_with_field_against_the_clean_oracle()
     e.close()
 
 
-@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "sic512_md3", "aloslab180_md3"])
+@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "sic512_md3", "aloslab180_md3", "pbt2272_md2"])
 @pytest.mark.parametrize("qeq_mode", [0, 1])
 def test_other_force_fields_and_systems_the_reference_ships(case, qeq_mode):
-    """pyrite (10-type ffield), MoS2, zinc-blende SiC and an alumina slab from the reference's conf/: 3 MD steps at tight tolerance
+    """pyrite (10-type ffield), MoS2, zinc-blende SiC, an alumina slab and an amorphous polymer cell (PBT, 2,272 atoms) from the reference's conf/: 2-3 MD steps at tight tolerance
     against the goldens of the real reference (state after the third step: positions, charges, forces)"""
     g = np.load(os.path.join(oa.GOLD, case + ".npz"))
     e = _engine(case, tuple(int(x) for x in g["mc"]), QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=qeq_mode)
-    e.QEq(); e.FORCE(); e.step(3)
+    e.QEq(); e.FORCE(); e.step(int(g["nsteps"]))
     a = e.atoms()
     o = np.argsort(a["gid"]); go = np.argsort(g["gid"])
     assert (a["gid"][o] == g["gid"][go]).all()

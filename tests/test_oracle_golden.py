@@ -240,11 +240,12 @@ def test_reference_example3_frame_including_its_stale_lookup_artefact():
     assert out[1][0] <= 1e-5 and 1e-3 < out[1][1] <= 3e-2 and out[1][2] <= 2.5e-3
 
 
-@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "sic512_md3", "aloslab180_md3"])
+@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "sic512_md3", "aloslab180_md3", "pbt2272_md2"])
 def test_other_force_fields_and_systems_the_reference_ships(case):
     """conf/init.fes (pyrite, a 10-type ffield), conf/init.mos2.ortho (4 types), conf/init.sic (zinc-blende SiC) and conf/init.aloslab
-    (alumina slab, 5 types): ffield parsing, cut-offs and every energy term on systems other than RDX; 3 MD steps at tight tolerance"""
+    (alumina slab, 5 types), conf/init.a-polys/PBT (amorphous poly(butylene terephthalate), 2,272 atoms): ffield parsing, cut-offs and
+    every energy term on systems other than RDX; 2-3 MD steps at tight tolerance"""
     g = np.load(os.path.join(GOLD, case + ".npz"))
-    g2, o, iters, pe = _run(case, tuple(int(x) for x in g["mc"]), steps=3, QEq_tol=1e-12, NMAXQEq=2000)
+    g2, o, iters, pe = _run(case, tuple(int(x) for x in g["mc"]), steps=int(g["nsteps"]), QEq_tol=1e-12, NMAXQEq=2000)
     assert iters == [int(x) for x in g["qeq_iters"]]
     _compare(g, o, ftol=1e-9, qtol=1e-10)
