@@ -390,6 +390,7 @@ typedef struct {
   int qeq_iters_total;
   long long pq_stale;                        /* PQEq lookups that fell outside the cutoff and left stale outputs behind (see pq_coulomb) */
   char err[256];
+  int qstep, md_nstep;                           /* QEq every qstep MD steps; MD steps done (nstep of main.F90:64) */
 } World;
 
 #define POS(r, i, k) ((r)->pos[(size_t)(k) * (r)->NBUFFER + (i)])
@@ -1765,7 +1766,9 @@ static int md_step(World *W) {
   }
   double z[3] = {0, 0, 0};
   if (COPYATOMS(W, MODE_MOVE, z)) return -1;
-  if (W->P.isPQEq ? PQEq(W) : QEq(W)) return -1;       /* qstep = 1; main.F90:77-83 */
+  if (W->md_nstep % (W->qstep > 0 ? W->qstep : 1) == 0)  /* if(mod(nstep,qstep)==0), main.F90:77-83; nstep counts from 0 */
+    if (W->P.isPQEq ? PQEq(W) : QEq(W)) return -1;
+  W->md_nstep++;
   if (FORCE(W)) return -1;
   for (int p = 0; p < W->nprocs; p++) {
     Rank *r = &W->R[p];
@@ -1979,6 +1982,8 @@ int rxo_init(void *w) { /* the rest of INITSYSTEM: cutoffs, cells, tables, 10 A 
 
 int rxo_qeq(void *w) { World *W = (World *)w; return W->P.isPQEq ? PQEq(W) : QEq(W); }   /* main.F90:27-31 */
 int rxo_force(void *w) { return FORCE((World *)w); }
+/* rxmd.in `QEq <isQEq> <NMAXQEq> <QEq_tol> <qstep>`: charges are re-equilibrated every qstep-th MD step only */
+void rxo_set_qstep(void *w, int qstep) { ((World *)w)->qstep = qstep; }
 int rxo_step(void *w, int nsteps) { for (int s = 0; s < nsteps; s++) if (md_step((World *)w)) return -1; return 0; }
 const char *rxo_error(void *w) { return ((World *)w)->err; }
 int rxo_natoms(void *w, int rank) { return ((World *)w)->R[rank].NATOMS; }

@@ -79,6 +79,8 @@ CASES = {
     # an amorphous polymer cell of the reference's conf/init.a-polys (poly(butylene terephthalate), 2,272 atoms, real coordinates -> fractional
     # by real_to_fractional above) with the top-level ffield: aromatic rings, esters -- every bonded term on a disordered structure
     "pbt2272_md2":    ("PBT", "ffield_rdx", (1, 1, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 2),
+    # charges re-equilibrated every third step only (rxmd.in QEq ... <qstep>, main.F90:77)
+    "rdx168_qstep3_md7": ("rdx.xyz", "ffield_rdx", (1, 1, 1), ["RXMDIN:QEq 1 2000 1.d-12 3"], 7),
     # multi-rank (real MPI build oracle/_ref/rxmd_mpi, conda MPICH): name: (..., vprocs)
     "rdx222_v211_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
     "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),

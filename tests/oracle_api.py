@@ -182,6 +182,9 @@ class Oracle:
     def set_charges(self, q, rank=0):
         q = np.ascontiguousarray(q, np.float64); self.L.rxo_set_charges(self.w, rank, q.ctypes.data_as(C.c_void_p))
 
+    def set_qstep(self, qstep):
+        self.L.rxo_set_qstep.argtypes = [C.c_void_p, C.c_int]; self.L.rxo_set_qstep(self.w, int(qstep))
+
     def set_qeq(self, isQEq, nmax, tol): self.L.rxo_set_qeq(self.w, isQEq, nmax, C.c_double(tol))
 
     def bonds(self, rank=0):

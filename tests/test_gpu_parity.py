@@ -494,6 +494,21 @@ def test_other_force_fields_and_systems_the_reference_ships(case, qeq_mode):
     e.close()
 
 
+@pytest.mark.parametrize("qeq_mode", [0, 1])
+def test_charges_every_third_step_only(qeq_mode):
+    """rxmd.in `QEq 1 2000 1.d-12 3` (qstep = 3, main.F90:77): 7 MD steps against the real reference"""
+    g = np.load(os.path.join(oa.GOLD, "rdx168_qstep3_md7.npz"))
+    e = _engine("rdx168", (1, 1, 1), QEq_tol=1e-12, NMAXQEq=2000, qstep=3, qeq_mode=qeq_mode)
+    e.QEq(); e.FORCE(); e.step(7)
+    assert e.stats()["qeq_calls"] == 4                              # the pre-loop call + steps 0, 3, 6
+    a = e.atoms()
+    assert (a["gid"] == g["gid"]).all()
+    assert np.abs(a["pos"] - g["pos"]).max() <= 1e-9
+    assert q_err(a["q"], g["charge"]) <= QTOL
+    assert f_err(a["f"], g["force"]) <= FTOL
+    e.close()
+
+
 def test_row_stride_of_the_10A_list_grows_when_the_density_estimate_is_too_low():
     """The list stride is sized from the mean density; a tiny explicit hint (maxneighbs10) keeps the reference's overflow trap,
     the automatic sizing must recover by growing to what the sweep reports."""

@@ -249,3 +249,19 @@ def test_other_force_fields_and_systems_the_reference_ships(case):
     g2, o, iters, pe = _run(case, tuple(int(x) for x in g["mc"]), steps=int(g["nsteps"]), QEq_tol=1e-12, NMAXQEq=2000)
     assert iters == [int(x) for x in g["qeq_iters"]]
     _compare(g, o, ftol=1e-9, qtol=1e-10)
+
+
+def test_charges_every_third_step_only():
+    """rxmd.in `QEq 1 2000 1.d-12 3`: QEq runs when mod(nstep, qstep) == 0 (main.F90:77), the charges are frozen in between"""
+    g = np.load(os.path.join(GOLD, "rdx168_qstep3_md7.npz"))
+    ff, names, frac, lat = oa.make_system("rdx168")
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff))
+    o = oa.Oracle(ff, lat2, ranks, QEq_tol=1e-12, NMAXQEq=2000)
+    o.set_qstep(3)
+    iters = [o.qeq()]; o.force()
+    for s in range(7):
+        o.step(1)
+        if s % 3 == 0:
+            iters.append(o.L.rxo_qeq_iters(o.w))
+    assert iters == [int(x) for x in g["qeq_iters"]]
+    _compare(g, o, ftol=1e-9, qtol=1e-10)
