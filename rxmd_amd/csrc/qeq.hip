@@ -543,7 +543,7 @@ void Engine::qeq() {
   sums_from_list = false;
   if (!lists_valid) build_ghosts_and_lists(prepass_on);
   const int nmax = (cfg.isQEq == 1) ? cfg.NMAXQEq : 1;
-  // one wavefront per row, four rows per workgroup: measured faster than a persistent grid-stride launch (1.10 vs 1.28 ms
+  // one wavefront per row, sixteen rows per workgroup: measured faster than a persistent grid-stride launch (1.10 vs 1.28 ms
   // per pass at 979,776 rows) -- many short waves overlap each other's load / gather / reduce phases
   constexpr int SPMV_WPB = 16;                   // wavefronts (= rows) per workgroup of the matrix pass
   const int rb = nblk(N, SPMV_WPB);
