@@ -62,6 +62,9 @@ class TorchTransport:
         try:
             self.n_exchange += 1
             nsend = int(nsend)
+            # the engine may pass pointers INTO the registered buffers (second message of an axis pair): honour the offsets
+            os_ = (int(send_ptr) - self.send_t.data_ptr()) // 8 if self.mode != "host" else 0
+            or_ = (int(recv_ptr) - self.recv_t.data_ptr()) // 8 if self.mode != "host" else 0
             if self.mode == "device":
                 cnt_s = torch.tensor([nsend], dtype=torch.int64, device=self.device)
                 cnt_r = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -71,8 +74,8 @@ class TorchTransport:
                     return -1
                 # every rank always posts both operations (a 1-element dummy stands for an empty message, like the
                 # reference's 1-double sentinel, comm.F90:321-327) so that sends and receives pair up on any rank grid
-                s = self.send_t[:max(nsend, 1)]
-                r = self.recv_t[:max(nrecv, 1)] if nrecv > 0 else torch.zeros(1, dtype=torch.float64, device=self.device)
+                s = self.send_t[os_:os_ + max(nsend, 1)]
+                r = self.recv_t[or_:or_ + max(nrecv, 1)] if nrecv > 0 else torch.zeros(1, dtype=torch.float64, device=self.device)
                 self._p2p(to, s, frm, r)
                 torch.cuda.synchronize(self.device)
                 return nrecv
@@ -84,14 +87,14 @@ class TorchTransport:
             if nrecv > cap:
                 return -1
             if self.mode == "staged":
-                s = self.send_t[:max(nsend, 1)].cpu()
+                s = self.send_t[os_:os_ + max(nsend, 1)].cpu()
             else:
                 s = torch.from_numpy(np.ctypeslib.as_array(C.cast(C.c_void_p(send_ptr), C.POINTER(C.c_double)), shape=(max(nsend, 1),)).copy()) if nsend > 0 else torch.zeros(1, dtype=torch.float64)
             r = torch.zeros(max(nrecv, 1), dtype=torch.float64)
             self._p2p(to, s, frm, r)
             if nrecv > 0:
                 if self.mode == "staged":
-                    self.recv_t[:nrecv].copy_(r[:nrecv])
+                    self.recv_t[or_:or_ + nrecv].copy_(r[:nrecv])
                     torch.cuda.synchronize(self.device)
                 else:
                     C.memmove(recv_ptr, r.numpy().ctypes.data, 8 * nrecv)

@@ -197,6 +197,9 @@ struct Engine {
   void halo_staged(double *v, int ncomp);           // the same through the six-stage exchange (multi-rank)
   long long exchange_stage(int d, bool reverse, long long nsend, long long known_nrecv = -1);  // one send_recv of comm.F90:291-364; returns #doubles received
   void exchange_pair(int d0, bool reverse, long long n0, long long r0, long long n1, long long r1);  // stages d0 and d0+1 (one axis) in one round, counts known
+  void exchange_pair_sized(int d0, long long n0, long long n1, long long &r0, long long &r1);       // the same when the receive counts are not known yet (ghost build)
+  void rccl_exchange_pair_sized(int to0, int from0, long long n0, long long &r0, int to1, int from1, long long n1, long long &r1);
+  int *flags2 = nullptr, *scanout2 = nullptr;       // second stage of an axis pair (ghost build)
   void rccl_exchange_pair(int to0, int from0, long long n0, long long r0, int to1, int from1, long long n1, long long r1);
   bool stage_pairs = true;                          // RXMD_NO_STAGE_PAIRS=1: one round per stage as the reference does (six per halo)
   void ensure_xbuf(size_t doubles);

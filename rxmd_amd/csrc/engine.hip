@@ -261,7 +261,7 @@ void Engine::alloc_device() {
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.ncell) + 2);
-  dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1);
+  dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
   dmalloc(nbr, ns); dmalloc(nbrcnt, nb); dmalloc(nbrindx, ns);
   dmalloc(bo0, ns); dmalloc(bo1, ns); dmalloc(bo2, ns); dmalloc(bo3, ns); dmalloc(dln2, ns); dmalloc(dln3, ns); dmalloc(dBOp, ns);
   dmalloc(A0, ns); dmalloc(A1, ns); dmalloc(A2, ns); dmalloc(A3, ns);
@@ -287,7 +287,7 @@ void Engine::alloc_device() {
 }
 
 void Engine::free_device() {
-  for (int a = 0; a < 3; ++a) { dfree(pos[a]); dfree(vel[a]); dfree(frc[a]); dfree(spos[a]); }
+  for (int a = 0; a < 3; ++a) { dfree(flags2); dfree(scanout2); dfree(pos[a]); dfree(vel[a]); dfree(frc[a]); dfree(spos[a]); }
   for (int a = 0; a < 3; ++a) dfree(shl[a]);
   dfree(sorted_shl); dfree(hsc); dfree(pqrow);
   if (pqblob) { (void)hipFree(pqblob); pqblob = nullptr; }
@@ -584,6 +584,34 @@ void Engine::ghost_build_staged() {
   k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
   copyptr[0] = N;
   sendoff[1] = 0;
+  if (stage_pairs) {
+    // the + and - stage of an axis scan the same atoms (residents and the ghosts of earlier axes): both selections, both size
+    // messages and both payloads go together -- three rounds and six host waits per ghost build instead of six and twelve
+    for (int d0 = 1; d0 <= 5; d0 += 2) {
+      const int d1 = d0 + 1, nscan = copyptr[cptridx_[d0]], axis = (d0 - 1) / 2;
+      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d0, box.lbox[axis], shell[axis], spos[axis], type, 0, flags);
+      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d1, box.lbox[axis], shell[axis], spos[axis], type, 0, flags2);
+      size_t tb = cubtmp_bytes;
+      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
+      tb = cubtmp_bytes;
+      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
+      int t0 = 0, t1 = 0;
+      RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipStreamSynchronize(stream));
+      if (sendoff[d0] + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
+      sendoff[d0 + 1] = sendoff[d0] + t0; sendoff[d1 + 1] = sendoff[d1] + t1;
+      if (t0 > 0) k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, -box.lbox[axis], flags, scanout, spos[0], spos[1], spos[2], type, gid, q, xbuf_send, sendidx + sendoff[d0]);
+      if (t1 > 0) k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, box.lbox[axis], flags2, scanout2, spos[0], spos[1], spos[2], type, gid, q, xbuf_send + 6LL * t0, sendidx + sendoff[d1]);
+      long long r0 = 0, r1 = 0;
+      exchange_pair_sized(d0, 6LL * t0, 6LL * t1, r0, r1);
+      const int c0 = static_cast<int>(r0 / 6), c1 = static_cast<int>(r1 / 6);
+      if (static_cast<long long>(copyptr[d0 - 1]) + c0 + c1 > NB)
+        throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
+      if (c0 + c1 > 0) k_unpack_ghosts<<<nblk(c0 + c1, 256), 256, 0, stream>>>(c0 + c1, copyptr[d0 - 1], xbuf_recv, spos[0], spos[1], spos[2], type, gid, q, gsrc);
+      copyptr[d0] = copyptr[d0 - 1] + c0; copyptr[d1] = copyptr[d0] + c1;
+    }
+  } else
   for (int d = 1; d <= 6; ++d) {
     const int nscan = copyptr[cptridx_[d]], axis = (d - 1) / 2;
     const double sft = (d & 1) ? -box.lbox[axis] : box.lbox[axis];
@@ -628,6 +656,25 @@ void Engine::exchange_pair(int d0, bool reverse, long long n0, long long r0, lon
   if (comm.exchange_known(comm.ctx, to0, xbuf_send, n0, from0, xbuf_recv, r0) != r0 ||
       comm.exchange_known(comm.ctx, to1, xbuf_send + n0, n1, from1, xbuf_recv + r0, r1) != r1)
     throw EngineError(RXMD_E_COMM, "halo size changed between the ghost build and a vector exchange");
+}
+
+// the same round when the receive counts are not known yet (ghost build): the two size messages travel in one group, one host
+// wait, then the two payloads in one group
+void Engine::exchange_pair_sized(int d0, long long n0, long long n1, long long &r0, long long &r1) {
+  const int d1 = d0 + 1;
+  const int to0 = target_node[d0], from0 = target_node[dinv_[d0]], to1 = target_node[d1], from1 = target_node[dinv_[d1]];
+  if (to0 == cfg.myid && from0 == cfg.myid && !(force_remote && nccl)) {
+    r0 = n0; r1 = n1;
+    if (n0 + n1 > 0) RX_HIP(hipMemcpyAsync(xbuf_recv, xbuf_send, sizeof(double) * (n0 + n1), hipMemcpyDeviceToDevice, stream));
+    return;
+  }
+  if (nccl) { rccl_exchange_pair_sized(to0, from0, n0, r0, to1, from1, n1, r1); return; }
+  if (!has_comm || !comm.exchange) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
+  RX_HIP(hipStreamSynchronize(stream));
+  r0 = comm.exchange(comm.ctx, to0, xbuf_send, n0, from0, xbuf_recv, static_cast<long long>(xbuf_doubles));
+  if (r0 < 0) throw EngineError(RXMD_E_COMM, "exchange callback failed");
+  r1 = comm.exchange(comm.ctx, to1, xbuf_send + n0, n1, from1, xbuf_recv + r0, static_cast<long long>(xbuf_doubles) - r0);
+  if (r1 < 0) throw EngineError(RXMD_E_COMM, "exchange callback failed");
 }
 
 // MODE_QCOPY1 / MODE_QCOPY2 (comm.F90:187-212): ghost slots of an ncomp-interleaved vector, axis by axis

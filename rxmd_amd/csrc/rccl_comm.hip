@@ -78,6 +78,24 @@ void Engine::rccl_exchange_pair(int to0, int from0, long long n0, long long r0, 
   RX_NCCL(ncclGroupEnd());
 }
 
+// the pair with unknown receive counts: one group for the two size messages, one host wait, one group for the two payloads
+void Engine::rccl_exchange_pair_sized(int to0, int from0, long long n0, long long &r0, int to1, int from1, long long n1, long long &r1) {
+  ncclComm_t c = C(nccl);
+  cnt_host[0] = static_cast<double>(n0); cnt_host[1] = static_cast<double>(n1);
+  RX_HIP(hipMemcpyAsync(cnt_dev, cnt_host, 2 * sizeof(double), hipMemcpyHostToDevice, stream));
+  RX_NCCL(ncclGroupStart());
+  RX_NCCL(ncclSend(cnt_dev, 1, ncclDouble, to0, c, stream));
+  RX_NCCL(ncclRecv(cnt_dev + 2, 1, ncclDouble, from0, c, stream));
+  RX_NCCL(ncclSend(cnt_dev + 1, 1, ncclDouble, to1, c, stream));
+  RX_NCCL(ncclRecv(cnt_dev + 3, 1, ncclDouble, from1, c, stream));
+  RX_NCCL(ncclGroupEnd());
+  RX_HIP(hipMemcpyAsync(cnt_host + 2, cnt_dev + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+  RX_HIP(hipStreamSynchronize(stream));
+  r0 = static_cast<long long>(cnt_host[2]); r1 = static_cast<long long>(cnt_host[3]);
+  if (r0 + r1 > static_cast<long long>(xbuf_doubles)) throw EngineError(RXMD_E_NBUFFER, "incoming messages larger than the exchange buffer");
+  rccl_exchange_pair(to0, from0, n0, r0, to1, from1, n1, r1);
+}
+
 // MPI_ALLREDUCE(SUM) of n device doubles, in place, in stream order
 void Engine::rccl_allreduce_dev(double *dev, int n) {
   RX_NCCL(ncclAllReduce(dev, dev, static_cast<size_t>(n), ncclDouble, ncclSum, C(nccl), stream));
