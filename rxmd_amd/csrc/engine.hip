@@ -800,6 +800,44 @@ void Engine::migrate() {
   int cp[7];
   cp[0] = N;
   int moved = 0;
+  if (multi() && stage_pairs) {
+    // the two stages of an axis are independent here too (an atom cannot leave through both faces of one axis): selections, size
+    // messages and payloads of both together, as in the ghost build
+    const int W = ff.pqeq ? 14 : 11;             // + shell displacement (comm.F90:153,165-167)
+    for (int d0 = 1; d0 <= 5; d0 += 2) {
+      const int d1 = d0 + 1, nscan = cp[cptridx_[d0]], axis = (d0 - 1) / 2;
+      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d0, box.lbox[axis], 0.0, spos[axis], type, 1, flags);
+      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d1, box.lbox[axis], 0.0, spos[axis], type, 1, flags2);
+      size_t tb = cubtmp_bytes;
+      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
+      tb = cubtmp_bytes;
+      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
+      int t0 = 0, t1 = 0;
+      RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipStreamSynchronize(stream));
+      ensure_xbuf(static_cast<size_t>(std::max(t0 + t1, 1)) * W + 4096);
+      double *b1 = xbuf_send + static_cast<size_t>(W) * t0;
+      if (t0 > 0) {
+        if (ff.pqeq) k_pack_extra3<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, flags, scanout, W, 11, shl[0], shl[1], shl[2], xbuf_send);
+        k_pack_move<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, -box.lbox[axis], flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv, xbuf_send, W);
+      }
+      if (t1 > 0) {
+        if (ff.pqeq) k_pack_extra3<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, flags2, scanout2, W, 11, shl[0], shl[1], shl[2], b1);
+        k_pack_move<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, box.lbox[axis], flags2, scanout2, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv, b1, W);
+      }
+      long long r0 = 0, r1 = 0;
+      exchange_pair_sized(d0, static_cast<long long>(W) * t0, static_cast<long long>(W) * t1, r0, r1);
+      const int c0 = static_cast<int>(r0 / W), c1 = static_cast<int>(r1 / W);
+      if (static_cast<long long>(cp[d0 - 1]) + c0 + c1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
+      if (c0 + c1 > 0) {
+        k_unpack_move<<<nblk(c0 + c1, 256), 256, 0, stream>>>(c0 + c1, cp[d0 - 1], xbuf_recv, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv, W);
+        if (ff.pqeq) k_unpack_extra3<<<nblk(c0 + c1, 256), 256, 0, stream>>>(c0 + c1, cp[d0 - 1], W, 11, xbuf_recv, shl[0], shl[1], shl[2]);
+      }
+      cp[d0] = cp[d0 - 1] + c0; cp[d1] = cp[d0] + c1;
+      moved += t0 + t1 + c0 + c1;
+    }
+  } else
   for (int d = 1; d <= 6; ++d) {
     const int nscan = cp[cptridx_[d]], axis = (d - 1) / 2;
     const double sft = (d & 1) ? -box.lbox[axis] : box.lbox[axis];
