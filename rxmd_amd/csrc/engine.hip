@@ -478,6 +478,29 @@ void Engine::ghost_build() {
   k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
   copyptr[0] = N;
   sendoff[1] = 0;
+  if (stage_pairs) {      // both stages of an axis scan the same atoms: one host wait per axis instead of one per stage
+    for (int d0 = 1; d0 <= 5; d0 += 2) {
+      const int d1 = d0 + 1, nscan = copyptr[cptridx_[d0]], axis = (d0 - 1) / 2;
+      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d0, box.lbox[axis], shell[axis], spos[axis], type, 0, flags);
+      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d1, box.lbox[axis], shell[axis], spos[axis], type, 0, flags2);
+      size_t tb = cubtmp_bytes;
+      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
+      tb = cubtmp_bytes;
+      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
+      int t0 = 0, t1 = 0;
+      RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipStreamSynchronize(stream));
+      if (static_cast<long long>(copyptr[d0 - 1]) + t0 + t1 > NB || sendoff[d0] + t0 + t1 > NB)
+        throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
+      sendoff[d0 + 1] = sendoff[d0] + t0; sendoff[d1 + 1] = sendoff[d1] + t1;
+      copyptr[d0] = copyptr[d0 - 1] + t0; copyptr[d1] = copyptr[d0] + t1;
+      if (t0 > 0)
+        k_append_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, copyptr[d0 - 1], N, axis, -box.lbox[axis], flags, scanout, spos[0], spos[1], spos[2], type, gid, q, gsrc, groot, sendidx + sendoff[d0]);
+      if (t1 > 0)
+        k_append_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, copyptr[d0], N, axis, box.lbox[axis], flags2, scanout2, spos[0], spos[1], spos[2], type, gid, q, gsrc, groot, sendidx + sendoff[d1]);
+    }
+  } else
   for (int d = 1; d <= 6; ++d) {
     const int nscan = copyptr[cptridx_[d]], axis = (d - 1) / 2;
     const double sft = (d & 1) ? -box.lbox[axis] : box.lbox[axis];   // xshift, comm.F90:531-548
