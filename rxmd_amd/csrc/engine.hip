@@ -860,6 +860,31 @@ void Engine::migrate() {
       cp[d0] = cp[d0 - 1] + c0; cp[d1] = cp[d0] + c1;
       moved += t0 + t1 + c0 + c1;
     }
+  } else if (!multi() && stage_pairs) {
+    for (int d0 = 1; d0 <= 5; d0 += 2) {           // single rank: the same pairing, one host wait per axis
+      const int d1 = d0 + 1, nscan = cp[cptridx_[d0]], axis = (d0 - 1) / 2;
+      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d0, box.lbox[axis], 0.0, spos[axis], type, 1, flags);
+      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d1, box.lbox[axis], 0.0, spos[axis], type, 1, flags2);
+      size_t tb = cubtmp_bytes;
+      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
+      tb = cubtmp_bytes;
+      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
+      int t0 = 0, t1 = 0;
+      RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipStreamSynchronize(stream));
+      if (static_cast<long long>(cp[d0 - 1]) + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
+      cp[d0] = cp[d0 - 1] + t0; cp[d1] = cp[d0] + t1;
+      if (t0 > 0) {
+        if (ff.pqeq) for (int a = 0; a < 3; ++a) k_move_append_extra<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d0 - 1], flags, scanout, shl[a]);
+        k_move_append<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d0 - 1], axis, -box.lbox[axis], flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
+      }
+      if (t1 > 0) {
+        if (ff.pqeq) for (int a = 0; a < 3; ++a) k_move_append_extra<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d0], flags2, scanout2, shl[a]);
+        k_move_append<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d0], axis, box.lbox[axis], flags2, scanout2, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
+      }
+      moved += t0 + t1;
+    }
   } else
   for (int d = 1; d <= 6; ++d) {
     const int nscan = cp[cptridx_[d]], axis = (d - 1) / 2;
