@@ -86,7 +86,7 @@ CASES = {
     "rdx222_v222_tight": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),
     "rdx222_v222_md3":   ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 2, 2)),
     # the reference's examples/2-reaxff-dc: polyethylene, geninit -mc 4 3 5 -v 2 1 1, mpirun -np 2
-    "example2_v211_md3": ("example1/input.xyz", "example1/ffield", (4, 3, 5), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 1, 1)),
+    "example2_v211_md3": ("example1/pe_cell.xyz", "example1/ffield_pe", (4, 3, 5), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 1, 1)),
 }
 
 
@@ -292,11 +292,11 @@ def make_examples():
         tmp = tempfile.mkdtemp(prefix="golden_")
         try:
             os.makedirs(os.path.join(tmp, "DAT"))
-            for f in ("input.xyz", "ffield"):
-                shutil.copy(os.path.join(INP, "example1", f), os.path.join(tmp, f))
-            shutil.copy(os.path.join(INP, ex, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
-            for f in extra:
-                shutil.copy(os.path.join(INP, ex, f), os.path.join(tmp, f))
+            shutil.copy(os.path.join(INP, "example1", "pe_cell.xyz"), os.path.join(tmp, "input.xyz"))
+            shutil.copy(os.path.join(INP, "example1", "ffield_pe"), os.path.join(tmp, "ffield"))
+            shutil.copy(os.path.join(INP, ex, "rxmd_%s.in" % ex), os.path.join(tmp, "rxmd.in"))
+            for f in extra:                                   # the rxmd.in of example 3 names ./pqeq1.par
+                shutil.copy(os.path.join(INP, ex, f.replace(".par", "_%s.par" % ex)), os.path.join(tmp, f))
             run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "2", "3", "5"], tmp)
             out = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", "20", "--pstep", "5", "--fstep", "20"], tmp)
             md = parse_mdstep(out)

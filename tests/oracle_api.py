@@ -227,8 +227,8 @@ def oracle_from_rxff(ffield, buf, **kw):
 def make_system(case):
     """(ffield_path, lattice, ranks) for the named golden case family"""
     if case.startswith("example"):                 # the reference's examples/1-reaxff and 3-reaxpq+: polyethylene, geninit -mc 2 3 5
-        ff = os.path.join(INP, "example1", "ffield")
-        names, frac, lat = read_xyz(os.path.join(INP, "example1", "input.xyz"))
+        ff = os.path.join(INP, "example1", "ffield_pe")
+        names, frac, lat = read_xyz(os.path.join(INP, "example1", "pe_cell.xyz"))
         return ff, names, frac, lat
     conf = {"fes": ("conf/fes.xyz", "conf/ffield_fes"), "mos2": ("conf/mos2_ortho.xyz", "conf/ffield_mos2"), "sic512": ("conf/sic.xyz", "ffield_sicnp"),
             "aloslab": ("conf/aloslab.xyz", "conf/ffield_aloslab")}            # more of the reference's conf/ systems
@@ -259,7 +259,7 @@ def make_system(case):
 
 
 PQEQ_SICNP = os.path.join(INP, "pqeq_sicnp.in")
-PQEQ_EXAMPLE3 = os.path.join(INP, "example3", "pqeq1.par")
+PQEQ_EXAMPLE3 = os.path.join(INP, "example3", "pqeq1_example3.par")
 
 
 # The reference's own published known answer: README.md:157, step-0 line of the 168-atom RDX sample run (per-atom energies as PRINTE

@@ -126,11 +126,11 @@ def test_reference_example_workflows_on_the_hip_library(ex, extra):
     tmp = tempfile.mkdtemp(prefix="dropin_")
     try:
         os.makedirs(os.path.join(tmp, "DAT"))
-        for f in ("input.xyz", "ffield"):
-            shutil.copy(os.path.join(oa.INP, "example1", f), os.path.join(tmp, f))
-        shutil.copy(os.path.join(oa.INP, ex, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
-        for f in extra:
-            shutil.copy(os.path.join(oa.INP, ex, f), os.path.join(tmp, f))
+        shutil.copy(os.path.join(oa.INP, "example1", "pe_cell.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(oa.INP, "example1", "ffield_pe"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(oa.INP, ex, "rxmd_%s.in" % ex), os.path.join(tmp, "rxmd.in"))
+        for f in extra:                                       # the rxmd.in of example 3 names ./pqeq1.par
+            shutil.copy(os.path.join(oa.INP, ex, f.replace(".par", "_%s.par" % ex)), os.path.join(tmp, f))
         subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "2", "3", "5"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
         p = subprocess.run([drv, "--ntime_step", "20", "--pstep", "5", "--fstep", "20"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert "successfully finished" in p.stdout, p.stdout[-3000:]
