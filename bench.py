@@ -16,34 +16,19 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 ATOMS_PER_GPU_CELLS = 18
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """Times the REAL reference (oracle/_ref/rxmd_omp: unmodified Fortran, OpenMP, built by oracle/Makefile) on the
-    host cores of this box on a bounded sample of the same workload: RDX 3x3x3 = 4,536 atoms (the largest cube that
-    fits the reference's compiled-in NBUFFER = 30000 with its 13 A ghost shell), same rxmd.in."""
-    ref = os.path.join(ROOT, "oracle", "_ref")
-    exe, gen = os.path.join(ref, "rxmd_omp"), os.path.join(ref, "geninit")
-    if not (os.path.exists(exe) and os.path.exists(gen)):
-        return None
-    cores = os.cpu_count() or 1
-    nthreads = min(cores, 64)
+def _run_reference(exe, gen, mc, nsteps, nthreads):
+    """one timed run of the reference's OpenMP build on RDX mc^3; returns (atoms, loop seconds, wall seconds) or None"""
     tmp = tempfile.mkdtemp(prefix="rxmd_cpu_")
     try:
         os.makedirs(os.path.join(tmp, "DAT"))
         shutil.copy(os.path.join(INP, "rdx.xyz"), os.path.join(tmp, "input.xyz"))
         shutil.copy(os.path.join(INP, "ffield_rdx"), os.path.join(tmp, "ffield"))
         shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
-        subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "3", "3", "3"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", str(mc), str(mc), str(mc)], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
         env = dict(os.environ, OMP_NUM_THREADS=str(nthreads), OMP_STACKSIZE="1G")
-
-        def unlimit():
-            try:
-                resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
-            except Exception:
-                pass
-        nsteps = 60
         t0 = time.time()
-        p = subprocess.run([exe, "--ntime_step", str(nsteps), "--pstep", "1000", "--fstep", "100000"], cwd=tmp, env=env, preexec_fn=unlimit,
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        p = subprocess.run([exe, "--ntime_step", str(nsteps), "--pstep", "1000", "--fstep", "100000"], cwd=tmp, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         wall = time.time() - t0
         loop = None
         for l in p.stdout.split("\n"):
@@ -51,13 +36,56 @@ def cpu_baseline(seconds_budget=30.0):
                 loop = float(l.split()[2])       # the reference's own timer around its MD loop (main.F90:35,108-109)
         if loop is None or loop <= 0 or "successfully finished" not in p.stdout:
             return None
-        atom_steps = 4536 * nsteps / loop
-        return {"value": atom_steps / (168 * ATOMS_PER_GPU_CELLS ** 3), "unit": "steps/s", "cores": nthreads, "kind": "reference",
-                "sample": "USCCACS/RXMD Fortran+OpenMP (oracle/_ref/rxmd_omp), RDX 3x3x3 = 4536 atoms, %d MD steps in %.2f s loop time "
-                          "(%.0f atom-steps/s), scaled to steps/s at 979,776 atoms" % (nsteps, loop, atom_steps),
-                "atom_steps_per_s": atom_steps, "wall_s": wall}
+        return 168 * mc ** 3, loop, wall
+    except Exception:
+        return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline():
+    """Times the REAL reference (oracle/_ref: Fortran + OpenMP, built by oracle/Makefile from the sources where they lie) on the host
+    cores of this box, on bounded samples of the same workload, same rxmd.in:
+      * rxmd_omp_big: the reference with ONLY its compiled-in capacity NBUFFER raised (module.F90:80, `sed` in the ignored build
+        directory), RDX 6x6x6 = 36,288 atoms x 10 MD steps -- the sample the headline comparison uses;
+      * rxmd_omp: the unmodified reference on the largest cube its NBUFFER = 30000 holds, RDX 3x3x3 = 4,536 atoms x 60 steps
+        (there the NBUFFER-sized overheads dominate) -- reported next to it.
+    Runs BEFORE torch / HIP are initialised in this process (fork of a GPU-initialised, multi-threaded parent is unsafe)."""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    gen = os.path.join(ref, "geninit")
+    if not os.path.exists(gen):
+        return None
+    try:                                          # the reference keeps NBUFFER-sized automatic arrays on the stack
+        resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+    except Exception:
+        try:
+            soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
+            resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
+        except Exception:
+            pass
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, 64)
+    full = 168 * ATOMS_PER_GPU_CELLS ** 3
+    out, samples = None, []
+    for exe, mc, nsteps, what in ((os.path.join(ref, "rxmd_omp_big"), 6, 10, "USCCACS/RXMD Fortran+OpenMP with NBUFFER raised (oracle/_ref/rxmd_omp_big)"),
+                                  (os.path.join(ref, "rxmd_omp"), 3, 60, "USCCACS/RXMD Fortran+OpenMP unmodified (oracle/_ref/rxmd_omp)")):
+        if not os.path.exists(exe):
+            continue
+        r = _run_reference(exe, gen, mc, nsteps, nthreads)
+        if r is None:
+            continue
+        atoms, loop, wall = r
+        rate = atoms * nsteps / loop
+        rec = {"sample": "%s, RDX %dx%dx%d = %d atoms, %d MD steps in %.2f s loop time (%.0f atom-steps/s), scaled to steps/s at %d atoms"
+                         % (what, mc, mc, mc, atoms, nsteps, loop, rate, full),
+               "atoms": atoms, "steps": nsteps, "loop_s": loop, "wall_s": wall, "atom_steps_per_s": rate, "value": rate / full}
+        samples.append(rec)
+        if out is None:
+            out = {"value": rate / full, "unit": "steps/s", "cores": nthreads, "kind": "reference", "sample": rec["sample"],
+                   "atom_steps_per_s": rate, "wall_s": wall}
+    if out is not None and len(samples) > 1:
+        out["other_samples"] = samples[1:]
+    return out
 
 
 def vprocs_for(n):
@@ -72,12 +100,17 @@ def main():
     ap.add_argument("--cells", type=int, default=ATOMS_PER_GPU_CELLS, help="RDX unit cells per edge per GPU (18 -> 979,776 atoms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--qeq-mode", type=int, default=1, help="1: one matrix pass per CG iteration (gradient by recurrence; default), 0: the reference's two passes")
-    ap.add_argument("--alt-steps", type=int, default=3, help="after the timed region, time this many steps in the other qeq_mode and report them under \"alt\" (0 = skip)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second leg (the other qeq_mode over the SAME trajectory window, reported under \"alt\")")
     ap.add_argument("--workload", default="rdx", choices=["rdx", "water", "sicnp"],
                     help="rdx: BASELINE configs[1]/[3] (headline); water: configs[2], perturbed ice Ih 60x35x40 = 2,016,000 atoms; "
                          "sicnp: configs[4], SiC nanoparticle + O2 with PQEq, 547-atom cell replicated --cells (default 12) per edge")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent periodic replicas instead of one decomposed box")
     a = ap.parse_args()
+
+    # the CPU baseline first: rank 0 of a 1-GPU run, before torch / HIP exist in this process
+    cb = None
+    if not a.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.workload == "rdx" and "RXMD_BENCH_FORCE_DIST" not in os.environ:
+        cb = cpu_baseline()
 
     import torch
     import rxmd_amd
@@ -145,7 +178,11 @@ def main():
     if use_dist and not a.replicas:
         from rxmd_amd.comm import TorchTransport
         dev = torch.device("cuda", local)
-        cap = int(natoms * 0.45 * 6) + (1 << 20)          # widest message: the 13 A ghost shell of one stage, 6 doubles per atom
+        # widest message pair of the six-stage exchange: the ghost build, 6 doubles per atom, both stages of an axis together.  Bound:
+        # everything a rank can hold besides its residents (NBUFFER is sized 1.12 x (1 + 2 shell/L)^3 x natoms; the 13 A shell is
+        # what the reference's NMINCELL x lcsize gives for RDX), i.e. 6 x 1.12 x ((1 + 26/L)^3 - 1) x natoms, plus slack
+        lmin = min(lat_super[i] / vp_local[i] for i in range(3))
+        cap = int(6 * 1.25 * natoms * ((1.0 + 27.0 / lmin) ** 3 - 1.0)) + (1 << 20)
         tr = None
         if backend == "nccl" and os.environ.get("RXMD_BENCH_TRANSPORT", "native") == "native":
             # native transport: the engine's own RCCL communicator (ncclSend/ncclRecv/ncclAllReduce on its stream, rccl_comm.hip);
@@ -219,16 +256,22 @@ def main():
         except Exception:
             probe = None
     alt = None
-    if a.alt_steps > 0 and world == 1:           # the other QEq algebra on the same trajectory, reported beside the headline
+    if not a.no_alt and world == 1:
+        # the other QEq algebra over the SAME window: restart from the same initial records, same warm-up, same number of steps (the
+        # reference's exit test makes the iteration count jump from step to step, so only equal windows compare)
         eng.set_qeq_mode(1 - a.qeq_mode)
-        eng.step(1)
+        eng.set_atoms_rxff(rec)
+        eng.QEq(); eng.FORCE()
+        eng.step(a.warmup)
         eng.reset_timers()
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        eng.step(a.alt_steps)
+        eng.step(a.steps)
         torch.cuda.synchronize(); dta = time.perf_counter() - t1
-        sa = eng.stats()                          # the reference's exit test makes the iteration count jump from step to step: quote it
-        alt = {"qeq_mode": 1 - a.qeq_mode, "steps": a.alt_steps, "ms_per_step": 1e3 * dta / a.alt_steps, "steps_per_s": a.alt_steps / dta,
-               "qeq_iters_per_step": sa["qeq_iters_total"] / max(sa["qeq_calls"], 1), "ms_qeq_per_iter": sa["ms_qeq"] / max(sa["qeq_iters_total"], 1)}
+        sa = eng.stats()
+        alt = {"qeq_mode": 1 - a.qeq_mode, "window": "same initial state, warm-up and step count as the headline leg", "steps": a.steps,
+               "ms_per_step": 1e3 * dta / a.steps, "steps_per_s": a.steps / dta,
+               "qeq_iters_per_step": sa["qeq_iters_total"] / max(sa["qeq_calls"], 1), "ms_qeq_per_iter": sa["ms_qeq"] / max(sa["qeq_iters_total"], 1),
+               "spmv_launches_per_step": sa["spmv_launches"] / a.steps}
         eng.set_qeq_mode(a.qeq_mode)
 
     if rank == 0:
@@ -250,12 +293,17 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 pass
-        # per-atom-step byte model of SURVEY 8d evaluated with the measured n10, nb, K
-        b_step = n10 * 12 + 40 + iters * (2 * n10 * 12 + 112) + n10 * 4 + 64 + nb * 104 * 5
+        # per-atom-step byte models with the measured n10, nb, K:
+        #  (i) SURVEY 8d's formula as written: TWO matrix passes per CG iteration (the reference algebra, qeq_mode 0)
+        # (ii) the bytes of the passes this run actually launched (qeq_mode 1: one pass per iteration + ~300 B of vector kernels)
+        passes = st["spmv_launches"] / a.steps
+        b_fixed = n10 * 12 + 40 + n10 * 4 + 64 + nb * 104 * 5
+        b_step_8d = b_fixed + iters * (2 * n10 * 12 + 112)
+        b_step_exec = b_fixed + passes * (n10 * 12 + 56) + iters * (300 if a.qeq_mode == 1 else 112)
         out = {
-            "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; aggregate over GPUs of per-GPU domains)" if a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS
-                      else "MD steps/sec (%s, %d atoms/GPU; aggregate over GPUs of per-GPU domains)" % (a.workload, natoms),
-            "value": steps_per_s * world, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; one step advances every GPU's domain: weak scaling, wall-clock steps/s of the whole job)" if a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS
+                      else "MD steps/sec (%s, %d atoms/GPU; wall-clock steps/s of the whole job)" % (a.workload, natoms),
+            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (unit cell of the reference's conf/init.%s replicated; v0=0, q0=0)" % ("rdx" if a.workload == "rdx" else a.workload),
             "config": {"workload": "%s = %d atoms/GPU, QEq tol %g, dt %g fs, mdmode 1 (NVE)" % (wname, natoms, cfg["QEq_tol"], cfg["dt"]),
@@ -268,16 +316,17 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_pass,
                          "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"],
                          "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,
-                         "step_model_bytes_per_atom": b_step, "step_frac_of_hbm_roofline": (b_step * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9)},
+                         "spmv_launches_per_step": passes,
+                         "step_bytes_per_atom_executed": b_step_exec, "step_frac_of_hbm_roofline": (b_step_exec * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9),
+                         "step_bytes_per_atom_survey8d_two_pass_formula": b_step_8d,
+                         "step_frac_survey8d_formula": (b_step_8d * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9)},
             "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded")},
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
         }
         if alt:
             out["alt"] = alt
-        if not a.no_cpu_baseline and world == 1 and a.workload == "rdx":
-            cb = cpu_baseline()
-            if cb:
-                out["cpu_baseline"] = cb
+        if cb:
+            out["cpu_baseline"] = cb
         import ctypes
         ctypes.CDLL(None).fflush(None)          # C-level stdout first (RCCL prints a version banner there): the JSON line stays last
         sys.stdout.flush()

@@ -112,6 +112,18 @@ module rxmd_hip_mod
        real(c_double), intent(in) :: atype(*), pos(*), q(*), spos(*)
        real(c_double), intent(out) :: f(*), pe(0:13)
      end function
+     integer(c_int) function rxmd_hip_put_lex(h, natoms, qsfp, qsfv) bind(c, name='rxmd_hip_put_lex')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: natoms
+       real(c_double), intent(in) :: qsfp(*), qsfv(*)
+     end function
+     integer(c_int) function rxmd_hip_get_lex(h, natoms, qsfp, qsfv) bind(c, name='rxmd_hip_get_lex')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: natoms
+       real(c_double), intent(out) :: qsfp(*), qsfv(*)
+     end function
      integer(c_int) function rxmd_hip_last_qeq_iters(h) bind(c, name='rxmd_hip_last_qeq_iters')
        import :: c_ptr, c_int
        type(c_ptr), value :: h
@@ -165,23 +177,32 @@ contains
 
   !> same arguments as the reference's QEq(atype,pos,q), src/qeq.F90:2,15-16
   subroutine QEq_hip(atype, pos, q)
-    use atoms, only: NBUFFER, NATOMS, nstep_qeq
+    use atoms, only: NBUFFER, NATOMS, nstep_qeq, qsfp, qsfv
     real(8), intent(in) :: atype(NBUFFER), pos(NBUFFER,3)
     real(8), intent(inout) :: q(NBUFFER)
     integer(c_int) :: rc
+    ! the fictitious charges of module atoms travel with the call (read with isQEq = 2, written with isQEq = 1: qeq.F90:41-42,51-52)
+    rc = rxmd_hip_put_lex(rxmd_hip_handle, int(NATOMS, c_int), qsfp, qsfv)
+    if (rc /= 0) call die('QEq (put_lex)', rc)
     rc = rxmd_hip_qeq_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, q)
     if (rc /= 0) call die('QEq', rc)
+    rc = rxmd_hip_get_lex(rxmd_hip_handle, int(NATOMS, c_int), qsfp, qsfv)
+    if (rc /= 0) call die('QEq (get_lex)', rc)
     nstep_qeq = rxmd_hip_last_qeq_iters(rxmd_hip_handle)        ! printed by PRINTE, src/main.F90:261
   end subroutine
 
   !> same arguments as the reference's PQEq(atype,pos,q), src/pqeq.F90:2; the shell displacements are module atoms' spos
   subroutine PQEq_hip(atype, pos, q)
-    use atoms, only: NBUFFER, NATOMS, nstep_qeq, spos
+    use atoms, only: NBUFFER, NATOMS, nstep_qeq, spos, qsfp, qsfv
     real(8), intent(in) :: atype(NBUFFER), pos(NBUFFER,3)
     real(8), intent(inout) :: q(NBUFFER)
     integer(c_int) :: rc
+    rc = rxmd_hip_put_lex(rxmd_hip_handle, int(NATOMS, c_int), qsfp, qsfv)
+    if (rc /= 0) call die('PQEq (put_lex)', rc)
     rc = rxmd_hip_pqeq_arrays(rxmd_hip_handle, int(NBUFFER, c_int), int(NATOMS, c_int), atype, pos, q, spos)
     if (rc /= 0) call die('PQEq', rc)
+    rc = rxmd_hip_get_lex(rxmd_hip_handle, int(NATOMS, c_int), qsfp, qsfv)
+    if (rc /= 0) call die('PQEq (get_lex)', rc)
     nstep_qeq = rxmd_hip_last_qeq_iters(rxmd_hip_handle)
   end subroutine
 

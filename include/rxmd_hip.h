@@ -124,6 +124,12 @@ int rxmd_hip_FORCE(rxmd_handle h, int nbuffer, int natoms, const double *atype, 
  * of module atoms (module.F90:286) go in, PQEq returns them moved (update_shell_positions, pqeq.F90:184-259) */
 int rxmd_hip_PQEq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *q, double *spos);
 int rxmd_hip_FORCE_pqeq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *f, const double *q, const double *spos, double pe[14]);
+/* the fictitious charges of the extended-Lagrangian method, module atoms' qsfp/qsfv (module.F90:289, integrated by the driver,
+ * main.F90:67-68,98; read AND written by QEq/PQEq, qeq.F90:41-42,51-52): put_lex hands the host's arrays to the NEXT
+ * rxmd_hip_QEq / rxmd_hip_PQEq call, get_lex returns what that call left (isQEq = 1: qsfp = q, qsfv = 0).  With isQEq = 2 the
+ * array-shaped QEq/PQEq refuse to run (RXMD_E_ARG) unless put_lex came first: the charges would start from qsfp = 0. */
+int rxmd_hip_put_lex(rxmd_handle h, int natoms, const double *qsfp, const double *qsfv);
+int rxmd_hip_get_lex(rxmd_handle h, int natoms, double *qsfp, double *qsfv);
 
 /* ---- introspection for tests, roofline accounting and the timers table (main.F90:135-182) ---- */
 typedef struct rxmd_stats {

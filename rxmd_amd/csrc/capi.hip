@@ -231,9 +231,14 @@ static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const do
     for (int a = 0; a < 3 && same; ++a) same = std::memcmp(e.last_pos[a].data(), pos + a * static_cast<size_t>(nbuffer), sizeof(double) * natoms) == 0;
     if (same) {
       if (q) RX_HIP(hipMemcpy(e.q, q, sizeof(double) * natoms, hipMemcpyHostToDevice));
+      if (e.lex_pending && e.lex_p.size() == static_cast<size_t>(natoms)) {
+        RX_HIP(hipMemcpy(e.qsfp, e.lex_p.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+        RX_HIP(hipMemcpy(e.qsfv, e.lex_v.data(), sizeof(double) * natoms, hipMemcpyHostToDevice));
+      }
       return;
     }
   }
+  const bool lex = e.lex_pending && e.lex_p.size() == static_cast<size_t>(natoms);
   e.last_atype.assign(atype, atype + natoms);
   for (int a = 0; a < 3; ++a) e.last_pos[a].assign(pos + a * static_cast<size_t>(nbuffer), pos + a * static_cast<size_t>(nbuffer) + natoms);
   std::vector<double> rec(10 * static_cast<size_t>(natoms), 0.0);
@@ -243,6 +248,7 @@ static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const do
     for (int a = 0; a < 3; ++a) o[a] = (e.box.Hi[a][0] * r[0] + e.box.Hi[a][1] * r[1] + e.box.Hi[a][2] * r[2]) - e.box.obox[a];
     o[6] = q ? q[i] : 0.0;
     o[7] = atype[i];
+    if (lex) { o[8] = e.lex_p[i]; o[9] = e.lex_v[i]; }
   }
   e.set_atoms_rxff(natoms, rec.data());
   // keep the caller's real coordinates bit for bit (the record round trip is only used for sizing/setup)
@@ -253,10 +259,31 @@ static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const do
   }
 }
 
+// isQEq = 2 starts the single CG step from qs = fqs*qsfp + (1-fqs)*q (qeq.F90:51-57): the host's qsfp must have come with put_lex
+static void require_lex(Engine &e, int natoms) {
+  if (e.cfg.isQEq == 2 && !(e.lex_pending && e.lex_p.size() == static_cast<size_t>(natoms)))
+    throw EngineError(RXMD_E_ARG, "isQEq = 2 through the array-shaped entry points needs rxmd_hip_put_lex(qsfp, qsfv) before every QEq/PQEq call");
+}
+int rxmd_hip_put_lex(rxmd_handle h, int natoms, const double *qsfp, const double *qsfv) {
+  if (!qsfp || !qsfv || natoms < 0) return RXMD_E_ARG;
+  return guarded(h, [&](Engine &e) { e.lex_p.assign(qsfp, qsfp + natoms); e.lex_v.assign(qsfv, qsfv + natoms); e.lex_pending = true; });
+}
+int rxmd_hip_get_lex(rxmd_handle h, int natoms, double *qsfp, double *qsfv) {
+  if (!qsfp || !qsfv) return RXMD_E_ARG;
+  return guarded(h, [&](Engine &e) {
+    if (!e.atoms_set || natoms != e.N) throw EngineError(RXMD_E_ARG, "get_lex: natoms does not match the atoms of the last call");
+    RX_HIP(hipStreamSynchronize(e.stream));
+    RX_HIP(hipMemcpy(qsfp, e.qsfp, sizeof(double) * natoms, hipMemcpyDeviceToHost));
+    RX_HIP(hipMemcpy(qsfv, e.qsfv, sizeof(double) * natoms, hipMemcpyDeviceToHost));
+  });
+}
+
 int rxmd_hip_QEq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *q) {
   if (!atype || !pos || !q) return RXMD_E_ARG;
   return guarded(h, [&](Engine &e) {
+    require_lex(e, natoms);
     upload_reference_arrays(e, nbuffer, natoms, atype, pos, q);
+    e.lex_pending = false;
     e.qeq();
     RX_HIP(hipMemcpy(q, e.q, sizeof(double) * natoms, hipMemcpyDeviceToHost));
   });
@@ -285,7 +312,9 @@ static void upload_shells(Engine &e, int nbuffer, int natoms, const double *spos
 int rxmd_hip_PQEq(rxmd_handle h, int nbuffer, int natoms, const double *atype, const double *pos, double *q, double *spos) {
   if (!atype || !pos || !q || !spos) return RXMD_E_ARG;
   return guarded(h, [&](Engine &e) {
+    require_lex(e, natoms);
     upload_reference_arrays(e, nbuffer, natoms, atype, pos, q);
+    e.lex_pending = false;
     upload_shells(e, nbuffer, natoms, spos);
     e.qeq();
     RX_HIP(hipMemcpy(q, e.q, sizeof(double) * natoms, hipMemcpyDeviceToHost));

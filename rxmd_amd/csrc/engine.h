@@ -164,6 +164,7 @@ struct Engine {
   void join_comm_stream() { RX_HIP(hipStreamWaitEvent(stream, ev_comm, 0)); }   // main stream waits for what on_comm_stream queued
   hipEvent_t ev[8] = {};
   std::vector<double> last_atype, last_pos[3];    // what the array-shaped entry points uploaded last (capi.hip)
+  std::vector<double> lex_p, lex_v; bool lex_pending = false;   // qsfp/qsfv handed over by rxmd_hip_put_lex for the next array-shaped QEq/PQEq
   rxmd_stats st{};
   int nstep_qeq = 0; double last_est = 0;
   long long step_count = 0;

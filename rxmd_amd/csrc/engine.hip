@@ -274,7 +274,7 @@ void Engine::alloc_device() {
   if (spmv_cell) dmalloc(nb10s, static_cast<size_t>(rows10) * S10);
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
-  dmalloc(partials, partials_cap); dmalloc(scal, 64);
+  dmalloc(partials, partials_cap + 1024); dmalloc(scal, 64);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
   dmalloc(d_err, 4);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 4 * sizeof(int)));
@@ -603,7 +603,10 @@ long long Engine::exchange_stage(int d, bool reverse, long long nsend, long long
 
 void Engine::ghost_build_staged() {
   const BoxDev B = boxdev(box);
-  ensure_xbuf(static_cast<size_t>(NB) * 6);
+  // own buffers: sized once for the worst case; host-supplied buffers (rxmd_hip_set_exchange_buffers): each axis asks for what its
+  // two messages need, the receive side is bounded by the transport (the callbacks get the capacity, the RCCL path checks it)
+  const bool xb_fixed = !xbuf_owned && xbuf_doubles > 0;
+  if (!xb_fixed) ensure_xbuf(static_cast<size_t>(NB) * 6);
   k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
   copyptr[0] = N;
   sendoff[1] = 0;
@@ -623,6 +626,7 @@ void Engine::ghost_build_staged() {
       RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       RX_HIP(hipStreamSynchronize(stream));
       if (sendoff[d0] + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
+      if (xb_fixed) ensure_xbuf(6 * (static_cast<size_t>(t0) + t1));
       sendoff[d0 + 1] = sendoff[d0] + t0; sendoff[d1 + 1] = sendoff[d1] + t1;
       if (t0 > 0) k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, -box.lbox[axis], flags, scanout, spos[0], spos[1], spos[2], type, gid, q, xbuf_send, sendidx + sendoff[d0]);
       if (t1 > 0) k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, box.lbox[axis], flags2, scanout2, spos[0], spos[1], spos[2], type, gid, q, xbuf_send + 6LL * t0, sendidx + sendoff[d1]);
@@ -645,6 +649,7 @@ void Engine::ghost_build_staged() {
     RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
     RX_HIP(hipStreamSynchronize(stream));
     if (sendoff[d] + total > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
+    if (xb_fixed) ensure_xbuf(6 * static_cast<size_t>(total));
     if (total > 0)
       k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, sft, flags, scanout, spos[0], spos[1], spos[2], type, gid, q, xbuf_send, sendidx + sendoff[d]);
     sendoff[d + 1] = sendoff[d] + total;

@@ -563,7 +563,7 @@ void Engine::qeq() {
   }
   const int cell_bs = 512;
   const int nred = use_cell ? grid.ncell : rb;                                      // partials one matrix pass leaves
-  double *lvl1 = partials + static_cast<size_t>(std::max(rb, grid.ncell)) * 4 + 64; // 128 x 4 first-level sums live behind the per-workgroup partials
+  double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) {
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;

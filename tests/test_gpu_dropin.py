@@ -46,6 +46,32 @@ def test_reference_driver_runs_on_the_hip_library():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def test_reference_driver_extended_lagrangian_charges_on_the_hip_library():
+    """--isQEq 2 through the drop-in driver: the fictitious charges qsfp/qsfv live in the reference's module atoms, are integrated by
+    its main.F90 (:67-68,98) and must travel into and out of every QEq call (rxmd_hip_put_lex / rxmd_hip_get_lex in QEq_hip);
+    10 steps against what the unmodified reference prints for the same run"""
+    drv, gen = os.path.join(REF, "rxmd_hipdrv"), os.path.join(REF, "geninit")
+    if not (os.path.exists(drv) and os.path.exists(gen)):
+        pytest.skip("oracle/_ref/rxmd_hipdrv was not built (needs the reference sources + amdflang: make -C oracle ref)")
+    g = np.load(os.path.join(oa.GOLD, "rdx168_lex_md10.npz"))
+    tmp = tempfile.mkdtemp(prefix="dropin_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(oa.INP, "rdx.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(oa.INP, "ffield_rdx"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(oa.INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "1", "1", "1"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        p = subprocess.run([drv, "--ntime_step", "10", "--pstep", "1", "--fstep", "10", "--isQEq", "2"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert "successfully finished" in p.stdout, p.stdout[-3000:]
+        rows = np.array([[float(x) for x in l.split()[1:13]] for l in p.stdout.split("\n") if l.startswith("MDstep:")])
+        ref = g["mdstep"][:len(rows), :12]
+        assert len(rows) == 10
+        assert np.allclose(rows[:, 1:3], ref[:, 1:3], rtol=2e-6)                    # total and potential energy per atom, es13.5
+        assert np.allclose(rows[:, 4:10], ref[:, 4:10], rtol=2e-3, atol=1e-6)       # the six energy groups, es11.3
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def test_reference_driver_with_pqeq_on_the_hip_library():
     """the same with --pqeq: PQEq(atype,pos,q) -> PQEq_hip, FORCE -> FORCE_hip carrying module atoms' spos in and out"""
     drv, gen = os.path.join(REF, "rxmd_hipdrv"), os.path.join(REF, "geninit")
