@@ -75,6 +75,12 @@ struct Grid {       // the engine's own cell grid over [-shell, L+shell) in norm
   double org[3];    // normalised origin (negative)
   double inv[3];    // cells per unit of normalised coordinate
   int ncell;
+  // every cell is cut into fz slices along z and the atoms are sorted by (x, y, z-slice): a column (x, y) of the grid is one contiguous,
+  // z-ordered run of the sorted arrays, so a sweep takes from each column only the slices within reach of ITS atom (lists.hip)
+  int fz, nzf;      // slices per cell; n[2] * fz
+  int nfine;        // n[0] * n[1] * nzf = length of cellstart - 1
+  double wid[3];    // perpendicular real width of one unit of normalised coordinate (orthorhombic: the lattice constant)
+  int ortho;        // 1: the three directions are orthogonal (distance^2 = sum of the three gaps^2), 0: only max(gap) is a bound
 };
 
 constexpr int WAVE = 64;
@@ -137,10 +143,8 @@ struct Engine {
   double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
   // 10 A list
   int *nb10 = nullptr, *n10 = nullptr; double *hess = nullptr;
-  unsigned short *nb10s = nullptr;   // same list, partner named by its position inside the row's 5x5x5-cell neighbourhood (bit 15: ghost): k_spmv_cell
-  size_t partials_cap = 0; bool cell_attr_set = false;
-  bool spmv_cell = false;            // env RXMD_SPMV_CELL=1: build nb10s and run the cell-tiled matrix pass
-  int nbhd_max = 0;                  // largest neighbourhood population of a resident's cell (sizes the LDS stage of k_spmv_cell)
+  size_t partials_cap = 0;
+  float4 *sorted_f4 = nullptr;       // cell-sorted (x, y, z, atom index as bits) in FP32: the candidate stream of the 10 A sweep's first test
   // reductions
   double *partials = nullptr;  // [nblocks_red * 16]
   double *scal = nullptr;      // device scalars (CG state)

@@ -167,7 +167,14 @@ void Engine::setup_after_atoms(const std::vector<long long> &npt) {
     grid.org[a] = -shell[a];
     grid.inv[a] = grid.n[a] / wn;
     grid.ncell *= grid.n[a];
+    grid.wid[a] = box.lat[a];                                  // orthorhombic: one unit of normalised coordinate = one lattice constant
   }
+  grid.ortho = 1;
+  // z-slices per cell: ~1/8 of a cell (0.6 A at the 5 A cell of a 10 A cutoff); bounded so that the slice ids fit the 31-bit sort key
+  grid.fz = 8;
+  while (grid.fz > 1 && static_cast<long long>(grid.ncell) * grid.fz > (1LL << 28)) grid.fz >>= 1;
+  grid.nzf = grid.n[2] * grid.fz;
+  grid.nfine = grid.n[0] * grid.n[1] * grid.nzf;
   tables_ready = true;
 }
 
@@ -260,8 +267,8 @@ void Engine::alloc_device() {
   dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb); dmalloc(hst2, nb); dmalloc(tickets, 16);
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(xs, nb);
-  dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.ncell) + 2);
-  dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
+  dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.nfine) + 2);
+  dmalloc(sorted_xyzi, nb); dmalloc(sorted_f4, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
   dmalloc(nbr, ns); dmalloc(nbrcnt, nb); dmalloc(nbrindx, ns);
   dmalloc(bo0, ns); dmalloc(bo1, ns); dmalloc(bo2, ns); dmalloc(bo3, ns); dmalloc(dln2, ns); dmalloc(dln3, ns); dmalloc(dBOp, ns);
   dmalloc(A0, ns); dmalloc(A1, ns); dmalloc(A2, ns); dmalloc(A3, ns);
@@ -270,8 +277,6 @@ void Engine::alloc_device() {
   dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
-  spmv_cell = (std::getenv("RXMD_SPMV_CELL") != nullptr);
-  if (spmv_cell) dmalloc(nb10s, static_cast<size_t>(rows10) * S10);
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dmalloc(scal, 64);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
@@ -298,7 +303,7 @@ void Engine::free_device() {
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(rows_int); dfree(rows_bnd);
-  dfree(nb10); dfree(nb10s); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
+  dfree(nb10); dfree(sorted_f4); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
@@ -968,22 +973,29 @@ __global__ void k_cell_ids(int G, Grid g, const double *sx, const double *sy, co
   int cx = static_cast<int>(floor((sx[i] - g.org[0]) * g.inv[0]));
   int cy = static_cast<int>(floor((sy[i] - g.org[1]) * g.inv[1]));
   int cz = static_cast<int>(floor((sz[i] - g.org[2]) * g.inv[2]));
-  cx = min(max(cx, 0), g.n[0] - 1); cy = min(max(cy, 0), g.n[1] - 1); cz = min(max(cz, 0), g.n[2] - 1);
-  cellid[i] = (cx * g.n[1] + cy) * g.n[2] + cz;
+  cx = min(max(cx, 0), g.n[0] - 1); cy = min(max(cy, 0), g.n[1] - 1);
+  // z: the slice index (fz slices per cell), one monotone expression of sz -- the sweeps rely on bin(s1) <= bin(s2) for s1 <= s2
+  int czf = static_cast<int>(floor((sz[i] - g.org[2]) * (g.inv[2] * g.fz)));
+  czf = min(max(czf, 0), g.nzf - 1);
+  cellid[i] = (cx * g.n[1] + cy) * g.nzf + czf;
   idx[i] = i;
 }
-__global__ void k_cell_starts(int G, int ncell, const int *cid_sorted, int *cellstart) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= G) return;
-  const int c = cid_sorted[k], prev = (k == 0) ? -1 : cid_sorted[k - 1];
-  for (int cc = prev + 1; cc <= c; ++cc) cellstart[cc] = k;
-  if (k == G - 1) for (int cc = c + 1; cc <= ncell; ++cc) cellstart[cc] = G;
+// cellstart[b] = first sorted position whose slice id is >= b (lower bound; one thread per slice, so empty stretches of a sparse box
+// cost nothing serial); cellstart[nfine] = G
+__global__ void k_cell_starts(int G, int nfine, const int *__restrict__ cid_sorted, int *__restrict__ cellstart) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nfine) return;
+  int lo = 0, hi = G;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (cid_sorted[mid] < b) lo = mid + 1; else hi = mid; }
+  cellstart[b] = lo;
 }
-__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, double4 *out, int *rootperm) {
+__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, double4 *out, float4 *out4, int *rootperm) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= G) return;
   const int i = perm[k];
-  out[k] = make_double4(x[i], y[i], z[i], __longlong_as_double(static_cast<long long>(i)));
+  const double xi = x[i], yi = y[i], zi = z[i];
+  out[k] = make_double4(xi, yi, zi, __longlong_as_double(static_cast<long long>(i)));
+  out4[k] = make_float4(static_cast<float>(xi), static_cast<float>(yi), static_cast<float>(zi), __int_as_float(i));
   rootperm[k] = (i < N) ? i : groot[i];
 }
 // xs[k] = v[owner of the atom at cell-sorted position k]: the ghost refresh (MODE_QCOPY1/2, comm.F90:187-212) and the
@@ -998,10 +1010,10 @@ void Engine::bin_cells() {
   k_cell_ids<<<nblk(G, 256), 256, 0, stream>>>(G, grid, spos[0], spos[1], spos[2], cellid, perm_in);
   size_t tb = cubtmp_bytes;
   int bits = 1;
-  while ((1LL << bits) < grid.ncell + 1 && bits < 31) ++bits;
+  while ((1LL << bits) < grid.nfine + 1 && bits < 31) ++bits;
   RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, cellid, cellid_sorted, perm_in, perm, G, 0, bits, stream));
-  k_cell_starts<<<nblk(G, 256), 256, 0, stream>>>(G, grid.ncell, cellid_sorted, cellstart);
-  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, rootperm);
+  k_cell_starts<<<nblk(grid.nfine + 1, 256), 256, 0, stream>>>(G, grid.nfine, cellid_sorted, cellstart);
+  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, sorted_f4, rootperm);
   if (ff.pqeq) pqeq_sorted_shells();
 }
 
@@ -1034,13 +1046,11 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     S10 = (static_cast<int>(need * 1.1) + 64 + 63) / 64 * 64;
     const size_t n = static_cast<size_t>(rows10) * S10;
     dfree(nb10); dfree(hess); dmalloc(nb10, n); dmalloc(hess, n);
-    if (spmv_cell) { dfree(nb10s); dmalloc(nb10s, n); }
     if (ff.pqeq) { dfree(hsc); dmalloc(hsc, n); }
     st.n10_stride = S10;
     build_list10();
     check_device_error("list build");
   }
-  nbhd_max = h_err[2];
   st.ms_lists += toc(0, 1);
   lists_valid = true;
 }
