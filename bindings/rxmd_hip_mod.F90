@@ -8,10 +8,20 @@
 !> The wrappers take the SAME arguments as the reference subroutines (atype(NBUFFER) packed
 !> type+gid*1e-13, pos/f(NBUFFER,3) column major, q(NBUFFER)), so `call QEq(atype,pos,q)` in
 !> main.F90:30,81 becomes `call QEq_hip(atype,pos,q)` and nothing else changes in the driver.
-!> Build:  amdflang -c bindings/rxmd_hip_mod.F90 ; link with -L rxmd_amd -lrxmd_hip
+!> Multi-rank (vprocs > 1 under the reference's MPI driver, examples/2-reaxff-dc: `mpirun -np 2 rxmd`, comm.F90:291-364):
+!> rxmd_hip_init installs a transport for the engine's six-stage exchange and its CG all-reduces --
+!>   * one GPU per rank: the engine's own RCCL communicator (ncclSend/ncclRecv/ncclAllReduce on its stream); MPI only broadcasts the
+!>     128-byte unique id (rxmd_hip_rccl_unique_id -> MPI_BCAST -> rxmd_hip_comm_init_rccl);
+!>   * fewer GPUs than ranks, or RXMD_HIP_TRANSPORT=mpi: MPI_SENDRECV / MPI_ALLREDUCE callbacks bound to rxmd_comm_ops, every message
+!>     staged through host memory (no GPU-aware MPI needed).
+!> Compiled with -DNOMPI (the reference's serial build) the transport is left out.
+!> Build:  amdflang -cpp [-DNOMPI | -I<mpi include>] -c bindings/rxmd_hip_mod.F90 ; link with -L rxmd_amd -lrxmd_hip
 module rxmd_hip_mod
   use iso_c_binding
   implicit none
+#ifndef NOMPI
+  include 'mpif.h'
+#endif
   private
   public :: rxmd_config, rxmd_hip_init, rxmd_hip_finalize, QEq_hip, PQEq_hip, FORCE_hip, rxmd_hip_handle
   public :: rxmd_hip_create, rxmd_hip_destroy, rxmd_hip_qeq, rxmd_hip_force, rxmd_hip_step, rxmd_hip_set_atoms_rxff, &
@@ -37,6 +47,14 @@ module rxmd_hip_mod
   end type
 
   type(c_ptr), save :: rxmd_hip_handle = c_null_ptr
+
+  !> mirrors `struct rxmd_comm_ops` (include/rxmd_hip.h)
+  type, bind(c) :: rxmd_comm_ops
+     type(c_ptr)    :: ctx
+     type(c_funptr) :: exchange, allreduce_sum, exchange_known
+  end type
+  type(rxmd_comm_ops), save, target :: mpi_ops
+  real(c_double), allocatable, save, target :: mpi_sbuf(:), mpi_rbuf(:)     ! host staging of one message each way
 
   interface
      subroutine rxmd_hip_default_config(cfg) bind(c, name='rxmd_hip_default_config')
@@ -112,6 +130,36 @@ module rxmd_hip_mod
        real(c_double), intent(in) :: atype(*), pos(*), q(*), spos(*)
        real(c_double), intent(out) :: f(*), pe(0:13)
      end function
+     integer(c_int) function rxmd_hip_set_comm(h, ops) bind(c, name='rxmd_hip_set_comm')
+       import :: c_ptr, c_int, rxmd_comm_ops
+       type(c_ptr), value :: h
+       type(rxmd_comm_ops), intent(in) :: ops
+     end function
+     integer(c_int) function rxmd_hip_rccl_unique_id(id128) bind(c, name='rxmd_hip_rccl_unique_id')
+       import :: c_int, c_char
+       character(kind=c_char), intent(out) :: id128(128)
+     end function
+     integer(c_int) function rxmd_hip_comm_init_rccl(h, id128, rank, world) bind(c, name='rxmd_hip_comm_init_rccl')
+       import :: c_ptr, c_int, c_char
+       type(c_ptr), value :: h
+       character(kind=c_char), intent(in) :: id128(128)
+       integer(c_int), value :: rank, world
+     end function
+     integer(c_int) function rxmd_hip_copy_to_host(dev, host, n) bind(c, name='rxmd_hip_copy_to_host')
+       import :: c_ptr, c_int, c_double, c_long_long
+       type(c_ptr), value :: dev
+       real(c_double), intent(out) :: host(*)
+       integer(c_long_long), value :: n
+     end function
+     integer(c_int) function rxmd_hip_copy_to_device(dev, host, n) bind(c, name='rxmd_hip_copy_to_device')
+       import :: c_ptr, c_int, c_double, c_long_long
+       type(c_ptr), value :: dev
+       real(c_double), intent(in) :: host(*)
+       integer(c_long_long), value :: n
+     end function
+     integer(c_int) function rxmd_hip_device_count() bind(c, name='rxmd_hip_device_count')
+       import :: c_int
+     end function
      integer(c_int) function rxmd_hip_put_lex(h, natoms, qsfp, qsfv) bind(c, name='rxmd_hip_put_lex')
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: h
@@ -155,6 +203,7 @@ contains
     cfg%vprocs = vprocs; cfg%myid = myid
     cfg%isQEq = isQEq; cfg%NMAXQEq = NMAXQEq; cfg%QEq_tol = QEq_tol; cfg%qstep = qstep; cfg%dt_fs = dt_fs
     cfg%device = device
+    if (device < 0) cfg%device = mod(myid, max(1, rxmd_hip_device_count()))     ! one GPU per rank of the node, round robin
     if (isLG) cfg%lg = 1
     if (isEfield) then                                          ! field force on cores and shells inside FORCE / PQEq (pot.F90:61, pqeq.F90:205)
        cfg%efield_dir = eFieldDir; cfg%efield_strength = eFieldStrength
@@ -167,7 +216,113 @@ contains
     endif
     rc = rxmd_hip_create(cfg, rxmd_hip_handle)
     if (rc /= 0) call die('rxmd_hip_create', rc)
+#ifndef NOMPI
+    if (vprocs(1)*vprocs(2)*vprocs(3) > 1) call install_transport(myid, vprocs(1)*vprocs(2)*vprocs(3))
+#endif
   end subroutine
+
+#ifndef NOMPI
+  !> the transport of a vprocs > 1 run (see the module header)
+  subroutine install_transport(myid, nprocs)
+    integer, intent(in) :: myid, nprocs
+    character(kind=c_char) :: id(128)
+    character(len=16) :: want
+    integer :: ierr, stat
+    integer(c_int) :: rc
+    logical :: use_rccl
+    call get_environment_variable('RXMD_HIP_TRANSPORT', want, status=stat)
+    if (stat /= 0) want = ' '
+    use_rccl = rxmd_hip_device_count() >= nprocs                ! RCCL wants one device per rank
+    if (trim(want) == 'mpi') use_rccl = .false.
+    if (trim(want) == 'rccl') use_rccl = .true.
+    if (use_rccl) then
+       id = c_null_char
+       if (myid == 0) then
+          rc = rxmd_hip_rccl_unique_id(id)
+          if (rc /= 0) call die('rxmd_hip_rccl_unique_id', rc)
+       endif
+       call MPI_BCAST(id, 128, MPI_CHARACTER, 0, MPI_COMM_WORLD, ierr)
+       rc = rxmd_hip_comm_init_rccl(rxmd_hip_handle, id, int(myid, c_int), int(nprocs, c_int))
+       if (rc /= 0) call die('rxmd_hip_comm_init_rccl', rc)
+       if (myid == 0) write(6,'(a,i4,a)') 'rxmd_hip: RCCL transport over ', nprocs, ' ranks (one GPU each)'
+    else
+       mpi_ops%ctx = c_null_ptr
+       mpi_ops%exchange = c_funloc(mpi_exchange)
+       mpi_ops%allreduce_sum = c_funloc(mpi_allreduce_sum)
+       mpi_ops%exchange_known = c_funloc(mpi_exchange_known)
+       rc = rxmd_hip_set_comm(rxmd_hip_handle, mpi_ops)
+       if (rc /= 0) call die('rxmd_hip_set_comm', rc)
+       if (myid == 0) write(6,'(a,i4,a)') 'rxmd_hip: host-staged MPI transport over ', nprocs, ' ranks'
+    endif
+  end subroutine
+
+  subroutine need_host_buffers(ns, nr)
+    integer(c_long_long), intent(in) :: ns, nr
+    if (.not. allocated(mpi_sbuf)) allocate(mpi_sbuf(max(ns, 65536_c_long_long)))
+    if (size(mpi_sbuf, kind=c_long_long) < ns) then
+       deallocate(mpi_sbuf); allocate(mpi_sbuf(ns + ns/4))
+    endif
+    if (.not. allocated(mpi_rbuf)) allocate(mpi_rbuf(max(nr, 65536_c_long_long)))
+    if (size(mpi_rbuf, kind=c_long_long) < nr) then
+       deallocate(mpi_rbuf); allocate(mpi_rbuf(nr + nr/4))
+    endif
+  end subroutine
+
+  !> rxmd_comm_ops.exchange: nsend doubles at device pointer `send` go to rank `to`; whatever rank `from` sends lands at device
+  !> pointer `recv` (capacity cap); returns the number received.  One send_recv of comm.F90:291-364: size first, then payload.
+  function mpi_exchange(ctx, to, send, nsend, from, recv, cap) bind(c) result(nrecv)
+    type(c_ptr), value :: ctx, send, recv
+    integer(c_int), value :: to, from
+    integer(c_long_long), value :: nsend, cap
+    integer(c_long_long) :: nrecv
+    integer(c_long_long) :: ns8(1), nr8(1)
+    integer :: ierr, stat(MPI_STATUS_SIZE)
+    ns8(1) = nsend
+    call MPI_SENDRECV(ns8, 1, MPI_INTEGER8, to, 20, nr8, 1, MPI_INTEGER8, from, 20, MPI_COMM_WORLD, stat, ierr)
+    nrecv = nr8(1)
+    if (ierr /= MPI_SUCCESS .or. nrecv > cap) then
+       nrecv = -1
+       return
+    endif
+    nrecv = mpi_exchange_known(ctx, to, send, nsend, from, recv, nrecv)
+  end function
+
+  !> rxmd_comm_ops.exchange_known: the same when the receiver already knows the count (vector halos, force return)
+  function mpi_exchange_known(ctx, to, send, nsend, from, recv, nrecv_in) bind(c) result(nrecv)
+    type(c_ptr), value :: ctx, send, recv
+    integer(c_int), value :: to, from
+    integer(c_long_long), value :: nsend, nrecv_in
+    integer(c_long_long) :: nrecv
+    integer :: ierr, stat(MPI_STATUS_SIZE)
+    integer(c_int) :: rc
+    nrecv = nrecv_in
+    call need_host_buffers(max(nsend, 1_c_long_long), max(nrecv, 1_c_long_long))
+    rc = rxmd_hip_copy_to_host(send, mpi_sbuf, nsend)
+    if (rc /= 0) then
+       nrecv = -1
+       return
+    endif
+    call MPI_SENDRECV(mpi_sbuf, int(nsend), MPI_DOUBLE_PRECISION, to, 21, mpi_rbuf, int(nrecv), MPI_DOUBLE_PRECISION, from, 21, &
+                      MPI_COMM_WORLD, stat, ierr)
+    if (ierr /= MPI_SUCCESS) then
+       nrecv = -1
+       return
+    endif
+    rc = rxmd_hip_copy_to_device(recv, mpi_rbuf, nrecv)
+    if (rc /= 0) nrecv = -1
+  end function
+
+  !> rxmd_comm_ops.allreduce_sum: n host doubles summed in place over all ranks (MPI_ALLREDUCE of qeq.F90:107,129,144,357)
+  function mpi_allreduce_sum(ctx, buf, n) bind(c) result(rc)
+    type(c_ptr), value :: ctx
+    integer(c_int), value :: n
+    real(c_double), intent(inout) :: buf(n)
+    integer(c_int) :: rc
+    integer :: ierr
+    call MPI_ALLREDUCE(MPI_IN_PLACE, buf, int(n), MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_WORLD, ierr)
+    rc = merge(0_c_int, 1_c_int, ierr == MPI_SUCCESS)
+  end function
+#endif
 
   subroutine rxmd_hip_finalize()
     integer(c_int) :: rc

@@ -180,6 +180,12 @@ int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops);
  * and every rank calls rxmd_hip_comm_init_rccl(h, id, myid, nprocs); a collective call.  Takes precedence over rxmd_comm_ops. */
 int rxmd_hip_rccl_unique_id(unsigned char out128[128]);
 int rxmd_hip_comm_init_rccl(rxmd_handle h, const unsigned char id128[128], int rank, int world);
+/* What a host transport without GPU-aware messaging needs (the MPI callbacks of bindings/rxmd_hip_mod.F90 stage every message
+ * through host memory): synchronous copies between the device pointers handed to `exchange` and host buffers, and the number
+ * of HIP devices this process sees (a Fortran driver picks `device = myid mod count`). */
+int rxmd_hip_copy_to_host(const double *dev, double *host, long long ndoubles);
+int rxmd_hip_copy_to_device(double *dev, const double *host, long long ndoubles);
+int rxmd_hip_device_count(void);
 /* Optional: let the host own the two message buffers (device memory, `ndoubles` each) that `exchange` is called
  * with -- e.g. torch tensors, so that torch.distributed can send them without wrapping foreign pointers. */
 int rxmd_hip_set_exchange_buffers(rxmd_handle h, double *send, double *recv, long long ndoubles);

@@ -79,6 +79,9 @@ SYMBOLS = [
     ("rxmd_hip_get_cutoffs", C.c_int, [H, PD, C.c_int, C.POINTER(C.c_double)]),
     ("rxmd_hip_debug_get", C.c_int, [H, C.c_int, PD, C.c_int]),
     ("rxmd_hip_set_comm", C.c_int, [H, C.POINTER(RxmdCommOps)]),
+    ("rxmd_hip_copy_to_host", C.c_int, [PD, PD, C.c_longlong]),
+    ("rxmd_hip_copy_to_device", C.c_int, [PD, PD, C.c_longlong]),
+    ("rxmd_hip_device_count", C.c_int, []),
     ("rxmd_hip_set_exchange_buffers", C.c_int, [H, PD, PD, C.c_longlong]),
     ("rxmd_host_comm_selftest", C.c_int, [C.POINTER(RxmdCommOps), C.c_int, C.c_int]),
     ("rxmd_host_geninit", C.c_longlong, [C.c_char_p, C.c_int, C.c_char_p, PD, PD, PD, PD, C.c_int, PD, C.c_longlong, PD]),

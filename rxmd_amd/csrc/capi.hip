@@ -438,6 +438,19 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
   return rc < 0 ? rc : n;
 }
 
+int rxmd_hip_copy_to_host(const double *dev, double *host, long long n) {
+  if (n < 0 || (n > 0 && (!dev || !host))) return RXMD_E_ARG;
+  return (n == 0 || hipMemcpy(host, dev, sizeof(double) * static_cast<size_t>(n), hipMemcpyDeviceToHost) == hipSuccess) ? RXMD_OK : RXMD_E_HIP;
+}
+int rxmd_hip_copy_to_device(double *dev, const double *host, long long n) {
+  if (n < 0 || (n > 0 && (!dev || !host))) return RXMD_E_ARG;
+  return (n == 0 || hipMemcpy(dev, host, sizeof(double) * static_cast<size_t>(n), hipMemcpyHostToDevice) == hipSuccess) ? RXMD_OK : RXMD_E_HIP;
+}
+int rxmd_hip_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int rxmd_hip_set_comm(rxmd_handle h, const rxmd_comm_ops *ops) {
   return guarded(h, [&](Engine &e) {
     if (!ops) { e.has_comm = false; return; }

@@ -51,7 +51,7 @@ struct DevFF {
   const int *inxn2, *inxn3, *inxn3hb, *inxn4;
   const DevNBTab *tabNB;   // [inxn * (NTABLE+2) + i]
   const double *tabQEq;    // [inxn * (NTABLE+2) + i]
-  double UDR, UDRi, rctap2, cutoff_vpar30, vpar1, vpar2;
+  double UDR, UDRi, rctap2, rctap_pad, cutoff_vpar30, vpar1, vpar2;   // rctap_pad: taper cutoff + the sweep padding (lists.hip)
   double plp1, povun3, povun4, povun6, povun7, povun8;
   double pval6, pval8, pval9, pval10, ppen2, ppen3, ppen4, pcoa2, pcoa3, pcoa4, ptor2, ptor3, ptor4, pcot2;
   // PQEq (pqeq != 0): per-type core charge Z and shell spring K, pair rows, and the three screened-Coulomb tables
@@ -145,6 +145,9 @@ struct Engine {
   int *nb10 = nullptr, *n10 = nullptr; double *hess = nullptr;
   size_t partials_cap = 0;
   float4 *sorted_f4 = nullptr;       // cell-sorted (x, y, z, atom index as bits) in FP32: the candidate stream of the 10 A sweep's first test
+  // the matrix pass's own 16-bit column stream (lists.hip, k_list10): entry = stencil column << 11 | ghost << 10 | offset in the column's run,
+  // rowhdr[row * 32 + column] = first sorted position of that run; 10 instead of 12 bytes per matrix entry
+  unsigned short *nb16 = nullptr; int *rowhdr = nullptr; bool idx16_on = false;
   // reductions
   double *partials = nullptr;  // [nblocks_red * 16]
   double *scal = nullptr;      // device scalars (CG state)

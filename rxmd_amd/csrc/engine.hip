@@ -237,6 +237,7 @@ void Engine::upload_ff() {
   dff.inxn2 = reinterpret_cast<int *>(base + off[5]); dff.inxn3 = reinterpret_cast<int *>(base + off[6]);
   dff.inxn3hb = reinterpret_cast<int *>(base + off[7]); dff.inxn4 = reinterpret_cast<int *>(base + off[8]);
   dff.tabNB = reinterpret_cast<DevNBTab *>(base + off[9]); dff.tabQEq = reinterpret_cast<double *>(base + off[10]);
+  dff.rctap_pad = ff.rctap + 1e-6;
   dff.UDR = ff.UDR; dff.UDRi = ff.UDRi; dff.rctap2 = ff.rctap2; dff.cutoff_vpar30 = ff.cutoff_vpar30; dff.vpar1 = ff.vpar1; dff.vpar2 = ff.vpar2;
   dff.plp1 = ff.plp1; dff.povun3 = ff.povun3; dff.povun4 = ff.povun4; dff.povun6 = ff.povun6; dff.povun7 = ff.povun7; dff.povun8 = ff.povun8;
   dff.pval6 = ff.pval6; dff.pval8 = ff.pval8; dff.pval9 = ff.pval9; dff.pval10 = ff.pval10; dff.ppen2 = ff.ppen2; dff.ppen3 = ff.ppen3; dff.ppen4 = ff.ppen4;
@@ -278,6 +279,8 @@ void Engine::alloc_device() {
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
+  idx16_on = (std::getenv("RXMD_SPMV_IDX32") == nullptr);
+  if (idx16_on) { dmalloc(nb16, static_cast<size_t>(rows10) * S10); dmalloc(rowhdr, static_cast<size_t>(rows10) * 32); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dmalloc(scal, 64);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
@@ -303,7 +306,7 @@ void Engine::free_device() {
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(rows_int); dfree(rows_bnd);
-  dfree(nb10); dfree(sorted_f4); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
+  dfree(nb10); dfree(sorted_f4); dfree(nb16); dfree(rowhdr); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
@@ -972,7 +975,6 @@ __global__ void k_cell_ids(int G, Grid g, const double *sx, const double *sy, co
   if (i >= G) return;
   int cx = static_cast<int>(floor((sx[i] - g.org[0]) * g.inv[0]));
   int cy = static_cast<int>(floor((sy[i] - g.org[1]) * g.inv[1]));
-  int cz = static_cast<int>(floor((sz[i] - g.org[2]) * g.inv[2]));
   cx = min(max(cx, 0), g.n[0] - 1); cy = min(max(cy, 0), g.n[1] - 1);
   // z: the slice index (fz slices per cell), one monotone expression of sz -- the sweeps rely on bin(s1) <= bin(s2) for s1 <= s2
   int czf = static_cast<int>(floor((sz[i] - g.org[2]) * (g.inv[2] * g.fz)));
@@ -1046,11 +1048,13 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     S10 = (static_cast<int>(need * 1.1) + 64 + 63) / 64 * 64;
     const size_t n = static_cast<size_t>(rows10) * S10;
     dfree(nb10); dfree(hess); dmalloc(nb10, n); dmalloc(hess, n);
+    if (nb16) { dfree(nb16); dmalloc(nb16, n); }
     if (ff.pqeq) { dfree(hsc); dmalloc(hsc, n); }
     st.n10_stride = S10;
     build_list10();
     check_device_error("list build");
   }
+  if (idx16_on && h_err[3] != 0) idx16_on = false;   // a stencil column with more than 1024 candidates: the matrix pass keeps the 32-bit entries
   st.ms_lists += toc(0, 1);
   lists_valid = true;
 }

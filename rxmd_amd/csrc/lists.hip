@@ -9,6 +9,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 namespace rxmd {
 
 static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
@@ -22,32 +24,70 @@ __global__ void k_pack_type(int G, const int *perm, const int *type, double4 *s)
   s[k].w = __longlong_as_double(w);
 }
 
+// ---- geometry of a sweep over the engine's grid ---------------------------------------------------------------------------
+// The atoms are sorted by (cell x, cell y, z-slice): column (x, y) is one contiguous run, ordered in z to the width of a slice
+// (Grid::fz slices per cell).  A sweep around an atom therefore takes from every column of its stencil only the slices that can
+// hold a partner: with gap = distance from the atom to the column's footprint in the x-y plane, partners lie within
+// dz = sqrt(rc^2 - gap^2) of the atom's z.  For the 10 A list that is 53 % of the atoms of the 5 x 5 x 5 cells (a third of them pass
+// the distance test instead of a quarter... of twice as many).  All bounds are conservative (padded by SWEEP_PAD); the exact
+// distance test decides.
+constexpr double SWEEP_PAD = 1e-6;      // [A] covers the rounding of the normalised <-> real round trip and of the face positions
+// real-space gap along axis a between normalised coordinate s (an atom of cell c_self) and cell c2
+__device__ inline double axis_gap(const Grid &g, int a, double s, int c_self, int c2) {
+  if (c2 == c_self) return 0.0;
+  const double face = g.org[a] + static_cast<double>(c2 > c_self ? c2 : c2 + 1) / g.inv[a];   // the face of c2 that looks at the atom
+  const double d = (c2 > c_self ? face - s : s - face) * g.wid[a];
+  return d > 0.0 ? d : 0.0;
+}
+__device__ inline int z_slice(const Grid &g, double sz) {          // the expression of k_cell_ids, monotone in sz
+  const int b = static_cast<int>(floor((sz - g.org[2]) * (g.inv[2] * g.fz)));
+  return min(max(b, 0), g.nzf - 1);
+}
+// run [k0, k0 + len) of the sorted arrays that column (x2, y2) contributes to a sweep of radius rcp around (sx, sy, sz); len = 0: none
+__device__ inline void column_run(const Grid &g, const int *__restrict__ cellstart, double sx, double sy, double sz, int cx, int cy, int x2, int y2,
+                                  double rcp, int &k0, int &len) {
+  k0 = 0; len = 0;
+  if (x2 < 0 || x2 >= g.n[0] || y2 < 0 || y2 >= g.n[1]) return;
+  const double gx = axis_gap(g, 0, sx, cx, x2), gy = axis_gap(g, 1, sy, cy, y2);
+  const double d2 = g.ortho ? gx * gx + gy * gy : fmax(gx, gy) * fmax(gx, gy);
+  if (d2 > rcp * rcp) return;
+  const double dzs = sqrt(rcp * rcp - d2) / g.wid[2];
+  const int lo = z_slice(g, sz - dzs), hi = z_slice(g, sz + dzs);
+  const int cbf = (x2 * g.n[1] + y2) * g.nzf;
+  k0 = cellstart[cbf + lo];
+  len = cellstart[cbf + hi + 1] - k0;
+}
+
 __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                       const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
-                                                      const double *__restrict__ z, const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {
+                                                      const double *__restrict__ z, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
+                                                      const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {
   // squared bond cut-off of every type pair in LDS (0 = the pair has no bond row): one LDS read per candidate instead of two
-  // dependent global look-ups (inxn2, then bond[inxn].rc2)
-  __shared__ double s_rc2[256];
+  // dependent global look-ups (inxn2, then bond[inxn].rc2); and per type the largest cut-off it has with any partner
+  __shared__ double s_rc2[256], s_rmax[16];
   for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) { const int ix = ff.inxn2[t]; s_rc2[t] = ix ? ff.bond[ix].rc2 : 0.0; }
+  __syncthreads();
+  if (threadIdx.x < ff.n1 && threadIdx.x < 16) {
+    double m = 0.0;
+    for (int t = 0; t < ff.n1; ++t) m = fmax(m, s_rc2[threadIdx.x * ff.n1 + t]);
+    s_rmax[threadIdx.x] = sqrt(m) + SWEEP_PAD;
+  }
   __syncthreads();
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
   const int c = cellid[i];
-  const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
+  const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
+  const double sxi = sx[i], syi = sy[i], szi = sz[i];
   const int ti = type[i];
   const double *rc2row = s_rc2 + ti * ff.n1;
-  const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.n[2] - 1);
+  const double rcp = s_rmax[ti];
   int cnt = 0;
   for (int dx = -1; dx <= 1; ++dx) {
-    const int x2 = cx + dx;
-    if (x2 < 0 || x2 >= g.n[0]) continue;
     for (int dy = -1; dy <= 1; ++dy) {
-      const int y2 = cy + dy;
-      if (y2 < 0 || y2 >= g.n[1]) continue;
-      const int cb = (x2 * g.n[1] + y2) * g.n[2];
-      const int k0 = cellstart[cb + z0], k1 = cellstart[cb + z1 + 1];
-      for (int k = k0; k < k1; ++k) {
+      int k0, len;
+      column_run(g, cellstart, sxi, syi, szi, cx, cy, cx + dx, cy + dy, rcp, k0, len);
+      for (int k = k0; k < k0 + len; ++k) {
         const double4 p = sorted[k];
         const long long w = __double_as_longlong(p.w);
         const int j = static_cast<int>(w & 0xffffffffLL);
@@ -100,37 +140,44 @@ __device__ inline double wave_sum_l(double v) {
   return v;
 }
 
-// One wavefront per resident row.  Lanes sweep the candidates of a stencil column 64 at a time,
-// the accepted ones are compacted with a ballot so that a row is written as contiguous runs
-// (coalesced 8-byte + 4-byte streams) in a deterministic order.
-// A list entry names the partner by its CELL-SORTED position (the loop variable of this sweep), not by atom index:
-// the consumers (QEq matrix passes, ENbond, Ehb) gather from cell-sorted copies, so the 64 lanes of a wavefront hit a
-// handful of cache lines instead of 64 scattered ones.  Bits: see NB10_* in engine.h.
+// One wavefront per resident row, two phases.
+// Phase 1 (sparse): the candidates of the row = the z-trimmed runs of its 25 stencil columns (column_run above), laid end to end and
+// cut into chunks of 64 -- every lane finds its column by a 5-step search of the run offsets in LDS -- four chunks loaded at once.
+// The distance test runs on an FP32 copy of the positions (16-byte candidates, full-rate arithmetic); only a candidate whose FP32
+// distance lies within `band32` of the cutoff (the rounding bound of that copy) is decided in FP64 from the exact positions, so the
+// accepted set is exactly the reference's  dr2 <= rctap2  (main.F90:458).  Survivors are compacted with a ballot into an LDS queue.
+// Phase 2 (dense): 64 queued survivors at a time -> exact FP64 distance, table interpolation, list entry, hessian value, row sums;
+// a row is written as contiguous runs (coalesced 8-byte + 4-byte streams) in a deterministic order.
+// A list entry names the partner by its CELL-SORTED position (the loop variable of this sweep), not by atom index: the consumers
+// (QEq matrix passes, ENbond, Ehb) gather from cell-sorted copies, so the 64 lanes of a wavefront hit a handful of cache lines
+// instead of 64 scattered ones.  Bits: see NB10_* in engine.h.
+// nb16 != nullptr: the matrix pass's own copy of the column stream in 16 bits -- bits 11-15 the stencil column, 10 ghost, 0-9 the
+// offset inside that column's run -- with the 25 run starts of the row in rowhdr[row * 32 ..]; an offset that does not fit raises err[3].
 // PQ: PQEq variant of qeq_initialize (pqeq.F90:262-353): core-core hessian from the pcc table, the shell-core matrix hsc of
 // get_hsh's Csicj term, and per row (fpqeq Eq. 30, sum_j H Z_j, sum_j hsc Z_j, shell-shell energy) -> pqrow
-template <bool SELFCHECK, bool PQ>
+template <bool SELFCHECK, bool PQ, bool PRE32>
 __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
-                                                 const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
-                                                 const double *__restrict__ z, const int *__restrict__ type, const long long *__restrict__ gid,
-                                                 int *__restrict__ nb10, unsigned short *__restrict__ nb10s, double *__restrict__ hess, int *__restrict__ n10, int *err,
+                                                 const double4 *__restrict__ sorted, const float4 *__restrict__ sorted4, float band32,
+                                                 const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                 const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz,
+                                                 const int *__restrict__ type, const long long *__restrict__ gid,
+                                                 int *__restrict__ nb10, unsigned short *__restrict__ nb16, int *__restrict__ rowhdr, double *__restrict__ hess, int *__restrict__ n10, int *err,
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
                                                  const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag) {
-  // dynamic LDS: [4][128] queue of accepted candidates (sorted position, neighbourhood position), [4][128] chunk table, then [4][S10] 16-bit rows
-  extern __shared__ int lds_all[];
+  __shared__ int2 s_q[4][128];           // accepted candidates: (sorted position, column << 16 | offset in the column's run)
+  __shared__ int s_P[4][32], s_K[4][32];  // per stencil column: candidates before it / first sorted position of its run
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
   if (i >= N) return;
-  constexpr int MAXCH = 128;                     // chunks of one row (RDX: 26-50)
-  int2 *sq = reinterpret_cast<int2 *>(lds_all) + w * 128;
-  int4 *ck = reinterpret_cast<int4 *>(lds_all + 4 * 128 * 2) + w * MAXCH;
-  unsigned short *srow = reinterpret_cast<unsigned short *>(lds_all + 4 * 128 * 2 + 4 * MAXCH * 4) + static_cast<size_t>(w) * S10;
-  int nchunk = 0;
+  int2 *sq = s_q[w];
+  int *cP = s_P[w], *cK = s_K[w];
   const int c = cellid[i];
-  const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
+  const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
+  const float xf = static_cast<float>(xi), yf = static_cast<float>(yi), zf = static_cast<float>(zi);
+  const float rc2f = static_cast<float>(ff.rctap2);
   const int ti = type[i];
-  const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.n[2] - 1);
   const size_t row = static_cast<size_t>(i) * S10;
   double sxi = 0.0, syi = 0.0, szi = 0.0, Zi = 0.0, p_f = 0.0, p_hz = 0.0, p_bz = 0.0, p_ss = 0.0;
   if (PQ) { sxi = shx[i]; syi = shy[i]; szi = shz[i]; Zi = ff.Zpq[ti]; }
@@ -138,12 +185,12 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   // get_gradient would need before the first iteration (qeq.F90:87) comes for free while the entries are in registers
   double ra = 0.0, rg = 0.0;
   bool anyghost = false;                          // does the row have a ghost partner (boundary row of the domain)?
+  bool wide = false;                              // an offset beyond the 10 bits of the 16-bit entry
   int cnt = 0;      // entries written so far
   int qn = 0;       // accepted candidates waiting in the queue
-  int loff = 0;     // candidates in the stencil columns already swept = position of this column inside the neighbourhood
 
-  // Phase 2, dense: one queued candidate per lane -> table interpolation, list entry, hessian value.  Only ~27 % of the
-  // candidates of a chunk pass the distance test, so doing this work on compacted batches keeps every lane busy.
+  // Phase 2, dense: one queued candidate per lane -> table interpolation, list entry, hessian value.  Only a third of the
+  // candidates pass the distance test, so doing this work on compacted batches keeps every lane busy.
   auto emit = [&](int nproc) {
     if (lane < nproc) {
       const int2 qe = sq[lane];
@@ -199,65 +246,76 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
         }
         anyghost |= (j >= N);
         nb10[row + slot] = static_cast<int>(ent);
-        if (nb10s) srow[slot] = static_cast<unsigned short>((qe.y & 0x7fff) | (j >= N ? 0x8000 : 0));
+        if (nb16) {
+          const int off = qe.y & 0xffff;
+          wide |= off > 1023;
+          nb16[row + slot] = static_cast<unsigned short>(((qe.y >> 16) << 11) | (j >= N ? 1024 : 0) | (off & 1023));
+        }
         hess[row + slot] = h;
       }
     }
     cnt += nproc;
   };
 
-  // chunk table of the row: the 25 stencil columns (contiguous runs of the sorted array) cut into 64-candidate chunks, in sweep
-  // order.  Lane t < 25 owns column t; an exclusive scan over the lanes places its chunks.  The sweep is bound by the latency of
-  // the candidate loads (26 dependent round trips per row when done one chunk at a time), so four chunks are loaded at once.
+  // the 25 stencil columns: lane t < 25 owns column t; an inclusive scan over the lanes lays the runs end to end
+  int L;
   {
     int k0 = 0, len = 0;
-    if (lane < 25) {
-      const int x2 = cx + lane / 5 - 2, y2 = cy + lane % 5 - 2;
-      if (x2 >= 0 && x2 < g.n[0] && y2 >= 0 && y2 < g.n[1]) {
-        const int cb = (x2 * g.n[1] + y2) * g.n[2];
-        k0 = cellstart[cb + z0];
-        len = cellstart[cb + z1 + 1] - k0;
-      }
-    }
-    int nch = (len + 63) >> 6, cpre = nch, lpre = len;      // inclusive scans over lanes 0..24 (chunks, candidates)
+    if (lane < 25) column_run(g, cellstart, spx[i], spy[i], spz[i], cx, cy, cx + lane / 5 - 2, cy + lane % 5 - 2, ff.rctap_pad, k0, len);
+    int lpre = len;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {
-      const int c2 = __shfl_up(cpre, o, 64), l2 = __shfl_up(lpre, o, 64);
-      if (lane >= o) { cpre += c2; lpre += l2; }
+      const int l2 = __shfl_up(lpre, o, 64);
+      if (lane >= o) lpre += l2;
     }
-    const int cfirst = cpre - nch, lfirst = lpre - len;
-    for (int t = 0; t < nch && cfirst + t < MAXCH; ++t) ck[cfirst + t] = make_int4(k0 + 64 * t, k0 + len, lfirst - k0, 0);
-    loff = __shfl(lpre, 24, 64);
-    nchunk = __shfl(cpre, 24, 64);
-    if (nchunk > MAXCH) { if (lane == 0) atomicCAS(&err[0], DERR_NONE, DERR_GRID); nchunk = MAXCH; }   // > 8192 candidates around one atom
+    if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; }
+    if (rowhdr && lane < 32) rowhdr[static_cast<size_t>(i) * 32 + lane] = k0;
+    L = __shfl(lpre, 31, 64);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  for (int c0 = 0; c0 < nchunk; c0 += 4) {
+  for (int c0 = 0; c0 < L; c0 += 256) {
     // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
-    double4 p[4];
-    int kk[4], lb[4];
+    int kk[4], tinfo[4];
     bool ok[4];
+    float4 pf[4];
+    double4 pd[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      ok[u] = false; kk[u] = 0; lb[u] = 0;
-      if (c0 + u < nchunk) {
-        const int4 ce = ck[c0 + u];
-        kk[u] = ce.x + lane; lb[u] = ce.z;
-        ok[u] = kk[u] < ce.y;
-      }
-      p[u] = ok[u] ? sorted[kk[u]] : make_double4(0, 0, 0, 0);
+      const int cc = c0 + 64 * u + lane;
+      ok[u] = cc < L;
+      int t = 0;                                 // the column of candidate cc: the last one that starts at or before it
+#pragma unroll
+      for (int st = 16; st > 0; st >>= 1) t += (cP[t + st] <= cc) ? st : 0;
+      const int off = cc - cP[t];
+      kk[u] = ok[u] ? cK[t] + off : 0;
+      tinfo[u] = (t << 16) | (off & 0xffff) | (off > 0xffff ? 0xffff : 0);
+      if (PRE32) pf[u] = ok[u] ? sorted4[kk[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      else pd[u] = ok[u] ? sorted[kk[u]] : make_double4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       bool in = false;
       if (ok[u]) {
-        const int j = static_cast<int>(__double_as_longlong(p[u].w) & 0xffffffffLL);
-        const double d0 = xi - p[u].x, d1 = yi - p[u].y, d2 = zi - p[u].z;
-        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-        in = (j != i) && (r2 <= ff.rctap2);       // dr2 <= rctap2, main.F90:458
+        if (PRE32) {
+          const int j = __float_as_int(pf[u].w);
+          const float e0 = xf - pf[u].x, e1 = yf - pf[u].y, e2 = zf - pf[u].z;
+          const float r2s = e0 * e0 + e1 * e1 + e2 * e2;
+          in = r2s <= rc2f - band32;
+          if (!in && r2s <= rc2f + band32) {     // too close to call in FP32: the exact positions decide (rare)
+            const double4 p = sorted[kk[u]];
+            const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
+            in = (d0 * d0 + d1 * d1 + d2 * d2) <= ff.rctap2;
+          }
+          in = in && (j != i);
+        } else {
+          const int j = static_cast<int>(__double_as_longlong(pd[u].w) & 0xffffffffLL);
+          const double d0 = xi - pd[u].x, d1 = yi - pd[u].y, d2 = zi - pd[u].z;
+          const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+          in = (j != i) && (r2 <= ff.rctap2);     // dr2 <= rctap2, main.F90:458
+        }
       }
       const unsigned long long m = __ballot(in);
-      if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(kk[u], lb[u] + kk[u]);
+      if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(kk[u], tinfo[u]);
       qn += __popcll(m);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (qn >= 64) {
@@ -274,14 +332,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   }
   if (qn > 0) emit(qn);
   if (cnt > S10) { if (lane == 0) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); } cnt = S10; }  // qeq.F90:248-252
-  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; if (nb10s) srow[cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
-  if (nb10s) {
-    const int nw = ((cnt + 3) & ~3) >> 1;            // the wavefront's own LDS row: no barrier needed beyond the wave's program order
-    const unsigned *sw = reinterpret_cast<const unsigned *>(srow);
-    unsigned *dw = reinterpret_cast<unsigned *>(nb10s + row);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (int t = lane; t < nw; t += 64) dw[t] = sw[t];
-  }
+  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; if (nb16) nb16[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
   if (xs0) {
     ra = wave_sum_l(ra); rg = wave_sum_l(rg);
     if (lane == 0) { s_all[i] = make_double2(ra, 0.0); s_gh[i] = make_double2(rg, 0.0); }
@@ -292,7 +343,8 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
     if (lane == 0) pqrow[i] = make_double4(p_f, p_hz, p_bz, p_ss);
   }
   { const unsigned long long mg = __ballot(anyghost); if (lane == 0 && rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0; }
-  if (lane == 0) { n10[i] = cnt; if (loff > __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&err[2], loff); }
+  if (nb16) { const unsigned long long mw = __ballot(wide); if (lane == 0 && mw != 0ULL) atomicMax(&err[3], 1); }
+  if (lane == 0) n10[i] = cnt;
 }
 
 // boundary rows keep their order, interior rows too: index lists for the two launches of the matrix pass
@@ -304,21 +356,28 @@ __global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__r
 
 void Engine::build_bonded_list() {
   k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi);
-  k_bonded_list<<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, nbr, nbrcnt, d_err);
+  k_bonded_list<<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
   k_reverse_index<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, d_err);
 }
 
 void Engine::build_list10() {
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
-  RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
   const bool selfcheck = (box.lat[0] < 2.0 * ff.rctap + 1.0) || (box.lat[1] < 2.0 * ff.rctap + 1.0) || (box.lat[2] < 2.0 * ff.rctap + 1.0);
-  const size_t lds = 4 * 128 * sizeof(int2) + 4 * 128 * sizeof(int4) + static_cast<size_t>(S10) * 4 * sizeof(unsigned short);
-#define RX_LIST10(SC, PQF)                                                                                                                     \
-  k_list10<SC, PQF><<<nblk(N, 4), 256, lds, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], type, gid, nb10, nb10s, \
-                                                      hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, \
-                                                      sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
-  if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
-  else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
+  // FP32 first test: |r2(fp32) - r2| <= 2 r sqrt(3) (1.2e-7 cmax) + 4 ulp(r2), cmax = largest coordinate; twice that as the band
+  static const bool pre32 = (std::getenv("RXMD_LIST_NO_FP32") == nullptr);
+  double cmax = 0.0;
+  for (int a = 0; a < 3; ++a) cmax = std::max(cmax, box.lat[a] * (box.obox[a] + box.lbox[a] + 2.0 * shell[a]));
+  const float band32 = static_cast<float>(1e-5 * cmax + 2e-4);
+  unsigned short *n16 = idx16_on ? nb16 : nullptr;
+  int *hdr = idx16_on ? rowhdr : nullptr;
+#define RX_LIST10(SC, PQF, P32)                                                                                                                  \
+  k_list10<SC, PQF, P32><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, sorted_f4, band32, pos[0], pos[1], pos[2], \
+                                                         spos[0], spos[1], spos[2], type, gid, nb10, n16, hdr, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, \
+                                                         sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
+#define RX_LIST10_P(SC, PQF) do { if (pre32) RX_LIST10(SC, PQF, true); else RX_LIST10(SC, PQF, false); } while (0)
+  if (ff.pqeq) { if (selfcheck) RX_LIST10_P(true, true); else RX_LIST10_P(false, true); }
+  else { if (selfcheck) RX_LIST10_P(true, false); else RX_LIST10_P(false, false); }
+#undef RX_LIST10_P
 #undef RX_LIST10
   if (multi()) {     // interior rows (no ghost partner) and boundary rows: the matrix pass does the former while the vector halo is in flight
     RX_HIP(hipMemsetAsync(flags + N, 0, sizeof(int), stream));

@@ -50,46 +50,11 @@ __device__ inline void block_store_partials(double (&acc)[NC], double *partials,
   }
 }
 
-// per-row tail of a matrix pass (lane 0 of the row's wavefront): the arithmetic of get_hsh / get_gradient around the row sums
 // PQEq (pqrow != nullptr): the second pair of sums (gs_,gt_) is over the shell-core matrix hsc instead of the ghost columns;
 // gradient gets the field term fpqeq (pqeq.F90:466), Est the core/shell terms of pqeq.F90:381-411 without the resident doubling
 __device__ inline double pq_est_row(const DevAtomP &ap, double Zi, const double4 &pr, double qi, double hq, double bq) {
   return ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * (qi + Zi) * (hq + pr.y) + pr.w - (bq + pr.z);
 }
-template <int MODE, bool STORE>
-__device__ inline void row_epilogue(int row, double as, double at, double gs_, double gt_, double mu, const DevFF &ff, const double2 *__restrict__ hst, double2 *__restrict__ gst,
-                                    const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
-                                    double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh, double (&acc)[4], const double4 *__restrict__ pqrow) {
-  if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
-  const int ti = type[row];
-  const DevAtomP ap = ff.atom[ti];
-  if (MODE == MODE_GRAD && pqrow) {
-    const double4 pr = pqrow[row];
-    const double2 qv = qst[row];
-    const double g1 = -ap.chi - ap.eta * qv.x - as - pr.x;
-    const double g2 = -1.0 - ap.eta * qv.y - at;
-    gst[row] = make_double2(g1, g2);
-    acc[0] += g1 * g1; acc[1] += g2 * g2;
-    acc[2] += pq_est_row(ap, ff.Zpq[ti], pr, q[row], as - mu * at, gs_ - mu * gt_);
-    return;
-  }
-  if (MODE == MODE_HSH) {
-    const double2 hv = hst[row], gv = gst[row];
-    const double ts = ap.eta * hv.x + as, tt = ap.eta * hv.y + at;      // qeq.F90:294-302
-    acc[0] += ts * hv.x; acc[1] += tt * hv.y;                           // hshs_sum, hsht_sum (:309-310)
-    acc[2] += gv.x * hv.x; acc[3] += gv.y * hv.y;                       // g.h (:119,123)
-  } else {
-    const double2 qv = qst[row];
-    const double g1 = -ap.chi - ap.eta * qv.x - as;                     // qeq.F90:349-350
-    const double g2 = -1.0 - ap.eta * qv.y - at;
-    gst[row] = make_double2(g1, g2);
-    acc[0] += g1 * g1; acc[1] += g2 * g2;                               // Gnew (:355-356)
-    const double qi = q[row];
-    const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
-    acc[2] += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
-  }
-}
-
 // STORE (qeq_mode 1): additionally keep the raw row sums (all columns / ghost columns) so that the next gradient and Est
 // follow from  H.(q + l h) = H.q + l H.h  with N-sized vector kernels instead of a second matrix pass.
 // One wavefront = one row (the launch covers the rows exactly), 16 rows per workgroup: workgroup dispatch is not free at a million
@@ -100,8 +65,14 @@ __device__ inline void row_epilogue(int row, double as, double at, double gs_, d
 // length, (b) four batches of 64 entries are in flight instead of eight, which brings the kernel from 99 to <= 80 VGPRs and from
 // 4 to 6 wavefronts per SIMD (measured on one box: 1.276 ms -> 1.21 with (a), 1.157 with (b), 1.06-1.12 with both), (c) PQEq is
 // a template parameter so that the plain kernel does not carry its code.
-template <int MODE, bool STORE, bool PQ>
-__global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
+// IDX16: the column stream is the 16-bit one of k_list10 (stencil column << 11 | ghost << 10 | offset in the column's run) and the 25 run
+// starts of the row sit in the lanes of ONE register (rowhdr, a coalesced 128-byte load next to the row length): a column index is
+// a cross-lane read (ds_bpermute) plus an add -- 10 instead of 12 bytes of HBM per entry.
+// SPEC: the first 256 entries of the two streams are requested BEFORE the row length is known (they lie inside the row's S10-entry slot
+// whatever the length; entries behind the row's end get weight 0 once it has arrived): one dependent round trip less per wavefront.
+template <int MODE, bool STORE, bool PQ, bool IDX16, bool SPEC>
+__global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const unsigned short *__restrict__ nb16, const int *__restrict__ rowhdr,
+                                               const double *__restrict__ hess, const int *__restrict__ n10,
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
                                                const double *__restrict__ scal, double *__restrict__ partials,
@@ -118,30 +89,52 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
   const int row = rowlist ? (widx < nrows ? rowlist[widx] : N) : widx;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (row < N) {
+    const size_t base = static_cast<size_t>(row) * S10;
+    unsigned e0[UNR];
+    double h0[UNR];
+    if (SPEC) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int k = lane + 64 * u;
+        const bool ok = k < S10;
+        if (IDX16) e0[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb16 + base + k)) : 0u;
+        else e0[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;
+        h0[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;
+      }
+    }
     const int n = n10[row];
+    const int hdr = IDX16 ? rowhdr[static_cast<size_t>(row) * 32 + (lane & 31)] : 0;
     // operands of the row tail, requested before the streams so that they are not a further dependent round trip after the reduction
     const int pf_t = type[row];
     const double2 pf_a = (MODE == MODE_HSH) ? hst[row] : qst[row];
     const double2 pf_b = (MODE == MODE_HSH) ? gst[row] : make_double2(q[row], 0.0);
     const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
-    const size_t base = static_cast<size_t>(row) * S10;
     double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    for (int k0 = lane; k0 < n; k0 += 64 * UNR) {
+    for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count: every lane stays in the loop (the cross-lane read of IDX16 needs its source lanes alive)
+      const int k0 = kb + lane;
       unsigned e[UNR];
       double h[UNR];
+      if (SPEC && kb == 0) {
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {            // the two coalesced streams of the row: issue every load first
-        const int k = k0 + 64 * u;
-        const bool ok = k < n;
-        e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;   // streamed once: keep it out of
-        h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;                        // the caches that hold the vector
+        for (int u = 0; u < UNR; ++u) { const bool ok = k0 + 64 * u < n; e[u] = ok ? e0[u] : 0u; h[u] = ok ? h0[u] : 0.0; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {            // the two coalesced streams of the row: issue every load first
+          const int k = k0 + 64 * u;
+          const bool ok = k < n;
+          if (IDX16) e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb16 + base + k)) : 0u;
+          else e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;   // streamed once: keep it out of
+          h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;                             // the caches that hold the vector
+        }
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
-        const double2 v = xv[e[u] & NB10_IDX_MASK];
+        const unsigned col = IDX16 ? static_cast<unsigned>(__shfl(hdr, static_cast<int>(e[u] >> 11), 64)) + (e[u] & 1023u) : (e[u] & NB10_IDX_MASK);
+        const bool ghost = IDX16 ? (e[u] & 1024u) != 0u : (e[u] & NB10_GHOST) != 0u;
+        const double2 v = xv[col];
         as += h[u] * v.x;
         at += h[u] * v.y;
-        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
+        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = ghost ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
         if ((MODE == MODE_GRAD || STORE) && PQ) {      // PQEq: second matrix (shell-core) over the same columns
           const int k = k0 + 64 * u;
           const double c = (k < n) ? __builtin_nontemporal_load(hsc + base + k) : 0.0;
@@ -172,95 +165,6 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
     }
   }
   block_store_partials<4>(acc, partials + static_cast<size_t>(pbase) * 4, 4);
-}
-
-// ---- cell-tiled matrix pass ------------------------------------------------------------------------------------
-// One workgroup per cell of the engine's grid.  Every row of the cell draws its partners from the same 5x5x5-cell
-// neighbourhood = 25 contiguous runs of the cell-sorted vector copy, so the workgroup stages that neighbourhood of (xs,xt)
-// in LDS once (coalesced, ~26 KB for RDX) and the per-entry gathers become ds_read_b128.  The list names a partner by its
-// position inside the neighbourhood (lists.hip, nb10s: 15 bits + ghost flag), which halves the index stream: a row entry
-// costs 8 + 2 bytes of HBM instead of 8 + 4 and no L1 gather.
-constexpr int UNRC = 4;   // 4 x 64 lanes x 2 entries = 512 entries in flight per wavefront
-template <int MODE, bool STORE>
-__global__ void __launch_bounds__(1024) k_spmv_cell(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellstart, const int *__restrict__ perm,
-                                                    const unsigned short *__restrict__ nb10s, const double *__restrict__ hess, const int *__restrict__ n10,
-                                                    const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
-                                                    const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
-                                                    const double *__restrict__ scal, double *__restrict__ partials,
-                                                    double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh) {
-  extern __shared__ double2 xl[];
-  __shared__ int s_k0[25], s_len[25], s_off[26];
-  __shared__ int s_any;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-  const int c = blockIdx.x;
-  const int r0 = cellstart[c], r1 = cellstart[c + 1];
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (threadIdx.x == 0) s_any = 0;
-  __syncthreads();
-  for (int k = r0 + threadIdx.x; k < r1; k += blockDim.x)
-    if (perm[k] < N) s_any = 1;
-  if (threadIdx.x < 25) {       // the stencil columns in the order k_list10 swept them
-    const int cz = c % g.n[2], cy = (c / g.n[2]) % g.n[1], cx = c / (g.n[2] * g.n[1]);
-    const int x2 = cx + threadIdx.x / 5 - 2, y2 = cy + threadIdx.x % 5 - 2;
-    int k0 = 0, len = 0;
-    if (x2 >= 0 && x2 < g.n[0] && y2 >= 0 && y2 < g.n[1]) {
-      const int cb = (x2 * g.n[1] + y2) * g.n[2];
-      k0 = cellstart[cb + max(cz - 2, 0)];
-      len = cellstart[cb + min(cz + 2, g.n[2] - 1) + 1] - k0;
-    }
-    s_k0[threadIdx.x] = k0; s_len[threadIdx.x] = len;
-  }
-  __syncthreads();
-  if (!s_any) {                 // a cell of the ghost shell: nothing to do
-    if (threadIdx.x < 4) __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * 4 + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  if (threadIdx.x == 0) {
-    int o = 0;
-    for (int t = 0; t < 25; ++t) { s_off[t] = o; o += s_len[t]; }
-    s_off[25] = o;
-  }
-  __syncthreads();
-  for (int col = w; col < 25; col += nwv) {     // a wavefront per column: coalesced 16-byte loads
-    const int k0 = s_k0[col], len = s_len[col], o = s_off[col];
-    for (int t = lane; t < len; t += 64) xl[o + t] = xv[k0 + t];
-  }
-  __syncthreads();
-  const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
-  for (int k = r0 + w; k < r1; k += nwv) {
-    const int row = perm[k];
-    if (row >= N) continue;
-    const int npair = (n10[row] + 3) >> 2 << 1;                     // rows are zero-padded to a multiple of 4 entries
-    const size_t base = static_cast<size_t>(row) * S10;
-    const unsigned *ep = reinterpret_cast<const unsigned *>(nb10s + base);
-    const f64x2 *hp = reinterpret_cast<const f64x2 *>(hess + base);
-    double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    for (int p0 = lane; p0 < npair; p0 += 64 * UNRC) {
-      unsigned e[UNRC];
-      f64x2 h[UNRC];
-#pragma unroll
-      for (int u = 0; u < UNRC; ++u) {
-        const int p = p0 + 64 * u;
-        const bool ok = p < npair;
-        e[u] = ok ? __builtin_nontemporal_load(ep + p) : 0u;
-        h[u] = ok ? __builtin_nontemporal_load(hp + p) : f64x2{0.0, 0.0};
-      }
-#pragma unroll
-      for (int u = 0; u < UNRC; ++u) {
-        const double2 v0 = xl[e[u] & 0x7fffu], v1 = xl[(e[u] >> 16) & 0x7fffu];
-        as += h[u].x * v0.x; at += h[u].x * v0.y;
-        as += h[u].y * v1.x; at += h[u].y * v1.y;
-        if (MODE == MODE_GRAD || STORE) {
-          if (e[u] & 0x8000u) { gs_ += h[u].x * v0.x; gt_ += h[u].x * v0.y; }
-          if (e[u] & 0x80000000u) { gs_ += h[u].y * v1.x; gt_ += h[u].y * v1.y; }
-        }
-      }
-    }
-    as = wave_sum(as); at = wave_sum(at);
-    if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-    if (lane == 0) row_epilogue<MODE, STORE>(row, as, at, gs_, gt_, mu, ff, hst, gst, qst, q, type, rs_all, rs_gh, acc, nullptr);
-  }
-  block_store_partials<4>(acc, partials, 4);
 }
 
 // bandwidth probe (debug tap 100): plain 16-byte-per-lane grid-stride read of the matrix value array; gives the
@@ -548,35 +452,25 @@ void Engine::qeq() {
   constexpr int SPMV_WPB = 16;                   // wavefronts (= rows) per workgroup of the matrix pass
   const int rb = nblk(N, SPMV_WPB);
   const int vb = std::min(nblk(N, 256), 2048);
-  // cell-tiled pass (k_spmv_cell) whenever the neighbourhood of a cell fits the 15-bit local index and the LDS stage
-  const size_t lds_bytes = (static_cast<size_t>(nbhd_max) + 64) / 64 * 64 * sizeof(double2);
-  // (opt-in: measured 1.21 ms against 1.13 ms per pass for the row kernel at 979,776 rows, see DESIGN.md "matrix pass variants")
-  const bool use_cell = spmv_cell && !ff.pqeq && nbhd_max > 0 && nbhd_max < 32768 && lds_bytes <= 128 * 1024 &&
-                        static_cast<size_t>(std::max(rb, grid.ncell)) * 4 + 1024 <= partials_cap;
-  if (use_cell && lds_bytes > 48 * 1024 && !cell_attr_set) {
-    const int lim = 128 * 1024;
-    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_cell<MODE_HSH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_cell<MODE_HSH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_cell<MODE_GRAD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_cell<MODE_GRAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    cell_attr_set = true;
-  }
-  const int cell_bs = 512;
-  const int nred = use_cell ? grid.ncell : rb;                                      // partials one matrix pass leaves
+  const int nred = rb;                                                             // partials one matrix pass leaves
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
+  static const bool spec = (std::getenv("RXMD_SPMV_SPEC") != nullptr);
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) {
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return;
-#define RX_PASS(M, S)                                                                                                                        \
-  do {                                                                                                                                       \
-    if (use_cell) k_spmv_cell<M, S><<<grid.ncell, cell_bs, lds_bytes, stream>>>(N, S10, grid, dff, cellstart, perm, nb10s, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg); \
-    else if (ff.pqeq) k_spmv<M, S, true><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase);  \
-    else k_spmv<M, S, false><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase);  \
+#define RX_PASS4(M, S, P, I, SP) k_spmv<M, S, P, I, SP><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, nb16, rowhdr, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase)
+#define RX_PASS3(M, S, P, I) do { if (spec) RX_PASS4(M, S, P, I, true); else RX_PASS4(M, S, P, I, false); } while (0)
+#define RX_PASS(M, S)                                                                                                  \
+  do {                                                                                                                 \
+    if (ff.pqeq) { if (idx16_on) RX_PASS3(M, S, true, true); else RX_PASS3(M, S, true, false); }                        \
+    else { if (idx16_on) RX_PASS3(M, S, false, true); else RX_PASS3(M, S, false, false); }                              \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }
 #undef RX_PASS
+#undef RX_PASS3
+#undef RX_PASS4
   };
   auto reduce = [&](int stage, int nb_) {
     if (!multi()) {                              // single rank: level-1 sums, final sum and scalar algebra in one launch
@@ -608,7 +502,7 @@ void Engine::qeq() {
   bool xs_current = false;       // the fused direction kernel leaves the sorted copy of the new (hs,ht) in xs
   const bool overlap_on = (std::getenv("RXMD_NO_HALO_OVERLAP") == nullptr);     // read per call: the tests switch it
   const bool est_with_update = (std::getenv("RXMD_EST_SEPARATE") == nullptr);
-  const bool overlap = overlap_on && multi() && onepass && !use_cell && !rows_split_pending_invalid();
+  const bool overlap = overlap_on && multi() && onepass && !rows_split_pending_invalid();
   bool halo_in_flight = false;
   for (it = 0; it <= nmax - 1; ++it) {
     if (0.5 * (std::fabs(GEst2) + std::fabs(Est)) < cfg.QEq_tol) break;                          // qeq.F90:114

@@ -48,6 +48,41 @@ def real_to_fractional(src, dst):
     open(dst, "w").write("\n".join(out) + "\n")
 
 
+def sic_fragment_fractional(path, box=40.0, radius=5.8):
+    """An isolated cluster cut out of conf/init.sicnp (SiC nanoparticle in O2): the atoms within `radius` of the midpoint between one
+    O atom and its nearest nanoparticle atom, O2 molecules kept whole -- the candidate whose cluster has a diameter below 11.8 A
+    (under the 12.5 A PQEq cut-off minus every shell displacement) and the most O atoms: 8 Si + 8 C + 5 O2 = 26 atoms, diameter
+    11.1 A.  Centred in a cubic box of 40 A, so that no pair -- core or shell, own image or neighbour image -- lies anywhere near
+    the cut-off: the reference's beyond-cut-off table look-ups (module.F90:401, which leave stale values behind) cannot occur,
+    and the trajectory of the reference is a clean PQEq trajectory."""
+    lines = open(os.path.join(INP, "sicnp.xyz")).read().split("\n")
+    n = int(lines[0].split()[0]); lat = [float(x) for x in lines[1].split()[:6]]
+    names = np.array([l.split()[0] for l in lines[2:2 + n]])
+    pos = np.array([[float(t) for t in l.split()[1:4]] for l in lines[2:2 + n]]) * np.array(lat[:3])
+    O = np.where(names == "O")[0]; NPa = np.where(names != "O")[0]
+    D = np.linalg.norm(pos[O][:, None] - pos[NPa][None], axis=2)
+    best = None
+    for oi in np.argsort(D.min(1), kind="stable")[:40]:
+        c = 0.5 * (pos[O[oi]] + pos[NPa[np.argmin(D[oi])]])
+        keep = set(np.where(np.linalg.norm(pos - c, axis=1) < radius)[0])
+        for i in list(keep):
+            if names[i] == "O":
+                dd = np.linalg.norm(pos[O] - pos[i], axis=1); o2 = np.argsort(dd, kind="stable")
+                if dd[o2[1]] < 1.5:
+                    keep.add(O[o2[1]])
+        idx = np.array(sorted(keep)); P = pos[idx]
+        diam = np.linalg.norm(P[:, None] - P[None], axis=2).max()
+        nO = int((names[idx] == "O").sum()); nSi = int((names[idx] == "Si").sum())
+        if diam < 11.8 and nO >= 4 and nSi >= 8 and (best is None or (nO, len(idx)) > best[0]):
+            best = ((nO, len(idx)), idx, diam)
+    idx = best[1]; P = pos[idx] - 0.5 * (pos[idx].min(0) + pos[idx].max(0)) + 0.5 * box
+    out = ["%d \"SiC fragment + O2 cut from conf/init.sicnp\"" % len(idx), "%.3f %.3f %.3f 90.000 90.000 90.000" % (box, box, box)]
+    for e, r in zip(names[idx], P / box):
+        out.append("%s %.12f %.12f %.12f" % (e, r[0], r[1], r[2]))
+    open(path, "w").write("\n".join(out) + "\n")
+    return len(idx), best[2]
+
+
 CASES = {
     # name: (xyz, ffield, mc, extra rxmd flags, nsteps for the dump run)
     "rdx168_tol7":   ("rdx.xyz", "ffield_rdx", (1, 1, 1), [], 0),
@@ -67,6 +102,9 @@ CASES = {
     "sicnp547_pqeq_efieldx_0": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 1 0.05"], 0),
     "sicnp547_pqeq_efieldx_md3": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 1 0.05"], 3),
     "sicnp547_pqeq_efield_md3": ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 3 0.05"], 3),
+    # PQEq MD on an isolated cluster in a 40 A box (sic_fragment_fractional above): no beyond-cut-off look-up can happen, the reference's
+    # own trajectory is the clean one -- 8 steps with the field along x, shells moving
+    "sicfrag26_pqeq_efieldx_md8": ("SICFRAG", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 1 0.05"], 8),
     # low-gradient dispersion correction (--lg: five-line atom blocks and a C_lg column in the ffield, param.F90:83-86,107-109,197-200;
     # table terms init.F90:496-514); conf/init.rdx.lg/{input.xyz,ffield}
     "rdx168_lg_tight": ("rdx_lg.xyz", "ffield_rdx_lg", (1, 1, 1), ["--lg", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
@@ -175,6 +213,8 @@ def make(name):
         os.makedirs(os.path.join(tmp, "DAT"))
         if xyz == "ICE":
             perturbed_ice_fractional(os.path.join(tmp, "input.xyz"))
+        elif xyz == "SICFRAG":
+            print("SiC fragment:", sic_fragment_fractional(os.path.join(tmp, "input.xyz")))
         elif xyz == "PBT":
             real_to_fractional(os.path.join(INP, "conf", "PBT_real.xyz"), os.path.join(tmp, "input.xyz"))
         else:
@@ -214,9 +254,9 @@ def make(name):
         outB = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(max(nsteps, 1)), "--pstep", "1",
                     "--fstep", "100000"] + flags, tmp)
         d["mdstep"] = parse_mdstep(outB)
-        if name.startswith("ice") or name.startswith("pbt"):
+        if name.startswith("ice") or name.startswith("pbt") or name.startswith("sicfrag"):
             d["input_xyz"] = np.array(open(os.path.join(tmp, "input.xyz")).read())
-        if name in ("rdx168_md10", "sicnp547_pqeq_md5"):
+        if name in ("rdx168_md10", "sicnp547_pqeq_md5", "sicfrag26_pqeq_efieldx_md8"):
             # the reference's own trajectory frame of the last step (OUTPUT -> WriteXYZ, fileio.F90:241-355): output data, kept as text
             outC = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(nsteps), "--pstep", "1", "--fstep", str(nsteps)] + flags, tmp)
             d["xyz_last"] = np.array(open(os.path.join(tmp, "DAT", "%09d.xyz" % nsteps)).read())

@@ -250,6 +250,10 @@ def make_system(case):
         ff = os.path.join(INP, "ffield_water")
         g = np.load(os.path.join(GOLD, "ice644_tight.npz"))
         names, frac, lat = read_xyz(str(g["input_xyz"]))
+    elif case.startswith("sicfrag"):               # the isolated SiC + O2 cluster in a 40 A box (make_golden.sic_fragment_fractional); input travels in the fixture
+        ff = os.path.join(INP, "ffield_sicnp")
+        g = np.load(os.path.join(GOLD, "sicfrag26_pqeq_efieldx_md8.npz"))
+        names, frac, lat = read_xyz(str(g["input_xyz"]))
     elif case.startswith("sicnp"):
         ff = os.path.join(INP, "ffield_sicnp")
         names, frac, lat = read_xyz(os.path.join(INP, "sicnp.xyz"))

@@ -191,3 +191,51 @@ def test_reference_example_workflows_on_the_hip_library(ex, extra):
             assert ds[len(ds) // 2] <= 5e-4 and ds[-1] <= 2.5e-3
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_reference_mpi_driver_two_ranks_on_the_hip_library():
+    """The reference's examples/2-reaxff-dc as shipped (`geninit -mc 4 3 5 -v 2 1 1`, `mpirun -np 2 rxmd`) with the reference's own
+    MPI driver on librxmd_hip.so (oracle/_ref/rxmd_hipdrv_mpi): its COPYATOMS(MODE_MOVE) migrates over MPI, every QEq / FORCE call
+    goes to one engine per rank, and the engines' six-stage exchange and CG all-reduces travel through the MPI_SENDRECV /
+    MPI_ALLREDUCE callbacks that bindings/rxmd_hip_mod.F90 installs (both ranks share the one GPU of this box, so the host-staged
+    transport is the one exercised; with one GPU per rank the same binding hands the engines an RCCL id over MPI_BCAST).
+    3 MD steps at tight tolerance against the real-MPI reference run of the same example: MDstep lines and the trajectory frame."""
+    drv, gen = os.path.join(REF, "rxmd_hipdrv_mpi"), os.path.join(REF, "geninit")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(drv) and os.path.exists(gen)):
+        pytest.skip("oracle/_ref/rxmd_hipdrv_mpi was not built (needs the reference sources + amdflang + MPICH: make -C oracle ref)")
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec on this box")
+    g = np.load(os.path.join(oa.GOLD, "example2_v211_md3.npz"))
+    tmp = tempfile.mkdtemp(prefix="dropin_mpi_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(oa.INP, "example1", "pe_cell.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(oa.INP, "example1", "ffield_pe"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(oa.INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "4", "3", "5", "-v", "2", "1", "1"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        env = dict(os.environ, RXMD_HIP_TRANSPORT="mpi")
+        p = subprocess.run([mpiexec, "-np", "2", drv, "--ntime_step", "3", "--pstep", "1", "--fstep", "3", "--vprocs", "2", "1", "1",
+                            "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert "successfully finished" in p.stdout, p.stdout[-3000:]
+        assert "host-staged MPI transport over    2 ranks" in p.stdout
+        rows = np.array([[float(x) for x in l.split()[1:13]] for l in p.stdout.split("\n") if l.startswith("MDstep:")])
+        ref = g["mdstep"][:len(rows), :12]
+        assert len(rows) == 3
+        assert np.allclose(rows[:, 1:3], ref[:, 1:3], rtol=2e-6)                     # total / potential energy per atom, es13.5
+        assert np.allclose(rows[:, 4:10], ref[:, 4:10], rtol=2e-3, atol=1e-6)        # the six energy groups, es11.3
+        # the frame both ranks wrote after the third step against the per-rank dumps of the MPI reference
+        gid = np.concatenate([g["gid_0"], g["gid_1"]]); pos = np.concatenate([g["pos_0"], g["pos_1"]]); chg = np.concatenate([g["charge_0"], g["charge_1"]])
+        want = {int(i): (x, c) for i, x, c in zip(gid, pos, chg)}
+        lines = open(os.path.join(tmp, "DAT", "000000003.xyz")).read().split("\n")
+        assert int(lines[0].split()[0]) == len(gid)
+        seen = 0
+        for l in lines[2:]:
+            if not l.strip():
+                continue
+            x = np.array([float(t) for t in l[3:39].split()]); q = float(l[39:47]); i = int(l[47:].split()[0])
+            assert np.abs(x - want[i][0]).max() <= 2.1e-5 and abs(q - want[i][1]) <= 1.1e-3
+            seen += 1
+        assert seen == len(gid)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -1,0 +1,66 @@
+"""Output path FROM HIP STATE: trajectory frames and checkpoints written by the engine, against the files the
+unmodified reference wrote for the same runs (WriteXYZ src/fileio.F90:241-355, WriteBIN src/fileio.F90:558-653)."""
+import os
+import numpy as np
+import pytest
+
+import oracle_api as oa
+from test_gpu_parity import _engine
+
+pytestmark = pytest.mark.gpu
+
+
+def test_xyz_frame_written_from_engine_state_is_the_references_file(tmp_path):
+    """10 MD steps of RDX-168 at the default settings (QEq_tol 1e-7), then RxmdEngine.write_xyz: header lines byte for byte, every atom line
+    the same element and global id at the same columns, positions to the last printed digit (f12.5), charges to the last printed
+    digit (f8.3; the CG exit noise of tol 1e-7 is two orders below it) -- and nearly all lines identical as bytes."""
+    g = np.load(os.path.join(oa.GOLD, "rdx168_md10.npz"))
+    e = _engine("rdx168", (1, 1, 1))
+    e.QEq(); e.FORCE(); e.step(10)
+    path = tmp_path / "000000010.xyz"
+    e.write_xyz(str(path))
+    e.close()
+    mine = open(path).read().split("\n"); theirs = str(g["xyz_last"]).split("\n")
+    assert mine[:2] == theirs[:2] and len(mine) == len(theirs) and mine[-1] == theirs[-1] == ""
+    same = 0
+    for a, b in zip(mine[2:-1], theirs[2:-1]):
+        assert len(a) == len(b) == 56 and a[:3] == b[:3] and a[47:] == b[47:]
+        assert np.abs(np.array([float(x) for x in a[3:39].split()]) - np.array([float(x) for x in b[3:39].split()])).max() <= 1.01e-5
+        assert abs(float(a[39:47]) - float(b[39:47])) <= 1.01e-3
+        same += a == b
+    assert same >= 0.97 * (len(mine) - 3), same
+
+
+@pytest.mark.parametrize("mode,kw", [(4, dict(vsfact=0.9)), (5, dict(treq=300.0)), (7, dict(treq=300.0)), (8, dict(treq=300.0))])
+def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, tmp_path):
+    """Continue the reference's own restart file (rxff.bin after 20 NVE steps) for 7 steps with velocity scaling every 3rd step, then
+    RxmdEngine.write_rxff: the header as bytes (process grid, atom count, step counter 27, lattice), and every record field against
+    the rxff.bin the reference wrote at the end of the same run -- normalised positions, velocities, charge, packed type+id, and the
+    fictitious charges qsfp / qsfv that main.F90:67-68,98 integrates in every mode."""
+    import rxmd_amd
+    g = np.load(os.path.join(oa.GOLD, "rdx168_thermo%d.npz" % mode))
+    ff = oa.make_system("rdx168")[0]
+    lat, vp, step0, recs = oa.parse_rxff(g["restart_rxff"])
+    e = rxmd_amd.RxmdEngine(ff, lat, QEq_tol=1e-12, NMAXQEq=2000)
+    e.set_atoms_rxff(recs[0])
+    e.QEq(); e.FORCE()
+    for nstep in range(7):
+        if nstep % 3 == 0:
+            e.thermostat(mode, **kw)
+        e.step(1)
+    path = tmp_path / "rxff.bin"
+    e.write_rxff(str(path), current_step=step0 + 7)
+    e.close()
+    mine = open(path, "rb").read(); theirs = bytes(g["final_rxff"])
+    nhead = 4 * (4 + 1 + 1) + 48
+    assert len(mine) == len(theirs) and mine[:nhead] == theirs[:nhead]
+    _, _, s1, r1 = oa.parse_rxff(np.frombuffer(mine, np.uint8)); _, _, s2, r2 = oa.parse_rxff(g["final_rxff"])
+    assert s1 == s2 == 27
+    a, b = r1[0], r2[0]
+    assert np.array_equal(a[:, 7], b[:, 7])                                   # type + gid * 1e-13, same local order
+    assert np.abs(a[:, 0:3] - b[:, 0:3]).max() <= 1e-10                       # normalised positions (1e-9 A)
+    assert np.abs(a[:, 3:6] - b[:, 3:6]).max() <= 1e-8 * np.abs(b[:, 3:6]).max()
+    qrms = np.sqrt((b[:, 6] ** 2).mean())
+    assert (np.abs(a[:, 6] - b[:, 6]) / np.maximum(np.abs(b[:, 6]), qrms)).max() <= 1e-6
+    assert (np.abs(a[:, 8] - b[:, 8]) / np.maximum(np.abs(b[:, 8]), qrms)).max() <= 1e-6
+    assert np.abs(a[:, 9] - b[:, 9]).max() <= 1e-6 * np.abs(b[:, 9]).max()

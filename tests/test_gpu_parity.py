@@ -352,14 +352,18 @@ def test_one_pass_qeq_mode_reaches_the_same_fixed_point(case, mc):
 
 
 @pytest.mark.parametrize("qeq_mode", [0, 1])
-def test_cell_tiled_matrix_pass_is_the_same_operator(qeq_mode, monkeypatch):
-    """RXMD_SPMV_CELL=1 switches the QEq matrix pass to the LDS-staged, 16-bit-index kernel (k_spmv_cell): another
-    summation order of the same rows, so the tight-tolerance fixed point must not move."""
-    monkeypatch.setenv("RXMD_SPMV_CELL", "1")
+@pytest.mark.parametrize("switch", ["RXMD_SPMV_IDX32", "RXMD_LIST_NO_FP32"])
+def test_list_and_matrix_pass_variants_are_the_same_operator(qeq_mode, switch, monkeypatch):
+    """The defaults -- 16-bit column stream of the QEq matrix pass (stencil column + offset, 10 bytes per entry) and the FP32 first
+    distance test of the 10 A sweep -- against their plain forms (32-bit entries; every candidate tested in FP64): the same pair set
+    (row lengths, hessian row sums) and the same tight-tolerance fixed point as the oracle."""
+    monkeypatch.setenv(switch, "1")
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
     o = _oracle("rdx222", (2, 2, 2), **kw); o.qeq(); o.force()
     e = _engine("rdx222", (2, 2, 2), qeq_mode=qeq_mode, **kw)
     it, est = e.QEq(); pe = e.FORCE(); a = e.atoms()
+    assert (e.debug(6).astype(int) == o.get(104).astype(int)).all()
+    assert np.allclose(e.debug(7), o.get(108), rtol=1e-12)
     assert q_err(a["q"], o.charges()) <= QTOL
     assert f_err(a["f"], o.forces()) <= FTOL
     assert abs(est - o.trace()[-1, 0]) <= 1e-9 * abs(est)
@@ -412,6 +416,31 @@ def test_pqeq_md_against_the_clean_oracle():
     # (2e-8 A apart, above): gate every term on the scale of the total energy instead of its own
     pe_e, pe_o = e.energy()["PE"], o.energy()
     assert np.abs(pe_e - pe_o).max() <= 1e-9 * abs(pe_o[0])
+    e.close()
+
+
+@pytest.mark.parametrize("qeq_mode", [0, 1])
+def test_pqeq_md_against_the_reference_on_a_cluster_without_stale_lookups(qeq_mode):
+    """PQEq MD against the REFERENCE ITSELF (not the oracle's clean switch): the isolated SiC + O2 cluster of
+    tests/golden/sicfrag26_pqeq_efieldx_md8.npz (26 atoms, diameter 11.1 A, 40 A box) has no pair near the 12.5 A cut-off, so the
+    reference's beyond-cut-off artefact (module.F90:401) cannot occur -- tests/test_oracle_golden.py asserts pqeq_stale() == 0 on it --
+    and its 8-step trajectory with the field along x and moving shells is what a clean PQEq gives.  Charges, forces <= 1e-6 of the
+    reference's dump, shell displacements against its trajectory frame."""
+    g = np.load(os.path.join(oa.GOLD, "sicfrag26_pqeq_efieldx_md8.npz"))
+    e = _engine("sicfrag", (1, 1, 1), pqeq=oa.PQEQ_SICNP, efield=(1, 0.05), QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=qeq_mode)
+    e.QEq(); e.FORCE(); e.step(8)
+    a = e.atoms()
+    o = np.argsort(a["gid"]); go = np.argsort(g["gid"])
+    assert (a["gid"][o] == g["gid"][go]).all()
+    assert np.abs(a["pos"][o] - g["pos"][go]).max() <= 1e-9
+    assert q_err(a["q"][o], g["charge"][go]) <= QTOL
+    assert f_err(a["f"][o], g["force"][go]) <= FTOL
+    t = str(g["xyz_last"]).split("\n")[2:-1]                    # WriteXYZ with PQEq (fileio.F90:241-355): ..., global id i9, shell displacement 3es20.12
+    ids = np.array([int(l[83:92]) for l in t]); sp = np.array([[float(x) for x in l[92:].split()] for l in t])
+    so = np.argsort(ids)
+    assert (ids[so] == a["gid"][o]).all()
+    assert np.linalg.norm(sp, axis=1).max() > 1e-3               # the shells have moved
+    assert np.abs(e.shells()[o] - sp[so]).max() <= 1e-8          # clipped 1e-3 A moves along (force / K): follows the charges' 1e-7 relative CG noise
     e.close()
 
 

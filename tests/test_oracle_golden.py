@@ -201,6 +201,45 @@ def test_pqeq_with_electric_field():
     _compare(g, o, ftol=1e-9, qtol=1e-10)
 
 
+def _pqeq_frame(txt):
+    """PQEq trajectory frame (WriteXYZ, fileio.F90:241-355): per atom position 3es20.12, charge es20.12, global id i9, shell displacement 3es20.12"""
+    t = str(txt).split("\n")[2:-1]
+    val = np.array([[float(x) for x in l[3:83].split()] + [float(x) for x in l[92:].split()] for l in t])
+    ids = np.array([int(l[83:92]) for l in t])
+    o = np.argsort(ids)
+    return ids[o], val[o, :3], val[o, 3], val[o, 4:]
+
+
+def test_pqeq_md_on_an_isolated_cluster_has_no_stale_lookup_and_matches_the_reference():
+    """PQEq MD pinned to the reference WITHOUT the stale-value artefact: an isolated 26-atom SiC + O2 cluster (diameter 11.1 A) in a
+    40 A box has no pair anywhere near the 12.5 A cut-off, so no core-shell / shell-shell look-up can fall outside it
+    (pqeq_stale() == 0 in faithful mode) and the reference's own 8-step trajectory (field along x, shells moving) is the clean one.
+    Both oracle modes must therefore give the SAME numbers, and both must be the reference's: positions, charges, forces of its
+    dump and the shell displacements of its frame."""
+    g = np.load(os.path.join(GOLD, "sicfrag26_pqeq_efieldx_md8.npz"))
+    ff, names, frac, lat = oa.make_system("sicfrag")
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff))
+    ids, xpos, xq, xsp = _pqeq_frame(g["xyz_last"])
+    res = []
+    for clean in (0, 1):
+        o = oa.Oracle(ff, lat2, ranks, pqeq=oa.PQEQ_SICNP, QEq_tol=1e-12, NMAXQEq=2000)
+        o.set_efield(1, 0.05); o.set_pqeq_clean(clean)
+        iters = [o.qeq()]; o.force()
+        for _ in range(8):
+            o.step(1); iters.append(o.L.rxo_qeq_iters(o.w))
+        assert o.pqeq_stale() == 0
+        assert iters == [int(x) for x in g["qeq_iters"]]
+        _compare(g, o, ftol=1e-9, qtol=1e-10)
+        order = np.argsort(o.gids())
+        assert (o.gids()[order] == ids).all()
+        assert np.abs(o.spos()[order] - xsp).max() <= 1e-12
+        assert np.abs(o.charges()[order] - xq).max() <= 1e-11
+        assert np.linalg.norm(xsp, axis=1).max() > 1e-3          # the shells did move (8 clipped 1e-3 A moves at most)
+        res.append((o.charges().copy(), o.forces().copy(), o.spos().copy()))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 def test_low_gradient_dispersion_tables():
     """--lg: the LG ffield format (param.F90:83-86,107-109,197-200) and the table terms of init.F90:496-514, on the reference's own
     conf/init.rdx.lg input; step 0 at the tight tolerance, then the 5-step trajectory with its iteration counts"""
