@@ -247,6 +247,12 @@ def main():
         dt = float(t.item())
     st = eng.stats()
     en = eng.energy()
+    per_rank = None
+    if use_dist:          # every rank's residents, ghosts and CG iterations: a decomposition that silently lost a neighbour shows here
+        mine = torch.tensor([st["natoms"], st["nghost_force"], st["qeq_iters_total"]], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"natoms": [int(t[0]) for t in allr], "nghost": [int(t[1]) for t in allr], "qeq_iters_total": [int(t[2]) for t in allr]}
     probe = None
     if world == 1:                               # plain 16-B/lane read of the matrix value array on this very box: the ceiling the pass is quoted next to
         try:
@@ -323,6 +329,9 @@ def main():
             "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded")},
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
         }
+        if per_rank:
+            out["per_rank"] = per_rank
+            out["config"]["ranks_in_communicator"] = world      # rccl_init checks ncclCommCount against the vprocs grid
         if alt:
             out["alt"] = alt
         if cb:

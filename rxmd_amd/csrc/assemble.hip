@@ -159,7 +159,7 @@ void Engine::force() {
   fold_ghost_forces();
   hipEventRecord(ev[5], stream);
   RX_HIP(hipMemcpyAsync(h_scal + 32, pe_d, sizeof(double) * 16, hipMemcpyDeviceToHost, stream));
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
   pe[0] = 0.0;
   for (int k = 1; k < 14; ++k) { pe[k] = h_scal[32 + k]; pe[0] += pe[k]; }   // PE(0)=sum(PE(1:13)), main.F90:236
   float ms = 0;
@@ -248,7 +248,7 @@ void Engine::thermostat(int mdmode, double treq_K, double vsfact, double gke) {
       k_type_sums<<<nb, 256, 0, stream>>>(N, t, type, dff, vel[0], vel[1], vel[2], partials);
       k_sum6<<<1, 64, 0, stream>>>(nb, partials, scal + 56);
       RX_HIP(hipMemcpyAsync(sums.data() + 6 * t, scal + 56, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipStreamSynchronize(stream));
+      sync_stream();
     }
     if (nprocs > 1) allreduce_host(sums.data(), static_cast<int>(sums.size()));      // MPI_ALLREDUCE, main.F90:699,738,783
   }
@@ -302,7 +302,7 @@ void Engine::remove_momentum() {
     k_type_sums<<<nb, 256, 0, stream>>>(N, t, type, dff, vel[0], vel[1], vel[2], partials);
     k_sum6<<<1, 64, 0, stream>>>(nb, partials, scal + 56);
     RX_HIP(hipMemcpyAsync(sums.data() + 6 * t, scal + 56, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
-    RX_HIP(hipStreamSynchronize(stream));
+    sync_stream();
   }
   if (nprocs > 1) allreduce_host(sums.data(), static_cast<int>(sums.size()));
   double mtot = 0.0, p[3] = {0, 0, 0};
@@ -332,7 +332,7 @@ void Engine::step(int nsteps) {
     k_kick<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], q, qsfp, qsfv);
     ++step_count;
   }
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
 }
 
 }  // namespace rxmd

@@ -219,6 +219,12 @@ struct Engine {
   void rccl_destroy();
   long long rccl_exchange(int to, int from, long long nsend, long long known_nrecv);
   void rccl_allreduce_dev(double *dev, int n);
+  // every host wait of the engine.  With a RCCL communicator attached a wait can depend on a peer that died or went another way (a
+  // rank-local overflow, a mismatch of the exchange pattern): the wait is then a bounded poll -- RXMD_COMM_TIMEOUT_S seconds, default
+  // 300 -- that aborts the communicator and throws RXMD_E_COMM instead of hanging the job.
+  void sync_stream();
+  void sync_event(hipEvent_t e);
+  double comm_timeout_s = 300.0;
   void allreduce_scal4(int n = 4);                 // MPI_ALLREDUCE of scal[S_RAW0..n-1] (qeq.hip)
   void allreduce_host(double *buf, int n);         // the same for a host vector (setup paths)
   void ghost_build_staged();

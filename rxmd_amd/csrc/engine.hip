@@ -121,7 +121,7 @@ void Engine::allreduce_host(double *buf, int n) {
     RX_HIP(hipMemcpyAsync(d, buf, sizeof(double) * n, hipMemcpyHostToDevice, stream));
     rccl_allreduce_dev(d, n);
     RX_HIP(hipMemcpyAsync(buf, d, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
-    RX_HIP(hipStreamSynchronize(stream));
+    sync_stream();
     (void)hipFree(d);
     return;
   }
@@ -131,7 +131,7 @@ void Engine::allreduce_host(double *buf, int n) {
 
 void Engine::check_device_error(const char *where) {
   RX_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int) * 4, hipMemcpyDeviceToHost, stream));
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
   const int e = h_err[0];
   if (e == DERR_NONE) return;
   RX_HIP(hipMemsetAsync(d_err, 0, sizeof(int) * 4, stream));
@@ -386,7 +386,7 @@ int Engine::get_atoms_rxff(double *rec, int capacity) {
   std::vector<double> hx[3], hv[3], hq(N), hp(N), hw(N);
   std::vector<int> ht(N);
   std::vector<long long> hg(N);
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
   for (int a = 0; a < 3; ++a) {
     hx[a].resize(N); hv[a].resize(N);
     RX_HIP(hipMemcpy(hx[a].data(), pos[a], sizeof(double) * N, hipMemcpyDeviceToHost));
@@ -498,7 +498,7 @@ void Engine::ghost_build() {
       int t0 = 0, t1 = 0;
       RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipStreamSynchronize(stream));
+      sync_stream();
       if (static_cast<long long>(copyptr[d0 - 1]) + t0 + t1 > NB || sendoff[d0] + t0 + t1 > NB)
         throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
       sendoff[d0 + 1] = sendoff[d0] + t0; sendoff[d1 + 1] = sendoff[d1] + t1;
@@ -517,7 +517,7 @@ void Engine::ghost_build() {
     RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
     int total = 0;
     RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-    RX_HIP(hipStreamSynchronize(stream));
+    sync_stream();
     if (static_cast<long long>(copyptr[d - 1]) + total > NB || sendoff[d] + total > NB)
       throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
     if (total > 0)
@@ -601,7 +601,7 @@ long long Engine::exchange_stage(int d, bool reverse, long long nsend, long long
   }
   if (nccl) return rccl_exchange(to, from, nsend, known_nrecv);       // native: stays in stream order
   if (!has_comm || !comm.exchange) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
-  RX_HIP(hipStreamSynchronize(stream));                        // the message must be packed before the transport reads it
+  sync_stream();                        // the message must be packed before the transport reads it
   const long long nr = (known_nrecv >= 0 && comm.exchange_known)
                            ? comm.exchange_known(comm.ctx, to, xbuf_send, nsend, from, xbuf_recv, known_nrecv)
                            : comm.exchange(comm.ctx, to, xbuf_send, nsend, from, xbuf_recv, static_cast<long long>(xbuf_doubles));
@@ -632,7 +632,7 @@ void Engine::ghost_build_staged() {
       int t0 = 0, t1 = 0;
       RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipStreamSynchronize(stream));
+      sync_stream();
       if (sendoff[d0] + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
       if (xb_fixed) ensure_xbuf(6 * (static_cast<size_t>(t0) + t1));
       sendoff[d0 + 1] = sendoff[d0] + t0; sendoff[d1 + 1] = sendoff[d1] + t1;
@@ -655,7 +655,7 @@ void Engine::ghost_build_staged() {
     RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
     int total = 0;
     RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-    RX_HIP(hipStreamSynchronize(stream));
+    sync_stream();
     if (sendoff[d] + total > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
     if (xb_fixed) ensure_xbuf(6 * static_cast<size_t>(total));
     if (total > 0)
@@ -688,7 +688,7 @@ void Engine::exchange_pair(int d0, bool reverse, long long n0, long long r0, lon
   }
   if (nccl) { rccl_exchange_pair(to0, from0, n0, r0, to1, from1, n1, r1); return; }
   if (!has_comm || !comm.exchange_known) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
   if (comm.exchange_known(comm.ctx, to0, xbuf_send, n0, from0, xbuf_recv, r0) != r0 ||
       comm.exchange_known(comm.ctx, to1, xbuf_send + n0, n1, from1, xbuf_recv + r0, r1) != r1)
     throw EngineError(RXMD_E_COMM, "halo size changed between the ghost build and a vector exchange");
@@ -706,7 +706,7 @@ void Engine::exchange_pair_sized(int d0, long long n0, long long n1, long long &
   }
   if (nccl) { rccl_exchange_pair_sized(to0, from0, n0, r0, to1, from1, n1, r1); return; }
   if (!has_comm || !comm.exchange) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
   r0 = comm.exchange(comm.ctx, to0, xbuf_send, n0, from0, xbuf_recv, static_cast<long long>(xbuf_doubles));
   if (r0 < 0) throw EngineError(RXMD_E_COMM, "exchange callback failed");
   r1 = comm.exchange(comm.ctx, to1, xbuf_send + n0, n1, from1, xbuf_recv + r0, static_cast<long long>(xbuf_doubles) - r0);
@@ -851,7 +851,7 @@ void Engine::migrate() {
       int t0 = 0, t1 = 0;
       RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipStreamSynchronize(stream));
+      sync_stream();
       ensure_xbuf(static_cast<size_t>(std::max(t0 + t1, 1)) * W + 4096);
       double *b1 = xbuf_send + static_cast<size_t>(W) * t0;
       if (t0 > 0) {
@@ -885,7 +885,7 @@ void Engine::migrate() {
       int t0 = 0, t1 = 0;
       RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipStreamSynchronize(stream));
+      sync_stream();
       if (static_cast<long long>(cp[d0 - 1]) + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
       cp[d0] = cp[d0 - 1] + t0; cp[d1] = cp[d0] + t1;
       if (t0 > 0) {
@@ -907,7 +907,7 @@ void Engine::migrate() {
     RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
     int total = 0;
     RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-    RX_HIP(hipStreamSynchronize(stream));
+    sync_stream();
     if (multi()) {
       const int W = ff.pqeq ? 14 : 11;             // + shell displacement (comm.F90:153,165-167)
       ensure_xbuf(static_cast<size_t>(std::max(total, 1)) * W + 4096);
@@ -941,7 +941,7 @@ void Engine::migrate() {
     size_t tb = cubtmp_bytes;
     RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, n + 1, stream));
     RX_HIP(hipMemcpyAsync(&newN, scanout + n, sizeof(int), hipMemcpyDeviceToHost, stream));
-    RX_HIP(hipStreamSynchronize(stream));
+    sync_stream();
     if (newN > rows10) throw EngineError(RXMD_E_NBUFFER, "resident count grew beyond the 10 A list capacity");
     // scratch: reuse force + bonded scratch arrays as compaction targets (they are recomputed every step)
     double *tmpd[9] = {frc[0], frc[1], frc[2], cds, cd, cc_, deltap, delta, nlp};

@@ -433,7 +433,7 @@ void Engine::allreduce_scal4(int n) {
   if (nccl) { rccl_allreduce_dev(scal + S_RAW0, n); return; }      // in stream order, no host round trip
   if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm or rxmd_hip_comm_init_rccl first");
   RX_HIP(hipMemcpyAsync(h_scal + 48, scal + S_RAW0, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
   if (comm.allreduce_sum(comm.ctx, h_scal + 48, n)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
   RX_HIP(hipMemcpyAsync(scal + S_RAW0, h_scal + 48, sizeof(double) * n, hipMemcpyHostToDevice, stream));
 }
@@ -495,7 +495,7 @@ void Engine::qeq() {
   }
   k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
   double GEst2 = 1e99, Est = h_scal[S_EST];
   int it = 0;
   float ms = 0;
@@ -560,7 +560,7 @@ void Engine::qeq() {
         });
         halo_in_flight = true;
       }
-      RX_HIP(hipEventSynchronize(ev_est));
+      sync_event(ev_est);
       Est = h_scal[S_EST];
       hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
       st.spmv_launches += 1;
@@ -576,7 +576,7 @@ void Engine::qeq() {
     reduce(3, nred);
     k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);
     RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-    RX_HIP(hipStreamSynchronize(stream));
+    sync_stream();
     Est = h_scal[S_EST];
     hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
     hipEventElapsedTime(&ms, ev[4], ev[5]); st.ms_qeq_spmv += ms;

@@ -6,7 +6,10 @@
 // scalars stay in stream order with the kernels that pack, unpack and consume them.
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "engine.h"
 
@@ -30,7 +33,40 @@ void Engine::rccl_init(const unsigned char id128[128], int rank, int world) {
   ncclComm_t c;
   RX_NCCL(ncclCommInitRank(&c, world, id, rank));
   nccl = c;
+  if (const char *t = std::getenv("RXMD_COMM_TIMEOUT_S")) { const double v = std::atof(t); if (v > 0.0) comm_timeout_s = v; }
+  int nr = 0;
+  RX_NCCL(ncclCommCount(c, &nr));
+  if (nr != world) throw EngineError(RXMD_E_COMM, "RCCL communicator has " + std::to_string(nr) + " ranks, expected " + std::to_string(world));
   if (!cnt_dev) { RX_HIP(hipMalloc(reinterpret_cast<void **>(&cnt_dev), 4 * sizeof(double))); RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&cnt_host), 4 * sizeof(double))); }
+}
+
+// bounded wait (see engine.h): `query` polls the stream or the event
+template <class Q>
+static void watched_wait(Engine &e, Q &&query, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  for (;;) {
+    const hipError_t r = query();
+    if (r == hipSuccess) return;
+    if (r != hipErrorNotReady) throw EngineError(RXMD_E_HIP, std::string(what) + ": " + hipGetErrorString(r));
+    if ((++spins & 1023u) == 0u) {
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (waited > e.comm_timeout_s) {
+        if (e.nccl) { (void)ncclCommAbort(C(e.nccl)); e.nccl = nullptr; }
+        throw EngineError(RXMD_E_COMM, "rank " + std::to_string(e.cfg.myid) + ": a wait that depends on the other ranks did not finish within " +
+                                           std::to_string(static_cast<int>(e.comm_timeout_s)) + " s (" + what + "); communicator aborted");
+      }
+      if (waited > 0.01) std::this_thread::sleep_for(std::chrono::microseconds(50));   // long waits stop burning the core
+    }
+  }
+}
+void Engine::sync_stream() {
+  if (!nccl) { RX_HIP(hipStreamSynchronize(stream)); return; }
+  watched_wait(*this, [&] { return hipStreamQuery(stream); }, "stream synchronisation");
+}
+void Engine::sync_event(hipEvent_t ev_) {
+  if (!nccl) { RX_HIP(hipEventSynchronize(ev_)); return; }
+  watched_wait(*this, [&] { return hipEventQuery(ev_); }, "event synchronisation");
 }
 
 void Engine::rccl_destroy() {
@@ -51,7 +87,7 @@ long long Engine::rccl_exchange(int to, int from, long long nsend, long long kno
     RX_NCCL(ncclRecv(cnt_dev + 1, 1, ncclDouble, from, c, stream));
     RX_NCCL(ncclGroupEnd());
     RX_HIP(hipMemcpyAsync(cnt_host + 1, cnt_dev + 1, sizeof(double), hipMemcpyDeviceToHost, stream));
-    RX_HIP(hipStreamSynchronize(stream));
+    sync_stream();
     nrecv = static_cast<long long>(cnt_host[1]);
     if (nrecv > static_cast<long long>(xbuf_doubles)) throw EngineError(RXMD_E_NBUFFER, "incoming message larger than the exchange buffer");
   }
@@ -90,7 +126,7 @@ void Engine::rccl_exchange_pair_sized(int to0, int from0, long long n0, long lon
   RX_NCCL(ncclRecv(cnt_dev + 3, 1, ncclDouble, from1, c, stream));
   RX_NCCL(ncclGroupEnd());
   RX_HIP(hipMemcpyAsync(cnt_host + 2, cnt_dev + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
-  RX_HIP(hipStreamSynchronize(stream));
+  sync_stream();
   r0 = static_cast<long long>(cnt_host[2]); r1 = static_cast<long long>(cnt_host[3]);
   if (r0 + r1 > static_cast<long long>(xbuf_doubles)) throw EngineError(RXMD_E_NBUFFER, "incoming messages larger than the exchange buffer");
   rccl_exchange_pair(to0, from0, n0, r0, to1, from1, n1, r1);

@@ -89,3 +89,35 @@ def engine_rank_empty(rank, world, port, steps, qeq_mode, out):
         dist.barrier(); dist.destroy_process_group()
     except Exception:
         out[rank] = dict(error=traceback.format_exc())
+
+
+def engine_rank_rccl(rank, world, port, case, vp, steps, qeq_mode, out):
+    """one rank of a vprocs run on ITS OWN GPU (device = rank) with the engine's native RCCL transport; gloo only carries the 128-byte id"""
+    try:
+        dist = _init(rank, world, port)
+        import torch
+        import oracle_api as oa
+        import rxmd_amd
+        from rxmd_amd import system
+        g = np.load(os.path.join(oa.GOLD, case + ".npz"))
+        mc = tuple(int(x) for x in g["mc"])
+        ff, names, frac, lat = oa.make_system(case)
+        lat_s, rec = system.geninit(ff, names, frac, lat, mc=mc, vprocs=vp, myid=rank)
+        e = rxmd_amd.RxmdEngine(ff, lat_s, vprocs=vp, myid=rank, QEq_tol=1e-12, NMAXQEq=2000, device=rank, qeq_mode=qeq_mode)
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(e.rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        e.init_rccl(bytes(idt.numpy().tobytes()), rank, world)
+        e.set_atoms_rxff(rec)
+        it, est = e.QEq()
+        pe = e.FORCE()
+        if steps:
+            e.step(steps)
+        a = e.atoms()
+        st = e.stats()
+        out[rank] = dict(gid=a["gid"], q=a["q"], f=a["f"], pos=a["pos"], iters=st["qeq_iters_last"], pe=pe, nghost=st["nghost_force"])
+        e.close()
+        dist.barrier(); dist.destroy_process_group()
+    except Exception:
+        out[rank] = dict(error=traceback.format_exc())
