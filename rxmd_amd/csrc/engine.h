@@ -80,6 +80,8 @@ struct Grid {       // the engine's own cell grid over [-shell, L+shell) in norm
   int fz, nzf;      // slices per cell; n[2] * fz
   int nfine;        // n[0] * n[1] * nzf = length of cellstart - 1
   double wid[3];    // perpendicular real width of one unit of normalised coordinate (orthorhombic: the lattice constant)
+  double cw[3];     // 1 / inv: cell edge in normalised units
+  double iwz;       // 1 / wid[2]
   int ortho;        // 1: the three directions are orthogonal (distance^2 = sum of the three gaps^2), 0: only max(gap) is a bound
 };
 
@@ -144,10 +146,6 @@ struct Engine {
   // 10 A list
   int *nb10 = nullptr, *n10 = nullptr; double *hess = nullptr;
   size_t partials_cap = 0;
-  float4 *sorted_f4 = nullptr;       // cell-sorted (x, y, z, atom index as bits) in FP32: the candidate stream of the 10 A sweep's first test
-  // the matrix pass's own 16-bit column stream (lists.hip, k_list10): entry = stencil column << 11 | ghost << 10 | offset in the column's run,
-  // rowhdr[row * 32 + column] = first sorted position of that run; 10 instead of 12 bytes per matrix entry
-  unsigned short *nb16 = nullptr; int *rowhdr = nullptr; bool idx16_on = false;
   // reductions
   double *partials = nullptr;  // [nblocks_red * 16]
   double *scal = nullptr;      // device scalars (CG state)

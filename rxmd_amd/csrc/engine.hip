@@ -168,7 +168,9 @@ void Engine::setup_after_atoms(const std::vector<long long> &npt) {
     grid.inv[a] = grid.n[a] / wn;
     grid.ncell *= grid.n[a];
     grid.wid[a] = box.lat[a];                                  // orthorhombic: one unit of normalised coordinate = one lattice constant
+    grid.cw[a] = 1.0 / grid.inv[a];
   }
+  grid.iwz = 1.0 / grid.wid[2];
   grid.ortho = 1;
   // z-slices per cell: ~1/8 of a cell (0.6 A at the 5 A cell of a 10 A cutoff); bounded so that the slice ids fit the 31-bit sort key
   grid.fz = 8;
@@ -269,7 +271,7 @@ void Engine::alloc_device() {
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.nfine) + 2);
-  dmalloc(sorted_xyzi, nb); dmalloc(sorted_f4, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
+  dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
   dmalloc(nbr, ns); dmalloc(nbrcnt, nb); dmalloc(nbrindx, ns);
   dmalloc(bo0, ns); dmalloc(bo1, ns); dmalloc(bo2, ns); dmalloc(bo3, ns); dmalloc(dln2, ns); dmalloc(dln3, ns); dmalloc(dBOp, ns);
   dmalloc(A0, ns); dmalloc(A1, ns); dmalloc(A2, ns); dmalloc(A3, ns);
@@ -279,8 +281,6 @@ void Engine::alloc_device() {
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
-  idx16_on = (std::getenv("RXMD_SPMV_IDX32") == nullptr);
-  if (idx16_on) { dmalloc(nb16, static_cast<size_t>(rows10) * S10); dmalloc(rowhdr, static_cast<size_t>(rows10) * 32); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dmalloc(scal, 64);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
@@ -306,7 +306,7 @@ void Engine::free_device() {
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(rows_int); dfree(rows_bnd);
-  dfree(nb10); dfree(sorted_f4); dfree(nb16); dfree(rowhdr); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
+  dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
@@ -991,13 +991,12 @@ __global__ void k_cell_starts(int G, int nfine, const int *__restrict__ cid_sort
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (cid_sorted[mid] < b) lo = mid + 1; else hi = mid; }
   cellstart[b] = lo;
 }
-__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, double4 *out, float4 *out4, int *rootperm) {
+__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, double4 *out, int *rootperm) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= G) return;
   const int i = perm[k];
   const double xi = x[i], yi = y[i], zi = z[i];
   out[k] = make_double4(xi, yi, zi, __longlong_as_double(static_cast<long long>(i)));
-  out4[k] = make_float4(static_cast<float>(xi), static_cast<float>(yi), static_cast<float>(zi), __int_as_float(i));
   rootperm[k] = (i < N) ? i : groot[i];
 }
 // xs[k] = v[owner of the atom at cell-sorted position k]: the ghost refresh (MODE_QCOPY1/2, comm.F90:187-212) and the
@@ -1015,7 +1014,7 @@ void Engine::bin_cells() {
   while ((1LL << bits) < grid.nfine + 1 && bits < 31) ++bits;
   RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, cellid, cellid_sorted, perm_in, perm, G, 0, bits, stream));
   k_cell_starts<<<nblk(grid.nfine + 1, 256), 256, 0, stream>>>(G, grid.nfine, cellid_sorted, cellstart);
-  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, sorted_f4, rootperm);
+  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, rootperm);
   if (ff.pqeq) pqeq_sorted_shells();
 }
 
@@ -1048,13 +1047,11 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     S10 = (static_cast<int>(need * 1.1) + 64 + 63) / 64 * 64;
     const size_t n = static_cast<size_t>(rows10) * S10;
     dfree(nb10); dfree(hess); dmalloc(nb10, n); dmalloc(hess, n);
-    if (nb16) { dfree(nb16); dmalloc(nb16, n); }
     if (ff.pqeq) { dfree(hsc); dmalloc(hsc, n); }
     st.n10_stride = S10;
     build_list10();
     check_device_error("list build");
   }
-  if (idx16_on && h_err[3] != 0) idx16_on = false;   // a stencil column with more than 1024 candidates: the matrix pass keeps the 32-bit entries
   st.ms_lists += toc(0, 1);
   lists_valid = true;
 }

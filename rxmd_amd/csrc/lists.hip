@@ -35,7 +35,7 @@ constexpr double SWEEP_PAD = 1e-6;      // [A] covers the rounding of the normal
 // real-space gap along axis a between normalised coordinate s (an atom of cell c_self) and cell c2
 __device__ inline double axis_gap(const Grid &g, int a, double s, int c_self, int c2) {
   if (c2 == c_self) return 0.0;
-  const double face = g.org[a] + static_cast<double>(c2 > c_self ? c2 : c2 + 1) / g.inv[a];   // the face of c2 that looks at the atom
+  const double face = g.org[a] + static_cast<double>(c2 > c_self ? c2 : c2 + 1) * g.cw[a];   // the face of c2 that looks at the atom
   const double d = (c2 > c_self ? face - s : s - face) * g.wid[a];
   return d > 0.0 ? d : 0.0;
 }
@@ -51,7 +51,7 @@ __device__ inline void column_run(const Grid &g, const int *__restrict__ cellsta
   const double gx = axis_gap(g, 0, sx, cx, x2), gy = axis_gap(g, 1, sy, cy, y2);
   const double d2 = g.ortho ? gx * gx + gy * gy : fmax(gx, gy) * fmax(gx, gy);
   if (d2 > rcp * rcp) return;
-  const double dzs = sqrt(rcp * rcp - d2) / g.wid[2];
+  const double dzs = sqrt(rcp * rcp - d2) * g.iwz;
   const int lo = z_slice(g, sz - dzs), hi = z_slice(g, sz + dzs);
   const int cbf = (x2 * g.n[1] + y2) * g.nzf;
   k0 = cellstart[cbf + lo];
@@ -142,41 +142,37 @@ __device__ inline double wave_sum_l(double v) {
 
 // One wavefront per resident row, two phases.
 // Phase 1 (sparse): the candidates of the row = the z-trimmed runs of its 25 stencil columns (column_run above), laid end to end and
-// cut into chunks of 64 -- every lane finds its column by a 5-step search of the run offsets in LDS -- four chunks loaded at once.
-// The distance test runs on an FP32 copy of the positions (16-byte candidates, full-rate arithmetic); only a candidate whose FP32
-// distance lies within `band32` of the cutoff (the rounding bound of that copy) is decided in FP64 from the exact positions, so the
-// accepted set is exactly the reference's  dr2 <= rctap2  (main.F90:458).  Survivors are compacted with a ballot into an LDS queue.
+// cut into chunks of 64 -- every lane finds its column by a 5-step search of the run offsets in LDS -- four chunks loaded at once;
+// the reference's test  dr2 <= rctap2  (main.F90:458); survivors are compacted with a ballot into an LDS queue.  (A first test on an
+// FP32 copy of the positions, with only the candidates inside the rounding band of the cutoff decided in FP64, was measured slower:
+// 4.62 against 4.43 ms -- the sweep is not bound by the arithmetic of this test.)
 // Phase 2 (dense): 64 queued survivors at a time -> exact FP64 distance, table interpolation, list entry, hessian value, row sums;
 // a row is written as contiguous runs (coalesced 8-byte + 4-byte streams) in a deterministic order.
 // A list entry names the partner by its CELL-SORTED position (the loop variable of this sweep), not by atom index: the consumers
 // (QEq matrix passes, ENbond, Ehb) gather from cell-sorted copies, so the 64 lanes of a wavefront hit a handful of cache lines
 // instead of 64 scattered ones.  Bits: see NB10_* in engine.h.
-// nb16 != nullptr: the matrix pass's own copy of the column stream in 16 bits -- bits 11-15 the stencil column, 10 ghost, 0-9 the
-// offset inside that column's run -- with the 25 run starts of the row in rowhdr[row * 32 ..]; an offset that does not fit raises err[3].
 // PQ: PQEq variant of qeq_initialize (pqeq.F90:262-353): core-core hessian from the pcc table, the shell-core matrix hsc of
 // get_hsh's Csicj term, and per row (fpqeq Eq. 30, sum_j H Z_j, sum_j hsc Z_j, shell-shell energy) -> pqrow
-template <bool SELFCHECK, bool PQ, bool PRE32>
+template <bool SELFCHECK, bool PQ>
 __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
-                                                 const double4 *__restrict__ sorted, const float4 *__restrict__ sorted4, float band32,
+                                                 const double4 *__restrict__ sorted,
                                                  const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                  const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz,
                                                  const int *__restrict__ type, const long long *__restrict__ gid,
-                                                 int *__restrict__ nb10, unsigned short *__restrict__ nb16, int *__restrict__ rowhdr, double *__restrict__ hess, int *__restrict__ n10, int *err,
+                                                 int *__restrict__ nb10, double *__restrict__ hess, int *__restrict__ n10, int *err,
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
                                                  const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag) {
-  __shared__ int2 s_q[4][128];           // accepted candidates: (sorted position, column << 16 | offset in the column's run)
+  __shared__ int s_q[4][128];            // accepted candidates: sorted position
   __shared__ int s_P[4][32], s_K[4][32];  // per stencil column: candidates before it / first sorted position of its run
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
   if (i >= N) return;
-  int2 *sq = s_q[w];
+  int *sq = s_q[w];
   int *cP = s_P[w], *cK = s_K[w];
   const int c = cellid[i];
   const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
-  const float xf = static_cast<float>(xi), yf = static_cast<float>(yi), zf = static_cast<float>(zi);
-  const float rc2f = static_cast<float>(ff.rctap2);
   const int ti = type[i];
   const size_t row = static_cast<size_t>(i) * S10;
   double sxi = 0.0, syi = 0.0, szi = 0.0, Zi = 0.0, p_f = 0.0, p_hz = 0.0, p_bz = 0.0, p_ss = 0.0;
@@ -185,7 +181,6 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   // get_gradient would need before the first iteration (qeq.F90:87) comes for free while the entries are in registers
   double ra = 0.0, rg = 0.0;
   bool anyghost = false;                          // does the row have a ghost partner (boundary row of the domain)?
-  bool wide = false;                              // an offset beyond the 10 bits of the 16-bit entry
   int cnt = 0;      // entries written so far
   int qn = 0;       // accepted candidates waiting in the queue
 
@@ -193,8 +188,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   // candidates pass the distance test, so doing this work on compacted batches keeps every lane busy.
   auto emit = [&](int nproc) {
     if (lane < nproc) {
-      const int2 qe = sq[lane];
-      const int k = qe.x, slot = cnt + lane;
+      const int k = sq[lane], slot = cnt + lane;
       if (slot < S10) {
         const double4 p = sorted[k];
         const long long wv = __double_as_longlong(p.w);
@@ -246,11 +240,6 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
         }
         anyghost |= (j >= N);
         nb10[row + slot] = static_cast<int>(ent);
-        if (nb16) {
-          const int off = qe.y & 0xffff;
-          wide |= off > 1023;
-          nb16[row + slot] = static_cast<unsigned short>(((qe.y >> 16) << 11) | (j >= N ? 1024 : 0) | (off & 1023));
-        }
         hess[row + slot] = h;
       }
     }
@@ -269,15 +258,13 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
       if (lane >= o) lpre += l2;
     }
     if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; }
-    if (rowhdr && lane < 32) rowhdr[static_cast<size_t>(i) * 32 + lane] = k0;
     L = __shfl(lpre, 31, 64);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   for (int c0 = 0; c0 < L; c0 += 256) {
     // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
-    int kk[4], tinfo[4];
+    int kk[4];
     bool ok[4];
-    float4 pf[4];
     double4 pd[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -286,42 +273,26 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
       int t = 0;                                 // the column of candidate cc: the last one that starts at or before it
 #pragma unroll
       for (int st = 16; st > 0; st >>= 1) t += (cP[t + st] <= cc) ? st : 0;
-      const int off = cc - cP[t];
-      kk[u] = ok[u] ? cK[t] + off : 0;
-      tinfo[u] = (t << 16) | (off & 0xffff) | (off > 0xffff ? 0xffff : 0);
-      if (PRE32) pf[u] = ok[u] ? sorted4[kk[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-      else pd[u] = ok[u] ? sorted[kk[u]] : make_double4(0, 0, 0, 0);
+      kk[u] = ok[u] ? cK[t] + (cc - cP[t]) : 0;
+      pd[u] = ok[u] ? sorted[kk[u]] : make_double4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       bool in = false;
       if (ok[u]) {
-        if (PRE32) {
-          const int j = __float_as_int(pf[u].w);
-          const float e0 = xf - pf[u].x, e1 = yf - pf[u].y, e2 = zf - pf[u].z;
-          const float r2s = e0 * e0 + e1 * e1 + e2 * e2;
-          in = r2s <= rc2f - band32;
-          if (!in && r2s <= rc2f + band32) {     // too close to call in FP32: the exact positions decide (rare)
-            const double4 p = sorted[kk[u]];
-            const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
-            in = (d0 * d0 + d1 * d1 + d2 * d2) <= ff.rctap2;
-          }
-          in = in && (j != i);
-        } else {
-          const int j = static_cast<int>(__double_as_longlong(pd[u].w) & 0xffffffffLL);
-          const double d0 = xi - pd[u].x, d1 = yi - pd[u].y, d2 = zi - pd[u].z;
-          const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-          in = (j != i) && (r2 <= ff.rctap2);     // dr2 <= rctap2, main.F90:458
-        }
+        const int j = static_cast<int>(__double_as_longlong(pd[u].w) & 0xffffffffLL);
+        const double d0 = xi - pd[u].x, d1 = yi - pd[u].y, d2 = zi - pd[u].z;
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        in = (j != i) && (r2 <= ff.rctap2);     // dr2 <= rctap2, main.F90:458
       }
       const unsigned long long m = __ballot(in);
-      if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(kk[u], tinfo[u]);
+      if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = kk[u];
       qn += __popcll(m);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (qn >= 64) {
         emit(64);
         const int rest = qn - 64;
-        int2 v = make_int2(0, 0);
+        int v = 0;
         if (lane < rest) v = sq[64 + lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (lane < rest) sq[lane] = v;
@@ -332,7 +303,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   }
   if (qn > 0) emit(qn);
   if (cnt > S10) { if (lane == 0) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); } cnt = S10; }  // qeq.F90:248-252
-  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; if (nb16) nb16[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
+  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
   if (xs0) {
     ra = wave_sum_l(ra); rg = wave_sum_l(rg);
     if (lane == 0) { s_all[i] = make_double2(ra, 0.0); s_gh[i] = make_double2(rg, 0.0); }
@@ -343,7 +314,6 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
     if (lane == 0) pqrow[i] = make_double4(p_f, p_hz, p_bz, p_ss);
   }
   { const unsigned long long mg = __ballot(anyghost); if (lane == 0 && rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0; }
-  if (nb16) { const unsigned long long mw = __ballot(wide); if (lane == 0 && mw != 0ULL) atomicMax(&err[3], 1); }
   if (lane == 0) n10[i] = cnt;
 }
 
@@ -363,21 +333,11 @@ void Engine::build_bonded_list() {
 void Engine::build_list10() {
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   const bool selfcheck = (box.lat[0] < 2.0 * ff.rctap + 1.0) || (box.lat[1] < 2.0 * ff.rctap + 1.0) || (box.lat[2] < 2.0 * ff.rctap + 1.0);
-  // FP32 first test: |r2(fp32) - r2| <= 2 r sqrt(3) (1.2e-7 cmax) + 4 ulp(r2), cmax = largest coordinate; twice that as the band
-  static const bool pre32 = (std::getenv("RXMD_LIST_NO_FP32") == nullptr);
-  double cmax = 0.0;
-  for (int a = 0; a < 3; ++a) cmax = std::max(cmax, box.lat[a] * (box.obox[a] + box.lbox[a] + 2.0 * shell[a]));
-  const float band32 = static_cast<float>(1e-5 * cmax + 2e-4);
-  unsigned short *n16 = idx16_on ? nb16 : nullptr;
-  int *hdr = idx16_on ? rowhdr : nullptr;
-#define RX_LIST10(SC, PQF, P32)                                                                                                                  \
-  k_list10<SC, PQF, P32><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, sorted_f4, band32, pos[0], pos[1], pos[2], \
-                                                         spos[0], spos[1], spos[2], type, gid, nb10, n16, hdr, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, \
-                                                         sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
-#define RX_LIST10_P(SC, PQF) do { if (pre32) RX_LIST10(SC, PQF, true); else RX_LIST10(SC, PQF, false); } while (0)
-  if (ff.pqeq) { if (selfcheck) RX_LIST10_P(true, true); else RX_LIST10_P(false, true); }
-  else { if (selfcheck) RX_LIST10_P(true, false); else RX_LIST10_P(false, false); }
-#undef RX_LIST10_P
+#define RX_LIST10(SC, PQF)                                                                                                                     \
+  k_list10<SC, PQF><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
+                                                    nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
+  if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
+  else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
 #undef RX_LIST10
   if (multi()) {     // interior rows (no ghost partner) and boundary rows: the matrix pass does the former while the vector halo is in flight
     RX_HIP(hipMemsetAsync(flags + N, 0, sizeof(int), stream));

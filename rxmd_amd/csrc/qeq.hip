@@ -65,14 +65,15 @@ __device__ inline double pq_est_row(const DevAtomP &ap, double Zi, const double4
 // length, (b) four batches of 64 entries are in flight instead of eight, which brings the kernel from 99 to <= 80 VGPRs and from
 // 4 to 6 wavefronts per SIMD (measured on one box: 1.276 ms -> 1.21 with (a), 1.157 with (b), 1.06-1.12 with both), (c) PQEq is
 // a template parameter so that the plain kernel does not carry its code.
-// IDX16: the column stream is the 16-bit one of k_list10 (stencil column << 11 | ghost << 10 | offset in the column's run) and the 25 run
-// starts of the row sit in the lanes of ONE register (rowhdr, a coalesced 128-byte load next to the row length): a column index is
-// a cross-lane read (ds_bpermute) plus an add -- 10 instead of 12 bytes of HBM per entry.
-// SPEC: the first 256 entries of the two streams are requested BEFORE the row length is known (they lie inside the row's S10-entry slot
-// whatever the length; entries behind the row's end get weight 0 once it has arrived): one dependent round trip less per wavefront.
-template <int MODE, bool STORE, bool PQ, bool IDX16, bool SPEC>
-__global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const unsigned short *__restrict__ nb16, const int *__restrict__ rowhdr,
-                                               const double *__restrict__ hess, const int *__restrict__ n10,
+// PIPE (default; RXMD_SPMV_NO_PIPE=1 switches it off): the loop is software-pipelined over the row's batches of 256 entries.  The first
+// batch of the two streams is requested BEFORE the row length is known (it lies inside the row's S10-entry slot whatever the length;
+// entries behind the row's end get weight 0 once the length has arrived), and batch b+1 is requested before the gathers of batch b
+// are issued: a wavefront waits for two dependent round trips less (measured on one box: 0.98 -> 0.93 ms per pass with the first
+// step alone).  What did NOT help once the chain was shorter: a 16-bit column stream (stencil column + offset, 10 instead of 12 bytes
+// per entry: 0.968 vs 0.988 ms without the pipelining, 0.931 vs 0.921 ms with it) -- the pass is bound by the latency chain of a
+// million short wavefronts, not by the bytes of the streams.
+template <int MODE, bool STORE, bool PQ, bool PIPE>
+__global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
                                                const double *__restrict__ scal, double *__restrict__ partials,
@@ -90,56 +91,46 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (row < N) {
     const size_t base = static_cast<size_t>(row) * S10;
-    unsigned e0[UNR];
-    double h0[UNR];
-    if (SPEC) {
+    unsigned e[UNR], en[UNR];
+    double h[UNR], hn[UNR], c[UNR], cn[UNR];
+    // one batch of the row's streams (entry, hessian value, PQEq: shell-core value) for entries [kb, kb + 256) below `bound`
+    auto request = [&](int kb, int bound, unsigned (&ee)[UNR], double (&hh)[UNR], double (&cc)[UNR]) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int k = lane + 64 * u;
-        const bool ok = k < S10;
-        if (IDX16) e0[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb16 + base + k)) : 0u;
-        else e0[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;
-        h0[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;
+        const int k = kb + lane + 64 * u;
+        const bool ok = k < bound;
+        ee[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;   // streamed once: keep it out of
+        hh[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;                        // the caches that hold the vector
+        if (PQ && (MODE == MODE_GRAD || STORE)) cc[u] = ok ? __builtin_nontemporal_load(hsc + base + k) : 0.0;
       }
-    }
+    };
+    if (PIPE) request(0, S10, e, h, c);
     const int n = n10[row];
-    const int hdr = IDX16 ? rowhdr[static_cast<size_t>(row) * 32 + (lane & 31)] : 0;
     // operands of the row tail, requested before the streams so that they are not a further dependent round trip after the reduction
     const int pf_t = type[row];
     const double2 pf_a = (MODE == MODE_HSH) ? hst[row] : qst[row];
     const double2 pf_b = (MODE == MODE_HSH) ? gst[row] : make_double2(q[row], 0.0);
     const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
     double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count: every lane stays in the loop (the cross-lane read of IDX16 needs its source lanes alive)
-      const int k0 = kb + lane;
-      unsigned e[UNR];
-      double h[UNR];
-      if (SPEC && kb == 0) {
+    if (PIPE) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) { const bool ok = k0 + 64 * u < n; e[u] = ok ? e0[u] : 0u; h[u] = ok ? h0[u] : 0.0; }
-      } else {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {            // the two coalesced streams of the row: issue every load first
-          const int k = k0 + 64 * u;
-          const bool ok = k < n;
-          if (IDX16) e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb16 + base + k)) : 0u;
-          else e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;   // streamed once: keep it out of
-          h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;                             // the caches that hold the vector
-        }
-      }
+      for (int u = 0; u < UNR; ++u) { const bool ok = lane + 64 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; if (PQ) c[u] = ok ? c[u] : 0.0; }
+    }
+    for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
+      if (!PIPE) request(kb, n, e, h, c);
+      const bool more = kb + 64 * UNR < n;
+      if (PIPE && more) request(kb + 64 * UNR, n, en, hn, cn);
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
-        const unsigned col = IDX16 ? static_cast<unsigned>(__shfl(hdr, static_cast<int>(e[u] >> 11), 64)) + (e[u] & 1023u) : (e[u] & NB10_IDX_MASK);
-        const bool ghost = IDX16 ? (e[u] & 1024u) != 0u : (e[u] & NB10_GHOST) != 0u;
-        const double2 v = xv[col];
+        const double2 v = xv[e[u] & NB10_IDX_MASK];
         as += h[u] * v.x;
         at += h[u] * v.y;
-        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = ghost ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
-        if ((MODE == MODE_GRAD || STORE) && PQ) {      // PQEq: second matrix (shell-core) over the same columns
-          const int k = k0 + 64 * u;
-          const double c = (k < n) ? __builtin_nontemporal_load(hsc + base + k) : 0.0;
-          gs_ += c * v.x; gt_ += c * v.y;
-        }
+        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
+        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }      // PQEq: second matrix (shell-core) over the same columns
+      }
+      if (PIPE && more) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { e[u] = en[u]; h[u] = hn[u]; if (PQ) c[u] = cn[u]; }
       }
     }
     as = wave_sum(as); at = wave_sum(at);
@@ -455,22 +446,20 @@ void Engine::qeq() {
   const int nred = rb;                                                             // partials one matrix pass leaves
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
-  static const bool spec = (std::getenv("RXMD_SPMV_SPEC") != nullptr);
+  const bool pipe = (std::getenv("RXMD_SPMV_NO_PIPE") == nullptr);      // read per call: the tests switch it
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) {
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return;
-#define RX_PASS4(M, S, P, I, SP) k_spmv<M, S, P, I, SP><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, nb16, rowhdr, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase)
-#define RX_PASS3(M, S, P, I) do { if (spec) RX_PASS4(M, S, P, I, true); else RX_PASS4(M, S, P, I, false); } while (0)
+#define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase)
 #define RX_PASS(M, S)                                                                                                  \
   do {                                                                                                                 \
-    if (ff.pqeq) { if (idx16_on) RX_PASS3(M, S, true, true); else RX_PASS3(M, S, true, false); }                        \
-    else { if (idx16_on) RX_PASS3(M, S, false, true); else RX_PASS3(M, S, false, false); }                              \
+    if (ff.pqeq) { if (pipe) RX_PASS3(M, S, true, true); else RX_PASS3(M, S, true, false); }                            \
+    else { if (pipe) RX_PASS3(M, S, false, true); else RX_PASS3(M, S, false, false); }                                  \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }
 #undef RX_PASS
 #undef RX_PASS3
-#undef RX_PASS4
   };
   auto reduce = [&](int stage, int nb_) {
     if (!multi()) {                              // single rank: level-1 sums, final sum and scalar algebra in one launch

@@ -57,7 +57,9 @@ def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, t
     _, _, s1, r1 = oa.parse_rxff(np.frombuffer(mine, np.uint8)); _, _, s2, r2 = oa.parse_rxff(g["final_rxff"])
     assert s1 == s2 == 27
     a, b = r1[0], r2[0]
-    assert np.array_equal(a[:, 7], b[:, 7])                                   # type + gid * 1e-13, same local order
+    ta, tb = np.rint(a[:, 7]), np.rint(b[:, 7])                               # atype = type + gid * 1e-13 (main.F90:582-593): same local order
+    assert np.array_equal(ta, tb) and np.array_equal(np.rint((a[:, 7] - ta) * 1e13), np.rint((b[:, 7] - tb) * 1e13))
+    assert np.abs(a[:, 7] - b[:, 7]).max() <= 4e-16                           # and the packed value itself to the last bit or two
     assert np.abs(a[:, 0:3] - b[:, 0:3]).max() <= 1e-10                       # normalised positions (1e-9 A)
     assert np.abs(a[:, 3:6] - b[:, 3:6]).max() <= 1e-8 * np.abs(b[:, 3:6]).max()
     qrms = np.sqrt((b[:, 6] ** 2).mean())
