@@ -16,6 +16,10 @@
 // (except the acceptor atom of a hydrogen bond, which is a 10 A partner and has no slot).
 #include "engine.h"
 
+#include <hipcub/hipcub.hpp>
+
+#include <cstdlib>
+
 namespace rxmd {
 
 static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
@@ -149,7 +153,21 @@ constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages
 #ifndef E4B_MINB
 #define E4B_MINB 3
 #endif
-__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+// Work order of the thread-per-centre angle kernel.  The cost of a centre atom grows with the square of its bonds above the bond-order
+// cut-off (RDX: a hydrogen has none or one, a ring carbon four to six), so in atom order a wavefront waits for its heaviest lane
+// while half of its lanes idle.  The centres are handed out sorted by that count, heaviest first: the lanes of a wavefront then run
+// loops of equal length.  Every centre writes only its own slots, so the order changes no result.
+__global__ void k_angle_key(int N, int NB, const int *__restrict__ nbrcnt, const double *__restrict__ bo0, int *__restrict__ key, int *__restrict__ idx) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  int c = 0;
+  const int nj = nbrcnt[j];
+  for (int s = 0; s < nj; ++s) c += (bo0[static_cast<size_t>(s) * NB + j] > cutof2_esub) ? 1 : 0;
+  key[j] = 31 - min(c, 31);
+  idx[j] = j;
+}
+
+__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ order, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
                                               const double *__restrict__ delta, const double *__restrict__ nlp, const double *__restrict__ dDlp,
@@ -157,9 +175,10 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
-  const int j = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
-  if (j < N) {
+  if (tid < N) {
+    const int j = order ? order[tid] : tid;
     const int tj = type[j], nj = nbrcnt[j];
     const DevAtomP aj = ff.atom[tj];
     const double xj = x[j], yj = y[j], zj = z[j];
@@ -272,6 +291,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
   block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
 }
 
+struct BoxImg { double H[9], Hi[9], L[3]; int ortho; };    // lattice vectors for the image test of the torsion's stress correction
 // Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to i,j,k,l.
 // Here ONE WAVEFRONT owns TWO consecutive centre atoms; lane t = (g<<5 | slot) owns the accumulators of bond `slot` of
 // atom g.  Phase A enumerates every (k1,i1,l1) combination of the two atoms, applies the reference's cheap bond-order
@@ -288,7 +308,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
                                               const double *__restrict__ etor, const double *__restrict__ econ,
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, double3 boxl) {
+                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, BoxImg bx) {
   // per (atom g, slot): the bond as seen from the centre
   __shared__ double s_bo[4][64], s_et[4][64], s_ec[4][64], s_rx[4][64], s_ry[4][64], s_rz[4][64], s_rn[4][64];
   __shared__ int s_nb[4][64], s_ty[4][64];
@@ -448,8 +468,15 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
         const double xk = x[k], yk = y[k], zk = z[k];
         // k is bonded to a resident: it lies inside the box or in the first image layer, so comparisons name the lattice vector
         // (floor(x / L) costs three FP64 divisions per torsion)
-        const double t0 = xk < 0.0 ? boxl.x : (xk >= boxl.x ? -boxl.x : 0.0), t1 = yk < 0.0 ? boxl.y : (yk >= boxl.y ? -boxl.y : 0.0),
-                     t2 = zk < 0.0 ? boxl.z : (zk >= boxl.z ? -boxl.z : 0.0);
+        double t0, t1, t2;
+        if (bx.ortho) {
+          t0 = xk < 0.0 ? bx.L[0] : (xk >= bx.L[0] ? -bx.L[0] : 0.0); t1 = yk < 0.0 ? bx.L[1] : (yk >= bx.L[1] ? -bx.L[1] : 0.0);
+          t2 = zk < 0.0 ? bx.L[2] : (zk >= bx.L[2] ? -bx.L[2] : 0.0);
+        } else {                                   // skewed box: which lattice vectors bring k home, from its normalised coordinates
+          const double n0 = -floor(bx.Hi[0] * xk + bx.Hi[1] * yk + bx.Hi[2] * zk), n1 = -floor(bx.Hi[3] * xk + bx.Hi[4] * yk + bx.Hi[5] * zk),
+                       n2 = -floor(bx.Hi[6] * xk + bx.Hi[7] * yk + bx.Hi[8] * zk);
+          t0 = bx.H[0] * n0 + bx.H[1] * n1 + bx.H[2] * n2; t1 = bx.H[3] * n0 + bx.H[4] * n1 + bx.H[5] * n2; t2 = bx.H[6] * n0 + bx.H[7] * n1 + bx.H[8] * n2;
+        }
         if (t0 != 0.0 || t1 != 0.0 || t2 != 0.0) {
           const double F0 = 0.5 * (o[1] + fself.x), F1 = 0.5 * (o[2] + fself.y), F2 = 0.5 * (o[3] + fself.z);
           if (t0 != 0.0) { atomicAdd(pe + 16, t0 * F0); atomicAdd(pe + 21, t0 * F1); }     // xx, xy
@@ -625,10 +652,21 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
 void Engine::bonded_energies() {
   double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
   k_ebond_elnpr<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, dDlp, cf1, cf2, cf3, cdn, ecoa, pe_d);
-  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+  // centres sorted by their number of bonds above the cut-off, heaviest first (scratch: the scan arrays of the ghost build)
+  const int *order = nullptr;
+  if (std::getenv("RXMD_E3B_ATOM_ORDER") == nullptr && N > 0) {
+    k_angle_key<<<nblk(N, 256), 256, 0, stream>>>(N, NB, nbrcnt, bo0, flags, flags2);
+    size_t tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, flags, scanout, flags2, scanout2, N, 0, 5, stream));
+    order = scanout2;
+  }
+  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, order, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
+  BoxImg bx;
+  for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
+  bx.ortho = grid.ortho;
   k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                          cds, frc[0], frc[1], frc[2], pe_d, make_double3(box.lat[0], box.lat[1], box.lat[2]));
+                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
   k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
 }
 

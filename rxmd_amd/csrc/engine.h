@@ -85,6 +85,19 @@ struct Grid {       // the engine's own cell grid over [-shell, L+shell) in norm
   int ortho;        // 1: the three directions are orthogonal (distance^2 = sum of the three gaps^2), 0: only max(gap) is a bound
 };
 
+// The reference's own cell meshes (non-orthogonal boxes only).  Its linked-list cells are laid out in units of the lattice VECTORS and
+// its stencils assume orthogonal axes (NEIGHBORLIST: +-1 cell, main.F90:349-351; the non-bonded mesh: cells whose offset passes an
+// orthogonal distance test, init.F90:549-592), and its QEq ghost shell is rctap divided by the lattice constants (qeq.F90:32).  In a
+// skewed cell these select FEWER pairs than the cutoffs do; the lists reproduce the selection so that the matrix and the forces are
+// the reference's.  With 90-degree angles every pair inside a cutoff passes all three and nothing is evaluated.
+struct RefMesh {
+  double Hi[9], obox[3];   // xu2xs: the reference bins ALL atoms, ghosts included, by Hi.r - obox (LINKEDLIST, main.F90:298)
+  double lc[3];            // bonded cell, normalised (lcsize, init.F90:661)
+  double nbl[3];           // non-bonded cell, normalised (nblcsize, init.F90:605)
+  double nblr[3];          // the same in length units of its lattice vector (init.F90:545)
+  double qlo[3], qhi[3];   // QEq ghost shell in normalised local coordinates: (-QCopyDr, lbox + QCopyDr]  (qeq.F90:32,69; comm.F90:551-576)
+};
+
 constexpr int WAVE = 64;
 
 // XCD-aware workgroup order: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2),
@@ -112,6 +125,7 @@ struct Engine {
   int cc[3] = {1, 1, 1};          // reference bonded cell counts, only to derive the ghost shell (init.F90:656)
   double shell[3] = {0, 0, 0};    // FORCE ghost shell in normalised units: NMINCELL*lcsize (pot.F90:28)
   Grid grid{};
+  RefMesh rmesh{};
 
   // ---- device memory ----
   DevFF dff{};
@@ -172,6 +186,7 @@ struct Engine {
   std::vector<double> lex_p, lex_v; bool lex_pending = false;   // qsfp/qsfv handed over by rxmd_hip_put_lex for the next array-shaped QEq/PQEq
   rxmd_stats st{};
   int nstep_qeq = 0; double last_est = 0;
+  double atype_resid = 0.0;        // geninit packs atype = type + gid*1e-13 + 1e-14 (geninit.F90:459), ReadXYZ without it (fileio.F90:421): what came in goes out
   long long step_count = 0;
 
   // ---- host API ----

@@ -57,8 +57,6 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   for (int a = 0; a < 3; ++a) if (cfg.vprocs[a] < 1) throw EngineError(RXMD_E_ARG, "vprocs must be >= 1");
   nprocs = cfg.vprocs[0] * cfg.vprocs[1] * cfg.vprocs[2];
   if (cfg.myid < 0 || cfg.myid >= nprocs) throw EngineError(RXMD_E_ARG, "myid outside the vprocs grid");
-  if (std::fabs(cfg.lattice[3] - 90.0) > 1e-9 || std::fabs(cfg.lattice[4] - 90.0) > 1e-9 || std::fabs(cfg.lattice[5] - 90.0) > 1e-9)
-    throw EngineError(RXMD_E_ARG, "only orthorhombic boxes are supported by the GPU cell grid (alpha=beta=gamma=90)");
   try { ff.parse(ffield_path, cfg.lg != 0); } catch (const std::exception &e) { throw EngineError(RXMD_E_FFIELD, e.what()); }
   // rank grid, reference src/init.F90:74-100
   vID[0] = cfg.myid % cfg.vprocs[0]; vID[1] = (cfg.myid / cfg.vprocs[0]) % cfg.vprocs[1]; vID[2] = cfg.myid / (cfg.vprocs[0] * cfg.vprocs[1]);
@@ -157,21 +155,34 @@ void Engine::setup_after_atoms(const std::vector<long long> &npt) {
     if (cc[a] < 1) throw EngineError(RXMD_E_ARG, "local box smaller than the bond cutoff");
     shell[a] = NMINCELL * (box.lbox[a] / cc[a]);               // dr of the FORCE ghost copy, pot.F90:28
   }
-  // the engine's own grid: one cell edge >= max(rctap/2, maxrc); stencil +-2 covers 10 A, +-1 the bonds
+  // the engine's own grid: one cell >= max(rctap/2, maxrc) wide, measured PERPENDICULAR to its faces (the planes of constant normalised
+  // coordinate a are 1 / |row a of Hi| apart per unit; with 90-degree angles that is the lattice constant); stencil +-2 covers the taper
+  // cutoff, +-1 the bonds
   const double cw = std::max(0.5 * ff.rctap, ff.maxrc) * (1.0 + 1e-9);
+  grid.ortho = (std::fabs(box.lat[3] - 90.0) < 1e-9 && std::fabs(box.lat[4] - 90.0) < 1e-9 && std::fabs(box.lat[5] - 90.0) < 1e-9) ? 1 : 0;
   grid.ncell = 1;
   for (int a = 0; a < 3; ++a) {
+    grid.wid[a] = grid.ortho ? box.lat[a] : 1.0 / std::sqrt(box.Hi[a][0] * box.Hi[a][0] + box.Hi[a][1] * box.Hi[a][1] + box.Hi[a][2] * box.Hi[a][2]);
     const double wn = box.lbox[a] + 2.0 * shell[a];
-    const double wreal = wn * box.lat[a];
+    const double wreal = wn * grid.wid[a];
     grid.n[a] = std::max(1, static_cast<int>(wreal / cw));
     grid.org[a] = -shell[a];
     grid.inv[a] = grid.n[a] / wn;
     grid.ncell *= grid.n[a];
-    grid.wid[a] = box.lat[a];                                  // orthorhombic: one unit of normalised coordinate = one lattice constant
     grid.cw[a] = 1.0 / grid.inv[a];
   }
   grid.iwz = 1.0 / grid.wid[2];
-  grid.ortho = 1;
+  // the reference's meshes (RefMesh, engine.h)
+  for (int a = 0; a < 3; ++a) {
+    for (int c = 0; c < 3; ++c) rmesh.Hi[3 * a + c] = box.Hi[a][c];
+    rmesh.obox[a] = box.obox[a];
+    rmesh.lc[a] = box.lbox[a] / cc[a];                          // lcsize, init.F90:661
+    const int nbcc = std::max(1, static_cast<int>(lreal[a] / 3.0));   // nblcsize = 3 A initial estimate, init.F90:538-545
+    rmesh.nblr[a] = lreal[a] / nbcc;
+    rmesh.nbl[a] = rmesh.nblr[a] / box.lat[a];                  // init.F90:605
+    rmesh.qlo[a] = -ff.rctap / box.lat[a];                      // QCopyDr, qeq.F90:32
+    rmesh.qhi[a] = box.lbox[a] + ff.rctap / box.lat[a];
+  }
   // z-slices per cell: ~1/8 of a cell (0.6 A at the 5 A cell of a 10 A cutoff); bounded so that the slice ids fit the 31-bit sort key
   grid.fz = 8;
   while (grid.fz > 1 && static_cast<long long>(grid.ncell) * grid.fz > (1LL << 28)) grid.fz >>= 1;
@@ -322,6 +333,7 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
   std::vector<long long> hg(natoms);
   for (int a = 0; a < 3; ++a) { hx[a].resize(natoms); hv[a].resize(natoms); }
   std::vector<long long> npt(ff.nso + 2, 0);
+  int n14 = 0;
   for (int i = 0; i < natoms; ++i) {
     const double *r = rec + 10 * static_cast<size_t>(i);
     const double s[3] = {r[0] + box.obox[0], r[1] + box.obox[1], r[2] + box.obox[2]};
@@ -332,7 +344,9 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
     ht[i] = t; hg[i] = std::llround((r[7] - t) * 1e13);                 // l2g, main.F90:582-593
     hp[i] = r[8]; hw[i] = r[9];
     npt[t]++;
+    if (r[7] == (static_cast<double>(t) + static_cast<double>(hg[i]) * 1e-13) + 1e-14) ++n14;
   }
+  atype_resid = (natoms > 0 && n14 == natoms) ? 1e-14 : 0.0;
   if (!tables_ready) {
     if (nprocs > 1) {
       std::vector<double> tmp(ff.nso + 1);
@@ -401,7 +415,7 @@ int Engine::get_atoms_rxff(double *rec, int capacity) {
     double *r = rec + 10 * static_cast<size_t>(i);
     for (int a = 0; a < 3; ++a) r[a] = (box.Hi[a][0] * hx[0][i] + box.Hi[a][1] * hx[1][i] + box.Hi[a][2] * hx[2][i]) - box.obox[a];  // xu2xs
     for (int a = 0; a < 3; ++a) r[3 + a] = hv[a][i];
-    r[6] = hq[i]; r[7] = ht[i] + hg[i] * 1e-13; r[8] = hp[i]; r[9] = hw[i];
+    r[6] = hq[i]; r[7] = (static_cast<double>(ht[i]) + static_cast<double>(hg[i]) * 1e-13) + atype_resid; r[8] = hp[i]; r[9] = hw[i];
   }
   return N;
 }

@@ -39,6 +39,33 @@ __device__ inline double axis_gap(const Grid &g, int a, double s, int c_self, in
   const double d = (c2 > c_self ? face - s : s - face) * g.wid[a];
   return d > 0.0 ? d : 0.0;
 }
+// ---- the reference's pair selection in a non-orthogonal box (RefMesh, engine.h) ----
+__device__ inline void ref_norm(const RefMesh &m, double x, double y, double z, double (&s)[3]) {     // xu2xs, main.F90:596-616
+  s[0] = (m.Hi[0] * x + m.Hi[1] * y + m.Hi[2] * z) - m.obox[0];
+  s[1] = (m.Hi[3] * x + m.Hi[4] * y + m.Hi[5] * z) - m.obox[1];
+  s[2] = (m.Hi[6] * x + m.Hi[7] * y + m.Hi[8] * z) - m.obox[2];
+}
+// NEIGHBORLIST visits the 3 x 3 x 3 cells around an atom's cell (main.F90:349-351): cells = floor(rnorm / lcsize), main.F90:305
+__device__ inline bool ref_bonded_cells_adjacent(const RefMesh &m, const double (&si)[3], const double (&sj)[3]) {
+  for (int a = 0; a < 3; ++a) {
+    const int d = static_cast<int>(floor(sj[a] / m.lc[a])) - static_cast<int>(floor(si[a] / m.lc[a]));
+    if (d < -1 || d > 1) return false;
+  }
+  return true;
+}
+// the non-bonded mesh: cell offset (i,j,k) is visited when the cells' nearest faces, taken as if the axes were orthogonal, are within
+// rctap (init.F90:556-592)
+__device__ inline bool ref_nb_cells_in_mesh(const RefMesh &m, const double (&si)[3], const double (&sj)[3], double rctap2) {
+  double dr2 = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    int d = static_cast<int>(floor(sj[a] / m.nbl[a])) - static_cast<int>(floor(si[a] / m.nbl[a]));
+    d = d > 0 ? d - 1 : (d < 0 ? d + 1 : 0);
+    const double rr = d * m.nblr[a];
+    dr2 += rr * rr;
+  }
+  return dr2 <= rctap2;
+}
+
 __device__ inline int z_slice(const Grid &g, double sz) {          // the expression of k_cell_ids, monotone in sz
   const int b = static_cast<int>(floor((sz - g.org[2]) * (g.inv[2] * g.fz)));
   return min(max(b, 0), g.nzf - 1);
@@ -49,16 +76,17 @@ __device__ inline void column_run(const Grid &g, const int *__restrict__ cellsta
   k0 = 0; len = 0;
   if (x2 < 0 || x2 >= g.n[0] || y2 < 0 || y2 >= g.n[1]) return;
   const double gx = axis_gap(g, 0, sx, cx, x2), gy = axis_gap(g, 1, sy, cy, y2);
+  // orthogonal axes: the three gaps add in quadrature; skewed axes: each perpendicular gap alone is a lower bound of the distance
   const double d2 = g.ortho ? gx * gx + gy * gy : fmax(gx, gy) * fmax(gx, gy);
   if (d2 > rcp * rcp) return;
-  const double dzs = sqrt(rcp * rcp - d2) * g.iwz;
+  const double dzs = (g.ortho ? sqrt(rcp * rcp - d2) : rcp) * g.iwz;
   const int lo = z_slice(g, sz - dzs), hi = z_slice(g, sz + dzs);
   const int cbf = (x2 * g.n[1] + y2) * g.nzf;
   k0 = cellstart[cbf + lo];
   len = cellstart[cbf + hi + 1] - k0;
 }
 
-__global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+__global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                       const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ z, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
                                                       const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {
@@ -82,6 +110,8 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
   const int ti = type[i];
   const double *rc2row = s_rc2 + ti * ff.n1;
   const double rcp = s_rmax[ti];
+  double si[3] = {0.0, 0.0, 0.0};
+  if (!g.ortho) ref_norm(rm, xi, yi, zi, si);
   int cnt = 0;
   for (int dx = -1; dx <= 1; ++dx) {
     for (int dy = -1; dy <= 1; ++dy) {
@@ -95,7 +125,9 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
         const int tj = static_cast<int>(w >> 32);
         const double d0 = p.x - xi, d1 = p.y - yi, d2 = p.z - zi;
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-        if (r2 < rc2row[tj]) {                  // dr2 < rc2(inxn), main.F90:366 (no bond row: cut-off 0)
+        bool in = r2 < rc2row[tj];              // dr2 < rc2(inxn), main.F90:366 (no bond row: cut-off 0)
+        if (in && !g.ortho) { double sj[3]; ref_norm(rm, p.x, p.y, p.z, sj); in = ref_bonded_cells_adjacent(rm, si, sj); }
+        if (in) {
           if (cnt < MAXNB) nbr[static_cast<size_t>(cnt) * NB + i] = j;
           ++cnt;
         }
@@ -154,7 +186,7 @@ __device__ inline double wave_sum_l(double v) {
 // PQ: PQEq variant of qeq_initialize (pqeq.F90:262-353): core-core hessian from the pcc table, the shell-core matrix hsc of
 // get_hsh's Csicj term, and per row (fpqeq Eq. 30, sum_j H Z_j, sum_j hsc Z_j, shell-shell energy) -> pqrow
 template <bool SELFCHECK, bool PQ>
-__global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+__global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted,
                                                  const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                  const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz,
@@ -175,6 +207,8 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
   const double xi = x[i], yi = y[i], zi = z[i];
   const int ti = type[i];
   const size_t row = static_cast<size_t>(i) * S10;
+  double sni[3] = {0.0, 0.0, 0.0};
+  if (!g.ortho) ref_norm(rm, xi, yi, zi, sni);
   double sxi = 0.0, syi = 0.0, szi = 0.0, Zi = 0.0, p_f = 0.0, p_hz = 0.0, p_bz = 0.0, p_ss = 0.0;
   if (PQ) { sxi = shx[i]; syi = shy[i]; szi = shz[i]; Zi = ff.Zpq[ti]; }
   // xs0 != nullptr: the sweep also forms the row sums H.(qs,qt) of the CG start vector (qt = 0) -- the matrix pass that
@@ -199,8 +233,14 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
         const float r2f = static_cast<float>(r2);
         double h = 0.0, hc = 0.0;
         const int inxn = ff.inxn2[ti * ff.n1 + tj];
+        // skewed box: a ghost partner beyond the reference's QEq ghost shell is in its FORCE list but not in its QEq matrix
+        bool inq = true;
+        if (!g.ortho && j >= N) {
+          const double g0 = spx[j], g1 = spy[j], g2 = spz[j];
+          inq = g0 > rm.qlo[0] && g0 <= rm.qhi[0] && g1 > rm.qlo[1] && g1 <= rm.qhi[1] && g2 > rm.qlo[2] && g2 <= rm.qhi[2];
+        }
         if (PQ) {
-          if (static_cast<double>(r2f) < ff.rctap2) {                  // the pair is in PQEq's own list (real(4) test, pqeq.F90:305)
+          if (inq && static_cast<double>(r2f) < ff.rctap2) {                  // the pair is in PQEq's own list (real(4) test, pqeq.F90:305)
             const double C0q = 14.4;                                   // Cclmb0_qeq, module.F90:682
             const double4 sj = sorted_shl[k];
             const double Zj = ff.Zpq[tj];
@@ -224,7 +264,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
             p_ss += 0.5 * C0q * E * Zi * Zj;
           }
           hsc[row + slot] = hc;
-        } else if (static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
+        } else if (inq && static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
           const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
           double drtb = static_cast<double>(r2f) - itb * ff.UDR;
           drtb = drtb * ff.UDRi;
@@ -284,6 +324,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, DevFF ff
         const double d0 = xi - pd[u].x, d1 = yi - pd[u].y, d2 = zi - pd[u].z;
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
         in = (j != i) && (r2 <= ff.rctap2);     // dr2 <= rctap2, main.F90:458
+        if (in && !g.ortho) { double sj[3]; ref_norm(rm, pd[u].x, pd[u].y, pd[u].z, sj); in = ref_nb_cells_in_mesh(rm, sni, sj, ff.rctap2); }
       }
       const unsigned long long m = __ballot(in);
       if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = kk[u];
@@ -326,15 +367,15 @@ __global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__r
 
 void Engine::build_bonded_list() {
   k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi);
-  k_bonded_list<<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
+  k_bonded_list<<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
   k_reverse_index<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, d_err);
 }
 
 void Engine::build_list10() {
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
-  const bool selfcheck = (box.lat[0] < 2.0 * ff.rctap + 1.0) || (box.lat[1] < 2.0 * ff.rctap + 1.0) || (box.lat[2] < 2.0 * ff.rctap + 1.0);
+  const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);
 #define RX_LIST10(SC, PQF)                                                                                                                     \
-  k_list10<SC, PQF><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
+  k_list10<SC, PQF><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
                                                     nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }

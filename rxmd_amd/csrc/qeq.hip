@@ -72,7 +72,7 @@ __device__ inline double pq_est_row(const DevAtomP &ap, double Zi, const double4
 // step alone).  What did NOT help once the chain was shorter: a 16-bit column stream (stencil column + offset, 10 instead of 12 bytes
 // per entry: 0.968 vs 0.988 ms without the pipelining, 0.931 vs 0.921 ms with it) -- the pass is bound by the latency chain of a
 // million short wavefronts, not by the bytes of the streams.
-template <int MODE, bool STORE, bool PQ, bool PIPE>
+template <int MODE, bool STORE, bool PQ, int PIPE>
 __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
@@ -117,9 +117,9 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
       for (int u = 0; u < UNR; ++u) { const bool ok = lane + 64 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; if (PQ) c[u] = ok ? c[u] : 0.0; }
     }
     for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
-      if (!PIPE) request(kb, n, e, h, c);
+      if (PIPE == 0 || (PIPE == 1 && kb > 0)) request(kb, n, e, h, c);
       const bool more = kb + 64 * UNR < n;
-      if (PIPE && more) request(kb + 64 * UNR, n, en, hn, cn);
+      if (PIPE == 2 && more) request(kb + 64 * UNR, n, en, hn, cn);
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
         const double2 v = xv[e[u] & NB10_IDX_MASK];
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
         if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
         if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }      // PQEq: second matrix (shell-core) over the same columns
       }
-      if (PIPE && more) {
+      if (PIPE == 2 && more) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) { e[u] = en[u]; h[u] = hn[u]; if (PQ) c[u] = cn[u]; }
       }
@@ -446,15 +446,17 @@ void Engine::qeq() {
   const int nred = rb;                                                             // partials one matrix pass leaves
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
-  const bool pipe = (std::getenv("RXMD_SPMV_NO_PIPE") == nullptr);      // read per call: the tests switch it
+  int pipe = 1;                                                           // 0 plain loop, 1 first batch ahead of the row length, 2 every batch ahead
+  if (std::getenv("RXMD_SPMV_NO_PIPE")) pipe = 0;                         // (read per call: the tests switch it)
+  else if (const char *pv = std::getenv("RXMD_SPMV_PIPE")) pipe = std::atoi(pv);
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) {
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return;
 #define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase)
 #define RX_PASS(M, S)                                                                                                  \
   do {                                                                                                                 \
-    if (ff.pqeq) { if (pipe) RX_PASS3(M, S, true, true); else RX_PASS3(M, S, true, false); }                            \
-    else { if (pipe) RX_PASS3(M, S, false, true); else RX_PASS3(M, S, false, false); }                                  \
+    if (ff.pqeq) { if (pipe == 2) RX_PASS3(M, S, true, 2); else if (pipe == 1) RX_PASS3(M, S, true, 1); else RX_PASS3(M, S, true, 0); }       \
+    else { if (pipe == 2) RX_PASS3(M, S, false, 2); else if (pipe == 1) RX_PASS3(M, S, false, 1); else RX_PASS3(M, S, false, 0); }           \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }

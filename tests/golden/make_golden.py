@@ -112,6 +112,10 @@ CASES = {
     # other systems and force fields the reference ships under conf/ (10-, 4-, 7- and 5-type ffields), 3 MD steps at tight tolerance
     "fes576_md3":     ("conf/fes.xyz", "conf/ffield_fes", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
     "mos2_216_md3":   ("conf/mos2_ortho.xyz", "conf/ffield_mos2", (2, 1, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
+    # the one non-orthorhombic input the reference ships: conf/init.mos2, 2H-MoS2 in its hexagonal cell (gamma = 120 degrees); 3 x 3 x 2 so that
+    # every box edge exceeds twice the 10 A cutoff.  Exercises the full H / HHi transforms (main.F90:596-616, init.F90:636-668) and the reference's
+    # cell meshes, which are laid out in lattice-vector units (init.F90:530-605)
+    "mos2_tri324_md3": ("conf/mos2_tri.xyz", "conf/ffield_mos2", (3, 3, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
     "sic512_md3":     ("conf/sic.xyz", "ffield_sicnp", (4, 4, 4), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
     "aloslab180_md3": ("conf/aloslab.xyz", "conf/ffield_aloslab", (3, 2, 1), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3),
     # an amorphous polymer cell of the reference's conf/init.a-polys (poly(butylene terephthalate), 2,272 atoms, real coordinates -> fractional

@@ -232,6 +232,9 @@ def make_system(case):
         return ff, names, frac, lat
     conf = {"fes": ("conf/fes.xyz", "conf/ffield_fes"), "mos2": ("conf/mos2_ortho.xyz", "conf/ffield_mos2"), "sic512": ("conf/sic.xyz", "ffield_sicnp"),
             "aloslab": ("conf/aloslab.xyz", "conf/ffield_aloslab")}            # more of the reference's conf/ systems
+    if case.startswith("mos2_tri"):                # the reference's conf/init.mos2 as shipped: hexagonal cell, gamma = 120 degrees
+        names, frac, lat = read_xyz(os.path.join(INP, "conf/mos2_tri.xyz"))
+        return os.path.join(INP, "conf/ffield_mos2"), names, frac, lat
     for k, (x, f) in conf.items():
         if case.startswith(k):
             names, frac, lat = read_xyz(os.path.join(INP, x))

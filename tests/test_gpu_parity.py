@@ -448,6 +448,32 @@ def test_pqeq_md_against_the_reference_on_a_cluster_without_stale_lookups(qeq_mo
     e.close()
 
 
+def test_skewed_box_pair_selection_and_stress_match_the_oracle():
+    """conf/init.mos2 (gamma = 120 degrees) against the oracle, which reproduces the real reference on this input to dump resolution
+    (tests/test_oracle_golden.py): the bonded and 10 A lists hold exactly the reference's pairs (its cell meshes are laid out along the
+    lattice vectors and drop pairs a cutoff sphere would hold), hessian row sums, energies, and the stress accumulators with the
+    torsion image correction along skewed lattice vectors."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    o = _oracle("mos2_tri324", (3, 3, 2), **kw); o.qeq(); o.force()
+    e = _engine("mos2_tri324", (3, 3, 2), **kw)
+    it, est = e.QEq(); pe = e.FORCE(); a = e.atoms()
+    assert (a["gid"] == o.gids()).all()
+    st = e.stats()
+    assert st["natoms"] + st["nghost_force"] == o.L.rxo_nghost_total(o.w, 0)
+    assert (e.debug(2).astype(int) == o.get(103).astype(int)).all()          # bonded neighbour counts, residents and ghosts
+    assert (e.debug(6).astype(int) == o.get(104).astype(int)).all()          # 10 A row lengths
+    assert np.allclose(e.debug(7), o.get(108), rtol=1e-12)                   # hessian row sums
+    assert q_err(a["q"], o.charges()) <= QTOL
+    assert f_err(a["f"], o.forces()) <= FTOL
+    assert e_err(pe, o.energy()) <= ETOL
+    a0, b0 = e.energy()["astr"], o.astr(reset=True)
+    assert np.abs(a0 - b0).max() <= 1e-8 * np.abs(b0).max()
+    e.step(2); o.step(2)
+    a1, b1 = e.energy()["astr"], o.astr(reset=True)
+    assert np.abs(a1 - b1).max() <= 1e-8 * np.abs(b1).max()
+    e.close()
+
+
 def test_stress_accumulators_match_the_oracle():
     """astr(1:6): virial over residents+ghosts before the fold (pot.F90:65-72) + kinetic part per step (main.F90:86-94),
     accumulated between reads like PRINTE; the oracle's values are pinned to the reference's printed pressure column"""
@@ -568,10 +594,13 @@ def test_reference_example3_small_box_pqeq_with_field_against_the_clean_oracle()
     e.close()
 
 
-@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "sic512_md3", "aloslab180_md3", "pbt2272_md2"])
+@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "mos2_tri324_md3", "sic512_md3", "aloslab180_md3", "pbt2272_md2"])
 @pytest.mark.parametrize("qeq_mode", [0, 1])
 def test_other_force_fields_and_systems_the_reference_ships(case, qeq_mode):
-    """pyrite (10-type ffield), MoS2, zinc-blende SiC, an alumina slab and an amorphous polymer cell (PBT, 2,272 atoms) from the reference's conf/: 2-3 MD steps at tight tolerance
+    """mos2_tri324: the one NON-ORTHORHOMBIC input of the reference (conf/init.mos2: hexagonal 2H-MoS2, gamma = 120 degrees, 3 x 3 x 2) -- the
+    full H / HHi transforms, the engine's grid measured perpendicular to the cell faces, and the reference's pair selection through its
+    lattice-vector cell meshes and QEq ghost shell (RefMesh, engine.h).
+    pyrite (10-type ffield), MoS2, zinc-blende SiC, an alumina slab and an amorphous polymer cell (PBT, 2,272 atoms) from the reference's conf/: 2-3 MD steps at tight tolerance
     against the goldens of the real reference (state after the third step: positions, charges, forces)"""
     g = np.load(os.path.join(oa.GOLD, case + ".npz"))
     e = _engine(case, tuple(int(x) for x in g["mc"]), QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=qeq_mode)

@@ -279,7 +279,7 @@ def test_reference_example3_frame_including_its_stale_lookup_artefact():
     assert out[1][0] <= 1e-5 and 1e-3 < out[1][1] <= 3e-2 and out[1][2] <= 2.5e-3
 
 
-@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "sic512_md3", "aloslab180_md3", "pbt2272_md2"])
+@pytest.mark.parametrize("case", ["fes576_md3", "mos2_216_md3", "mos2_tri324_md3", "sic512_md3", "aloslab180_md3", "pbt2272_md2"])
 def test_other_force_fields_and_systems_the_reference_ships(case):
     """conf/init.fes (pyrite, a 10-type ffield), conf/init.mos2.ortho (4 types), conf/init.sic (zinc-blende SiC) and conf/init.aloslab
     (alumina slab, 5 types), conf/init.a-polys/PBT (amorphous poly(butylene terephthalate), 2,272 atoms): ffield parsing, cut-offs and
