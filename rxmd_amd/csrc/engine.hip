@@ -57,6 +57,14 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   for (int a = 0; a < 3; ++a) if (cfg.vprocs[a] < 1) throw EngineError(RXMD_E_ARG, "vprocs must be >= 1");
   nprocs = cfg.vprocs[0] * cfg.vprocs[1] * cfg.vprocs[2];
   if (cfg.myid < 0 || cfg.myid >= nprocs) throw EngineError(RXMD_E_ARG, "myid outside the vprocs grid");
+  {   // a box the H matrix of GetBoxParams (init.F90:610-633) cannot describe: non-positive edge, angle outside (0,180), zero volume
+    const double *L = cfg.lattice, d2r = std::atan(1.0) / 45.0;
+    const double ca = std::cos(L[3] * d2r), cb = std::cos(L[4] * d2r), cg = std::cos(L[5] * d2r);
+    const double v2 = 1.0 - ca * ca - cb * cb - cg * cg + 2.0 * ca * cb * cg;
+    bool ok = L[0] > 0.0 && L[1] > 0.0 && L[2] > 0.0 && v2 > 1e-12;
+    for (int a = 3; a < 6; ++a) ok = ok && L[a] > 0.0 && L[a] < 180.0;
+    if (!ok) throw EngineError(RXMD_E_ARG, "lattice does not span a box (edges must be positive, angles inside (0,180) and not coplanar)");
+  }
   try { ff.parse(ffield_path, cfg.lg != 0); } catch (const std::exception &e) { throw EngineError(RXMD_E_FFIELD, e.what()); }
   // rank grid, reference src/init.F90:74-100
   vID[0] = cfg.myid % cfg.vprocs[0]; vID[1] = (cfg.myid / cfg.vprocs[0]) % cfg.vprocs[1]; vID[2] = cfg.myid / (cfg.vprocs[0] * cfg.vprocs[1]);

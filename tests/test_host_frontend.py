@@ -169,7 +169,7 @@ def test_engine_fails_loudly_without_gpu_or_with_bad_input():
         rxmd_amd.RxmdEngine("/nonexistent/ffield", lat)
     assert ei.value.code == -2
     with pytest.raises(rxmd_amd.RxmdError) as ei:
-        rxmd_amd.RxmdEngine(FF_RDX, [10, 10, 10, 90, 80, 90])
+        rxmd_amd.RxmdEngine(FF_RDX, [10, 10, 10, 60, 60, 150])       # coplanar lattice vectors: no box (skewed boxes as such are fine)
     assert ei.value.code == -1
 
 
