@@ -159,6 +159,7 @@ struct Engine {
   double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
   // 10 A list
   int *nb10 = nullptr, *n10 = nullptr; double *hess = nullptr;
+  int *rowghost = nullptr;     // 1: the row has a ghost partner (a boundary row of the domain); the matrix pass skips the ghost-column sums of the others
   size_t partials_cap = 0;
   // reductions
   double *partials = nullptr;  // [nblocks_red * 16]

@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace rxmd {
 
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
                                                const double *__restrict__ scal, double *__restrict__ partials,
                                                double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
                                                const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
-                                               const int *__restrict__ rowlist, int nrows, int pbase) {
+                                               const int *__restrict__ rowlist, int nrows, int pbase, const int *__restrict__ rowghost) {
   // rowlist != nullptr: this launch covers nrows rows named by the list (interior or boundary rows of a multi-rank domain);
   // its workgroups write their partial sums behind the pbase workgroups of the other launch
   const int lane = threadIdx.x & 63;
@@ -106,6 +107,9 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
     };
     if (PIPE) request(0, S10, e, h, c);
     const int n = n10[row];
+    // plain QEq: the second pair of sums runs over the GHOST columns only; three rows in four of a large domain have none (rowghost,
+    // written by the list sweep) and skip those FMAs and their reduction -- the pass is co-limited by FP64 issue
+    const bool second = (MODE == MODE_GRAD || STORE) && (PQ || !rowghost || rowghost[row] != 0);
     // operands of the row tail, requested before the streams so that they are not a further dependent round trip after the reduction
     const int pf_t = type[row];
     const double2 pf_a = (MODE == MODE_HSH) ? hst[row] : qst[row];
@@ -116,25 +120,29 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 #pragma unroll
       for (int u = 0; u < UNR; ++u) { const bool ok = lane + 64 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; if (PQ) c[u] = ok ? c[u] : 0.0; }
     }
-    for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
-      if (PIPE == 0 || (PIPE == 1 && kb > 0)) request(kb, n, e, h, c);
-      const bool more = kb + 64 * UNR < n;
-      if (PIPE == 2 && more) request(kb + 64 * UNR, n, en, hn, cn);
+    auto sweep = [&](auto sec_tag) {             // the row loop, specialised on whether the ghost-column sums are wanted
+      constexpr bool SEC = decltype(sec_tag)::value;
+      for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
+        if (PIPE == 0 || (PIPE == 1 && kb > 0)) request(kb, n, e, h, c);
+        const bool more = kb + 64 * UNR < n;
+        if (PIPE == 2 && more) request(kb + 64 * UNR, n, en, hn, cn);
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
-        const double2 v = xv[e[u] & NB10_IDX_MASK];
-        as += h[u] * v.x;
-        at += h[u] * v.y;
-        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
-        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }      // PQEq: second matrix (shell-core) over the same columns
-      }
-      if (PIPE == 2 && more) {
+        for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
+          const double2 v = xv[e[u] & NB10_IDX_MASK];
+          as += h[u] * v.x;
+          at += h[u] * v.y;
+          if ((MODE == MODE_GRAD || STORE) && !PQ && SEC) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
+          if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }      // PQEq: second matrix (shell-core) over the same columns
+        }
+        if (PIPE == 2 && more) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) { e[u] = en[u]; h[u] = hn[u]; if (PQ) c[u] = cn[u]; }
+          for (int u = 0; u < UNR; ++u) { e[u] = en[u]; h[u] = hn[u]; if (PQ) c[u] = cn[u]; }
+        }
       }
-    }
+    };
+    if (second) sweep(std::true_type{}); else sweep(std::false_type{});
     as = wave_sum(as); at = wave_sum(at);
-    if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+    if (second) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
     if (lane == 0) {
       if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
       const DevAtomP ap = ff.atom[pf_t];
@@ -446,13 +454,14 @@ void Engine::qeq() {
   const int nred = rb;                                                             // partials one matrix pass leaves
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
+  const int *rg_flag = std::getenv("RXMD_SPMV_ALL_ROWS_GHOST") ? nullptr : rowghost;   // A/B switch: every row forms the ghost-column sums
   int pipe = 1;                                                           // 0 plain loop, 1 first batch ahead of the row length, 2 every batch ahead
   if (std::getenv("RXMD_SPMV_NO_PIPE")) pipe = 0;                         // (read per call: the tests switch it)
   else if (const char *pv = std::getenv("RXMD_SPMV_PIPE")) pipe = std::atoi(pv);
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) {
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return;
-#define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase)
+#define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase, rg_flag)
 #define RX_PASS(M, S)                                                                                                  \
   do {                                                                                                                 \
     if (ff.pqeq) { if (pipe == 2) RX_PASS3(M, S, true, 2); else if (pipe == 1) RX_PASS3(M, S, true, 1); else RX_PASS3(M, S, true, 0); }       \

