@@ -100,6 +100,12 @@ int rxmd_hip_force(rxmd_handle h, double pe[14]);
  * QEq every qstep, FORCE, vkick); mdmode 1 (NVE).  Call rxmd_hip_qeq + rxmd_hip_force once before
  * the first step, as main.F90:27-32 does. */
 int rxmd_hip_step(rxmd_handle h, int nsteps);
+/* mdmode 10: the reference's geometry minimiser (ConjugateGradient, src/cg.F90:26-98 -- Polak-Ribiere directions, bracketing by the
+ * Armijo rule, golden-section line search, every trial point a COPYATOMS(MODE_MOVE) + QEq + FORCE) on the device-resident state:
+ * positions, search direction and gradients never leave HBM.  ftol = rxmd.in `CG_tol` (energy criterion per atom), max_loops =
+ * CG_MaxMinLoop (500).  Returns the number of CG loops (>= 0) or an error; *pe = final potential energy, *evaluations = QEq+FORCE
+ * pairs spent.  Velocities are zero afterwards, as the reference leaves them (cg.F90:39). */
+int rxmd_hip_minimise(rxmd_handle h, double ftol, int max_loops, double *pe, long long *evaluations);
 /* nstep_qeq of the last QEq call (printed in the MDstep line, src/main.F90:261); negative = error */
 int rxmd_hip_last_qeq_iters(rxmd_handle h);
 /* The velocity scaling the reference's MD loop applies at its head when mod(nstep,sstep)==0 (src/main.F90:45-61), on the

@@ -70,6 +70,7 @@ SYMBOLS = [
     ("rxmd_hip_FORCE_pqeq", C.c_int, [H, C.c_int, C.c_int, PD, PD, PD, PD, PD, PD]),
     ("rxmd_hip_put_lex", C.c_int, [H, C.c_int, PD, PD]),
     ("rxmd_hip_get_lex", C.c_int, [H, C.c_int, PD, PD]),
+    ("rxmd_hip_minimise", C.c_int, [H, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     ("rxmd_hip_last_qeq_iters", C.c_int, [H]),
     ("rxmd_hip_thermostat", C.c_int, [H, C.c_int, C.c_double, C.c_double, C.c_double]),
     ("rxmd_hip_rccl_unique_id", C.c_int, [C.c_char_p]),

@@ -189,6 +189,12 @@ int rxmd_hip_step(rxmd_handle h, int nsteps) {
   });
 }
 
+int rxmd_hip_minimise(rxmd_handle h, double ftol, int max_loops, double *pe, long long *evaluations) {
+  int loops = 0;
+  const int rc = guarded(h, [&](Engine &e) { loops = e.minimise(ftol, max_loops > 0 ? max_loops : 500, pe, evaluations); });
+  return rc ? rc : loops;
+}
+
 int rxmd_hip_last_qeq_iters(rxmd_handle h) {
   int n = 0;
   const int rc = guarded(h, [&](Engine &e) { n = e.nstep_qeq; });

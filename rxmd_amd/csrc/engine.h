@@ -159,7 +159,6 @@ struct Engine {
   double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
   // 10 A list
   int *nb10 = nullptr, *n10 = nullptr; double *hess = nullptr;
-  int *rowghost = nullptr;     // 1: the row has a ghost partner (a boundary row of the domain); the matrix pass skips the ghost-column sums of the others
   size_t partials_cap = 0;
   // reductions
   double *partials = nullptr;  // [nblocks_red * 16]
@@ -205,6 +204,7 @@ struct Engine {
   void step(int nsteps);
   void migrate();                  // COPYATOMS(MODE_MOVE)
   void thermostat(int mdmode, double treq_K, double vsfact, double gke);   // velocity scaling of the MD loop head (assemble.hip)
+  int minimise(double ftol, int max_loops, double *pe_final, long long *evaluations);   // mdmode 10: the reference's conjugate-gradient minimiser (minimise.hip)
 
   // pieces (each in its own .hip)
   void setup_after_atoms(const std::vector<long long> &natoms_per_type_global);

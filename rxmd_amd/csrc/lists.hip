@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
                                                  int *__restrict__ nb10, double *__restrict__ hess, int *__restrict__ n10, int *err,
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
-                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag, int *__restrict__ rowghost) {
+                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag) {
   __shared__ int s_q[4][128];            // accepted candidates: sorted position
   __shared__ int s_P[4][32], s_K[4][32];  // per stencil column: candidates before it / first sorted position of its run
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
     if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) hsc[row + cnt + lane] = 0.0;
     if (lane == 0) pqrow[i] = make_double4(p_f, p_hz, p_bz, p_ss);
   }
-  { const unsigned long long mg = __ballot(anyghost); if (lane == 0) { rowghost[i] = (mg != 0ULL) ? 1 : 0; if (rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0; } }
+  { const unsigned long long mg = __ballot(anyghost); if (lane == 0 && rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0; }
   if (lane == 0) n10[i] = cnt;
 }
 
@@ -376,7 +376,7 @@ void Engine::build_list10() {
   const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);
 #define RX_LIST10(SC, PQF)                                                                                                                     \
   k_list10<SC, PQF><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
-                                                    nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr, rowghost)
+                                                    nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
 #undef RX_LIST10

@@ -66,13 +66,14 @@ __device__ inline double pq_est_row(const DevAtomP &ap, double Zi, const double4
 // length, (b) four batches of 64 entries are in flight instead of eight, which brings the kernel from 99 to <= 80 VGPRs and from
 // 4 to 6 wavefronts per SIMD (measured on one box: 1.276 ms -> 1.21 with (a), 1.157 with (b), 1.06-1.12 with both), (c) PQEq is
 // a template parameter so that the plain kernel does not carry its code.
-// PIPE (default; RXMD_SPMV_NO_PIPE=1 switches it off): the loop is software-pipelined over the row's batches of 256 entries.  The first
-// batch of the two streams is requested BEFORE the row length is known (it lies inside the row's S10-entry slot whatever the length;
-// entries behind the row's end get weight 0 once the length has arrived), and batch b+1 is requested before the gathers of batch b
-// are issued: a wavefront waits for two dependent round trips less (measured on one box: 0.98 -> 0.93 ms per pass with the first
-// step alone).  What did NOT help once the chain was shorter: a 16-bit column stream (stencil column + offset, 10 instead of 12 bytes
-// per entry: 0.968 vs 0.988 ms without the pipelining, 0.931 vs 0.921 ms with it) -- the pass is bound by the latency chain of a
-// million short wavefronts, not by the bytes of the streams.
+// PIPE (default; RXMD_SPMV_NO_PIPE=1 switches it off): the first batch of the two streams is requested BEFORE the row length is known (it lies
+// inside the row's S10-entry slot whatever the length; entries behind the row's end get weight 0 once the length has arrived), one
+// dependent round trip less per wavefront.  Measured 0.98 -> 0.93 ms per pass on one box and no difference on another (0.941 / 0.949 /
+// 0.938): the pass is insensitive to its latency chain.  It is insensitive to the BYTES of its streams too: a 16-bit column stream
+// (stencil column + offset in the column's run, 10 instead of 12 bytes per entry) gave 0.968 vs 0.988 ms without the early request and
+// 0.931 vs 0.921 ms with it; requesting every batch ahead of the previous one's gathers, a tighter row stride (448 or 512 instead of
+// 640 entries) and skipping the ghost-column sums on the three rows in four that have no ghost partner (7 % SLOWER: the flag is one
+// more scalar round trip in front of the loop) changed nothing or lost.  All were dropped again; see DESIGN.md 3.
 template <int MODE, bool STORE, bool PQ, int PIPE>
 __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
                                                const double *__restrict__ scal, double *__restrict__ partials,
                                                double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
                                                const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
-                                               const int *__restrict__ rowlist, int nrows, int pbase, const int *__restrict__ rowghost) {
+                                               const int *__restrict__ rowlist, int nrows, int pbase) {
   // rowlist != nullptr: this launch covers nrows rows named by the list (interior or boundary rows of a multi-rank domain);
   // its workgroups write their partial sums behind the pbase workgroups of the other launch
   const int lane = threadIdx.x & 63;
@@ -92,8 +93,8 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (row < N) {
     const size_t base = static_cast<size_t>(row) * S10;
-    unsigned e[UNR], en[UNR];
-    double h[UNR], hn[UNR], c[UNR], cn[UNR];
+    unsigned e[UNR];
+    double h[UNR], c[UNR];
     // one batch of the row's streams (entry, hessian value, PQEq: shell-core value) for entries [kb, kb + 256) below `bound`
     auto request = [&](int kb, int bound, unsigned (&ee)[UNR], double (&hh)[UNR], double (&cc)[UNR]) {
 #pragma unroll
@@ -107,9 +108,6 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
     };
     if (PIPE) request(0, S10, e, h, c);
     const int n = n10[row];
-    // plain QEq: the second pair of sums runs over the GHOST columns only; three rows in four of a large domain have none (rowghost,
-    // written by the list sweep) and skip those FMAs and their reduction -- the pass is co-limited by FP64 issue
-    const bool second = (MODE == MODE_GRAD || STORE) && (PQ || !rowghost || rowghost[row] != 0);
     // operands of the row tail, requested before the streams so that they are not a further dependent round trip after the reduction
     const int pf_t = type[row];
     const double2 pf_a = (MODE == MODE_HSH) ? hst[row] : qst[row];
@@ -120,29 +118,19 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 #pragma unroll
       for (int u = 0; u < UNR; ++u) { const bool ok = lane + 64 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; if (PQ) c[u] = ok ? c[u] : 0.0; }
     }
-    auto sweep = [&](auto sec_tag) {             // the row loop, specialised on whether the ghost-column sums are wanted
-      constexpr bool SEC = decltype(sec_tag)::value;
-      for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
-        if (PIPE == 0 || (PIPE == 1 && kb > 0)) request(kb, n, e, h, c);
-        const bool more = kb + 64 * UNR < n;
-        if (PIPE == 2 && more) request(kb + 64 * UNR, n, en, hn, cn);
+    for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
+      if (PIPE == 0 || (PIPE == 1 && kb > 0)) request(kb, n, e, h, c);
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
-          const double2 v = xv[e[u] & NB10_IDX_MASK];
-          as += h[u] * v.x;
-          at += h[u] * v.y;
-          if ((MODE == MODE_GRAD || STORE) && !PQ && SEC) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
-          if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }      // PQEq: second matrix (shell-core) over the same columns
-        }
-        if (PIPE == 2 && more) {
-#pragma unroll
-          for (int u = 0; u < UNR; ++u) { e[u] = en[u]; h[u] = hn[u]; if (PQ) c[u] = cn[u]; }
-        }
+      for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
+        const double2 v = xv[e[u] & NB10_IDX_MASK];
+        as += h[u] * v.x;
+        at += h[u] * v.y;
+        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
+        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }      // PQEq: second matrix (shell-core) over the same columns
       }
-    };
-    if (second) sweep(std::true_type{}); else sweep(std::false_type{});
+    }
     as = wave_sum(as); at = wave_sum(at);
-    if (second) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+    if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
     if (lane == 0) {
       if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
       const DevAtomP ap = ff.atom[pf_t];
@@ -454,18 +442,15 @@ void Engine::qeq() {
   const int nred = rb;                                                             // partials one matrix pass leaves
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
-  const int *rg_flag = std::getenv("RXMD_SPMV_ALL_ROWS_GHOST") ? nullptr : rowghost;   // A/B switch: every row forms the ghost-column sums
-  int pipe = 1;                                                           // 0 plain loop, 1 first batch ahead of the row length, 2 every batch ahead
-  if (std::getenv("RXMD_SPMV_NO_PIPE")) pipe = 0;                         // (read per call: the tests switch it)
-  else if (const char *pv = std::getenv("RXMD_SPMV_PIPE")) pipe = std::atoi(pv);
+  const bool pipe = (std::getenv("RXMD_SPMV_NO_PIPE") == nullptr);        // read per call: the tests switch it
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) {
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return;
-#define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase, rg_flag)
+#define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase)
 #define RX_PASS(M, S)                                                                                                  \
   do {                                                                                                                 \
-    if (ff.pqeq) { if (pipe == 2) RX_PASS3(M, S, true, 2); else if (pipe == 1) RX_PASS3(M, S, true, 1); else RX_PASS3(M, S, true, 0); }       \
-    else { if (pipe == 2) RX_PASS3(M, S, false, 2); else if (pipe == 1) RX_PASS3(M, S, false, 1); else RX_PASS3(M, S, false, 0); }           \
+    if (ff.pqeq) { if (pipe) RX_PASS3(M, S, true, 1); else RX_PASS3(M, S, true, 0); }                                  \
+    else { if (pipe) RX_PASS3(M, S, false, 1); else RX_PASS3(M, S, false, 0); }                                        \
   } while (0)
     if (mode == MODE_HSH) { if (store) RX_PASS(MODE_HSH, true); else RX_PASS(MODE_HSH, false); }
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }

@@ -153,6 +153,12 @@ class RxmdEngine:
         """nsteps passes of the MD loop body, reference src/main.F90:64-98"""
         self._chk(self.L.rxmd_hip_step(self.h, int(nsteps)))
 
+    def minimise(self, ftol=1e-4, max_loops=500):
+        """mdmode 10, the reference's ConjugateGradient (src/cg.F90:26-98) on the device-resident state -> (CG loops, final PE, QEq+FORCE evaluations)"""
+        pe = C.c_double(0); ev = C.c_longlong(0)
+        loops = self._chk(self.L.rxmd_hip_minimise(self.h, float(ftol), int(max_loops), C.byref(pe), C.byref(ev)))
+        return loops, pe.value, ev.value
+
     def energy(self):
         ke = C.c_double(0); qs = C.c_double(0); pe = np.zeros(14); astr = np.zeros(6)
         self._chk(self.L.rxmd_hip_get_energy(self.h, C.byref(ke), C.byref(qs), _ptr(pe), _ptr(astr)))

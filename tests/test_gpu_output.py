@@ -67,3 +67,25 @@ def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, t
     assert (np.abs(a[:, 8] - b[:, 8]) / np.maximum(np.abs(b[:, 8]), qrms)).max() <= 1e-6
     # qsfv += 0.5 dt Lex_w2 (q - qsfp) with 0.5 dt Lex_w2 = Lex_k / dt = 391 in the reference's time unit: the 1e-7 CG noise of the charges, amplified
     assert np.abs(a[:, 9] - b[:, 9]).max() <= 2e-5 * np.abs(b[:, 9]).max()
+
+
+def test_device_resident_minimiser_finds_the_references_minimum():
+    """mdmode 10 on the device-resident primitive (rxmd_hip_minimise = ConjugateGradient of src/cg.F90 restated over HBM-resident
+    positions, directions and gradients; every trial point is migrate + QEq + FORCE on the device): RDX-168 with CG_tol 1e-5 at
+    tight QEq tolerance against the structure the unmodified reference writes when its own minimiser has converged.  The golden-section
+    search stops at a relative step tolerance of 1e-6 (cg.F90:16), so two runs of the same algorithm agree to ~1e-4 A."""
+    g = np.load(os.path.join(oa.GOLD, "rdx168_minimiser.npz"))
+    e = _engine("rdx168", (1, 1, 1), QEq_tol=1e-12, NMAXQEq=2000)
+    e0 = e.FORCE()[0] if e.QEq() else None
+    loops, pe, evals = e.minimise(ftol=1e-5)
+    assert 1 <= loops < 500 and evals > 10
+    assert pe < e0 - 1.0                                        # it went downhill (kcal/mol for the whole cell)
+    a = e.atoms()
+    theirs = str(g["xyz"]).split("\n")[2:-1]
+    ids = np.array([int(l[47:]) for l in theirs]); ref = np.array([[float(x) for x in l[3:39].split()] for l in theirs]); qref = np.array([float(l[39:47]) for l in theirs])
+    o = np.argsort(a["gid"]); ro = np.argsort(ids)
+    assert (a["gid"][o] == ids[ro]).all()
+    assert np.abs(a["pos"][o] - ref[ro]).max() <= 3e-4
+    assert np.abs(a["q"][o] - qref[ro]).max() <= 1.1e-3
+    assert np.abs(a["v"]).max() == 0.0
+    e.close()
