@@ -562,335 +562,6 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Torsions ONCE.  k_e4b above evaluates every torsion i-j-k-l from both ends because a centre atom can only write the slots of its own
-// bonds.  Of the terms of one torsion (pot.F90:1178-1194) that restriction really binds two: the force on l and the coefficient of
-// bond k-l live in slot (k, l1), which belongs to the wavefront of k.  Everything else has a home among j's own slots -- the force on
-// k is "the force on the neighbour in slot k1", cdbnd(k) goes through cdn(j, k1).  So the wavefront of j evaluates its centre bonds
-// in the reference's orientation gid(j) < gid(k) only, books i, j, k and the bonds i-j, j-k itself, sums the (k, l1) terms over i in
-// LDS, and leaves them in a MAILBOX addressed by (j, centre bond, l): one writer per record, no atomics.  k_e4b_collect then lets
-// every atom k (ghosts included: the reference scatters onto ghosts and folds them back, comm.F90:385-396) pick up the records its
-// neighbours j < k left for it and add them to its own slots.  Forces land on the same local indices as in the reference, so the
-// virial sum needs no image correction.  Half the torsions of k_e4b, half its enumeration.
-// Bounds: E4_CM centre bonds per atom, E4_LM l-entries per centre bond in the mailbox; what does not fit (never seen in the
-// reference's systems: RDX needs 5 and 7) goes to (k, l1) with global atomics instead.
-constexpr int E4_CM = 6, E4_LM = 8;
-__global__ void __launch_bounds__(256, E4B_MINB) k_e4b_once(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
-                                              const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                                              const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
-                                              const double *__restrict__ etor, const double *__restrict__ econ,
-                                              double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cdn,
-                                              double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe,
-                                              int *__restrict__ mb_k1, int *__restrict__ mb_l1, double *__restrict__ mb_val) {
-  __shared__ double s_bo[4][64], s_et[4][64], s_ec[4][64], s_rx[4][64], s_ry[4][64], s_rz[4][64], s_rn[4][64];
-  __shared__ int s_nb[4][64], s_ty[4][64];
-  __shared__ double s_btb2[4][64], s_dfn11[4][64];
-  __shared__ int s_nk[4][64], s_c[4][64];        // s_nk = 0: no torsion through this bond; s_c: its mailbox row (-1: does not fit)
-  __shared__ unsigned s_lm[4][64];               // per centre bond: which slots of k carry a bond above the cut-off (ranks name the mailbox entries)
-  __shared__ int s_q[4][128];
-  __shared__ double s_acc[4][64][7];
-  __shared__ double s_kl[4][2][E4_CM][E4_LM][4]; // per (atom g, centre bond, l): coefficient of bond k-l and force on l, summed over i
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int jbase = (blockIdx.x * 4 + w) * 2;
-  if (jbase >= N) return;
-  const int g_me = lane >> 5, sl_me = lane & 31;
-  const int j_me = jbase + g_me;
-  const bool has_me = j_me < N;
-  const int nj_me = has_me ? min(nbrcnt[j_me], WSLOT) : 0;
-  const int tj_me = has_me ? type[j_me] : 1;
-  const double xj_me = has_me ? x[j_me] : 0.0, yj_me = has_me ? y[j_me] : 0.0, zj_me = has_me ? z[j_me] : 0.0;
-  s_nk[w][lane] = 0; s_c[w][lane] = -1; s_lm[w][lane] = 0u;
-  bool centre = false;
-  if (sl_me < nj_me) {
-    const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
-    const int i = nbr[o], ti = type[i];
-    const double rx = x[i] - xj_me, ry = y[i] - yj_me, rz = z[i] - zj_me;
-    const double b = bo0[o];
-    s_nb[w][lane] = i; s_ty[w][lane] = ti;
-    s_bo[w][lane] = b; s_et[w][lane] = etor[o]; s_ec[w][lane] = econ[o];
-    s_rx[w][lane] = rx; s_ry[w][lane] = ry; s_rz[w][lane] = rz; s_rn[w][lane] = sqrt(rx * rx + ry * ry + rz * rz);
-    if (b > cutof2_esub && gid[j_me] < gid[i]) {                    // a centre bond j-k in the reference's orientation (pot.F90:1021-1023)
-      const DevAtomP aj = ff.atom[tj_me];
-      const double delta_ang_jk = (delta[j_me] + aj.Val - aj.Valangle) + (delta[i] + ff.atom[ti].Val - ff.atom[ti].Valangle);
-      const double exp_tor3 = exp(-ff.ptor3 * delta_ang_jk), exp_tor4 = exp(ff.ptor4 * delta_ang_jk);
-      const double exp_tor34_i = 1.0 / (1.0 + exp_tor3 + exp_tor4);
-      const double fn11 = (2.0 + exp_tor3) * exp_tor34_i;
-      s_dfn11[w][lane] = (-ff.ptor3 * exp_tor3 + (ff.ptor3 * exp_tor3 - ff.ptor4 * exp_tor4) * (2.0 + exp_tor3) * exp_tor34_i) * exp_tor34_i;
-      s_btb2[w][lane] = 2.0 - bo2[o] - fn11;
-      s_nk[w][lane] = nbrcnt[i];
-      centre = true;
-    }
-  }
-  {                                               // mailbox row of every centre bond: its rank among the centre bonds of its atom
-    const unsigned long long mc = __ballot(centre);
-    const unsigned half = static_cast<unsigned>(g_me ? (mc >> 32) : (mc & 0xffffffffULL));
-    if (centre) { const int c = __popc(half & ((1u << sl_me) - 1u)); s_c[w][lane] = c < E4_CM ? c : -1; }
-  }
-  for (int t = lane; t < 2 * E4_CM * E4_LM * 4; t += 64) (&s_kl[w][0][0][0][0])[t] = 0.0;
-#pragma unroll
-  for (int c = 0; c < 7; ++c) s_acc[w][lane][c] = 0.0;
-  wave_lds_sync();
-  const int njg[2] = {__shfl(nj_me, 0, 64), __shfl(nj_me, 32, 64)};
-  const int tjg[2] = {__shfl(tj_me, 0, 64), __shfl(tj_me, 32, 64)};
-  double e8 = 0.0, e9 = 0.0;
-  int qn = 0;
-
-  auto evaluate = [&](int cnt) {                  // phase B: the first cnt (<= 64) queue entries, one per lane
-    double o[7] = {0, 0, 0, 0, 0, 0, 0};
-    V3 fself = {0.0, 0.0, 0.0}, fkk = {0.0, 0.0, 0.0}, fll = {0.0, 0.0, 0.0};
-    double cd_self = 0.0, cfkl = 0.0;
-    int key = -1;
-    size_t ol = 0;
-    if (lane < cnt) {
-      key = s_q[w][lane];
-      const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31, l1 = key & 31;
-      const int sk = g * 32 + k1, si = g * 32 + i1;
-      const int k = s_nb[w][sk], tk = s_ty[w][sk], tj = tjg[g];
-      const double BOjk_f = s_bo[w][sk], BOij_f = s_bo[w][si];
-      const double BOjk = BOjk_f - cutof2_esub, BOij = BOij_f - cutof2_esub;
-      ol = static_cast<size_t>(l1) * NB + k;
-      const int l = nbr[ol];
-      const int inxn = ff.inxn4[((s_ty[w][si] * ff.n1 + tj) * ff.n1 + tk) * ff.n1 + type[l]];
-      const DevTorsP tp = ff.tors[inxn];
-      const V3 rjk = {-s_rx[w][sk], -s_ry[w][sk], -s_rz[w][sk]};          // r_j - r_k
-      const double njk = s_rn[w][sk];
-      const V3 rij = {s_rx[w][si], s_ry[w][si], s_rz[w][si]};
-      const double nij = s_rn[w][si];
-      const V3 rkl = {x[k] - x[l], y[k] - y[l], z[k] - z[l]};                 // r_k - r_l
-      const double nkl = sqrt(dot(rkl, rkl));
-      const double inij = 1.0 / nij, injk = 1.0 / njk, inkl = 1.0 / nkl;
-      double cos_ijk = -dot(rij, rjk) * (inij * injk);
-      if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
-      if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
-      const double sin_ijk = sqrt((1.0 - cos_ijk) * (1.0 + cos_ijk));
-      const double tan_ijk_i = cos_ijk / sin_ijk;
-      const V3 n1v = {rij.x * inij, rij.y * inij, rij.z * inij}, n2v = {rjk.x * injk, rjk.y * injk, rjk.z * injk}, n3v = {rkl.x * inkl, rkl.y * inkl, rkl.z * inkl};
-      const V3 c1v = {n1v.y * n2v.z - n1v.z * n2v.y, n1v.z * n2v.x - n1v.x * n2v.z, n1v.x * n2v.y - n1v.y * n2v.x};
-      const V3 c2v = {n2v.y * n3v.z - n2v.z * n3v.y, n2v.z * n3v.x - n2v.x * n3v.z, n2v.x * n3v.y - n2v.y * n3v.x};
-      double nc1 = sqrt(dot(c1v, c1v)), nc2 = sqrt(dot(c2v, c2v));
-      if (nc1 < NSMALL) nc1 = NSMALL;
-      if (nc2 < NSMALL) nc2 = NSMALL;
-      const double BOkl = bo0[ol] - cutof2_esub;
-      const double et1 = s_et[w][si], et2 = s_et[w][sk], et3 = etor[ol];
-      const double fn10 = (1.0 - et1) * (1.0 - et2) * (1.0 - et3);
-      const double fn12 = s_ec[w][si] * s_ec[w][sk] * econ[ol];
-      const double btb2 = s_btb2[w][sk];
-      const double exp_tor1 = exp(tp.ptor1 * (btb2 * btb2));
-      double cos_jkl = -dot(rjk, rkl) * (injk * inkl);
-      if (cos_jkl > MAXANGLE) cos_jkl = MAXANGLE;
-      if (cos_jkl < MINANGLE) cos_jkl = MINANGLE;
-      const double sin_jkl = sqrt((1.0 - cos_jkl) * (1.0 + cos_jkl));
-      const double tan_jkl_i = cos_jkl / sin_jkl;
-      double c1 = dot(c1v, c2v) / (nc1 * nc2);
-      if (c1 > MAXANGLE) c1 = MAXANGLE;
-      if (c1 < MINANGLE) c1 = MINANGLE;
-      const double c1sq = c1 * c1;
-      const double cos_2w = 2.0 * c1sq - 1.0;
-      const double c2 = 1.0 - cos_2w, c3 = 1.0 + (4.0 * c1sq - 3.0) * c1;
-      const double vsum = tp.V1 * (1.0 + c1) + tp.V2 * exp_tor1 * c2 + tp.V3 * c3;
-      const double ss = sin_ijk * sin_jkl;
-      const double PEconj = tp.pcot1 * fn12 * (1.0 + (c1sq - 1.0) * ss);
-      e8 += 0.5 * fn10 * ss * vsum; e9 += PEconj;
-      const double CEt1 = 0.5 * ss * vsum;
-      const double CEt2 = -tp.ptor1 * fn10 * ss * tp.V2 * exp_tor1 * btb2 * c2;
-      const double CEt3 = CEt2 * s_dfn11[w][sk];
-      const double CEt4 = CEt1 * ff.ptor2 * et1 * (1.0 - et2) * (1.0 - et3);
-      const double CEt5 = CEt1 * ff.ptor2 * (1.0 - et1) * et2 * (1.0 - et3);
-      const double CEt6 = CEt1 * ff.ptor2 * (1.0 - et1) * (1.0 - et2) * et3;
-      const double cmn = -0.5 * fn10 * vsum;
-      const double CEt7 = cmn * sin_jkl * tan_ijk_i, CEt8 = cmn * sin_ijk * tan_jkl_i;
-      const double CEt9 = fn10 * ss * (0.5 * tp.V1 - 2.0 * tp.V2 * exp_tor1 * c1 + 1.5 * tp.V3 * (cos_2w + 2.0 * c1sq));
-      const double Cconj = -2.0 * ff.pcot2 * PEconj;
-      const double CEc1 = Cconj * (BOij - 1.5), CEc2 = Cconj * (BOjk - 1.5), CEc3 = Cconj * (BOkl - 1.5);
-      const double CEc4 = -tp.pcot1 * fn12 * (c1sq - 1.0) * tan_ijk_i * sin_jkl;
-      const double CEc5 = -tp.pcot1 * fn12 * (c1sq - 1.0) * sin_ijk * tan_jkl_i;
-      const double CEc6 = 2.0 * tp.pcot1 * fn12 * c1 * ss;
-      o[0] = CEc1 + CEt4;                                                   // ForceB(i-j, C4body_b(1))
-      o[4] = CEc2 + CEt5; o[5] = CEt2; o[6] = CEt3; cd_self = CEt3;         // ForceBbo(j-k), cdbnd(k), cdbnd(j)   (pot.F90:1178-1194)
-      cfkl = CEc3 + CEt6;                                                   // ForceB(k-l, C4body_b(3))
-      // angle i-j-k: forces on i and k, the centre j takes the rest (ForceA3)
-      V3 fi, fk;
-      angle_forces(CEc4 + CEt7, rij, nij, rjk, njk, fi, fk);
-      o[1] = fi.x; o[2] = fi.y; o[3] = fi.z;
-      fkk = fk;
-      fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z;
-      // angle j-k-l: forces on j and l, the centre k takes the rest
-      V3 fj2, fl2;
-      angle_forces(CEc5 + CEt8, rjk, njk, rkl, nkl, fj2, fl2);
-      fself.x += fj2.x; fself.y += fj2.y; fself.z += fj2.z;
-      fll = fl2;
-      fkk.x -= fj2.x + fl2.x; fkk.y -= fj2.y + fl2.y; fkk.z -= fj2.z + fl2.z;
-      // dihedral (ForceA4, pot.F90:1369-1459): i: fij, j: -fij + fjk, k: -fjk + fkl, l: -fkl
-      {
-        const double coeff = CEc6 + CEt9;
-        const double C00 = nij * nij, C01 = dot(rij, rjk), C02 = dot(rij, rkl), C11 = njk * njk, C12 = dot(rjk, rkl), C22 = nkl * nkl;
-        const double D0 = C00 * C11 - C01 * C01, Dm1 = C11 * C22 - C12 * C12;
-        const double coDD = coeff * (1.0 / sqrt(D0 * Dm1));
-        const double com = C01 * C12 - C02 * C11;
-        const double cD0 = com / D0, cDm = com / Dm1;
-        const double Cwi1 = C11 * cD0, Cwi2 = -(C12 + C01 * cD0), Cwi3 = C11;
-        const double Cwj1 = -(C12 + (C11 + C01) * cD0);
-        const double Cwj2 = -(-C12 - 2 * C02 - C22 * cDm - (C00 + C01) * cD0);
-        const double Cwj3 = -(C01 + C11 + C12 * cDm);
-        const double Cwl1 = -C11, Cwl2 = C01 + C12 * cDm, Cwl3 = -(C11 * cDm);
-        const V3 fij = {coDD * (Cwi1 * rij.x + Cwi2 * rjk.x + Cwi3 * rkl.x), coDD * (Cwi1 * rij.y + Cwi2 * rjk.y + Cwi3 * rkl.y),
-                        coDD * (Cwi1 * rij.z + Cwi2 * rjk.z + Cwi3 * rkl.z)};
-        const V3 fjk = {coDD * ((Cwj1 + Cwi1) * rij.x + (Cwj2 + Cwi2) * rjk.x + (Cwj3 + Cwi3) * rkl.x),
-                        coDD * ((Cwj1 + Cwi1) * rij.y + (Cwj2 + Cwi2) * rjk.y + (Cwj3 + Cwi3) * rkl.y),
-                        coDD * ((Cwj1 + Cwi1) * rij.z + (Cwj2 + Cwi2) * rjk.z + (Cwj3 + Cwi3) * rkl.z)};
-        const V3 fkl = {-coDD * (Cwl1 * rij.x + Cwl2 * rjk.x + Cwl3 * rkl.x), -coDD * (Cwl1 * rij.y + Cwl2 * rjk.y + Cwl3 * rkl.y),
-                        -coDD * (Cwl1 * rij.z + Cwl2 * rjk.z + Cwl3 * rkl.z)};
-        o[1] += fij.x; o[2] += fij.y; o[3] += fij.z;
-        fself.x += -fij.x + fjk.x; fself.y += -fij.y + fjk.y; fself.z += -fij.z + fjk.z;
-        fkk.x += -fjk.x + fkl.x; fkk.y += -fjk.y + fkl.y; fkk.z += -fjk.z + fkl.z;
-        fll.x -= fkl.x; fll.y -= fkl.y; fll.z -= fkl.z;
-      }
-    }
-    if (key >= 0) {
-      const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31, l1 = key & 31;
-      double *ai = &s_acc[w][g * 32 + i1][0], *ak = &s_acc[w][g * 32 + k1][0], *as = &s_acc[w][g * 32 + 31][0];
-      atomicAdd(ai + 0, o[0]); atomicAdd(ai + 1, o[1]); atomicAdd(ai + 2, o[2]); atomicAdd(ai + 3, o[3]);
-      atomicAdd(ak + 1, fkk.x); atomicAdd(ak + 2, fkk.y); atomicAdd(ak + 3, fkk.z);
-      atomicAdd(ak + 4, o[4]); atomicAdd(ak + 5, o[5]); atomicAdd(ak + 6, o[6]);
-      atomicAdd(as + 1, fself.x); atomicAdd(as + 2, fself.y); atomicAdd(as + 3, fself.z); atomicAdd(as + 6, cd_self);
-      const int c = s_c[w][g * 32 + k1];
-      const int m = __popc(s_lm[w][g * 32 + k1] & ((1u << l1) - 1u));
-      if (c >= 0 && m < E4_LM) {
-        double *kl = &s_kl[w][g][c][m][0];
-        atomicAdd(kl + 0, cfkl); atomicAdd(kl + 1, fll.x); atomicAdd(kl + 2, fll.y); atomicAdd(kl + 3, fll.z);
-      } else {                                      // does not fit the mailbox: straight to slot (k, l1)
-        atomicAdd(cf1 + ol, cfkl); atomicAdd(fnx + ol, fll.x); atomicAdd(fny + ol, fll.y); atomicAdd(fnz + ol, fll.z);
-      }
-    }
-    wave_lds_sync();
-  };
-
-  // phase A: enumerate, filter, compact
-  for (int g = 0; g < 2; ++g) {
-    const int nj = njg[g];
-    for (int k1 = 0; k1 < nj; ++k1) {
-      const int sk = g * 32 + k1;
-      const int nk = s_nk[w][sk];
-      if (nk == 0) continue;
-      const double BOjk_f = s_bo[w][sk];
-      const int k = s_nb[w][sk], j = jbase + g;
-      const int nkc = min(nk, WSLOT);
-      {                                             // which slots of k hold a bond above the cut-off: their ranks address the mailbox
-        const bool capl = (lane < nkc) && (bo0[static_cast<size_t>(lane) * NB + k] > cutof2_esub);
-        const unsigned long long ml = __ballot(capl);
-        if (lane == 0) s_lm[w][sk] = static_cast<unsigned>(ml & 0xffffffffULL);
-      }
-      const int total = nj * nkc;
-      for (int c0 = 0; c0 < total; c0 += 64) {
-        const int c = c0 + lane;
-        bool go = false;
-        int i1 = 0, l1 = 0;
-        if (c < total) {
-          i1 = c / nkc; l1 = c - i1 * nkc;
-          const double BOij_f = s_bo[w][g * 32 + i1];
-          const int i = s_nb[w][g * 32 + i1];
-          const size_t ol = static_cast<size_t>(l1) * NB + k;
-          const double BOkl_f = bo0[ol];
-          go = (i1 != k1) && (BOij_f > cutof2_esub) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
-               (BOkl_f > cutof2_esub) && (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0);
-          if (go) {
-            const int l = nbr[ol];
-            go = (l != i) && (l != j) && (ff.inxn4[((s_ty[w][g * 32 + i1] * ff.n1 + tjg[g]) * ff.n1 + s_ty[w][sk]) * ff.n1 + type[l]] != 0);
-          }
-        }
-        const unsigned long long m = __ballot(go);
-        if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
-        qn += __popcll(m);
-        wave_lds_sync();
-        if (qn >= 64) {
-          evaluate(64);
-          const int rest = qn - 64;
-          const int v = (lane < rest) ? s_q[w][64 + lane] : 0;
-          wave_lds_sync();
-          if (lane < rest) s_q[w][lane] = v;
-          wave_lds_sync();
-          qn = rest;
-        }
-      }
-    }
-  }
-  if (qn > 0) evaluate(qn);
-
-  wave_lds_sync();
-  const double a_cf = s_acc[w][lane][0], a_fx = s_acc[w][lane][1], a_fy = s_acc[w][lane][2], a_fz = s_acc[w][lane][3];
-  const double a_cjk1 = s_acc[w][lane][4], a_cjk2 = s_acc[w][lane][5], a_cdk = s_acc[w][lane][6];
-  if (sl_me < nj_me) {
-    const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
-    if (a_cf != 0.0 || a_cjk1 != 0.0) cf1[o] += a_cf + a_cjk1;
-    if (a_cjk2 != 0.0) cf2[o] += a_cjk2;
-    if (a_cdk != 0.0) cdn[o] += a_cdk;
-    if (a_fx != 0.0 || a_fy != 0.0 || a_fz != 0.0) { fnx[o] += a_fx; fny[o] += a_fy; fnz[o] += a_fz; }
-  }
-  if (sl_me == 31 && has_me) {
-    cds[j_me] += a_cdk;
-    fx[j_me] += a_fx; fy[j_me] += a_fy; fz[j_me] += a_fz;
-  }
-  // the mailbox of the two atoms: header (slot of every centre bond that got a row, -1 otherwise), then per row the slots l1 in rank
-  // order (-1 behind the last) and the four sums.  Every word is written: no clearing between steps.
-  if (has_me && sl_me < E4_CM) {
-    int v = -1;
-    for (int s = 0; s < nj_me; ++s) if (s_c[w][g_me * 32 + s] == sl_me) v = s;
-    mb_k1[static_cast<size_t>(j_me) * E4_CM + sl_me] = v;
-  }
-  for (int t = lane; t < 2 * E4_CM * E4_LM; t += 64) {
-    const int g = t / (E4_CM * E4_LM), c = (t / E4_LM) % E4_CM, m = t % E4_LM;
-    const int j = jbase + g;
-    if (j >= N) continue;
-    // the centre bond that owns row c of atom g, and the m-th bonded slot of its k
-    int l1 = -1;
-    for (int s = 0; s < njg[g]; ++s)
-      if (s_c[w][g * 32 + s] == c) {
-        unsigned mk = s_lm[w][g * 32 + s];
-        for (int r = 0; r < m && mk; ++r) mk &= mk - 1u;                    // drop the m lowest set bits
-        if (mk) l1 = __ffs(static_cast<int>(mk)) - 1;
-      }
-    const size_t e_ = (static_cast<size_t>(j) * E4_CM + c) * E4_LM + m;
-    mb_l1[e_] = l1;
-    if (l1 >= 0) {
-      const double *kl = &s_kl[w][g][c][m][0];
-      mb_val[4 * e_ + 0] = kl[0]; mb_val[4 * e_ + 1] = kl[1]; mb_val[4 * e_ + 2] = kl[2]; mb_val[4 * e_ + 3] = kl[3];
-    }
-  }
-  e8 = wave_sum_b(e8); e9 = wave_sum_b(e9);
-  if (lane == 0) {
-    if (e8 != 0.0) atomicAdd(pe + 8, e8);
-    if (e9 != 0.0) atomicAdd(pe + 9, e9);
-  }
-}
-
-// every atom k (residents and ghosts) adds what its neighbours j with gid(j) < gid(k) left in their mailboxes to its own slots (k, l1)
-__global__ void __launch_bounds__(256) k_e4b_collect(int G, int N, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
-                                                      const long long *__restrict__ gid, const int *__restrict__ mb_k1, const int *__restrict__ mb_l1, const double *__restrict__ mb_val,
-                                                      double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= G) return;
-  const int nk = nbrcnt[k];
-  const long long gk = gid[k];
-  for (int s = 0; s < nk; ++s) {
-    const size_t os = static_cast<size_t>(s) * NB + k;
-    const int j = nbr[os];
-    if (j >= N || !(gid[j] < gk)) continue;                                  // centres are residents; the reference's orientation
-    const int js = nbrindx[os];                                              // slot of k in j's list
-    for (int c = 0; c < E4_CM; ++c) {
-      if (mb_k1[static_cast<size_t>(j) * E4_CM + c] != js) continue;
-      for (int m = 0; m < E4_LM; ++m) {
-        const size_t e_ = (static_cast<size_t>(j) * E4_CM + c) * E4_LM + m;
-        const int l1 = mb_l1[e_];
-        if (l1 < 0) break;
-        const size_t ol = static_cast<size_t>(l1) * NB + k;
-        cf1[ol] += mb_val[4 * e_ + 0]; fnx[ol] += mb_val[4 * e_ + 1]; fny[ol] += mb_val[4 * e_ + 2]; fnz[ol] += mb_val[4 * e_ + 3];
-      }
-      break;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Hydrogen bonds.  One wavefront per donor atom i; lanes sweep i's 10 A row for acceptors k.
 // Hydrogen is atom type 2, hard-coded in the reference (pot.F90:595) and kept.
 __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
@@ -991,23 +662,11 @@ void Engine::bonded_energies() {
   }
   k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, order, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
-  if (std::getenv("RXMD_E4B_TWO_VISITS") == nullptr) {        // every torsion once + mailbox hand-over of the (k, l) terms (default)
-    if (!mb_val) {
-      const size_t ne = static_cast<size_t>(NB) * E4_CM * E4_LM;
-      RX_HIP(hipMalloc(reinterpret_cast<void **>(&mb_k1), sizeof(int) * static_cast<size_t>(NB) * E4_CM));
-      RX_HIP(hipMalloc(reinterpret_cast<void **>(&mb_l1), sizeof(int) * ne));
-      RX_HIP(hipMalloc(reinterpret_cast<void **>(&mb_val), sizeof(double) * 4 * ne));
-    }
-    k_e4b_once<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                                 cds, frc[0], frc[1], frc[2], pe_d, mb_k1, mb_l1, mb_val);
-    k_e4b_collect<<<nblk(G, 256), 256, 0, stream>>>(G, N, NB, nbr, nbrcnt, nbrindx, gid, mb_k1, mb_l1, mb_val, cf1, fnx, fny, fnz);
-  } else {
-    BoxImg bx;
-    for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
-    bx.ortho = grid.ortho;
-    k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                            cds, frc[0], frc[1], frc[2], pe_d, bx);
-  }
+  BoxImg bx;
+  for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
+  bx.ortho = grid.ortho;
+  k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
   k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
 }
 

@@ -157,7 +157,6 @@ struct Engine {
   double *etor = nullptr, *econ = nullptr, *epen = nullptr, *ecoa = nullptr;   // per-bond exponentials shared by many angles/torsions
   double *deltap = nullptr, *delta = nullptr, *nlp = nullptr, *dDlp = nullptr, *deltalp = nullptr;
   double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
-  int *mb_k1 = nullptr, *mb_l1 = nullptr; double *mb_val = nullptr;   // torsion mailbox: (k, l) terms handed from the wavefront of j to atom k (bonded.hip, k_e4b_once)
   // 10 A list
   int *nb10 = nullptr, *n10 = nullptr; double *hess = nullptr;
   size_t partials_cap = 0;

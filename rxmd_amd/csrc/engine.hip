@@ -323,7 +323,6 @@ void Engine::free_device() {
   dfree(sorted_xyzi); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
   dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
-  dfree(mb_k1); dfree(mb_l1); dfree(mb_val);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(rows_int); dfree(rows_bnd);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);

@@ -323,7 +323,11 @@ def make_minimiser():
                            preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY)))
         assert "successfully finished structural optimization" in p.stdout, p.stdout[-2000:]
         xyz = open(os.path.join(tmp, "DAT", "000000000.xyz")).read()
-        np.savez_compressed(os.path.join(HERE, "rdx168_minimiser.npz"), xyz=np.array(xyz), stdout_tail=np.array(p.stdout[-1500:]))
+        # the line search the reference prints on the way (cg.F90:122-124,262-263): bracket, then per golden-section round ax bx cx dx PEbx PEcx
+        bracket = [float(l.split()[-1]) for l in p.stdout.split("\n") if "bracket has been found" in l]
+        gs = np.array([[float(x) for x in l.split()[1:7]] for l in p.stdout.split("\n") if l.strip().startswith("ax,bx,cx,dx,PEbx,PEcx:")])
+        np.savez_compressed(os.path.join(HERE, "rdx168_minimiser.npz"), xyz=np.array(xyz), stdout_tail=np.array(p.stdout[-1500:]),
+                            bracket=np.array(bracket), golden_section=gs)
         print("rdx168_minimiser", len(xyz))
     finally:
         shutil.rmtree(tmp)
