@@ -125,8 +125,13 @@ def test_reference_minimiser_runs_on_the_hip_library():
         with open(os.path.join(tmp, "rxmd.in"), "a") as f:
             f.write("CG_tol 1.d-5\n")
         subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "1", "1", "1"], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        try:                                  # cg.F90 keeps NBUFFER-sized automatic arrays on the stack; raised in THIS process (inherited), no preexec_fn
+            resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+        except (ValueError, OSError):
+            soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
+            resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
         p = subprocess.run([drv, "--mdmode", "10", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                           timeout=900, preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY)))
+                           timeout=900)
         assert "successfully finished structural optimization" in p.stdout, p.stdout[-3000:]
         mine = open(os.path.join(tmp, "DAT", "000000000.xyz")).read().split("\n")
         theirs = str(g["xyz"]).split("\n")
