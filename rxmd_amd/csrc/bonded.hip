@@ -28,11 +28,7 @@ static constexpr double MINBO0 = 1e-4, cutof2_esub = 1e-4;                      
 static constexpr double MAXANGLE = 0.999999999999, MINANGLE = -0.999999999999, NSMALL = 1e-10;   // module.F90:85-87
 static constexpr double PI_ = 3.14159265358979;                                                  // module.F90:90
 
-__device__ inline double wave_sum_b(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ inline double wave_sum_b(double v) { return wave_sum64(v); }   // DPP reduction, engine.h
 // sum over the block, then one atomic per block into the energy accumulator
 __device__ inline void block_energy_add(double v, double *dst) {
   __shared__ double sm[8];

@@ -108,6 +108,25 @@ __device__ inline int xcd_swizzle(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// Sum of a double over the 64 lanes of a wavefront, the total returned to every lane.  HIP's __shfl_xor compiles to ds_bpermute (two per
+// double and step: 12 dependent LDS-crossbar round trips per sum); this form stays in the vector ALU: four steps inside each row of 16
+// lanes with DPP lane permutations (quad swaps, half-row mirror, row mirror), two row broadcasts (lane 15 -> next row, lane 31 -> upper
+// half, written only where the row mask says), the total read from lane 63 into scalar registers.  Fixed summation order.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_move(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ inline double wave_sum64(double v) {
+  v += dpp_move<0xb1, 0xf>(v);     // quad_perm:[1,0,3,2]
+  v += dpp_move<0x4e, 0xf>(v);     // quad_perm:[2,3,0,1]
+  v += dpp_move<0x141, 0xf>(v);    // row_half_mirror
+  v += dpp_move<0x140, 0xf>(v);    // row_mirror: every lane of a row now holds the row's sum
+  v += dpp_move<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 struct Engine {
   rxmd_config cfg{};
   std::string ffield_path, pqeq_path, err;

@@ -166,11 +166,7 @@ __device__ inline bool pq_lookup(const DevFF &ff, const double4 *__restrict__ ta
   E = nd.x + t * nd.y; F = nd.z + t * nd.w;
   return true;
 }
-__device__ inline double wave_sum_l(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ inline double wave_sum_l(double v) { return wave_sum64(v); }   // DPP reduction, engine.h
 
 // One wavefront per resident row, two phases.
 // Phase 1 (sparse): the candidates of the row = the z-trimmed runs of its 25 stencil columns (column_run above), laid end to end and

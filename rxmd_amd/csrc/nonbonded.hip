@@ -18,11 +18,7 @@ __global__ void k_sorted_charge(int G, const int *__restrict__ rootperm, const d
   if (k < G) pk[k].w = q[rootperm[k]];
 }
 
-__device__ inline double wave_sum_n(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ inline double wave_sum_n(double v) { return wave_sum64(v); }   // DPP reduction, engine.h
 
 #ifndef NB_UNR
 #define NB_UNR 8      // entries per lane and pass: a whole RDX row in one pass (measured 4.83 / 4.59 / 4.45 / 4.10 ms at 1 / 2 / 4 / 8)

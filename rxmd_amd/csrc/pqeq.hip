@@ -26,11 +26,7 @@ __device__ inline bool pq_lookup2(const DevFF &ff, const double4 *__restrict__ t
   E = nd.x + t * nd.y; F = nd.z + t * nd.w;
   return true;
 }
-__device__ inline double wave_sum_p(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ inline double wave_sum_p(double v) { return wave_sum64(v); }   // DPP reduction, engine.h
 
 __global__ void k_sorted_shl(int G, const int *__restrict__ perm, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz, double4 *__restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;

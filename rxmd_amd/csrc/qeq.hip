@@ -29,11 +29,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int UNR = SPMV_UNR;   // 4 x 64 = 256 entries in flight per wavefront and pass of the row loop (see k_spmv)
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ inline double wave_sum(double v) { return wave_sum64(v); }   // DPP reduction, engine.h
 
 template <int NC>
 __device__ inline void block_store_partials(double (&acc)[NC], double *partials, int ncomp_stride) {
