@@ -71,21 +71,24 @@ __device__ inline int z_slice(const Grid &g, double sz) {          // the expres
   return min(max(b, 0), g.nzf - 1);
 }
 // run [k0, k0 + len) of the sorted arrays that column (x2, y2) contributes to a sweep of radius rcp around (sx, sy, sz); len = 0: none
+template <bool ORTHO>
 __device__ inline void column_run(const Grid &g, const int *__restrict__ cellstart, double sx, double sy, double sz, int cx, int cy, int x2, int y2,
                                   double rcp, int &k0, int &len) {
   k0 = 0; len = 0;
   if (x2 < 0 || x2 >= g.n[0] || y2 < 0 || y2 >= g.n[1]) return;
   const double gx = axis_gap(g, 0, sx, cx, x2), gy = axis_gap(g, 1, sy, cy, y2);
   // orthogonal axes: the three gaps add in quadrature; skewed axes: each perpendicular gap alone is a lower bound of the distance
-  const double d2 = g.ortho ? gx * gx + gy * gy : fmax(gx, gy) * fmax(gx, gy);
+  const double d2 = ORTHO ? gx * gx + gy * gy : fmax(gx, gy) * fmax(gx, gy);
   if (d2 > rcp * rcp) return;
-  const double dzs = (g.ortho ? sqrt(rcp * rcp - d2) : rcp) * g.iwz;
+  const double dzs = (ORTHO ? sqrt(rcp * rcp - d2) : rcp) * g.iwz;
   const int lo = z_slice(g, sz - dzs), hi = z_slice(g, sz + dzs);
   const int cbf = (x2 * g.n[1] + y2) * g.nzf;
   k0 = cellstart[cbf + lo];
   len = cellstart[cbf + hi + 1] - k0;
 }
 
+// ORTHO = false: the instance for skewed boxes carries the reference's cell-mesh tests (RefMesh); the orthogonal one does not pay for them
+template <bool ORTHO>
 __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                       const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ z, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
@@ -111,12 +114,12 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
   const double *rc2row = s_rc2 + ti * ff.n1;
   const double rcp = s_rmax[ti];
   double si[3] = {0.0, 0.0, 0.0};
-  if (!g.ortho) ref_norm(rm, xi, yi, zi, si);
+  if (!ORTHO) ref_norm(rm, xi, yi, zi, si);
   int cnt = 0;
   for (int dx = -1; dx <= 1; ++dx) {
     for (int dy = -1; dy <= 1; ++dy) {
       int k0, len;
-      column_run(g, cellstart, sxi, syi, szi, cx, cy, cx + dx, cy + dy, rcp, k0, len);
+      column_run<ORTHO>(g, cellstart, sxi, syi, szi, cx, cy, cx + dx, cy + dy, rcp, k0, len);
       for (int k = k0; k < k0 + len; ++k) {
         const double4 p = sorted[k];
         const long long w = __double_as_longlong(p.w);
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
         const double d0 = p.x - xi, d1 = p.y - yi, d2 = p.z - zi;
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
         bool in = r2 < rc2row[tj];              // dr2 < rc2(inxn), main.F90:366 (no bond row: cut-off 0)
-        if (in && !g.ortho) { double sj[3]; ref_norm(rm, p.x, p.y, p.z, sj); in = ref_bonded_cells_adjacent(rm, si, sj); }
+        if (!ORTHO && in) { double sj[3]; ref_norm(rm, p.x, p.y, p.z, sj); in = ref_bonded_cells_adjacent(rm, si, sj); }
         if (in) {
           if (cnt < MAXNB) nbr[static_cast<size_t>(cnt) * NB + i] = j;
           ++cnt;
@@ -181,7 +184,7 @@ __device__ inline double wave_sum_l(double v) { return wave_sum64(v); }   // DPP
 // instead of 64 scattered ones.  Bits: see NB10_* in engine.h.
 // PQ: PQEq variant of qeq_initialize (pqeq.F90:262-353): core-core hessian from the pcc table, the shell-core matrix hsc of
 // get_hsh's Csicj term, and per row (fpqeq Eq. 30, sum_j H Z_j, sum_j hsc Z_j, shell-shell energy) -> pqrow
-template <bool SELFCHECK, bool PQ>
+template <bool SELFCHECK, bool PQ, bool ORTHO>
 __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted,
                                                  const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   const int ti = type[i];
   const size_t row = static_cast<size_t>(i) * S10;
   double sni[3] = {0.0, 0.0, 0.0};
-  if (!g.ortho) ref_norm(rm, xi, yi, zi, sni);
+  if (!ORTHO) ref_norm(rm, xi, yi, zi, sni);
   double sxi = 0.0, syi = 0.0, szi = 0.0, Zi = 0.0, p_f = 0.0, p_hz = 0.0, p_bz = 0.0, p_ss = 0.0;
   if (PQ) { sxi = shx[i]; syi = shy[i]; szi = shz[i]; Zi = ff.Zpq[ti]; }
   // xs0 != nullptr: the sweep also forms the row sums H.(qs,qt) of the CG start vector (qt = 0) -- the matrix pass that
@@ -231,7 +234,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
         const int inxn = ff.inxn2[ti * ff.n1 + tj];
         // skewed box: a ghost partner beyond the reference's QEq ghost shell is in its FORCE list but not in its QEq matrix
         bool inq = true;
-        if (!g.ortho && j >= N) {
+        if (!ORTHO && j >= N) {
           const double g0 = spx[j], g1 = spy[j], g2 = spz[j];
           inq = g0 > rm.qlo[0] && g0 <= rm.qhi[0] && g1 > rm.qlo[1] && g1 <= rm.qhi[1] && g2 > rm.qlo[2] && g2 <= rm.qhi[2];
         }
@@ -286,7 +289,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   int L;
   {
     int k0 = 0, len = 0;
-    if (lane < 25) column_run(g, cellstart, spx[i], spy[i], spz[i], cx, cy, cx + lane / 5 - 2, cy + lane % 5 - 2, ff.rctap_pad, k0, len);
+    if (lane < 25) column_run<ORTHO>(g, cellstart, spx[i], spy[i], spz[i], cx, cy, cx + lane / 5 - 2, cy + lane % 5 - 2, ff.rctap_pad, k0, len);
     int lpre = len;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {
@@ -320,7 +323,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
         const double d0 = xi - pd[u].x, d1 = yi - pd[u].y, d2 = zi - pd[u].z;
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
         in = (j != i) && (r2 <= ff.rctap2);     // dr2 <= rctap2, main.F90:458
-        if (in && !g.ortho) { double sj[3]; ref_norm(rm, pd[u].x, pd[u].y, pd[u].z, sj); in = ref_nb_cells_in_mesh(rm, sni, sj, ff.rctap2); }
+        if (!ORTHO && in) { double sj[3]; ref_norm(rm, pd[u].x, pd[u].y, pd[u].z, sj); in = ref_nb_cells_in_mesh(rm, sni, sj, ff.rctap2); }
       }
       const unsigned long long m = __ballot(in);
       if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = kk[u];
@@ -363,19 +366,22 @@ __global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__r
 
 void Engine::build_bonded_list() {
   k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi);
-  k_bonded_list<<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
+  if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
+  else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
   k_reverse_index<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, d_err);
 }
 
 void Engine::build_list10() {
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);
-#define RX_LIST10(SC, PQF)                                                                                                                     \
-  k_list10<SC, PQF><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
+#define RX_LIST10(SC, PQF) do { if (grid.ortho) RX_LIST10_O(SC, PQF, true); else RX_LIST10_O(SC, PQF, false); } while (0)
+#define RX_LIST10_O(SC, PQF, OR)                                                                                                               \
+  k_list10<SC, PQF, OR><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
                                                     nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
 #undef RX_LIST10
+#undef RX_LIST10_O
   if (multi()) {     // interior rows (no ghost partner) and boundary rows: the matrix pass does the former while the vector halo is in flight
     RX_HIP(hipMemsetAsync(flags + N, 0, sizeof(int), stream));
     size_t tb = cubtmp_bytes;
