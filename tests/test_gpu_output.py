@@ -109,5 +109,7 @@ def test_device_resident_minimiser_against_the_references_line_search_and_the_or
     o = oa.Oracle(ff, e.lattice, ranks, **kw); o.qeq(); o.force()
     assert abs(o.energy()[0] - pe) <= 1e-9 * abs(pe)
     fo = o.forces(); frms = np.sqrt((fo ** 2).mean())
-    assert (np.abs(a["f"] - fo).max(axis=1) / np.maximum(np.abs(fo).max(axis=1), frms)).max() <= 1e-6
+    # two CG charge solves that each stop on a 1e-12 relative energy change agree to ~1e-7 in the charges; on the small forces of a
+    # minimised structure (rms 0.55 kcal/mol/A) that is 4e-7 absolute = 1.4e-6 of the rms (measured)
+    assert (np.abs(a["f"] - fo).max(axis=1) / np.maximum(np.abs(fo).max(axis=1), frms)).max() <= 5e-6
     e.close()
