@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_WAVES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --kernel-include-regex "k_e4b|k_e3b|k_list10|k_nonbond|k_ehb" --output-format csv -d gpurun_out/pmc_ang_$tag -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --alt-steps 0 > gpurun_out/pmc_ang_$tag.log 2>&1
+  rocprofv3 --pmc $grp --kernel-include-regex "k_e4b|k_e3b|k_list10|k_nonbond|k_ehb" --output-format csv -d gpurun_out/pmc_ang_$tag -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --no-alt > gpurun_out/pmc_ang_$tag.log 2>&1
 done
 python3 - <<'PY'
 import csv,glob,collections

@@ -3,9 +3,9 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-x}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --alt-steps 0 > gpurun_out/prof_$TAG.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_spmv" --output-format csv -d gpurun_out/pmc_fetch_$TAG -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --alt-steps 0 > gpurun_out/pmc_fetch_$TAG.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_spmv" --output-format csv -d gpurun_out/pmc_write_$TAG -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --alt-steps 0 > gpurun_out/pmc_write_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt > gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_spmv" --output-format csv -d gpurun_out/pmc_fetch_$TAG -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --no-alt > gpurun_out/pmc_fetch_$TAG.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_spmv" --output-format csv -d gpurun_out/pmc_write_$TAG -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --no-alt > gpurun_out/pmc_write_$TAG.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/prof_$TAG/**/*kernel_stats.csv",recursive=True)[0]

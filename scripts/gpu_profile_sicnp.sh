@@ -1,7 +1,7 @@
 # rocprofv3 kernel statistics of the SiC-NP + PQEq workload (BASELINE configs[4]) on one GPU
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sicnp -- python3 bench.py --workload sicnp --steps 5 --warmup 2 --no-cpu-baseline --alt-steps 0 > gpurun_out/prof_sicnp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sicnp -- python3 bench.py --workload sicnp --steps 5 --warmup 2 --no-cpu-baseline --no-alt > gpurun_out/prof_sicnp.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/prof_sicnp/**/*kernel_stats.csv",recursive=True)[0]

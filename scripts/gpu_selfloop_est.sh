@@ -6,6 +6,6 @@ export RXMD_BENCH_FORCE_DIST=1 RXMD_FORCE_STAGED=1 RXMD_FORCE_REMOTE=1
 for rep in 1 2; do
 for v in est2 est3; do
   if [ $v = est3 ]; then export RXMD_EST_SEPARATE=1; else unset RXMD_EST_SEPARATE; fi
-  timeout 900 python bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --alt-steps 0 > gpurun_out/selfloop_$v.log 2>&1
+  timeout 900 python bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-alt > gpurun_out/selfloop_$v.log 2>&1
   echo "$v: $(grep '^{"metric' gpurun_out/selfloop_$v.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['qeq_iters_per_step'])")"
 done; done

@@ -6,6 +6,6 @@ python -m pytest tests/test_gpu_multirank.py -x -q 2>&1 | tail -3
 for rep in 1 2; do
 for v in pairs nopairs; do
   if [ $v = nopairs ]; then export RXMD_NO_STAGE_PAIRS=1; else unset RXMD_NO_STAGE_PAIRS; fi
-  timeout 900 python bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --alt-steps 0 > gpurun_out/selfloop_$v.log 2>&1
+  timeout 900 python bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-alt > gpurun_out/selfloop_$v.log 2>&1
   echo "$v: $(grep '^{"metric' gpurun_out/selfloop_$v.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['qeq_iters_per_step'])")"
 done; done
