@@ -3,8 +3,8 @@
 //   NEIGHBORLIST            reference src/main.F90:321-417   -> k_bonded_list + k_reverse_index
 //   qeq_initialize          reference src/qeq.F90:183-268    \  one sweep: k_list10
 //   GetNonbondingPairList   reference src/main.F90:420-477   /  (the reference walks the stencil twice)
-// Candidates come from the engine's own cell grid (cell edge >= max(5 A, maxrc)), cell-sorted with z
-// fastest, so a (dx,dy) column of the stencil is ONE contiguous range of the sorted array.
+// Candidates come from the engine's own cell grid (cells >= max(rctap/2, maxrc) wide, perpendicular to their faces), sorted by
+// (cell x, cell y, z-slice): a (dx,dy) column of the stencil is ONE contiguous, z-ordered run of the sorted arrays.
 #include "engine.h"
 
 #include <hipcub/hipcub.hpp>
