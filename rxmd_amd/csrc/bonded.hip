@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
   block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
 }
 
-struct BoxImg { double H[9], Hi[9], L[3]; int ortho; };    // lattice vectors for the image test of the torsion's stress correction
+struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // probe != 0 (timing experiments only): phase B is skipped    // lattice vectors for the image test of the torsion's stress correction
 // Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to i,j,k,l.
 // Here ONE WAVEFRONT owns TWO consecutive centre atoms; lane t = (g<<5 | slot) owns the accumulators of bond `slot` of
 // atom g.  Phase A enumerates every (k1,i1,l1) combination of the two atoms, applies the reference's cheap bond-order
@@ -312,6 +312,10 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   __shared__ double s_btb2[4][64], s_dfn11[4][64];
   __shared__ int s_nk[4][64], s_own[4][64];
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
+  // phase A walks only bonds above the cut-off: the slots of each centre atom that qualify, and per centre bond the qualifying slots
+  // of k with what the filter needs of them (bond order, atom l, its type) -- staged once per centre bond by the lanes side by side
+  __shared__ int s_cap[4][64], s_capl[4][32], s_ll[4][32], s_tl[4][32];
+  __shared__ double s_bokl[4][32];
   // per (atom g, slot) accumulators, updated with LDS atomics by the lanes that evaluate torsions: [0] cf1 and [1..3] force of the
   // i-j bond / its neighbour, [4] cf1, [5] cf2, [6] cdbnd of the centre bond; slot 31 (never a bond) holds the centre atom's own
   // force in [1..3] and cdbnd in [6].  (An earlier version wrote 11 results per torsion to LDS and let every owner lane scan all 64
@@ -327,11 +331,13 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   const int tj_me = has_me ? type[j_me] : 1;
   const double xj_me = has_me ? x[j_me] : 0.0, yj_me = has_me ? y[j_me] : 0.0, zj_me = has_me ? z[j_me] : 0.0;
   s_nk[w][lane] = 0;
+  bool cap_me = false;
   if (sl_me < nj_me) {
     const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
     const int i = nbr[o], ti = type[i];
     const double rx = x[i] - xj_me, ry = y[i] - yj_me, rz = z[i] - zj_me;      // r_i - r_j
     const double b = bo0[o];
+    cap_me = b > cutof2_esub;
     s_nb[w][lane] = i; s_ty[w][lane] = ti;
     s_bo[w][lane] = b; s_et[w][lane] = etor[o]; s_ec[w][lane] = econ[o];
     s_rx[w][lane] = rx; s_ry[w][lane] = ry; s_rz[w][lane] = rz; s_rn[w][lane] = sqrt(rx * rx + ry * ry + rz * rz);
@@ -349,6 +355,13 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   }
 #pragma unroll
   for (int c = 0; c < 7; ++c) s_acc[w][lane][c] = 0.0;
+  int ncapg[2];
+  {                                               // the qualifying slots of each of the two centre atoms, in slot order
+    const unsigned long long mc = __ballot(cap_me);
+    const unsigned half = static_cast<unsigned>(g_me ? (mc >> 32) : (mc & 0xffffffffULL));
+    if (cap_me) s_cap[w][g_me * 32 + __popc(half & ((1u << sl_me) - 1u))] = sl_me;
+    ncapg[0] = __popc(static_cast<unsigned>(mc & 0xffffffffULL)); ncapg[1] = __popc(static_cast<unsigned>(mc >> 32));
+  }
   wave_lds_sync();
   const int njg[2] = {__shfl(nj_me, 0, 64), __shfl(nj_me, 32, 64)};
   const int tjg[2] = {__shfl(tj_me, 0, 64), __shfl(tj_me, 32, 64)};
@@ -356,6 +369,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   int qn = 0;                                     // (slot 31 is never a bond: its lane accumulates the centre atom's own force and cdbnd)
 
   auto evaluate = [&](int cnt) {                  // phase B: the first cnt (<= 64) queue entries, one per lane
+    if (bx.probe) return;
     double o[7] = {0, 0, 0, 0, 0, 0, 0};
     V3 fself = {0.0, 0.0, 0.0};
     double cd_self = 0.0;
@@ -493,30 +507,43 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
 
   // phase A: enumerate, filter, compact
   for (int g = 0; g < 2; ++g) {
-    const int nj = njg[g];
+    const int nj = njg[g], ncj = ncapg[g];
     for (int k1 = 0; k1 < nj; ++k1) {
       const int sk = g * 32 + k1;
       const int nk = s_nk[w][sk];
       if (nk == 0) continue;
       const double BOjk_f = s_bo[w][sk];
       const int k = s_nb[w][sk], j = jbase + g;
-      const int total = nj * min(nk, WSLOT);
+      int nck;
+      {                                           // the qualifying slots of k (pot.F90:1072), staged by the lanes side by side
+        const int nkc = min(nk, WSLOT);
+        double bl = 0.0;
+        if (lane < nkc) bl = bo0[static_cast<size_t>(lane) * NB + k];
+        const bool capl = (lane < nkc) && (bl > cutof2_esub);
+        const unsigned long long ml = __ballot(capl);
+        if (capl) {
+          const int r = __popcll(ml & ((1ULL << lane) - 1ULL));
+          const int l = nbr[static_cast<size_t>(lane) * NB + k];
+          s_capl[w][r] = lane; s_bokl[w][r] = bl; s_ll[w][r] = l; s_tl[w][r] = type[l];
+        }
+        nck = __popcll(ml);
+        wave_lds_sync();
+      }
+      const int total = ncj * nck;
       for (int c0 = 0; c0 < total; c0 += 64) {
         const int c = c0 + lane;
         bool go = false;
         int i1 = 0, l1 = 0;
         if (c < total) {
-          i1 = c / min(nk, WSLOT); l1 = c - i1 * min(nk, WSLOT);
+          const int ci = c / nck, cl = c - ci * nck;
+          i1 = s_cap[w][g * 32 + ci]; l1 = s_capl[w][cl];
           const double BOij_f = s_bo[w][g * 32 + i1];
           const int i = s_nb[w][g * 32 + i1];
-          const size_t ol = static_cast<size_t>(l1) * NB + k;
-          const double BOkl_f = bo0[ol];
-          go = (i1 != k1) && (BOij_f > cutof2_esub) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
-               (BOkl_f > cutof2_esub) && (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0);
-          if (go) {
-            const int l = nbr[ol];
-            go = (l != i) && (l != j) && (ff.inxn4[((s_ty[w][g * 32 + i1] * ff.n1 + tjg[g]) * ff.n1 + s_ty[w][sk]) * ff.n1 + type[l]] != 0);
-          }
+          const double BOkl_f = s_bokl[w][cl];
+          const int l = s_ll[w][cl];
+          go = (i1 != k1) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
+               (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0) && (l != i) && (l != j);
+          if (go) go = ff.inxn4[((s_ty[w][g * 32 + i1] * ff.n1 + tjg[g]) * ff.n1 + s_ty[w][sk]) * ff.n1 + s_tl[w][cl]] != 0;
         }
         const unsigned long long m = __ballot(go);
         if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
@@ -660,7 +687,7 @@ void Engine::bonded_energies() {
                                           cds, frc[0], frc[1], frc[2], pe_d);
   BoxImg bx;
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
-  bx.ortho = grid.ortho;
+  bx.ortho = grid.ortho; bx.probe = std::getenv("RXMD_E4B_PROBE_PHASE_A") ? 1 : 0;
   k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d, bx);
   k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);

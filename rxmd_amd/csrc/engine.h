@@ -83,6 +83,7 @@ struct Grid {       // the engine's own cell grid over [-shell, L+shell) in norm
   double cw[3];     // 1 / inv: cell edge in normalised units
   double iwz;       // 1 / wid[2]
   int ortho;        // 1: the three directions are orthogonal (distance^2 = sum of the three gaps^2), 0: only max(gap) is a bound
+  int probe;        // timing experiments only (RXMD_LIST_PROBE): 1 = the 10 A sweep stops after its per-row set-up, 2 = it skips the emission
 };
 
 // The reference's own cell meshes (non-orthogonal boxes only).  Its linked-list cells are laid out in units of the lattice VECTORS and

@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   // Phase 2, dense: one queued candidate per lane -> table interpolation, list entry, hessian value.  Only a third of the
   // candidates pass the distance test, so doing this work on compacted batches keeps every lane busy.
   auto emit = [&](int nproc) {
+    if (g.probe == 2) { cnt += nproc; return; }
     if (lane < nproc) {
       const int k = sq[lane], slot = cnt + lane;
       if (slot < S10) {
@@ -300,6 +301,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
     L = __shfl(lpre, 31, 64);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (g.probe == 1) { if (lane == 0) n10[i] = L; return; }
   for (int c0 = 0; c0 < L; c0 += 256) {
     // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
     int kk[4];
@@ -372,6 +374,7 @@ void Engine::build_bonded_list() {
 }
 
 void Engine::build_list10() {
+  if (const char *pv = std::getenv("RXMD_LIST_PROBE")) grid.probe = std::atoi(pv);
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);
 #define RX_LIST10(SC, PQF) do { if (grid.ortho) RX_LIST10_O(SC, PQF, true); else RX_LIST10_O(SC, PQF, false); } while (0)
