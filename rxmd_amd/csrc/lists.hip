@@ -194,12 +194,19 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
                                                  const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag) {
-  __shared__ int s_q[4][128];            // accepted candidates: sorted position
+  __shared__ int s_q[4][128];            // accepted candidates: sorted position ...
+  __shared__ double s_r2[4][128];        // ... their squared distance (the exact FP64 value of the test) ...
+  __shared__ long long s_w[4][128];      // ... and (type << 32 | atom index): the dense phase needs no second gather of the candidate
   __shared__ int s_P[4][32], s_K[4][32];  // per stencil column: candidates before it / first sorted position of its run
+  __shared__ int s_ix2[256];             // inxn2 row of the row's type would do; the whole (n1 x n1) table is 64-256 words
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
+  for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) s_ix2[t] = ff.inxn2[t];
+  __syncthreads();
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
   if (i >= N) return;
   int *sq = s_q[w];
+  double *sr2 = s_r2[w];
+  long long *sw = s_w[w];
   int *cP = s_P[w], *cK = s_K[w];
   const int c = cellid[i];
   const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
@@ -224,15 +231,15 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
     if (lane < nproc) {
       const int k = sq[lane], slot = cnt + lane;
       if (slot < S10) {
-        const double4 p = sorted[k];
-        const long long wv = __double_as_longlong(p.w);
+        const long long wv = sw[lane];
         const int j = static_cast<int>(wv & 0xffffffffLL), tj = static_cast<int>(wv >> 32);
-        const double d0 = xi - p.x, d1 = yi - p.y, d2 = zi - p.z;
-        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        const double r2 = sr2[lane];
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+        if (PQ) { const double4 p = sorted[k]; d0 = xi - p.x; d1 = yi - p.y; d2 = zi - p.z; }   // the shell terms need the vector
         // hessian entry as qeq_initialize computes it: r^2 rounded to REAL(4) first (qeq.F90:191,222-240)
         const float r2f = static_cast<float>(r2);
         double h = 0.0, hc = 0.0;
-        const int inxn = ff.inxn2[ti * ff.n1 + tj];
+        const int inxn = s_ix2[ti * ff.n1 + tj];
         // skewed box: a ghost partner beyond the reference's QEq ghost shell is in its FORCE list but not in its QEq matrix
         bool inq = true;
         if (!ORTHO && j >= N) {
@@ -320,24 +327,26 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       bool in = false;
+      double r2q = 0.0;
       if (ok[u]) {
         const int j = static_cast<int>(__double_as_longlong(pd[u].w) & 0xffffffffLL);
         const double d0 = xi - pd[u].x, d1 = yi - pd[u].y, d2 = zi - pd[u].z;
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        r2q = r2;
         in = (j != i) && (r2 <= ff.rctap2);     // dr2 <= rctap2, main.F90:458
         if (!ORTHO && in) { double sj[3]; ref_norm(rm, pd[u].x, pd[u].y, pd[u].z, sj); in = ref_nb_cells_in_mesh(rm, sni, sj, ff.rctap2); }
       }
       const unsigned long long m = __ballot(in);
-      if (in) sq[qn + __popcll(m & ((1ULL << lane) - 1ULL))] = kk[u];
+      if (in) { const int qp = qn + __popcll(m & ((1ULL << lane) - 1ULL)); sq[qp] = kk[u]; sr2[qp] = r2q; sw[qp] = __double_as_longlong(pd[u].w); }
       qn += __popcll(m);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (qn >= 64) {
         emit(64);
         const int rest = qn - 64;
-        int v = 0;
-        if (lane < rest) v = sq[64 + lane];
+        int v = 0; double vr = 0.0; long long vw = 0;
+        if (lane < rest) { v = sq[64 + lane]; vr = sr2[64 + lane]; vw = sw[64 + lane]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (lane < rest) sq[lane] = v;
+        if (lane < rest) { sq[lane] = v; sr2[lane] = vr; sw[lane] = vw; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         qn = rest;
       }
