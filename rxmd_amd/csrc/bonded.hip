@@ -179,11 +179,13 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
     const DevAtomP aj = ff.atom[tj];
     const double xj = x[j], yj = y[j], zj = z[j];
     double sum_BO8 = 0.0, sum_SBO1 = 0.0;
+    unsigned capmask = 0u;
     for (int n1 = 0; n1 < nj; ++n1) {
       const size_t o = static_cast<size_t>(n1) * NB + j;
       const double b = bo0[o], b2 = b * b, b4 = b2 * b2;
       sum_BO8 -= b4 * b4;                                                  // BO**8, pot.F90:362
       sum_SBO1 += bo2[o] + bo3[o];
+      if (b - cutof2_esub > 0.0) capmask |= 1u << n1;                      // pot.F90:372-373, 385-386
     }
     const double prod_SBO = exp(sum_BO8);
     const double dlj = delta[j];
@@ -209,18 +211,19 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
     // sums over all angles of the terms that ForceBbo(j,n1,...) applies to EVERY bond of j (pot.F90:526-532)
     double S_d1 = 0.0, S_v6 = 0.0, S_v5 = 0.0;
     V3 fself = {0.0, 0.0, 0.0};
-    for (int i1 = 0; i1 < nj - 1; ++i1) {
+    for (unsigned mi = capmask; mi & (mi - 1u);) {
+      const int i1 = __ffs(mi) - 1;
+      mi &= mi - 1u;
       const size_t oi = static_cast<size_t>(i1) * NB + j;
       const double BOij_f = bo0[oi], BOij = BOij_f - cutof2_esub;
-      if (!(BOij > 0.0)) continue;
       const int i = nbr[oi], ti = type[i];
       const V3 rij = {x[i] - xj, y[i] - yj, z[i] - zj};
       const double nij = sqrt(dot(rij, rij));
       double ai_cf = 0.0, ai_cd = 0.0, ai_fx = 0.0, ai_fy = 0.0, ai_fz = 0.0;      // the i-j bond's own sums over k1: one write after the loop
-      for (int k1 = i1 + 1; k1 < nj; ++k1) {
+      for (unsigned mk = mi; mk; mk &= mk - 1u) {
+        const int k1 = __ffs(mk) - 1;
         const size_t ok = static_cast<size_t>(k1) * NB + j;
         const double BOjk_f = bo0[ok], BOjk = BOjk_f - cutof2_esub;
-        if (!(BOjk > 0.0)) continue;
         if (!(BOij_f * BOjk_f > cutof2_esub)) continue;
         const int k = nbr[ok], tk = type[k];
         const int inxn = ff.inxn3[(ti * ff.n1 + tj) * ff.n1 + tk];
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
   block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
 }
 
-struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // probe (timing experiments only, RXMD_E4B_PROBE): 1 = set-up only, 2 = phase B skipped    // lattice vectors for the image test of the torsion's stress correction
+struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // probe (timing experiments only, RXMD_E4B_PROBE): 1 = set-up only, 2 = phase B skipped, 5 = PE(8), PE(9) count batches and entries    // lattice vectors for the image test of the torsion's stress correction
 // Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to i,j,k,l.
 // Here ONE WAVEFRONT owns TWO consecutive centre atoms; lane t = (g<<5 | slot) owns the accumulators of bond `slot` of
 // atom g.  Phase A enumerates every (k1,i1,l1) combination of the two atoms, applies the reference's cheap bond-order
@@ -298,7 +301,7 @@ struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // probe (t
 // the i-j bond coefficient always; the k/l side is booked when atom k is the centre.  Per-bond sums are formed by each
 // evaluating lane adding its results to the (atom, slot) accumulators in LDS (ds_add_f64): no global atomics, and the order of the
 // additions is fixed by the queue order and the lane order inside one LDS instruction.
-__global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx, const int *__restrict__ type,
+__global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
                                               const double *__restrict__ etor, const double *__restrict__ econ,
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
   // phase A walks only bonds above the cut-off: the slots of each centre atom that qualify, and per centre bond the qualifying slots
   // of k with what the filter needs of them (bond order, atom l, its type) -- staged once per centre bond by the lanes side by side
-  __shared__ int s_cap[4][64], s_cb[4][64], s_js[4][64], s_capl[4][32];
+  __shared__ int s_cap[4][64], s_capl[4][32], s_ll[4][32], s_tl[4][32];
   __shared__ double s_bokl[4][32];
   // per (atom g, slot) accumulators, updated with LDS atomics by the lanes that evaluate torsions: [0] cf1 and [1..3] force of the
   // i-j bond / its neighbour, [4] cf1, [5] cf2, [6] cdbnd of the centre bond; slot 31 (never a bond) holds the centre atom's own
@@ -338,7 +341,6 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     const double rx = x[i] - xj_me, ry = y[i] - yj_me, rz = z[i] - zj_me;      // r_i - r_j
     const double b = bo0[o];
     cap_me = b > cutof2_esub;
-    s_js[w][lane] = nbrindx[o];                  // the slot j has in this neighbour's list: as a centre bond's k it names l == j
     s_nb[w][lane] = i; s_ty[w][lane] = ti;
     s_bo[w][lane] = b; s_et[w][lane] = etor[o]; s_ec[w][lane] = econ[o];
     s_rx[w][lane] = rx; s_ry[w][lane] = ry; s_rz[w][lane] = rz; s_rn[w][lane] = sqrt(rx * rx + ry * ry + rz * rz);
@@ -356,31 +358,28 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   }
 #pragma unroll
   for (int c = 0; c < 7; ++c) s_acc[w][lane][c] = 0.0;
-  int ncapg[2], ncb;
+  int ncapg[2];
   {                                               // the qualifying slots of each of the two centre atoms, in slot order
     const unsigned long long mc = __ballot(cap_me);
     const unsigned half = static_cast<unsigned>(g_me ? (mc >> 32) : (mc & 0xffffffffULL));
     if (cap_me) s_cap[w][g_me * 32 + __popc(half & ((1u << sl_me) - 1u))] = sl_me;
     ncapg[0] = __popc(static_cast<unsigned>(mc & 0xffffffffULL)); ncapg[1] = __popc(static_cast<unsigned>(mc >> 32));
-    // the centre bonds of the wavefront (a qualifying slot whose k has neighbours), atom 0's first: phase A walks this list and
-    // requests the bond orders of the NEXT centre bond's k while it enumerates the current one
-    const bool cb = cap_me && sl_me < nj_me;     // = s_nk > 0 (cap_me implies the slot exists; nbrcnt of a bonded atom is >= 1)
-    const unsigned long long mb = __ballot(cb);
-    if (cb) s_cb[w][__popcll(mb & ((1ULL << lane) - 1ULL))] = lane;
-    ncb = __popcll(mb);
   }
   wave_lds_sync();
+  const int njg[2] = {__shfl(nj_me, 0, 64), __shfl(nj_me, 32, 64)};
   const int tjg[2] = {__shfl(tj_me, 0, 64), __shfl(tj_me, 32, 64)};
   double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
   int qn = 0;                                     // (slot 31 is never a bond: its lane accumulates the centre atom's own force and cdbnd)
 
   auto evaluate = [&](int cnt) {                  // phase B: the first cnt (<= 64) queue entries, one per lane
     if (bx.probe == 2) return;
+    if (bx.probe == 5) { if (lane == 0) { atomicAdd(pe + 8, 1.0); atomicAdd(pe + 9, static_cast<double>(cnt)); } return; }
     double o[7] = {0, 0, 0, 0, 0, 0, 0};
     V3 fself = {0.0, 0.0, 0.0};
     double cd_self = 0.0;
-    int key = (lane < cnt) ? s_q[w][lane] : -1;
-    if (key >= 0) {
+    int key = -1;
+    if (lane < cnt) {
+      key = s_q[w][lane];
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31, l1 = key & 31;
       const int sk = g * 32 + k1, si = g * 32 + i1;
       const int k = s_nb[w][sk], tk = s_ty[w][sk], tj = tjg[g];
@@ -390,8 +389,6 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
       const size_t ol = static_cast<size_t>(l1) * NB + k;
       const int l = nbr[ol];
       const int inxn = ff.inxn4[((s_ty[w][si] * ff.n1 + tj) * ff.n1 + tk) * ff.n1 + type[l]];
-      if (l == s_nb[w][si] || inxn == 0) key = -1;   // a three-membered ring, or no torsion row (pot.F90:1078-1081): rare, so tested here and not per centre bond
-      else {
       const DevTorsP tp = ff.tors[inxn];
       const V3 rjk = {-s_rx[w][sk], -s_ry[w][sk], -s_rz[w][sk]};          // r_j - r_k
       const double njk = s_rn[w][sk];
@@ -501,7 +498,6 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
           if (t2 != 0.0) { atomicAdd(pe + 18, t2 * F2); atomicAdd(pe + 20, t2 * F0); }     // zz, zx
         }
       }
-      }   // else: a valid torsion
     }
     if (key >= 0) {
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31;
@@ -514,33 +510,27 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   };
 
   if (bx.probe == 1) return;                      // timing experiment: set-up only
-  // phase A: enumerate, filter, compact.  Per centre bond j-k one global round trip (the bond orders of k's slots, pot.F90:1072), and
-  // that one is requested a centre bond ahead; everything else the filter needs sits in LDS.  l == i and a missing torsion row are
-  // tested in phase B (a second and third dependent round trip per centre bond cost more than the rare idle lane there).
-  double bl_next = 0.0;
-  if (ncb > 0) {
-    const int c0_ = s_cb[w][0];
-    if (lane < min(s_nk[w][c0_], WSLOT)) bl_next = bo0[static_cast<size_t>(lane) * NB + s_nb[w][c0_]];
-  }
-  for (int r = 0; r < ncb; ++r) {
-    const int sk = s_cb[w][r];
-    const int g = sk >> 5, k1 = sk & 31;
-    const int ncj = ncapg[g];
-    {
+  // phase A: enumerate, filter, compact
+  for (int g = 0; g < 2; ++g) {
+    const int nj = njg[g], ncj = ncapg[g];
+    for (int k1 = 0; k1 < nj; ++k1) {
+      const int sk = g * 32 + k1;
+      const int nk = s_nk[w][sk];
+      if (nk == 0) continue;
       const double BOjk_f = s_bo[w][sk];
-      const int k = s_nb[w][sk];
-      const int js = s_js[w][sk];
-      const double bl = bl_next;
-      const int nkc = min(s_nk[w][sk], WSLOT);
-      if (r + 1 < ncb) {                          // the next centre bond's column, in flight while this one is enumerated
-        const int sn = s_cb[w][r + 1];
-        bl_next = (lane < min(s_nk[w][sn], WSLOT)) ? bo0[static_cast<size_t>(lane) * NB + s_nb[w][sn]] : 0.0;
-      }
+      const int k = s_nb[w][sk], j = jbase + g;
       int nck;
-      {
+      {                                           // the qualifying slots of k (pot.F90:1072), staged by the lanes side by side
+        const int nkc = min(nk, WSLOT);
+        double bl = 0.0;
+        if (lane < nkc) bl = bo0[static_cast<size_t>(lane) * NB + k];
         const bool capl = (lane < nkc) && (bl > cutof2_esub);
         const unsigned long long ml = __ballot(capl);
-        if (capl) { const int rr = __popcll(ml & ((1ULL << lane) - 1ULL)); s_capl[w][rr] = lane; s_bokl[w][rr] = bl; }
+        if (capl) {
+          const int r = __popcll(ml & ((1ULL << lane) - 1ULL));
+          const int l = nbr[static_cast<size_t>(lane) * NB + k];
+          s_capl[w][r] = lane; s_bokl[w][r] = bl; s_ll[w][r] = l; s_tl[w][r] = type[l];
+        }
         nck = __popcll(ml);
         wave_lds_sync();
       }
@@ -555,8 +545,10 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
           const double BOij_f = s_bo[w][g * 32 + i1];
           const int i = s_nb[w][g * 32 + i1];
           const double BOkl_f = s_bokl[w][cl];
-          go = (i1 != k1) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) && (l1 != js) &&
-               (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0);
+          const int l = s_ll[w][cl];
+          go = (i1 != k1) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
+               (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0) && (l != i) && (l != j);
+          if (go) go = ff.inxn4[((s_ty[w][g * 32 + i1] * ff.n1 + tjg[g]) * ff.n1 + s_ty[w][sk]) * ff.n1 + s_tl[w][cl]] != 0;
         }
         const unsigned long long m = __ballot(go);
         if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
@@ -701,7 +693,7 @@ void Engine::bonded_energies() {
   BoxImg bx;
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
   bx.ortho = grid.ortho; bx.probe = std::getenv("RXMD_E4B_PROBE") ? std::atoi(std::getenv("RXMD_E4B_PROBE")) : 0;
-  k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, nbrindx, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d, bx);
   k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
 }

@@ -245,6 +245,7 @@ struct Engine {
   void rccl_exchange_pair(int to0, int from0, long long n0, long long r0, int to1, int from1, long long n1, long long r1);
   bool stage_pairs = true;                          // RXMD_NO_STAGE_PAIRS=1: one round per stage as the reference does (six per halo)
   void ensure_xbuf(size_t doubles);
+  void grow_xbuf_keep_send(size_t need, size_t keep);
   bool multi() const { return nprocs > 1 || force_staged; }
   // native RCCL transport (rccl_comm.hip); force_staged / force_remote (env RXMD_FORCE_STAGED / RXMD_FORCE_REMOTE) push a
   // single rank through the staged exchange and through RCCL self send/recv: how the multi-GPU code path runs on ONE GPU in the tests

@@ -615,6 +615,19 @@ void Engine::ensure_xbuf(size_t doubles) {
   xbuf_owned = true;
 }
 
+// a message announced by its size message does not fit: the engine's own buffers grow with the packed send data kept (a caller that
+// sized them from its send count only, as the migration does, needs no worst case); host-supplied buffers cannot grow
+void Engine::grow_xbuf_keep_send(size_t need, size_t keep) {
+  if (!xbuf_owned) throw EngineError(RXMD_E_NBUFFER, "incoming message larger than the host-supplied exchange buffers");
+  double *ns = nullptr, *nr = nullptr;
+  const size_t cap = need + need / 4 + 4096;
+  dmalloc(ns, cap); dmalloc(nr, cap);
+  if (keep > 0) RX_HIP(hipMemcpyAsync(ns, xbuf_send, sizeof(double) * keep, hipMemcpyDeviceToDevice, stream));
+  sync_stream();
+  dfree(xbuf_send); dfree(xbuf_recv);
+  xbuf_send = ns; xbuf_recv = nr; xbuf_doubles = cap;
+}
+
 long long Engine::exchange_stage(int d, bool reverse, long long nsend, long long known_nrecv) {
   const int to = reverse ? target_node[dinv_[d]] : target_node[d];
   const int from = reverse ? target_node[d] : target_node[dinv_[d]];

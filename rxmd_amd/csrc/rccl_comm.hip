@@ -89,7 +89,7 @@ long long Engine::rccl_exchange(int to, int from, long long nsend, long long kno
     RX_HIP(hipMemcpyAsync(cnt_host + 1, cnt_dev + 1, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync_stream();
     nrecv = static_cast<long long>(cnt_host[1]);
-    if (nrecv > static_cast<long long>(xbuf_doubles)) throw EngineError(RXMD_E_NBUFFER, "incoming message larger than the exchange buffer");
+    if (nrecv > static_cast<long long>(xbuf_doubles)) grow_xbuf_keep_send(static_cast<size_t>(nrecv), static_cast<size_t>(nsend));
   }
   if (nsend > 0 || nrecv > 0) {
     RX_NCCL(ncclGroupStart());
@@ -128,7 +128,7 @@ void Engine::rccl_exchange_pair_sized(int to0, int from0, long long n0, long lon
   RX_HIP(hipMemcpyAsync(cnt_host + 2, cnt_dev + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
   sync_stream();
   r0 = static_cast<long long>(cnt_host[2]); r1 = static_cast<long long>(cnt_host[3]);
-  if (r0 + r1 > static_cast<long long>(xbuf_doubles)) throw EngineError(RXMD_E_NBUFFER, "incoming messages larger than the exchange buffer");
+  if (r0 + r1 > static_cast<long long>(xbuf_doubles)) grow_xbuf_keep_send(static_cast<size_t>(r0 + r1), static_cast<size_t>(n0 + n1));
   rccl_exchange_pair(to0, from0, n0, r0, to1, from1, n1, r1);
 }
 
