@@ -149,21 +149,11 @@ constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages
 #ifndef E4B_MINB
 #define E4B_MINB 3
 #endif
-// Work order of the thread-per-centre angle kernel.  The cost of a centre atom grows with the square of its bonds above the bond-order
-// cut-off (RDX: a hydrogen has none or one, a ring carbon four to six), so in atom order a wavefront waits for its heaviest lane
-// while half of its lanes idle.  The centres are handed out sorted by that count, heaviest first: the lanes of a wavefront then run
-// loops of equal length.  Every centre writes only its own slots, so the order changes no result.
-__global__ void k_angle_key(int N, int NB, const int *__restrict__ nbrcnt, const double *__restrict__ bo0, int *__restrict__ key, int *__restrict__ idx) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= N) return;
-  int c = 0;
-  const int nj = nbrcnt[j];
-  for (int s = 0; s < nj; ++s) c += (bo0[static_cast<size_t>(s) * NB + j] > cutof2_esub) ? 1 : 0;
-  key[j] = 31 - min(c, 31);
-  idx[j] = j;
-}
-
-__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ order, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+// Work order of the thread-per-centre angle kernel: atom order.  (Round 2 first handed the centres out sorted by their number of bonds
+// above the cut-off -- 3.5 -> 2.8 ms while the loops walked slots; once they walk set bits (below) a lane's trip count is its own
+// pair count, and the sorted order only scatters the slot-major accesses, one 64-byte line per lane: 2.7 ms sorted, 1.8 ms in atom
+// order, sorted inside tiles of 128 / 256 / 512 / 1024 atoms 1.84 / 1.97 / 2.86 / 4.19 ms.)
+__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
                                               const double *__restrict__ delta, const double *__restrict__ nlp, const double *__restrict__ dDlp,
@@ -174,7 +164,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
   if (tid < N) {
-    const int j = order ? order[tid] : tid;
+    const int j = tid;
     const int tj = type[j], nj = nbrcnt[j];
     const DevAtomP aj = ff.atom[tj];
     const double xj = x[j], yj = y[j], zj = z[j];
@@ -680,15 +670,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
 void Engine::bonded_energies() {
   double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
   k_ebond_elnpr<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, dDlp, cf1, cf2, cf3, cdn, ecoa, pe_d);
-  // centres sorted by their number of bonds above the cut-off, heaviest first (scratch: the scan arrays of the ghost build)
-  const int *order = nullptr;
-  if (std::getenv("RXMD_E3B_ATOM_ORDER") == nullptr && N > 0) {
-    k_angle_key<<<nblk(N, 256), 256, 0, stream>>>(N, NB, nbrcnt, bo0, flags, flags2);
-    size_t tb = cubtmp_bytes;
-    RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, flags, scanout, flags2, scanout2, N, 0, 5, stream));
-    order = scanout2;
-  }
-  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, order, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
   BoxImg bx;
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }

@@ -8,7 +8,7 @@ B="python3 bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline"
 RXMD_SPMV_PIPE=1 $B > $O/b_pipe1.json 2> $O/b_pipe1.err
 RXMD_SPMV_PIPE=2 $B > $O/b_pipe2.json 2>/dev/null
 RXMD_SPMV_PIPE=0 $B > $O/b_pipe0.json 2>/dev/null
-RXMD_SPMV_PIPE=1 RXMD_E3B_ATOM_ORDER=1 $B > $O/b_pipe1_e3batom.json 2>/dev/null
+RXMD_SPMV_PIPE=1 $B > $O/b_pipe1_e3batom.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $O/prof_default.log 2>&1
 python3 - <<PY
 import csv,glob
