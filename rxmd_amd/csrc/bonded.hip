@@ -3,7 +3,7 @@
 //   E3b   (pot.F90:319-557)                           -> k_e3b   (thread per centre atom)
 //   E4b   (pot.F90:980-1227)                          -> k_e4b   (wavefront per two centre atoms, ballot-compacted work queue;
 //                                                                  every torsion visited from both ends)
-//   Ehb   (pot.F90:559-673)                           -> k_ehb   (one wavefront per donor atom)
+//   Ehb   (pot.F90:559-673)                           -> k_ehb   (a wavefront finds the donors among 64 atoms, then sweeps their rows)
 // The reference scatters every derivative at once with atomics (ForceB/ForceBbo/ForceA3/ForceA4,
 // pot.F90:1276-1521).  Here a thread owns one centre atom and accumulates ONLY into that atom's own
 // rows of the slot-major tables:
@@ -300,10 +300,9 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, BoxImg bx) {
   // per (atom g, slot): the bond as seen from the centre
   __shared__ double s_bo[4][64], s_et[4][64], s_ec[4][64], s_rx[4][64], s_ry[4][64], s_rz[4][64], s_rn[4][64];
-  __shared__ int s_nb[4][64], s_ty[4][64];
-  // per (atom g, slot) as CENTRE bond k1: factors shared by all torsions around it; s_nk = 0 marks "no torsion through this bond"
+  __shared__ int s_nb[4][64], s_meta[4][64];     // s_meta: type of the neighbour | its bond count << 8 | "this centre owns the bond" << 16
+  // per (atom g, slot) as CENTRE bond k1: factors shared by all torsions around it; a bond count of 0 marks "no torsion through this bond"
   __shared__ double s_btb2[4][64], s_dfn11[4][64];
-  __shared__ int s_nk[4][64], s_own[4][64];
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
   // phase A walks only bonds above the cut-off: the slots of each centre atom that qualify, and per centre bond the qualifying slots
   // of k with what the filter needs of them (bond order, atom l, its type) -- staged once per centre bond by the lanes side by side
@@ -323,7 +322,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   const int nj_me = has_me ? min(nbrcnt[j_me], WSLOT) : 0;
   const int tj_me = has_me ? type[j_me] : 1;
   const double xj_me = has_me ? x[j_me] : 0.0, yj_me = has_me ? y[j_me] : 0.0, zj_me = has_me ? z[j_me] : 0.0;
-  s_nk[w][lane] = 0;
+  s_meta[w][lane] = 0;
   bool cap_me = false;
   if (sl_me < nj_me) {
     const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
@@ -331,7 +330,8 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     const double rx = x[i] - xj_me, ry = y[i] - yj_me, rz = z[i] - zj_me;      // r_i - r_j
     const double b = bo0[o];
     cap_me = b > cutof2_esub;
-    s_nb[w][lane] = i; s_ty[w][lane] = ti;
+    s_nb[w][lane] = i;
+    int meta = ti;
     s_bo[w][lane] = b; s_et[w][lane] = etor[o]; s_ec[w][lane] = econ[o];
     s_rx[w][lane] = rx; s_ry[w][lane] = ry; s_rz[w][lane] = rz; s_rn[w][lane] = sqrt(rx * rx + ry * ry + rz * rz);
     if (b > cutof2_esub) {                       // this slot as a centre bond j-k (pot.F90:1023)
@@ -342,9 +342,9 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
       const double fn11 = (2.0 + exp_tor3) * exp_tor34_i;
       s_dfn11[w][lane] = (-ff.ptor3 * exp_tor3 + (ff.ptor3 * exp_tor3 - ff.ptor4 * exp_tor4) * (2.0 + exp_tor3) * exp_tor34_i) * exp_tor34_i;
       s_btb2[w][lane] = 2.0 - bo2[o] - fn11;
-      s_nk[w][lane] = nbrcnt[i];
-      s_own[w][lane] = gid[j_me] < gid[i] ? 1 : 0;
+      meta |= (min(nbrcnt[i], 255) << 8) | (gid[j_me] < gid[i] ? 1 << 16 : 0);
     }
+    s_meta[w][lane] = meta;
   }
 #pragma unroll
   for (int c = 0; c < 7; ++c) s_acc[w][lane][c] = 0.0;
@@ -372,13 +372,13 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
       key = s_q[w][lane];
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31, l1 = key & 31;
       const int sk = g * 32 + k1, si = g * 32 + i1;
-      const int k = s_nb[w][sk], tk = s_ty[w][sk], tj = tjg[g];
+      const int k = s_nb[w][sk], mk_ = s_meta[w][sk], tk = mk_ & 255, tj = tjg[g];
       const double BOjk_f = s_bo[w][sk], BOij_f = s_bo[w][si];
       const double BOjk = BOjk_f - cutof2_esub, BOij = BOij_f - cutof2_esub;
-      const bool own = s_own[w][sk] != 0;
+      const bool own = (mk_ >> 16) != 0;
       const size_t ol = static_cast<size_t>(l1) * NB + k;
       const int l = nbr[ol];
-      const int inxn = ff.inxn4[((s_ty[w][si] * ff.n1 + tj) * ff.n1 + tk) * ff.n1 + type[l]];
+      const int inxn = ff.inxn4[(((s_meta[w][si] & 255) * ff.n1 + tj) * ff.n1 + tk) * ff.n1 + type[l]];
       const DevTorsP tp = ff.tors[inxn];
       const V3 rjk = {-s_rx[w][sk], -s_ry[w][sk], -s_rz[w][sk]};          // r_j - r_k
       const double njk = s_rn[w][sk];
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     const int nj = njg[g], ncj = ncapg[g];
     for (int k1 = 0; k1 < nj; ++k1) {
       const int sk = g * 32 + k1;
-      const int nk = s_nk[w][sk];
+      const int nk = (s_meta[w][sk] >> 8) & 255;
       if (nk == 0) continue;
       const double BOjk_f = s_bo[w][sk];
       const int k = s_nb[w][sk], j = jbase + g;
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
           const int l = s_ll[w][cl];
           go = (i1 != k1) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
                (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0) && (l != i) && (l != j);
-          if (go) go = ff.inxn4[((s_ty[w][g * 32 + i1] * ff.n1 + tjg[g]) * ff.n1 + s_ty[w][sk]) * ff.n1 + s_tl[w][cl]] != 0;
+          if (go) go = ff.inxn4[(((s_meta[w][g * 32 + i1] & 255) * ff.n1 + tjg[g]) * ff.n1 + (s_meta[w][sk] & 255)) * ff.n1 + s_tl[w][cl]] != 0;
         }
         const unsigned long long m = __ballot(go);
         if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
@@ -580,87 +580,128 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Hydrogen bonds.  One wavefront per donor atom i; lanes sweep i's 10 A row for acceptors k.
+// Hydrogen bonds.  The lanes of a wavefront sweep the 10 A row of a donor atom i for acceptors k.
 // Hydrogen is atom type 2, hard-coded in the reference (pot.F90:595) and kept.
 __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10,
                                               const double4 *__restrict__ pk, const int *__restrict__ perm,
                                               double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                              double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
-  const int lane = threadIdx.x & 63;
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
+                                              double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, int probe) {
+  constexpr int EHB_CHUNK = 640;                          // row entries compacted at a time (a row of the default stride in one go)
+  __shared__ unsigned s_cand[4][EHB_CHUNK];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  // A wavefront takes 64 consecutive atoms.  First every lane decides for its own atom whether it is a donor with a hydrogen partner
+  // (coalesced slot-major reads; in RDX one atom in fourteen is) and leaves a bit mask of those slots; then the wavefront sweeps the
+  // 10 A rows of the atoms that have one, one after the other.  (One wavefront per atom spent most of the kernel starting a million
+  // wavefronts that found nothing: 1.5 ms, of which the sweeps themselves were about a third.)
+  const int a0 = (xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w) * 64;
   double e10 = 0.0;
-  if (i < N) {
-    const int ti = type[i], cnt = nbrcnt[i];
-    bool donor = false;                                  // does any (ti, 2, k) hydrogen-bond row exist?
+  unsigned hslots = 0u;
+  int ti_l = 0;
+  if (a0 + lane < N) {
+    const int ia = a0 + lane;
+    ti_l = type[ia];
+    bool donor_l = false;                                // does any (ti, 2, k) hydrogen-bond row exist?
     if (ff.nso >= 2)
-      for (int t = 1; t <= ff.nso; ++t) donor |= (ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + t] != 0);
-    if (donor) {
+      for (int t = 1; t <= ff.nso; ++t) donor_l |= (ff.inxn3hb[(ti_l * ff.n1 + 2) * ff.n1 + t] != 0);
+    if (donor_l) {
+      const int cnt_l = min(nbrcnt[ia], 32);
+      for (int sl = 0; sl < cnt_l; ++sl) {
+        const size_t ol = static_cast<size_t>(sl) * NB + ia;
+        if (type[nbr[ol]] == 2 && bo0[ol] > MINBO0) hslots |= 1u << sl;      // pot.F90:595
+      }
+    }
+  }
+  for (unsigned long long todo = __ballot(hslots != 0u); todo; todo &= todo - 1) {
+    const int src = __ffsll(static_cast<long long>(todo)) - 1;
+    const int i = a0 + src;                                // wave-uniform
+    const int ti = __shfl(ti_l, src, 64);
+    unsigned long long hmask = static_cast<unsigned long long>(__shfl(static_cast<int>(hslots), src, 64)) & 0xffffffffULL;
+    {
       const double xi = x[i], yi = y[i], zi = z[i];
       const int n = n10[i];
       const size_t row = static_cast<size_t>(i) * S10;
       const int inx_l = (lane >= 1 && lane <= ff.nso) ? ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + lane] : 0;
-      // the lanes test the bond slots side by side (one round trip instead of cnt dependent ones: three atoms in four have no
-      // hydrogen partner and leave here); the surviving slots are then visited in slot order
-      int jl = 0; double bl = 0.0; bool hq = false;
-      if (lane < cnt) {
+      int jl = 0; double bl = 0.0;                       // lane s holds atom and bond order of slot s
+      if (lane < 32 && ((hmask >> lane) & 1ULL)) {
         const size_t ol = static_cast<size_t>(lane) * NB + i;
         jl = nbr[ol]; bl = bo0[ol];
-        hq = (type[jl] == 2 && bl > MINBO0);
       }
-      unsigned long long hmask = __ballot(hq);
-      while (hmask) {
-        const int s = __ffsll(static_cast<long long>(hmask)) - 1;
-        hmask &= hmask - 1;
-        const size_t o = static_cast<size_t>(s) * NB + i;
-        const int j = __shfl(jl, s, 64);
-        const double BOij = __shfl(bl, s, 64);
-        const V3 rij = {xi - x[j], yi - y[j], zi - z[j]};
-        const double nij = sqrt(dot(rij, rij));
-        double cfs = 0.0, nterm = 0.0;
-        V3 fi_s = {0, 0, 0}, fj_s = {0, 0, 0};
-        for (int k0 = 0; k0 < n; k0 += 64) {                                // wave-uniform trip count: the shuffle below needs every lane
-          const int kk = k0 + lane;
-          const unsigned ent = kk < n ? static_cast<unsigned>(nb10[row + kk]) : 0u;
-          const int inx = __shfl(inx_l, static_cast<int>((ent >> NB10_IDX_BITS) & 15u), 64);   // (ti, H, type k) row, held by lane = type k
-          if (kk >= n || inx == 0) continue;
-          const int ks = static_cast<int>(ent & NB10_IDX_MASK);
-          const int k = perm[ks];                                          // list entries are cell-sorted positions
-          if (k == j || k == i) continue;
-          const double4 pk_ = pk[ks];
-          const V3 rik = {xi - pk_.x, yi - pk_.y, zi - pk_.z};
-          if (!(dot(rik, rik) < 100.0)) continue;                          // rchb2, pot.F90:610
-          const DevHbP hp = ff.hb[inx];
-          const V3 rjk = {x[j] - pk_.x, y[j] - pk_.y, z[j] - pk_.z};
-          const double njk = sqrt(dot(rjk, rjk));
-          double cos_ijk = -dot(rij, rjk) / (nij * njk);
-          if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
-          if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
-          const double sh2 = 0.5 * (1.0 - cos_ijk);                        // sin^2(theta/2)
-          const double sin_xhz4 = sh2 * sh2, cos_xhz1 = 1.0 - cos_ijk;
-          const double exp_hb2 = exp(-hp.phb2 * BOij);
-          const double exp_hb3 = exp(-hp.phb3 * (hp.r0hb / njk + njk / hp.r0hb - 2.0));
-          const double PEhb = hp.phb1 * (1.0 - exp_hb2) * exp_hb3 * sin_xhz4;
-          e10 += PEhb; nterm += 1.0;
-          cfs += hp.phb1 * hp.phb2 * exp_hb2 * exp_hb3 * sin_xhz4;         // CEhb(1) -> ForceB(i,j)
-          const double CEhb2 = -0.5 * hp.phb1 * (1.0 - exp_hb2) * exp_hb3 * cos_xhz1;
-          const double CEhb3 = -PEhb * hp.phb3 * (-hp.r0hb / (njk * njk) + 1.0 / hp.r0hb) * (1.0 / njk);
-          V3 fi, fk;
-          angle_forces(CEhb2, rij, nij, rjk, njk, fi, fk);
-          const V3 ff3 = {CEhb3 * rjk.x, CEhb3 * rjk.y, CEhb3 * rjk.z};   // f(j) -= ff ; f(k) += ff
-          fi_s.x += fi.x; fi_s.y += fi.y; fi_s.z += fi.z;
-          fj_s.x += -(fi.x + fk.x) - ff3.x; fj_s.y += -(fi.y + fk.y) - ff3.y; fj_s.z += -(fi.z + fk.z) - ff3.z;
-          atomicAdd(fx + k, fk.x + ff3.x); atomicAdd(fy + k, fk.y + ff3.y); atomicAdd(fz + k, fk.z + ff3.z);
+      // The acceptor candidates of the row depend on the types only, not on the hydrogen: they are compacted once into LDS (the 64
+      // entry words of every batch requested together, one round trip for the whole row), and every hydrogen slot then walks dense
+      // batches whose loads -- atom, position, parameter row -- are independent of each other.  Walking the row itself cost four
+      // dependent round trips per 64 entries, half of them without a parameter row (1.87 -> 1.48 ms).
+      for (int c0 = 0; hmask != 0ULL && c0 < n; c0 += EHB_CHUNK) {
+        const int cend = min(n, c0 + EHB_CHUNK);
+        unsigned ent[EHB_CHUNK / 64];
+#pragma unroll
+        for (int u = 0; u < EHB_CHUNK / 64; ++u) { const int kk = c0 + 64 * u + lane; ent[u] = kk < cend ? static_cast<unsigned>(nb10[row + kk]) : 0xffffffffu; }
+        int qn = 0;
+#pragma unroll
+        for (int u = 0; u < EHB_CHUNK / 64; ++u) {
+          if (c0 + 64 * u >= cend) break;                                    // wave-uniform
+          const bool valid = ent[u] != 0xffffffffu;
+          const int inx = __shfl(inx_l, static_cast<int>((ent[u] >> NB10_IDX_BITS) & 15u), 64);   // (ti, H, type k) row, held by lane = type k
+          const bool keep = valid && inx != 0;
+          const unsigned long long m = __ballot(keep);
+          if (keep) s_cand[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = ent[u];
+          qn += __popcll(m);
         }
-        cfs = wave_sum_b(cfs); nterm = wave_sum_b(nterm);
-        fi_s.x = wave_sum_b(fi_s.x); fi_s.y = wave_sum_b(fi_s.y); fi_s.z = wave_sum_b(fi_s.z);
-        fj_s.x = wave_sum_b(fj_s.x); fj_s.y = wave_sum_b(fj_s.y); fj_s.z = wave_sum_b(fj_s.z);
-        if (lane == 0 && nterm > 0.0) {
-          cf1[o] += cfs;
-          fnx[o] += fj_s.x; fny[o] += fj_s.y; fnz[o] += fj_s.z;
-          atomicAdd(fx + i, fi_s.x); atomicAdd(fy + i, fi_s.y); atomicAdd(fz + i, fi_s.z);
+        wave_lds_sync();
+        for (unsigned long long hm = hmask; hm; hm &= hm - 1) {
+          const int s = __ffsll(static_cast<long long>(hm)) - 1;
+          const size_t o = static_cast<size_t>(s) * NB + i;
+          const int j = __shfl(jl, s, 64);
+          const double BOij = __shfl(bl, s, 64);
+          const double xj = x[j], yj = y[j], zj = z[j];
+          const V3 rij = {xi - xj, yi - yj, zi - zj};
+          const double nij = sqrt(dot(rij, rij));
+          double cfs = 0.0, nterm = 0.0;
+          V3 fi_s = {0, 0, 0}, fj_s = {0, 0, 0};
+          for (int q0 = 0; q0 < qn; q0 += 64) {                              // wave-uniform trip count: the shuffle below needs every lane
+            const int qq = q0 + lane;
+            const unsigned e = qq < qn ? s_cand[w][qq] : 0u;
+            const int inx = __shfl(inx_l, static_cast<int>((e >> NB10_IDX_BITS) & 15u), 64);
+            if (qq >= qn) continue;
+            const int ks = static_cast<int>(e & NB10_IDX_MASK);
+            const int k = perm[ks];                                          // list entries are cell-sorted positions
+            const double4 pk_ = pk[ks];
+            const DevHbP hp = ff.hb[inx];
+            if (k == j || k == i) continue;
+            const V3 rik = {xi - pk_.x, yi - pk_.y, zi - pk_.z};
+            if (!(dot(rik, rik) < 100.0)) continue;                          // rchb2, pot.F90:610
+            const V3 rjk = {xj - pk_.x, yj - pk_.y, zj - pk_.z};
+            const double njk = sqrt(dot(rjk, rjk));
+            double cos_ijk = -dot(rij, rjk) / (nij * njk);
+            if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
+            if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
+            const double sh2 = 0.5 * (1.0 - cos_ijk);                        // sin^2(theta/2)
+            const double sin_xhz4 = sh2 * sh2, cos_xhz1 = 1.0 - cos_ijk;
+            const double exp_hb2 = exp(-hp.phb2 * BOij);
+            const double exp_hb3 = exp(-hp.phb3 * (hp.r0hb / njk + njk / hp.r0hb - 2.0));
+            const double PEhb = hp.phb1 * (1.0 - exp_hb2) * exp_hb3 * sin_xhz4;
+            e10 += PEhb; nterm += 1.0;
+            cfs += hp.phb1 * hp.phb2 * exp_hb2 * exp_hb3 * sin_xhz4;         // CEhb(1) -> ForceB(i,j)
+            const double CEhb2 = -0.5 * hp.phb1 * (1.0 - exp_hb2) * exp_hb3 * cos_xhz1;
+            const double CEhb3 = -PEhb * hp.phb3 * (-hp.r0hb / (njk * njk) + 1.0 / hp.r0hb) * (1.0 / njk);
+            V3 fi, fk;
+            angle_forces(CEhb2, rij, nij, rjk, njk, fi, fk);
+            const V3 ff3 = {CEhb3 * rjk.x, CEhb3 * rjk.y, CEhb3 * rjk.z};   // f(j) -= ff ; f(k) += ff
+            fi_s.x += fi.x; fi_s.y += fi.y; fi_s.z += fi.z;
+            fj_s.x += -(fi.x + fk.x) - ff3.x; fj_s.y += -(fi.y + fk.y) - ff3.y; fj_s.z += -(fi.z + fk.z) - ff3.z;
+            if (probe != 1) { atomicAdd(fx + k, fk.x + ff3.x); atomicAdd(fy + k, fk.y + ff3.y); atomicAdd(fz + k, fk.z + ff3.z); }
+          }
+          cfs = wave_sum_b(cfs); nterm = wave_sum_b(nterm);
+          fi_s.x = wave_sum_b(fi_s.x); fi_s.y = wave_sum_b(fi_s.y); fi_s.z = wave_sum_b(fi_s.z);
+          fj_s.x = wave_sum_b(fj_s.x); fj_s.y = wave_sum_b(fj_s.y); fj_s.z = wave_sum_b(fj_s.z);
+          if (lane == 0 && nterm > 0.0) {
+            cf1[o] += cfs;
+            fnx[o] += fj_s.x; fny[o] += fj_s.y; fnz[o] += fj_s.z;
+            atomicAdd(fx + i, fi_s.x); atomicAdd(fy + i, fi_s.y); atomicAdd(fz + i, fi_s.z);
+          }
         }
+        wave_lds_sync();
       }
     }
   }
@@ -677,7 +718,7 @@ void Engine::bonded_energies() {
   bx.ortho = grid.ortho; bx.probe = std::getenv("RXMD_E4B_PROBE") ? std::atoi(std::getenv("RXMD_E4B_PROBE")) : 0;
   k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d, bx);
-  k_ehb<<<nblk(N, 4), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
+  k_ehb<<<nblk(N, 256), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, std::getenv("RXMD_EHB_PROBE") ? std::atoi(std::getenv("RXMD_EHB_PROBE")) : 0);
 }
 
 }  // namespace rxmd
