@@ -282,8 +282,10 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
 
 struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // probe (timing experiments only, RXMD_E4B_PROBE): 1 = set-up only, 2 = phase B skipped, 5 = PE(8), PE(9) count batches and entries    // lattice vectors for the image test of the torsion's stress correction
 // Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to i,j,k,l.
-// Here ONE WAVEFRONT owns TWO consecutive centre atoms; lane t = (g<<5 | slot) owns the accumulators of bond `slot` of
-// atom g.  Phase A enumerates every (k1,i1,l1) combination of the two atoms, applies the reference's cheap bond-order
+// Here ONE WAVEFRONT owns NG = 64 / SL consecutive centre atoms; lane t = (g * SL + slot) owns the accumulators of bond `slot` of
+// atom g.  SL = 32 slots (two atoms) holds any list (MAXNEIGHBS = 30); SL = 16 (four atoms) is launched when no atom of the step has
+// more than 15 bonds, as in RDX: half as many wavefronts set up and enumerate, and their queues fill the 64-lane batches better
+// (two RDX atoms queue 52 torsions: 1.38 batches per wavefront at 58 % of the lanes).  Phase A enumerates every (k1,i1,l1) combination of the two atoms, applies the reference's cheap bond-order
 // cut-offs (pot.F90:1023,1044,1072,1078,1081) and compacts the survivors with a ballot into an LDS queue; phase B
 // evaluates 64 surviving torsions at a time with every lane busy (only ~1 in 8 combinations survives in RDX).
 // A torsion is visited from both ends: a lane books the energy, the j-k bond coefficient and the cdbnd terms only when
@@ -291,6 +293,7 @@ struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // probe (t
 // the i-j bond coefficient always; the k/l side is booked when atom k is the centre.  Per-bond sums are formed by each
 // evaluating lane adding its results to the (atom, slot) accumulators in LDS (ds_add_f64): no global atomics, and the order of the
 // additions is fixed by the queue order and the lane order inside one LDS instruction.
+template <int LSL>
 __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
@@ -306,20 +309,22 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
   // phase A walks only bonds above the cut-off: the slots of each centre atom that qualify, and per centre bond the qualifying slots
   // of k with what the filter needs of them (bond order, atom l, its type) -- staged once per centre bond by the lanes side by side
-  __shared__ int s_cap[4][64], s_capl[4][32], s_ll[4][32], s_tl[4][32];
+  __shared__ int s_cap[4][64], s_capl[4][32], s_ll[4][32], s_tl[4][32], s_gj[4][4][2];   // s_gj: bond count and type of each centre atom
   __shared__ double s_bokl[4][32];
   // per (atom g, slot) accumulators, updated with LDS atomics by the lanes that evaluate torsions: [0] cf1 and [1..3] force of the
   // i-j bond / its neighbour, [4] cf1, [5] cf2, [6] cdbnd of the centre bond; slot 31 (never a bond) holds the centre atom's own
   // force in [1..3] and cdbnd in [6].  (An earlier version wrote 11 results per torsion to LDS and let every owner lane scan all 64
   // of them: that scan cost about as many instructions as the torsion itself.)
   __shared__ double s_acc[4][64][7];
+  constexpr int SL = 1 << LSL, NG = 64 >> LSL, SELF = SL - 1;       // slots per atom, atoms per wavefront, the slot that stands for the atom itself
+  constexpr unsigned GM = (SL == 32) ? 0xffffffffu : ((1u << (SL & 31)) - 1u);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
-  const int jbase = (blockIdx.x * 4 + w) * 2;
+  const int jbase = (blockIdx.x * 4 + w) * NG;
   if (jbase >= N) return;                        // whole wavefront leaves together; no block-level barrier below
-  const int g_me = lane >> 5, sl_me = lane & 31;
+  const int g_me = lane >> LSL, sl_me = lane & (SL - 1);
   const int j_me = jbase + g_me;
   const bool has_me = j_me < N;
-  const int nj_me = has_me ? min(nbrcnt[j_me], WSLOT) : 0;
+  const int nj_me = has_me ? min(nbrcnt[j_me], SELF) : 0;
   const int tj_me = has_me ? type[j_me] : 1;
   const double xj_me = has_me ? x[j_me] : 0.0, yj_me = has_me ? y[j_me] : 0.0, zj_me = has_me ? z[j_me] : 0.0;
   s_meta[w][lane] = 0;
@@ -348,18 +353,15 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   }
 #pragma unroll
   for (int c = 0; c < 7; ++c) s_acc[w][lane][c] = 0.0;
-  int ncapg[2];
-  {                                               // the qualifying slots of each of the two centre atoms, in slot order
-    const unsigned long long mc = __ballot(cap_me);
-    const unsigned half = static_cast<unsigned>(g_me ? (mc >> 32) : (mc & 0xffffffffULL));
-    if (cap_me) s_cap[w][g_me * 32 + __popc(half & ((1u << sl_me) - 1u))] = sl_me;
-    ncapg[0] = __popc(static_cast<unsigned>(mc & 0xffffffffULL)); ncapg[1] = __popc(static_cast<unsigned>(mc >> 32));
+  const unsigned long long capmask = __ballot(cap_me);
+  {                                               // the qualifying slots of each centre atom, in slot order
+    const unsigned mine = static_cast<unsigned>(capmask >> (g_me * SL)) & GM;
+    if (cap_me) s_cap[w][g_me * SL + __popc(mine & ((1u << sl_me) - 1u))] = sl_me;
+    if (sl_me == 0) { s_gj[w][g_me][0] = nj_me; s_gj[w][g_me][1] = tj_me; }
   }
   wave_lds_sync();
-  const int njg[2] = {__shfl(nj_me, 0, 64), __shfl(nj_me, 32, 64)};
-  const int tjg[2] = {__shfl(tj_me, 0, 64), __shfl(tj_me, 32, 64)};
   double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
-  int qn = 0;                                     // (slot 31 is never a bond: its lane accumulates the centre atom's own force and cdbnd)
+  int qn = 0;                                     // (slot SELF is never a bond: its lane accumulates the centre atom's own force and cdbnd)
 
   auto evaluate = [&](int cnt) {                  // phase B: the first cnt (<= 64) queue entries, one per lane
     if (bx.probe == 2) return;
@@ -371,8 +373,8 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     if (lane < cnt) {
       key = s_q[w][lane];
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31, l1 = key & 31;
-      const int sk = g * 32 + k1, si = g * 32 + i1;
-      const int k = s_nb[w][sk], mk_ = s_meta[w][sk], tk = mk_ & 255, tj = tjg[g];
+      const int sk = g * SL + k1, si = g * SL + i1;
+      const int k = s_nb[w][sk], mk_ = s_meta[w][sk], tk = mk_ & 255, tj = s_gj[w][g][1];
       const double BOjk_f = s_bo[w][sk], BOij_f = s_bo[w][si];
       const double BOjk = BOjk_f - cutof2_esub, BOij = BOij_f - cutof2_esub;
       const bool own = (mk_ >> 16) != 0;
@@ -491,7 +493,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     }
     if (key >= 0) {
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31;
-      double *ai = &s_acc[w][g * 32 + i1][0], *ak = &s_acc[w][g * 32 + k1][0], *as = &s_acc[w][g * 32 + 31][0];
+      double *ai = &s_acc[w][g * SL + i1][0], *ak = &s_acc[w][g * SL + k1][0], *as = &s_acc[w][g * SL + SELF][0];
       atomicAdd(ai + 0, o[0]); atomicAdd(ai + 1, o[1]); atomicAdd(ai + 2, o[2]); atomicAdd(ai + 3, o[3]);
       atomicAdd(ak + 4, o[4]); atomicAdd(ak + 5, o[5]); atomicAdd(ak + 6, o[6]);
       atomicAdd(as + 1, fself.x); atomicAdd(as + 2, fself.y); atomicAdd(as + 3, fself.z); atomicAdd(as + 6, cd_self);
@@ -501,10 +503,11 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
 
   if (bx.probe == 1) return;                      // timing experiment: set-up only
   // phase A: enumerate, filter, compact
-  for (int g = 0; g < 2; ++g) {
-    const int nj = njg[g], ncj = ncapg[g];
+  for (int g = 0; g < NG; ++g) {
+    const int nj = __builtin_amdgcn_readfirstlane(s_gj[w][g][0]), tjc = __builtin_amdgcn_readfirstlane(s_gj[w][g][1]);
+    const int ncj = __popc(static_cast<unsigned>(capmask >> (g * SL)) & GM);
     for (int k1 = 0; k1 < nj; ++k1) {
-      const int sk = g * 32 + k1;
+      const int sk = g * SL + k1;
       const int nk = (s_meta[w][sk] >> 8) & 255;
       if (nk == 0) continue;
       const double BOjk_f = s_bo[w][sk];
@@ -531,14 +534,14 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
         int i1 = 0, l1 = 0;
         if (c < total) {
           const int ci = c / nck, cl = c - ci * nck;
-          i1 = s_cap[w][g * 32 + ci]; l1 = s_capl[w][cl];
-          const double BOij_f = s_bo[w][g * 32 + i1];
-          const int i = s_nb[w][g * 32 + i1];
+          i1 = s_cap[w][g * SL + ci]; l1 = s_capl[w][cl];
+          const double BOij_f = s_bo[w][g * SL + i1];
+          const int i = s_nb[w][g * SL + i1];
           const double BOkl_f = s_bokl[w][cl];
           const int l = s_ll[w][cl];
           go = (i1 != k1) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
                (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0) && (l != i) && (l != j);
-          if (go) go = ff.inxn4[(((s_meta[w][g * 32 + i1] & 255) * ff.n1 + tjg[g]) * ff.n1 + (s_meta[w][sk] & 255)) * ff.n1 + s_tl[w][cl]] != 0;
+          if (go) go = ff.inxn4[(((s_meta[w][g * SL + i1] & 255) * ff.n1 + tjc) * ff.n1 + (s_meta[w][sk] & 255)) * ff.n1 + s_tl[w][cl]] != 0;
         }
         const unsigned long long m = __ballot(go);
         if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
@@ -568,7 +571,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     if (a_cdk != 0.0) cdn[o] += a_cdk;
     if (a_fx != 0.0 || a_fy != 0.0 || a_fz != 0.0) { fnx[o] += a_fx; fny[o] += a_fy; fnz[o] += a_fz; }
   }
-  if (sl_me == 31 && has_me) {
+  if (sl_me == SELF && has_me) {
     cds[j_me] += a_cdk;
     fx[j_me] += a_fx; fy[j_me] += a_fy; fz[j_me] += a_fz;
   }
@@ -716,8 +719,13 @@ void Engine::bonded_energies() {
   BoxImg bx;
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
   bx.ortho = grid.ortho; bx.probe = std::getenv("RXMD_E4B_PROBE") ? std::atoi(std::getenv("RXMD_E4B_PROBE")) : 0;
-  k_e4b<<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
+  // four atoms per wavefront when every bond list of this step fits 15 slots (h_err[2] = the largest list, read with the error word
+  // after the list build); RXMD_E4B_SLOTS=32 forces the general kernel (tests)
+  const bool narrow = h_err[2] <= 15 && !(std::getenv("RXMD_E4B_SLOTS") && std::atoi(std::getenv("RXMD_E4B_SLOTS")) == 32);
+  if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+                                                         cds, frc[0], frc[1], frc[2], pe_d, bx);
+  else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+                                                 cds, frc[0], frc[1], frc[2], pe_d, bx);
   k_ehb<<<nblk(N, 256), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, std::getenv("RXMD_EHB_PROBE") ? std::atoi(std::getenv("RXMD_EHB_PROBE")) : 0);
 }
 

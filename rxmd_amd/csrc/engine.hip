@@ -140,7 +140,7 @@ void Engine::check_device_error(const char *where) {
   sync_stream();
   const int e = h_err[0];
   if (e == DERR_NONE) return;
-  RX_HIP(hipMemsetAsync(d_err, 0, sizeof(int) * 4, stream));
+  RX_HIP(hipMemsetAsync(d_err, 0, sizeof(int) * 2, stream));   // [2] (longest bond list of the build) stays: a retry rebuilds the 10 A list only
   const std::string w = std::string(where) + ": ";
   if (e == DERR_MAXNB) throw EngineError(RXMD_E_MAXNEIGHBS, w + "overflow of max # in neighbor list (MAXNEIGHBS=" + std::to_string(MAXNB) + ", needed " + std::to_string(h_err[1]) + ")");
   if (e == DERR_MAXN10) throw EngineError(RXMD_E_MAXNEIGHBS10, w + "nbplist greater than MAXNEIGHBS10=" + std::to_string(S10) + " (needed " + std::to_string(h_err[1]) + ")");

@@ -139,6 +139,8 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
   }
   if (cnt > MAXNB) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXNB); cnt = MAXNB; }  // main.F90:402-407
   nbrcnt[i] = cnt;
+  // err[2] = the longest list of this build if any is longer than 15 (the torsion kernel packs four atoms into a wavefront otherwise)
+  if (cnt > 15 && __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[2], cnt);
 }
 
 // nbrindx(i,i1) = j1 such that nbrlist(j,j1) == i   (main.F90:383-399)
@@ -377,6 +379,7 @@ __global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__r
 
 void Engine::build_bonded_list() {
   k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi);
+  RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
   if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
   else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
   k_reverse_index<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, d_err);
