@@ -435,6 +435,9 @@ void Engine::qeq() {
   constexpr int SPMV_WPB = 16;                   // wavefronts (= rows) per workgroup of the matrix pass
   const int rb = nblk(N, SPMV_WPB);
   const int vb = std::min(nblk(N, 256), 2048);
+  // the update kernel finishes its own reduction (last workgroup: one set of partials per workgroup, then the scalar algebra): with one
+  // workgroup per CU that tail is short -- 45.8 / 39.3 / 33.8 / 32.6 us per launch at 2048 / 1024 / 512 / 256 workgroups, 68 at 4096
+  const int vb_upd = std::min(nblk(N, 256), 256);
   const int nred = rb;                                                             // partials one matrix pass leaves
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
@@ -514,14 +517,14 @@ void Engine::qeq() {
       // iteration instead of three; any rank count: Est is final BEFORE the direction kernel, so its copy to the host, the host's exit
       // test and the launch of the next matrix pass all run underneath the direction update and the sorted copy / halo
       const bool est3 = !ff.pqeq && est_with_update;
-      if (est3) k_cg_update<true><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 6 : 0);
-      else k_cg_update<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
+      if (est3) k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 6 : 0);
+      else k_cg_update<false><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
       if (!fuse) { allreduce_scal4(est3 ? 8 : 4); k_scalar_algebra<<<1, 64, 0, stream>>>(est3 ? 6 : 4, scal); }
       if (est3) { RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream)); RX_HIP(hipEventRecord(ev_est, stream)); }
       // the direction update runs over the residents in atom order (every access coalesced); the cell-sorted copy with the images
       // is one gather pass queued behind it (sorted_copy).  Doing both in one kernel over the sorted positions
       // (five random 16-byte accesses per atom) was 0.4 ms per step slower.
-      k_cg_direction<<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : (fuse ? 5 : 0));
+      k_cg_direction<<<est3 ? vb : vb_upd, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : (fuse ? 5 : 0));
       if (!fuse && !est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
       if (!est3) {       // PQEq: Est comes out of the direction kernel; the host still waits for this copy only, not for the sorted copy behind it
         RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
