@@ -184,7 +184,7 @@ struct Engine {
   double *partials = nullptr;  // [nblocks_red * 16]
   double *scal = nullptr;      // device scalars (CG state)
   double *h_scal = nullptr;    // pinned host mirror
-  int *d_err = nullptr, *h_err = nullptr;
+  int *d_err = nullptr, *h_err = nullptr, *h_cnt = nullptr;   // h_err: pinned, 4 ints of the device error word + 4 (h_cnt) for the counts the host waits for
   double *xbuf_send = nullptr, *xbuf_recv = nullptr; size_t xbuf_doubles = 0; bool xbuf_owned = false;   // staged-exchange message buffers
   double pe[14] = {0}, astr[6] = {0};
 

@@ -304,7 +304,8 @@ void Engine::alloc_device() {
   dmalloc(partials, partials_cap + 1024); dmalloc(scal, 64);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
   dmalloc(d_err, 4);
-  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 4 * sizeof(int)));
+  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 8 * sizeof(int)));
+  h_cnt = h_err + 4;
   // hipcub scratch sized for the largest scan / sort we issue
   size_t b1 = 0, b2 = 0;
   hipcub::DeviceScan::ExclusiveSum(nullptr, b1, flags, scanout, NB + 1, stream);
@@ -519,9 +520,10 @@ void Engine::ghost_build() {
       tb = cubtmp_bytes;
       RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
       int t0 = 0, t1 = 0;
-      RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(h_cnt + 1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync_stream();
+      t0 = h_cnt[0]; t1 = h_cnt[1];   // counts arrive in pinned host memory
       if (static_cast<long long>(copyptr[d0 - 1]) + t0 + t1 > NB || sendoff[d0] + t0 + t1 > NB)
         throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
       sendoff[d0 + 1] = sendoff[d0] + t0; sendoff[d1 + 1] = sendoff[d1] + t1;
@@ -539,8 +541,9 @@ void Engine::ghost_build() {
     size_t tb = cubtmp_bytes;
     RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
     int total = 0;
-    RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
     sync_stream();
+    total = h_cnt[0];   // counts arrive in pinned host memory
     if (static_cast<long long>(copyptr[d - 1]) + total > NB || sendoff[d] + total > NB)
       throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
     if (total > 0)
@@ -666,9 +669,10 @@ void Engine::ghost_build_staged() {
       tb = cubtmp_bytes;
       RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
       int t0 = 0, t1 = 0;
-      RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(h_cnt + 1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync_stream();
+      t0 = h_cnt[0]; t1 = h_cnt[1];   // counts arrive in pinned host memory
       if (sendoff[d0] + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
       if (xb_fixed) ensure_xbuf(6 * (static_cast<size_t>(t0) + t1));
       sendoff[d0 + 1] = sendoff[d0] + t0; sendoff[d1 + 1] = sendoff[d1] + t1;
@@ -690,8 +694,9 @@ void Engine::ghost_build_staged() {
     size_t tb = cubtmp_bytes;
     RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
     int total = 0;
-    RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
     sync_stream();
+    total = h_cnt[0];   // counts arrive in pinned host memory
     if (sendoff[d] + total > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
     if (xb_fixed) ensure_xbuf(6 * static_cast<size_t>(total));
     if (total > 0)
@@ -885,9 +890,10 @@ void Engine::migrate() {
       tb = cubtmp_bytes;
       RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
       int t0 = 0, t1 = 0;
-      RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(h_cnt + 1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync_stream();
+      t0 = h_cnt[0]; t1 = h_cnt[1];   // counts arrive in pinned host memory
       ensure_xbuf(static_cast<size_t>(std::max(t0 + t1, 1)) * W + 4096);
       double *b1 = xbuf_send + static_cast<size_t>(W) * t0;
       if (t0 > 0) {
@@ -919,9 +925,10 @@ void Engine::migrate() {
       tb = cubtmp_bytes;
       RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
       int t0 = 0, t1 = 0;
-      RX_HIP(hipMemcpyAsync(&t0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipMemcpyAsync(&t1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipMemcpyAsync(h_cnt + 1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync_stream();
+      t0 = h_cnt[0]; t1 = h_cnt[1];   // counts arrive in pinned host memory
       if (static_cast<long long>(cp[d0 - 1]) + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
       cp[d0] = cp[d0 - 1] + t0; cp[d1] = cp[d0] + t1;
       if (t0 > 0) {
@@ -942,8 +949,9 @@ void Engine::migrate() {
     size_t tb = cubtmp_bytes;
     RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
     int total = 0;
-    RX_HIP(hipMemcpyAsync(&total, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
     sync_stream();
+    total = h_cnt[0];   // counts arrive in pinned host memory
     if (multi()) {
       const int W = ff.pqeq ? 14 : 11;             // + shell displacement (comm.F90:153,165-167)
       ensure_xbuf(static_cast<size_t>(std::max(total, 1)) * W + 4096);
@@ -976,8 +984,9 @@ void Engine::migrate() {
     k_alive_flags<<<nblk(n + 1, 256), 256, 0, stream>>>(n, type, flags);
     size_t tb = cubtmp_bytes;
     RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, n + 1, stream));
-    RX_HIP(hipMemcpyAsync(&newN, scanout + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + n, sizeof(int), hipMemcpyDeviceToHost, stream));
     sync_stream();
+    newN = h_cnt[0];   // counts arrive in pinned host memory
     if (newN > rows10) throw EngineError(RXMD_E_NBUFFER, "resident count grew beyond the 10 A list capacity");
     // scratch: reuse force + bonded scratch arrays as compaction targets (they are recomputed every step)
     double *tmpd[9] = {frc[0], frc[1], frc[2], cds, cd, cc_, deltap, delta, nlp};
