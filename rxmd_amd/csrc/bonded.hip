@@ -309,22 +309,58 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
   // phase A walks only bonds above the cut-off: the slots of each centre atom that qualify, and per centre bond the qualifying slots
   // of k with what the filter needs of them (bond order, atom l, its type) -- staged once per centre bond by the lanes side by side
-  __shared__ int s_cap[4][64], s_capl[4][32], s_ll[4][32], s_tl[4][32], s_gj[4][4][2];   // s_gj: bond count and type of each centre atom
+  __shared__ int s_cap[4][64], s_capl[4][32], s_ll[4][32], s_tl[4][32], s_gj[4][8][2];   // s_gj: bond count and type of each centre atom
+  __shared__ int s_base[4][9];                   // LSL == 0: first lane of each atom of the pass, and the end
   __shared__ double s_bokl[4][32];
   // per (atom g, slot) accumulators, updated with LDS atomics by the lanes that evaluate torsions: [0] cf1 and [1..3] force of the
   // i-j bond / its neighbour, [4] cf1, [5] cf2, [6] cdbnd of the centre bond; slot 31 (never a bond) holds the centre atom's own
   // force in [1..3] and cdbnd in [6].  (An earlier version wrote 11 results per torsion to LDS and let every owner lane scan all 64
   // of them: that scan cost about as many instructions as the torsion itself.)
   __shared__ double s_acc[4][64][7];
-  constexpr int SL = 1 << LSL, NG = 64 >> LSL, SELF = SL - 1;       // slots per atom, atoms per wavefront, the slot that stands for the atom itself
-  constexpr unsigned GM = (SL == 32) ? 0xffffffffu : ((1u << (SL & 31)) - 1u);
+  // LSL = 5 / 4: two / four atoms with a fixed range of 32 / 16 lanes each.  LSL = 0 ("packed", needs every list <= 15 like LSL = 4):
+  // eight atoms, each with as many lanes as it has bonds plus one, laid end to end -- RDX atoms have 5.3 bonds on average, so the
+  // set-up and the enumeration run with most lanes busy instead of a third; the few groups of eight that need more than 64 lanes
+  // (one in twenty in the RDX crystal) are done in two passes of four atoms.
+  constexpr bool PACK = (LSL == 0);
+  constexpr int SL = PACK ? 16 : (1 << (LSL & 31)), NG = PACK ? 8 : (64 >> (LSL & 31));       // (widest) lane range of an atom, atoms per wavefront
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
   const int jbase = (blockIdx.x * 4 + w) * NG;
   if (jbase >= N) return;                        // whole wavefront leaves together; no block-level barrier below
-  const int g_me = lane >> LSL, sl_me = lane & (SL - 1);
-  const int j_me = jbase + g_me;
-  const bool has_me = j_me < N;
-  const int nj_me = has_me ? min(nbrcnt[j_me], SELF) : 0;
+  double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
+  int npass = 1, c_me = 0, cpre = 0;
+  if (PACK) {                                     // lanes 0..7: lanes the atom needs, inclusive prefix
+    if (lane < 8 && jbase + lane < N) c_me = min(nbrcnt[jbase + lane], 15) + 1;
+    cpre = c_me;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { const int t = __shfl_up(cpre, o, 64); if (lane >= o) cpre += t; }
+    npass = (__shfl(cpre, 7, 64) <= 64) ? 1 : 2;
+  }
+  auto gbase = [&](int g) { return PACK ? s_base[w][g] : (g << (LSL & 31)); };       // first lane of atom g of this pass
+  for (int pass = 0; pass < npass; ++pass) {
+  const int g0 = PACK ? (npass == 1 ? 0 : 4 * pass) : 0, ng = PACK ? (npass == 1 ? 8 : 4) : NG;   // atoms of this pass
+  int g_me, sl_me, nj_me, j_me;
+  bool has_me;
+  if (PACK) {
+    const int off0 = __shfl(cpre - c_me, g0, 64);
+    if (lane >= g0 && lane < g0 + ng) {
+      s_base[w][lane - g0] = cpre - c_me - off0;
+      s_gj[w][lane - g0][0] = max(c_me - 1, 0); s_gj[w][lane - g0][1] = 1;   // (an atom behind the last one has no lane to write these)
+    }
+    if (lane == g0 + ng - 1) s_base[w][ng] = cpre - off0;
+    wave_lds_sync();
+    g_me = 0;
+    for (int g = 1; g < ng; ++g) g_me += (lane >= s_base[w][g]) ? 1 : 0;
+    has_me = lane < s_base[w][ng];
+    sl_me = has_me ? lane - s_base[w][g_me] : 1;
+    nj_me = has_me ? s_base[w][g_me + 1] - s_base[w][g_me] - 1 : 0;
+    j_me = jbase + g0 + g_me;
+  } else {
+    g_me = lane >> (LSL & 31); sl_me = lane & (SL - 1);
+    j_me = jbase + g_me;
+    has_me = j_me < N;
+    nj_me = has_me ? min(nbrcnt[j_me], SL - 1) : 0;
+  }
+  const bool self_me = has_me && (PACK ? sl_me == nj_me : sl_me == SL - 1);   // the lane that stands for the atom itself (never a bond)
   const int tj_me = has_me ? type[j_me] : 1;
   const double xj_me = has_me ? x[j_me] : 0.0, yj_me = has_me ? y[j_me] : 0.0, zj_me = has_me ? z[j_me] : 0.0;
   s_meta[w][lane] = 0;
@@ -355,13 +391,13 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   for (int c = 0; c < 7; ++c) s_acc[w][lane][c] = 0.0;
   const unsigned long long capmask = __ballot(cap_me);
   {                                               // the qualifying slots of each centre atom, in slot order
-    const unsigned mine = static_cast<unsigned>(capmask >> (g_me * SL)) & GM;
-    if (cap_me) s_cap[w][g_me * SL + __popc(mine & ((1u << sl_me) - 1u))] = sl_me;
-    if (sl_me == 0) { s_gj[w][g_me][0] = nj_me; s_gj[w][g_me][1] = tj_me; }
+    const int gb_me = gbase(g_me);
+    const unsigned mine = static_cast<unsigned>(capmask >> gb_me) & ((SL == 32) ? 0xffffffffu : ((1u << (SL & 31)) - 1u));   // (bits of the next atom above sl_me do not matter)
+    if (cap_me) s_cap[w][gb_me + __popc(mine & ((1u << sl_me) - 1u))] = sl_me;
+    if (sl_me == 0 && (has_me || !PACK)) { s_gj[w][g_me][0] = nj_me; s_gj[w][g_me][1] = tj_me; }
   }
   wave_lds_sync();
-  double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
-  int qn = 0;                                     // (slot SELF is never a bond: its lane accumulates the centre atom's own force and cdbnd)
+  int qn = 0;
 
   auto evaluate = [&](int cnt) {                  // phase B: the first cnt (<= 64) queue entries, one per lane
     if (bx.probe == 2) return;
@@ -373,7 +409,8 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     if (lane < cnt) {
       key = s_q[w][lane];
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31, l1 = key & 31;
-      const int sk = g * SL + k1, si = g * SL + i1;
+      const int gb = gbase(g);
+      const int sk = gb + k1, si = gb + i1;
       const int k = s_nb[w][sk], mk_ = s_meta[w][sk], tk = mk_ & 255, tj = s_gj[w][g][1];
       const double BOjk_f = s_bo[w][sk], BOij_f = s_bo[w][si];
       const double BOjk = BOjk_f - cutof2_esub, BOij = BOij_f - cutof2_esub;
@@ -493,7 +530,8 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     }
     if (key >= 0) {
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31;
-      double *ai = &s_acc[w][g * SL + i1][0], *ak = &s_acc[w][g * SL + k1][0], *as = &s_acc[w][g * SL + SELF][0];
+      const int gb = gbase(g), gself = PACK ? s_base[w][g + 1] - 1 : gb + SL - 1;
+      double *ai = &s_acc[w][gb + i1][0], *ak = &s_acc[w][gb + k1][0], *as = &s_acc[w][gself][0];
       atomicAdd(ai + 0, o[0]); atomicAdd(ai + 1, o[1]); atomicAdd(ai + 2, o[2]); atomicAdd(ai + 3, o[3]);
       atomicAdd(ak + 4, o[4]); atomicAdd(ak + 5, o[5]); atomicAdd(ak + 6, o[6]);
       atomicAdd(as + 1, fself.x); atomicAdd(as + 2, fself.y); atomicAdd(as + 3, fself.z); atomicAdd(as + 6, cd_self);
@@ -503,15 +541,17 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
 
   if (bx.probe == 1) return;                      // timing experiment: set-up only
   // phase A: enumerate, filter, compact
-  for (int g = 0; g < NG; ++g) {
+  for (int g = 0; g < ng; ++g) {
+    const int gb = __builtin_amdgcn_readfirstlane(gbase(g));
     const int nj = __builtin_amdgcn_readfirstlane(s_gj[w][g][0]), tjc = __builtin_amdgcn_readfirstlane(s_gj[w][g][1]);
-    const int ncj = __popc(static_cast<unsigned>(capmask >> (g * SL)) & GM);
+    const int gw = PACK ? nj + 1 : SL;                                    // lanes of this atom
+    const int ncj = __popc(static_cast<unsigned>(capmask >> gb) & ((gw == 32) ? 0xffffffffu : ((1u << (gw & 31)) - 1u)));
     for (int k1 = 0; k1 < nj; ++k1) {
-      const int sk = g * SL + k1;
+      const int sk = gb + k1;
       const int nk = (s_meta[w][sk] >> 8) & 255;
       if (nk == 0) continue;
       const double BOjk_f = s_bo[w][sk];
-      const int k = s_nb[w][sk], j = jbase + g;
+      const int k = s_nb[w][sk], j = jbase + g0 + g;
       int nck;
       {                                           // the qualifying slots of k (pot.F90:1072), staged by the lanes side by side
         const int nkc = min(nk, WSLOT);
@@ -534,14 +574,14 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
         int i1 = 0, l1 = 0;
         if (c < total) {
           const int ci = c / nck, cl = c - ci * nck;
-          i1 = s_cap[w][g * SL + ci]; l1 = s_capl[w][cl];
-          const double BOij_f = s_bo[w][g * SL + i1];
-          const int i = s_nb[w][g * SL + i1];
+          i1 = s_cap[w][gb + ci]; l1 = s_capl[w][cl];
+          const double BOij_f = s_bo[w][gb + i1];
+          const int i = s_nb[w][gb + i1];
           const double BOkl_f = s_bokl[w][cl];
           const int l = s_ll[w][cl];
           go = (i1 != k1) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
                (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0) && (l != i) && (l != j);
-          if (go) go = ff.inxn4[(((s_meta[w][g * SL + i1] & 255) * ff.n1 + tjc) * ff.n1 + (s_meta[w][sk] & 255)) * ff.n1 + s_tl[w][cl]] != 0;
+          if (go) go = ff.inxn4[(((s_meta[w][gb + i1] & 255) * ff.n1 + tjc) * ff.n1 + (s_meta[w][sk] & 255)) * ff.n1 + s_tl[w][cl]] != 0;
         }
         const unsigned long long m = __ballot(go);
         if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
@@ -571,10 +611,12 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     if (a_cdk != 0.0) cdn[o] += a_cdk;
     if (a_fx != 0.0 || a_fy != 0.0 || a_fz != 0.0) { fnx[o] += a_fx; fny[o] += a_fy; fnz[o] += a_fz; }
   }
-  if (sl_me == SELF && has_me) {
+  if (self_me) {
     cds[j_me] += a_cdk;
     fx[j_me] += a_fx; fy[j_me] += a_fy; fz[j_me] += a_fz;
   }
+  wave_lds_sync();                                // the next pass (packed form, two passes) rebuilds the tables
+  }   // pass
   e8 = wave_sum_b(e8); e9 = wave_sum_b(e9);
   if (lane == 0) {
     if (e8 != 0.0) atomicAdd(pe + 8, e8);
@@ -721,8 +763,11 @@ void Engine::bonded_energies() {
   bx.ortho = grid.ortho; bx.probe = std::getenv("RXMD_E4B_PROBE") ? std::atoi(std::getenv("RXMD_E4B_PROBE")) : 0;
   // four atoms per wavefront when every bond list of this step fits 15 slots (h_err[2] = the largest list, read with the error word
   // after the list build); RXMD_E4B_SLOTS=32 forces the general kernel (tests)
-  const bool narrow = h_err[2] <= 15 && !(std::getenv("RXMD_E4B_SLOTS") && std::atoi(std::getenv("RXMD_E4B_SLOTS")) == 32);
-  if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  const int want = std::getenv("RXMD_E4B_SLOTS") ? std::atoi(std::getenv("RXMD_E4B_SLOTS")) : 0;   // 32 / 16: force the general / the four-atom instance (tests)
+  const bool narrow = h_err[2] <= 15 && want != 32;
+  if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+                                                                         cds, frc[0], frc[1], frc[2], pe_d, bx);
+  else if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
   else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                  cds, frc[0], frc[1], frc[2], pe_d, bx);

@@ -374,24 +374,26 @@ def test_matrix_pass_without_the_software_pipeline_is_the_same_operator(qeq_mode
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
 
 
-def test_torsion_kernel_with_two_and_four_atoms_per_wavefront_gives_the_same_forces(monkeypatch):
-    """k_e4b packs four centre atoms into a wavefront when no bond list of the step is longer than 15 (RDX) and two otherwise;
-    RXMD_E4B_SLOTS=32 forces the general kernel.  Every (atom, slot) accumulator receives the same additions in the same order, so the
-    forces must be bit-identical; the torsion energies are summed per lane and may differ in the last bits."""
+def test_torsion_kernel_instances_give_the_same_forces(monkeypatch):
+    """k_e4b has three instances: eight centre atoms per wavefront with their bond slots laid end to end (default when no bond list of
+    the step is longer than 15, as in RDX), four atoms with 16 slots each (RXMD_E4B_SLOTS=16) and two with 32 (any list;
+    RXMD_E4B_SLOTS=32).  Every (atom, slot) accumulator receives the same additions in the same order in all of them, so the forces must
+    be bit-identical; the torsion energies are summed per lane and may differ in the last bits."""
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
     o = _oracle("rdx222", (2, 2, 2), **kw); o.qeq(); o.force()
     res = []
-    for general in (False, True):
-        if general:
-            monkeypatch.setenv("RXMD_E4B_SLOTS", "32")
+    for slots in (None, "16", "32"):
+        if slots:
+            monkeypatch.setenv("RXMD_E4B_SLOTS", slots)
         e = _engine("rdx222", (2, 2, 2), **kw)
         e.QEq(); pe = e.FORCE(); a = e.atoms()
         assert f_err(a["f"], o.forces()) <= FTOL
         assert e_err(pe, o.energy()) <= ETOL
         res.append((a["f"].copy(), pe.copy()))
         e.close()
-    assert np.array_equal(res[0][0], res[1][0])
-    assert np.allclose(res[0][1], res[1][1], rtol=1e-12, atol=1e-12)
+    for r in res[1:]:
+        assert np.array_equal(res[0][0], r[0])
+        assert np.allclose(res[0][1], r[1], rtol=1e-12, atol=1e-12)
 
 
 # ---- PQEq (pqeq.F90 / ENbond_PQEq): SiC nanoparticle in O2, conf/init.sicnp, 547 atoms, polarizable shells ----------------
