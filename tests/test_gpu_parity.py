@@ -374,18 +374,19 @@ def test_matrix_pass_without_the_software_pipeline_is_the_same_operator(qeq_mode
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
 
 
-def test_torsion_kernel_instances_give_the_same_forces(monkeypatch):
+@pytest.mark.parametrize("case,mc", [("rdx222", (2, 2, 2)), ("ice644", (6, 4, 4)), ("example1", (2, 3, 5))])
+def test_torsion_kernel_instances_give_the_same_forces(case, mc, monkeypatch):
     """k_e4b has three instances: eight centre atoms per wavefront with their bond slots laid end to end (default when no bond list of
     the step is longer than 15, as in RDX), four atoms with 16 slots each (RXMD_E4B_SLOTS=16) and two with 32 (any list;
     RXMD_E4B_SLOTS=32).  Every (atom, slot) accumulator receives the same additions in the same order in all of them, so the forces must
     be bit-identical; the torsion energies are summed per lane and may differ in the last bits."""
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
-    o = _oracle("rdx222", (2, 2, 2), **kw); o.qeq(); o.force()
+    o = _oracle(case, mc, **kw); o.qeq(); o.force()
     res = []
     for slots in (None, "16", "32"):
         if slots:
             monkeypatch.setenv("RXMD_E4B_SLOTS", slots)
-        e = _engine("rdx222", (2, 2, 2), **kw)
+        e = _engine(case, mc, **kw)
         e.QEq(); pe = e.FORCE(); a = e.atoms()
         assert f_err(a["f"], o.forces()) <= FTOL
         assert e_err(pe, o.energy()) <= ETOL
