@@ -317,27 +317,28 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   // force in [1..3] and cdbnd in [6].  (An earlier version wrote 11 results per torsion to LDS and let every owner lane scan all 64
   // of them: that scan cost about as many instructions as the torsion itself.)
   __shared__ double s_acc[4][64][7];
-  // LSL = 5 / 4: two / four atoms with a fixed range of 32 / 16 lanes each.  LSL = 0 ("packed", needs every list <= 15 like LSL = 4):
-  // eight atoms, each with as many lanes as it has bonds plus one, laid end to end -- RDX atoms have 5.3 bonds on average, so the
-  // set-up and the enumeration run with most lanes busy instead of a third; the few groups of eight that need more than 64 lanes
-  // (one in twenty in the RDX crystal) are done in two passes of four atoms.
-  constexpr bool PACK = (LSL == 0);
-  constexpr int SL = PACK ? 16 : (1 << (LSL & 31)), NG = PACK ? 8 : (64 >> (LSL & 31));       // (widest) lane range of an atom, atoms per wavefront
+  // LSL = 5 / 4: two / four atoms with a fixed range of 32 / 16 lanes each.  LSL = 0 / 1 ("packed"): eight atoms with lists <= 15 /
+  // four atoms with any list, each with as many lanes as it has bonds plus one, laid end to end -- RDX atoms have 5.3 bonds on
+  // average, so the set-up and the enumeration run with most lanes busy instead of a third; the few groups that need more than 64
+  // lanes (one group of eight in twenty in the RDX crystal) are done in two passes of half the atoms each.
+  constexpr bool PACK = (LSL <= 1);
+  constexpr int PKN = (LSL == 0) ? 8 : 4, CAP = (LSL == 0) ? 15 : 31;                          // packed: atoms per wavefront, longest list
+  constexpr int SL = PACK ? CAP + 1 : (1 << (LSL & 31)), NG = PACK ? PKN : (64 >> (LSL & 31));  // (widest) lane range of an atom, atoms per wavefront
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
   const int jbase = (blockIdx.x * 4 + w) * NG;
   if (jbase >= N) return;                        // whole wavefront leaves together; no block-level barrier below
   double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
   int npass = 1, c_me = 0, cpre = 0;
-  if (PACK) {                                     // lanes 0..7: lanes the atom needs, inclusive prefix
-    if (lane < 8 && jbase + lane < N) c_me = min(nbrcnt[jbase + lane], 15) + 1;
+  if (PACK) {                                     // lanes 0..PKN-1: lanes the atom needs, inclusive prefix
+    if (lane < PKN && jbase + lane < N) c_me = min(nbrcnt[jbase + lane], CAP) + 1;
     cpre = c_me;
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { const int t = __shfl_up(cpre, o, 64); if (lane >= o) cpre += t; }
-    npass = (__shfl(cpre, 7, 64) <= 64) ? 1 : 2;
+    for (int o = 1; o < PKN; o <<= 1) { const int t = __shfl_up(cpre, o, 64); if (lane >= o) cpre += t; }
+    npass = (__shfl(cpre, PKN - 1, 64) <= 64) ? 1 : 2;
   }
   auto gbase = [&](int g) { return PACK ? s_base[w][g] : (g << (LSL & 31)); };       // first lane of atom g of this pass
   for (int pass = 0; pass < npass; ++pass) {
-  const int g0 = PACK ? (npass == 1 ? 0 : 4 * pass) : 0, ng = PACK ? (npass == 1 ? 8 : 4) : NG;   // atoms of this pass
+  const int g0 = PACK ? (npass == 1 ? 0 : (PKN / 2) * pass) : 0, ng = PACK ? (npass == 1 ? PKN : PKN / 2) : NG;   // atoms of this pass
   int g_me, sl_me, nj_me, j_me;
   bool has_me;
   if (PACK) {
@@ -763,9 +764,14 @@ void Engine::bonded_energies() {
   bx.ortho = grid.ortho; bx.probe = std::getenv("RXMD_E4B_PROBE") ? std::atoi(std::getenv("RXMD_E4B_PROBE")) : 0;
   // four atoms per wavefront when every bond list of this step fits 15 slots (h_err[2] = the largest list, read with the error word
   // after the list build); RXMD_E4B_SLOTS=32 forces the general kernel (tests)
-  const int want = std::getenv("RXMD_E4B_SLOTS") ? std::atoi(std::getenv("RXMD_E4B_SLOTS")) : 0;   // 32 / 16: force the general / the four-atom instance (tests)
-  const bool narrow = h_err[2] <= 15 && want != 32;
-  if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  // instances (RXMD_E4B_SLOTS forces one, tests): packed eight atoms (default when no list of the step is longer than 15), two atoms
+  // x 32 slots (32; default otherwise), packed four atoms (4: any list; on the SiC workload, 16+ bonds per atom, it needs two passes
+  // for most groups and is slower than the default there, 3.69 against 3.47 ms), four atoms x 16 slots (16, needs lists <= 15)
+  const int want = std::getenv("RXMD_E4B_SLOTS") ? std::atoi(std::getenv("RXMD_E4B_SLOTS")) : 0;
+  const bool narrow = h_err[2] <= 15 && want != 32 && want != 4;
+  if (want == 4) k_e4b<1><<<nblk(N, 16), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+                                                                       cds, frc[0], frc[1], frc[2], pe_d, bx);
+  else if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
   else if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);

@@ -376,14 +376,14 @@ def test_matrix_pass_without_the_software_pipeline_is_the_same_operator(qeq_mode
 
 @pytest.mark.parametrize("case,mc", [("rdx222", (2, 2, 2)), ("ice644", (6, 4, 4)), ("example1", (2, 3, 5))])
 def test_torsion_kernel_instances_give_the_same_forces(case, mc, monkeypatch):
-    """k_e4b has three instances: eight centre atoms per wavefront with their bond slots laid end to end (default when no bond list of
-    the step is longer than 15, as in RDX), four atoms with 16 slots each (RXMD_E4B_SLOTS=16) and two with 32 (any list;
-    RXMD_E4B_SLOTS=32).  Every (atom, slot) accumulator receives the same additions in the same order in all of them, so the forces must
+    """k_e4b has four instances: eight centre atoms per wavefront with their bond slots laid end to end (default when no bond list of
+    the step is longer than 15, as in RDX), four atoms laid end to end (any list; RXMD_E4B_SLOTS=4), four atoms with 16 slots each
+    (RXMD_E4B_SLOTS=16, lists <= 15) and two with 32 (any list, the default otherwise; RXMD_E4B_SLOTS=32).  Every (atom, slot) accumulator receives the same additions in the same order in all of them, so the forces must
     be bit-identical; the torsion energies are summed per lane and may differ in the last bits."""
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
     o = _oracle(case, mc, **kw); o.qeq(); o.force()
     res = []
-    for slots in (None, "16", "32"):
+    for slots in (None, "4", "16", "32"):
         if slots:
             monkeypatch.setenv("RXMD_E4B_SLOTS", slots)
         e = _engine(case, mc, **kw)
