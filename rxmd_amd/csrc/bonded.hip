@@ -1,7 +1,7 @@
 // bonded.hip -- bonded energy terms of FORCE (reference src/pot.F90) as own-slot accumulation kernels.
 //   Ebond (pot.F90:926-977) + Elnpr (pot.F90:148-316) -> k_ebond_elnpr
 //   E3b   (pot.F90:319-557)                           -> k_e3b   (thread per centre atom)
-//   E4b   (pot.F90:980-1227)                          -> k_e4b   (wavefront per two centre atoms, ballot-compacted work queue;
+//   E4b   (pot.F90:980-1227)                          -> k_e4b   (wavefront per eight / four / two centre atoms, ballot-compacted work queue;
 //                                                                  every torsion visited from both ends)
 //   Ehb   (pot.F90:559-673)                           -> k_ehb   (a wavefront finds the donors among 64 atoms, then sweeps their rows)
 // The reference scatters every derivative at once with atomics (ForceB/ForceBbo/ForceA3/ForceA4,
