@@ -64,8 +64,15 @@ __global__ void __launch_bounds__(256) k_shell_update(int N, int S10, DevFF ff, 
   const int n = n10[i];
   const size_t row = static_cast<size_t>(i) * S10;
   double f0 = 0.0, f1 = 0.0, f2 = 0.0;
-  for (int k = lane; k < n; k += 64) {
-    const unsigned e = static_cast<unsigned>(nb10[row + k]);     // an own periodic image stays in (the reference only excludes i == j)
+  constexpr int SU = 8;                                              // entries per lane and pass, all entry words requested first (as k_nonbond)
+  for (int k0 = lane; k0 < n; k0 += 64 * SU) {
+    unsigned ee[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) { const int k = k0 + 64 * u; ee[u] = (k < n) ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + row + k)) : 0xffffffffu; }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+    const unsigned e = ee[u];                                        // an own periodic image stays in (the reference only excludes i == j)
+    if (e == 0xffffffffu) continue;
     const int p = e & NB10_IDX_MASK, tj = (e >> NB10_IDX_BITS) & 15u;
     const double4 pj = pk[p], sj = sorted_shl[p];
     const int prow = ff.inxnpq[ti * ff.npq1 + tj];
@@ -78,6 +85,7 @@ __global__ void __launch_bounds__(256) k_shell_update(int N, int S10, DevFF ff, 
     pq_lookup2(ff, ff.tabPss, prow, d0 * d0 + d1 * d1 + d2 * d2, E, F);
     c = Cclmb0 * F * Zi * Zj;                                        // ff = Cclmb0*sf*Z_i*Z_j (:234-235)
     f0 -= c * d0; f1 -= c * d1; f2 -= c * d2;
+    }
   }
   f0 = wave_sum_p(f0); f1 = wave_sum_p(f1); f2 = wave_sum_p(f2);
   if (lane == 0) {
@@ -132,8 +140,14 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
     const int *ix2 = ff.inxn2 + ti * ff.n1;
     double f0 = 0.0, f1 = 0.0, f2 = 0.0;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;   // pair virial (stress note in nonbonded.hip)
-    for (int k = lane; k < n; k += 64) {
-      const unsigned e = static_cast<unsigned>(nb10[row + k]);
+    constexpr int PU = 4;                                           // entries per lane and pass, their entry words requested first (as k_nonbond)
+    for (int k0 = lane; k0 < n; k0 += 64 * PU) {
+      unsigned ee[PU];
+#pragma unroll
+      for (int u = 0; u < PU; ++u) { const int k = k0 + 64 * u; ee[u] = (k < n) ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + row + k)) : NB10_SELF; }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+      const unsigned e = ee[u];
       if (e & NB10_SELF) continue;
       const int p = e & NB10_IDX_MASK, tj = (e >> NB10_IDX_BITS) & 15u;
       const double4 pj = pk[p], sj = sorted_shl[p];
@@ -165,6 +179,7 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
       e12 += 0.5 * ec;
       f0 -= g0; f1 -= g1; f2 -= g2;
       v0 -= 0.5 * d0 * g0; v1 -= 0.5 * d1 * g1; v2 -= 0.5 * d2 * g2; v3 -= 0.5 * d1 * g2; v4 -= 0.5 * d2 * g0; v5 -= 0.5 * d0 * g1;
+      }
     }
     f0 = wave_sum_p(f0); f1 = wave_sum_p(f1); f2 = wave_sum_p(f2);
     v0 = wave_sum_p(v0); v1 = wave_sum_p(v1); v2 = wave_sum_p(v2); v3 = wave_sum_p(v3); v4 = wave_sum_p(v4); v5 = wave_sum_p(v5);
