@@ -635,17 +635,21 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
                                               double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, int probe) {
   constexpr int EHB_CHUNK = 640;                          // row entries compacted at a time (a row of the default stride in one go)
+  // atoms per wavefront: the lanes beyond it idle in the (cheap) search for donors, but the sweeps of the donors found spread over
+  // more wavefronts -- 1.37 / 1.21 / 1.14 / 1.13 / 1.26 ms at 64 / 32 / 16 / 8 / 4 atoms
+  constexpr int EHB_APW = 16;
   __shared__ unsigned s_cand[4][EHB_CHUNK];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  // A wavefront takes 64 consecutive atoms.  First every lane decides for its own atom whether it is a donor with a hydrogen partner
+  // A wavefront takes EHB_APW consecutive atoms.  First every lane decides for its own atom whether it is a donor with a hydrogen partner
   // (coalesced slot-major reads; in RDX one atom in fourteen is) and leaves a bit mask of those slots; then the wavefront sweeps the
   // 10 A rows of the atoms that have one, one after the other.  (One wavefront per atom spent most of the kernel starting a million
   // wavefronts that found nothing: 1.5 ms, of which the sweeps themselves were about a third.)
-  const int a0 = (xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w) * 64;
+  const int apw = (probe >> 8) ? (probe >> 8) : EHB_APW; // atoms per wavefront (probe bits 8..: experiment)
+  const int a0 = (xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w) * apw;
   double e10 = 0.0;
   unsigned hslots = 0u;
   int ti_l = 0;
-  if (a0 + lane < N) {
+  if (lane < apw && a0 + lane < N) {
     const int ia = a0 + lane;
     ti_l = type[ia];
     bool donor_l = false;                                // does any (ti, 2, k) hydrogen-bond row exist?
@@ -736,7 +740,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
             const V3 ff3 = {CEhb3 * rjk.x, CEhb3 * rjk.y, CEhb3 * rjk.z};   // f(j) -= ff ; f(k) += ff
             fi_s.x += fi.x; fi_s.y += fi.y; fi_s.z += fi.z;
             fj_s.x += -(fi.x + fk.x) - ff3.x; fj_s.y += -(fi.y + fk.y) - ff3.y; fj_s.z += -(fi.z + fk.z) - ff3.z;
-            if (probe != 1) { atomicAdd(fx + k, fk.x + ff3.x); atomicAdd(fy + k, fk.y + ff3.y); atomicAdd(fz + k, fk.z + ff3.z); }
+            if ((probe & 255) != 1) { atomicAdd(fx + k, fk.x + ff3.x); atomicAdd(fy + k, fk.y + ff3.y); atomicAdd(fz + k, fk.z + ff3.z); }
           }
           cfs = wave_sum_b(cfs); nterm = wave_sum_b(nterm);
           fi_s.x = wave_sum_b(fi_s.x); fi_s.y = wave_sum_b(fi_s.y); fi_s.z = wave_sum_b(fi_s.z);
@@ -777,7 +781,9 @@ void Engine::bonded_energies() {
                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
   else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                  cds, frc[0], frc[1], frc[2], pe_d, bx);
-  k_ehb<<<nblk(N, 256), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, std::getenv("RXMD_EHB_PROBE") ? std::atoi(std::getenv("RXMD_EHB_PROBE")) : 0);
+  const int ehb_probe = std::getenv("RXMD_EHB_PROBE") ? std::atoi(std::getenv("RXMD_EHB_PROBE")) : 0;
+  const int ehb_apw = (ehb_probe >> 8) ? (ehb_probe >> 8) : 16;    // = EHB_APW of k_ehb
+  k_ehb<<<nblk(N, 4 * ehb_apw), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_probe);
 }
 
 }  // namespace rxmd
