@@ -89,6 +89,10 @@ int rxmd_hip_set_velocities(rxmd_handle h, int natoms, const double *v);
 /* PQEq shell displacements spos(natoms,3) of the residents, real units (module.F90:286; written by WriteXYZ, fileio.F90:332-333).
  * get returns natoms; both fail with RXMD_E_STATE when the engine was created without pqeq_path */
 int rxmd_hip_get_shells(rxmd_handle h, double *spos3, int capacity);
+/* Bond lists of the residents after the last rxmd_hip_force: what WriteBND reads from nbrlist / BO(0,:,:) (fileio.F90:27-148).
+ * count[i] = nbrlist(i,0); partner_gid[i*maxnb + s] = l2g(atype(nbrlist(i,s+1))); bo[i*maxnb + s] = BO(0,i,s+1); maxnb >= the
+ * engine's MAXNEIGHBS (30 unless rxmd_config.maxneighbs says otherwise).  Returns natoms. */
+int rxmd_hip_get_bonds(rxmd_handle h, int capacity, int maxnb, int *count, long long *partner_gid, double *bo);
 int rxmd_hip_set_shells(rxmd_handle h, int natoms, const double *spos3);
 
 /* ---- the hot path, device resident ---------------------------------------------------------- */

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("rxmd_hip_set_charges", C.c_int, [H, C.c_int, PD]),
     ("rxmd_hip_set_velocities", C.c_int, [H, C.c_int, PD]),
     ("rxmd_hip_get_shells", C.c_int, [H, PD, C.c_int]),
+    ("rxmd_hip_get_bonds", C.c_int, [H, C.c_int, C.c_int, C.c_void_p, C.c_void_p, PD]),
     ("rxmd_hip_set_shells", C.c_int, [H, C.c_int, PD]),
     ("rxmd_hip_qeq", C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("rxmd_hip_force", C.c_int, [H, PD]),

@@ -137,6 +137,35 @@ int rxmd_hip_set_velocities(rxmd_handle h, int natoms, const double *v) {
   });
 }
 
+int rxmd_hip_get_bonds(rxmd_handle h, int capacity, int maxnb, int *count, long long *partner_gid, double *bo) {
+  int n = 0;
+  const int rc = guarded(h, [&](Engine &e) {
+    if (!count || !partner_gid || !bo || capacity < e.N || maxnb < e.MAXNB) throw EngineError(RXMD_E_ARG, "capacity smaller than natoms or maxnb smaller than MAXNEIGHBS");
+    if (!e.lists_valid) throw EngineError(RXMD_E_STATE, "no bond lists: call rxmd_hip_force first");
+    RX_HIP(hipStreamSynchronize(e.stream));
+    const int N = e.N, G = e.G;
+    std::vector<int> cnt(N), nb(static_cast<size_t>(e.MAXNB) * N);
+    std::vector<double> b(static_cast<size_t>(e.MAXNB) * N);
+    std::vector<long long> g(G);
+    RX_HIP(hipMemcpy(cnt.data(), e.nbrcnt, sizeof(int) * N, hipMemcpyDeviceToHost));
+    RX_HIP(hipMemcpy(g.data(), e.gid, sizeof(long long) * G, hipMemcpyDeviceToHost));
+    for (int s = 0; s < e.MAXNB; ++s) {            // the tables are slot-major with stride NB
+      RX_HIP(hipMemcpy(nb.data() + static_cast<size_t>(s) * N, e.nbr + static_cast<size_t>(s) * e.NB, sizeof(int) * N, hipMemcpyDeviceToHost));
+      RX_HIP(hipMemcpy(b.data() + static_cast<size_t>(s) * N, e.bo0 + static_cast<size_t>(s) * e.NB, sizeof(double) * N, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < N; ++i) {
+      const int c = std::min(cnt[i], e.MAXNB);
+      count[i] = c;
+      for (int s = 0; s < c; ++s) {
+        partner_gid[static_cast<size_t>(i) * maxnb + s] = g[nb[static_cast<size_t>(s) * N + i]];
+        bo[static_cast<size_t>(i) * maxnb + s] = b[static_cast<size_t>(s) * N + i];
+      }
+    }
+    n = N;
+  });
+  return rc ? rc : n;
+}
+
 int rxmd_hip_get_shells(rxmd_handle h, double *spos3, int capacity) {
   int n = 0;
   const int rc = guarded(h, [&](Engine &e) {

@@ -112,6 +112,30 @@ class RxmdEngine:
         with open(path, "w") as f:
             f.write(txt)
 
+    def bonds(self):
+        """bond lists of the residents after the last FORCE (nbrlist / BO(0,:,:), what WriteBND reads): (count[n], partner_gid[n,maxnb], bo[n,maxnb])"""
+        n = self.natoms; mx = 32
+        cnt = np.zeros(n, np.int32); pg = np.zeros((n, mx), np.int64); bo = np.zeros((n, mx))
+        self._chk(self.L.rxmd_hip_get_bonds(self.h, n, mx, _ptr(cnt), _ptr(pg), _ptr(bo)))
+        return cnt, pg, bo
+
+    def write_bnd(self, path):
+        """bond file of the current frame in the reference's WriteBND layout (fileio.F90:27-148); with several ranks the parts are concatenated in rank order"""
+        from . import system
+        a = self.atoms(); cnt, pg, bo = self.bonds()
+        with open(path, "w") as f:
+            f.write(system.format_bnd(a["gid"], a["type"], a["pos"], cnt, pg, bo))
+
+    def write_pdb(self, path, astr=None):
+        """pdb frame in the reference's WritePDB layout (fileio.F90:151-238); astr: the stress accumulators whose mean diagonal goes to the last
+        column (default: the engine's own since the last energy read)"""
+        from . import system
+        a = self.atoms()
+        if astr is None:
+            astr = self.energy()["astr"]
+        with open(path, "w") as f:
+            f.write(system.format_pdb(system.ffield_type_names(self._ff.decode()), a["gid"], a["type"], a["pos"], a["q"], astr))
+
     def write_rxff(self, path, current_step=0):
         """checkpoint in the reference's WriteBIN layout (fileio.F90:558-653), single rank"""
         from . import system

@@ -92,6 +92,49 @@ def format_xyz(lattice, type_names, gid, types, pos, q, shells=None, natoms_tota
     return "".join(out)
 
 
+BND_CUTOFF = 0.3      # bonds below this bond order are not written (fileio.F90:47,113)
+USTRS = 6.94728103     # [GPa], module.F90:200
+
+
+def _fortran_f(width, dec, v):
+    """Fortran fw.d: right-justified, all asterisks when the number does not fit"""
+    t = "%*.*f" % (width, dec, v)
+    if len(t) > width and t.startswith("0."):       # gfortran and flang drop the optional leading zero before they give up
+        t = t[1:]
+    elif len(t) > width and t.startswith("-0."):
+        t = "-" + t[2:]
+    return t if len(t) <= width else "*" * width
+
+
+def format_bnd(gid, types, pos, count, partner_gid, bo):
+    """The bond file of one frame as the reference's WriteBND writes it (src/fileio.F90:27-148), the input of its util/ tools: per
+    resident `i12.12` global id, `3f12.3` position, `2i3` type and number of bonds listed, then `i12.12` partner id and `f6.3` bond
+    order for every bond with BO >= 0.3, the line left-adjusted.  count / partner_gid / bo as rxmd_hip_get_bonds returns them: the
+    partners of a line come in the engine's list order, a permutation of the order the reference's linked-list cells produce."""
+    out = []
+    for i in range(len(gid)):
+        sel = [s for s in range(int(count[i])) if not bo[i][s] < BND_CUTOFF]
+        line = "%012d %12.3f%12.3f%12.3f %3d%3d" % (gid[i], pos[i][0], pos[i][1], pos[i][2], types[i], len(sel))
+        line += "".join(" %012d%s" % (partner_gid[i][s], _fortran_f(6, 3, bo[i][s])) for s in sel)
+        out.append(line.strip() + "\n")
+    return "".join(out)
+
+
+def format_pdb(type_names, gid, types, pos, q, astr=(0.0, 0.0, 0.0)):
+    """One frame as the reference's WritePDB writes it (src/fileio.F90:151-238): `A6,I5,1x,A2,i12,4x,3f8.3,f6.2,f6.2` -- 'ATOM', a zero,
+    the element, the global id, the position, the CHARGE in the temperature-factor column (`tt = q(i)`, :213) and
+    sum(astr(1:3))/3*USTRS of the run's stress accumulators in the last column (the same number on every line; asterisks when it
+    does not fit f6.2, as the reference prints); 67 characters per line with the new-line."""
+    ss = (astr[0] + astr[1] + astr[2]) / 3.0 * USTRS
+    out = []
+    for i in range(len(gid)):
+        nm = type_names[int(types[i])][:2].ljust(2)
+        body = "ATOM  %5d %s%12d    %s%s%s%s%s" % (0, nm, gid[i], _fortran_f(8, 3, pos[i][0]), _fortran_f(8, 3, pos[i][1]), _fortran_f(8, 3, pos[i][2]),
+                                                  _fortran_f(6, 2, q[i]), _fortran_f(6, 2, ss))
+        out.append(body.ljust(66)[:66] + "\n")
+    return "".join(out)
+
+
 def ffield_type_names(ffield, lg=False):
     """element names of the ffield atom types, 1-based list (index 0 unused) -- the reference's atmname (param.F90:103)"""
     L = _lib.load()

@@ -262,8 +262,13 @@ def make(name):
             d["input_xyz"] = np.array(open(os.path.join(tmp, "input.xyz")).read())
         if name in ("rdx168_md10", "sicnp547_pqeq_md5", "sicfrag26_pqeq_efieldx_md8"):
             # the reference's own trajectory frame of the last step (OUTPUT -> WriteXYZ, fileio.F90:241-355): output data, kept as text
-            outC = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(nsteps), "--pstep", "1", "--fstep", str(nsteps)] + flags, tmp)
+            # (+ the bond file and the pdb frame of the same step: WriteBND fileio.F90:27-148, WritePDB :151-238)
+            outC = run([os.path.join(REFBIN, "rxmd"), "--ntime_step", str(nsteps), "--pstep", "1", "--fstep", str(nsteps), "--isBondFile", "--isPDB"] + flags, tmp)
             d["xyz_last"] = np.array(open(os.path.join(tmp, "DAT", "%09d.xyz" % nsteps)).read())
+            for ext in ("bnd", "pdb"):
+                fn = os.path.join(tmp, "DAT", "%09d.%s" % (nsteps, ext))
+                if os.path.exists(fn):
+                    d[ext + "_last"] = np.array(open(fn, errors="replace").read())
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         print(name, "natoms", len(gid), "qeq_iters", d.get("qeq_iters"), "PE/atom", d["mdstep"][0][2] if len(d["mdstep"]) else None)
     finally:

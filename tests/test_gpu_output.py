@@ -31,6 +31,41 @@ def test_xyz_frame_written_from_engine_state_is_the_references_file(tmp_path):
     assert same >= 0.97 * (len(mine) - 3), same
 
 
+def test_bond_file_and_pdb_frame_written_from_engine_state_are_the_references_files(tmp_path):
+    """The same run as above with the reference's --isBondFile --isPDB: RxmdEngine.write_bnd (WriteBND, fileio.F90:27-148: the input of
+    rxmd's util/ tools) and write_pdb (WritePDB, fileio.F90:151-238).  Bond file: every line the same global id, type, number of listed
+    bonds and the same (partner id, bond order f6.3) pairs -- in the order of the engine's bond list, which walks the cells in another
+    order than the reference's linked lists (a permutation inside the line) -- positions to f12.3; pdb: the fixed columns byte for byte, positions to f8.3, the charge column to f6.2, the stress column as printed."""
+    g = np.load(os.path.join(oa.GOLD, "rdx168_md10.npz"))
+    e = _engine("rdx168", (1, 1, 1))
+    e.QEq(); e.FORCE(); e.step(9)
+    e.energy()                                   # PRINTE every step (pstep 1): the stress accumulators the last frame sees are those of the last step
+    e.step(1)
+    pb, pp = tmp_path / "000000010.bnd", tmp_path / "000000010.pdb"
+    e.write_bnd(str(pb)); e.write_pdb(str(pp))
+    e.close()
+    mine = open(pb).read().split("\n"); theirs = str(g["bnd_last"]).split("\n")
+    assert len(mine) == len(theirs) == 169 and mine[-1] == theirs[-1] == ""
+    same = 0
+    for a, b in zip(mine[:-1], theirs[:-1]):
+        ta, tb = a.split(), b.split()
+        assert len(ta) == len(tb) and ta[0] == tb[0] and ta[4:6] == tb[4:6] and sorted(ta[6::2]) == sorted(tb[6::2]), (a, b)
+        assert np.abs(np.array([float(v) for v in ta[1:4]]) - np.array([float(v) for v in tb[1:4]])).max() <= 1.01e-3
+        pa = sorted(zip(ta[6::2], ta[7::2])); pb_ = sorted(zip(tb[6::2], tb[7::2]))
+        assert max([abs(float(u[1]) - float(v[1])) for u, v in zip(pa, pb_)] + [0.0]) <= 1.01e-3
+        same += a[:58] == b[:58] and pa == pb_
+    assert same >= 0.97 * 168, same
+    mine = open(pp).read().split("\n"); theirs = str(g["pdb_last"]).split("\n")
+    assert len(mine) == len(theirs) == 169
+    same = 0
+    for a, b in zip(mine[:-1], theirs[:-1]):
+        assert len(a) == len(b) == 66 and a[:30] == b[:30] and a[60:] == b[60:], (a, b)
+        assert np.abs(np.array([float(a[30 + 8 * c:38 + 8 * c]) - float(b[30 + 8 * c:38 + 8 * c]) for c in range(3)])).max() <= 1.01e-3
+        assert abs(float(a[54:60]) - float(b[54:60])) <= 1.01e-2
+        same += a == b
+    assert same >= 0.97 * 168, same
+
+
 @pytest.mark.parametrize("mode,kw", [(4, dict(vsfact=0.9)), (5, dict(treq=300.0)), (7, dict(treq=300.0)), (8, dict(treq=300.0))])
 def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, tmp_path):
     """Continue the reference's own restart file (rxff.bin after 20 NVE steps) for 7 steps with velocity scaling every 3rd step, then

@@ -304,3 +304,41 @@ def test_charges_every_third_step_only():
             iters.append(o.L.rxo_qeq_iters(o.w))
     assert iters == [int(x) for x in g["qeq_iters"]]
     _compare(g, o, ftol=1e-9, qtol=1e-10)
+
+
+def test_bond_file_and_pdb_formatters_against_the_references_files():
+    """rxmd_amd.system.format_bnd / format_pdb (the host side of RxmdEngine.write_bnd / write_pdb) fed with the oracle's state after the
+    same 10 steps, against the files the reference wrote with --isBondFile --isPDB (WriteBND fileio.F90:27-148, WritePDB :151-238):
+    line structure, ids, partner order and the fixed columns exactly, the printed numbers to their last digit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from rxmd_amd import system
+    g = np.load(os.path.join(GOLD, "rdx168_md10.npz"))
+    ff, names, frac, lat = oa.make_system("rdx168")
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=(1, 1, 1))
+    o = oa.Oracle(ff, lat2, ranks); o.qeq(); o.force(); o.step(10)
+    nbr, bo = o.bonds()
+    gid = o.gids(); n = len(gid); gall = o.get(106).astype(np.int64); typ = o.get(4).astype(int)
+    cnt = (nbr[:n] > 0).sum(axis=1)
+    pg = np.zeros((n, 32), np.int64); b = np.zeros((n, 32))
+    for i in range(n):
+        pg[i, :cnt[i]] = gall[nbr[i, :cnt[i]] - 1]; b[i, :cnt[i]] = bo[i, :cnt[i]]
+    mine = system.format_bnd(gid, typ, o.pos(), cnt, pg, b).split("\n"); theirs = str(g["bnd_last"]).split("\n")
+    assert len(mine) == len(theirs) == n + 1
+    same = 0
+    for x, y in zip(mine[:-1], theirs[:-1]):
+        tx, ty = x.split(), y.split()
+        assert len(tx) == len(ty) and tx[0] == ty[0] and tx[4:6] == ty[4:6] and tx[6::2] == ty[6::2], (x, y)
+        assert np.abs(np.array([float(v) for v in tx[1:4] + tx[7::2]]) - np.array([float(v) for v in ty[1:4] + ty[7::2]])).max() <= 1.01e-3
+        same += x == y
+    assert same >= 0.97 * n, same
+    tnames = [""] + oa.ffield_names(ff)
+    mine = system.format_pdb(tnames, gid, typ, o.pos(), o.charges(), astr=(1e9, 1e9, 1e9)).split("\n"); theirs = str(g["pdb_last"]).split("\n")
+    assert len(mine) == len(theirs) == n + 1
+    same = 0
+    for x, y in zip(mine[:-1], theirs[:-1]):
+        assert len(x) == len(y) == 66 and x[:30] == y[:30] and x[60:] == y[60:] == "******", (x, y)
+        assert max(abs(float(x[30 + 8 * c:38 + 8 * c]) - float(y[30 + 8 * c:38 + 8 * c])) for c in range(3)) <= 1.01e-3
+        assert abs(float(x[54:60]) - float(y[54:60])) <= 1.01e-2
+        same += x == y
+    assert same >= 0.97 * n, same
