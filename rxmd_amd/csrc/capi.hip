@@ -276,6 +276,13 @@ static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const do
   const bool lex = e.lex_pending && e.lex_p.size() == static_cast<size_t>(natoms);
   e.last_atype.assign(atype, atype + natoms);
   for (int a = 0; a < 3; ++a) e.last_pos[a].assign(pos + a * static_cast<size_t>(nbuffer), pos + a * static_cast<size_t>(nbuffer) + natoms);
+  // every call after the first (the engine is sized, its tables exist): the caller's arrays go to the device as they are -- no
+  // 10-double records, no second copy of the coordinates; the packed type is split there (k_split_atype)
+  if (e.tables_ready && natoms <= e.rows10 && natoms < e.NB && std::getenv("RXMD_LEVEL1_RECORDS") == nullptr) {
+    e.set_atoms_arrays(natoms, atype, pos, pos + static_cast<size_t>(nbuffer), pos + 2 * static_cast<size_t>(nbuffer), q,
+                       lex ? e.lex_p.data() : nullptr, lex ? e.lex_v.data() : nullptr);
+    return;
+  }
   std::vector<double> rec(10 * static_cast<size_t>(natoms), 0.0);
   for (int i = 0; i < natoms; ++i) {
     const double r[3] = {pos[i], pos[static_cast<size_t>(nbuffer) + i], pos[2 * static_cast<size_t>(nbuffer) + i]};   // pos(NBUFFER,3) column-major
@@ -329,11 +336,8 @@ int rxmd_hip_FORCE(rxmd_handle h, int nbuffer, int natoms, const double *atype, 
   return guarded(h, [&](Engine &e) {
     upload_reference_arrays(e, nbuffer, natoms, atype, pos, q);
     e.force();
-    std::vector<double> tmp(natoms);
-    for (int a = 0; a < 3; ++a) {
-      RX_HIP(hipMemcpy(tmp.data(), e.frc[a], sizeof(double) * natoms, hipMemcpyDeviceToHost));
-      for (int i = 0; i < natoms; ++i) f[a * static_cast<size_t>(nbuffer) + i] = tmp[i];
-    }
+    for (int a = 0; a < 3; ++a)                      // f(NBUFFER,3) column-major: component a of the residents is contiguous
+      RX_HIP(hipMemcpy(f + a * static_cast<size_t>(nbuffer), e.frc[a], sizeof(double) * natoms, hipMemcpyDeviceToHost));
     if (pe) std::memcpy(pe, e.pe, sizeof(double) * 14);
   });
 }
@@ -362,11 +366,8 @@ int rxmd_hip_FORCE_pqeq(rxmd_handle h, int nbuffer, int natoms, const double *at
     upload_reference_arrays(e, nbuffer, natoms, atype, pos, q);
     upload_shells(e, nbuffer, natoms, spos);
     e.force();
-    std::vector<double> tmp(natoms);
-    for (int a = 0; a < 3; ++a) {
-      RX_HIP(hipMemcpy(tmp.data(), e.frc[a], sizeof(double) * natoms, hipMemcpyDeviceToHost));
-      for (int i = 0; i < natoms; ++i) f[a * static_cast<size_t>(nbuffer) + i] = tmp[i];
-    }
+    for (int a = 0; a < 3; ++a)                      // f(NBUFFER,3) column-major: component a of the residents is contiguous
+      RX_HIP(hipMemcpy(f + a * static_cast<size_t>(nbuffer), e.frc[a], sizeof(double) * natoms, hipMemcpyDeviceToHost));
     if (pe) std::memcpy(pe, e.pe, sizeof(double) * 14);
   });
 }

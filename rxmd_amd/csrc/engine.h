@@ -213,6 +213,9 @@ struct Engine {
   explicit Engine(const rxmd_config &c);
   ~Engine();
   void set_atoms_rxff(int natoms, const double *rec10);
+  // the same from the reference's own arrays (atype packed as type + gid*1e-13, REAL coordinates by component): no host-side record,
+  // the packed type is split on the device.  Only once the engine is sized (after a first set_atoms_rxff); velocities are zeroed.
+  void set_atoms_arrays(int natoms, const double *atype, const double *x, const double *y, const double *z, const double *q, const double *lexp, const double *lexv);
   int get_atoms_rxff(double *rec10, int capacity);
   void build_ghosts_and_lists(bool qeq_prepass = false);   // COPYATOMS(MODE_COPY) + LINKEDLIST + NEIGHBORLIST + 10 A list/hessian, once per step
   void qeq_start_vectors();        // qs, qt, hs, ht of qeq.F90:36-63 and their cell-sorted copy (before the list sweep that uses them)
@@ -289,6 +292,6 @@ constexpr unsigned NB10_IDX_MASK = (1u << NB10_IDX_BITS) - 1u;
 constexpr unsigned NB10_GHOST = 1u << 30, NB10_SELF = 1u << 31;
 
 // device error codes written by kernels into Engine::d_err
-enum { DERR_NONE = 0, DERR_MAXNB = 1, DERR_MAXN10 = 2, DERR_GRID = 3, DERR_NBRINDX = 4 };
+enum { DERR_NONE = 0, DERR_MAXNB = 1, DERR_MAXN10 = 2, DERR_GRID = 3, DERR_NBRINDX = 4, DERR_TYPE = 5 };
 
 }  // namespace rxmd

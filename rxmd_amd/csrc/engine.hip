@@ -145,6 +145,7 @@ void Engine::check_device_error(const char *where) {
   if (e == DERR_MAXNB) throw EngineError(RXMD_E_MAXNEIGHBS, w + "overflow of max # in neighbor list (MAXNEIGHBS=" + std::to_string(MAXNB) + ", needed " + std::to_string(h_err[1]) + ")");
   if (e == DERR_MAXN10) throw EngineError(RXMD_E_MAXNEIGHBS10, w + "nbplist greater than MAXNEIGHBS10=" + std::to_string(S10) + " (needed " + std::to_string(h_err[1]) + ")");
   if (e == DERR_NBRINDX) throw EngineError(RXMD_E_STATE, w + "inconsistency between nbrlist and nbrindx");
+  if (e == DERR_TYPE) throw EngineError(RXMD_E_ARG, w + "atom type outside the ffield");
   throw EngineError(RXMD_E_STATE, w + "device error " + std::to_string(e));
 }
 
@@ -401,6 +402,41 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
   RX_HIP(hipMemcpy(gid, hg.data(), sizeof(long long) * natoms, hipMemcpyHostToDevice));
   atoms_set = true; lists_valid = false; ghosts_valid = false;
   st.natoms = N;
+}
+
+// atype = type + l2g * 1e-13 (main.F90:582-593) -> type, global id; a type outside the ffield raises the device error word
+__global__ void k_split_atype(int n, int nso, const double *__restrict__ atype, int *__restrict__ type, long long *__restrict__ gid, int *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = atype[i];
+  const int t = static_cast<int>(llround(a));
+  if (t < 1 || t > nso) { atomicCAS(&err[0], DERR_NONE, DERR_TYPE); type[i] = 1; gid[i] = 0; return; }
+  type[i] = t; gid[i] = llround((a - t) * 1e13);
+}
+void Engine::set_atoms_arrays(int natoms, const double *atype, const double *x, const double *y, const double *z, const double *qh, const double *lexp, const double *lexv) {
+  if (!tables_ready) throw EngineError(RXMD_E_STATE, "set_atoms_arrays before the engine was sized");
+  if (natoms < 0 || natoms > rows10 || natoms >= NB) throw EngineError(RXMD_E_NBUFFER, "more atoms than the engine was sized for");
+  sync_stream();                                   // nothing of the previous call may still read what is overwritten
+  const double *xyz[3] = {x, y, z};
+  const size_t nbytes = sizeof(double) * static_cast<size_t>(natoms);
+  if (natoms > 0) {
+    RX_HIP(hipMemcpyAsync(cds, atype, nbytes, hipMemcpyHostToDevice, stream));     // cds: per-atom scratch of FORCE, free between calls
+    k_split_atype<<<(natoms + 255) / 256, 256, 0, stream>>>(natoms, ff.nso, cds, type, gid, d_err);
+    for (int a = 0; a < 3; ++a) {
+      RX_HIP(hipMemcpyAsync(pos[a], xyz[a], nbytes, hipMemcpyHostToDevice, stream));
+      RX_HIP(hipMemsetAsync(vel[a], 0, nbytes, stream));
+    }
+    if (qh) RX_HIP(hipMemcpyAsync(q, qh, nbytes, hipMemcpyHostToDevice, stream)); else RX_HIP(hipMemsetAsync(q, 0, nbytes, stream));
+    if (lexp && lexv) { RX_HIP(hipMemcpyAsync(qsfp, lexp, nbytes, hipMemcpyHostToDevice, stream)); RX_HIP(hipMemcpyAsync(qsfv, lexv, nbytes, hipMemcpyHostToDevice, stream)); }
+    else { RX_HIP(hipMemsetAsync(qsfp, 0, nbytes, stream)); RX_HIP(hipMemsetAsync(qsfv, 0, nbytes, stream)); }
+  }
+  for (int a = 0; a < 3; ++a) RX_HIP(hipMemsetAsync(frc[a], 0, sizeof(double) * NB, stream));
+  if (ff.pqeq) for (int a = 0; a < 3; ++a) RX_HIP(hipMemsetAsync(shl[a], 0, sizeof(double) * NB, stream));
+  N = natoms; G = natoms;
+  atoms_set = true; lists_valid = false; ghosts_valid = false;
+  atype_resid = 0.0;
+  st.natoms = N;
+  check_device_error("set_atoms_arrays");          // (synchronises: the caller's arrays are free again)
 }
 
 int Engine::get_atoms_rxff(double *rec, int capacity) {
