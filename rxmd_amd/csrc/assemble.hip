@@ -226,12 +226,41 @@ __global__ void k_sum6(int nblocks, const double *__restrict__ partials, double 
   for (int b = 0; b < nblocks; ++b) s += partials[b * 6 + c];
   out6[c] = s;
 }
+// PRINTE's two sums over the residents (main.F90:225-230): kinetic energy sum hmas(ity) v.v and total charge; fixed grid and a fixed
+// order of the final sum, so the numbers do not depend on scheduling
+__global__ void __launch_bounds__(256) k_ke_qsum(int n, const int *__restrict__ type, DevFF ff, const double *__restrict__ vx, const double *__restrict__ vy,
+                                                  const double *__restrict__ vz, const double *__restrict__ q, double *__restrict__ partials) {
+  __shared__ double sm[256];
+  double a[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v0 = vx[i], v1 = vy[i], v2 = vz[i];
+    a[0] += 0.5 * ff.atom[type[i]].mass * (v0 * v0 + v1 * v1 + v2 * v2);       // hmas = mass / 2, init.F90:106
+    a[1] += q[i];
+  }
+  for (int c = 0; c < 2; ++c) {
+    sm[threadIdx.x] = a[c];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) partials[blockIdx.x * 6 + c] = sm[0];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partials[blockIdx.x * 6 + 2 + threadIdx.x] = 0.0;
+}
 struct ScaleArgs { double c[16]; double vcm[3]; };
 __global__ void k_scale_velocities(int n, ScaleArgs a, const int *__restrict__ type, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double c = a.c[type[i]];
   vx[i] = c * vx[i] - a.vcm[0]; vy[i] = c * vy[i] - a.vcm[1]; vz[i] = c * vz[i] - a.vcm[2];
+}
+
+void Engine::kinetic_and_charge(double &ke, double &qsum) {
+  const int nb = 240;
+  k_ke_qsum<<<nb, 256, 0, stream>>>(N, type, dff, vel[0], vel[1], vel[2], q, partials);
+  k_sum6<<<1, 64, 0, stream>>>(nb, partials, scal + 56);
+  RX_HIP(hipMemcpyAsync(h_scal + 56, scal + 56, sizeof(double) * 2, hipMemcpyDeviceToHost, stream));
+  sync_stream();
+  ke = h_scal[56]; qsum = h_scal[57];
 }
 
 void Engine::thermostat(int mdmode, double treq_K, double vsfact, double gke) {

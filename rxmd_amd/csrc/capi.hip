@@ -237,15 +237,8 @@ int rxmd_hip_thermostat(rxmd_handle h, int mdmode, double treq_K, double vsfact,
 int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], double astr[6]) {
   return guarded(h, [&](Engine &e) {
     if (!e.atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
-    const int n = e.N;
-    RX_HIP(hipStreamSynchronize(e.stream));
-    std::vector<double> v[3], q(n);
-    std::vector<int> t(n);
-    for (int a = 0; a < 3; ++a) { v[a].resize(n); RX_HIP(hipMemcpy(v[a].data(), e.vel[a], sizeof(double) * n, hipMemcpyDeviceToHost)); }
-    RX_HIP(hipMemcpy(q.data(), e.q, sizeof(double) * n, hipMemcpyDeviceToHost));
-    RX_HIP(hipMemcpy(t.data(), e.type, sizeof(int) * n, hipMemcpyDeviceToHost));
     double k = 0.0, qs = 0.0;
-    for (int i = 0; i < n; ++i) { k += e.hmas[t[i]] * (v[0][i] * v[0][i] + v[1][i] * v[1][i] + v[2][i] * v[2][i]); qs += q[i]; }  // main.F90:225-230
+    e.kinetic_and_charge(k, qs);                       // main.F90:225-230, summed on the device in a fixed order
     if (ke) *ke = k;
     if (qsum) *qsum = qs;
     if (pe) std::memcpy(pe, e.pe, sizeof(double) * 14);

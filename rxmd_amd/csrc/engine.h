@@ -212,6 +212,7 @@ struct Engine {
   // ---- host API ----
   explicit Engine(const rxmd_config &c);
   ~Engine();
+  void kinetic_and_charge(double &ke, double &qsum);   // sum hmas v^2 and sum q over the residents (PRINTE, main.F90:225-230); assemble.hip
   void set_atoms_rxff(int natoms, const double *rec10);
   // the same from the reference's own arrays (atype packed as type + gid*1e-13, REAL coordinates by component): no host-side record,
   // the packed type is split on the device.  Only once the engine is sized (after a first set_atoms_rxff); velocities are zeroed.
