@@ -282,11 +282,13 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
 
 struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // probe (timing experiments only, RXMD_E4B_PROBE): 1 = set-up only, 2 = phase B skipped, 5 = PE(8), PE(9) count batches and entries    // lattice vectors for the image test of the torsion's stress correction
 // Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to i,j,k,l.
-// Here ONE WAVEFRONT owns NG = 64 / SL consecutive centre atoms; lane t = (g * SL + slot) owns the accumulators of bond `slot` of
-// atom g.  SL = 32 slots (two atoms) holds any list (MAXNEIGHBS = 30); SL = 16 (four atoms) is launched when no atom of the step has
-// more than 15 bonds, as in RDX: half as many wavefronts set up and enumerate, and their queues fill the 64-lane batches better
-// (two RDX atoms queue 52 torsions: 1.38 batches per wavefront at 58 % of the lanes).  Phase A enumerates every (k1,i1,l1) combination of the two atoms, applies the reference's cheap bond-order
-// cut-offs (pot.F90:1023,1044,1072,1078,1081) and compacts the survivors with a ballot into an LDS queue; phase B
+// Here ONE WAVEFRONT owns several consecutive centre atoms; every bond slot of an atom has a lane that owns its accumulators, and
+// one more lane stands for the atom itself.  Four layouts (template LSL, chosen per step from the longest bond list, see
+// Engine::bonded_energies): two atoms x 32 lanes (any list, MAXNEIGHBS = 30), four atoms x 16 lanes, and the packed forms -- eight
+// (lists <= 15) or four atoms with their lanes laid end to end.  More atoms per wavefront = fewer wavefronts that set up and
+// enumerate, more of their lanes busy, fuller 64-lane batches (two RDX atoms queue 52 torsions: 1.38 batches per wavefront at 58 %
+// of the lanes; eight atoms: 6.3 -> 3.9 ms).  Phase A enumerates every (k1,i1,l1) combination of the atoms, applies the reference's
+// cheap bond-order cut-offs (pot.F90:1023,1044,1072,1078,1081) and compacts the survivors with a ballot into an LDS queue; phase B
 // evaluates 64 surviving torsions at a time with every lane busy (only ~1 in 8 combinations survives in RDX).
 // A torsion is visited from both ends: a lane books the energy, the j-k bond coefficient and the cdbnd terms only when
 // gid(j) < gid(k) (the reference's orientation, which the index-ordered ccbnd rule depends on), the forces on i and j and
