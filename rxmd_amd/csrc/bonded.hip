@@ -311,9 +311,11 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
   // phase A walks only bonds above the cut-off: the slots of each centre atom that qualify, and per centre bond the qualifying slots
   // of k with what the filter needs of them (bond order, atom l, its type) -- staged once per centre bond by the lanes side by side
-  __shared__ int s_cap[4][64], s_capl[4][32], s_ll[4][32], s_tl[4][32], s_gj[4][8][2];   // s_gj: bond count and type of each centre atom
+  __shared__ int s_cap[4][64], s_capl[4][64], s_ll[4][64], s_tl[4][64], s_gj[4][8][2];   // s_gj: bond count and type of each centre atom
+  __shared__ int s_cb[4][64];                    // the centre bonds of the pass: atom << 8 | lane of the slot
+  __shared__ int s_cd[4][4][9];                  // per centre bond of a round: atom, lane, first lane of the atom, type of j, k, j, number of qualifying k-slots, 1/that, combinations
   __shared__ int s_base[4][9];                   // LSL == 0: first lane of each atom of the pass, and the end
-  __shared__ double s_bokl[4][32];
+  __shared__ double s_bokl[4][64];
   // per (atom g, slot) accumulators, updated with LDS atomics by the lanes that evaluate torsions: [0] cf1 and [1..3] force of the
   // i-j bond / its neighbour, [4] cf1, [5] cf2, [6] cdbnd of the centre bond; slot 31 (never a bond) holds the centre atom's own
   // force in [1..3] and cdbnd in [6].  (An earlier version wrote 11 results per torsion to LDS and let every owner lane scan all 64
@@ -327,6 +329,15 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   constexpr int PKN = (LSL == 0) ? 8 : 4, CAP = (LSL == 0) ? 15 : 31;                          // packed: atoms per wavefront, longest list
   constexpr int SL = PACK ? CAP + 1 : (1 << (LSL & 31)), NG = PACK ? PKN : (64 >> (LSL & 31));  // (widest) lane range of an atom, atoms per wavefront
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
+  // "is there a torsion row for these four types" (pot.F90:1078) as a bit table in LDS when the ffield has at most 7 atom types
+  // (n1^4 <= 4096 bits): the enumeration asks it for every candidate, and a look-up in global memory is a dependent round trip
+  // per centre bond
+  __shared__ unsigned s_tor[128];
+  const bool tor_lds = ff.n1 <= 8;
+  if (tor_lds) {
+    if (threadIdx.x < 128) s_tor[threadIdx.x] = ff.tor_bits[threadIdx.x];      // built once on the host (upload_ff)
+    __syncthreads();
+  }
   const int jbase = (blockIdx.x * 4 + w) * NG;
   if (jbase >= N) return;                        // whole wavefront leaves together; no block-level barrier below
   double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
@@ -543,64 +554,98 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   };
 
   if (bx.probe == 1) return;                      // timing experiment: set-up only
-  // phase A: enumerate, filter, compact
-  for (int g = 0; g < ng; ++g) {
-    const int gb = __builtin_amdgcn_readfirstlane(gbase(g));
-    const int nj = __builtin_amdgcn_readfirstlane(s_gj[w][g][0]), tjc = __builtin_amdgcn_readfirstlane(s_gj[w][g][1]);
-    const int gw = PACK ? nj + 1 : SL;                                    // lanes of this atom
-    const int ncj = __popc(static_cast<unsigned>(capmask >> gb) & ((gw == 32) ? 0xffffffffu : ((1u << (gw & 31)) - 1u)));
-    for (int k1 = 0; k1 < nj; ++k1) {
-      const int sk = gb + k1;
-      const int nk = (s_meta[w][sk] >> 8) & 255;
-      if (nk == 0) continue;
-      const double BOjk_f = s_bo[w][sk];
-      const int k = s_nb[w][sk], j = jbase + g0 + g;
-      int nck;
-      {                                           // the qualifying slots of k (pot.F90:1072), staged by the lanes side by side
-        const int nkc = min(nk, WSLOT);
-        double bl = 0.0;
-        if (lane < nkc) bl = bo0[static_cast<size_t>(lane) * NB + k];
-        const bool capl = (lane < nkc) && (bl > cutof2_esub);
-        const unsigned long long ml = __ballot(capl);
-        if (capl) {
-          const int r = __popcll(ml & ((1ULL << lane) - 1ULL));
-          const int l = nbr[static_cast<size_t>(lane) * NB + k];
-          s_capl[w][r] = lane; s_bokl[w][r] = bl; s_ll[w][r] = l; s_tl[w][r] = type[l];
-        }
-        nck = __popcll(ml);
-        wave_lds_sync();
+  // phase A: enumerate, filter, compact.  The centre bonds of the pass (every slot above the cut-off, in (atom, slot) order) are taken
+  // CPB at a time: the lanes stage the qualifying slots of their k atoms (pot.F90:1072: bond order, atom l, its type -- three
+  // dependent loads) side by side, KW lanes per centre bond, so that a wavefront of eight atoms with ~40 centre bonds waits for ~10
+  // such rounds instead of 40 (one centre bond at a time: set-up + enumeration 2.43 ms of the 3.96 ms kernel); the enumeration of a
+  // centre bond then reads LDS only.
+  constexpr int KW = (LSL == 5 || LSL == 1) ? 32 : 16, CPB = 64 / KW;   // lanes per centre bond (longest list of any atom + 1), centre bonds per round
+  const int ncb = __popcll(capmask);
+  if (cap_me) { const int r = __popcll(capmask & ((1ULL << lane) - 1ULL)); s_cb[w][r] = (g_me << 8) | lane; }
+  wave_lds_sync();
+  for (int r0 = 0; r0 < ncb; r0 += CPB) {
+    unsigned long long ml;
+    {
+      const int cbl = lane / KW, ks = lane % KW, r = r0 + cbl;
+      double bl = 0.0;
+      bool capl = false;
+      int kk = 0;
+      if (r < ncb) {
+        const int sk = s_cb[w][r] & 255;
+        kk = s_nb[w][sk];
+        if (ks < min((s_meta[w][sk] >> 8) & 255, KW == 32 ? WSLOT : KW)) { bl = bo0[static_cast<size_t>(ks) * NB + kk]; capl = bl > cutof2_esub; }
       }
-      const int total = ncj * nck;
-      for (int c0 = 0; c0 < total; c0 += 64) {
-        const int c = c0 + lane;
-        bool go = false;
-        int i1 = 0, l1 = 0;
-        if (c < total) {
-          const int ci = c / nck, cl = c - ci * nck;
-          i1 = s_cap[w][gb + ci]; l1 = s_capl[w][cl];
-          const double BOij_f = s_bo[w][gb + i1];
-          const int i = s_nb[w][gb + i1];
-          const double BOkl_f = s_bokl[w][cl];
-          const int l = s_ll[w][cl];
-          go = (i1 != k1) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
-               (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0) && (l != i) && (l != j);
-          if (go) go = ff.inxn4[(((s_meta[w][gb + i1] & 255) * ff.n1 + tjc) * ff.n1 + (s_meta[w][sk] & 255)) * ff.n1 + s_tl[w][cl]] != 0;
-        }
-        const unsigned long long m = __ballot(go);
-        if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
-        qn += __popcll(m);
-        wave_lds_sync();
-        if (qn >= 64) {
-          evaluate(64);
-          const int rest = qn - 64;
-          const int v = (lane < rest) ? s_q[w][64 + lane] : 0;
-          wave_lds_sync();
-          if (lane < rest) s_q[w][lane] = v;
-          wave_lds_sync();
-          qn = rest;
-        }
+      ml = __ballot(capl);
+      if (capl) {
+        const unsigned sub = static_cast<unsigned>(ml >> (cbl * KW)) & ((KW == 32) ? 0xffffffffu : 0xffffu);
+        const int pos = cbl * KW + __popc(sub & ((1u << ks) - 1u));
+        const int l = nbr[static_cast<size_t>(ks) * NB + kk];
+        s_capl[w][pos] = ks; s_bokl[w][pos] = bl; s_ll[w][pos] = l; s_tl[w][pos] = type[l];
       }
     }
+    // what the combinations of each centre bond of the round need, written by lanes 0..CPB-1: the combinations of all of them are
+    // then enumerated together, 64 at a time (a centre bond of RDX has ~25: one pass per centre bond left most lanes idle)
+    if (lane < CPB) {
+      int T = 0;
+      if (r0 + lane < ncb) {
+        const int ent = s_cb[w][r0 + lane];
+        const int g = ent >> 8, sk = ent & 255, gb = gbase(g), nj = s_gj[w][g][0];
+        const int gw = PACK ? nj + 1 : SL;                                  // lanes of this atom
+        const int ncj = __popc(static_cast<unsigned>(capmask >> gb) & ((gw == 32) ? 0xffffffffu : ((1u << (gw & 31)) - 1u)));
+        const int nck = __popc(static_cast<unsigned>(ml >> (lane * KW)) & ((KW == 32) ? 0xffffffffu : 0xffffu));
+        int *d = &s_cd[w][lane][0];
+        d[0] = g; d[1] = sk; d[2] = gb; d[3] = s_gj[w][g][1]; d[4] = s_nb[w][sk]; d[5] = jbase + g0 + g; d[6] = nck;
+        d[7] = __float_as_int(1.0f / static_cast<float>(max(nck, 1)));     // c / nck for c < 1024, nck <= 31: exact through (c + 0.5) * (1 / nck) in FP32
+        T = ncj * nck;
+      }
+      s_cd[w][lane][8] = T;
+    }
+    wave_lds_sync();
+    int P[CPB + 1];
+    P[0] = 0;
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) P[c + 1] = P[c] + __builtin_amdgcn_readfirstlane(s_cd[w][c][8]);
+    const int total = P[CPB];
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      const int idx = c0 + lane;
+      bool go = false;
+      int key = 0;
+      if (idx < total) {
+        int cb = 0;
+#pragma unroll
+        for (int c = 1; c < CPB; ++c) cb += (idx >= P[c]) ? 1 : 0;
+        int pb = P[0];
+#pragma unroll
+        for (int c = 1; c < CPB; ++c) pb = (cb >= c) ? P[c] : pb;
+        const int *d = &s_cd[w][cb][0];
+        const int g = d[0], sk = d[1], gb = d[2], tjc = d[3], k = d[4], j = d[5], nck = d[6], k1 = sk - gb, c = idx - pb;
+        const int ci = static_cast<int>((static_cast<float>(c) + 0.5f) * __int_as_float(d[7])), cl = cb * KW + (c - ci * nck);
+        const int i1 = s_cap[w][gb + ci], l1 = s_capl[w][cl];
+        const double BOjk_f = s_bo[w][sk], BOij_f = s_bo[w][gb + i1], BOkl_f = s_bokl[w][cl];
+        const int i = s_nb[w][gb + i1], l = s_ll[w][cl];
+        go = (i1 != k1) && (BOij_f * BOjk_f > cutof2_esub) && (i != k) &&
+             (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0) && (l != i) && (l != j);
+        if (go) {
+          const int i4 = (((s_meta[w][gb + i1] & 255) * ff.n1 + tjc) * ff.n1 + (s_meta[w][sk] & 255)) * ff.n1 + s_tl[w][cl];
+          go = tor_lds ? ((s_tor[i4 >> 5] >> (i4 & 31)) & 1u) != 0u : ff.inxn4[i4] != 0;
+        }
+        key = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
+      }
+      const unsigned long long m = __ballot(go);
+      if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = key;
+      qn += __popcll(m);
+      wave_lds_sync();
+      if (qn >= 64) {
+        evaluate(64);
+        const int rest = qn - 64;
+        const int v = (lane < rest) ? s_q[w][64 + lane] : 0;
+        wave_lds_sync();
+        if (lane < rest) s_q[w][lane] = v;
+        wave_lds_sync();
+        qn = rest;
+      }
+    }
+    wave_lds_sync();                                // the next round overwrites the k-side lists
   }
   if (qn > 0) evaluate(qn);
 

@@ -49,6 +49,7 @@ struct DevFF {
   int nso, n1, nboty;
   const DevAtomP *atom; const DevBondP *bond; const DevAngleP *angle; const DevTorsP *tors; const DevHbP *hb;
   const int *inxn2, *inxn3, *inxn3hb, *inxn4;
+  const unsigned *tor_bits;     // inxn4 != 0 as a bit table of 4096 bits (valid when n1 <= 8): k_e4b keeps it in LDS
   const DevNBTab *tabNB;   // [inxn * (NTABLE+2) + i]
   const double *tabQEq;    // [inxn * (NTABLE+2) + i]
   double UDR, UDRi, rctap2, rctap_pad, cutoff_vpar30, vpar1, vpar2;   // rctap_pad: taper cutoff + the sweep padding (lists.hip)

@@ -241,12 +241,18 @@ void Engine::upload_ff() {
     zk.assign(2 * (ff.npq + 1), 0.0);
     for (int t = 1; t <= ff.npq; ++t) { zk[t] = ff.Zpq[t]; zk[ff.npq + 1 + t] = ff.Kspq[t]; }
   }
+  // inxn4 followed by "is there a torsion row" as 4096 bits (ffields with at most 7 atom types)
+  std::vector<int> inxn4x(ff.inxn4);
+  inxn4x.resize(ff.inxn4.size() + 128, 0);
+  if (n1 <= 8)
+    for (size_t i = 0; i < ff.inxn4.size(); ++i)
+      if (ff.inxn4[i] != 0) inxn4x[ff.inxn4.size() + (i >> 5)] |= static_cast<int>(1u << (i & 31));
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
   size_t off[12], tot = 0;
   const size_t sz[11] = {a.size() * sizeof(DevAtomP), b.size() * sizeof(DevBondP), an.size() * sizeof(DevAngleP), to.size() * sizeof(DevTorsP),
-                         hb.size() * sizeof(DevHbP), ff.inxn2.size() * 4, ff.inxn3.size() * 4, ff.inxn3hb.size() * 4, ff.inxn4.size() * 4,
+                         hb.size() * sizeof(DevHbP), ff.inxn2.size() * 4, ff.inxn3.size() * 4, ff.inxn3hb.size() * 4, inxn4x.size() * 4,
                          nb.size() * sizeof(DevNBTab), ff.tblQEq.size() * 8};
-  const void *src[11] = {a.data(), b.data(), an.data(), to.data(), hb.data(), ff.inxn2.data(), ff.inxn3.data(), ff.inxn3hb.data(), ff.inxn4.data(), nb.data(), ff.tblQEq.data()};
+  const void *src[11] = {a.data(), b.data(), an.data(), to.data(), hb.data(), ff.inxn2.data(), ff.inxn3.data(), ff.inxn3hb.data(), inxn4x.data(), nb.data(), ff.tblQEq.data()};
   for (int i = 0; i < 11; ++i) { off[i] = tot; tot += al(sz[i]); }
   if (ffblob) { (void)hipFree(ffblob); ffblob = nullptr; }
   RX_HIP(hipMalloc(&ffblob, tot));
@@ -258,6 +264,7 @@ void Engine::upload_ff() {
   dff.hb = reinterpret_cast<DevHbP *>(base + off[4]);
   dff.inxn2 = reinterpret_cast<int *>(base + off[5]); dff.inxn3 = reinterpret_cast<int *>(base + off[6]);
   dff.inxn3hb = reinterpret_cast<int *>(base + off[7]); dff.inxn4 = reinterpret_cast<int *>(base + off[8]);
+  dff.tor_bits = reinterpret_cast<unsigned *>(base + off[8]) + ff.inxn4.size();
   dff.tabNB = reinterpret_cast<DevNBTab *>(base + off[9]); dff.tabQEq = reinterpret_cast<double *>(base + off[10]);
   dff.rctap_pad = ff.rctap + 1e-6;
   dff.UDR = ff.UDR; dff.UDRi = ff.UDRi; dff.rctap2 = ff.rctap2; dff.cutoff_vpar30 = ff.cutoff_vpar30; dff.vpar1 = ff.vpar1; dff.vpar2 = ff.vpar2;
