@@ -151,7 +151,14 @@ typedef struct rxmd_stats {
   double ms_qeq, ms_qeq_list, ms_qeq_spmv, ms_force, ms_lists, ms_bo, ms_nonbond, ms_bonded, ms_step_total;
   long long spmv_launches;              /* number of matrix passes timed in ms_qeq_spmv */
   int n10_stride, nbuffer, cells10[3], cells3[3];
-  int reserved[8];
+  int n_boundary_rows;                  /* rows of the 10 A matrix with a ghost partner (vprocs > 1: the launch that waits for the vector halo) */
+  int reserved[7];
+  /* the exchanges of a vprocs > 1 run (comm.F90:2-100), event-timed on the stream they run on, summed since rxmd_hip_reset_timers:
+   * ghost build (MODE_COPY incl. its size messages), migration (MODE_MOVE), vector / charge halos (MODE_QCOPY1/2: pack, send-recv,
+   * unpack), the part of them the main stream had to WAIT for (exposed: from the join with the halo stream to the halo's end; the
+   * whole halo when overlap is off), scalar all-reduces (qeq.F90:107,129,144,357), reverse force fold (MODE_CPBK) */
+  double ms_ghost_build, ms_migrate, ms_halo, ms_halo_exposed, ms_allreduce, ms_fold;
+  long long halo_calls, allreduce_calls;
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);
@@ -164,7 +171,8 @@ int rxmd_hip_get_table(rxmd_handle h, int which, double *out, int capacity);
 int rxmd_hip_get_cutoffs(rxmd_handle h, double *rc, int capacity, double *maxrc);
 /* debugging taps on device state after rxmd_hip_force (residents+ghosts, engine order):
  * what: 0 delta  1 deltap  2 bonded neighbour count  3 real pos (x3)  4 gid  5 type  6 n10 count (residents)
- *       7 hessian row sums (residents) */
+ *       7 hessian row sums (residents)  8 cdbnd gathered per atom  9 charges incl. ghosts
+ *       10 ccbnd as ForceBondedTerms consumes it (pot.F90:129-135)  100 read-bandwidth probe */
 int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity);
 
 /* ---- multi-rank surface (COPYATOMS, src/comm.F90) ------------------------------------------- */

@@ -371,6 +371,7 @@ typedef struct {
   int *nbrlist, *nbrindx;              /* [i*(MAXNEIGHBS+1)+k] */
   int *nbplist; double *hessian;       /* rows of maxn10+1 for residents */
   double *BO, *dln_BOp, *dBOp, *A0, *A1, *A2, *A3, *deltap, *delta, *nlp, *dDlp, *deltalp, *ccbnd, *cdbnd;
+  double *ccused;   /* test tap only: ccbnd(i) as ForceBondedTerms consumes it (pot.F90:129-135), kept before it is zeroed (:138) */
   double PE[14], astr[6];
   double *sbuf; int ns, ne; double *rbuf; int nr; size_t sbuf_cap, rbuf_cap;
   char *commflag;
@@ -1705,6 +1706,7 @@ static void ForceBondedTerms(Rank *r) { /* pot.F90:113-144 -- index-ordered on p
       int j = NBR(r, i, j1);
       for (int k = 0; k < 3; k++) { double ff = r->ccbnd[i] * r->dBOp[SL(r, i, j1)] * (POS(r, i, k) - POS(r, j, k)); FRC(r, i, k) -= ff; FRC(r, j, k) += ff; }
     }
+    r->ccused[i] = r->ccbnd[i];
     r->ccbnd[i] = 0.0;
   }
 }
@@ -1868,7 +1870,7 @@ static void alloc_rank(World *W, Rank *r, int p, int NBUFFER) {
   r->nbrlist = ialloc(NB * (MAXNEIGHBS + 1)); r->nbrindx = ialloc(NB * (MAXNEIGHBS + 1));
   size_t ns = NB * (MAXNEIGHBS + 1);
   r->BO = dalloc(ns * 4); r->dln_BOp = dalloc(ns * 3); r->dBOp = dalloc(ns); r->A0 = dalloc(ns); r->A1 = dalloc(ns); r->A2 = dalloc(ns); r->A3 = dalloc(ns);
-  r->deltap = dalloc(2 * NB); r->delta = dalloc(NB); r->nlp = dalloc(NB); r->dDlp = dalloc(NB); r->deltalp = dalloc(NB); r->ccbnd = dalloc(NB); r->cdbnd = dalloc(NB);
+  r->deltap = dalloc(2 * NB); r->delta = dalloc(NB); r->nlp = dalloc(NB); r->dDlp = dalloc(NB); r->deltalp = dalloc(NB); r->ccbnd = dalloc(NB); r->cdbnd = dalloc(NB); r->ccused = dalloc(NB);
   r->commflag = (char *)calloc(NB, 1);
 }
 
@@ -2049,6 +2051,8 @@ int rxo_get(void *w, int rank, int what, double *out) {
     case 104: for (int i = 1; i <= n; i++) out[i - 1] = NBP(r, i, 0); return n;
     case 105: for (int i = 1; i <= G; i++) out[i - 1] = r->ity[i]; return G;
     case 106: for (int i = 1; i <= G; i++) out[i - 1] = (double)r->gid[i]; return G;
+    case 109: for (int i = 1; i <= G; i++) out[i - 1] = r->ccused[i]; return G;   /* ccbnd(i) at the moment pot.F90:129-135 uses it */
+    case 110: for (int i = 1; i <= G; i++) out[i - 1] = r->cdbnd[i]; return G;    /* cdbnd(i) after the energy terms */
     case 108: for (int i = 1; i <= n; i++) { double s = 0; for (int k = 1; k <= NBP(r, i, 0); k++) s += HES(r, i, k); out[i - 1] = s; } return n;
   }
   return -1;

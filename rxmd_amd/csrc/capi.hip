@@ -380,6 +380,7 @@ int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out) {
       e.st.nnz10 = s10; e.st.nbonds = sb; e.st.max_n10 = m10; e.st.max_nb = mb;
     }
     e.st.natoms = e.N;
+    e.st.n_boundary_rows = (e.multi() && e.lists_valid && !e.rows_split_pending_invalid()) ? e.n_bnd : 0;
     *out = e.st;
   });
 }
@@ -388,6 +389,8 @@ int rxmd_hip_reset_timers(rxmd_handle h) {
   return guarded(h, [&](Engine &e) {
     e.st.ms_qeq = e.st.ms_qeq_list = e.st.ms_qeq_spmv = e.st.ms_force = e.st.ms_lists = e.st.ms_bo = e.st.ms_nonbond = e.st.ms_bonded = e.st.ms_step_total = 0.0;
     e.st.spmv_launches = 0; e.st.qeq_iters_total = 0; e.st.qeq_calls = 0;
+    e.st.ms_ghost_build = e.st.ms_migrate = e.st.ms_halo = e.st.ms_halo_exposed = e.st.ms_allreduce = e.st.ms_fold = 0.0;
+    e.st.halo_calls = e.st.allreduce_calls = 0;
   });
 }
 
@@ -455,6 +458,7 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
       }
       case 8: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.cd, G, 1, 0); break;
       case 9: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.q, G, 1, 0); break;
+      case 10: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.cc_, G, 1, 0); break;
       case 100: {   // read-bandwidth probe over the whole value array: out = {ms, bytes} for a few grid sizes
         n = 4; if (capacity < 8) throw EngineError(RXMD_E_ARG, "capacity");
         const int grids[4] = {2048, 8192, 32768, 131072};

@@ -79,7 +79,52 @@ def test_tight_tolerance_parity_vs_oracle(case, mc):
     assert (e.debug(2).astype(int) == o.get(103).astype(int)).all()
     assert (e.debug(6).astype(int) == o.get(104).astype(int)).all()
     assert np.allclose(e.debug(7), o.get(108), rtol=1e-12)
+    check_bond_order_taps(e, o)
     e.close()
+
+
+def check_bond_order_taps(e, o):
+    """a9 / a10 / a18 directly: delta' of BOPRIM (bo.F90:28-118), delta and the corrected bond orders of BOFULL (bo.F90:121-298), cdbnd after
+    the energy terms and ccbnd as ForceBondedTerms consumes it in local index order (pot.F90:113-144), residents and ghosts"""
+    n = len(o.gids())
+    cnt, pg, bo = e.bonds()
+    onbr, obo = o.bonds()
+    gidG = o.get(106).astype(np.int64)
+    compare_bond_order_taps(dict(deltap=e.debug(1), delta=e.debug(0), cd=e.debug(8), cc=e.debug(10), cnt=cnt, pg=pg, bo=bo),
+                            dict(deltap=o.get(102), delta=o.get(101), cd=o.get(110), cc=o.get(109), cnt=o.get(103)[:n], nbr=onbr[:n], bo=obo[:n], gidG=gidG,
+                                 pos=o.get(100, width=3)), n, np.asarray(e.lattice[:3]))
+
+
+def compare_bond_order_taps(E, O, n, box, rtol=1e-10):
+    """E: the engine's taps, O: the oracle's.  Tolerance 1e-10, not 1e-12: the reference sends ALL positions through normalised coordinates and
+    back in every COPYATOMS call (comm.F90:222-227,260-264; two calls per CG iteration), which moves them by ~1e-12 A before FORCE sees
+    them; the engine keeps the residents where they are.  1e-12 A x d(BO')/dr of a few per A = the 1e-11 measured on delta'."""
+    gidG = O["gidG"]
+    for k in ("deltap", "delta", "cd"):
+        assert np.abs(E[k] - O[k]).max() <= rtol * max(np.abs(O[k]).max(), 1.0), k
+    cnt = E["cnt"]
+    assert np.array_equal(cnt, O["cnt"].astype(cnt.dtype))
+    for i in range(n):
+        c = int(cnt[i])
+        ge, go = E["pg"][i, :c], gidG[O["nbr"][i, :c] - 1]
+        ie, io = np.lexsort((E["bo"][i, :c], ge)), np.lexsort((O["bo"][i, :c], go))      # an atom can be bonded to two images of one partner in a one-cell box
+        assert np.array_equal(ge[ie], go[io])
+        assert np.abs(E["bo"][i, :c][ie] - O["bo"][i, :c][io]).max(initial=0.0) <= rtol
+    # ccbnd.  The reference evaluates a torsion i-j-k-l once, from the centre atom with the smaller gid, and scatters the coefficient of the
+    # far bond k-l to WHICHEVER IMAGES of k and l that centre atom sees (pot.F90:1188-1215 -> ForceB); the engine books the far bond from k's
+    # own visit of the torsion, i.e. on the image of k that is a centre atom there (DESIGN.md 4).  Forces are linear in ccbnd and
+    # translation invariant, so after the CPBK fold both give the same forces, but per INDEX the two differ for atoms whose torsions cross
+    # the box.  What must agree: ccbnd summed over the images of an atom, and ccbnd per index for atoms deeper inside the box than any
+    # torsion reaches (3 bonds < 12 A) -- none in the boxes of 1-2 cut-offs, most of a 36k-atom box.
+    G = len(gidG)
+    scale = max(np.abs(O["cc"]).max(), 1.0)
+    se = np.bincount(gidG, weights=E["cc"][:G]); so = np.bincount(gidG, weights=O["cc"][:G])
+    assert np.abs(se - so).max() <= 1e-9 * scale
+    depth = np.minimum(O["pos"][:n], box - O["pos"][:n]).min(axis=1)
+    deep = depth > 12.0
+    if deep.any():
+        assert np.abs(E["cc"][:n][deep] - O["cc"][:n][deep]).max() <= 1e-9 * scale
+    return int(deep.sum())
 
 
 @pytest.mark.parametrize("case,npz", [("rdx168", "rdx168_tight"), ("rdx222", "rdx222_tight"), ("ice644", "ice644_tight")])
