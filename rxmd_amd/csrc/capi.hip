@@ -12,7 +12,7 @@
 
 #include "engine.h"
 
-namespace rxmd { double stream_probe_ms(Engine &e, int blocks); }
+namespace rxmd { double stream_probe_ms(Engine &e, int blocks); double ring_probe_ms(Engine &e, int reps); }
 using rxmd::Engine;
 using rxmd::EngineError;
 
@@ -465,6 +465,7 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
         for (int g = 0; g < 4; ++g) { out[2 * g] = rxmd::stream_probe_ms(e, grids[g]); out[2 * g + 1] = static_cast<double>(e.rows10) * e.S10 * 8.0; }
         n = 8; break;
       }
+      case 101: n = 1; if (capacity < 1) throw EngineError(RXMD_E_ARG, "capacity"); out[0] = rxmd::ring_probe_ms(e, 10); break;   // ring matrix pass alone (experiments)
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");
     }
   });

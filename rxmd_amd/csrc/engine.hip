@@ -97,6 +97,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw EngineError(RXMD_E_HIP, "no HIP device visible: this engine has no CPU path");
   RX_HIP(hipSetDevice(cfg.device));
+  { hipDeviceProp_t pr; RX_HIP(hipGetDeviceProperties(&pr, cfg.device)); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
   RX_HIP(hipStreamCreate(&stream));
   if (std::getenv("RXMD_SINGLE_STREAM")) comm_stream = stream;   // diagnostic: the halo work queues on the main stream (no second hardware queue)
   else {                                         // highest priority: pack / send-recv / unpack kernels of a halo go ahead of the queued compute workgroups
@@ -335,6 +336,7 @@ void Engine::free_device() {
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(rows_int); dfree(rows_bnd);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
+  for (int k = 0; k < 3; ++k) { if (rsched[k]) (void)hipFree(rsched[k]); rsched[k] = nullptr; }
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
@@ -1140,6 +1142,7 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     build_list10();
     check_device_error("list build");
   }
+  max_row10 = h_err[3];                             // longest 10 A row of this build (k_list10)
   st.ms_lists += toc(0, 1);
   lists_valid = true;
 }

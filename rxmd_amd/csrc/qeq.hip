@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace rxmd {
 
@@ -150,6 +151,330 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
   block_store_partials<4>(acc, partials + static_cast<size_t>(pbase) * 4, 4);
 }
 
+// ---- the matrix pass as a packed stream through an LDS ring (LDS-DMA) ---------------------------------------------------------
+// One persistent workgroup per CU owns a contiguous range of rows.  Wave 0 (the LOADER) streams the used part of consecutive rows --
+// hessian values, packed entries, PQEq: shell-core values -- from their ELL slots straight into LDS rings with
+// `global_load_lds_dwordx4 ... nt` (16 B per lane, 1 KiB per instruction, no VGPR destination; the per-lane SOURCE address skips the unused
+// tail of every slot, the LDS destination is base + lane * 16, so the rows lie packed end to end in the ring).  Waves 1..C (the CONSUMERS)
+// take the rows round-robin: wait until their row has landed, read entry + value from LDS, gather (hs,ht) / (qs,qt) from the
+// cell-sorted copy, FMA, reduce, run the row tail.  What this removes from the wavefront-per-row kernel above: a million wavefront
+// launches per pass, the row length as a dependent round trip in front of every row's loads, and the cap that VGPR-staged loads put on
+// the bytes a CU keeps in flight (here: what the ring holds; the loader runs up to RING_V instructions = RING_V KiB ahead of the last
+// row it has published).  One partial sum per workgroup (<= #CUs) instead of one per sixteen rows.
+//   protocol (all in LDS): tab[t & 63] = (row, ring position, length) written by the loader before it issues row t of its sequence;
+//   `landed` = number of rows whose data is in LDS (the loader counts its DMA instructions; after `s_waitcnt vmcnt(V)` all but the V
+//   youngest have landed); crow[c] = sequence number of the oldest row consumer c still needs -- the loader re-uses ring space
+//   behind min_c crow[c].  A row never wraps: when it does not fit before the ring's end it starts at 0.
+//   Before the loader waits for space it drains its DMAs and publishes everything it has issued (no consumer can then wait for a row
+//   that only further issues would publish).  One row always fits (host: S10 <= R), so the oldest row in flight is always processed.
+#ifndef RING_V_DEF
+#define RING_V_DEF 48
+#endif
+constexpr int RING_V = RING_V_DEF;            // DMA instructions the loader leaves in flight behind its publication point (vmcnt is 6 bits)
+constexpr int RING_NL = 1;            // loader waves per workgroup: each issues every other DMA instruction of a row (measured: a second loader per workgroup does not raise the stream rate, 1.05 against 0.92 ms for the bare stream -- two workgroups per CU with one loader each do)
+constexpr int RING_MAXC = 16 - RING_NL;   // consumer waves (with the loaders: 16 waves = the 1024-thread workgroup limit)
+struct RingCtl { int landed[RING_NL]; int pad_[16 - RING_NL]; int crow[16]; int tab[64 * 4]; double acc[16][4]; double chi[16], eta[16], Zpq[16]; double res[16][6]; int resrow[16]; };   // chi/eta/Z per atom type: the row tail reads LDS, not a type -> parameter chain in HBM
+
+__device__ inline void glds16_nt(const void *gsrc, unsigned lds_byte_addr) {   // M0 = LDS destination of lane 0; written in the statement that reads it
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+// NI consecutive LDS-DMA instructions of one stream of one row: global source = sbase + voff (SGPR base + 32-bit lane offset, lane * 16)
+// + 1024 * k, LDS destination = M0 + lane * 16 + 1024 * k (the immediate offset moves BOTH addresses: scripts/micro/glds_offset.hip),
+// EXEC of instruction k = the first min(max(cnt - 64 k, 0), 64) lanes.  Seven scalar instructions and one DMA per KiB, no vector ALU;
+// the caller runs with all lanes on.  An instruction whose EXEC is 0 moves nothing and still counts in vmcnt.
+#ifndef RING_DMA_POLICY
+#define RING_DMA_POLICY "nt"       // cache policy bits of the stream's DMA instructions (experiments: -DRING_DMA_POLICY='"sc1 nt"')
+#endif
+#define RX_GLDS_STEP(OFF)                                                                                                      \
+  "s_max_i32 %[t], %[c], 0\n\ts_bfm_b64 exec, %[t], 0\n\ts_cmp_gt_i32 %[t], 63\n\ts_cmov_b64 exec, -1\n\t"                      \
+  "global_load_lds_dwordx4 %[v], %[sb] offset:" #OFF " " RING_DMA_POLICY "\n\ts_sub_i32 %[c], %[c], 64\n\t"
+template <int NI>
+__device__ inline void glds16_nt_group(unsigned voff, const void *sbase, unsigned lds_byte_addr, int cnt) {
+  static_assert(NI >= 1 && NI <= 4, "the immediate offset has 13 bits");
+  int t;
+  if (NI == 4) asm volatile("s_mov_b32 m0, %[dst]\n\t" RX_GLDS_STEP(0) RX_GLDS_STEP(1024) RX_GLDS_STEP(2048) RX_GLDS_STEP(3072) "s_mov_b64 exec, -1"
+                            : [t] "=&s"(t), [c] "+s"(cnt) : [v] "v"(voff), [sb] "s"(sbase), [dst] "s"(lds_byte_addr) : "memory", "scc");
+  if (NI == 3) asm volatile("s_mov_b32 m0, %[dst]\n\t" RX_GLDS_STEP(0) RX_GLDS_STEP(1024) RX_GLDS_STEP(2048) "s_mov_b64 exec, -1"
+                            : [t] "=&s"(t), [c] "+s"(cnt) : [v] "v"(voff), [sb] "s"(sbase), [dst] "s"(lds_byte_addr) : "memory", "scc");
+  if (NI == 2) asm volatile("s_mov_b32 m0, %[dst]\n\t" RX_GLDS_STEP(0) RX_GLDS_STEP(1024) "s_mov_b64 exec, -1"
+                            : [t] "=&s"(t), [c] "+s"(cnt) : [v] "v"(voff), [sb] "s"(sbase), [dst] "s"(lds_byte_addr) : "memory", "scc");
+  if (NI == 1) asm volatile("s_mov_b32 m0, %[dst]\n\t" RX_GLDS_STEP(0) "s_mov_b64 exec, -1"
+                            : [t] "=&s"(t), [c] "+s"(cnt) : [v] "v"(voff), [sb] "s"(sbase), [dst] "s"(lds_byte_addr) : "memory", "scc");
+}
+template <class F, int... I> __device__ inline void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ inline void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }   // f(integral_constant<0>) ... f(integral_constant<N-1>)
+__device__ inline unsigned lds_offset(const void *p) { return __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>(p))); }   // low 32 bits of a flat LDS address
+__device__ inline int wave_min_int(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Which rows a workgroup of the ring pass streams.  contiguous: workgroup w takes rows [w * per, (w + 1) * per).  cyclic (default when
+// the grid is a multiple of 8): the 8 XCDs each own a contiguous eighth of the rows -- the gather vector of an XCD stays in its own L2 --
+// and inside an XCD's range the rows go round-robin over its workgroups, so that at any moment the XCD reads ONE advancing window of the
+// matrix (q consecutive rows) instead of q streams far apart: DRAM sees 8 sequential streams, not 512.
+__host__ __device__ inline int ring_rows_per_wg(int nrows, int nwg) { return (nrows + nwg - 1) / nwg + 1; }
+__host__ __device__ inline int ring_rows_of_wg(int nrows, int nwg, int w, int cyclic) {
+  if (!cyclic) { const int per = (nrows + nwg - 1) / nwg; const int i0 = min(nrows, w * per); return min(nrows, i0 + per) - i0; }
+  const int q = nwg >> 3, x = w / q, j = w - x * q;
+  const int gb = static_cast<int>(static_cast<long long>(nrows) * x / 8), ge = static_cast<int>(static_cast<long long>(nrows) * (x + 1) / 8);
+  return ge - gb > j ? (ge - gb - j + q - 1) / q : 0;
+}
+__global__ void __launch_bounds__(256) k_ring_schedule(int nrows, int nwg, int cyclic, const int *__restrict__ rowlist, const int *__restrict__ n10, int2 *__restrict__ sched) {
+  const int per = ring_rows_per_wg(nrows, nwg);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nwg * per) return;
+  const int w = idx / per, k = idx - w * per;
+  int2 o = make_int2(0, 0);
+  if (k < ring_rows_of_wg(nrows, nwg, w, cyclic)) {
+    int i;
+    if (!cyclic) i = w * ((nrows + nwg - 1) / nwg) + k;
+    else { const int q = nwg >> 3, x = w / q, j = w - x * q; i = static_cast<int>(static_cast<long long>(nrows) * x / 8) + j + q * k; }
+    const int row = rowlist ? rowlist[i] : i;
+    o = make_int2(row, n10[row]);
+  }
+  sched[idx] = o;
+}
+template <int MODE, bool STORE, bool PQ, int KH>     // KH: value-stream DMA instructions per row = rows of up to 128 * KH entries
+__global__ void __launch_bounds__(1024, 8) k_spmv_ring(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
+                                                    const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
+                                                    const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
+                                                    const double *__restrict__ scal, double *__restrict__ partials,
+                                                    double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
+                                                    const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
+                                                    const int2 *__restrict__ sched, int sched_cyclic, int nrows, int pbase, int R, int C) {
+  extern __shared__ __attribute__((aligned(16))) char ring_smem[];
+  double *hring = reinterpret_cast<double *>(ring_smem);
+  double *cring = hring + (PQ ? R : 0);
+  int *iring = reinterpret_cast<int *>(hring + (PQ ? 2 : 1) * static_cast<size_t>(R));
+  RingCtl *ctl = reinterpret_cast<RingCtl *>(iring + R);
+  // flags: relaxed workgroup-scope atomics = plain ds_read / ds_write (a `volatile` access is not given its address space back and
+  // becomes a flat system-scope load behind s_waitcnt vmcnt(0) lgkmcnt(0): the consumer would wait for its own global stores)
+  auto flag_load = [](const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto flag_store = [](int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int probe = swz >> 8;     // timing experiments only (RXMD_RING_PROBE): 1 consumers only release, 2 no gathers, 3 no DMA
+  swz &= 0xff;
+  const int wg = swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x);
+  // rows of this workgroup: entries [wg * per, wg * per + total) of the schedule (k_ring_schedule): (row, length) pairs in the order it streams them
+  const int per = ring_rows_per_wg(nrows, gridDim.x);
+  const int total = ring_rows_of_wg(nrows, gridDim.x, wg, sched_cyclic);
+  const int2 *__restrict__ my = sched + static_cast<size_t>(wg) * per;
+  if (threadIdx.x < RING_NL) ctl->landed[threadIdx.x] = 0;
+  if (threadIdx.x < 16) ctl->crow[threadIdx.x] = static_cast<int>(threadIdx.x) < C ? static_cast<int>(threadIdx.x) : 0x7fffffff;
+  if (threadIdx.x < 64) { ctl->acc[threadIdx.x >> 2][threadIdx.x & 3] = 0.0; }
+  if (threadIdx.x >= 64 && threadIdx.x < 80) {
+    const int ty = threadIdx.x - 64;
+    const bool has = ty <= ff.nso;
+    ctl->chi[ty] = has ? ff.atom[ty].chi : 0.0; ctl->eta[ty] = has ? ff.atom[ty].eta : 0.0; ctl->Zpq[ty] = (PQ && has) ? ff.Zpq[ty] : 0.0;
+  }
+  __syncthreads();
+  if (wv < RING_NL) {
+    // ---------------- loaders ----------------
+    // A lone wave issues an instruction every 8-10 cycles at best (branches cost a refill), and the budget is ~500 cycles per row: the loop
+    // is straight-line.  Every row takes exactly KH + KI (+ KH) DMA instructions whatever its length -- instruction k of a stream runs
+    // with EXEC = the granules the row has left for it, possibly none (an instruction with EXEC = 0 still counts in vmcnt and retires at
+    // once) -- so the row whose data has landed follows from the instruction count alone: after s_waitcnt vmcnt(RING_V) all rows but the
+    // youngest RING_V / K are in LDS.  Ring space is tracked in VIRTUAL (never wrapping) positions: a row occupies [vs, vs + n4), the tail
+    // skipped at a wrap counts as occupied, and a row fits while vs + n4 <= vstart(oldest row in use) + R.
+    __builtin_amdgcn_s_setprio(3);
+    // Two loader waves (on different SIMDs) run the same bookkeeping and take alternate instructions of every row; each publishes the rows
+    // ITS instructions have landed, a consumer waits for both.
+    constexpr bool PQS = PQ && (MODE == MODE_GRAD || STORE);
+    constexpr int KS = (PQS ? 2 * KH + KH / 2 : KH + KH / 2) / RING_NL;   // DMA instructions per row and loader
+    constexpr int LAG = (RING_V + KS - 1) / KS;             // rows behind the newest issue that s_waitcnt vmcnt(LAG * KS) guarantees
+    static_assert(((PQS ? 2 * KH + KH / 2 : KH + KH / 2) % RING_NL) == 0, "instructions per row must split evenly over the loaders");
+    const int role = wv;
+    const unsigned hbase = lds_offset(hring), cbase = lds_offset(cring), ibase = lds_offset(iring);
+    int cur = 0, vcur = 0, t = 0, tail = 0, vlimit = R;
+    int h_vs = 0;                                   // per-lane history: lane (t & 63) holds the virtual start of row t
+    int2 nxt = make_int2(0, 0);
+    if (total > 0) nxt = my[0];
+    for (int i = 0; i < total; ++i) {
+      const int row = __builtin_amdgcn_readfirstlane(nxt.x), n = __builtin_amdgcn_readfirstlane(nxt.y);
+      if (i + 1 < total) nxt = my[i + 1];           // contiguous per workgroup: scalar loads that stay in the scalar cache
+      const int n4 = max(4, (n + 3) & ~3);          // an empty row still owns a granule: ring positions stay distinct
+      if (cur + n4 > R) { vcur += R - cur; cur = 0; }
+      const int rp = cur, vs = vcur;
+      if (vs + n4 > vlimit || t - tail >= 64) {     // slow path: find out how far the consumers have come
+        bool drained = false;
+        for (;;) {
+          const int cr = lane < C ? flag_load(&ctl->crow[lane]) : 0x7fffffff;
+          tail = __builtin_amdgcn_readfirstlane(min(t, wave_min_int(cr)));
+          vlimit = (tail < t ? __builtin_amdgcn_readlane(h_vs, tail & 63) : vs) + R;
+          if (vs + n4 <= vlimit && t - tail < 64) break;
+          if (!drained) {                           // nothing a consumer waits for may depend on further issues
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) flag_store(&ctl->landed[role], t);
+            drained = true;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (lane == 0 && role == 0) *reinterpret_cast<int4 *>(&ctl->tab[(t & 63) * 4]) = make_int4(row, rp, n, 0);
+      if (lane == (t & 63)) h_vs = vs;
+      if (probe != 3) {
+        const size_t base = static_cast<size_t>(row) * S10;
+        const int gh = n > 0 ? n4 >> 1 : 0, gi = n > 0 ? n4 >> 2 : 0;      // 16-byte granules of the value / entry streams
+        const unsigned voff = static_cast<unsigned>(lane) * 16u;
+        // value stream: KH instructions of 128 entries; (PQEq) the same for the shell-core values; entry words: KH / 2 instructions of 256
+        static_assert(RING_NL == 1, "the grouped issue is written for one loader per workgroup");
+#pragma unroll
+        for (int g = 0; g < KH; g += 4) glds16_nt_group<4>(voff, hess + base + 128 * g, hbase + static_cast<unsigned>(rp + 128 * g) * 8u, gh - 64 * g);
+        if (PQS) {
+#pragma unroll
+          for (int g = 0; g < KH; g += 4) glds16_nt_group<4>(voff, hsc + base + 128 * g, cbase + static_cast<unsigned>(rp + 128 * g) * 8u, gh - 64 * g);
+        }
+#pragma unroll
+        for (int g = 0; g < KH / 2; g += 4) glds16_nt_group<(KH / 2 >= 4 ? 4 : KH / 2)>(voff, nb10 + base + 256 * g, ibase + static_cast<unsigned>(rp + 256 * g) * 4u, gi - 64 * g);
+      }
+      cur += n4; vcur += n4; ++t;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LAG * KS) : "memory");
+      if (lane == 0) flag_store(&ctl->landed[role], max(0, t - LAG));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) flag_store(&ctl->landed[role], t);
+  } else if (wv < RING_NL + C) {
+    // ---------------- consumer ----------------
+    const int c = wv - RING_NL;
+    // The results of a row wait in LDS (ctl->res) and go to HBM only after the NEXT row's gathers are in flight: a store issued at the end
+    // of its own row would have to complete before the next row may overwrite the registers it reads (s_waitcnt vmcnt(0) at the loop
+    // head).  The four running sums of the consumer live in LDS as well (ctl->acc, ds_add_f64): the kernel has to fit 64 VGPRs.
+    if (lane == 0) ctl->resrow[c] = -1;
+    auto flush = [&]() {
+      if (lane == 0) {
+        const int st_row = ctl->resrow[c];
+        if (st_row >= 0) {
+          const double2 ra = make_double2(ctl->res[c][0], ctl->res[c][1]), rb = make_double2(ctl->res[c][2], ctl->res[c][3]);
+          if (MODE == MODE_HSH) { if (STORE) { rs_all[st_row] = ra; rs_gh[st_row] = rb; } }
+          else { gst[st_row] = ra; if (STORE) { rs_all[st_row] = rb; rs_gh[st_row] = make_double2(ctl->res[c][4], ctl->res[c][5]); } }
+        }
+      }
+    };
+    auto acc_add = [&](int k, double v) { __hip_atomic_fetch_add(&ctl->acc[c][k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    for (int t = c; t < total; t += C) {
+      for (;;) {
+        int l = flag_load(&ctl->landed[0]);
+#pragma unroll
+        for (int r = 1; r < RING_NL; ++r) l = min(l, flag_load(&ctl->landed[r]));
+        if (l > t) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+      const int4 te = *reinterpret_cast<const int4 *>(&ctl->tab[(t & 63) * 4]);
+      const int row = __builtin_amdgcn_readfirstlane(te.x), rp = __builtin_amdgcn_readfirstlane(te.y), n = __builtin_amdgcn_readfirstlane(te.z);
+      const int n4 = (n + 3) & ~3;
+      if (probe == 1) { if (lane == 0) flag_store(&ctl->crow[c], t + C); continue; }
+      int rowv = row;                               // the row index as a VGPR: tail operands come by VECTOR loads (as scalar loads they would
+      asm volatile("" : "+v"(rowv));                // share lgkmcnt with the LDS reads, and scalar loads return out of order)
+      double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+      int pf_t = 0;
+      double2 pf_a = make_double2(0.0, 0.0), pf_b = make_double2(0.0, 0.0);
+      double4 pf_pq = make_double4(0.0, 0.0, 0.0, 0.0);
+      // One SECTION = up to 512 entries of the row (all of an RDX row).  Order: every LDS read of the section; the ring space is released as
+      // soon as the last section's values sit in registers (the loader refills it while this row is still gathering); gathers in two groups of
+      // four; the stores of the PREVIOUS row and the tail operands of this one are queued behind the first group -- vmcnt counts in order,
+      // so nothing the arithmetic waits for stands behind an HBM round trip.
+      for (int kb = 0; kb < n4 || kb == 0; kb += 512) {
+        unsigned e[8];
+        double h[8], cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = kb + 64 * u + lane;
+          const bool ok = k < n4;
+          e[u] = ok ? static_cast<unsigned>(iring[rp + k]) : 0u;
+          h[u] = ok ? hring[rp + k] : 0.0;
+          if (PQ && (MODE == MODE_GRAD || STORE)) cv[u] = ok ? cring[rp + k] : 0.0;
+        }
+        const bool last = kb + 512 >= n4;
+        if (last) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) flag_store(&ctl->crow[c], t + C); }
+        auto group = [&](auto u0c) {
+          constexpr int U0 = decltype(u0c)::value;
+          double2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = xv[probe == 2 ? (lane & 15) : (e[U0 + u] & NB10_IDX_MASK)];
+          if (U0 == 0 && kb == 0) {
+            asm volatile("" ::: "memory");
+            flush();
+            pf_t = type[rowv];
+            pf_a = (MODE == MODE_HSH) ? hst[rowv] : qst[rowv];
+            pf_b = (MODE == MODE_HSH) ? gst[rowv] : make_double2(q[rowv], 0.0);
+            if (PQ && MODE == MODE_GRAD) pf_pq = pqrow[rowv];
+            asm volatile("" ::: "memory");
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double hh = h[U0 + u];
+            as += hh * v[u].x;
+            at += hh * v[u].y;
+            if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[U0 + u] & NB10_GHOST) ? hh : 0.0; gs_ += hg * v[u].x; gt_ += hg * v[u].y; }
+            if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += cv[U0 + u] * v[u].x; gt_ += cv[U0 + u] * v[u].y; }
+          }
+        };
+        group(std::integral_constant<int, 0>{});
+        if (kb + 256 < n4) group(std::integral_constant<int, 4>{});
+      }
+      const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
+      as = wave_sum(as); at = wave_sum(at);
+      if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+      const double chi_i = ctl->chi[pf_t], eta_i = ctl->eta[pf_t];
+      if (lane == 0) {
+        ctl->resrow[c] = row;
+        if (MODE == MODE_HSH) {
+          ctl->res[c][0] = as; ctl->res[c][1] = at; ctl->res[c][2] = gs_; ctl->res[c][3] = gt_;
+          const double ts = eta_i * pf_a.x + as, tt = eta_i * pf_a.y + at;        // qeq.F90:294-302
+          acc_add(0, ts * pf_a.x); acc_add(1, tt * pf_a.y);                       // hshs_sum, hsht_sum (:309-310)
+          acc_add(2, pf_b.x * pf_a.x); acc_add(3, pf_b.y * pf_a.y);               // g.h (:119,123)
+        } else {
+          const double fpq = PQ ? pf_pq.x : 0.0;
+          const double g1 = -chi_i - eta_i * pf_a.x - as - fpq;                   // qeq.F90:349-350 (pqeq.F90:466)
+          const double g2 = -1.0 - eta_i * pf_a.y - at;
+          ctl->res[c][0] = g1; ctl->res[c][1] = g2; ctl->res[c][2] = as; ctl->res[c][3] = at; ctl->res[c][4] = gs_; ctl->res[c][5] = gt_;
+          acc_add(0, g1 * g1); acc_add(1, g2 * g2);                               // Gnew (:355-356)
+          const double qi = pf_b.x;
+          const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+          if (PQ) { DevAtomP ap; ap.chi = chi_i; ap.eta = eta_i; acc_add(2, pq_est_row(ap, ctl->Zpq[pf_t], pf_pq, qi, hq_all, gs_ - mu * gt_)); }
+          else acc_add(2, chi_i * qi + 0.5 * eta_i * qi * qi + 0.5 * qi * (hq_all + hq_res));  // Est (:297-306)
+        }
+      }
+    }
+    flush();
+    if (lane == 0) flag_store(&ctl->crow[c], 0x7fffffff);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {                            // the workgroup's partial: its consumers in order (fixed summation order)
+    double s = 0.0;
+    for (int k = 0; k < C; ++k) s += ctl->acc[k][threadIdx.x];
+    __hip_atomic_store(partials + (static_cast<size_t>(pbase) + wg) * 4 + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// timing probe of the ring pass in isolation (debug tap 101; experiments only): env RXMD_RING_PROBE / _R / _C / _WG as in Engine::qeq.
+// Writes the scratch row sums wall / wgh and the partials only; returns the average launch time.
+double ring_probe_ms(Engine &e, int reps) {
+  auto geti = [](const char *k, int d) { const char *v = std::getenv(k); return v ? std::atoi(v) : d; };
+  const int probe = geti("RXMD_RING_PROBE", 0), R = geti("RXMD_RING_R", 6144) & ~63, C = std::max(1, std::min(RING_MAXC, geti("RXMD_RING_C", RING_MAXC)));
+  const int wgs = geti("RXMD_RING_WG", 2 * e.num_cu);
+  const size_t lds = static_cast<size_t>(R) * 12 + sizeof(RingCtl);
+  if (e.ff.pqeq || e.max_row10 > 512 || e.max_row10 > R || lds > 160 * 1024) return -1.0;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring<MODE_HSH, true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int nwg = std::max(1, std::min(wgs, e.N / (2 * C)));
+  const int cyclic = (geti("RXMD_RING_CYCLIC", 1) && nwg >= 8 && (nwg & 7) == 0) ? 1 : 0;
+  if (!e.rsched[0]) hipMalloc(reinterpret_cast<void **>(&e.rsched[0]), sizeof(int2) * (static_cast<size_t>(e.rows10) + 2 * 4096 + 64));
+  k_ring_schedule<<<nblk(nwg * ring_rows_per_wg(e.N, nwg), 256), 256, 0, e.stream>>>(e.N, nwg, cyclic, nullptr, e.n10, e.rsched[0]);
+  e.rsched_valid[0] = false;                      // the next real pass rebuilds its own
+  for (int r = 0; r < reps + 1; ++r) {
+    if (r == 1) hipEventRecord(e.ev[2], e.stream);
+    k_spmv_ring<MODE_HSH, true, false, 4><<<nwg, 64 * (C + RING_NL), lds, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh,
+                                                                           e.hsc, e.pqrow, 1 | (probe << 8), e.rsched[0], cyclic, e.N, 0, R, C);
+  }
+  hipEventRecord(e.ev[3], e.stream);
+  hipEventSynchronize(e.ev[3]);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
+  return ms / reps;
+}
 // bandwidth probe (debug tap 100): plain 16-byte-per-lane grid-stride read of the matrix value array; gives the
 // read ceiling of the box the roofline fraction is quoted next to
 __global__ void __launch_bounds__(256) k_stream_probe(size_t n16, const f64x2 *__restrict__ a, double *__restrict__ out) {
@@ -438,13 +763,52 @@ void Engine::qeq() {
   // the update kernel finishes its own reduction (last workgroup: one set of partials per workgroup, then the scalar algebra): with one
   // workgroup per CU that tail is short -- 45.8 / 39.3 / 33.8 / 32.6 us per launch at 2048 / 1024 / 512 / 256 workgroups, 68 at 4096
   const int vb_upd = std::min(nblk(N, 256), 256);
-  const int nred = rb;                                                             // partials one matrix pass leaves
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
   const bool pipe = (std::getenv("RXMD_SPMV_NO_PIPE") == nullptr);        // read per call: the tests switch it
-  auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) {
+  // the ring kernel (k_spmv_ring): one persistent workgroup per CU.  RXMD_SPMV_RING=0 keeps the wavefront-per-row kernel (which also serves
+  // small systems -- a persistent launch has nothing to stream there -- and rows that would not fit the ring)
+  static const int ring_env = std::getenv("RXMD_SPMV_RING") ? std::atoi(std::getenv("RXMD_SPMV_RING")) : 1;
+  static const int ring_R_env = std::getenv("RXMD_RING_R") ? std::atoi(std::getenv("RXMD_RING_R")) : 0;
+  static const int ring_C = std::getenv("RXMD_RING_C") ? std::max(1, std::min(RING_MAXC, std::atoi(std::getenv("RXMD_RING_C")))) : RING_MAXC;
+  static const int ring_min_rows = std::getenv("RXMD_RING_MIN_ROWS") ? std::atoi(std::getenv("RXMD_RING_MIN_ROWS")) : 16384;
+  static const int ring_wg_env = std::getenv("RXMD_RING_WG") ? std::atoi(std::getenv("RXMD_RING_WG")) : 0;
+  static const int ring_cyclic = std::getenv("RXMD_RING_CYCLIC") ? std::atoi(std::getenv("RXMD_RING_CYCLIC")) : 1;
+  static const int ring_probe = std::getenv("RXMD_RING_PROBE") ? std::atoi(std::getenv("RXMD_RING_PROBE")) : 0;
+  const int ring_R = ring_R_env > 0 ? (ring_R_env & ~63) : (ff.pqeq ? 3584 : 6144);        // ring entries of 12 (PQEq: 20) bytes: with the control block < 80 KB, two workgroups per CU
+  const size_t ring_lds = static_cast<size_t>(ring_R) * (ff.pqeq ? 20 : 12) + sizeof(RingCtl);
+  const int ring_wgs = ring_wg_env > 0 ? ring_wg_env : 2 * num_cu;
+  // returns the number of partial-sum sets (of four) the launch leaves behind partials[pbase * 4]
+  auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) -> int {
+    const int nr = rowlist ? nrows : N;
+    if (ring_env && max_row10 <= std::min(ring_R, 1024) && nr >= ring_min_rows && ring_lds <= 160 * 1024 && ff.nso <= 15) {
+      const int nwg = std::max(1, std::min(ring_wgs, nr / (2 * ring_C)));
+      const int cyclic = (ring_cyclic && nwg >= 8 && (nwg & 7) == 0 && swz) ? 1 : 0;
+      const int which = rowlist == nullptr ? 0 : (rowlist == rows_int ? 1 : 2);
+      if (!rsched[which]) RX_HIP(hipMalloc(reinterpret_cast<void **>(&rsched[which]), sizeof(int2) * (static_cast<size_t>(rows10) + 2 * 4096 + 64)));
+      if (!rsched_valid[which]) {                  // once per list build: (row, length) pairs in each workgroup's streaming order
+        const int tot = nwg * ring_rows_per_wg(nr, nwg);
+        k_ring_schedule<<<nblk(tot, 256), 256, 0, stream>>>(nr, nwg, cyclic, rowlist, n10, rsched[which]);
+        rsched_valid[which] = true;
+      }
+      const int2 *sched = rsched[which];
+#define RX_RING4(M, S, P, K)                                                                                                               \
+  do {                                                                                                                                     \
+    static bool attr_set = false;                                                                                                          \
+    if (!attr_set) { RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring<M, S, P, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
+    k_spmv_ring<M, S, P, K><<<nwg, 64 * (ring_C + RING_NL), ring_lds, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz | (ring_probe << 8), sched, cyclic, nr, pbase, ring_R, ring_C); \
+  } while (0)
+#define RX_RING3(M, S, P) do { if (max_row10 <= 512) RX_RING4(M, S, P, 4); else RX_RING4(M, S, P, 8); } while (0)
+#define RX_RING(M, S) do { if (ff.pqeq) RX_RING3(M, S, true); else RX_RING3(M, S, false); } while (0)
+      if (mode == MODE_HSH) { if (store) RX_RING(MODE_HSH, true); else RX_RING(MODE_HSH, false); }
+      else { if (store) RX_RING(MODE_GRAD, true); else RX_RING(MODE_GRAD, false); }
+#undef RX_RING
+#undef RX_RING4
+#undef RX_RING3
+      return nwg;
+    }
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
-    if (rbl == 0) return;
+    if (rbl == 0) return 0;
 #define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase)
 #define RX_PASS(M, S)                                                                                                  \
   do {                                                                                                                 \
@@ -455,6 +819,7 @@ void Engine::qeq() {
     else { if (store) RX_PASS(MODE_GRAD, true); else RX_PASS(MODE_GRAD, false); }
 #undef RX_PASS
 #undef RX_PASS3
+    return rbl;
   };
   auto reduce = [&](int stage, int nb_) {
     if (!multi()) {                              // single rank: level-1 sums, final sum and scalar algebra in one launch
@@ -474,8 +839,8 @@ void Engine::qeq() {
     reduce(3, vb);
   } else {
     qeq_start_vectors();
-    pass(MODE_GRAD, onepass, onepass ? sall : nullptr, onepass ? sgh : nullptr);
-    reduce(3, nred);
+    const int np0 = pass(MODE_GRAD, onepass, onepass ? sall : nullptr, onepass ? sgh : nullptr);
+    reduce(3, np0);
   }
   k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
@@ -495,21 +860,21 @@ void Engine::qeq() {
     if (halo_in_flight) {
       // multi-rank overlap: the (hs,ht) halo of this iteration was started on the second stream right after the direction update;
       // rows without a ghost partner do not need it
-      const int n_int = N - n_bnd, nb_int = nblk(n_int, SPMV_WPB);
+      const int n_int = N - n_bnd;
       hipEventRecord(ev[2], stream);
-      pass(MODE_HSH, onepass, wall, wgh, rows_int, n_int, 0);
+      const int np_int = pass(MODE_HSH, onepass, wall, wgh, rows_int, n_int, 0);
       join_comm_stream();
-      pass(MODE_HSH, onepass, wall, wgh, rows_bnd, n_bnd, nb_int);
+      const int np_bnd = pass(MODE_HSH, onepass, wall, wgh, rows_bnd, n_bnd, np_int);
       hipEventRecord(ev[3], stream);
-      reduce(1, nb_int + nblk(n_bnd, SPMV_WPB));
+      reduce(1, np_int + np_bnd);
       halo_in_flight = false;
     } else {
       if (!xs_current) sorted_copy(hst);                                                         // QCOPY2, qeq.F90:93,164
       xs_current = false;
       hipEventRecord(ev[2], stream);
-      pass(MODE_HSH, onepass, onepass ? wall : nullptr, onepass ? wgh : nullptr);
+      const int np1 = pass(MODE_HSH, onepass, onepass ? wall : nullptr, onepass ? wgh : nullptr);
       hipEventRecord(ev[3], stream);
-      reduce(1, nred);
+      reduce(1, np1);
     }
     if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
       const bool fuse = !multi();                  // single rank: every reduction finishes in-kernel; multi: sums, all-reduce, algebra
@@ -555,9 +920,9 @@ void Engine::qeq() {
     k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);
     sorted_copy(qst);                                                                            // QCOPY1, qeq.F90:153
     hipEventRecord(ev[4], stream);
-    pass(MODE_GRAD, false, nullptr, nullptr);
+    const int np2 = pass(MODE_GRAD, false, nullptr, nullptr);
     hipEventRecord(ev[5], stream);
-    reduce(3, nred);
+    reduce(3, np2);
     k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 0, scal, gst, hst);
     RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
     sync_stream();
