@@ -27,7 +27,13 @@ def _run_reference(exe, gen, mc, nsteps, nthreads):
         subprocess.run([gen, "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", str(mc), str(mc), str(mc)], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
         env = dict(os.environ, OMP_NUM_THREADS=str(nthreads), OMP_STACKSIZE="1G")
         t0 = time.time()
-        p = subprocess.run([exe, "--ntime_step", str(nsteps), "--pstep", "1000", "--fstep", "100000"], cwd=tmp, env=env,
+        def unlimited_stack():                # in the child only: the benchmark process keeps its own limits
+            try:
+                resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+            except Exception:
+                soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
+                resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
+        p = subprocess.run([exe, "--ntime_step", str(nsteps), "--pstep", "1000", "--fstep", "100000"], cwd=tmp, env=env, preexec_fn=unlimited_stack,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         wall = time.time() - t0
         loop = None
@@ -43,35 +49,46 @@ def _run_reference(exe, gen, mc, nsteps, nthreads):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def physical_cores():
+    """physical cores of this host (lscpu: sockets x cores per socket); falls back to the logical count"""
+    try:
+        out = subprocess.run(["lscpu"], stdout=subprocess.PIPE, text=True, timeout=10).stdout
+        kv = {l.split(":")[0].strip(): l.split(":")[1].strip() for l in out.split("\n") if ":" in l}
+        return max(1, int(kv["Socket(s)"]) * int(kv["Core(s) per socket"])), int(kv.get("Thread(s) per core", "1"))
+    except Exception:
+        return os.cpu_count() or 1, 1
+
+
 def cpu_baseline():
-    """Times the REAL reference (oracle/_ref: Fortran + OpenMP, built by oracle/Makefile from the sources where they lie) on the host
-    cores of this box, on bounded samples of the same workload, same rxmd.in:
-      * rxmd_omp_big: the reference with ONLY its compiled-in capacity NBUFFER raised (module.F90:80, `sed` in the ignored build
-        directory), RDX 6x6x6 = 36,288 atoms x 10 MD steps -- the sample the headline comparison uses;
+    """Times the REAL reference (oracle/_ref: Fortran + OpenMP, built by oracle/Makefile from the sources where they lie) on the PHYSICAL
+    host cores of this box (OMP_NUM_THREADS = sockets x cores per socket, lscpu), on bounded samples of the same workload, same rxmd.in:
+      * rxmd_omp_huge: the reference with ONLY its compiled-in capacity NBUFFER raised to 600,000 (module.F90:80), RDX 12x12x12 = 290,304
+        atoms x 5 MD steps -- the sample BASELINE.md 3 plans, and the headline comparison when it ran;
+      * rxmd_omp_big (NBUFFER 150,000): RDX 6x6x6 = 36,288 atoms x 10 MD steps;
       * rxmd_omp: the unmodified reference on the largest cube its NBUFFER = 30000 holds, RDX 3x3x3 = 4,536 atoms x 60 steps
-        (there the NBUFFER-sized overheads dominate) -- reported next to it.
-    Runs BEFORE torch / HIP are initialised in this process (fork of a GPU-initialised, multi-threaded parent is unsafe)."""
+        (there the NBUFFER-sized overheads dominate).
+    Runs BEFORE torch / HIP are initialised in this process (fork of a GPU-initialised, multi-threaded parent is unsafe).  The
+    reference keeps NBUFFER-sized automatic arrays on the stack: the stack limit is raised in the CHILD only (preexec_fn)."""
     ref = os.path.join(ROOT, "oracle", "_ref")
     gen = os.path.join(ref, "geninit")
     if not os.path.exists(gen):
         return None
-    try:                                          # the reference keeps NBUFFER-sized automatic arrays on the stack
-        resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
-    except Exception:
-        try:
-            soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
-            resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
-        except Exception:
-            pass
-    cores = os.cpu_count() or 1
-    nthreads = min(cores, 64)
+    cores, smt = physical_cores()
     full = 168 * ATOMS_PER_GPU_CELLS ** 3
     out, samples = None, []
-    for exe, mc, nsteps, what in ((os.path.join(ref, "rxmd_omp_big"), 6, 10, "USCCACS/RXMD Fortran+OpenMP with NBUFFER raised (oracle/_ref/rxmd_omp_big)"),
-                                  (os.path.join(ref, "rxmd_omp"), 3, 60, "USCCACS/RXMD Fortran+OpenMP unmodified (oracle/_ref/rxmd_omp)")):
+    try:
+        mem_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2 ** 30
+    except Exception:
+        mem_gb = 0
+    plan = []
+    if mem_gb >= 40:                       # NBUFFER 600,000: nbplist + hessian alone are 10.8 GB
+        plan.append((os.path.join(ref, "rxmd_omp_huge"), 12, 5, "USCCACS/RXMD Fortran+OpenMP with NBUFFER raised to 600000 (oracle/_ref/rxmd_omp_huge)"))
+    plan.append((os.path.join(ref, "rxmd_omp_big"), 6, 10, "USCCACS/RXMD Fortran+OpenMP with NBUFFER raised to 150000 (oracle/_ref/rxmd_omp_big)"))
+    plan.append((os.path.join(ref, "rxmd_omp"), 3, 60, "USCCACS/RXMD Fortran+OpenMP unmodified (oracle/_ref/rxmd_omp)"))
+    for exe, mc, nsteps, what in plan:
         if not os.path.exists(exe):
             continue
-        r = _run_reference(exe, gen, mc, nsteps, nthreads)
+        r = _run_reference(exe, gen, mc, nsteps, cores)
         if r is None:
             continue
         atoms, loop, wall = r
@@ -81,11 +98,83 @@ def cpu_baseline():
                "atoms": atoms, "steps": nsteps, "loop_s": loop, "wall_s": wall, "atom_steps_per_s": rate, "value": rate / full}
         samples.append(rec)
         if out is None:
-            out = {"value": rate / full, "unit": "steps/s", "cores": nthreads, "kind": "reference", "sample": rec["sample"],
+            out = {"value": rate / full, "unit": "steps/s", "cores": cores, "threads_per_core_on_host": smt, "kind": "reference", "sample": rec["sample"],
                    "atom_steps_per_s": rate, "wall_s": wall}
     if out is not None and len(samples) > 1:
         out["other_samples"] = samples[1:]
     return out
+
+
+def make_workload(workload, ncells):
+    """(ffield, names, fractional coordinates, lattice, cells per edge per GPU, description, pqeq parameter file) of a BASELINE configuration"""
+    from rxmd_amd import system
+    pqeq = None
+    if workload == "rdx":
+        ff = os.path.join(INP, "ffield_rdx")
+        names, frac, lat = system.read_xyz(os.path.join(INP, "rdx.xyz"))
+        cells = (ncells,) * 3
+        wname = "RDX %dx%dx%d cells per GPU" % cells
+    elif workload == "water":
+        # BASELINE configs[2] / SURVEY 8d C3: conf/init.water/ice-1h.xyz holds REAL coordinates with exactly collinear
+        # O-H...O triples (NaN in the reference, SURVEY 0.5): Gaussian kick sigma 0.02 A, numpy default_rng(12345)
+        import numpy as np
+        ff = os.path.join(INP, "ffield_water")
+        lines = open(os.path.join(INP, "ice-1h_real.xyz")).read().split("\n")
+        n0 = int(lines[0].split()[0]); lat = [float(x) for x in lines[1].split()[:6]]
+        rng = np.random.default_rng(12345)
+        names, frac = [], []
+        for l in lines[2:2 + n0]:
+            e, x, y, z = l.split()[:4]
+            r = np.array([float(x), float(y), float(z)]) + rng.normal(0.0, 0.02, 3)
+            names.append(e); frac.append(r / np.array(lat[:3]))
+        frac = np.array(frac)
+        cells = (60, 35, 40) if ncells == ATOMS_PER_GPU_CELLS else (ncells,) * 3
+        wname = "perturbed ice Ih %dx%dx%d cells per GPU" % cells
+    else:
+        ff = os.path.join(INP, "ffield_sicnp")
+        names, frac, lat = system.read_xyz(os.path.join(INP, "sicnp.xyz"))
+        pqeq = os.path.join(INP, "pqeq_sicnp.in")
+        c = 12 if ncells == ATOMS_PER_GPU_CELLS else ncells
+        cells = (c, c, c)
+        wname = "SiC nanoparticle + O2 (conf/init.sicnp) %dx%dx%d cells per GPU, PQEq" % cells
+    return ff, names, frac, lat, cells, wname, pqeq
+
+
+def pass_bytes(st, pq):
+    """algorithmic bytes of ONE matrix pass: value f64 + column i32 per entry (PQEq: + the shell-core value f64 of pqeq.F90:381-411,
+    streamed by the pass that produces Est) + ~7 vector words per row"""
+    return st["nnz10"] * (20.0 if pq else 12.0) + st["natoms"] * 56.0
+
+
+def compact_leg(workload, ncells, steps, warmup, device, **kw):
+    """one more configuration in the same process, single rank: set-up, QEq + FORCE, warm-up, `steps` timed steps -> a compact record"""
+    import torch, rxmd_amd
+    from rxmd_amd import system
+    ff, names, frac, lat, cells, wname, pqeq = make_workload(workload, ncells)
+    cfg = system.parse_rxmd_in(os.path.join(INP, "rxmd.in"))
+    lat_super, rec = system.geninit(ff, names, frac, lat, mc=cells)
+    ekw = dict(isQEq=cfg["isQEq"], NMAXQEq=cfg["NMAXQEq"], QEq_tol=cfg["QEq_tol"], qstep=cfg["qstep"], dt_fs=cfg["dt"], device=device, qeq_mode=1, pqeq=pqeq)
+    ekw.update(kw)
+    eng = rxmd_amd.RxmdEngine(ff, lat_super, **ekw)
+    try:
+        eng.set_atoms_rxff(rec)
+        eng.QEq(); eng.FORCE(); eng.step(warmup); eng.reset_timers()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.step(steps)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        st = eng.stats()
+        launches = max(st["spmv_launches"], 1)
+        ms_spmv = st["ms_qeq_spmv"] / launches
+        bp = pass_bytes(st, pqeq is not None)
+        ach = bp / (ms_spmv * 1e-3) / 1e9 if ms_spmv > 0 else 0.0
+        return {"workload": "%s = %d atoms, QEq tol %g, dt %g fs" % (wname, len(rec), ekw["QEq_tol"], ekw["dt_fs"]), "isQEq": ekw["isQEq"], "qeq_mode": ekw["qeq_mode"],
+                "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "steps_per_s": steps / dt, "ns_per_day": steps / dt * ekw["dt_fs"] * 86400e-6,
+                "qeq_iters_per_step": st["qeq_iters_total"] / max(st["qeq_calls"], 1), "spmv_launches_per_step": st["spmv_launches"] / steps,
+                "roofline": {"bound": "hbm", "kernel": "k_spmv", "bytes_per_entry": 20 if pqeq else 12, "algorithmic_bytes_per_launch": bp, "avg_launch_ms": ms_spmv, "achieved": ach,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS},
+                "breakdown_ms_per_step": {k: st[k] / steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded")}}
+    finally:
+        eng.close()
 
 
 def vprocs_for(n):
@@ -105,6 +194,7 @@ def main():
                     help="rdx: BASELINE configs[1]/[3] (headline); water: configs[2], perturbed ice Ih 60x35x40 = 2,016,000 atoms; "
                          "sicnp: configs[4], SiC nanoparticle + O2 with PQEq, 547-atom cell replicated --cells (default 12) per edge")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent periodic replicas instead of one decomposed box")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of BASELINE configs[2] (water) and configs[4] (SiC nanoparticle, PQEq) and the isQEq 2 leg")
     a = ap.parse_args()
 
     # the CPU baseline first: rank 0 of a 1-GPU run, before torch / HIP exist in this process
@@ -132,35 +222,7 @@ def main():
             dist.init_process_group(backend)
     vp = vprocs_for(world)
 
-    pqeq = None
-    if a.workload == "rdx":
-        ff = os.path.join(INP, "ffield_rdx")
-        names, frac, lat = system.read_xyz(os.path.join(INP, "rdx.xyz"))
-        cells = (a.cells,) * 3
-        wname = "RDX %dx%dx%d cells per GPU" % cells
-    elif a.workload == "water":
-        # BASELINE configs[2] / SURVEY 8d C3: conf/init.water/ice-1h.xyz holds REAL coordinates with exactly collinear
-        # O-H...O triples (NaN in the reference): Gaussian kick sigma 0.02 A, numpy default_rng(12345)
-        import numpy as np
-        ff = os.path.join(INP, "ffield_water")
-        lines = open(os.path.join(INP, "ice-1h_real.xyz")).read().split("\n")
-        n0 = int(lines[0].split()[0]); lat = [float(x) for x in lines[1].split()[:6]]
-        rng = np.random.default_rng(12345)
-        names, frac = [], []
-        for l in lines[2:2 + n0]:
-            e, x, y, z = l.split()[:4]
-            r = np.array([float(x), float(y), float(z)]) + rng.normal(0.0, 0.02, 3)
-            names.append(e); frac.append(r / np.array(lat[:3]))
-        frac = np.array(frac)
-        cells = (60, 35, 40) if a.cells == ATOMS_PER_GPU_CELLS else (a.cells,) * 3
-        wname = "perturbed ice Ih %dx%dx%d cells per GPU" % cells
-    else:
-        ff = os.path.join(INP, "ffield_sicnp")
-        names, frac, lat = system.read_xyz(os.path.join(INP, "sicnp.xyz"))
-        pqeq = os.path.join(INP, "pqeq_sicnp.in")
-        c = 12 if a.cells == ATOMS_PER_GPU_CELLS else a.cells
-        cells = (c, c, c)
-        wname = "SiC nanoparticle + O2 (conf/init.sicnp) %dx%dx%d cells per GPU, PQEq" % cells
+    ff, names, frac, lat, cells, wname, pqeq = make_workload(a.workload, a.cells)
     mc = tuple(cells[i] * vp[i] for i in range(3))
     cfg = system.parse_rxmd_in(os.path.join(INP, "rxmd.in"))
     # weak scaling (BASELINE configs[3]): the box is cells*vprocs unit cells per edge, every rank owns one domain of the
@@ -248,11 +310,17 @@ def main():
     st = eng.stats()
     en = eng.energy()
     per_rank = None
-    if use_dist:          # every rank's residents, ghosts and CG iterations: a decomposition that silently lost a neighbour shows here
-        mine = torch.tensor([st["natoms"], st["nghost_force"], st["qeq_iters_total"]], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+    if use_dist:          # every rank's residents, ghosts, CG iterations and exchange timers: a decomposition that silently lost a neighbour, or a rank
+        # that waits for its halo, shows here
+        tkeys = ("ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold", "ms_qeq", "ms_force", "ms_lists")
+        mine = torch.tensor([st["natoms"], st["nghost_force"], st["qeq_iters_total"], st["n_boundary_rows"]] + [st[k] / a.steps for k in tkeys],
+                            dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = {"natoms": [int(t[0]) for t in allr], "nghost": [int(t[1]) for t in allr], "qeq_iters_total": [int(t[2]) for t in allr]}
+        per_rank = {"natoms": [int(t[0]) for t in allr], "nghost": [int(t[1]) for t in allr], "qeq_iters_total": [int(t[2]) for t in allr],
+                    "boundary_rows": [int(t[3]) for t in allr]}
+        for j, k in enumerate(tkeys):
+            per_rank[k + "_per_step"] = [round(float(t[4 + j]), 4) for t in allr]
     probe = None
     if world == 1:                               # plain 16-B/lane read of the matrix value array on this very box: the ceiling the pass is quoted next to
         try:
@@ -280,6 +348,22 @@ def main():
                "spmv_launches_per_step": sa["spmv_launches"] / a.steps}
         eng.set_qeq_mode(a.qeq_mode)
 
+    other, alt_lex = None, None
+    if world == 1 and not a.no_other_configs and a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS:
+        eng.close(); eng = None                                   # the 979,776-atom engine gives its memory back first
+        # isQEq = 2 (qeq.F90:51-57, main.F90:67-68,98): the reference's own production mode -- extended-Lagrangian charges, ONE CG step per MD
+        # step; there the non-CG part of the step IS the step
+        try:
+            alt_lex = compact_leg("rdx", ATOMS_PER_GPU_CELLS, a.steps, a.warmup, local, isQEq=2)
+        except Exception as ex:
+            alt_lex = {"error": str(ex)}
+        other = []
+        for w in ("water", "sicnp"):                              # BASELINE configs[2] and configs[4] at their one-GPU sizes
+            try:
+                other.append(compact_leg(w, ATOMS_PER_GPU_CELLS, 8, 2, local))
+            except Exception as ex:
+                other.append({"workload": w, "error": str(ex)})
+
     if rank == 0:
         steps_per_s = a.steps / dt
         n10 = st["nnz10"] / max(st["natoms"], 1)
@@ -288,7 +372,7 @@ def main():
         launches = max(st["spmv_launches"], 1)
         ms_spmv = st["ms_qeq_spmv"] / launches
         # algorithmic bytes of ONE matrix pass (value f64 + column i32 per entry, + ~7 vector words per row)
-        bytes_pass = st["nnz10"] * 12.0 + st["natoms"] * 56.0
+        bytes_pass = pass_bytes(st, pqeq is not None)
         achieved = bytes_pass / (ms_spmv * 1e-3) / 1e9 if ms_spmv > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
@@ -299,13 +383,47 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 pass
+        # (filled below from profiles/kernel_traffic.json when that file is newer)
         # per-atom-step byte models with the measured n10, nb, K:
         #  (i) SURVEY 8d's formula as written: TWO matrix passes per CG iteration (the reference algebra, qeq_mode 0)
         # (ii) the bytes of the passes this run actually launched (qeq_mode 1: one pass per iteration + ~300 B of vector kernels)
         passes = st["spmv_launches"] / a.steps
         b_fixed = n10 * 12 + 40 + n10 * 4 + 64 + nb * 104 * 5
-        b_step_8d = b_fixed + iters * (2 * n10 * 12 + 112)
-        b_step_exec = b_fixed + passes * (n10 * 12 + 56) + iters * (300 if a.qeq_mode == 1 else 112)
+        b_step_exec = b_fixed + passes * (n10 * (20 if pqeq else 12) + 56) + iters * (300 if a.qeq_mode == 1 else 112)
+        # the kernels behind the ~21 ms of a step that are not the matrix pass: HIP-event time per launch (rxmd_stats.ms_k_*), algorithmic bytes
+        # per launch (SURVEY 8d / DESIGN.md 3), PMC bytes per launch where profiles/kernel_traffic.json holds them for this workload
+        ktraffic = {}
+        kfile = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+        if os.path.exists(kfile):
+            try:
+                kj = json.load(open(kfile))
+                if kj.get("natoms") == st["natoms"]:
+                    ktraffic = kj.get("hbm_bytes_per_launch", {})
+            except Exception:
+                pass
+        def traffic_for(*parts):
+            """PMC bytes per launch of the kernels whose names start with one of `parts` (template instances included), summed; None if absent"""
+            hit = [v for k, v in ktraffic.items() if any(k == p_ or k.startswith(p_ + "<") for p_ in parts)]
+            return sum(hit) if hit else None
+        G = st["natoms"] + st["nghost_force"]
+        ncg = max(st["qeq_iters_total"], 1)
+        ms_cg_vec = max(st["ms_qeq"] - st["ms_qeq_spmv"] - st["ms_lists"], 0.0) / ncg       # per CG iteration: update + direction + sorted copy (+ reduction)
+        kdefs = [("k_list10", "ms_k_list10", st["nnz10"] * 12.0 + st["natoms"] * 40.0, a.steps, "10 A sweep: entry + value written once (qeq.F90:183-268, main.F90:420-477)"),
+                 ("k_nonbond", "ms_k_nonbond", st["nnz10"] * 4.0 + st["natoms"] * 64.0, a.steps, "ENbond: the entry stream (pot.F90:676-781)"),
+                 ("k_bo_prime+k_bo_full", "ms_k_bondorder", G * nb * 104.0, a.steps, "BOPRIM + BOFULL over residents and ghosts (bo.F90:28-298)"),
+                 ("k_e3b", "ms_k_e3b", st["natoms"] * nb * 104.0, a.steps, "E3b (pot.F90:319-557): FP64 chains, not bytes, bound it"),
+                 ("k_e4b", "ms_k_e4b", st["natoms"] * nb * 104.0, a.steps, "E4b (pot.F90:980-1227): FP64 chains"),
+                 ("k_ehb", "ms_k_ehb", st["natoms"] * nb * 104.0, a.steps, "Ehb (pot.F90:559-673)"),
+                 ("k_cd_gather+k_ccbnd+k_bond_forces", "ms_k_assemble", G * nb * 104.0, a.steps, "ForceBondedTerms as gathers (pot.F90:113-144)")]
+        kernels = []
+        for name, key, byts, cnt, note in kdefs:
+            ms = st.get(key, 0.0) / max(cnt, 1)
+            ach_k = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": traffic_for(*name.split("+")), "note": note})
+        kernels.append({"name": "CG vector kernels (k_cg_update, k_cg_direction, k_sorted_vec, k_reduce_fused)", "ms": ms_cg_vec, "algorithmic_bytes": st["natoms"] * 300.0,
+                        "achieved_GBs": st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 if ms_cg_vec > 0 else 0.0,
+                        "frac": (st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_cg_vec > 0 else 0.0, "traffic": traffic_for("k_cg_update", "k_cg_direction", "k_sorted_vec", "k_reduce_fused"),
+                        "note": "per CG iteration, everything of qeq() that is neither the matrix pass nor the list build"})
         out = {
             "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; one step advances every GPU's domain: weak scaling, wall-clock steps/s of the whole job)" if a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS
                       else "MD steps/sec (%s, %d atoms/GPU; wall-clock steps/s of the whole job)" % (a.workload, natoms),
@@ -323,10 +441,11 @@ def main():
                          "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"],
                          "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,
                          "spmv_launches_per_step": passes,
+                         "bytes_per_entry": 20 if pqeq else 12,
                          "step_bytes_per_atom_executed": b_step_exec, "step_frac_of_hbm_roofline": (b_step_exec * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9),
-                         "step_bytes_per_atom_survey8d_two_pass_formula": b_step_8d,
-                         "step_frac_survey8d_formula": (b_step_8d * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9)},
-            "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded")},
+                         "kernels": kernels},
+            "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded",
+                                                                    "ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold")},
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
         }
         if per_rank:
@@ -334,13 +453,18 @@ def main():
             out["config"]["ranks_in_communicator"] = world      # rccl_init checks ncclCommCount against the vprocs grid
         if alt:
             out["alt"] = alt
+        if alt_lex:
+            out["alt_lex"] = alt_lex
+        if other:
+            out["other_configs"] = other
         if cb:
             out["cpu_baseline"] = cb
         import ctypes
         ctypes.CDLL(None).fflush(None)          # C-level stdout first (RCCL prints a version banner there): the JSON line stays last
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -113,7 +113,9 @@ int rxmd_hip_minimise(rxmd_handle h, double ftol, int max_loops, double *pe, lon
 /* nstep_qeq of the last QEq call (printed in the MDstep line, src/main.F90:261); negative = error */
 int rxmd_hip_last_qeq_iters(rxmd_handle h);
 /* The velocity scaling the reference's MD loop applies at its head when mod(nstep,sstep)==0 (src/main.F90:45-61), on the
- * device: mdmode 4 (v *= vsfact), 5 (rescale to treq_K; gke_per_atom = kinetic energy per atom of the last PRINTE, <= 0: the
+ * device: mdmode 0 and 6 (INITVELOCITY, src/init.F90:292-360: fresh unit-variance Gaussian velocities for every atom -- a counter-based
+ * generator keyed by the GLOBAL atom id, so the draw does not depend on the decomposition; RXMD_SEED in the environment changes the
+ * stream -- centre-of-mass velocity removed through the all-reduce, scaled to kinetic energy 1.5 treq per atom), 4 (v *= vsfact), 5 (rescale to treq_K; gke_per_atom = kinetic energy per atom of the last PRINTE, <= 0: the
  * current one), 7 (per element, ScaleTemperature :722-763), 8 (only beyond 5 %, AdjustTemperature :684-719); 7 and 8 remove the
  * centre-of-mass momentum afterwards (LinearMomentum :766-797).  The caller keeps the sstep cadence:
  *   for (n = 0; n < nsteps; n += sstep) { rxmd_hip_thermostat(h, mdmode, treq, vsfact, -1); rxmd_hip_step(h, sstep); } */
@@ -159,6 +161,9 @@ typedef struct rxmd_stats {
    * whole halo when overlap is off), scalar all-reduces (qeq.F90:107,129,144,357), reverse force fold (MODE_CPBK) */
   double ms_ghost_build, ms_migrate, ms_halo, ms_halo_exposed, ms_allreduce, ms_fold;
   long long halo_calls, allreduce_calls;
+  /* single kernels, HIP events on the engine's stream around each launch, summed like the timers above (bench.py: roofline.kernels):
+   * the 10 A sweep, ENbond (PQEq: ENbond_PQEq), E3b, E4b, Ehb, BOPRIM + BOFULL, the assembly gathers of ForceBondedTerms */
+  double ms_k_list10, ms_k_nonbond, ms_k_e3b, ms_k_e4b, ms_k_ehb, ms_k_bondorder, ms_k_assemble;
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);

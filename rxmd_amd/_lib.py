@@ -26,7 +26,9 @@ class RxmdStats(C.Structure):
                 ("spmv_launches", C.c_longlong), ("n10_stride", C.c_int), ("nbuffer", C.c_int), ("cells10", C.c_int * 3), ("cells3", C.c_int * 3),
                 ("n_boundary_rows", C.c_int), ("reserved", C.c_int * 7),
                 ("ms_ghost_build", C.c_double), ("ms_migrate", C.c_double), ("ms_halo", C.c_double), ("ms_halo_exposed", C.c_double),
-                ("ms_allreduce", C.c_double), ("ms_fold", C.c_double), ("halo_calls", C.c_longlong), ("allreduce_calls", C.c_longlong)]
+                ("ms_allreduce", C.c_double), ("ms_fold", C.c_double), ("halo_calls", C.c_longlong), ("allreduce_calls", C.c_longlong),
+                ("ms_k_list10", C.c_double), ("ms_k_nonbond", C.c_double), ("ms_k_e3b", C.c_double), ("ms_k_e4b", C.c_double), ("ms_k_ehb", C.c_double),
+                ("ms_k_bondorder", C.c_double), ("ms_k_assemble", C.c_double)]
 
     def asdict(self):
         d = {}

@@ -17,6 +17,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace rxmd {
@@ -147,21 +148,22 @@ void Engine::force() {
   // the ghost-charge halo needs nothing from the bond orders and they need no charges: on a multi-rank run the exchange goes to
   // the second stream and meets the main stream again in front of the nonbonded kernel
   if (multi()) on_comm_stream([&] { charge_halo(); }); else charge_halo();
-  bond_orders();
+  { const bool kt = kt_begin(&st.ms_k_bondorder); bond_orders(); kt_end(kt); }
   hipEventRecord(ev[3], stream);
   if (multi()) join_comm_stream();
-  if (ff.pqeq) nonbonded_pqeq(); else nonbonded();     // pot.F90:48-52
+  { const bool kt = kt_begin(&st.ms_k_nonbond); if (ff.pqeq) nonbonded_pqeq(); else nonbonded(); kt_end(kt); }     // pot.F90:48-52
   hipEventRecord(ev[4], stream);
   bonded_energies();
   if (ff.pqeq) efield_force();                         // pot.F90:61, before ForceBondedTerms
-  assemble_forces();
+  { const bool kt = kt_begin(&st.ms_k_assemble); assemble_forces(); kt_end(kt); }
   accumulate_stress(false);                            // pot.F90:65-72, before the ghost forces are folded back
-  fold_ghost_forces();
+  { const bool kt = kt_begin(&st.ms_fold); fold_ghost_forces(); kt_end(kt); }
   hipEventRecord(ev[5], stream);
   RX_HIP(hipMemcpyAsync(h_scal + 32, pe_d, sizeof(double) * 16, hipMemcpyDeviceToHost, stream));
   sync_stream();
   pe[0] = 0.0;
   for (int k = 1; k < 14; ++k) { pe[k] = h_scal[32 + k]; pe[0] += pe[k]; }   // PE(0)=sum(PE(1:13)), main.F90:236
+  collect_timers();
   float ms = 0;
   hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_bo += ms;
   hipEventElapsedTime(&ms, ev[3], ev[4]); st.ms_nonbond += ms;
@@ -246,6 +248,27 @@ __global__ void __launch_bounds__(256) k_ke_qsum(int n, const int *__restrict__ 
   }
   if (threadIdx.x < 4) partials[blockIdx.x * 6 + 2 + threadIdx.x] = 0.0;
 }
+// INITVELOCITY (init.F90:292-360), first half: unit-variance Gaussian velocity components, the same distribution for every element as the
+// reference draws them (its Box-Muller pairs atoms i, i+1 off one random_number stream; which atom gets which deviate is not defined
+// beyond that).  Here a counter-based generator keyed by (seed, draw, GLOBAL atom id, component): the velocities of an atom do not depend
+// on the rank that owns it, on its local index or on the number of ranks.
+__device__ inline unsigned long long mix64(unsigned long long z) {     // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ULL; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31);
+}
+__global__ void k_random_velocities(int n, unsigned long long seed, unsigned long long draw, const long long *__restrict__ gid,
+                                    double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = mix64(seed ^ mix64(draw)) ^ mix64(static_cast<unsigned long long>(gid[i]) * 0xD1342543DE82EF95ULL);
+  double v[3];
+  for (int k = 0; k < 3; ++k) {
+    const unsigned long long a = mix64(key + 2ULL * k), b = mix64(key + 2ULL * k + 1ULL);
+    const double u1 = (static_cast<double>(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);      // (0, 1)
+    const double u2 = (static_cast<double>(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    v[k] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);                          // Box-Muller
+  }
+  vx[i] = v[0]; vy[i] = v[1]; vz[i] = v[2];
+}
 struct ScaleArgs { double c[16]; double vcm[3]; };
 __global__ void k_scale_velocities(int n, ScaleArgs a, const int *__restrict__ type, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,7 +293,11 @@ void Engine::thermostat(int mdmode, double treq_K, double vsfact, double gke) {
   const double treq = treq_K / UTEMP0;                               // init.F90:72
   ScaleArgs sa{};
   std::vector<double> sums(6 * (ff.nso + 1), 0.0);
-  const bool need_sums = (mdmode == 7 || mdmode == 8 || (mdmode == 5 && gke <= 0.0));
+  if (mdmode == 0 || mdmode == 6) {                                  // main.F90:54-55 -> INITVELOCITY: fresh Gaussian velocities before the sums
+    static const unsigned long long seed = std::getenv("RXMD_SEED") ? std::strtoull(std::getenv("RXMD_SEED"), nullptr, 10) : 0x5DEECE66DULL;
+    k_random_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, seed, velocity_draws++, gid, vel[0], vel[1], vel[2]);
+  }
+  const bool need_sums = (mdmode == 0 || mdmode == 6 || mdmode == 7 || mdmode == 8 || (mdmode == 5 && gke <= 0.0));
   if (need_sums) {
     const int nb = 240;
     for (int t = 1; t <= ff.nso; ++t) {
@@ -300,8 +327,17 @@ void Engine::thermostat(int mdmode, double treq_K, double vsfact, double gke) {
       sa.c[t] = n > 1.0 ? std::sqrt((treq * UTEMP0) / (sums[6 * t + 1] / n * UTEMP)) : 0.0;   // main.F90:742-751
     }
     remove_momentum = true;
+  } else if (mdmode == 0 || mdmode == 6) {
+    // centre-of-mass velocity off (MPI_ALLREDUCE of sum m v and sum m, init.F90:333-341), then every velocity scaled so that the kinetic energy
+    // per atom is 1.5 treq (init.F90:343-358).  KE of the shifted velocities from the sums at hand: sum m/2 |v - c|^2 = KE - |P|^2 / (2 M).
+    double P2 = 0.0, Pa[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) { for (int t = 1; t <= ff.nso; ++t) Pa[a] += sums[6 * t + 2 + a]; P2 += Pa[a] * Pa[a]; }
+    const double gke_new = (ektot - 0.5 * P2 / mtot) / ntot;
+    const double vfactor = std::sqrt(1.5 * treq / gke_new);
+    for (int t = 0; t < 16; ++t) sa.c[t] = vfactor;
+    for (int a = 0; a < 3; ++a) sa.vcm[a] = vfactor * Pa[a] / mtot;
   } else {
-    throw EngineError(RXMD_E_ARG, "thermostat: mdmode must be 4, 5, 7 or 8 (0/6 draw random velocities on the host side)");
+    throw EngineError(RXMD_E_ARG, "thermostat: mdmode must be 0, 4, 5, 6, 7 or 8");
   }
   if (remove_momentum)                                               // LinearMomentum of the scaled velocities
     for (int a = 0; a < 3; ++a) {
@@ -353,7 +389,7 @@ void Engine::step(int nsteps) {
       k_drift<<<nblk(N, 256), 256, 0, stream>>>(N, dt, vel[0], vel[1], vel[2], pos[0], pos[1], pos[2]);
     } else
       k_kick_drift<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], pos[0], pos[1], pos[2], q, qsfp, qsfv);
-    migrate();                                                           // main.F90:75
+    { const bool kt = kt_begin(&st.ms_migrate); migrate(); kt_end(kt); }                                 // main.F90:75
     const int qs = cfg.qstep > 0 ? cfg.qstep : 1;
     if (step_count % qs == 0) qeq();                                     // main.F90:77-83
     force();                                                             // main.F90:84

@@ -808,8 +808,10 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
 void Engine::bonded_energies() {
   double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
   k_ebond_elnpr<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, dDlp, cf1, cf2, cf3, cdn, ecoa, pe_d);
-  k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+const bool kt3 = kt_begin(&st.ms_k_e3b);
+    k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
+  kt_end(kt3);
   BoxImg bx;
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
   bx.ortho = grid.ortho; bx.probe = std::getenv("RXMD_E4B_PROBE") ? std::atoi(std::getenv("RXMD_E4B_PROBE")) : 0;
@@ -820,6 +822,7 @@ void Engine::bonded_energies() {
   // for most groups and is slower than the default there, 3.69 against 3.47 ms), four atoms x 16 slots (16, needs lists <= 15)
   const int want = std::getenv("RXMD_E4B_SLOTS") ? std::atoi(std::getenv("RXMD_E4B_SLOTS")) : 0;
   const bool narrow = h_err[2] <= 15 && want != 32 && want != 4;
+  const bool kt4 = kt_begin(&st.ms_k_e4b);
   if (want == 4) k_e4b<1><<<nblk(N, 16), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                                        cds, frc[0], frc[1], frc[2], pe_d, bx);
   else if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
@@ -830,7 +833,10 @@ void Engine::bonded_energies() {
                                                  cds, frc[0], frc[1], frc[2], pe_d, bx);
   const int ehb_probe = std::getenv("RXMD_EHB_PROBE") ? std::atoi(std::getenv("RXMD_EHB_PROBE")) : 0;
   const int ehb_apw = (ehb_probe >> 8) ? (ehb_probe >> 8) : 16;    // = EHB_APW of k_ehb
+  kt_end(kt4);
+  const bool kth = kt_begin(&st.ms_k_ehb);
   k_ehb<<<nblk(N, 4 * ehb_apw), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_probe);
+  kt_end(kth);
 }
 
 }  // namespace rxmd

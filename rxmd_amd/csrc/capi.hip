@@ -254,9 +254,18 @@ int rxmd_hip_get_energy(rxmd_handle h, double *ke, double *qsum, double pe[14], 
 static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const double *atype, const double *pos, const double *q) {
   if (natoms < 0 || (natoms == 0 && e.nprocs == 1) || nbuffer < natoms) throw EngineError(RXMD_E_ARG, "bad natoms/nbuffer");
   // FORCE right after QEq (src/main.F90:77-84) hands over the same atoms: keep ghosts, cells and both lists, refresh the charges only
-  if (e.atoms_set && e.lists_valid && natoms == e.N && e.last_atype.size() == static_cast<size_t>(natoms)) {
-    bool same = std::memcmp(e.last_atype.data(), atype, sizeof(double) * natoms) == 0;
+  {
+    bool same = e.atoms_set && e.lists_valid && natoms == e.N && e.last_atype.size() == static_cast<size_t>(natoms);
+    if (same) same = std::memcmp(e.last_atype.data(), atype, sizeof(double) * natoms) == 0;
     for (int a = 0; a < 3 && same; ++a) same = std::memcmp(e.last_pos[a].data(), pos + a * static_cast<size_t>(nbuffer), sizeof(double) * natoms) == 0;
+    // The shortcut decides whether the next qeq()/force() rebuilds ghosts and lists -- a COLLECTIVE exchange.  With several ranks it must be the
+    // same decision everywhere (a rank that owns no atom compares equal trivially and would sit out the six-stage exchange its neighbours
+    // enter): every rank keeps its lists only if every rank may.
+    if (e.nprocs > 1) {
+      double differ = same ? 0.0 : 1.0;
+      e.allreduce_host(&differ, 1);
+      same = differ == 0.0;
+    }
     if (same) {
       if (q) RX_HIP(hipMemcpy(e.q, q, sizeof(double) * natoms, hipMemcpyHostToDevice));
       if (e.lex_pending && e.lex_p.size() == static_cast<size_t>(natoms)) {
@@ -391,6 +400,7 @@ int rxmd_hip_reset_timers(rxmd_handle h) {
     e.st.spmv_launches = 0; e.st.qeq_iters_total = 0; e.st.qeq_calls = 0;
     e.st.ms_ghost_build = e.st.ms_migrate = e.st.ms_halo = e.st.ms_halo_exposed = e.st.ms_allreduce = e.st.ms_fold = 0.0;
     e.st.halo_calls = e.st.allreduce_calls = 0;
+    e.st.ms_k_list10 = e.st.ms_k_nonbond = e.st.ms_k_e3b = e.st.ms_k_e4b = e.st.ms_k_ehb = e.st.ms_k_bondorder = e.st.ms_k_assemble = 0.0;
   });
 }
 

@@ -166,6 +166,7 @@ struct Engine {
   double2 *sall = nullptr, *sgh = nullptr, *wall = nullptr, *wgh = nullptr;  // qeq_mode 1: row sums H.(qs,qt), H.(hs,ht): all columns / ghost columns
   int *gsrc = nullptr, *groot = nullptr;                    // ghost -> source index on sender ; -> resident root (self exchange)
   int *rootperm = nullptr;                                  // cell-sorted position -> resident that owns the value (ghosts resolved)
+  int *invpos = nullptr;                                    // atom (resident or ghost) -> its cell-sorted position: the direction kernel of the CG scatters the new vector straight into xs
   double2 *xs = nullptr;                                    // cell-sorted gather copy of a QEq vector pair (residents+ghosts)
   int *sendidx = nullptr; int sendoff[8] = {0};             // per-stage send index lists (local indices), concatenated
   // cell binning
@@ -200,11 +201,15 @@ struct Engine {
     RX_HIP(hipEventRecord(ev_main, stream));
     RX_HIP(hipStreamWaitEvent(comm_stream, ev_main, 0));
     std::swap(stream, comm_stream);
-    try { body(); } catch (...) { std::swap(stream, comm_stream); throw; }
+    in_comm_region = true;
+    try { body(); } catch (...) { in_comm_region = false; std::swap(stream, comm_stream); throw; }
+    in_comm_region = false;
     std::swap(stream, comm_stream);
     RX_HIP(hipEventRecord(ev_comm, comm_stream));
   }
-  void join_comm_stream() { RX_HIP(hipStreamWaitEvent(stream, ev_comm, 0)); }   // main stream waits for what on_comm_stream queued
+  bool in_comm_region = false;
+  // main stream waits for what on_comm_stream queued; the wait itself is timed: that is the part of the exchange the compute did not hide
+  void join_comm_stream() { const bool kt = kt_begin(&st.ms_halo_exposed); RX_HIP(hipStreamWaitEvent(stream, ev_comm, 0)); kt_end(kt); }
   hipEvent_t ev[8] = {};
   std::vector<double> last_atype, last_pos[3];    // what the array-shaped entry points uploaded last (capi.hip)
   std::vector<double> lex_p, lex_v; bool lex_pending = false;   // qsfp/qsfv handed over by rxmd_hip_put_lex for the next array-shaped QEq/PQEq
@@ -212,6 +217,7 @@ struct Engine {
   int nstep_qeq = 0; double last_est = 0;
   double atype_resid = 0.0;        // geninit packs atype = type + gid*1e-13 + 1e-14 (geninit.F90:459), ReadXYZ without it (fileio.F90:421): what came in goes out
   long long step_count = 0;
+  unsigned long long velocity_draws = 0;    // INITVELOCITY calls so far: the draw index of the counter-based generator (assemble.hip)
 
   // ---- host API ----
   explicit Engine(const rxmd_config &c);
@@ -252,7 +258,20 @@ struct Engine {
   int *flags2 = nullptr, *scanout2 = nullptr;       // second stage of an axis pair (ghost build)
   void rccl_exchange_pair(int to0, int from0, long long n0, long long r0, int to1, int from1, long long n1, long long r1);
   bool stage_pairs = true;                          // RXMD_NO_STAGE_PAIRS=1: one round per stage as the reference does (six per halo)
+  // Direct vector halo (RXMD_HALO_DIRECT=1): every ghost value comes straight from the rank that OWNS the atom, all peers in one grouped
+  // exchange, instead of the reference's x -> y -> z forwarding (comm.F90:68-86: three dependent rounds per halo).  The ghost build carries
+  // (owner rank, owner's local index) along with every atom; after it each rank asks its ghosts' owners for their index lists once.
+  long long *gowner = nullptr;                      // per atom: owner's local index * 1024 + owner rank
+  bool halo_direct = false, dh_ready = false;
+  int *dh_ghost = nullptr, *dh_serve = nullptr;     // ghost indices grouped by owner rank ; my residents grouped by the rank that asked for them
+  int *dh_keys = nullptr, *dh_keys2 = nullptr, *dh_vals = nullptr, *dh_off = nullptr; int dh_serve_cap = 0;
+  std::vector<long long> dh_need_off, dh_serve_off; // prefix offsets per rank (atoms)
+  void direct_halo_setup();
+  void halo_direct_exchange(double *v, int ncomp);
+  void exchange_many(const std::vector<long long> &soff, const std::vector<long long> &roff, int ncomp);   // segment p of xbuf_send -> rank p, segment p of xbuf_recv <- rank p
+  void rccl_exchange_many(const std::vector<long long> &soff, const std::vector<long long> &roff, int ncomp);
   void ensure_xbuf(size_t doubles);
+  size_t migrate_xbuf_doubles(size_t from_send_count) const;
   void grow_xbuf_keep_send(size_t need, size_t keep);
   bool multi() const { return nprocs > 1 || force_staged; }
   // native RCCL transport (rccl_comm.hip); force_staged / force_remote (env RXMD_FORCE_STAGED / RXMD_FORCE_REMOTE) push a
@@ -287,6 +306,27 @@ struct Engine {
   void accumulate_stress(bool kinetic);   // astr(1:6) on the device (scal[48..53])
   void check_device_error(const char *where);
   double reduce_partials(int ncomp, int nblocks, double *out);  // host-side helper
+  // Event pairs around single launches / exchanges, from a small pool; a finished pair is read back the next time the host has synchronised
+  // with a stream anyway (collect_timers: only pairs whose end event has completed -- an exchange on the second stream may still be running),
+  // so timing costs no host wait.  A pair adds its milliseconds to up to two rxmd_stats fields.
+  struct KtPair { hipEvent_t a = nullptr, b = nullptr; double *dst = nullptr, *dst2 = nullptr; long long *cnt = nullptr; };
+  std::vector<KtPair> kt_free, kt_pending;
+  int kt_open = -1;                                // (one nesting level is enough: begin ... end on the stream current at the time)
+  KtPair kt_cur{};
+  bool kt_begin(double *dst, double *dst2 = nullptr, long long *cnt = nullptr) {
+    if (kt_free.empty() || kt_cur.a) return false;
+    kt_cur = kt_free.back(); kt_free.pop_back();
+    kt_cur.dst = dst; kt_cur.dst2 = dst2; kt_cur.cnt = cnt;
+    hipEventRecord(kt_cur.a, stream);
+    return true;
+  }
+  void kt_end(bool open) {
+    if (!open) return;
+    hipEventRecord(kt_cur.b, stream);
+    kt_pending.push_back(kt_cur);
+    kt_cur = KtPair{};
+  }
+  void collect_timers();          // after a stream synchronisation
   void tic(int k) { hipEventRecord(ev[k], stream); }
   double toc(int k0, int k1) { hipEventRecord(ev[k1], stream); hipEventSynchronize(ev[k1]); float ms = 0; hipEventElapsedTime(&ms, ev[k0], ev[k1]); return ms; }
 };

@@ -92,6 +92,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
     throw EngineError(RXMD_E_ARG, "efield needs a PQEq parameter file (core charges Z) and a direction 1..3");
   stage_pairs = std::getenv("RXMD_NO_STAGE_PAIRS") == nullptr;
   force_staged = std::getenv("RXMD_FORCE_STAGED") != nullptr; force_remote = std::getenv("RXMD_FORCE_REMOTE") != nullptr;
+  halo_direct = std::getenv("RXMD_HALO_DIRECT") != nullptr && std::atoi(std::getenv("RXMD_HALO_DIRECT")) != 0;
   MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
   if (MAXNB > 31) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 31 (the wavefront-per-centre kernels stage the bond slots of two atoms in one 64-lane wavefront; the reference uses 30)");
   int ndev = 0;
@@ -99,6 +100,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   RX_HIP(hipSetDevice(cfg.device));
   { hipDeviceProp_t pr; RX_HIP(hipGetDeviceProperties(&pr, cfg.device)); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
   RX_HIP(hipStreamCreate(&stream));
+  for (int k = 0; k < 64; ++k) { KtPair p; RX_HIP(hipEventCreate(&p.a)); RX_HIP(hipEventCreate(&p.b)); kt_free.push_back(p); }
   if (std::getenv("RXMD_SINGLE_STREAM")) comm_stream = stream;   // diagnostic: the halo work queues on the main stream (no second hardware queue)
   else {                                         // highest priority: pack / send-recv / unpack kernels of a halo go ahead of the queued compute workgroups
     int lo = 0, hi = 0;
@@ -114,6 +116,7 @@ Engine::~Engine() {
   rccl_destroy();
   free_device();
   for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+  for (auto *v : {&kt_free, &kt_pending}) for (auto &p : *v) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
   if (ev_main) (void)hipEventDestroy(ev_main);
   if (ev_comm) (void)hipEventDestroy(ev_comm);
   if (ev_est) (void)hipEventDestroy(ev_est);
@@ -122,6 +125,14 @@ Engine::~Engine() {
 }
 
 void Engine::allreduce_host(double *buf, int n) {
+  if (nccl && n <= 8) {                       // the usual case: a scalar or two -- the tail of the device scalar block is the staging area
+    double *d = scal + 64;
+    RX_HIP(hipMemcpyAsync(d, buf, sizeof(double) * n, hipMemcpyHostToDevice, stream));
+    rccl_allreduce_dev(d, n);
+    RX_HIP(hipMemcpyAsync(buf, d, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    sync_stream();
+    return;
+  }
   if (nccl) {
     double *d = nullptr;
     RX_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * n));
@@ -134,6 +145,22 @@ void Engine::allreduce_host(double *buf, int n) {
   }
   if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm or rxmd_hip_comm_init_rccl first");
   if (comm.allreduce_sum(comm.ctx, buf, n)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
+}
+
+void Engine::collect_timers() {
+  size_t keep = 0;
+  for (size_t i = 0; i < kt_pending.size(); ++i) {
+    KtPair p = kt_pending[i];
+    float ms = 0;
+    if (hipEventQuery(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      if (p.dst) *p.dst += ms;
+      if (p.dst2) *p.dst2 += ms;
+      if (p.cnt) *p.cnt += 1;
+      p.dst = p.dst2 = nullptr; p.cnt = nullptr;
+      kt_free.push_back(p);
+    } else kt_pending[keep++] = p;
+  }
+  kt_pending.resize(keep);
 }
 
 void Engine::check_device_error(const char *where) {
@@ -297,7 +324,7 @@ void Engine::alloc_device() {
   }
   dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb); dmalloc(hst2, nb); dmalloc(tickets, 16);
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
-  dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(xs, nb);
+  dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(gowner, nb); dmalloc(dh_ghost, nb); dmalloc(dh_keys, nb); dmalloc(dh_keys2, nb); dmalloc(dh_vals, nb); dmalloc(dh_off, 1100); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(invpos, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.nfine) + 2);
   dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
   dmalloc(nbr, ns); dmalloc(nbrcnt, nb); dmalloc(nbrindx, ns);
@@ -310,7 +337,7 @@ void Engine::alloc_device() {
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
-  dmalloc(partials, partials_cap + 1024); dmalloc(scal, 64);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
+  dmalloc(partials, partials_cap + 1024); dmalloc(scal, 80);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
   dmalloc(d_err, 4);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 8 * sizeof(int)));
@@ -329,7 +356,8 @@ void Engine::free_device() {
   dfree(sorted_shl); dfree(hsc); dfree(pqrow);
   if (pqblob) { (void)hipFree(pqblob); pqblob = nullptr; }
   dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst); dfree(hst2); dfree(tickets); dfree(sall); dfree(sgh); dfree(wall); dfree(wgh);
-  dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(xs); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
+  dfree(gowner); dfree(dh_ghost); dfree(dh_keys); dfree(dh_keys2); dfree(dh_vals); dfree(dh_off); dfree(dh_serve);
+  dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(invpos); dfree(xs); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
   dfree(sorted_xyzi); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
   dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
@@ -613,22 +641,27 @@ void Engine::halo_refresh(double2 *v2, double *v1) {
 // multi-rank: the same six stages with pack -> send_recv -> unpack (reference src/comm.F90:68-86).  A stage whose
 // partner is this rank (vprocs(axis) == 1) is a device copy; otherwise the host-supplied transport moves the bytes.
 __global__ void k_pack_ghosts(int nscan, int axis, double sft, const int *flags, const int *scanout, const double *sx, const double *sy, const double *sz,
-                              const int *type, const long long *gid, const double *q, double *buf, int *sendlist) {
+                              const int *type, const long long *gid, const double *q, double *buf, int *sendlist, int nres, int myid, const long long *gowner) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= nscan || !flags[n]) return;
   const int k = scanout[n];
   double a = sx[n], b = sy[n], c = sz[n];
   if (axis == 0) a += sft; else if (axis == 1) b += sft; else c += sft;
   double *o = buf + 6 * static_cast<size_t>(k);
-  o[0] = a; o[1] = b; o[2] = c; o[3] = static_cast<double>(type[n]); o[4] = static_cast<double>(gid[n]); o[5] = q[n];
+  // the type word also carries who owns the atom: (owner's local index * 1024 + owner rank) * 64 + type, exact in a double.  A resident is its
+  // own owner; a ghost that is forwarded keeps the owner it arrived with (direct vector halo, engine.h)
+  const long long own = (n < nres) ? (static_cast<long long>(n) * 1024 + myid) : gowner[n];
+  o[0] = a; o[1] = b; o[2] = c; o[3] = static_cast<double>(own * 64 + type[n]); o[4] = static_cast<double>(gid[n]); o[5] = q[n];
   sendlist[k] = n;
 }
-__global__ void k_unpack_ghosts(int cnt, int base, const double *buf, double *sx, double *sy, double *sz, int *type, long long *gid, double *q, int *gsrc) {
+__global__ void k_unpack_ghosts(int cnt, int base, const double *buf, double *sx, double *sy, double *sz, int *type, long long *gid, double *q, int *gsrc, long long *gowner) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= cnt) return;
   const double *o = buf + 6 * static_cast<size_t>(k);
   const int m = base + k;
-  sx[m] = o[0]; sy[m] = o[1]; sz[m] = o[2]; type[m] = static_cast<int>(llrint(o[3])); gid[m] = llrint(o[4]); q[m] = o[5];
+  const long long w = llrint(o[3]);
+  sx[m] = o[0]; sy[m] = o[1]; sz[m] = o[2]; type[m] = static_cast<int>(w & 63); gid[m] = llrint(o[4]); q[m] = o[5];
+  gowner[m] = w >> 6;
   gsrc[m] = -1;
 }
 __global__ void k_pack_vec(int cnt, int ncomp, const int *sendlist, const double *v, double *buf) {
@@ -652,6 +685,16 @@ __global__ void k_add_force(int cnt, const int *sendlist, const double *buf, dou
   if (k >= cnt) return;
   const int n = sendlist[k];      // unique within a stage
   fx[n] += buf[3 * static_cast<size_t>(k)]; fy[n] += buf[3 * static_cast<size_t>(k) + 1]; fz[n] += buf[3 * static_cast<size_t>(k) + 2];
+}
+
+// The migration sizes its message buffers from what THIS rank sends.  The RCCL transport learns the incoming size first and grows the
+// buffers (grow_xbuf_keep_send); a callback transport (rxmd_comm_ops: torch.distributed, the host-staged MPI binding) has one call
+// per message and would have to fail after its size exchange, leaving the peer inside its payload exchange.  With callbacks and the
+// engine's own buffers the receive side is therefore sized for the worst case the ghost build already allocates (NBUFFER x 6 doubles:
+// more migrants than a rank can hold); host-supplied buffers keep their contract (the callback gets the capacity).
+size_t Engine::migrate_xbuf_doubles(size_t from_send_count) const {
+  if (nccl || !multi() || (!xbuf_owned && xbuf_doubles > 0)) return from_send_count;
+  return std::max(from_send_count, static_cast<size_t>(NB) * 6);
 }
 
 void Engine::ensure_xbuf(size_t doubles) {
@@ -721,14 +764,14 @@ void Engine::ghost_build_staged() {
       if (sendoff[d0] + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
       if (xb_fixed) ensure_xbuf(6 * (static_cast<size_t>(t0) + t1));
       sendoff[d0 + 1] = sendoff[d0] + t0; sendoff[d1 + 1] = sendoff[d1] + t1;
-      if (t0 > 0) k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, -box.lbox[axis], flags, scanout, spos[0], spos[1], spos[2], type, gid, q, xbuf_send, sendidx + sendoff[d0]);
-      if (t1 > 0) k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, box.lbox[axis], flags2, scanout2, spos[0], spos[1], spos[2], type, gid, q, xbuf_send + 6LL * t0, sendidx + sendoff[d1]);
+      if (t0 > 0) k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, -box.lbox[axis], flags, scanout, spos[0], spos[1], spos[2], type, gid, q, xbuf_send, sendidx + sendoff[d0], N, cfg.myid, gowner);
+      if (t1 > 0) k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, box.lbox[axis], flags2, scanout2, spos[0], spos[1], spos[2], type, gid, q, xbuf_send + 6LL * t0, sendidx + sendoff[d1], N, cfg.myid, gowner);
       long long r0 = 0, r1 = 0;
       exchange_pair_sized(d0, 6LL * t0, 6LL * t1, r0, r1);
       const int c0 = static_cast<int>(r0 / 6), c1 = static_cast<int>(r1 / 6);
       if (static_cast<long long>(copyptr[d0 - 1]) + c0 + c1 > NB)
         throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
-      if (c0 + c1 > 0) k_unpack_ghosts<<<nblk(c0 + c1, 256), 256, 0, stream>>>(c0 + c1, copyptr[d0 - 1], xbuf_recv, spos[0], spos[1], spos[2], type, gid, q, gsrc);
+      if (c0 + c1 > 0) k_unpack_ghosts<<<nblk(c0 + c1, 256), 256, 0, stream>>>(c0 + c1, copyptr[d0 - 1], xbuf_recv, spos[0], spos[1], spos[2], type, gid, q, gsrc, gowner);
       copyptr[d0] = copyptr[d0 - 1] + c0; copyptr[d1] = copyptr[d0] + c1;
     }
   } else
@@ -745,19 +788,20 @@ void Engine::ghost_build_staged() {
     if (sendoff[d] + total > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in store_atoms (send list)");
     if (xb_fixed) ensure_xbuf(6 * static_cast<size_t>(total));
     if (total > 0)
-      k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, sft, flags, scanout, spos[0], spos[1], spos[2], type, gid, q, xbuf_send, sendidx + sendoff[d]);
+      k_pack_ghosts<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, sft, flags, scanout, spos[0], spos[1], spos[2], type, gid, q, xbuf_send, sendidx + sendoff[d], N, cfg.myid, gowner);
     sendoff[d + 1] = sendoff[d] + total;
     const long long nr = exchange_stage(d, false, 6LL * total);
     const int cnt = static_cast<int>(nr / 6);
     if (static_cast<long long>(copyptr[d - 1]) + cnt > NB)
       throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
-    if (cnt > 0) k_unpack_ghosts<<<nblk(cnt, 256), 256, 0, stream>>>(cnt, copyptr[d - 1], xbuf_recv, spos[0], spos[1], spos[2], type, gid, q, gsrc);
+    if (cnt > 0) k_unpack_ghosts<<<nblk(cnt, 256), 256, 0, stream>>>(cnt, copyptr[d - 1], xbuf_recv, spos[0], spos[1], spos[2], type, gid, q, gsrc, gowner);
     copyptr[d] = copyptr[d - 1] + cnt;
   }
   G = copyptr[6];
   if (G > N) k_to_real<<<nblk(G - N, 256), 256, 0, stream>>>(B, N, G, spos[0], spos[1], spos[2], pos[0], pos[1], pos[2]);
   ghosts_valid = true;
   st.nghost_force = G - N; st.nghost_qeq = G - N;
+  if (halo_direct) direct_halo_setup();             // owners and index lists of this build's ghosts (engine.h)
 }
 
 // The + and - stage of one axis are independent (both scan residents and the ghosts of EARLIER axes only, comm.F90:55-66), and
@@ -799,8 +843,105 @@ void Engine::exchange_pair_sized(int d0, long long n0, long long n1, long long &
   if (r1 < 0) throw EngineError(RXMD_E_COMM, "exchange callback failed");
 }
 
+// ---- direct vector halo (RXMD_HALO_DIRECT=1; engine.h) -----------------------------------------------------------------------------
+__global__ void k_dh_keys(int N, int G, const long long *__restrict__ gowner, int *__restrict__ keys, int *__restrict__ vals) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G - N) return;
+  keys[t] = static_cast<int>(gowner[N + t] & 1023); vals[t] = N + t;
+}
+__global__ void k_dh_offsets(int np, int n, const int *__restrict__ keys_sorted, int *__restrict__ off) {     // off[p] = first position whose owner rank is >= p
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > np) return;
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys_sorted[mid] < p) lo = mid + 1; else hi = mid; }
+  off[p] = lo;
+}
+__global__ void k_dh_requests(int n, const int *__restrict__ ghost, const long long *__restrict__ gowner, double *__restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = static_cast<double>(gowner[ghost[k]] >> 10);
+}
+__global__ void k_dh_to_int(int n, const double *__restrict__ in, int *__restrict__ out, int nres, int *err) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const long long i = llrint(in[k]);
+  if (i < 0 || i >= nres) { atomicCAS(&err[0], DERR_NONE, DERR_GRID); out[k] = 0; return; }   // a request for an atom this rank does not own
+  out[k] = static_cast<int>(i);
+}
+__global__ void k_dh_unpack(int cnt, int ncomp, const int *__restrict__ ghost, const double *__restrict__ buf, double *__restrict__ v) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const int m = ghost[k];
+  for (int c = 0; c < ncomp; ++c) v[static_cast<size_t>(m) * ncomp + c] = buf[static_cast<size_t>(k) * ncomp + c];
+}
+
+// segment p of xbuf_send goes to rank p, segment p of xbuf_recv comes from rank p (offsets in atoms, ncomp doubles each): RCCL -- every
+// peer in ONE group; callbacks -- np - 1 shifted send_recv rounds (to = me + r, from = me - r: every rank is in the same round at the same
+// time, and every rank always posts both halves, as the transports expect); the rank's own segment is a device copy
+void Engine::exchange_many(const std::vector<long long> &soff, const std::vector<long long> &roff, int ncomp) {
+  const int me = cfg.myid, np = nprocs;
+  const bool self_remote = force_remote && nccl;
+  if (!self_remote) {
+    const long long sc = (soff[me + 1] - soff[me]) * ncomp, rc = (roff[me + 1] - roff[me]) * ncomp;
+    if (sc != rc) throw EngineError(RXMD_E_COMM, "direct halo: a rank disagrees with itself about its own images");
+    if (sc > 0) RX_HIP(hipMemcpyAsync(xbuf_recv + roff[me] * ncomp, xbuf_send + soff[me] * ncomp, sizeof(double) * sc, hipMemcpyDeviceToDevice, stream));
+  }
+  if (nccl) { rccl_exchange_many(soff, roff, ncomp); return; }
+  if (np == 1) return;
+  if (!has_comm || !comm.exchange) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm first");
+  sync_stream();
+  for (int r = 1; r < np; ++r) {
+    const int to = (me + r) % np, from = (me - r + np) % np;
+    const long long sc = (soff[to + 1] - soff[to]) * ncomp, rc = (roff[from + 1] - roff[from]) * ncomp;
+    const long long got = comm.exchange_known ? comm.exchange_known(comm.ctx, to, xbuf_send + soff[to] * ncomp, sc, from, xbuf_recv + roff[from] * ncomp, rc)
+                                              : comm.exchange(comm.ctx, to, xbuf_send + soff[to] * ncomp, sc, from, xbuf_recv + roff[from] * ncomp, static_cast<long long>(xbuf_doubles) - roff[from] * ncomp);
+    if (got != rc) throw EngineError(RXMD_E_COMM, "direct halo: message size differs from what the request phase announced");
+  }
+}
+
+// after a ghost build: group the ghosts by owner rank, tell every rank how many of its atoms each other rank needs (one all-reduce of an
+// np x np table), send the owners their index lists
+void Engine::direct_halo_setup() {
+  dh_ready = false;
+  const int np = nprocs, me = cfg.myid, ng = G - N;
+  if (np > 1000) throw EngineError(RXMD_E_ARG, "direct halo: more than 1000 ranks");
+  dh_need_off.assign(np + 1, 0); dh_serve_off.assign(np + 1, 0);
+  if (ng > 0) {
+    k_dh_keys<<<nblk(ng, 256), 256, 0, stream>>>(N, G, gowner, dh_keys, dh_vals);
+    size_t tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, dh_keys, dh_keys2, dh_vals, dh_ghost, ng, 0, 10, stream));
+  }
+  k_dh_offsets<<<nblk(np + 1, 256), 256, 0, stream>>>(np, ng, dh_keys2, dh_off);
+  std::vector<int> off(np + 1);
+  RX_HIP(hipMemcpyAsync(off.data(), dh_off, sizeof(int) * (np + 1), hipMemcpyDeviceToHost, stream));
+  sync_stream();
+  for (int p = 0; p <= np; ++p) dh_need_off[p] = off[p];
+  std::vector<double> table(static_cast<size_t>(np) * np, 0.0);                 // table[a * np + b] = atoms of rank b that rank a holds as ghosts
+  for (int p = 0; p < np; ++p) table[static_cast<size_t>(me) * np + p] = static_cast<double>(off[p + 1] - off[p]);
+  if (np > 1) allreduce_host(table.data(), np * np);
+  for (int p = 0; p < np; ++p) dh_serve_off[p + 1] = dh_serve_off[p] + static_cast<long long>(table[static_cast<size_t>(p) * np + me]);
+  const long long nserve = dh_serve_off[np];
+  ensure_xbuf(static_cast<size_t>(std::max<long long>(std::max<long long>(ng, nserve), 1)) * 3);      // up to three components per atom (PQEq shells)
+  if (nserve > dh_serve_cap) { dfree(dh_serve); dh_serve_cap = static_cast<int>(nserve + nserve / 4 + 1024); dmalloc(dh_serve, dh_serve_cap); }
+  if (ng > 0) k_dh_requests<<<nblk(ng, 256), 256, 0, stream>>>(ng, dh_ghost, gowner, xbuf_send);
+  exchange_many(dh_need_off, dh_serve_off, 1);                                   // my requests out, the other ranks' requests in
+  if (nserve > 0) k_dh_to_int<<<nblk(nserve, 256), 256, 0, stream>>>(static_cast<int>(nserve), xbuf_recv, dh_serve, N, d_err);
+  dh_ready = true;
+}
+
+void Engine::halo_direct_exchange(double *v, int ncomp) {
+  const int ng = G - N;
+  const long long nserve = dh_serve_off[nprocs];
+  if (nserve > 0) k_pack_vec<<<nblk(nserve, 256), 256, 0, stream>>>(static_cast<int>(nserve), ncomp, dh_serve, v, xbuf_send);
+  exchange_many(dh_serve_off, dh_need_off, ncomp);
+  if (ng > 0) k_dh_unpack<<<nblk(ng, 256), 256, 0, stream>>>(ng, ncomp, dh_ghost, xbuf_recv, v);
+}
+
 // MODE_QCOPY1 / MODE_QCOPY2 (comm.F90:187-212): ghost slots of an ncomp-interleaved vector, axis by axis
 void Engine::halo_staged(double *v, int ncomp) {
+  // QCOPY1 / QCOPY2 (comm.F90:2-100 with MODE_QCOPY*): on the second stream the part the main stream waits for is measured at the join
+  const bool kt = kt_begin(&st.ms_halo, in_comm_region ? nullptr : &st.ms_halo_exposed, &st.halo_calls);
+  struct End { Engine *e; bool kt; ~End() { e->kt_end(kt); } } end_{this, kt};
+  if (halo_direct && dh_ready) { halo_direct_exchange(v, ncomp); return; }
   if (stage_pairs && (nccl || (has_comm && comm.exchange_known))) {
     for (int d0 = 1; d0 <= 5; d0 += 2) {
       const int ns0 = sendoff[d0 + 1] - sendoff[d0], ns1 = sendoff[d0 + 2] - sendoff[d0 + 1];
@@ -939,7 +1080,7 @@ void Engine::migrate() {
       RX_HIP(hipMemcpyAsync(h_cnt + 1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
       sync_stream();
       t0 = h_cnt[0]; t1 = h_cnt[1];   // counts arrive in pinned host memory
-      ensure_xbuf(static_cast<size_t>(std::max(t0 + t1, 1)) * W + 4096);
+      ensure_xbuf(migrate_xbuf_doubles(static_cast<size_t>(std::max(t0 + t1, 1)) * W + 4096));
       double *b1 = xbuf_send + static_cast<size_t>(W) * t0;
       if (t0 > 0) {
         if (ff.pqeq) k_pack_extra3<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, flags, scanout, W, 11, shl[0], shl[1], shl[2], xbuf_send);
@@ -999,7 +1140,7 @@ void Engine::migrate() {
     total = h_cnt[0];   // counts arrive in pinned host memory
     if (multi()) {
       const int W = ff.pqeq ? 14 : 11;             // + shell displacement (comm.F90:153,165-167)
-      ensure_xbuf(static_cast<size_t>(std::max(total, 1)) * W + 4096);
+      ensure_xbuf(migrate_xbuf_doubles(static_cast<size_t>(std::max(total, 1)) * W + 4096));
       if (total > 0) {
         if (ff.pqeq) k_pack_extra3<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, flags, scanout, W, 11, shl[0], shl[1], shl[2], xbuf_send);
         k_pack_move<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, axis, sft, flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv, xbuf_send, W);
@@ -1081,13 +1222,14 @@ __global__ void k_cell_starts(int G, int nfine, const int *__restrict__ cid_sort
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (cid_sorted[mid] < b) lo = mid + 1; else hi = mid; }
   cellstart[b] = lo;
 }
-__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, double4 *out, int *rootperm) {
+__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, double4 *out, int *rootperm, int *invpos) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= G) return;
   const int i = perm[k];
   const double xi = x[i], yi = y[i], zi = z[i];
   out[k] = make_double4(xi, yi, zi, __longlong_as_double(static_cast<long long>(i)));
   rootperm[k] = (i < N) ? i : groot[i];
+  invpos[i] = k;
 }
 // xs[k] = v[owner of the atom at cell-sorted position k]: the ghost refresh (MODE_QCOPY1/2, comm.F90:187-212) and the
 // spatially sorted gather copy of the vector in one pass
@@ -1104,7 +1246,7 @@ void Engine::bin_cells() {
   while ((1LL << bits) < grid.nfine + 1 && bits < 31) ++bits;
   RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, cellid, cellid_sorted, perm_in, perm, G, 0, bits, stream));
   k_cell_starts<<<nblk(grid.nfine + 1, 256), 256, 0, stream>>>(G, grid.nfine, cellid_sorted, cellstart);
-  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, rootperm);
+  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, rootperm, invpos);
   if (ff.pqeq) pqeq_sorted_shells();
 }
 
@@ -1120,7 +1262,7 @@ void Engine::sorted_copy(const double2 *v) {
 void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   tic(0);
-  ghost_build();
+  { const bool kt = kt_begin(&st.ms_ghost_build); ghost_build(); kt_end(kt); }
   bin_cells();
   build_bonded_list();
   sums_from_list = qeq_prepass;
@@ -1143,6 +1285,7 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     check_device_error("list build");
   }
   max_row10 = h_err[3];                             // longest 10 A row of this build (k_list10)
+  collect_timers();
   st.ms_lists += toc(0, 1);
   lists_valid = true;
 }

@@ -400,8 +400,10 @@ void Engine::build_list10() {
 #define RX_LIST10_O(SC, PQF, OR)                                                                                                               \
   k_list10<SC, PQF, OR><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
                                                     nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
+  const bool kt10 = kt_begin(&st.ms_k_list10);
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
+  kt_end(kt10);
 #undef RX_LIST10
 #undef RX_LIST10_O
   if (multi()) {     // interior rows (no ghost partner) and boundary rows: the matrix pass does the former while the vector halo is in flight

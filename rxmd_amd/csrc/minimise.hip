@@ -9,6 +9,12 @@
 // Restated, not copied: the reference re-evaluates the energy and forces of the unmoved atoms in every bracketing round and
 // evaluates a second Wolfe condition it never uses (cg.F90:127: `.not.WolfeC1 .or. .not.WolfeC1`); both are left out -- they
 // change nothing but the start vector of the next charge solve.
+// Deliberate deviation: LineMinimization calls MigrateVec3D(pos, p, g, stepl) (cg.F90:226,299-310), which migrates the DIRECTION p displaced
+// along g with an uninitialised atype -- the compaction of COPYATOMS(MODE_MOVE) then destroys p.  Here the gradient g
+// rides with the atoms displaced along p, which is what the surrounding code needs: the search direction and the gradient of the next
+// loop in the atoms' new order.
+// State on return: positions, charges, forces, PE(1:13), ghosts and lists are those of the final positions on BOTH exits (energy
+// criterion met, or max_loops reached -- the bracketing of a further loop is not started then).
 #include "engine.h"
 
 #include <cmath>
@@ -46,7 +52,7 @@ __global__ void __launch_bounds__(256) k_dot3(int n, const double *__restrict__ 
 
 namespace {
 struct Vec3 { double *c[3] = {nullptr, nullptr, nullptr}; };
-struct Snapshot { Vec3 pos, vel; double *q = nullptr, *qsfp = nullptr, *qsfv = nullptr; int *type = nullptr; long long *gid = nullptr; int N = 0; };
+struct Snapshot { Vec3 pos, vel, shl; double *q = nullptr, *qsfp = nullptr, *qsfv = nullptr; int *type = nullptr; long long *gid = nullptr; int N = 0; };
 
 struct Minimiser {
   Engine &e;
@@ -57,13 +63,14 @@ struct Minimiser {
   explicit Minimiser(Engine &en) : e(en) {
     auto al = [&](Vec3 &v) { for (int a = 0; a < 3; ++a) { RX_HIP(hipMalloc(reinterpret_cast<void **>(&v.c[a]), sizeof(double) * e.NB)); RX_HIP(hipMemset(v.c[a], 0, sizeof(double) * e.NB)); } };
     al(P); al(G); al(Gold); al(snap.pos); al(snap.vel);
+    if (e.ff.pqeq) al(snap.shl);          // PQEq: the shell displacements migrate with their atoms (comm.F90:153,165-167) and are relaxed by every trial solve
     RX_HIP(hipMalloc(reinterpret_cast<void **>(&snap.q), sizeof(double) * e.NB)); RX_HIP(hipMalloc(reinterpret_cast<void **>(&snap.qsfp), sizeof(double) * e.NB));
     RX_HIP(hipMalloc(reinterpret_cast<void **>(&snap.qsfv), sizeof(double) * e.NB)); RX_HIP(hipMalloc(reinterpret_cast<void **>(&snap.type), sizeof(int) * e.NB));
     RX_HIP(hipMalloc(reinterpret_cast<void **>(&snap.gid), sizeof(long long) * e.NB));
   }
   ~Minimiser() {
     auto fr = [](Vec3 &v) { for (int a = 0; a < 3; ++a) if (v.c[a]) (void)hipFree(v.c[a]); };
-    fr(P); fr(G); fr(Gold); fr(snap.pos); fr(snap.vel);
+    fr(P); fr(G); fr(Gold); fr(snap.pos); fr(snap.vel); fr(snap.shl);
     (void)hipFree(snap.q); (void)hipFree(snap.qsfp); (void)hipFree(snap.qsfv); (void)hipFree(snap.type); (void)hipFree(snap.gid);
   }
   void copy3(Vec3 &dst, double *const src[3], int n) { for (int a = 0; a < 3; ++a) RX_HIP(hipMemcpyAsync(dst.c[a], src[a], sizeof(double) * n, hipMemcpyDeviceToDevice, e.stream)); }
@@ -71,6 +78,7 @@ struct Minimiser {
   void save() {
     const int n = e.N; snap.N = n;
     copy3(snap.pos, e.pos, n); copy3(snap.vel, e.vel, n);
+    if (e.ff.pqeq) copy3(snap.shl, e.shl, n);
     RX_HIP(hipMemcpyAsync(snap.q, e.q, sizeof(double) * n, hipMemcpyDeviceToDevice, e.stream));
     RX_HIP(hipMemcpyAsync(snap.qsfp, e.qsfp, sizeof(double) * n, hipMemcpyDeviceToDevice, e.stream));
     RX_HIP(hipMemcpyAsync(snap.qsfv, e.qsfv, sizeof(double) * n, hipMemcpyDeviceToDevice, e.stream));
@@ -80,6 +88,7 @@ struct Minimiser {
   void restore() {
     const int n = snap.N;
     copy3(e.pos, snap.pos, n); copy3(e.vel, snap.vel, n);
+    if (e.ff.pqeq) copy3(e.shl, snap.shl, n);
     RX_HIP(hipMemcpyAsync(e.q, snap.q, sizeof(double) * n, hipMemcpyDeviceToDevice, e.stream));
     RX_HIP(hipMemcpyAsync(e.qsfp, snap.qsfp, sizeof(double) * n, hipMemcpyDeviceToDevice, e.stream));
     RX_HIP(hipMemcpyAsync(e.qsfv, snap.qsfv, sizeof(double) * n, hipMemcpyDeviceToDevice, e.stream));
@@ -167,6 +176,7 @@ int Engine::minimise(double ftol, int max_loops, double *pe_final, long long *ev
     if (std::fabs(genew - geold) <= ftol * m.gnatoms) { ++loop; break; }       // cg.F90:75-80
     const double b1 = m.dot(m.Gold, m.Gold, N), b2 = m.dot(m.G, m.G, N), b3 = m.dot(m.G, m.Gold, N);
     k_direction3<<<nblk(N, 256), 256, 0, stream>>>(N, (b2 - b3) / b1, m.G.c[0], m.G.c[1], m.G.c[2], m.P.c[0], m.P.c[1], m.P.c[2]);   // cg.F90:91
+    if (loop + 1 >= max_loops) { ++loop; break; }          // out of loops: no trial points behind the last evaluation -- forces, PE(1:13), lists and *pe_final all belong to the final positions
     stepl = m.bracket(genew);
   }
   sync_stream();

@@ -210,6 +210,103 @@ __device__ inline int wave_min_int(int v) {
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
   return v;
 }
+// ---- wavefront per row, the row's streams brought in by LDS-DMA (k_spmv_dma) -----------------------------------------------------
+// The row kernel above keeps 4 x 64 entries of a row in flight because every staged load costs VGPRs.  Here a wavefront issues its WHOLE
+// row at once -- value stream, entry words (PQEq: shell-core values) by `global_load_lds_dwordx4 ... nt` into its own LDS slot, no VGPR
+// destination -- waits for it, and then runs the same gather / FMA / reduce / tail over LDS reads.  No roles, no flags: the only
+// difference to k_spmv is where the streams land.  LDS bounds the residency: slot = rowcap * 12 (20) bytes per wavefront.
+template <int MODE, bool STORE, bool PQ, int KH>
+__global__ void __launch_bounds__(1024) k_spmv_dma(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
+                                                   const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
+                                                   const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
+                                                   const double *__restrict__ scal, double *__restrict__ partials,
+                                                   double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
+                                                   const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
+                                                   const int *__restrict__ rowlist, int nrows, int pbase) {
+  extern __shared__ __attribute__((aligned(16))) char dma_smem[];
+  constexpr bool PQS = PQ && (MODE == MODE_GRAD || STORE);
+  constexpr int CAP = 128 * KH;                                     // entries per slot
+  constexpr int SLOT = CAP * (PQS ? 20 : 12);                       // bytes: values, (shell-core values,) entry words
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int widx = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + wv;
+  const int row = rowlist ? (widx < nrows ? rowlist[widx] : N) : widx;
+  char *slot = dma_smem + static_cast<size_t>(wv) * SLOT;
+  const double *hl = reinterpret_cast<const double *>(slot);
+  const double *cl = hl + (PQS ? CAP : 0);
+  const int *il = reinterpret_cast<const int *>(hl + (PQS ? 2 : 1) * CAP);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (row < N) {
+    const int n = n10[row];
+    const int n4 = (n + 3) & ~3;
+    int rowv = row;
+    asm volatile("" : "+v"(rowv));                // tail operands by vector loads, requested before the streams
+    const int pf_t = type[rowv];
+    const double2 pf_a = (MODE == MODE_HSH) ? hst[rowv] : qst[rowv];
+    const double2 pf_b = (MODE == MODE_HSH) ? gst[rowv] : make_double2(q[rowv], 0.0);
+    const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
+    {
+      const size_t base = static_cast<size_t>(row) * S10;
+      const unsigned voff = static_cast<unsigned>(lane) * 16u;
+      const unsigned hb = lds_offset(hl), cb = lds_offset(cl), ib = lds_offset(il);
+      const int gh = n4 >> 1, gi = n4 >> 2;
+#pragma unroll
+      for (int g = 0; g < KH; g += 4) glds16_nt_group<4>(voff, hess + base + 128 * g, hb + 1024u * g, gh - 64 * g);
+      if (PQS) {
+#pragma unroll
+        for (int g = 0; g < KH; g += 4) glds16_nt_group<4>(voff, hsc + base + 128 * g, cb + 1024u * g, gh - 64 * g);
+      }
+#pragma unroll
+      for (int g = 0; g < KH / 2; g += 4) glds16_nt_group<(KH / 2 >= 4 ? 4 : KH / 2)>(voff, nb10 + base + 256 * g, ib + 1024u * g, gi - 64 * g);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+    for (int kb = 0; kb < n4; kb += 64 * UNR) {
+      unsigned e[UNR];
+      double h[UNR], c[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int k = kb + lane + 64 * u;
+        const bool ok = k < n4;
+        e[u] = ok ? static_cast<unsigned>(il[k]) : 0u;
+        h[u] = ok ? hl[k] : 0.0;
+        if (PQS) c[u] = ok ? cl[k] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const double2 v = xv[e[u] & NB10_IDX_MASK];
+        as += h[u] * v.x;
+        at += h[u] * v.y;
+        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }
+        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }
+      }
+    }
+    as = wave_sum(as); at = wave_sum(at);
+    if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+    if (lane == 0) {
+      if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+      const DevAtomP ap = ff.atom[pf_t];
+      if (MODE == MODE_HSH) {
+        const double ts = ap.eta * pf_a.x + as, tt = ap.eta * pf_a.y + at;
+        acc[0] = ts * pf_a.x; acc[1] = tt * pf_a.y;
+        acc[2] = pf_b.x * pf_a.x; acc[3] = pf_b.y * pf_a.y;
+      } else {
+        const double fpq = PQ ? pqrow[row].x : 0.0;
+        const double g1 = -ap.chi - ap.eta * pf_a.x - as - fpq;
+        const double g2 = -1.0 - ap.eta * pf_a.y - at;
+        gst[row] = make_double2(g1, g2);
+        acc[0] = g1 * g1; acc[1] = g2 * g2;
+        const double qi = pf_b.x;
+        const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+        if (PQ) acc[2] = pq_est_row(ap, ff.Zpq[pf_t], pqrow[row], qi, hq_all, gs_ - mu * gt_);
+        else acc[2] = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
+      }
+    }
+  }
+  block_store_partials<4>(acc, partials + static_cast<size_t>(pbase) * 4, 4);
+}
+
 // Which rows a workgroup of the ring pass streams.  contiguous: workgroup w takes rows [w * per, (w + 1) * per).  cyclic (default when
 // the grid is a multiple of 8): the 8 XCDs each own a contiguous eighth of the rows -- the gather vector of an XCD stays in its own L2 --
 // and inside an XCD's range the rows go round-robin over its workgroups, so that at any moment the XCD reads ONE advancing window of the
@@ -656,12 +753,15 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
 __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type,
                                                        const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new,
                                                        const double2 *__restrict__ qst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double *__restrict__ q,
-                                                       double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage) {
+                                                       double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage,
+                                                       int G, const int *__restrict__ invpos, const int *__restrict__ groot, double2 *__restrict__ xs) {
   const double mu = scal[S_MU], b1 = scal[S_BETA_S], b2 = scal[S_BETA_T];
   double es = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     const double2 g = gst[i], h = hst[i];
-    hst_new[i] = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
+    const double2 hn = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
+    hst_new[i] = hn;
+    if (xs) xs[invpos[i]] = hn;                      // single rank: the cell-sorted gather copy of the next matrix pass (QCOPY2, qeq.F90:164) is written here ...
     const DevAtomP ap = ff.atom[type[i]];
     const double2 qv = qst[i], a = sall[i], gh = sgh[i];
     const double qi = qv.x - mu * qv.y;
@@ -670,6 +770,12 @@ __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *_
     if (pqrow) es += pq_est_row(ap, ff.Zpq[type[i]], pqrow[i], qi, hq_all, gh.x - mu * gh.y);
     else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
   }
+  if (xs)                                            // ... including the periodic images: a ghost recomputes the value of its owner (two coalesced-by-owner reads)
+    for (int t = N + blockIdx.x * blockDim.x + threadIdx.x; t < G; t += gridDim.x * blockDim.x) {
+      const int r = groot[t];
+      const double2 g = gst[r], h = hst[r];
+      xs[invpos[t]] = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
+    }
   if (stage < 0) return;
   double acc[4] = {wave_sum(es), 0.0, 0.0, 0.0};
   block_store_partials<4>(acc, partials, 4);
@@ -737,7 +843,9 @@ void Engine::qeq_start_vectors() {
 }
 
 void Engine::allreduce_scal4(int n) {
-  if (nprocs == 1 && !nccl) return;              // forced staged mode of a single rank without a communicator: nothing to add
+  if (nprocs == 1 && !nccl) return;
+  const bool kt = kt_begin(&st.ms_allreduce, nullptr, &st.allreduce_calls);
+  struct End { Engine *e; bool kt; ~End() { e->kt_end(kt); } } end_{this, kt};              // forced staged mode of a single rank without a communicator: nothing to add
   if (nccl) { rccl_allreduce_dev(scal + S_RAW0, n); return; }      // in stream order, no host round trip
   if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm or rxmd_hip_comm_init_rccl first");
   RX_HIP(hipMemcpyAsync(h_scal + 48, scal + S_RAW0, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
@@ -768,7 +876,10 @@ void Engine::qeq() {
   const bool pipe = (std::getenv("RXMD_SPMV_NO_PIPE") == nullptr);        // read per call: the tests switch it
   // the ring kernel (k_spmv_ring): one persistent workgroup per CU.  RXMD_SPMV_RING=0 keeps the wavefront-per-row kernel (which also serves
   // small systems -- a persistent launch has nothing to stream there -- and rows that would not fit the ring)
-  static const int ring_env = std::getenv("RXMD_SPMV_RING") ? std::atoi(std::getenv("RXMD_SPMV_RING")) : 1;
+  static const int ring_env = std::getenv("RXMD_SPMV_RING") ? std::atoi(std::getenv("RXMD_SPMV_RING")) : 0;
+  const int dma_env = std::getenv("RXMD_SPMV_DMA") ? std::atoi(std::getenv("RXMD_SPMV_DMA")) : 0;       // read per call: the tests switch it
+  const int dma_wpb_env = std::getenv("RXMD_DMA_WPB") ? std::atoi(std::getenv("RXMD_DMA_WPB")) : 0;
+  const int dma_lds_env = std::getenv("RXMD_DMA_LDS") ? std::atoi(std::getenv("RXMD_DMA_LDS")) : 0;
   static const int ring_R_env = std::getenv("RXMD_RING_R") ? std::atoi(std::getenv("RXMD_RING_R")) : 0;
   static const int ring_C = std::getenv("RXMD_RING_C") ? std::max(1, std::min(RING_MAXC, std::atoi(std::getenv("RXMD_RING_C")))) : RING_MAXC;
   static const int ring_min_rows = std::getenv("RXMD_RING_MIN_ROWS") ? std::atoi(std::getenv("RXMD_RING_MIN_ROWS")) : 16384;
@@ -806,6 +917,27 @@ void Engine::qeq() {
 #undef RX_RING4
 #undef RX_RING3
       return nwg;
+    }
+    if (dma_env && max_row10 <= 1024 && ff.nso <= 15) {
+      const int kh = max_row10 <= 512 ? 4 : 8;
+      const int slot = 128 * kh * (ff.pqeq ? 20 : 12);
+      const int wpb = std::max(1, std::min(dma_wpb_env > 0 ? dma_wpb_env : 16, (dma_lds_env > 0 ? dma_lds_env : 80 * 1024) / slot));
+      const int nbl = nblk(nr, wpb);
+      if (nbl == 0) return 0;
+#define RX_DMA4(M, S, P, K)                                                                                                                \
+  do {                                                                                                                                     \
+    static bool attr_set = false;                                                                                                          \
+    if (!attr_set) { RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_dma<M, S, P, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }   /* + the static staging of block_store_partials */ \
+    k_spmv_dma<M, S, P, K><<<nbl, 64 * wpb, static_cast<size_t>(wpb) * slot, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nr, pbase); \
+  } while (0)
+#define RX_DMA3(M, S, P) do { if (kh == 4) RX_DMA4(M, S, P, 4); else RX_DMA4(M, S, P, 8); } while (0)
+#define RX_DMA(M, S) do { if (ff.pqeq) RX_DMA3(M, S, true); else RX_DMA3(M, S, false); } while (0)
+      if (mode == MODE_HSH) { if (store) RX_DMA(MODE_HSH, true); else RX_DMA(MODE_HSH, false); }
+      else { if (store) RX_DMA(MODE_GRAD, true); else RX_DMA(MODE_GRAD, false); }
+#undef RX_DMA
+#undef RX_DMA3
+#undef RX_DMA4
+      return nbl;
     }
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return 0;
@@ -851,6 +983,7 @@ void Engine::qeq() {
   bool xs_current = false;       // the fused direction kernel leaves the sorted copy of the new (hs,ht) in xs
   const bool overlap_on = (std::getenv("RXMD_NO_HALO_OVERLAP") == nullptr);     // read per call: the tests switch it
   const bool est_with_update = (std::getenv("RXMD_EST_SEPARATE") == nullptr);
+  const bool cg_scatter = (std::getenv("RXMD_CG_NO_SCATTER") == nullptr);
   const bool overlap = overlap_on && multi() && onepass && !rows_split_pending_invalid();
   bool halo_in_flight = false;
   for (it = 0; it <= nmax - 1; ++it) {
@@ -889,7 +1022,11 @@ void Engine::qeq() {
       // the direction update runs over the residents in atom order (every access coalesced); the cell-sorted copy with the images
       // is one gather pass queued behind it (sorted_copy).  Doing both in one kernel over the sorted positions
       // (five random 16-byte accesses per atom) was 0.4 ms per step slower.
-      k_cg_direction<<<est3 ? vb : vb_upd, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : (fuse ? 5 : 0));
+      // single rank: the direction kernel also scatters the new (hs,ht) to its cell-sorted positions, residents and their periodic images -- the
+      // separate gather pass (k_sorted_vec, 12 us per iteration) is gone (RXMD_CG_NO_SCATTER=1 restores it)
+      const bool scatter = fuse && cg_scatter && it + 1 <= nmax - 1;
+      k_cg_direction<<<est3 ? vb : vb_upd, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : (fuse ? 5 : 0),
+                                                                 G, invpos, groot, scatter ? xs : nullptr);
       if (!fuse && !est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
       if (!est3) {       // PQEq: Est comes out of the direction kernel; the host still waits for this copy only, not for the sorted copy behind it
         RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
@@ -898,7 +1035,7 @@ void Engine::qeq() {
       std::swap(hst, hst2);
       xs_current = false;
       if (!overlap && it + 1 <= nmax - 1) {        // sorted copy (multi-rank: after the (hs,ht) halo) queued before the host waits for Est
-        sorted_copy(hst);
+        if (!scatter) sorted_copy(hst);
         xs_current = true;
       }
       if (overlap && it + 1 <= nmax - 1) {         // overlapped: residents' part of the sorted copy now, halo + ghosts' part on the second stream
@@ -910,6 +1047,7 @@ void Engine::qeq() {
         halo_in_flight = true;
       }
       sync_event(ev_est);
+      collect_timers();
       Est = h_scal[S_EST];
       hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
       st.spmv_launches += 1;

@@ -132,6 +132,23 @@ void Engine::rccl_exchange_pair_sized(int to0, int from0, long long n0, long lon
   rccl_exchange_pair(to0, from0, n0, r0, to1, from1, n1, r1);
 }
 
+// direct halo: one group with every peer (engine.hip: exchange_many); the rank's own segment only in the self-loop test mode
+void Engine::rccl_exchange_many(const std::vector<long long> &soff, const std::vector<long long> &roff, int ncomp) {
+  ncclComm_t c = C(nccl);
+  const int np = (force_staged && nprocs == 1) ? 1 : nprocs;
+  bool any = false;
+  for (int p = 0; p < np && !any; ++p) any = (p != cfg.myid || force_remote) && (soff[p + 1] > soff[p] || roff[p + 1] > roff[p]);
+  if (!any) return;
+  RX_NCCL(ncclGroupStart());
+  for (int p = 0; p < np; ++p) {
+    if (p == cfg.myid && !force_remote) continue;
+    const long long sc = (soff[p + 1] - soff[p]) * ncomp, rc = (roff[p + 1] - roff[p]) * ncomp;
+    if (sc > 0) RX_NCCL(ncclSend(xbuf_send + soff[p] * ncomp, static_cast<size_t>(sc), ncclDouble, p, c, stream));
+    if (rc > 0) RX_NCCL(ncclRecv(xbuf_recv + roff[p] * ncomp, static_cast<size_t>(rc), ncclDouble, p, c, stream));
+  }
+  RX_NCCL(ncclGroupEnd());
+}
+
 // MPI_ALLREDUCE(SUM) of n device doubles, in place, in stream order
 void Engine::rccl_allreduce_dev(double *dev, int n) {
   RX_NCCL(ncclAllReduce(dev, dev, static_cast<size_t>(n), ncclDouble, ncclSum, C(nccl), stream));

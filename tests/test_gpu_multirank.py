@@ -46,6 +46,17 @@ def test_vprocs_parity_vs_mpi_reference(case, steps):
         assert o["nex"] > 0 and o["nar"] > 0
 
 
+@pytest.mark.parametrize("case,steps", [("rdx222_v222_md3", 3), ("example2_v211_md3", 3)])
+def test_direct_vector_halo_vs_mpi_reference(case, steps, monkeypatch):
+    """RXMD_HALO_DIRECT=1: every ghost value of a QEq vector / charge halo comes straight from the rank that owns the atom (owner rank and
+    owner index travel with the ghost build, one request phase per build, then ONE exchange with all peers per halo) instead of the
+    reference's x -> y -> z forwarding (comm.F90:68-86).  8 ranks of a 2 x 2 x 2 grid have 7 distinct peers each; the messages go through
+    the host-staged callbacks (np - 1 shifted send_recv rounds).  Same goldens of the real MPI reference as the staged halo: per-rank
+    order, charges, forces, positions after 3 MD steps."""
+    monkeypatch.setenv("RXMD_HALO_DIRECT", "1")
+    test_vprocs_parity_vs_mpi_reference(case, steps)
+
+
 @pytest.mark.parametrize("case,steps,qeq_mode", [("rdx222_v211_tight", 0, 0), ("example2_v211_md3", 3, 1)])
 def test_native_rccl_with_real_peers_vs_mpi_reference(case, steps, qeq_mode):
     """The native transport with REAL peers: one process per GPU, ncclSend/ncclRecv/ncclAllReduce between two MI355X (runs only on a
@@ -109,8 +120,8 @@ def test_a_rank_that_owns_no_atom(qeq_mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("qeq_mode,overlap", [(0, True), (1, True), (1, False)])
-def test_native_rccl_transport_self_loop(qeq_mode, overlap, monkeypatch):
+@pytest.mark.parametrize("qeq_mode,overlap,direct", [(0, True, False), (1, True, False), (1, False, False), (1, True, True), (1, False, True)])
+def test_native_rccl_transport_self_loop(qeq_mode, overlap, direct, monkeypatch):
     """The native transport (rccl_comm.hip: ncclSend/ncclRecv/ncclAllReduce on the engine's stream) on ONE GPU: a single rank is
     pushed through the staged six-stage exchange (RXMD_FORCE_STAGED) and every message through RCCL send/recv to itself
     (RXMD_FORCE_REMOTE) -- the code path of vprocs > 1 minus the wire.  Must reproduce the single-rank oracle trajectory."""
@@ -122,6 +133,8 @@ def test_native_rccl_transport_self_loop(qeq_mode, overlap, monkeypatch):
     monkeypatch.setenv("RXMD_FORCE_REMOTE", "1")
     if not overlap:          # default: the (hs,ht) halo runs on a second stream under the interior rows of the matrix pass (qeq_mode 1)
         monkeypatch.setenv("RXMD_NO_HALO_OVERLAP", "1")
+    if direct:               # the direct vector halo (one grouped RCCL exchange; here the only peer is the rank itself)
+        monkeypatch.setenv("RXMD_HALO_DIRECT", "1")
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
     e = _engine("rdx222", (2, 2, 2), qeq_mode=qeq_mode, **kw)
     e.init_rccl(e.rccl_unique_id(), 0, 1)

@@ -756,3 +756,52 @@ def test_full_size_nve_trajectory_conserves_energy(qeq_mode):
     assert en1["KE"] / n > 1e-5                      # the crystal started at rest and is moving now
     assert abs(en1["qsum"]) <= 1e-6
     e.close()
+
+
+def test_random_velocities_mdmode_0_and_6():
+    """mdmode 0 / 6 (main.F90:54-55 -> INITVELOCITY, init.F90:292-360) on the device: random, so the checks are the properties the reference's
+    routine guarantees -- temperature exactly treq, zero total momentum, unit-variance Gaussian components with the SAME variance for every
+    element (the reference does not weight by mass) -- plus what the counter-based generator adds: an atom's draw depends on its global id
+    only (not on its local index: the same atoms handed over in another order get the same velocities), and a second call draws anew."""
+    import rxmd_amd
+    from rxmd_amd import system
+    UTEMP0 = 503.398008
+    ff, names, frac, lat = oa.make_system("rdx168")
+    lat3, rec = system.geninit(ff, names, frac, lat, mc=(6, 6, 6))
+    n = len(rec)
+    lines = open(ff).read().split("\n"); npar = int(lines[1].split()[0]); nso = int(lines[2 + npar].split()[0])
+    mass = {t + 1: float(lines[2 + npar + 4 + 4 * t][3:].split()[2]) for t in range(nso)}       # param.F90:102-104: name, rat, Val, mass
+    res = []
+    for order in (np.arange(n), np.random.default_rng(3).permutation(n)):
+        e = rxmd_amd.RxmdEngine(ff, lat3)
+        e.set_atoms_rxff(rec[order])
+        e.thermostat(6, treq=300.0)
+        a = e.atoms(); en = e.energy()
+        o = np.argsort(a["gid"])
+        res.append((a["gid"][o], a["v"][o], a["type"][o], en["KE"]))
+        if len(res) == 1:
+            e.thermostat(0, treq=450.0)
+            a2 = e.atoms(); en2 = e.energy()
+            v2 = a2["v"][np.argsort(a2["gid"])]
+        e.close()
+    gid, v, typ, ke = res[0]
+    # temperature: KE per atom = 1.5 treq in the reference's units (init.F90:355-358), i.e. T = KE/n * UTEMP = treq
+    assert abs(ke / n * UTEMP0 * 2.0 / 3.0 - 300.0) <= 1e-9 * 300.0
+    assert abs(en2["KE"] / n * UTEMP0 * 2.0 / 3.0 - 450.0) <= 1e-9 * 450.0
+    m = np.array([mass[int(t)] for t in typ])
+    p = (m[:, None] * v).sum(axis=0)
+    assert np.abs(p).max() <= 1e-9 * (m[:, None] * np.abs(v)).sum()          # centre-of-mass velocity removed
+    # unit-variance Gaussian before the common scale factor: same variance for every element, kurtosis 3, components uncorrelated
+    s_all = v.std()
+    for t in (1, 2, 3, 4):
+        vt = v[typ == t]
+        assert abs(vt.std() / s_all - 1.0) <= 0.03
+    z = v.reshape(-1) / s_all
+    assert abs(z.mean()) <= 0.01 and abs((z ** 4).mean() - 3.0) <= 0.06 and abs((z ** 3).mean()) <= 0.03
+    c = np.corrcoef(v.T)
+    assert np.abs(c - np.eye(3)).max() <= 0.02
+    # keyed by the global id: another local order, the same velocities
+    assert np.array_equal(res[1][0], gid)
+    assert np.abs(res[1][1] - v).max() <= 1e-12 * np.abs(v).max()
+    # a second call is a new draw
+    assert np.abs(np.corrcoef(v2.reshape(-1), v.reshape(-1))[0, 1]) <= 0.02

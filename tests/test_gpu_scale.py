@@ -126,8 +126,8 @@ def test_perturbed_rdx_36k_against_the_oracle(qeq_mode, oracle36k):
     e.close()
 
 
-@pytest.mark.parametrize("qeq_mode,overlap", [(1, True), (1, False), (0, True)])
-def test_perturbed_rdx_36k_through_the_multi_rank_path(qeq_mode, overlap, oracle36k, monkeypatch):
+@pytest.mark.parametrize("qeq_mode,overlap,direct", [(1, True, False), (1, False, False), (0, True, False), (1, True, True)])
+def test_perturbed_rdx_36k_through_the_multi_rank_path(qeq_mode, overlap, direct, oracle36k, monkeypatch):
     """the vprocs > 1 code path on one GPU (staged six-stage exchange, every message through RCCL send/recv to self, device all-reduces)
     with a REAL interior row set: the matrix pass runs as an interior launch under the (hs,ht) halo and a boundary launch behind it"""
     s0, s1 = oracle36k
@@ -135,6 +135,8 @@ def test_perturbed_rdx_36k_through_the_multi_rank_path(qeq_mode, overlap, oracle
     monkeypatch.setenv("RXMD_FORCE_REMOTE", "1")
     if not overlap:
         monkeypatch.setenv("RXMD_NO_HALO_OVERLAP", "1")
+    if direct:                                   # RXMD_HALO_DIRECT=1: ghost values straight from their owners in one grouped exchange (engine.h)
+        monkeypatch.setenv("RXMD_HALO_DIRECT", "1")
     e = _engine36k(qeq_mode)
     e.init_rccl(e.rccl_unique_id(), 0, 1)
     it, est = e.QEq(); pe = e.FORCE()
