@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
     unsigned long long hmask = static_cast<unsigned long long>(__shfl(static_cast<int>(hslots), src, 64)) & 0xffffffffULL;
     {
       const double xi = x[i], yi = y[i], zi = z[i];
-      const int n = n10[i];
+      const int n = n10[i] & N10_COUNT;
       const size_t row = static_cast<size_t>(i) * S10;
       const int inx_l = (lane >= 1 && lane <= ff.nso) ? ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + lane] : 0;
       int jl = 0; double bl = 0.0;                       // lane s holds atom and bond order of slot s

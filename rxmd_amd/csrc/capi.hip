@@ -384,7 +384,7 @@ int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out) {
       RX_HIP(hipMemcpy(n10.data(), e.n10, sizeof(int) * e.N, hipMemcpyDeviceToHost));
       RX_HIP(hipMemcpy(nb.data(), e.nbrcnt, sizeof(int) * e.G, hipMemcpyDeviceToHost));
       long long s10 = 0, sb = 0; int m10 = 0, mb = 0;
-      for (int v : n10) { s10 += v; m10 = std::max(m10, v); }
+      for (int v : n10) { v &= rxmd::N10_COUNT; s10 += v; m10 = std::max(m10, v); }
       for (int v : nb) { sb += v; mb = std::max(mb, v); }
       e.st.nnz10 = s10; e.st.nbonds = sb; e.st.max_n10 = m10; e.st.max_nb = mb;
     }
@@ -454,10 +454,11 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
       case 3: n = G; if (capacity < 3 * n) throw EngineError(RXMD_E_ARG, "capacity"); for (int a = 0; a < 3; ++a) pull_d(e.pos[a], G, 3, a); break;
       case 4: { n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); std::vector<long long> t(G); RX_HIP(hipMemcpy(t.data(), e.gid, sizeof(long long) * G, hipMemcpyDeviceToHost)); for (int i = 0; i < G; ++i) out[i] = static_cast<double>(t[i]); break; }
       case 5: { n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); std::vector<int> t(G); RX_HIP(hipMemcpy(t.data(), e.type, sizeof(int) * G, hipMemcpyDeviceToHost)); for (int i = 0; i < G; ++i) out[i] = t[i]; break; }
-      case 6: { n = N; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); std::vector<int> t(N); RX_HIP(hipMemcpy(t.data(), e.n10, sizeof(int) * N, hipMemcpyDeviceToHost)); for (int i = 0; i < N; ++i) out[i] = t[i]; break; }
+      case 6: { n = N; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); std::vector<int> t(N); RX_HIP(hipMemcpy(t.data(), e.n10, sizeof(int) * N, hipMemcpyDeviceToHost)); for (int i = 0; i < N; ++i) out[i] = t[i] & rxmd::N10_COUNT; break; }
       case 7: {
         n = N; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity");
         std::vector<int> c(N); RX_HIP(hipMemcpy(c.data(), e.n10, sizeof(int) * N, hipMemcpyDeviceToHost));
+        for (int &v : c) v &= rxmd::N10_COUNT;
         std::vector<double> row(e.S10);
         for (int i = 0; i < N; ++i) {
           RX_HIP(hipMemcpy(row.data(), e.hess + static_cast<size_t>(i) * e.S10, sizeof(double) * c[i], hipMemcpyDeviceToHost));

@@ -117,7 +117,10 @@ __device__ inline int xcd_swizzle(int bid, int nwg) {
 template <int CTRL, int ROW_MASK>
 __device__ inline double dpp_move(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false));
+  // v_mov_dpp with NO defined `old` value (mov_dpp, not update_dpp(0, ...)): a defined one costs a v_mov per DPP move to initialise the
+  // destination (48 of the ~300 vector instructions of a matrix-pass row).  Only the two row broadcasts leave lanes unwritten (rows 0 / 2, rows 0 / 1), and what those lanes
+  // hold afterwards is never read again: the total is taken from lane 63.
+  return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, false), __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, false));
 }
 __device__ inline double wave_sum64(double v) {
   v += dpp_move<0xb1, 0xf>(v);     // quad_perm:[1,0,3,2]
@@ -142,7 +145,7 @@ struct Engine {
 
   // capacities
   int NB = 0, MAXNB = 30, S10 = 0, rows10 = 0;
-  int max_row10 = 0;              // longest row of the current 10 A list
+  int max_row10 = 0, min_row10 = 0;   // longest / shortest row of the current 10 A list
   int2 *rsched[3] = {nullptr, nullptr, nullptr}; bool rsched_valid[3] = {false, false, false};   // ring matrix pass: (row, length) in streaming order per workgroup: all rows / interior / boundary (qeq.hip)
   int num_cu = 256;               // compute units of the device: grid of the persistent kernels (one workgroup per CU)
   int N = 0, G = 0, copyptr[7] = {0};
@@ -196,7 +199,7 @@ struct Engine {
   hipStream_t stream = nullptr;
   // second stream for the halo exchanges that overlap with compute (multi-rank): pack / RCCL send-recv / unpack run here while
   // the main stream works on what does not need the ghosts yet; events order the two (engine.hip: on_comm_stream)
-  hipStream_t comm_stream = nullptr; hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_est = nullptr;   // ev_est: Est of a CG iteration has reached the host
+  hipStream_t comm_stream = nullptr; hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_est = nullptr, ev_spec[2] = {nullptr, nullptr};   // ev_est: Est of a CG iteration has reached the host
   template <class F> void on_comm_stream(F &&body) {          // body runs with `stream` == comm_stream, after everything queued on the main stream so far
     RX_HIP(hipEventRecord(ev_main, stream));
     RX_HIP(hipStreamWaitEvent(comm_stream, ev_main, 0));
@@ -287,6 +290,7 @@ struct Engine {
   void sync_stream();
   void sync_event(hipEvent_t e);
   double comm_timeout_s = 300.0;
+  bool spin_wait = true;
   void allreduce_scal4(int n = 4);                 // MPI_ALLREDUCE of scal[S_RAW0..n-1] (qeq.hip)
   void allreduce_host(double *buf, int n);         // the same for a host vector (setup paths)
   void ghost_build_staged();
@@ -335,6 +339,10 @@ struct Engine {
 constexpr int NB10_IDX_BITS = 26;
 constexpr unsigned NB10_IDX_MASK = (1u << NB10_IDX_BITS) - 1u;
 constexpr unsigned NB10_GHOST = 1u << 30, NB10_SELF = 1u << 31;
+
+// n10[row] = entries of the row; bit 30: the row has a ghost partner (a boundary row of the domain).  The matrix pass needs the sums over
+// ghost columns only there (74 % of the rows of a 979,776-atom domain have none) and reads the flag with the length it needs anyway.
+constexpr int N10_GHOST_ROW = 1 << 30, N10_COUNT = N10_GHOST_ROW - 1;
 
 // device error codes written by kernels into Engine::d_err
 enum { DERR_NONE = 0, DERR_MAXNB = 1, DERR_MAXN10 = 2, DERR_GRID = 3, DERR_NBRINDX = 4, DERR_TYPE = 5 };

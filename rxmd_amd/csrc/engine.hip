@@ -92,6 +92,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
     throw EngineError(RXMD_E_ARG, "efield needs a PQEq parameter file (core charges Z) and a direction 1..3");
   stage_pairs = std::getenv("RXMD_NO_STAGE_PAIRS") == nullptr;
   force_staged = std::getenv("RXMD_FORCE_STAGED") != nullptr; force_remote = std::getenv("RXMD_FORCE_REMOTE") != nullptr;
+  if (const char *sw = std::getenv("RXMD_SPIN_WAIT")) spin_wait = std::atoi(sw) != 0;
   halo_direct = std::getenv("RXMD_HALO_DIRECT") != nullptr && std::atoi(std::getenv("RXMD_HALO_DIRECT")) != 0;
   MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
   if (MAXNB > 31) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 31 (the wavefront-per-centre kernels stage the bond slots of two atoms in one 64-lane wavefront; the reference uses 30)");
@@ -109,6 +110,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   }
   RX_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   RX_HIP(hipEventCreateWithFlags(&ev_est, hipEventDisableTiming));
+  RX_HIP(hipEventCreateWithFlags(&ev_spec[0], hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_spec[1], hipEventDisableTiming));
   for (auto &e : ev) RX_HIP(hipEventCreate(&e));
 }
 
@@ -120,6 +122,7 @@ Engine::~Engine() {
   if (ev_main) (void)hipEventDestroy(ev_main);
   if (ev_comm) (void)hipEventDestroy(ev_comm);
   if (ev_est) (void)hipEventDestroy(ev_est);
+  for (auto &e2 : ev_spec) if (e2) (void)hipEventDestroy(e2);
   if (comm_stream && comm_stream != stream) (void)hipStreamDestroy(comm_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
@@ -164,7 +167,7 @@ void Engine::collect_timers() {
 }
 
 void Engine::check_device_error(const char *where) {
-  RX_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int) * 4, hipMemcpyDeviceToHost, stream));
+  RX_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
   sync_stream();
   const int e = h_err[0];
   if (e == DERR_NONE) return;
@@ -338,10 +341,10 @@ void Engine::alloc_device() {
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dmalloc(scal, 80);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
-  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 64 * sizeof(double)));
-  dmalloc(d_err, 4);
-  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 8 * sizeof(int)));
-  h_cnt = h_err + 4;
+  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 192 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip)
+  dmalloc(d_err, 8);
+  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 16 * sizeof(int)));
+  h_cnt = h_err + 8;
   // hipcub scratch sized for the largest scan / sort we issue
   size_t b1 = 0, b2 = 0;
   hipcub::DeviceScan::ExclusiveSum(nullptr, b1, flags, scanout, NB + 1, stream);
@@ -1284,7 +1287,7 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     build_list10();
     check_device_error("list build");
   }
-  max_row10 = h_err[3];                             // longest 10 A row of this build (k_list10)
+  max_row10 = h_err[3]; min_row10 = std::min(h_err[4], h_err[3]);   // longest / shortest 10 A row of this build (k_list10)
   collect_timers();
   st.ms_lists += toc(0, 1);
   lists_valid = true;

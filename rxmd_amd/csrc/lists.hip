@@ -366,12 +366,14 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
     if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) hsc[row + cnt + lane] = 0.0;
     if (lane == 0) pqrow[i] = make_double4(p_f, p_hz, p_bz, p_ss);
   }
-  { const unsigned long long mg = __ballot(anyghost); if (lane == 0 && rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0; }
+  const unsigned long long mg = __ballot(anyghost);
+  if (lane == 0 && rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0;
   if (lane == 0) {
-    n10[i] = cnt;
+    n10[i] = cnt | (mg != 0ULL ? N10_GHOST_ROW : 0);
     // err[3] = the longest 10 A row of this build (the ring matrix pass issues a fixed number of DMA instructions per row and needs the bound;
     // read with the error word the host waits for anyway).  One atomic per new maximum, not per row.
     if (__hip_atomic_load(&err[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[3], cnt);
+    if (__hip_atomic_load(&err[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cnt) atomicMin(&err[4], cnt);     // ... and the shortest
   }
 }
 
@@ -393,6 +395,7 @@ void Engine::build_bonded_list() {
 void Engine::build_list10() {
   if (const char *pv = std::getenv("RXMD_LIST_PROBE")) grid.probe = std::atoi(pv);
   RX_HIP(hipMemsetAsync(d_err + 3, 0, sizeof(int), stream));
+  RX_HIP(hipMemsetAsync(d_err + 4, 0x7f, sizeof(int), stream));      // 0x7f7f7f7f: larger than any row
   rsched_valid[0] = rsched_valid[1] = rsched_valid[2] = false;
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);

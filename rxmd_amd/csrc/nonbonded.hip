@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64 * NB_WPB) k_nonbond(int N, int S10, DevFF f
   if (i < N) {
     const double xi = x[i], yi = y[i], zi = z[i], qi = q[i];
     const int ti = type[i];
-    const int n = n10[i];
+    const int n = n10[i] & N10_COUNT;
     const size_t row = static_cast<size_t>(i) * S10;
     const int *ix2 = ff.inxn2 + ti * ff.n1;
     double f0 = 0.0, f1 = 0.0, f2 = 0.0;

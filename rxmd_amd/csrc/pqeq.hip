@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_shell_update(int N, int S10, DevFF ff, 
   const double s0 = sx[i], s1 = sy[i], s2 = sz[i];
   const double hx = x[i] + s0, hy = y[i] + s1, hz = z[i] + s2;      // shell position
   const double Zi = ff.Zpq[ti], Ki = ff.Kspq[ti];
-  const int n = n10[i];
+  const int n = n10[i] & N10_COUNT;
   const size_t row = static_cast<size_t>(i) * S10;
   double f0 = 0.0, f1 = 0.0, f2 = 0.0;
   constexpr int SU = 8;                                              // entries per lane and pass, all entry words requested first (as k_nonbond)
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_nonbond_pqeq(int N, int S10, DevFF ff, 
     const double s0 = sx[i], s1 = sy[i], s2 = sz[i];
     const int ti = type[i];
     const double Zi = ff.Zpq[ti], qic = qi + Zi;
-    const int n = n10[i];
+    const int n = n10[i] & N10_COUNT;
     const size_t row = static_cast<size_t>(i) * S10;
     const int *ix2 = ff.inxn2 + ti * ff.n1;
     double f0 = 0.0, f1 = 0.0, f2 = 0.0;

@@ -22,13 +22,20 @@ namespace rxmd {
 
 static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
-enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_RAW0, S_RAW1, S_RAW2, S_RAW3, S_RAW4, S_RAW5, S_RAW6, S_RAW7, S_COUNT };
+enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_RAW0, S_RAW1, S_RAW2, S_RAW3, S_RAW4, S_RAW5, S_RAW6, S_RAW7, S_STOP, S_STOP1, S_TOL, S_COUNT };
 enum { MODE_HSH = 0, MODE_GRAD = 1 };
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef SPMV_UNR
 #define SPMV_UNR 4
 #endif
-constexpr int UNR = SPMV_UNR;   // 4 x 64 = 256 entries in flight per wavefront and pass of the row loop (see k_spmv)
+constexpr int UNR = SPMV_UNR;
+#ifndef SPMV_LEAN_GH
+#define SPMV_LEAN_GH 0
+#endif
+#ifndef SPMV_LEAN_FULL
+#define SPMV_LEAN_FULL 0
+#endif
+constexpr bool LEAN_GH = SPMV_LEAN_GH != 0, LEAN_FULL = SPMV_LEAN_FULL != 0;   // measured and left off: ghost sums only on boundary rows / complete batches without bounds -- fewer vector instructions, not faster   // 4 x 64 = 256 entries in flight per wavefront and pass of the row loop (see k_spmv)
 
 __device__ inline double wave_sum(double v) { return wave_sum64(v); }   // DPP reduction, engine.h
 
@@ -78,7 +85,8 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
                                                const double *__restrict__ scal, double *__restrict__ partials,
                                                double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
                                                const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
-                                               const int *__restrict__ rowlist, int nrows, int pbase) {
+                                               const int *__restrict__ rowlist, int nrows, int pbase, const double *__restrict__ stopflag) {
+  if (stopflag && *stopflag != 0.0) return;        // run-ahead CG loop: the iteration this launch belongs to was decided not to happen (scalar_algebra stage 6)
   // rowlist != nullptr: this launch covers nrows rows named by the list (interior or boundary rows of a multi-rank domain);
   // its workgroups write their partial sums behind the pbase workgroups of the other launch
   const int lane = threadIdx.x & 63;
@@ -103,31 +111,51 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
         if (PQ && (MODE == MODE_GRAD || STORE)) cc[u] = ok ? __builtin_nontemporal_load(hsc + base + k) : 0.0;
       }
     };
-    if (PIPE) request(0, S10, e, h, c);
-    const int n = n10[row];
+    auto request_full = [&](int kb, unsigned (&ee)[UNR], double (&hh)[UNR], double (&cc)[UNR]) {      // a complete batch needs no bounds
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int k = kb + lane + 64 * u;
+        ee[u] = static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k));
+        hh[u] = __builtin_nontemporal_load(hess + base + k);
+        if (PQ && (MODE == MODE_GRAD || STORE)) cc[u] = __builtin_nontemporal_load(hsc + base + k);
+      }
+    };
+    if (PIPE) { if (LEAN_FULL && S10 >= 64 * UNR) request_full(0, e, h, c); else request(0, S10, e, h, c); }
+    const int nraw = n10[row];
+    const int n = nraw & N10_COUNT;
+    // plain QEq: the sums over ghost columns exist only on boundary rows of the domain (the flag rides in the row length, engine.h); on the
+    // other rows -- three in four at 979,776 atoms -- the six vector instructions per batch that select and add them, and their two
+    // wavefront reductions, are not executed (counters: 306 vector instructions per row before, the vector unit busy 51 % of the time)
+    const bool gh_row = PQ || !LEAN_GH || (nraw & N10_GHOST_ROW) != 0;
     // operands of the row tail, requested before the streams so that they are not a further dependent round trip after the reduction
     const int pf_t = type[row];
     const double2 pf_a = (MODE == MODE_HSH) ? hst[row] : qst[row];
     const double2 pf_b = (MODE == MODE_HSH) ? gst[row] : make_double2(q[row], 0.0);
     const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
     double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    if (PIPE) {
+    if (PIPE && (!LEAN_FULL || n < 64 * UNR)) {                  // a row shorter than the first batch: entries behind its end get weight 0 (longer rows skip the re-masking)
 #pragma unroll
       for (int u = 0; u < UNR; ++u) { const bool ok = lane + 64 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; if (PQ) c[u] = ok ? c[u] : 0.0; }
     }
-    for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
-      if (PIPE == 0 || (PIPE == 1 && kb > 0)) request(kb, n, e, h, c);
+    auto accumulate = [&](auto ghc) {
+      constexpr bool GH = decltype(ghc)::value;
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
         const double2 v = xv[e[u] & NB10_IDX_MASK];
         as += h[u] * v.x;
         at += h[u] * v.y;
-        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
+        if (GH && (MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
         if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }      // PQEq: second matrix (shell-core) over the same columns
       }
+    };
+    for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
+      if (PIPE == 0 || (PIPE == 1 && kb > 0)) {
+        if (LEAN_FULL && kb + 64 * UNR <= n) request_full(kb, e, h, c); else request(kb, n, e, h, c);
+      }
+      if (!LEAN_GH || gh_row) accumulate(std::true_type{}); else accumulate(std::false_type{});
     }
     as = wave_sum(as); at = wave_sum(at);
-    if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+    if ((MODE == MODE_GRAD || STORE) && (!LEAN_GH || gh_row)) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
     if (lane == 0) {
       if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
       const DevAtomP ap = ff.atom[pf_t];
@@ -222,7 +250,7 @@ __global__ void __launch_bounds__(1024) k_spmv_dma(int N, int S10, DevFF ff, con
                                                    const double *__restrict__ scal, double *__restrict__ partials,
                                                    double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
                                                    const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
-                                                   const int *__restrict__ rowlist, int nrows, int pbase) {
+                                                   const int *__restrict__ rowlist, int nrows, int pbase, int dma_n4) {
   extern __shared__ __attribute__((aligned(16))) char dma_smem[];
   constexpr bool PQS = PQ && (MODE == MODE_GRAD || STORE);
   constexpr int CAP = 128 * KH;                                     // entries per slot
@@ -238,8 +266,12 @@ __global__ void __launch_bounds__(1024) k_spmv_dma(int N, int S10, DevFF ff, con
   const int *il = reinterpret_cast<const int *>(hl + (PQS ? 2 : 1) * CAP);
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (row < N) {
-    const int n = n10[row];
-    const int n4 = (n + 3) & ~3;
+    // dma_n4 > 0 (the rows of this build are nearly equally long: crystals, liquids): the streams are requested for the LONGEST row's length
+    // without waiting for this row's -- the few entries behind its end lie inside its own ELL slot and get weight 0 below -- so nothing
+    // stands between the wavefront's launch and its stream (the row length arrives while the stream is in flight)
+    int nspec = dma_n4;
+    const int n = (nspec > 0) ? 0 : (n10[row] & N10_COUNT);
+    const int nd4 = (nspec > 0) ? nspec : ((n + 3) & ~3);
     int rowv = row;
     asm volatile("" : "+v"(rowv));                // tail operands by vector loads, requested before the streams
     const int pf_t = type[rowv];
@@ -250,7 +282,7 @@ __global__ void __launch_bounds__(1024) k_spmv_dma(int N, int S10, DevFF ff, con
       const size_t base = static_cast<size_t>(row) * S10;
       const unsigned voff = static_cast<unsigned>(lane) * 16u;
       const unsigned hb = lds_offset(hl), cb = lds_offset(cl), ib = lds_offset(il);
-      const int gh = n4 >> 1, gi = n4 >> 2;
+      const int gh = nd4 >> 1, gi = nd4 >> 2;
 #pragma unroll
       for (int g = 0; g < KH; g += 4) glds16_nt_group<4>(voff, hess + base + 128 * g, hb + 1024u * g, gh - 64 * g);
       if (PQS) {
@@ -261,6 +293,7 @@ __global__ void __launch_bounds__(1024) k_spmv_dma(int N, int S10, DevFF ff, con
       for (int g = 0; g < KH / 2; g += 4) glds16_nt_group<(KH / 2 >= 4 ? 4 : KH / 2)>(voff, nb10 + base + 256 * g, ib + 1024u * g, gi - 64 * g);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    const int n4 = (((nspec > 0) ? (n10[row] & N10_COUNT) : n) + 3) & ~3;
     double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
     for (int kb = 0; kb < n4; kb += 64 * UNR) {
       unsigned e[UNR];
@@ -329,7 +362,7 @@ __global__ void __launch_bounds__(256) k_ring_schedule(int nrows, int nwg, int c
     if (!cyclic) i = w * ((nrows + nwg - 1) / nwg) + k;
     else { const int q = nwg >> 3, x = w / q, j = w - x * q; i = static_cast<int>(static_cast<long long>(nrows) * x / 8) + j + q * k; }
     const int row = rowlist ? rowlist[i] : i;
-    o = make_int2(row, n10[row]);
+    o = make_int2(row, n10[row] & N10_COUNT);
   }
   sched[idx] = o;
 }
@@ -351,7 +384,8 @@ __global__ void __launch_bounds__(1024, 8) k_spmv_ring(int N, int S10, DevFF ff,
   auto flag_load = [](const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   auto flag_store = [](int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int probe = swz >> 8;     // timing experiments only (RXMD_RING_PROBE): 1 consumers only release, 2 no gathers, 3 no DMA
+  const int probe = (swz >> 8) & 0xff;     // timing experiments only (RXMD_RING_PROBE): 1 consumers only release, 2 no gathers, 3 no DMA
+  const bool grouped = (swz >> 16) & 1;      // consumers start the C rows of a group TOGETHER (when the group's last row has landed): consecutive rows share their vector lines in L1
   swz &= 0xff;
   const int wg = swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x);
   // rows of this workgroup: entries [wg * per, wg * per + total) of the schedule (k_ring_schedule): (row, length) pairs in the order it streams them
@@ -455,7 +489,7 @@ __global__ void __launch_bounds__(1024, 8) k_spmv_ring(int N, int S10, DevFF ff,
         int l = flag_load(&ctl->landed[0]);
 #pragma unroll
         for (int r = 1; r < RING_NL; ++r) l = min(l, flag_load(&ctl->landed[r]));
-        if (l > t) break;
+        if (l > (grouped ? min(total - 1, (t / C) * C + C - 1) : t)) break;
         __builtin_amdgcn_s_sleep(1);
       }
       asm volatile("" ::: "memory");
@@ -564,7 +598,7 @@ double ring_probe_ms(Engine &e, int reps) {
   for (int r = 0; r < reps + 1; ++r) {
     if (r == 1) hipEventRecord(e.ev[2], e.stream);
     k_spmv_ring<MODE_HSH, true, false, 4><<<nwg, 64 * (C + RING_NL), lds, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh,
-                                                                           e.hsc, e.pqrow, 1 | (probe << 8), e.rsched[0], cyclic, e.N, 0, R, C);
+                                                                           e.hsc, e.pqrow, 1 | (probe << 8) | (geti("RXMD_RING_GROUP", 0) << 16), e.rsched[0], cyclic, e.N, 0, R, C);
   }
   hipEventRecord(e.ev[3], e.stream);
   hipEventSynchronize(e.ev[3]);
@@ -614,6 +648,8 @@ __device__ inline double block_sum_256(double v, double *sm) {
 // stage 6 (qeq_mode 1, multi-rank): stage 4 and Est in one -- Est is a quadratic in mu whose three coefficients are sums the
 //          update kernel can form before mu exists (k_cg_update<true>), so the iteration needs two all-reduces instead of three
 __device__ inline void scalar_algebra(int stage, double *__restrict__ scal) {
+  const int par = stage >> 4;                     // run-ahead CG loop: which of the two stop flags this iteration's decision goes to (the NEXT iteration's parity)
+  stage &= 15;
   const double r[4] = {scal[S_RAW0], scal[S_RAW1], scal[S_RAW2], scal[S_RAW3]};
   if (stage == 1) {
     scal[S_HSH_S] = r[0]; scal[S_HSH_T] = r[1]; scal[S_GH_S] = r[2]; scal[S_GH_T] = r[3];
@@ -635,7 +671,15 @@ __device__ inline void scalar_algebra(int stage, double *__restrict__ scal) {
     scal[S_GOLD_S] = go_s; scal[S_GOLD_T] = go_t;
     scal[S_GNEW_S] = r[2]; scal[S_GNEW_T] = r[3];
     scal[S_BETA_S] = r[2] / go_s; scal[S_BETA_T] = r[3] / go_t;
-    if (stage == 6) scal[S_EST] = scal[S_RAW4] - mu * scal[S_RAW5] + mu * mu * scal[S_RAW6];
+    if (stage == 6) {
+      const double prev = scal[S_EST], est = scal[S_RAW4] - mu * scal[S_RAW5] + mu * mu * scal[S_RAW6];
+      scal[S_EST] = est;
+      // the exit test the NEXT iteration starts with (qeq.F90:114-115), decided here where Est becomes final: the run-ahead CG loop has
+      // that iteration's kernels queued already, they return at once when the flag is set; the host reads the same flag, it does not re-evaluate
+      const double tol = scal[S_TOL];
+      const bool stop = (0.5 * (fabs(prev) + fabs(est)) < tol) || (fabs(prev) > 0.0 && fabs(est / prev - 1.0) < tol);
+      scal[S_STOP + par] = stop ? 1.0 : 0.0;      // two flags, by iteration parity: the kernels of iteration k read flag k & 1, which only update(k - 1) writes
+    }
   } else {
     scal[S_EST] = r[0];
   }
@@ -678,7 +722,8 @@ __device__ inline void block_finish(int nblocks, double *partials, unsigned *tic
 
 // the matrix pass leaves one partial per workgroup (245k at 979,776 rows): 128 workgroups sum contiguous chunks,
 // the last of them finishes (one launch for level-1 sums, final sum and scalar algebra)
-__global__ void __launch_bounds__(256) k_reduce_fused(int nblocks, const double *__restrict__ partials, double *__restrict__ lvl1, unsigned *ticket, int stage, double *__restrict__ scal) {
+__global__ void __launch_bounds__(256) k_reduce_fused(int nblocks, const double *__restrict__ partials, double *__restrict__ lvl1, unsigned *ticket, int stage, double *__restrict__ scal, const double *__restrict__ stopflag = nullptr) {
+  if (stopflag && *stopflag != 0.0) return;
   __shared__ double sm[256];
   const int per = (nblocks + gridDim.x - 1) / gridDim.x;
   const int b0 = blockIdx.x * per, b1 = min(nblocks, b0 + per);
@@ -716,7 +761,8 @@ __global__ void __launch_bounds__(256) k_update_qst(int N, const double *__restr
 template <bool EST3>
 __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ hst, double2 *__restrict__ qst,
                                                     const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
-                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage) {
+                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage, const double *__restrict__ stopflag) {
+  if (stopflag && *stopflag != 0.0) return;
   const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
   double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
@@ -754,7 +800,8 @@ __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *_
                                                        const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new,
                                                        const double2 *__restrict__ qst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double *__restrict__ q,
                                                        double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage,
-                                                       int G, const int *__restrict__ invpos, const int *__restrict__ groot, double2 *__restrict__ xs) {
+                                                       int G, const int *__restrict__ invpos, const int *__restrict__ groot, double2 *__restrict__ xs, const double *__restrict__ stopflag) {
+  if (stopflag && *stopflag != 0.0) return;
   const double mu = scal[S_MU], b1 = scal[S_BETA_S], b2 = scal[S_BETA_T];
   double es = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
@@ -880,16 +927,19 @@ void Engine::qeq() {
   const int dma_env = std::getenv("RXMD_SPMV_DMA") ? std::atoi(std::getenv("RXMD_SPMV_DMA")) : 0;       // read per call: the tests switch it
   const int dma_wpb_env = std::getenv("RXMD_DMA_WPB") ? std::atoi(std::getenv("RXMD_DMA_WPB")) : 0;
   const int dma_lds_env = std::getenv("RXMD_DMA_LDS") ? std::atoi(std::getenv("RXMD_DMA_LDS")) : 0;
+  const int dma_spec_env = std::getenv("RXMD_DMA_SPEC") ? std::atoi(std::getenv("RXMD_DMA_SPEC")) : 1;
   static const int ring_R_env = std::getenv("RXMD_RING_R") ? std::atoi(std::getenv("RXMD_RING_R")) : 0;
   static const int ring_C = std::getenv("RXMD_RING_C") ? std::max(1, std::min(RING_MAXC, std::atoi(std::getenv("RXMD_RING_C")))) : RING_MAXC;
   static const int ring_min_rows = std::getenv("RXMD_RING_MIN_ROWS") ? std::atoi(std::getenv("RXMD_RING_MIN_ROWS")) : 16384;
   static const int ring_wg_env = std::getenv("RXMD_RING_WG") ? std::atoi(std::getenv("RXMD_RING_WG")) : 0;
   static const int ring_cyclic = std::getenv("RXMD_RING_CYCLIC") ? std::atoi(std::getenv("RXMD_RING_CYCLIC")) : 1;
+  static const int ring_group = std::getenv("RXMD_RING_GROUP") ? std::atoi(std::getenv("RXMD_RING_GROUP")) : 0;
   static const int ring_probe = std::getenv("RXMD_RING_PROBE") ? std::atoi(std::getenv("RXMD_RING_PROBE")) : 0;
   const int ring_R = ring_R_env > 0 ? (ring_R_env & ~63) : (ff.pqeq ? 3584 : 6144);        // ring entries of 12 (PQEq: 20) bytes: with the control block < 80 KB, two workgroups per CU
   const size_t ring_lds = static_cast<size_t>(ring_R) * (ff.pqeq ? 20 : 12) + sizeof(RingCtl);
   const int ring_wgs = ring_wg_env > 0 ? ring_wg_env : 2 * num_cu;
   // returns the number of partial-sum sets (of four) the launch leaves behind partials[pbase * 4]
+  const double *stopflag = nullptr;            // run-ahead CG loop only: kernels of an iteration return at once when scal[S_STOP] is set
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) -> int {
     const int nr = rowlist ? nrows : N;
     if (ring_env && max_row10 <= std::min(ring_R, 1024) && nr >= ring_min_rows && ring_lds <= 160 * 1024 && ff.nso <= 15) {
@@ -907,7 +957,7 @@ void Engine::qeq() {
   do {                                                                                                                                     \
     static bool attr_set = false;                                                                                                          \
     if (!attr_set) { RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_ring<M, S, P, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
-    k_spmv_ring<M, S, P, K><<<nwg, 64 * (ring_C + RING_NL), ring_lds, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz | (ring_probe << 8), sched, cyclic, nr, pbase, ring_R, ring_C); \
+    k_spmv_ring<M, S, P, K><<<nwg, 64 * (ring_C + RING_NL), ring_lds, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz | (ring_probe << 8) | (ring_group << 16), sched, cyclic, nr, pbase, ring_R, ring_C); \
   } while (0)
 #define RX_RING3(M, S, P) do { if (max_row10 <= 512) RX_RING4(M, S, P, 4); else RX_RING4(M, S, P, 8); } while (0)
 #define RX_RING(M, S) do { if (ff.pqeq) RX_RING3(M, S, true); else RX_RING3(M, S, false); } while (0)
@@ -924,11 +974,13 @@ void Engine::qeq() {
       const int wpb = std::max(1, std::min(dma_wpb_env > 0 ? dma_wpb_env : 16, (dma_lds_env > 0 ? dma_lds_env : 80 * 1024) / slot));
       const int nbl = nblk(nr, wpb);
       if (nbl == 0) return 0;
+      // rows nearly equally long (the longest within 12 % of the shortest): request every row's streams for the longest row's length, no dependent row-length load first
+      const int dma_n4 = (dma_spec_env && min_row10 > 0 && max_row10 * 100 <= min_row10 * 112) ? ((max_row10 + 3) & ~3) : 0;
 #define RX_DMA4(M, S, P, K)                                                                                                                \
   do {                                                                                                                                     \
     static bool attr_set = false;                                                                                                          \
     if (!attr_set) { RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spmv_dma<M, S, P, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }   /* + the static staging of block_store_partials */ \
-    k_spmv_dma<M, S, P, K><<<nbl, 64 * wpb, static_cast<size_t>(wpb) * slot, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nr, pbase); \
+    k_spmv_dma<M, S, P, K><<<nbl, 64 * wpb, static_cast<size_t>(wpb) * slot, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nr, pbase, dma_n4); \
   } while (0)
 #define RX_DMA3(M, S, P) do { if (kh == 4) RX_DMA4(M, S, P, 4); else RX_DMA4(M, S, P, 8); } while (0)
 #define RX_DMA(M, S) do { if (ff.pqeq) RX_DMA3(M, S, true); else RX_DMA3(M, S, false); } while (0)
@@ -941,7 +993,7 @@ void Engine::qeq() {
     }
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return 0;
-#define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase)
+#define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase, stopflag)
 #define RX_PASS(M, S)                                                                                                  \
   do {                                                                                                                 \
     if (ff.pqeq) { if (pipe) RX_PASS3(M, S, true, 1); else RX_PASS3(M, S, true, 0); }                                  \
@@ -955,8 +1007,8 @@ void Engine::qeq() {
   };
   auto reduce = [&](int stage, int nb_) {
     if (!multi()) {                              // single rank: level-1 sums, final sum and scalar algebra in one launch
-      if (nb_ > 1024) k_reduce_fused<<<128, 256, 0, stream>>>(nb_, partials, lvl1, tickets, stage, scal);
-      else k_reduce_fused<<<1, 256, 0, stream>>>(nb_, partials, lvl1, tickets, stage, scal);
+      if (nb_ > 1024) k_reduce_fused<<<128, 256, 0, stream>>>(nb_, partials, lvl1, tickets, stage, scal, stopflag);
+      else k_reduce_fused<<<1, 256, 0, stream>>>(nb_, partials, lvl1, tickets, stage, scal, stopflag);
       return;
     }
     if (nb_ > 1024) k_reduce_fused<<<128, 256, 0, stream>>>(nb_, partials, lvl1, tickets, 0, scal);   // stage 0: rank-local sums only
@@ -965,6 +1017,8 @@ void Engine::qeq() {
     k_scalar_algebra<<<1, 64, 0, stream>>>(stage, scal);
   };
   RX_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 32, stream));
+  h_scal[60] = cfg.QEq_tol;
+  RX_HIP(hipMemcpyAsync(scal + S_TOL, h_scal + 60, sizeof(double), hipMemcpyHostToDevice, stream));
   const bool onepass = (cfg.qeq_mode == 1);
   if (sums_from_list) {
     k_grad_start<<<vb, 256, 0, stream>>>(N, dff, type, qst, q, sall, sgh, gst, partials, pqrow);
@@ -986,6 +1040,59 @@ void Engine::qeq() {
   const bool cg_scatter = (std::getenv("RXMD_CG_NO_SCATTER") == nullptr);
   const bool overlap = overlap_on && multi() && onepass && !rows_split_pending_invalid();
   bool halo_in_flight = false;
+  // ---- run-ahead loop (single rank, qeq_mode 1, plain QEq; RXMD_CG_NO_RUNAHEAD=1 switches it off) ------------------------------------
+  // The host is one iteration BEHIND the device: iteration it is queued in full before the host has seen the Est that decides whether it
+  // happens.  The decision (qeq.F90:114-115) is made on the device where Est becomes final (scalar_algebra stage 6 -> scal[S_STOP]); the
+  // kernels of an iteration that is not to happen return at once; the host reads the same flag.  Iteration counts, charges and every
+  // sum are those of the loop below -- what changes is that no host round trip lies between two iterations (on a host that shares its
+  // cores with other jobs the blocking loop lost 90 us per iteration: 172 against 80 us of everything that is not the matrix pass).
+  const bool runahead = !multi() && onepass && !ff.pqeq && est_with_update && std::getenv("RXMD_CG_NO_RUNAHEAD") == nullptr;
+  if (runahead) {
+    auto exit_test = [&](double prev, double est) {
+      return (0.5 * (std::fabs(prev) + std::fabs(est)) < cfg.QEq_tol) || (std::fabs(prev) > 0.0 && std::fabs(est / prev - 1.0) < cfg.QEq_tol);
+    };
+    auto enqueue = [&](int k) {                    // everything of iteration k; on the device a no-op when its stop flag is set
+      stopflag = (k == 0) ? nullptr : scal + S_STOP + (k & 1);    // iteration 0 is decided by the host (Est of the start vector is here already)
+      if (!xs_current) sorted_copy(hst);           // first iteration only: afterwards the direction kernel leaves the sorted copy behind
+      xs_current = false;
+      const bool kt = kt_begin(&st.ms_qeq_spmv);
+      const int np1 = pass(MODE_HSH, true, wall, wgh);
+      kt_end(kt);
+      reduce(1, np1);
+      k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag);
+      RX_HIP(hipMemcpyAsync(h_scal + 64 + 64 * (k & 1), scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
+      RX_HIP(hipEventRecord(ev_spec[k & 1], stream));
+      const bool scatter = cg_scatter && k + 1 <= nmax - 1;
+      k_cg_direction<<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, stopflag);
+      std::swap(hst, hst2);
+      if (k + 1 <= nmax - 1) { if (!scatter) sorted_copy(hst); xs_current = true; }
+    };
+    it = 0;
+    if (nmax >= 1 && !exit_test(GEst2, Est)) {
+      GEst2 = Est;
+      enqueue(0);
+      for (it = 1;; ++it) {
+        const bool queued = it <= nmax - 1;
+        if (queued) enqueue(it);                   // ahead of the decision
+        sync_event(ev_spec[(it - 1) & 1]);         // iteration it - 1 has produced its Est and the decision about iteration it
+        collect_timers();
+        const double *hs = h_scal + 64 + 64 * ((it - 1) & 1);
+        Est = hs[S_EST];
+        st.spmv_launches += 1;
+        if (!queued) break;                        // NMAXQEq iterations done
+        if (hs[S_STOP + (it & 1)] != 0.0) { std::swap(hst, hst2); break; }       // iteration it did not happen: its direction kernel wrote nothing, undo the swap
+        GEst2 = Est;
+      }
+      stopflag = nullptr;
+    }
+    if (ff.pqeq) pqeq_update_shells();
+    nstep_qeq = it; last_est = Est;
+    st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1;
+    sync_stream();                                 // the kernels of an iteration that did not happen are still in the queue: cheap, but they read scal
+    collect_timers();
+    st.ms_qeq += toc(6, 7);
+    return;
+  }
   for (it = 0; it <= nmax - 1; ++it) {
     if (0.5 * (std::fabs(GEst2) + std::fabs(Est)) < cfg.QEq_tol) break;                          // qeq.F90:114
     if (std::fabs(GEst2) > 0.0 && std::fabs(Est / GEst2 - 1.0) < cfg.QEq_tol) break;            // qeq.F90:115
@@ -1015,8 +1122,8 @@ void Engine::qeq() {
       // iteration instead of three; any rank count: Est is final BEFORE the direction kernel, so its copy to the host, the host's exit
       // test and the launch of the next matrix pass all run underneath the direction update and the sorted copy / halo
       const bool est3 = !ff.pqeq && est_with_update;
-      if (est3) k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 6 : 0);
-      else k_cg_update<false><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0);
+      if (est3) k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 6 : 0, nullptr);
+      else k_cg_update<false><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0, nullptr);
       if (!fuse) { allreduce_scal4(est3 ? 8 : 4); k_scalar_algebra<<<1, 64, 0, stream>>>(est3 ? 6 : 4, scal); }
       if (est3) { RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream)); RX_HIP(hipEventRecord(ev_est, stream)); }
       // the direction update runs over the residents in atom order (every access coalesced); the cell-sorted copy with the images
@@ -1026,7 +1133,7 @@ void Engine::qeq() {
       // separate gather pass (k_sorted_vec, 12 us per iteration) is gone (RXMD_CG_NO_SCATTER=1 restores it)
       const bool scatter = fuse && cg_scatter && it + 1 <= nmax - 1;
       k_cg_direction<<<est3 ? vb : vb_upd, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : (fuse ? 5 : 0),
-                                                                 G, invpos, groot, scatter ? xs : nullptr);
+                                                                 G, invpos, groot, scatter ? xs : nullptr, nullptr);
       if (!fuse && !est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
       if (!est3) {       // PQEq: Est comes out of the direction kernel; the host still waits for this copy only, not for the sorted copy behind it
         RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));

@@ -65,7 +65,12 @@ void Engine::sync_stream() {
   watched_wait(*this, [&] { return hipStreamQuery(stream); }, "stream synchronisation");
 }
 void Engine::sync_event(hipEvent_t ev_) {
-  if (!nccl) { RX_HIP(hipEventSynchronize(ev_)); return; }
+  if (!nccl) {
+    // the per-iteration wait of the CG loop: on some hosts a blocking wait wakes up 50-100 us after the event (the GPU then idles between
+    // the iterations); spin_wait polls instead (RXMD_SPIN_WAIT=0: the blocking wait)
+    if (spin_wait) { hipError_t r; while ((r = hipEventQuery(ev_)) == hipErrorNotReady) {} if (r != hipSuccess) RX_HIP(r); return; }
+    RX_HIP(hipEventSynchronize(ev_)); return;
+  }
   watched_wait(*this, [&] { return hipEventQuery(ev_); }, "event synchronisation");
 }
 

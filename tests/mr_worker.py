@@ -121,3 +121,31 @@ def engine_rank_rccl(rank, world, port, case, vp, steps, qeq_mode, out):
         dist.barrier(); dist.destroy_process_group()
     except Exception:
         out[rank] = dict(error=traceback.format_exc())
+
+
+def engine_rank_perturbed(rank, world, port, vp, steps, qeq_mode, out):
+    """one rank of the 36,288-atom perturbed RDX system of tests/test_gpu_scale.py; all ranks share GPU 0, messages staged over gloo"""
+    try:
+        dist = _init(rank, world, port)
+        import torch
+        import rxmd_amd
+        from rxmd_amd.comm import TorchTransport
+        import test_gpu_scale as ts
+        ff, lat2, ranks, vs = ts._perturbed_rdx(vp)
+        r = ranks[rank]
+        n = len(r["type"])
+        rec = np.zeros((n, 10))
+        rec[:, 0:3] = r["rnorm"]; rec[:, 3:6] = vs[rank]; rec[:, 7] = r["type"] + r["gid"] * 1e-13
+        e = rxmd_amd.RxmdEngine(ff, lat2, vprocs=vp, myid=rank, device=0, qeq_mode=qeq_mode, **ts.KW)
+        tr = TorchTransport(mode="staged", device=torch.device("cuda", 0), capacity_doubles=1 << 22)
+        tr.attach(e)
+        e.set_atoms_rxff(rec)
+        e.QEq(); e.FORCE()
+        if steps:
+            e.step(steps)
+        a = e.atoms(); st = e.stats()
+        out[rank] = dict(gid=a["gid"], q=a["q"], f=a["f"], pos=a["pos"], natoms=st["natoms"], n_boundary_rows=st["n_boundary_rows"], err=repr(tr.error))
+        e.close()
+        dist.barrier(); dist.destroy_process_group()
+    except Exception:
+        out[rank] = dict(error=traceback.format_exc())

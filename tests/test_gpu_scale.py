@@ -33,8 +33,9 @@ KW = dict(QEq_tol=1e-300, NMAXQEq=100)
 NSTEPS = 3
 
 
-def _perturbed_rdx():
-    """RDX 6x6x6 as geninit lays it out, every atom displaced by N(0, 0.05 A) per component, velocities N(0, 0.05) (230 K)"""
+def _perturbed_rdx(vprocs=(1, 1, 1)):
+    """RDX 6x6x6 as geninit lays it out, every atom displaced by N(0, 0.05 A) per component, velocities N(0, 0.05) (230 K); with vprocs the
+    atoms are dealt to the domains of the rank grid the way geninit does (geninit.F90:493-527) -> (ffield, lattice, per-rank dicts, per-rank v)"""
     ff, names, frac, lat = oa.make_system("rdx168")
     lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=MC)
     rng = np.random.default_rng(2026)
@@ -42,9 +43,21 @@ def _perturbed_rdx():
     rn = ranks[0]["rnorm"] + rng.normal(0, 0.05, (n, 3)) / np.asarray(lat2[:3])
     # back into [0, 1) like geninit (geninit.F90:476-480) and every COPYATOMS(MODE_MOVE) leave them: a resident outside the box is not
     # a state the reference's driver produces (its QEq ghost shell of exactly rctap would miss partners of such an atom)
-    ranks[0]["rnorm"] = rn - np.floor(rn)
+    rn = rn - np.floor(rn)
     v = rng.normal(0, 0.05, (n, 3))
-    return ff, lat2, ranks, v
+    if tuple(vprocs) == (1, 1, 1):
+        ranks[0]["rnorm"] = rn
+        return ff, lat2, ranks, v
+    vp = np.array(vprocs)
+    dom = (rn * vp).astype(np.int64)
+    sid = dom[:, 0] + dom[:, 1] * vp[0] + dom[:, 2] * vp[0] * vp[1]
+    out, vs = [], []
+    for p in range(int(vp.prod())):
+        sel = np.nonzero(sid == p)[0]
+        obox = (1.0 / vp) * np.array([p % vp[0], (p // vp[0]) % vp[1], p // (vp[0] * vp[1])])
+        out.append(dict(rnorm=rn[sel] - obox, type=ranks[0]["type"][sel].copy(), gid=ranks[0]["gid"][sel].copy()))
+        vs.append(v[sel].copy())
+    return ff, lat2, out, vs
 
 
 @pytest.fixture(scope="module")
@@ -177,3 +190,36 @@ def test_forces_of_the_979776_atom_crystal_by_periodicity():
     e.set_charges(np.tile(qo[1, 1, 1], 18 ** 3))
     e.FORCE(); a = e.atoms(); e.close()
     assert f_err(inner(a["f"], (3,)), fref) <= FTOL
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_perturbed_rdx_36k_on_two_ranks_against_the_two_rank_oracle(direct, monkeypatch):
+    """the 36,288-atom perturbed crystal as a 2 x 1 x 1 decomposition: two engine ranks (one GPU, messages host-staged over gloo) against the
+    oracle run with the same vprocs -- per-rank local order after three migrations, charges, forces, positions.  Both halves of the box
+    have interior rows (the two-launch matrix pass under the halo) and boundary rows; `direct`: the owner-to-ghost vector halo."""
+    import socket
+    import torch.multiprocessing as mp
+    import mr_worker
+    if direct:
+        monkeypatch.setenv("RXMD_HALO_DIRECT", "1")
+    vp = (2, 1, 1)
+    ff, lat2, ranks, vs = _perturbed_rdx(vp)
+    nmax = max(len(r["type"]) for r in ranks)
+    o = oa.Oracle(ff, lat2, ranks, vprocs=vp, nbuffer=10 * nmax, v0=vs, **KW)
+    o.qeq(); o.force(); o.step(NSTEPS)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        ps = [ctx.Process(target=mr_worker.engine_rank_perturbed, args=(r, 2, port, vp, NSTEPS, 1, out)) for r in range(2)]
+        [p.start() for p in ps]; [p.join(900) for p in ps]
+        assert len(out) == 2, "a rank died"
+        res = [out[r] for r in range(2)]
+    for r, x in enumerate(res):
+        assert "error" not in x, x.get("error")
+        assert x["err"] == "None"
+        assert 0 < x["n_boundary_rows"] < x["natoms"]
+        assert np.array_equal(x["gid"], o.gids(r))
+        assert np.abs(x["pos"] - o.pos(r)).max() <= 1e-9
+        assert q_err(x["q"], o.charges(r)) <= QTOL
+        assert f_err(x["f"], o.forces(r)) <= FTOL
