@@ -179,6 +179,108 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
   block_store_partials<4>(acc, partials + static_cast<size_t>(pbase) * 4, 4);
 }
 
+// ---- two rows per wavefront, SIDE BY SIDE (k_spmv2) -----------------------------------------------------------------------------
+// Every form of the pass measured so far turns a row around in 0.92-0.97 ns chip-wide whatever the row holds -- RDX 430 entries, water 357,
+// the SiC + O2 system 212 with a third stream -- i.e. a CU finishes a row every 240 ns with its 32 wavefronts, each alive 6.5 us: the fixed
+// part of a wavefront's life (launch, kernel arguments, row length, first batch, gathers, reduction, tail, the workgroup barrier of the
+// partial sums) bounds the pass, and 32 wavefronts per CU is the hardware's limit.  Here a wavefront holds TWO rows at the same time, lanes
+// 0-31 one and lanes 32-63 the other: 64 rows in flight per CU, the fixed part paid once per pair.  (Two rows one AFTER the other in a
+// wavefront -- round 2 -- left the rows in flight at 32 and lost.)  A lane walks its row with stride 32; the four sums of a row are reduced
+// inside its half (five DPP steps: the four inside a row of 16 lanes, then row 0 -> 1 and 2 -> 3); lane 16 of each half runs the row tail.
+__device__ inline double half_sum32(double v) {    // sum over the 32 lanes of a half; valid in lanes 16-31 (first half) and 48-63 (second half)
+  v += dpp_move<0xb1, 0xf>(v);
+  v += dpp_move<0x4e, 0xf>(v);
+  v += dpp_move<0x141, 0xf>(v);
+  v += dpp_move<0x140, 0xf>(v);
+  v += dpp_move<0x142, 0xa>(v);                    // row_bcast:15 into rows 1 and 3
+  return v;
+}
+template <int MODE, bool STORE, bool PQ>
+__global__ void __launch_bounds__(1024) k_spmv2(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
+                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
+                                                const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
+                                                const double *__restrict__ scal, double *__restrict__ partials,
+                                                double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
+                                                const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
+                                                const int *__restrict__ rowlist, int nrows, int pbase, const double *__restrict__ stopflag) {
+  if (stopflag && *stopflag != 0.0) return;
+#ifndef SPMV2_U
+#define SPMV2_U 8
+#endif
+  constexpr int U2 = SPMV2_U;                       // U2 x 32 entries of each row in flight per trip
+  const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+  const int wpb = blockDim.x >> 6;
+  const int widx = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int ridx = 2 * widx + half;
+  const int row = rowlist ? (ridx < nrows ? rowlist[ridx] : N) : (ridx < nrows ? ridx : N);
+  const bool live = row < N;
+  const int rowc = live ? row : 0;
+  const size_t base = static_cast<size_t>(rowc) * S10;
+  unsigned e[U2];
+  double h[U2], c[U2];
+  auto request = [&](int kb, int bound) {
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      const int k = kb + hl + 32 * u;
+      const bool ok = k < bound;
+      e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;
+      h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;
+      if (PQ && (MODE == MODE_GRAD || STORE)) c[u] = ok ? __builtin_nontemporal_load(hsc + base + k) : 0.0;
+    }
+  };
+  request(0, live ? S10 : 0);                       // before the row length is known: the first batch lies inside the row's slot whatever the length
+  const int n = live ? (n10[rowc] & N10_COUNT) : 0;
+  const int pf_t = type[rowc];
+  const double2 pf_a = (MODE == MODE_HSH) ? hst[rowc] : qst[rowc];
+  const double2 pf_b = (MODE == MODE_HSH) ? gst[rowc] : make_double2(q[rowc], 0.0);
+  const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
+  const int nmax = max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 32));
+#pragma unroll
+  for (int u = 0; u < U2; ++u) { const bool ok = hl + 32 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; if (PQ) c[u] = ok ? c[u] : 0.0; }
+  double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+  for (int kb = 0; kb < nmax; kb += 32 * U2) {     // wave-uniform trip count: the longer of the two rows
+    if (kb > 0) request(kb, n);
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      const double2 v = xv[e[u] & NB10_IDX_MASK];
+      as += h[u] * v.x;
+      at += h[u] * v.y;
+      if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }
+      if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }
+    }
+  }
+  as = half_sum32(as); at = half_sum32(at);
+  if (MODE == MODE_GRAD || STORE) { gs_ = half_sum32(gs_); gt_ = half_sum32(gt_); }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (hl == 16 && live) {
+    if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+    const DevAtomP ap = ff.atom[pf_t];
+    if (MODE == MODE_HSH) {
+      const double ts = ap.eta * pf_a.x + as, tt = ap.eta * pf_a.y + at;      // qeq.F90:294-302
+      acc[0] = ts * pf_a.x; acc[1] = tt * pf_a.y;                             // hshs_sum, hsht_sum (:309-310)
+      acc[2] = pf_b.x * pf_a.x; acc[3] = pf_b.y * pf_a.y;                     // g.h (:119,123)
+    } else {
+      const double fpq = PQ ? pqrow[row].x : 0.0;
+      const double g1 = -ap.chi - ap.eta * pf_a.x - as - fpq;                 // qeq.F90:349-350 (pqeq.F90:466)
+      const double g2 = -1.0 - ap.eta * pf_a.y - at;
+      gst[row] = make_double2(g1, g2);
+      acc[0] = g1 * g1; acc[1] = g2 * g2;                                     // Gnew (:355-356)
+      const double qi = pf_b.x;
+      const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+      if (PQ) acc[2] = pq_est_row(ap, ff.Zpq[pf_t], pqrow[row], qi, hq_all, gs_ - mu * gt_);
+      else acc[2] = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
+    }
+  }
+  // the wavefront's partial = first row + second row (lanes 16 and 48), handed to lane 0 for the workgroup's fixed-order sum
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double a16 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(acc[k]), 16), __builtin_amdgcn_readlane(__double2loint(acc[k]), 16));
+    const double a48 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(acc[k]), 48), __builtin_amdgcn_readlane(__double2loint(acc[k]), 48));
+    acc[k] = a16 + a48;
+  }
+  block_store_partials<4>(acc, partials + static_cast<size_t>(pbase) * 4, 4);
+}
+
 // ---- the matrix pass as a packed stream through an LDS ring (LDS-DMA) ---------------------------------------------------------
 // One persistent workgroup per CU owns a contiguous range of rows.  Wave 0 (the LOADER) streams the used part of consecutive rows --
 // hessian values, packed entries, PQEq: shell-core values -- from their ELL slots straight into LDS rings with
@@ -924,6 +1026,7 @@ void Engine::qeq() {
   // the ring kernel (k_spmv_ring): one persistent workgroup per CU.  RXMD_SPMV_RING=0 keeps the wavefront-per-row kernel (which also serves
   // small systems -- a persistent launch has nothing to stream there -- and rows that would not fit the ring)
   static const int ring_env = std::getenv("RXMD_SPMV_RING") ? std::atoi(std::getenv("RXMD_SPMV_RING")) : 0;
+  const int spmv2_env = std::getenv("RXMD_SPMV2") ? std::atoi(std::getenv("RXMD_SPMV2")) : 0;    // read per call
   const int dma_env = std::getenv("RXMD_SPMV_DMA") ? std::atoi(std::getenv("RXMD_SPMV_DMA")) : 0;       // read per call: the tests switch it
   const int dma_wpb_env = std::getenv("RXMD_DMA_WPB") ? std::atoi(std::getenv("RXMD_DMA_WPB")) : 0;
   const int dma_lds_env = std::getenv("RXMD_DMA_LDS") ? std::atoi(std::getenv("RXMD_DMA_LDS")) : 0;
@@ -942,7 +1045,9 @@ void Engine::qeq() {
   const double *stopflag = nullptr;            // run-ahead CG loop only: kernels of an iteration return at once when scal[S_STOP] is set
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) -> int {
     const int nr = rowlist ? nrows : N;
-    if (ring_env && max_row10 <= std::min(ring_R, 1024) && nr >= ring_min_rows && ring_lds <= 160 * 1024 && ff.nso <= 15) {
+    // (not with PQEq: at the 64 registers two workgroups per CU allow, its instances spill, and a scratch access in the loader wave would break
+    // the loader's own count of its outstanding DMA instructions)
+    if (ring_env && !ff.pqeq && max_row10 <= std::min(ring_R, 1024) && nr >= ring_min_rows && ring_lds <= 160 * 1024 && ff.nso <= 15) {
       const int nwg = std::max(1, std::min(ring_wgs, nr / (2 * ring_C)));
       const int cyclic = (ring_cyclic && nwg >= 8 && (nwg & 7) == 0 && swz) ? 1 : 0;
       const int which = rowlist == nullptr ? 0 : (rowlist == rows_int ? 1 : 2);
@@ -990,6 +1095,15 @@ void Engine::qeq() {
 #undef RX_DMA3
 #undef RX_DMA4
       return nbl;
+    }
+    if (spmv2_env) {                              // two rows per wavefront, side by side
+      const int rb2 = nblk((nr + 1) / 2, SPMV_WPB);
+#define RX_P2(M, S) do { if (ff.pqeq) k_spmv2<M, S, true><<<rb2, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nr, pbase, stopflag); \
+                         else k_spmv2<M, S, false><<<rb2, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nr, pbase, stopflag); } while (0)
+      if (mode == MODE_HSH) { if (store) RX_P2(MODE_HSH, true); else RX_P2(MODE_HSH, false); }
+      else { if (store) RX_P2(MODE_GRAD, true); else RX_P2(MODE_GRAD, false); }
+#undef RX_P2
+      return rb2;
     }
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return 0;
