@@ -12,7 +12,7 @@
 
 #include "engine.h"
 
-namespace rxmd { double stream_probe_ms(Engine &e, int blocks); double ring_probe_ms(Engine &e, int reps); }
+namespace rxmd { double stream_probe_ms(Engine &e, int blocks); double ring_probe_ms(Engine &e, int reps); void spmv_bisect_ms(Engine &e, double *out4); }
 using rxmd::Engine;
 using rxmd::EngineError;
 
@@ -477,6 +477,7 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
         n = 8; break;
       }
       case 101: n = 1; if (capacity < 1) throw EngineError(RXMD_E_ARG, "capacity"); out[0] = rxmd::ring_probe_ms(e, 10); break;   // ring matrix pass alone (experiments)
+      case 102: n = 7; if (capacity < 7) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_bisect_ms(e, out); break;   // stripped-down forms of the row kernel (experiments)
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");
     }
   });

@@ -683,6 +683,85 @@ __global__ void __launch_bounds__(1024, 8) k_spmv_ring(int N, int S10, DevFF ff,
   }
 }
 
+// ---- where does the row kernel's time go?  Stripped-down forms of k_spmv, timed in isolation (debug tap 102; experiments only) -------
+//   LEVEL 0: the two streams of a row only (4 x 64 entries per trip as k_spmv), one sum, one wavefront reduction, no store
+//   LEVEL 1: + the 16-byte gather per entry and the two FMAs
+//   LEVEL 2: + the ghost-column sums and all four reductions
+//   LEVEL 3: + the tail operands (type, hst, gst of the row)   LEVEL 4: + the two 16-byte row stores
+//   LEVEL 5: + the per-workgroup partials with their barrier (= the work of k_spmv<HSH, STORE>)   LEVEL 6: as 5 with ONE 32-byte row store
+template <int LEVEL>
+__global__ void __launch_bounds__(1024) k_spmv_bisect(int N, int S10, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
+                                                      const double2 *__restrict__ xv, const double2 *__restrict__ hst, const double2 *__restrict__ gst,
+                                                      const int *__restrict__ type, double *__restrict__ partials, double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh, double *__restrict__ sink) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int row = xcd_swizzle(blockIdx.x, gridDim.x) * wpb + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (row < N) {
+    const size_t base = static_cast<size_t>(row) * S10;
+    unsigned e[UNR];
+    double h[UNR];
+    auto request = [&](int kb, int bound) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int k = kb + lane + 64 * u;
+        const bool ok = k < bound;
+        e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;
+        h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;
+      }
+    };
+    request(0, S10);
+    const int n = n10[row] & N10_COUNT;
+    int pf_t = 0; double2 pf_a = make_double2(0, 0), pf_b = make_double2(0, 0);
+    if (LEVEL >= 3) { pf_t = type[row]; pf_a = hst[row]; pf_b = gst[row]; }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) { const bool ok = lane + 64 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; }
+    double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+    for (int kb = 0; kb < n; kb += 64 * UNR) {
+      if (kb > 0) request(kb, n);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (LEVEL == 0) { as += h[u] * static_cast<double>(e[u] & 255u); }
+        else {
+          const double2 v = xv[e[u] & NB10_IDX_MASK];
+          as += h[u] * v.x; at += h[u] * v.y;
+          if (LEVEL >= 2) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }
+        }
+      }
+    }
+    as = wave_sum(as);
+    if (LEVEL >= 1) at = wave_sum(at);
+    if (LEVEL >= 2) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+    if (lane == 0) {
+      if (LEVEL >= 3) {
+        if (LEVEL == 4 || LEVEL == 5) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+        if (LEVEL == 6) reinterpret_cast<double4 *>(sink)[row + 1] = make_double4(as, at, gs_, gt_);      // (sink: a 32-byte-per-row buffer for this level)
+        acc[0] = (0.5 * pf_a.x + as) * pf_a.x; acc[1] = (0.5 * pf_a.y + at) * pf_a.y; acc[2] = pf_b.x * pf_a.x + pf_t; acc[3] = pf_b.y * pf_a.y;
+        if (LEVEL == 3 && acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e-300) sink[0] = as;
+      } else if (as + at + gs_ + gt_ == 1.2345e-300) sink[0] = as;       // keeps the sums alive
+    }
+  }
+  if (LEVEL >= 5) block_store_partials<4>(acc, partials, 4);
+}
+void spmv_bisect_ms(Engine &e, double *out4) {
+  const int rb = nblk(e.N, 16);
+  double *buf32 = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&buf32), sizeof(double) * 4 * (static_cast<size_t>(e.N) + 2)) != hipSuccess) return;
+  auto run = [&](auto lv) {
+    constexpr int L = decltype(lv)::value;
+    for (int r = 0; r < 11; ++r) {
+      if (r == 1) hipEventRecord(e.ev[2], e.stream);
+      k_spmv_bisect<L><<<rb, 1024, 0, e.stream>>>(e.N, e.S10, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.type, e.partials, e.wall, e.wgh, buf32);
+    }
+    hipEventRecord(e.ev[3], e.stream); hipEventSynchronize(e.ev[3]);
+    float ms = 0; hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
+    return static_cast<double>(ms) / 10.0;
+  };
+  out4[0] = run(std::integral_constant<int, 0>{}); out4[1] = run(std::integral_constant<int, 1>{});
+  out4[2] = run(std::integral_constant<int, 2>{}); out4[3] = run(std::integral_constant<int, 3>{});
+  out4[4] = run(std::integral_constant<int, 4>{}); out4[5] = run(std::integral_constant<int, 5>{}); out4[6] = run(std::integral_constant<int, 6>{});
+  (void)hipFree(buf32);
+}
+
 // timing probe of the ring pass in isolation (debug tap 101; experiments only): env RXMD_RING_PROBE / _R / _C / _WG as in Engine::qeq.
 // Writes the scratch row sums wall / wgh and the partials only; returns the average launch time.
 double ring_probe_ms(Engine &e, int reps) {
