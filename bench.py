@@ -438,7 +438,7 @@ def main():
             "qeq_iters_per_step": iters, "ms_qeq_per_iter": st["ms_qeq"] / max(st["qeq_iters_total"], 1), "n10": n10, "nb": nb,
             "roofline": {"bound": "hbm", "kernel": "k_spmv (QEq matrix pass, qeq.hip)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_pass,
-                         "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"],
+                         "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"], "launches_that_returned_at_once": st.get("spmv_noop_launches", 0),
                          "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,
                          "spmv_launches_per_step": passes,
                          "bytes_per_entry": 20 if pqeq else 12,

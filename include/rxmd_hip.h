@@ -154,7 +154,9 @@ typedef struct rxmd_stats {
   long long spmv_launches;              /* number of matrix passes timed in ms_qeq_spmv */
   int n10_stride, nbuffer, cells10[3], cells3[3];
   int n_boundary_rows;                  /* rows of the 10 A matrix with a ghost partner (vprocs > 1: the launch that waits for the vector halo) */
-  int reserved[7];
+  int spmv_noop_launches;               /* run-ahead CG loop: matrix-pass launches that returned at once (the iteration queued ahead of the exit decision; one per QEq
+                                         * call that ends by the exit test).  NOT in spmv_launches / ms_qeq_spmv; a kernel trace counts them as k_spmv calls */
+  int reserved[6];
   /* the exchanges of a vprocs > 1 run (comm.F90:2-100), event-timed on the stream they run on, summed since rxmd_hip_reset_timers:
    * ghost build (MODE_COPY incl. its size messages), migration (MODE_MOVE), vector / charge halos (MODE_QCOPY1/2: pack, send-recv,
    * unpack), the part of them the main stream had to WAIT for (exposed: from the join with the halo stream to the halo's end; the

@@ -24,7 +24,7 @@ class RxmdStats(C.Structure):
                 ("ms_qeq", C.c_double), ("ms_qeq_list", C.c_double), ("ms_qeq_spmv", C.c_double), ("ms_force", C.c_double), ("ms_lists", C.c_double),
                 ("ms_bo", C.c_double), ("ms_nonbond", C.c_double), ("ms_bonded", C.c_double), ("ms_step_total", C.c_double),
                 ("spmv_launches", C.c_longlong), ("n10_stride", C.c_int), ("nbuffer", C.c_int), ("cells10", C.c_int * 3), ("cells3", C.c_int * 3),
-                ("n_boundary_rows", C.c_int), ("reserved", C.c_int * 7),
+                ("n_boundary_rows", C.c_int), ("spmv_noop_launches", C.c_int), ("reserved", C.c_int * 6),
                 ("ms_ghost_build", C.c_double), ("ms_migrate", C.c_double), ("ms_halo", C.c_double), ("ms_halo_exposed", C.c_double),
                 ("ms_allreduce", C.c_double), ("ms_fold", C.c_double), ("halo_calls", C.c_longlong), ("allreduce_calls", C.c_longlong),
                 ("ms_k_list10", C.c_double), ("ms_k_nonbond", C.c_double), ("ms_k_e3b", C.c_double), ("ms_k_e4b", C.c_double), ("ms_k_ehb", C.c_double),

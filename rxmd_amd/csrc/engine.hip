@@ -111,6 +111,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   RX_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   RX_HIP(hipEventCreateWithFlags(&ev_est, hipEventDisableTiming));
   RX_HIP(hipEventCreateWithFlags(&ev_spec[0], hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_spec[1], hipEventDisableTiming));
+  for (auto &pr : ev_pass) for (auto &e2 : pr) RX_HIP(hipEventCreate(&e2));
   for (auto &e : ev) RX_HIP(hipEventCreate(&e));
 }
 
@@ -123,6 +124,7 @@ Engine::~Engine() {
   if (ev_comm) (void)hipEventDestroy(ev_comm);
   if (ev_est) (void)hipEventDestroy(ev_est);
   for (auto &e2 : ev_spec) if (e2) (void)hipEventDestroy(e2);
+  for (auto &pr : ev_pass) for (auto &e2 : pr) if (e2) (void)hipEventDestroy(e2);
   if (comm_stream && comm_stream != stream) (void)hipStreamDestroy(comm_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }

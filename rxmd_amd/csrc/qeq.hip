@@ -35,6 +35,10 @@ constexpr int UNR = SPMV_UNR;
 #ifndef SPMV_LEAN_FULL
 #define SPMV_LEAN_FULL 0
 #endif
+#ifndef SPMV_WG_TAIL
+#define SPMV_WG_TAIL 1
+#endif
+constexpr bool WG_TAIL = SPMV_WG_TAIL != 0;   // row tails of a workgroup run together by its wavefront 0 (k_spmv)
 constexpr bool LEAN_GH = SPMV_LEAN_GH != 0, LEAN_FULL = SPMV_LEAN_FULL != 0;   // measured and left off: ghost sums only on boundary rows / complete batches without bounds -- fewer vector instructions, not faster   // 4 x 64 = 256 entries in flight per wavefront and pass of the row loop (see k_spmv)
 
 __device__ inline double wave_sum(double v) { return wave_sum64(v); }   // DPP reduction, engine.h
@@ -95,6 +99,11 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
   // scalar registers -- 44 instead of 57 VGPRs and scalar address arithmetic: 1.03-1.09 -> 0.95 ms per pass on the same box
   const int widx = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int row = rowlist ? (widx < nrows ? rowlist[widx] : N) : widx;
+  // WG_TAIL: the row tails of a workgroup are run by the first lanes of its wavefront 0 after the barrier the partial sums need anyway -- the
+  // operands of consecutive rows (type, hst / qst, gst / q) and their results (row sums, gradient) are then a handful of coalesced requests
+  // per workgroup instead of five per row (k_spmv_bisect: tail operands, row stores and partials are 6-8 % of the pass)
+  __shared__ double s_row[16][4];
+  const int wave_in_wg = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (row < N) {
     const size_t base = static_cast<size_t>(row) * S10;
@@ -127,10 +136,9 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
     // other rows -- three in four at 979,776 atoms -- the six vector instructions per batch that select and add them, and their two
     // wavefront reductions, are not executed (counters: 306 vector instructions per row before, the vector unit busy 51 % of the time)
     const bool gh_row = PQ || !LEAN_GH || (nraw & N10_GHOST_ROW) != 0;
-    // operands of the row tail, requested before the streams so that they are not a further dependent round trip after the reduction
-    const int pf_t = type[row];
-    const double2 pf_a = (MODE == MODE_HSH) ? hst[row] : qst[row];
-    const double2 pf_b = (MODE == MODE_HSH) ? gst[row] : make_double2(q[row], 0.0);
+    // per-wavefront tail (WG_TAIL off): its operands are requested before the streams so that they are not a further dependent round trip
+    int pf_t = 0; double2 pf_a = make_double2(0.0, 0.0), pf_b = make_double2(0.0, 0.0);
+    if (!WG_TAIL) { pf_t = type[row]; pf_a = (MODE == MODE_HSH) ? hst[row] : qst[row]; pf_b = (MODE == MODE_HSH) ? gst[row] : make_double2(q[row], 0.0); }
     const double mu = (MODE == MODE_GRAD) ? scal[S_MU] : 0.0;
     double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
     if (PIPE && (!LEAN_FULL || n < 64 * UNR)) {                  // a row shorter than the first batch: entries behind its end get weight 0 (longer rows skip the re-masking)
@@ -156,7 +164,8 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
     }
     as = wave_sum(as); at = wave_sum(at);
     if ((MODE == MODE_GRAD || STORE) && (!LEAN_GH || gh_row)) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-    if (lane == 0) {
+    if (WG_TAIL) { if (lane == 0) { s_row[wave_in_wg][0] = as; s_row[wave_in_wg][1] = at; s_row[wave_in_wg][2] = gs_; s_row[wave_in_wg][3] = gt_; } }
+    else if (lane == 0) {
       if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
       const DevAtomP ap = ff.atom[pf_t];
       if (MODE == MODE_HSH) {
@@ -176,7 +185,43 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
       }
     }
   }
-  block_store_partials<4>(acc, partials + static_cast<size_t>(pbase) * 4, 4);
+  if (!WG_TAIL) { block_store_partials<4>(acc, partials + static_cast<size_t>(pbase) * 4, 4); return; }
+  __syncthreads();
+  if (wave_in_wg != 0) return;
+  {
+    const int r_idx = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + lane;     // lane r = the row of wavefront r
+    const int r = (lane < wpb) ? (rowlist ? (r_idx < nrows ? rowlist[r_idx] : N) : r_idx) : N;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (r < N) {
+      const double as = s_row[lane][0], at = s_row[lane][1], gs_ = s_row[lane][2], gt_ = s_row[lane][3];
+      const int t = type[r];
+      const double2 pa = (MODE == MODE_HSH) ? hst[r] : qst[r];
+      const DevAtomP ap = ff.atom[t];
+      if (STORE) { rs_all[r] = make_double2(as, at); rs_gh[r] = make_double2(gs_, gt_); }
+      if (MODE == MODE_HSH) {
+        const double2 pb = gst[r];
+        const double ts = ap.eta * pa.x + as, tt = ap.eta * pa.y + at;          // qeq.F90:294-302
+        a0 = ts * pa.x; a1 = tt * pa.y;                                         // hshs_sum, hsht_sum (:309-310)
+        a2 = pb.x * pa.x; a3 = pb.y * pa.y;                                     // g.h (:119,123)
+      } else {
+        const double mu = scal[S_MU];
+        const double fpq = PQ ? pqrow[r].x : 0.0;
+        const double g1 = -ap.chi - ap.eta * pa.x - as - fpq;                   // qeq.F90:349-350 (pqeq.F90:466)
+        const double g2 = -1.0 - ap.eta * pa.y - at;
+        gst[r] = make_double2(g1, g2);
+        a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
+        const double qi = q[r];
+        const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+        if (PQ) a2 = pq_est_row(ap, ff.Zpq[t], pqrow[r], qi, hq_all, gs_ - mu * gt_);
+        else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
+      }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);           // fixed order over the workgroup's rows
+    if (lane < 4) {
+      const double v = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
+      __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---- two rows per wavefront, SIDE BY SIDE (k_spmv2) -----------------------------------------------------------------------------
@@ -1248,9 +1293,9 @@ void Engine::qeq() {
       stopflag = (k == 0) ? nullptr : scal + S_STOP + (k & 1);    // iteration 0 is decided by the host (Est of the start vector is here already)
       if (!xs_current) sorted_copy(hst);           // first iteration only: afterwards the direction kernel leaves the sorted copy behind
       xs_current = false;
-      const bool kt = kt_begin(&st.ms_qeq_spmv);
+      hipEventRecord(ev_pass[k & 1][0], stream);   // read once the host has confirmed that the iteration happened (a pass that returned at once is not timed)
       const int np1 = pass(MODE_HSH, true, wall, wgh);
-      kt_end(kt);
+      hipEventRecord(ev_pass[k & 1][1], stream);
       reduce(1, np1);
       k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag);
       RX_HIP(hipMemcpyAsync(h_scal + 64 + 64 * (k & 1), scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
@@ -1271,9 +1316,10 @@ void Engine::qeq() {
         collect_timers();
         const double *hs = h_scal + 64 + 64 * ((it - 1) & 1);
         Est = hs[S_EST];
+        { float pms = 0; if (hipEventElapsedTime(&pms, ev_pass[(it - 1) & 1][0], ev_pass[(it - 1) & 1][1]) == hipSuccess) st.ms_qeq_spmv += pms; }
         st.spmv_launches += 1;
         if (!queued) break;                        // NMAXQEq iterations done
-        if (hs[S_STOP + (it & 1)] != 0.0) { std::swap(hst, hst2); break; }       // iteration it did not happen: its direction kernel wrote nothing, undo the swap
+        if (hs[S_STOP + (it & 1)] != 0.0) { std::swap(hst, hst2); st.spmv_noop_launches += 1; break; }       // iteration it did not happen: its direction kernel wrote nothing, undo the swap
         GEst2 = Est;
       }
       stopflag = nullptr;
