@@ -172,7 +172,7 @@ def compact_leg(workload, ncells, steps, warmup, device, **kw):
                 "qeq_iters_per_step": st["qeq_iters_total"] / max(st["qeq_calls"], 1), "spmv_launches_per_step": st["spmv_launches"] / steps,
                 "roofline": {"bound": "hbm", "kernel": "k_spmv", "bytes_per_entry": 20 if pqeq else 12, "algorithmic_bytes_per_launch": bp, "avg_launch_ms": ms_spmv, "achieved": ach,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS},
-                "breakdown_ms_per_step": {k: st[k] / steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded")}}
+                "breakdown_ms_per_step": {k: st[k] / steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_winbuild")}}
     finally:
         eng.close()
 
@@ -445,7 +445,7 @@ def main():
                          "step_bytes_per_atom_executed": b_step_exec, "step_frac_of_hbm_roofline": (b_step_exec * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9),
                          "kernels": kernels},
             "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded",
-                                                                    "ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold")},
+                                                                    "ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold", "ms_k_winbuild")},
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
         }
         if per_rank:

@@ -166,6 +166,10 @@ typedef struct rxmd_stats {
   /* single kernels, HIP events on the engine's stream around each launch, summed like the timers above (bench.py: roofline.kernels):
    * the 10 A sweep, ENbond (PQEq: ENbond_PQEq), E3b, E4b, Ehb, BOPRIM + BOFULL, the assembly gathers of ForceBondedTerms */
   double ms_k_list10, ms_k_nonbond, ms_k_e3b, ms_k_e4b, ms_k_ehb, ms_k_bondorder, ms_k_assemble;
+  /* window form of the 10 A matrix (groups of 16 cell-sorted rows whose partners the matrix pass holds in LDS): its build per list build,
+   * the number of groups, the largest window in units of 8 cell-sorted positions, 1 when the matrix pass uses it (0: the row pass) */
+  double ms_k_winbuild;
+  int win_groups, win_max_units, win_in_use, reserved2;
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);

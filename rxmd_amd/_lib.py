@@ -28,14 +28,15 @@ class RxmdStats(C.Structure):
                 ("ms_ghost_build", C.c_double), ("ms_migrate", C.c_double), ("ms_halo", C.c_double), ("ms_halo_exposed", C.c_double),
                 ("ms_allreduce", C.c_double), ("ms_fold", C.c_double), ("halo_calls", C.c_longlong), ("allreduce_calls", C.c_longlong),
                 ("ms_k_list10", C.c_double), ("ms_k_nonbond", C.c_double), ("ms_k_e3b", C.c_double), ("ms_k_e4b", C.c_double), ("ms_k_ehb", C.c_double),
-                ("ms_k_bondorder", C.c_double), ("ms_k_assemble", C.c_double)]
+                ("ms_k_bondorder", C.c_double), ("ms_k_assemble", C.c_double), ("ms_k_winbuild", C.c_double),
+                ("win_groups", C.c_int), ("win_max_units", C.c_int), ("win_in_use", C.c_int), ("reserved2", C.c_int)]
 
     def asdict(self):
         d = {}
         for name, _ in self._fields_:
             v = getattr(self, name)
             d[name] = list(v) if hasattr(v, "__len__") else v
-        d.pop("reserved")
+        d.pop("reserved"); d.pop("reserved2")
         return d
 
 

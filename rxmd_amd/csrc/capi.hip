@@ -12,7 +12,7 @@
 
 #include "engine.h"
 
-namespace rxmd { double stream_probe_ms(Engine &e, int blocks); double ring_probe_ms(Engine &e, int reps); void spmv_bisect_ms(Engine &e, double *out4); }
+namespace rxmd { double stream_probe_ms(Engine &e, int blocks); double ring_probe_ms(Engine &e, int reps); void spmv_bisect_ms(Engine &e, double *out4); void spmv_winprobe_ms(Engine &e, double *out2); void spmv_isolated_ms(Engine &e, double *out); }
 using rxmd::Engine;
 using rxmd::EngineError;
 
@@ -390,6 +390,7 @@ int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out) {
     }
     e.st.natoms = e.N;
     e.st.n_boundary_rows = (e.multi() && e.lists_valid && !e.rows_split_pending_invalid()) ? e.n_bnd : 0;
+    e.st.win_groups = e.win_groups; e.st.win_max_units = e.win_maxunits; e.st.win_in_use = e.win_used ? 1 : 0;
     *out = e.st;
   });
 }
@@ -400,7 +401,7 @@ int rxmd_hip_reset_timers(rxmd_handle h) {
     e.st.spmv_launches = 0; e.st.spmv_noop_launches = 0; e.st.qeq_iters_total = 0; e.st.qeq_calls = 0;
     e.st.ms_ghost_build = e.st.ms_migrate = e.st.ms_halo = e.st.ms_halo_exposed = e.st.ms_allreduce = e.st.ms_fold = 0.0;
     e.st.halo_calls = e.st.allreduce_calls = 0;
-    e.st.ms_k_list10 = e.st.ms_k_nonbond = e.st.ms_k_e3b = e.st.ms_k_e4b = e.st.ms_k_ehb = e.st.ms_k_bondorder = e.st.ms_k_assemble = 0.0;
+    e.st.ms_k_list10 = e.st.ms_k_nonbond = e.st.ms_k_e3b = e.st.ms_k_e4b = e.st.ms_k_ehb = e.st.ms_k_bondorder = e.st.ms_k_assemble = e.st.ms_k_winbuild = 0.0;
   });
 }
 
@@ -477,6 +478,8 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
         n = 8; break;
       }
       case 101: n = 1; if (capacity < 1) throw EngineError(RXMD_E_ARG, "capacity"); out[0] = rxmd::ring_probe_ms(e, 10); break;   // ring matrix pass alone (experiments)
+      case 104: n = 2; if (capacity < 2) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_isolated_ms(e, out); break;   // real window pass / row pass back to back (experiments)
+      case 103: n = 9; if (capacity < 9) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_winprobe_ms(e, out); break;   // window pass, synthetic timing probe (experiments)
       case 102: n = 7; if (capacity < 7) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_bisect_ms(e, out); break;   // stripped-down forms of the row kernel (experiments)
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");
     }

@@ -252,6 +252,16 @@ struct Engine {
   void bin_cells();
   void build_bonded_list();
   void build_list10();
+  // Window form of the 10 A matrix (lists.hip, qeq.hip k_spmv_win): the residents in cell-sorted order in groups of WIN_ROWS rows; per group the
+  // set of cell-sorted positions its rows couple to, in units of WIN_UNIT consecutive positions (win_k: first position of each unit, ascending;
+  // win_cnt: units); per list entry a 16-bit slot in that window (sl10, bit 15 = ghost column).  The matrix pass stages the window's vector
+  // entries in LDS with coalesced loads and reads them from there instead of gathering 16 bytes per entry.
+  void build_windows();
+  int *rows_sorted = nullptr, *win_k = nullptr, *win_cnt = nullptr;
+  int *win_gint = nullptr, *win_gbnd = nullptr; int win_nbnd = 0;     // multi-rank: groups without / with a row that has a ghost partner
+  unsigned short *sl10 = nullptr;
+  int win_groups = 0, win_maxunits = 0;
+  bool win_valid = false, win_used = false;    // win_used: the last matrix pass was a window pass
   void halo_refresh(double2 *v2, double *v1);       // QCOPY1/QCOPY2: ghosts <- owners (self exchange, resolved roots)
   void halo_staged(double *v, int ncomp);           // the same through the six-stage exchange (multi-rank)
   long long exchange_stage(int d, bool reverse, long long nsend, long long known_nrecv = -1);  // one send_recv of comm.F90:291-364; returns #doubles received
@@ -343,6 +353,10 @@ constexpr unsigned NB10_GHOST = 1u << 30, NB10_SELF = 1u << 31;
 // n10[row] = entries of the row; bit 30: the row has a ghost partner (a boundary row of the domain).  The matrix pass needs the sums over
 // ghost columns only there (74 % of the rows of a 979,776-atom domain have none) and reads the flag with the length it needs anyway.
 constexpr int N10_GHOST_ROW = 1 << 30, N10_COUNT = N10_GHOST_ROW - 1;
+constexpr int WIN_ROWS = 16;        // rows of a window group = wavefronts of a workgroup of the window pass
+constexpr int WIN_UNIT = 8;         // cell-sorted positions per window unit (8 x 16 bytes = one 128-byte line of the sorted vector)
+constexpr int WIN_MAXUNITS = 448;   // units a group's descriptor holds: 3,584 slots = 56 KB of LDS (two workgroups per CU)
+constexpr int WIN_BMW = 2048;       // 64-bit words of the coverage map the build kernel keeps in LDS: a group's positions may span 2048 x 64 x 8 = 1 M
 
 // device error codes written by kernels into Engine::d_err
 enum { DERR_NONE = 0, DERR_MAXNB = 1, DERR_MAXN10 = 2, DERR_GRID = 3, DERR_NBRINDX = 4, DERR_TYPE = 5 };

@@ -341,6 +341,8 @@ void Engine::alloc_device() {
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
+  { const size_t ng = (static_cast<size_t>(rows10) + WIN_ROWS - 1) / WIN_ROWS + 1;
+    dmalloc(rows_sorted, static_cast<size_t>(rows10) + WIN_ROWS); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dmalloc(scal, 80);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 192 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip)
@@ -367,7 +369,7 @@ void Engine::free_device() {
   dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
-  dfree(rows_int); dfree(rows_bnd);
+  dfree(rows_int); dfree(rows_bnd); dfree(rows_sorted); dfree(win_k); dfree(win_cnt); dfree(win_gint); dfree(win_gbnd); dfree(sl10);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   for (int k = 0; k < 3; ++k) { if (rsched[k]) (void)hipFree(rsched[k]); rsched[k] = nullptr; }
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
@@ -1283,13 +1285,14 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     const int need = h_err[1];
     S10 = (static_cast<int>(need * 1.1) + 64 + 63) / 64 * 64;
     const size_t n = static_cast<size_t>(rows10) * S10;
-    dfree(nb10); dfree(hess); dmalloc(nb10, n); dmalloc(hess, n);
+    dfree(nb10); dfree(hess); dfree(sl10); dmalloc(nb10, n); dmalloc(hess, n); dmalloc(sl10, n);
     if (ff.pqeq) { dfree(hsc); dmalloc(hsc, n); }
     st.n10_stride = S10;
     build_list10();
     check_device_error("list build");
   }
   max_row10 = h_err[3]; min_row10 = std::min(h_err[4], h_err[3]);   // longest / shortest 10 A row of this build (k_list10)
+  win_maxunits = h_err[5]; win_valid = win_groups > 0 && h_err[6] == 0 && win_maxunits > 0 && (!multi() || (win_nbnd >= 0 && win_nbnd <= win_groups));   // window form of the matrix (build_windows)
   collect_timers();
   st.ms_lists += toc(0, 1);
   lists_valid = true;

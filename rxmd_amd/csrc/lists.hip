@@ -384,6 +384,147 @@ __global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__r
   if (flag[i]) rows_bnd[scan[i]] = i; else rows_int[i - scan[i]] = i;
 }
 
+// ---- window form of the 10 A matrix (engine.h: WIN_*) -------------------------------------------------------------------------------
+__global__ void k_resident_flags(int G, int N, const int *__restrict__ perm, int *__restrict__ flag) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k <= G) flag[k] = (k < G && perm[k] < N) ? 1 : 0;
+}
+__global__ void k_rows_sorted(int G, int N, const int *__restrict__ perm, const int *__restrict__ rank, int *__restrict__ rows_sorted) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < G && perm[k] < N) rows_sorted[rank[k]] = perm[k];
+}
+// One workgroup of eight wavefronts per group of WIN_ROWS rows, two rows per wavefront with their entries in registers (NE x 64 >= the row
+// stride; one round trip for all of them): the positions the rows couple to are marked in an LDS map, one bit per unit of WIN_UNIT positions
+// counted from the group's smallest; a unit's rank among the marked ones is its place in the window; an entry's slot is 8 x rank + position
+// inside the unit.  Whatever order k_list10 left the entries in, and whether or not the group's rows sit in one cell column.
+template <int NE>
+__global__ void __launch_bounds__(512) k_win_build(int N, int S10, const int *__restrict__ rows_sorted, const int *__restrict__ nb10, const int *__restrict__ n10,
+                                                   unsigned short *__restrict__ sl10, int *__restrict__ win_k, int *__restrict__ win_cnt, int *__restrict__ gflag, int *err, int probe) {
+  __shared__ unsigned long long bm[WIN_BMW];
+  __shared__ int pre[WIN_BMW];
+  __shared__ int s_min, s_max, s_total, s_bnd;
+  constexpr int NWAVES = 8, RPW = WIN_ROWS / NWAVES;  // rows per wavefront
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+  int row[RPW], n[RPW];
+  unsigned ent[RPW][NE];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int ridx = g * WIN_ROWS + wave * RPW + j;
+    row[j] = ridx < N ? rows_sorted[ridx] : -1;
+  }
+  bool bnd = false;                                   // does a row of the group have a ghost partner? (multi-rank: the group waits for the vector halo)
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) { const int nraw = row[j] >= 0 ? n10[row[j]] : 0; n[j] = nraw & N10_COUNT; bnd |= (nraw & N10_GHOST_ROW) != 0; }
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const size_t base = static_cast<size_t>(row[j] >= 0 ? row[j] : 0) * S10;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) { const int e = lane + 64 * u; ent[j][u] = e < n[j] ? static_cast<unsigned>(nb10[base + e]) : 0xffffffffu; }
+  }
+  for (int w = tid; w < WIN_BMW; w += 64 * NWAVES) bm[w] = 0ULL;
+  if (tid == 0) { s_min = 0x7fffffff; s_max = -1; s_bnd = 0; }
+  __syncthreads();
+  if (gflag && bnd && lane == 0) atomicOr(&s_bnd, 1);
+  int kmn = 0x7fffffff, kmx = -1;
+#pragma unroll
+  for (int j = 0; j < RPW; ++j)
+#pragma unroll
+    for (int u = 0; u < NE; ++u)
+      if (ent[j][u] != 0xffffffffu) { const int k = static_cast<int>(ent[j][u] & NB10_IDX_MASK); kmn = min(kmn, k); kmx = max(kmx, k); }
+  for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, __shfl_xor(kmn, o, 64)); kmx = max(kmx, __shfl_xor(kmx, o, 64)); }
+  if (lane == 0 && kmx >= 0) { atomicMin(&s_min, kmn); atomicMax(&s_max, kmx); }
+  __syncthreads();
+  if (tid == 0 && gflag) gflag[g] = s_bnd;
+  if (s_max < 0) { if (tid == 0) win_cnt[g] = 0; return; }                       // no entries at all (isolated atoms)
+  const int kmin = s_min & ~(WIN_UNIT - 1);
+  const int nwords = (((s_max - kmin) / WIN_UNIT + 1) + 63) >> 6;
+  if (nwords > WIN_BMW) { if (tid == 0) { win_cnt[g] = 0; atomicExch(&err[6], 1); } return; }
+  if (probe == 1) { if (tid == 0) win_cnt[g] = nwords; return; }
+#pragma unroll
+  for (int j = 0; j < RPW; ++j)
+#pragma unroll
+    for (int u = 0; u < NE; ++u)
+    {   // the entries of a row ascend: a lane marks its unit only if the lane before it (in its row of 16 lanes) has a different one --
+        // atomics of one wavefront instruction to the same LDS word are serialised, and three entries in four are repeats
+      const int o = ent[j][u] != 0xffffffffu ? (static_cast<int>(ent[j][u] & NB10_IDX_MASK) - kmin) / WIN_UNIT : -1;
+      const int oprev = __builtin_amdgcn_update_dpp(-2, o, 0x111, 0xf, 0xf, false);     // row_shr:1; lane 0 of a row keeps -2
+      if (o >= 0 && o != oprev) atomicOr(&bm[o >> 6], 1ULL << (o & 63));
+    }
+  __syncthreads();
+  if (probe == 2) { if (tid == 0) win_cnt[g] = static_cast<int>(bm[0]); return; }
+  if (wave == 0) {                                    // exclusive prefix of the words' populations: lane l takes the words [l per, (l + 1) per)
+    const int per = (nwords + 63) >> 6;
+    int sum = 0;
+    for (int w = lane * per; w < min(nwords, (lane + 1) * per); ++w) sum += __popcll(bm[w]);
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    int run = inc - sum;
+    for (int w = lane * per; w < min(nwords, (lane + 1) * per); ++w) { pre[w] = run; run += __popcll(bm[w]); }
+    if (lane == 63) s_total = inc;
+  }
+  __syncthreads();
+  const int nunits = s_total;
+  if (probe == 3) { if (tid == 0) win_cnt[g] = nunits; return; }
+  if (nunits > WIN_MAXUNITS) { if (tid == 0) { win_cnt[g] = 0; atomicExch(&err[6], 1); atomicMax(&err[5], nunits); } return; }
+  for (int w = tid; w < nwords; w += 64 * NWAVES) {   // unit list: most words of the range are empty (25 runs of ~8 units in ~170 words)
+    unsigned long long m = bm[w];
+    int r = pre[w];
+    while (m) { const int b = __ffsll(static_cast<long long>(m)) - 1; m &= m - 1ULL; win_k[static_cast<size_t>(g) * WIN_MAXUNITS + r++] = kmin + WIN_UNIT * (64 * w + b); }
+  }
+  if (probe == 4) { if (tid == 0) win_cnt[g] = nunits; return; }
+  if (tid == 0) { win_cnt[g] = nunits; if (__hip_atomic_load(&err[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) atomicMax(&err[5], nunits); }
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    if (row[j] < 0) continue;
+    const size_t base = static_cast<size_t>(row[j]) * S10;
+    const int npad = (n[j] + 3) & ~3;                 // k_list10 zero-pads a row to a multiple of 4: those entries get slot 0
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = lane + 64 * u;
+      if (e >= npad) continue;
+      unsigned short sl = 0;
+      if (e < n[j]) {
+        const int d = static_cast<int>(ent[j][u] & NB10_IDX_MASK) - kmin, o = d / WIN_UNIT;
+        const unsigned long long m = bm[o >> 6];
+        const int r = pre[o >> 6] + __popcll(m & ((1ULL << (o & 63)) - 1ULL));
+        sl = static_cast<unsigned short>((WIN_UNIT * r + (d & (WIN_UNIT - 1))) | ((ent[j][u] & NB10_GHOST) ? 0x8000 : 0));
+      }
+      sl10[base + e] = sl;
+    }
+  }
+}
+
+__global__ void k_split_groups(int ng, const int *__restrict__ flag, const int *__restrict__ scan, int *__restrict__ g_int, int *__restrict__ g_bnd) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  if (flag[g]) g_bnd[scan[g]] = g; else g_int[g - scan[g]] = g;
+}
+
+void Engine::build_windows() {
+  win_groups = 0;
+  if (std::getenv("RXMD_SPMV_NO_WIN") || (S10 & 3) || N <= 0 || S10 > 1024) return;
+  k_resident_flags<<<nblk(G + 1, 256), 256, 0, stream>>>(G, N, perm, flags2);
+  size_t tb = cubtmp_bytes;
+  RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, G + 1, stream));
+  k_rows_sorted<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, scanout2, rows_sorted);
+  RX_HIP(hipMemsetAsync(d_err + 5, 0, 2 * sizeof(int), stream));
+  win_groups = (N + WIN_ROWS - 1) / WIN_ROWS;
+  int *gflag = multi() ? flags2 : nullptr;           // (the resident flags are used up)
+  const int wprobe = std::getenv("RXMD_WINB_PROBE") ? std::atoi(std::getenv("RXMD_WINB_PROBE")) : 0;   // timing probes: stop after a phase (the pass must be off then)
+  const bool ktw = kt_begin(&st.ms_k_winbuild);
+  if (S10 <= 512) k_win_build<8><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
+  else if (S10 <= 768) k_win_build<12><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
+  else k_win_build<16><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
+  kt_end(ktw);
+  if (multi()) {                                     // interior groups (no row with a ghost partner) / boundary groups: the two launches of an overlapped pass
+    RX_HIP(hipMemsetAsync(flags2 + win_groups, 0, sizeof(int), stream));
+    tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, win_groups + 1, stream));
+    k_split_groups<<<nblk(win_groups, 256), 256, 0, stream>>>(win_groups, flags2, scanout2, win_gint, win_gbnd);
+    RX_HIP(hipMemcpyAsync(&win_nbnd, scanout2 + win_groups, sizeof(int), hipMemcpyDeviceToHost, stream));   // valid after the synchronisation of the list build's error check
+  }
+}
+
 void Engine::build_bonded_list() {
   k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi);
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
@@ -409,6 +550,8 @@ void Engine::build_list10() {
   kt_end(kt10);
 #undef RX_LIST10
 #undef RX_LIST10_O
+  win_valid = false;
+  build_windows();
   if (multi()) {     // interior rows (no ghost partner) and boundary rows: the matrix pass does the former while the vector halo is in flight
     RX_HIP(hipMemsetAsync(flags + N, 0, sizeof(int), stream));
     size_t tb = cubtmp_bytes;

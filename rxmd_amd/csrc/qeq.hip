@@ -224,6 +224,119 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
   }
 }
 
+// ---- window pass (k_spmv_win) -------------------------------------------------------------------------------------------------------------
+// The 16 rows of a group (consecutive residents in cell-sorted order, engine.h WIN_*) couple to nearly the same partners: ~1,500 cell-sorted
+// positions for ~430 entries per row.  The workgroup copies the vector entries of that window into LDS with coalesced loads (8 consecutive
+// positions = one 128-byte line per unit) and every row reads its partners from there: a 16-bit slot per entry (bit 15: ghost column) replaces
+// the 4-byte entry and the 16-byte gather per entry through the vector memory path disappears.  Streams: value 8 + slot 2 bytes per entry, two
+// entries per lane and request (16-byte / 4-byte loads), 256 entries of a row in flight.  Same sums in the same per-row roles as k_spmv; the
+// order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
+// Timing probe with synthetic slots before it was built (debug tap 103): 0.76 ms against 0.93 ms of k_spmv on the same box.
+template <int MODE, bool STORE, bool PQ>
+__global__ void __launch_bounds__(64 * WIN_ROWS) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
+                                                            const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
+                                                            const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
+                                                            const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
+                                                            const double *__restrict__ scal, double *__restrict__ partials,
+                                                            double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
+                                                            const double *__restrict__ hsc, const double4 *__restrict__ pqrow,
+                                                            const int *__restrict__ grouplist, int ngroups, int pbase, const double *__restrict__ stopflag) {
+  if (stopflag && *stopflag != 0.0) return;
+  extern __shared__ double2 s_x[];                  // the window: slot -> (xs, xt)
+  __shared__ double s_row[WIN_ROWS][4];
+  constexpr int STEPS = 2;                          // 2 x 128 entries of the row in flight
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int gidx = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int grp = grouplist ? (gidx < ngroups ? grouplist[gidx] : -1) : (gidx < ngroups ? gidx : -1);
+  const int ridx = grp * WIN_ROWS + wave;
+  const int row = (grp >= 0 && ridx < N) ? rows_sorted[ridx] : N;
+  const bool live = row < N;
+  const size_t base = static_cast<size_t>(live ? row : 0) * S10;
+  const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
+  const d2v *cv2 = reinterpret_cast<const d2v *>((PQ ? hsc : hess) + base);
+  const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
+  double2 v[STEPS], c[STEPS]; unsigned ss[STEPS];
+  auto request = [&](int kb, int bound) {          // entries kb + 128 u + 2 lane and the next one
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      const int k = kb + 128 * u + 2 * lane;
+      const bool ok = k < bound;
+      if (ok) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); v[u] = make_double2(t2.x, t2.y); } else v[u] = make_double2(0.0, 0.0);
+      ss[u] = ok ? __builtin_nontemporal_load(sl2 + (k >> 1)) : 0u;
+      if (PQ && (MODE == MODE_GRAD || STORE)) { if (ok) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); c[u] = make_double2(t2.x, t2.y); } else c[u] = make_double2(0.0, 0.0); }
+    }
+  };
+  request(0, live ? S10 : 0);                       // before the row length is known: the first batch lies inside the row's slot whatever the length
+  const int n = live ? (n10[row] & N10_COUNT) : 0;
+  if (grp >= 0) {                                   // the group's window: unit t >> 3, position t & 7
+    const int nslots = WIN_UNIT * win_cnt[grp];
+    const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
+    for (int t = threadIdx.x; t < nslots; t += blockDim.x) s_x[t] = xv[min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1)];
+  }
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u) {                // entries behind the row's end: weight 0, slot 0
+    const int k = 128 * u + 2 * lane;
+    if (k >= n) { v[u].x = 0.0; ss[u] &= 0xffff0000u; if (PQ) c[u].x = 0.0; }
+    if (k + 1 >= n) { v[u].y = 0.0; ss[u] &= 0x0000ffffu; if (PQ) c[u].y = 0.0; }
+  }
+  __syncthreads();
+  double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+  for (int kb = 0; kb < n; kb += 128 * STEPS) {     // wave-uniform trip count
+    if (kb > 0) request(kb, n);                     // (an odd row end: entry n is the zero padding of the row, slot 0)
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      const double2 x0 = s_x[ss[u] & 0x7fffu], x1 = s_x[(ss[u] >> 16) & 0x7fffu];
+      as += v[u].x * x0.x; at += v[u].x * x0.y; as += v[u].y * x1.x; at += v[u].y * x1.y;
+      if ((MODE == MODE_GRAD || STORE) && !PQ) {
+        const double g0 = (ss[u] & 0x8000u) ? v[u].x : 0.0, g1 = (ss[u] & 0x80000000u) ? v[u].y : 0.0;     // select the weight, not the sums
+        gs_ += g0 * x0.x; gt_ += g0 * x0.y; gs_ += g1 * x1.x; gt_ += g1 * x1.y;
+      }
+      if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * x0.x; gt_ += c[u].x * x0.y; gs_ += c[u].y * x1.x; gt_ += c[u].y * x1.y; }
+    }
+  }
+  as = wave_sum(as); at = wave_sum(at);
+  if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+  if (lane == 0) { s_row[wave][0] = as; s_row[wave][1] = at; s_row[wave][2] = gs_; s_row[wave][3] = gt_; }
+  __syncthreads();
+  if (wave != 0) return;
+  {                                                 // the row tails of the group, lane r = the row of wavefront r (as k_spmv)
+    const int r_idx = grp * WIN_ROWS + lane;
+    const int r = (grp >= 0 && lane < WIN_ROWS && r_idx < N) ? rows_sorted[r_idx] : N;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (r < N) {
+      const double ras = s_row[lane][0], rat = s_row[lane][1], rgs = s_row[lane][2], rgt = s_row[lane][3];
+      const int t = type[r];
+      const double2 pa = (MODE == MODE_HSH) ? hst[r] : qst[r];
+      const DevAtomP ap = ff.atom[t];
+      if (STORE) { rs_all[r] = make_double2(ras, rat); rs_gh[r] = make_double2(rgs, rgt); }
+      if (MODE == MODE_HSH) {
+        const double2 pb = gst[r];
+        const double ts = ap.eta * pa.x + ras, tt = ap.eta * pa.y + rat;        // qeq.F90:294-302
+        a0 = ts * pa.x; a1 = tt * pa.y;                                         // hshs_sum, hsht_sum (:309-310)
+        a2 = pb.x * pa.x; a3 = pb.y * pa.y;                                     // g.h (:119,123)
+      } else {
+        const double mu = scal[S_MU];
+        const double fpq = PQ ? pqrow[r].x : 0.0;
+        const double g1 = -ap.chi - ap.eta * pa.x - ras - fpq;                  // qeq.F90:349-350 (pqeq.F90:466)
+        const double g2 = -1.0 - ap.eta * pa.y - rat;
+        gst[r] = make_double2(g1, g2);
+        a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
+        const double qi = q[r];
+        const double hq_all = ras - mu * rat, hq_res = (ras - rgs) - mu * (rat - rgt);
+        if (PQ) a2 = pq_est_row(ap, ff.Zpq[t], pqrow[r], qi, hq_all, rgs - mu * rgt);
+        else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
+      }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);           // fixed order over the group's rows
+    if (lane < 4) {
+      const double val = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
+      __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- two rows per wavefront, SIDE BY SIDE (k_spmv2) -----------------------------------------------------------------------------
 // Every form of the pass measured so far turns a row around in 0.92-0.97 ns chip-wide whatever the row holds -- RDX 430 entries, water 357,
 // the SiC + O2 system 212 with a third stream -- i.e. a CU finishes a row every 240 ns with its 32 wavefronts, each alive 6.5 us: the fixed
@@ -807,6 +920,224 @@ void spmv_bisect_ms(Engine &e, double *out4) {
   (void)hipFree(buf32);
 }
 
+// ---- window pass, timing probe (debug tap 103; experiments only) -----------------------------------------------------------------------
+// What would a pass cost that (a) holds the vector entries of a 16-row group's common partner window in LDS (staged with coalesced loads,
+// read back conflict-free) instead of gathering 16 bytes per entry, (b) replaces the 4-byte entry stream by a bit per window slot and row
+// (value k of the row belongs to the k-th set bit), (c) has two dependent global round trips per wavefront (bit words -> values) instead of
+// four?  The bit words here are SYNTHETIC (hashed, ~31 % set like RDX: 420 of 1,344 slots) and the windows arbitrary runs of the sorted
+// vector, so the sums mean nothing; bytes, instruction mix, LDS traffic and the workgroup structure are those of the real thing.
+constexpr int WIN_NW = 21, WIN_NWS = 24, WIN_RUNS = 25, WIN_RUNLEN = 54;     // 21 words of 64 slots; 25 runs of 54 slots = 1,350 >= 1,344
+__global__ void k_winprobe_setup(int N, unsigned long long *__restrict__ bm) {
+  const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<size_t>(N) * WIN_NWS) return;
+  auto mix = [](unsigned long long z) { z += 0x9e3779b97f4a7c15ULL; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); };
+  const unsigned long long h1 = mix(4 * t), h2 = mix(4 * t + 1), h3 = mix(4 * t + 2), h4 = mix(4 * t + 3);
+  bm[t] = (t % WIN_NWS) < WIN_NW ? ((h1 & h2) | (h1 & h3 & h4)) : 0ULL;
+}
+template <int VARIANT, bool NT>
+__global__ void __launch_bounds__(1024) k_spmv_winprobe(int N, int G, int S10, const double *__restrict__ hess, const unsigned long long *__restrict__ bm,
+                                                        const double2 *__restrict__ xv, const double2 *__restrict__ hst, const double2 *__restrict__ gst,
+                                                        const int *__restrict__ type, DevFF ff, double *__restrict__ partials, double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh) {
+  __shared__ double2 s_x[WIN_NW * 64 + 64];
+  __shared__ unsigned long long s_gm[WIN_NWS];
+  __shared__ double s_row[16][4];
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int grp = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int row = grp * wpb + wave;
+  const bool live = row < N;
+  const size_t base = static_cast<size_t>(live ? row : 0) * S10;
+  // bit words of the row: lane w holds word w
+  unsigned long long m = 0ULL;
+  if (live && lane < WIN_NW) m = __builtin_nontemporal_load(bm + static_cast<size_t>(row) * WIN_NWS + lane);
+  // the group's window: run t by wavefront t % 16 (coalesced 16-byte loads of the sorted vector)
+  for (int t = wave; t < WIN_RUNS; t += wpb) {
+    const int k0 = static_cast<int>((static_cast<long long>(grp) * 16 + static_cast<long long>(t) * 509) % (G - 64));
+    if (lane < WIN_RUNLEN && t * WIN_RUNLEN + lane < WIN_NW * 64 + 64) s_x[t * WIN_RUNLEN + lane] = xv[k0 + lane];
+  }
+  if (threadIdx.x < WIN_NWS) s_gm[threadIdx.x] = (threadIdx.x & 3) == 0 ? 0x00ff00ff00ff00ffULL : 0ULL;      // which slots are ghosts
+  // values: the k-th set bit of the row names value k of the row's slot -- all words requested before the first is used
+  double v[WIN_NW];
+  int pw = 0;
+  const unsigned bit_lo = lane < 32 ? (1u << lane) : 0u, bit_hi = lane < 32 ? 0u : (1u << (lane - 32));
+#pragma unroll
+  for (int w = 0; w < WIN_NW; ++w) {
+    const unsigned lo = __builtin_amdgcn_readlane(static_cast<unsigned>(m), w), hi = __builtin_amdgcn_readlane(static_cast<unsigned>(m >> 32), w);
+    const unsigned long long mw = (static_cast<unsigned long long>(hi) << 32) | lo;
+    const int idx = pw + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+    const bool on = ((lo & bit_lo) | (hi & bit_hi)) != 0u;
+    v[w] = on ? (NT ? __builtin_nontemporal_load(hess + base + idx) : hess[base + idx]) : 0.0;
+    pw += __popcll(mw);
+  }
+  __syncthreads();
+  unsigned long long gmv = lane < WIN_NWS ? s_gm[lane] : 0ULL;
+  double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+#pragma unroll
+  for (int w = 0; w < WIN_NW; ++w) {
+    const double2 x = s_x[64 * w + lane];
+    as += v[w] * x.x; at += v[w] * x.y;
+    if (VARIANT >= 1) {
+      const unsigned glo = __builtin_amdgcn_readlane(static_cast<unsigned>(gmv), w), ghi = __builtin_amdgcn_readlane(static_cast<unsigned>(gmv >> 32), w);
+      const double hg = ((glo & bit_lo) | (ghi & bit_hi)) != 0u ? v[w] : 0.0;
+      gs_ += hg * x.x; gt_ += hg * x.y;
+    }
+  }
+  as = wave_sum(as); at = wave_sum(at); gs_ = wave_sum(gs_); gt_ = wave_sum(gt_);
+  if (lane == 0) { s_row[wave][0] = as; s_row[wave][1] = at; s_row[wave][2] = gs_; s_row[wave][3] = gt_; }
+  __syncthreads();
+  if (wave != 0) return;
+  const int r = (lane < wpb && grp * wpb + lane < N) ? grp * wpb + lane : N;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (r < N) {
+    const double ras = s_row[lane][0], rat = s_row[lane][1];
+    const int t = type[r];
+    const double2 pa = hst[r], pb = gst[r];
+    const DevAtomP ap = ff.atom[t];
+    rs_all[r] = make_double2(ras, rat); rs_gh[r] = make_double2(s_row[lane][2], s_row[lane][3]);
+    const double ts = ap.eta * pa.x + ras, tt = ap.eta * pa.y + rat;
+    a0 = ts * pa.x; a1 = tt * pa.y; a2 = pb.x * pa.x; a3 = pb.y * pa.y;
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+  if (lane < 4) {
+    const double val = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
+    __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * 4 + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// the same with a 16-bit window slot per entry (bit 15: ghost column) next to the value: the row kernel's streams, two entries per lane and
+// request (values 16 bytes, slots 4 bytes per lane), its gathers replaced by LDS reads.  10 instead of 12 bytes per entry.
+__global__ void k_win16_setup(int N, int S10, unsigned short *__restrict__ sl) {
+  const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<size_t>(N) * S10) return;
+  const int e = static_cast<int>(t % S10);
+  unsigned long long z = t + 0x9e3779b97f4a7c15ULL; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z ^= z >> 27;
+  sl[t] = static_cast<unsigned short>(((e * 3 + static_cast<int>(z & 1)) % (WIN_NW * 64)) | ((z & 0xf0) == 0 ? 0x8000 : 0));
+}
+template <int STEPS, int IND>        // IND bit 0: rows through rows_sorted; bit 1: the real windows through win_k / win_cnt
+__global__ void __launch_bounds__(1024) k_spmv_win16probe(int N, int G, int S10, const double *__restrict__ hess, const unsigned short *__restrict__ sl, const int *__restrict__ n10,
+                                                          const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
+                                                          const double2 *__restrict__ xv, const double2 *__restrict__ hst, const double2 *__restrict__ gst,
+                                                          const int *__restrict__ type, DevFF ff, double *__restrict__ partials, double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh) {
+  __shared__ double2 s_x[(IND & 2) ? WIN_MAXUNITS * WIN_UNIT : WIN_NW * 64 + 64];
+  __shared__ double s_row[16][4];
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int grp = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ridx = grp * wpb + wave;
+  const int row = (IND & 1) ? (ridx < N ? rows_sorted[ridx] : N) : ridx;
+  const bool live = row < N;
+  const size_t base = static_cast<size_t>(live ? row : 0) * S10;
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
+  const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl + base);
+  double2 v[STEPS]; unsigned ss[STEPS];
+  auto request = [&](int kb, int bound) {          // entries kb + 128 u + 2 lane, + 1
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      const int k = kb + 128 * u + 2 * lane;
+      const bool ok = k < bound;
+      if (ok) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); v[u] = make_double2(t2.x, t2.y); } else v[u] = make_double2(0.0, 0.0);
+      ss[u] = ok ? __builtin_nontemporal_load(sl2 + (k >> 1)) : 0u;
+    }
+  };
+  request(0, live ? S10 : 0);
+  const int n = live ? (n10[row] & N10_COUNT) : 0;
+  if (IND & 2) {
+    const int nslots = WIN_UNIT * win_cnt[grp];
+    const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
+    for (int t = threadIdx.x; t < nslots; t += blockDim.x) s_x[t] = xv[min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1)];
+  } else
+  for (int t = wave; t < WIN_RUNS; t += wpb) {
+    const int k0 = static_cast<int>((static_cast<long long>(grp) * 16 + static_cast<long long>(t) * 509) % (G - 64));
+    if (lane < WIN_RUNLEN && t * WIN_RUNLEN + lane < WIN_NW * 64 + 64) s_x[t * WIN_RUNLEN + lane] = xv[k0 + lane];
+  }
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u) {                // entries behind the row's end get weight 0
+    const int k = 128 * u + 2 * lane;
+    v[u].x = k < n ? v[u].x : 0.0; v[u].y = k + 1 < n ? v[u].y : 0.0;
+  }
+  __syncthreads();
+  double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+  for (int kb = 0; kb < n; kb += 128 * STEPS) {
+    if (kb > 0) request(kb, n);
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      const double2 x0 = s_x[ss[u] & 0x7fffu], x1 = s_x[(ss[u] >> 16) & 0x7fffu];
+      as += v[u].x * x0.x; at += v[u].x * x0.y; as += v[u].y * x1.x; at += v[u].y * x1.y;
+      const double g0 = (ss[u] & 0x8000u) ? v[u].x : 0.0, g1 = (ss[u] & 0x80000000u) ? v[u].y : 0.0;
+      gs_ += g0 * x0.x; gt_ += g0 * x0.y; gs_ += g1 * x1.x; gt_ += g1 * x1.y;
+    }
+  }
+  as = wave_sum(as); at = wave_sum(at); gs_ = wave_sum(gs_); gt_ = wave_sum(gt_);
+  if (lane == 0) { s_row[wave][0] = as; s_row[wave][1] = at; s_row[wave][2] = gs_; s_row[wave][3] = gt_; }
+  __syncthreads();
+  if (wave != 0) return;
+  const int r = (lane < wpb && grp * wpb + lane < N) ? grp * wpb + lane : N;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (r < N) {
+    const double ras = s_row[lane][0], rat = s_row[lane][1];
+    const int t = type[r];
+    const double2 pa = hst[r], pb = gst[r];
+    const DevAtomP ap = ff.atom[t];
+    rs_all[r] = make_double2(ras, rat); rs_gh[r] = make_double2(s_row[lane][2], s_row[lane][3]);
+    const double ts = ap.eta * pa.x + ras, tt = ap.eta * pa.y + rat;
+    a0 = ts * pa.x; a1 = tt * pa.y; a2 = pb.x * pa.x; a3 = pb.y * pa.y;
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+  if (lane < 4) {
+    const double val = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
+    __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * 4 + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+void spmv_winprobe_ms(Engine &e, double *out) {
+  unsigned long long *bm = nullptr;
+  unsigned short *sl = nullptr;
+  for (int k = 0; k < 9; ++k) out[k] = -1.0;
+  if (e.S10 < 600 || (e.S10 & 1) || hipMalloc(reinterpret_cast<void **>(&bm), sizeof(unsigned long long) * static_cast<size_t>(e.N) * WIN_NWS) != hipSuccess) return;
+  if (hipMalloc(reinterpret_cast<void **>(&sl), sizeof(unsigned short) * static_cast<size_t>(e.N) * e.S10) != hipSuccess) { (void)hipFree(bm); return; }
+  const size_t nt = static_cast<size_t>(e.N) * WIN_NWS, ns = static_cast<size_t>(e.N) * e.S10;
+  k_winprobe_setup<<<static_cast<unsigned>((nt + 255) / 256), 256, 0, e.stream>>>(e.N, bm);
+  k_win16_setup<<<static_cast<unsigned>((ns + 255) / 256), 256, 0, e.stream>>>(e.N, e.S10, sl);
+  const int rb = nblk(e.N, 16);
+  auto timed = [&](auto launch) {
+    for (int r = 0; r < 11; ++r) {
+      if (r == 1) hipEventRecord(e.ev[2], e.stream);
+      launch();
+    }
+    hipEventRecord(e.ev[3], e.stream); hipEventSynchronize(e.ev[3]);
+    float ms = 0; hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
+    return static_cast<double>(ms) / 10.0;
+  };
+#define RX_WP(V, NT) timed([&] { k_spmv_winprobe<V, NT><<<rb, 1024, 0, e.stream>>>(e.N, e.G, e.S10, e.hess, bm, e.xs, e.hst, e.gst, e.type, e.dff, e.partials, e.wall, e.wgh); })
+  out[0] = RX_WP(0, true); out[1] = RX_WP(1, true); out[2] = RX_WP(0, false); out[3] = RX_WP(1, false);
+#undef RX_WP
+#define RX_W16(I) timed([&] { k_spmv_win16probe<2, I><<<rb, 1024, 0, e.stream>>>(e.N, e.G, e.S10, e.hess, sl, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.type, e.dff, e.partials, e.wall, e.wgh); })
+  out[4] = RX_W16(0);
+  if (e.win_valid) { out[5] = RX_W16(1); out[6] = RX_W16(2); out[7] = RX_W16(3); out[8] = e.win_maxunits; }
+#undef RX_W16
+  (void)hipFree(bm); (void)hipFree(sl);
+}
+
+// the real window pass and the real row pass back to back, ten launches each (debug tap 104; experiments only)
+void spmv_isolated_ms(Engine &e, double *out) {
+  out[0] = out[1] = -1.0;
+  const int reps = std::getenv("RXMD_ISO_REPS") ? std::max(1, std::atoi(std::getenv("RXMD_ISO_REPS"))) : 10;
+  auto timed = [&](auto launch) {
+    for (int r = 0; r < reps + 1; ++r) {
+      if (r == 1) hipEventRecord(e.ev[2], e.stream);
+      launch();
+    }
+    hipEventRecord(e.ev[3], e.stream); hipEventSynchronize(e.ev[3]);
+    float ms = 0; hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
+    return static_cast<double>(ms) / reps;
+  };
+  if (e.ff.pqeq) return;
+  if (e.win_valid) {
+    const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
+    out[0] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+  }
+  out[1] = timed([&] { k_spmv<MODE_HSH, true, false, 1><<<nblk(e.N, 16), 1024, 0, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, 1, nullptr, e.N, 0, nullptr); });
+}
+
 // timing probe of the ring pass in isolation (debug tap 101; experiments only): env RXMD_RING_PROBE / _R / _C / _WG as in Engine::qeq.
 // Writes the scratch row sums wall / wgh and the partials only; returns the average launch time.
 double ring_probe_ms(Engine &e, int reps) {
@@ -1155,6 +1486,7 @@ void Engine::qeq() {
   const int dma_wpb_env = std::getenv("RXMD_DMA_WPB") ? std::atoi(std::getenv("RXMD_DMA_WPB")) : 0;
   const int dma_lds_env = std::getenv("RXMD_DMA_LDS") ? std::atoi(std::getenv("RXMD_DMA_LDS")) : 0;
   const int dma_spec_env = std::getenv("RXMD_DMA_SPEC") ? std::atoi(std::getenv("RXMD_DMA_SPEC")) : 1;
+  const bool win_env = std::getenv("RXMD_SPMV_WIN") == nullptr || std::atoi(std::getenv("RXMD_SPMV_WIN")) != 0;   // read per call: the tests switch it
   static const int ring_R_env = std::getenv("RXMD_RING_R") ? std::atoi(std::getenv("RXMD_RING_R")) : 0;
   static const int ring_C = std::getenv("RXMD_RING_C") ? std::max(1, std::min(RING_MAXC, std::atoi(std::getenv("RXMD_RING_C")))) : RING_MAXC;
   static const int ring_min_rows = std::getenv("RXMD_RING_MIN_ROWS") ? std::atoi(std::getenv("RXMD_RING_MIN_ROWS")) : 16384;
@@ -1169,6 +1501,21 @@ void Engine::qeq() {
   const double *stopflag = nullptr;            // run-ahead CG loop only: kernels of an iteration return at once when scal[S_STOP] is set
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) -> int {
     const int nr = rowlist ? nrows : N;
+    win_used = false;
+    if (win_valid && win_env && (!rowlist || rowlist == rows_int || rowlist == rows_bnd)) {   // window pass: the group's partners in LDS, 16-bit slots (k_spmv_win)
+      win_used = true;
+      const int *glist = !rowlist ? nullptr : (rowlist == rows_int ? win_gint : win_gbnd);    // multi-rank overlap: interior groups while the halo is in flight, then the rest
+      const int ng = !rowlist ? win_groups : (rowlist == rows_int ? win_groups - win_nbnd : win_nbnd);
+      if (ng == 0) return 0;
+      const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
+#define RX_WIN3(M, S, P) k_spmv_win<M, S, P><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag)
+#define RX_WIN(M, S) do { if (ff.pqeq) RX_WIN3(M, S, true); else RX_WIN3(M, S, false); } while (0)
+      if (mode == MODE_HSH) { if (store) RX_WIN(MODE_HSH, true); else RX_WIN(MODE_HSH, false); }
+      else { if (store) RX_WIN(MODE_GRAD, true); else RX_WIN(MODE_GRAD, false); }
+#undef RX_WIN
+#undef RX_WIN3
+      return ng;
+    }
     // (not with PQEq: at the 64 registers two workgroups per CU allow, its instances spill, and a scratch access in the loader wave would break
     // the loader's own count of its outstanding DMA instructions)
     if (ring_env && !ff.pqeq && max_row10 <= std::min(ring_R, 1024) && nr >= ring_min_rows && ring_lds <= 160 * 1024 && ff.nso <= 15) {

@@ -404,6 +404,7 @@ def test_matrix_pass_without_the_software_pipeline_is_the_same_operator(qeq_mode
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
     o = _oracle("rdx222", (2, 2, 2), **kw); o.qeq(); o.force()
     res = []
+    monkeypatch.setenv("RXMD_SPMV_WIN", "0")          # the row pass (k_spmv), not the window pass that is the default
     for off in (False, True):
         if off:
             monkeypatch.setenv("RXMD_SPMV_NO_PIPE", "1")
@@ -417,6 +418,33 @@ def test_matrix_pass_without_the_software_pipeline_is_the_same_operator(qeq_mode
         res.append((it, a["q"].copy()))
         e.close()
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("case,mc,qeq_mode", [("rdx222", (2, 2, 2), 0), ("rdx222", (2, 2, 2), 1), ("rdx168", (5, 5, 5), 1), ("ice644", (6, 4, 4), 1), ("sicnp", (1, 1, 1), 0), ("sicnp", (1, 1, 1), 1)])
+def test_window_pass_and_row_pass_are_the_same_operator(case, mc, qeq_mode, monkeypatch):
+    """The default QEq matrix pass (k_spmv_win) holds the partners of a group of 16 cell-sorted rows in LDS and reads them through a 16-bit
+    slot per entry; RXMD_SPMV_WIN=0 is the wavefront-per-row pass with its 16-byte gather per entry (also the fallback when a window does
+    not fit).  Same matrix, same vectors -- only the order in which a row's products are added differs: at the tight tolerance both reach
+    the oracle's fixed point, and the stats say which pass ran."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    if case == "sicnp":
+        kw["pqeq"] = oa.PQEQ_SICNP                  # PQEq: a third stream (shell-core matrix) over the same slots
+    o = _oracle(case, mc, **kw); o.qeq(); o.force()
+    res = {}
+    for win in ("1", "0"):
+        monkeypatch.setenv("RXMD_SPMV_WIN", win)
+        e = _engine(case, mc, qeq_mode=qeq_mode, **kw)
+        it, est = e.QEq(); pe = e.FORCE(); a = e.atoms(); st = e.stats()
+        assert st["win_in_use"] == int(win), st
+        assert st["win_groups"] == (st["natoms"] + 15) // 16 and 0 < st["win_max_units"] <= 448
+        assert q_err(a["q"], o.charges()) <= QTOL
+        assert f_err(a["f"], o.forces()) <= FTOL
+        assert abs(est - o.trace()[-1, 0]) <= 1e-9 * abs(est)
+        res[win] = (a["q"].copy(), a["f"].copy(), pe)
+        e.close()
+    # (the exit test of qeq.F90:114-115 stops both a few 1e-9 short of the fixed point, each on its own side of it)
+    assert q_err(res["1"][0], res["0"][0]) <= 1e-7 and f_err(res["1"][1], res["0"][1]) <= 1e-7
+    assert e_err(res["1"][2], res["0"][2]) <= 1e-8
 
 
 @pytest.mark.parametrize("case,mc", [("rdx222", (2, 2, 2)), ("ice644", (6, 4, 4)), ("example1", (2, 3, 5))])
