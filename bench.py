@@ -142,8 +142,19 @@ def make_workload(workload, ncells):
 
 def pass_bytes(st, pq):
     """algorithmic bytes of ONE matrix pass: value f64 + column i32 per entry (PQEq: + the shell-core value f64 of pqeq.F90:381-411,
-    streamed by the pass that produces Est) + ~7 vector words per row"""
+    streamed by the pass that produces Est) + ~7 vector words per row.  This is the figure `roofline.achieved` is computed from whatever the
+    pass streams: the survey says a scheme that beats the formula is still reported against it."""
     return st["nnz10"] * (20.0 if pq else 12.0) + st["natoms"] * 56.0
+
+
+def pass_info(st, pq):
+    """which matrix pass ran, and the bytes it really streams per launch: the window pass (k_spmv_win) reads a 16-bit window slot instead of the
+    4-byte entry (10 / 18 bytes per entry) plus the window's vector entries once per group of 16 rows"""
+    win = bool(st.get("win_in_use", 0))
+    bpe = (18.0 if pq else 10.0) if win else (20.0 if pq else 12.0)
+    return {"pass": "window (k_spmv_win: 16 cell-sorted rows per workgroup, partners staged in LDS, 16-bit slots)" if win else "row (k_spmv: one wavefront per row, 16-byte gather per entry)",
+            "bytes_per_entry_streamed": bpe, "streamed_bytes_per_launch": st["nnz10"] * bpe + st["natoms"] * 56.0,
+            "window_groups": st.get("win_groups", 0), "largest_window_slots": 8 * st.get("win_max_units", 0)}
 
 
 def compact_leg(workload, ncells, steps, warmup, device, **kw):
@@ -170,8 +181,8 @@ def compact_leg(workload, ncells, steps, warmup, device, **kw):
         return {"workload": "%s = %d atoms, QEq tol %g, dt %g fs" % (wname, len(rec), ekw["QEq_tol"], ekw["dt_fs"]), "isQEq": ekw["isQEq"], "qeq_mode": ekw["qeq_mode"],
                 "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "steps_per_s": steps / dt, "ns_per_day": steps / dt * ekw["dt_fs"] * 86400e-6,
                 "qeq_iters_per_step": st["qeq_iters_total"] / max(st["qeq_calls"], 1), "spmv_launches_per_step": st["spmv_launches"] / steps,
-                "roofline": {"bound": "hbm", "kernel": "k_spmv", "bytes_per_entry": 20 if pqeq else 12, "algorithmic_bytes_per_launch": bp, "avg_launch_ms": ms_spmv, "achieved": ach,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS},
+                "roofline": dict({"bound": "hbm", "kernel": "k_spmv_win" if st.get("win_in_use") else "k_spmv", "bytes_per_entry": 20 if pqeq else 12, "algorithmic_bytes_per_launch": bp, "avg_launch_ms": ms_spmv, "achieved": ach,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}, **pass_info(st, pqeq is not None)),
                 "breakdown_ms_per_step": {k: st[k] / steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_winbuild")}}
     finally:
         eng.close()
@@ -388,8 +399,9 @@ def main():
         #  (i) SURVEY 8d's formula as written: TWO matrix passes per CG iteration (the reference algebra, qeq_mode 0)
         # (ii) the bytes of the passes this run actually launched (qeq_mode 1: one pass per iteration + ~300 B of vector kernels)
         passes = st["spmv_launches"] / a.steps
-        b_fixed = n10 * 12 + 40 + n10 * 4 + 64 + nb * 104 * 5
-        b_step_exec = b_fixed + passes * (n10 * (20 if pqeq else 12) + 56) + iters * (300 if a.qeq_mode == 1 else 112)
+        pinfo = pass_info(st, pqeq is not None)
+        b_fixed = n10 * 12 + 40 + n10 * 4 + 64 + nb * 104 * 5 + (n10 * 6 if st.get("win_in_use") else 0)      # window build: entries read, slots written
+        b_step_exec = b_fixed + passes * (n10 * pinfo["bytes_per_entry_streamed"] + 56) + iters * (300 if a.qeq_mode == 1 else 112)
         # the kernels behind the ~21 ms of a step that are not the matrix pass: HIP-event time per launch (rxmd_stats.ms_k_*), algorithmic bytes
         # per launch (SURVEY 8d / DESIGN.md 3), PMC bytes per launch where profiles/kernel_traffic.json holds them for this workload
         ktraffic = {}
@@ -424,6 +436,15 @@ def main():
                         "achieved_GBs": st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 if ms_cg_vec > 0 else 0.0,
                         "frac": (st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_cg_vec > 0 else 0.0, "traffic": traffic_for("k_cg_update", "k_cg_direction", "k_sorted_vec", "k_reduce_fused"),
                         "note": "per CG iteration, everything of qeq() that is neither the matrix pass nor the list build"})
+        t_pass = traffic_for("k_spmv_win" if st.get("win_in_use") else "k_spmv")
+        if t_pass is not None:
+            traffic = t_pass
+        elif st.get("win_in_use"):
+            traffic = None                           # (profiles/spmv_traffic.json is the row pass)
+        kernels.append({"name": "k_win_build", "ms": st.get("ms_k_winbuild", 0.0) / max(a.steps, 1), "algorithmic_bytes": st["nnz10"] * 6.0,
+                        "achieved_GBs": (st["nnz10"] * 6.0 / (st["ms_k_winbuild"] / a.steps * 1e-3) / 1e9) if st.get("ms_k_winbuild", 0.0) > 0 else 0.0,
+                        "frac": (st["nnz10"] * 6.0 / (st["ms_k_winbuild"] / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS) if st.get("ms_k_winbuild", 0.0) > 0 else 0.0,
+                        "traffic": traffic_for("k_win_build"), "note": "window form of the matrix, once per list build: entries read, 16-bit slots written"})
         out = {
             "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; one step advances every GPU's domain: weak scaling, wall-clock steps/s of the whole job)" if a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS
                       else "MD steps/sec (%s, %d atoms/GPU; wall-clock steps/s of the whole job)" % (a.workload, natoms),
@@ -436,8 +457,11 @@ def main():
                        "qeq_mode": a.qeq_mode},
             "steps_per_s_wall": steps_per_s, "ns_per_day": steps_per_s * cfg["dt"] * 86400e-6, "atom_steps_per_s": steps_per_s * natoms * world,
             "qeq_iters_per_step": iters, "ms_qeq_per_iter": st["ms_qeq"] / max(st["qeq_iters_total"], 1), "n10": n10, "nb": nb,
-            "roofline": {"bound": "hbm", "kernel": "k_spmv (QEq matrix pass, qeq.hip)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("k_spmv_win" if st.get("win_in_use") else "k_spmv") + " (QEq matrix pass, qeq.hip)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_pass,
+                         "pass": pinfo["pass"], "bytes_per_entry_streamed": pinfo["bytes_per_entry_streamed"], "streamed_bytes_per_launch": pinfo["streamed_bytes_per_launch"],
+                         "streamed_GBs": (pinfo["streamed_bytes_per_launch"] / (ms_spmv * 1e-3) / 1e9) if ms_spmv > 0 else 0.0,
+                         "window_groups": pinfo["window_groups"], "largest_window_slots": pinfo["largest_window_slots"],
                          "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"], "launches_that_returned_at_once": st.get("spmv_noop_launches", 0),
                          "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,
                          "spmv_launches_per_step": passes,

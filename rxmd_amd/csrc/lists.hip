@@ -415,6 +415,10 @@ __global__ void __launch_bounds__(512) k_win_build(int N, int S10, const int *__
   bool bnd = false;                                   // does a row of the group have a ghost partner? (multi-rank: the group waits for the vector halo)
 #pragma unroll
   for (int j = 0; j < RPW; ++j) { const int nraw = row[j] >= 0 ? n10[row[j]] : 0; n[j] = nraw & N10_COUNT; bnd |= (nraw & N10_GHOST_ROW) != 0; }
+  bool toolong = false;
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) toolong |= n[j] > 64 * NE;
+  if (toolong) { if (lane == 0) atomicExch(&err[6], 1); }    // (uniform per wavefront; the group still completes with the entries it holds)
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
     const size_t base = static_cast<size_t>(row[j] >= 0 ? row[j] : 0) * S10;
@@ -512,8 +516,11 @@ void Engine::build_windows() {
   int *gflag = multi() ? flags2 : nullptr;           // (the resident flags are used up)
   const int wprobe = std::getenv("RXMD_WINB_PROBE") ? std::atoi(std::getenv("RXMD_WINB_PROBE")) : 0;   // timing probes: stop after a phase (the pass must be off then)
   const bool ktw = kt_begin(&st.ms_k_winbuild);
-  if (S10 <= 512) k_win_build<8><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
-  else if (S10 <= 768) k_win_build<12><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
+  // entries per lane the kernel keeps in registers: by the longest row of the PREVIOUS build plus a margin (this build's is not known on the
+  // host yet); a row that outgrows it sets the failure word and this step's passes are row passes
+  const int need = max_row10 > 0 ? std::min(S10, max_row10 + max_row10 / 16 + 8) : S10;
+  if (need <= 512) k_win_build<8><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
+  else if (need <= 768) k_win_build<12><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
   else k_win_build<16><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
   kt_end(ktw);
   if (multi()) {                                     // interior groups (no row with a ghost partner) / boundary groups: the two launches of an overlapped pass

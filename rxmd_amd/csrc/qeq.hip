@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
 // Timing probe with synthetic slots before it was built (debug tap 103): 0.76 ms against 0.93 ms of k_spmv on the same box.
 template <int MODE, bool STORE, bool PQ>
-__global__ void __launch_bounds__(64 * WIN_ROWS) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
+__global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
                                                             const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
@@ -245,13 +245,23 @@ __global__ void __launch_bounds__(64 * WIN_ROWS) k_spmv_win(int N, int G, int S1
   extern __shared__ double2 s_x[];                  // the window: slot -> (xs, xt)
   __shared__ double s_row[WIN_ROWS][4];
   constexpr int STEPS = 2;                          // 2 x 128 entries of the row in flight
+  constexpr int NT = 64 * WIN_ROWS;
   typedef double d2v __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int gidx = xcd_swizzle(blockIdx.x, gridDim.x);
   const int grp = grouplist ? (gidx < ngroups ? grouplist[gidx] : -1) : (gidx < ngroups ? gidx : -1);
+  if (grp < 0) return;                              // (whole workgroup)
+  // Round trip 1: everything that needs only the group number -- the row of this wavefront, the window's size, the first positions of the
+  // window units this thread will copy (two rounds of 1,024 slots cover 256 units; the descriptor row is WIN_MAXUNITS long whatever the
+  // count), and for wavefront 0 the rows whose tails it runs at the end.
   const int ridx = grp * WIN_ROWS + wave;
-  const int row = (grp >= 0 && ridx < N) ? rows_sorted[ridx] : N;
+  const int row = ridx < N ? rows_sorted[ridx] : N;
+  const int nslots = WIN_UNIT * win_cnt[grp];
+  const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
+  const int t0 = threadIdx.x, t1 = threadIdx.x + NT;
+  const int wk0 = wk[t0 / WIN_UNIT], wk1 = wk[t1 / WIN_UNIT];                      // (t1 / 8 < 256 <= WIN_MAXUNITS)
+  const int r_tail = (wave == 0 && lane < WIN_ROWS && grp * WIN_ROWS + lane < N) ? rows_sorted[grp * WIN_ROWS + lane] : N;
   const bool live = row < N;
   const size_t base = static_cast<size_t>(live ? row : 0) * S10;
   const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
@@ -268,13 +278,27 @@ __global__ void __launch_bounds__(64 * WIN_ROWS) k_spmv_win(int N, int G, int S1
       if (PQ && (MODE == MODE_GRAD || STORE)) { if (ok) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); c[u] = make_double2(t2.x, t2.y); } else c[u] = make_double2(0.0, 0.0); }
     }
   };
-  request(0, live ? S10 : 0);                       // before the row length is known: the first batch lies inside the row's slot whatever the length
+  // Round trip 2: the window's vector entries FIRST (they return first, and the workgroup's barrier waits for them only), then the row's
+  // first batch -- before the row length is known: it lies inside the row's slot whatever the length -- the length, the tail operands.
+  double2 x0 = make_double2(0.0, 0.0), x1 = x0;
+  if (t0 < nslots) x0 = xv[min(wk0 + (t0 & (WIN_UNIT - 1)), G - 1)];
+  if (t1 < nslots) x1 = xv[min(wk1 + (t1 & (WIN_UNIT - 1)), G - 1)];
+  request(0, live ? S10 : 0);
   const int n = live ? (n10[row] & N10_COUNT) : 0;
-  if (grp >= 0) {                                   // the group's window: unit t >> 3, position t & 7
-    const int nslots = WIN_UNIT * win_cnt[grp];
-    const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
-    for (int t = threadIdx.x; t < nslots; t += blockDim.x) s_x[t] = xv[min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1)];
-  }
+  constexpr bool EARLY_TAIL = !PQ;                  // (the PQEq instances have no registers to spare: their tail operands are requested at the end)
+  int tl_t = 0; double2 tl_a = make_double2(0.0, 0.0), tl_b = tl_a; double4 tl_p = make_double4(0.0, 0.0, 0.0, 0.0);
+  auto tail_operands = [&]() {
+    if (r_tail < N) {
+      tl_t = type[r_tail];
+      tl_a = (MODE == MODE_HSH) ? hst[r_tail] : qst[r_tail];
+      tl_b = (MODE == MODE_HSH) ? gst[r_tail] : make_double2(q[r_tail], 0.0);
+      if (PQ && MODE == MODE_GRAD) tl_p = pqrow[r_tail];
+    }
+  };
+  if (EARLY_TAIL) tail_operands();
+  if (t0 < nslots) s_x[t0] = x0;
+  if (t1 < nslots) s_x[t1] = x1;
+  for (int t = threadIdx.x + 2 * NT; t < nslots; t += NT) s_x[t] = xv[min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1)];   // a window of more than 256 units
 #pragma unroll
   for (int u = 0; u < STEPS; ++u) {                // entries behind the row's end: weight 0, slot 0
     const int k = 128 * u + 2 * lane;
@@ -287,13 +311,13 @@ __global__ void __launch_bounds__(64 * WIN_ROWS) k_spmv_win(int N, int G, int S1
     if (kb > 0) request(kb, n);                     // (an odd row end: entry n is the zero padding of the row, slot 0)
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
-      const double2 x0 = s_x[ss[u] & 0x7fffu], x1 = s_x[(ss[u] >> 16) & 0x7fffu];
-      as += v[u].x * x0.x; at += v[u].x * x0.y; as += v[u].y * x1.x; at += v[u].y * x1.y;
+      const double2 y0 = s_x[ss[u] & 0x7fffu], y1 = s_x[(ss[u] >> 16) & 0x7fffu];
+      as += v[u].x * y0.x; at += v[u].x * y0.y; as += v[u].y * y1.x; at += v[u].y * y1.y;
       if ((MODE == MODE_GRAD || STORE) && !PQ) {
         const double g0 = (ss[u] & 0x8000u) ? v[u].x : 0.0, g1 = (ss[u] & 0x80000000u) ? v[u].y : 0.0;     // select the weight, not the sums
-        gs_ += g0 * x0.x; gt_ += g0 * x0.y; gs_ += g1 * x1.x; gt_ += g1 * x1.y;
+        gs_ += g0 * y0.x; gt_ += g0 * y0.y; gs_ += g1 * y1.x; gt_ += g1 * y1.y;
       }
-      if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * x0.x; gt_ += c[u].x * x0.y; gs_ += c[u].y * x1.x; gt_ += c[u].y * x1.y; }
+      if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * y0.x; gt_ += c[u].x * y0.y; gs_ += c[u].y * y1.x; gt_ += c[u].y * y1.y; }
     }
   }
   as = wave_sum(as); at = wave_sum(at);
@@ -301,31 +325,30 @@ __global__ void __launch_bounds__(64 * WIN_ROWS) k_spmv_win(int N, int G, int S1
   if (lane == 0) { s_row[wave][0] = as; s_row[wave][1] = at; s_row[wave][2] = gs_; s_row[wave][3] = gt_; }
   __syncthreads();
   if (wave != 0) return;
-  {                                                 // the row tails of the group, lane r = the row of wavefront r (as k_spmv)
-    const int r_idx = grp * WIN_ROWS + lane;
-    const int r = (grp >= 0 && lane < WIN_ROWS && r_idx < N) ? rows_sorted[r_idx] : N;
+  {                                                 // the row tails of the group, lane r = the row of wavefront r (as k_spmv); operands are here already
+    const int r = r_tail;
+    if (!EARLY_TAIL) tail_operands();
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (r < N) {
       const double ras = s_row[lane][0], rat = s_row[lane][1], rgs = s_row[lane][2], rgt = s_row[lane][3];
-      const int t = type[r];
-      const double2 pa = (MODE == MODE_HSH) ? hst[r] : qst[r];
-      const DevAtomP ap = ff.atom[t];
+      const double2 pa = tl_a;
+      const DevAtomP ap = ff.atom[tl_t];
       if (STORE) { rs_all[r] = make_double2(ras, rat); rs_gh[r] = make_double2(rgs, rgt); }
       if (MODE == MODE_HSH) {
-        const double2 pb = gst[r];
+        const double2 pb = tl_b;
         const double ts = ap.eta * pa.x + ras, tt = ap.eta * pa.y + rat;        // qeq.F90:294-302
         a0 = ts * pa.x; a1 = tt * pa.y;                                         // hshs_sum, hsht_sum (:309-310)
         a2 = pb.x * pa.x; a3 = pb.y * pa.y;                                     // g.h (:119,123)
       } else {
         const double mu = scal[S_MU];
-        const double fpq = PQ ? pqrow[r].x : 0.0;
+        const double fpq = PQ ? tl_p.x : 0.0;
         const double g1 = -ap.chi - ap.eta * pa.x - ras - fpq;                  // qeq.F90:349-350 (pqeq.F90:466)
         const double g2 = -1.0 - ap.eta * pa.y - rat;
         gst[r] = make_double2(g1, g2);
         a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
-        const double qi = q[r];
+        const double qi = tl_b.x;
         const double hq_all = ras - mu * rat, hq_res = (ras - rgs) - mu * (rat - rgt);
-        if (PQ) a2 = pq_est_row(ap, ff.Zpq[t], pqrow[r], qi, hq_all, rgs - mu * rgt);
+        if (PQ) a2 = pq_est_row(ap, ff.Zpq[tl_t], tl_p, qi, hq_all, rgs - mu * rgt);
         else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
       }
     }
