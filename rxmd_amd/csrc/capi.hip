@@ -12,7 +12,7 @@
 
 #include "engine.h"
 
-namespace rxmd { double stream_probe_ms(Engine &e, int blocks); double ring_probe_ms(Engine &e, int reps); void spmv_bisect_ms(Engine &e, double *out4); void spmv_winprobe_ms(Engine &e, double *out2); void spmv_isolated_ms(Engine &e, double *out); }
+namespace rxmd { double stream_probe_ms(Engine &e, int blocks); void spmv_bisect_ms(Engine &e, double *out4); void spmv_isolated_ms(Engine &e, double *out); }
 using rxmd::Engine;
 using rxmd::EngineError;
 
@@ -477,9 +477,7 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
         for (int g = 0; g < 4; ++g) { out[2 * g] = rxmd::stream_probe_ms(e, grids[g]); out[2 * g + 1] = static_cast<double>(e.rows10) * e.S10 * 8.0; }
         n = 8; break;
       }
-      case 101: n = 1; if (capacity < 1) throw EngineError(RXMD_E_ARG, "capacity"); out[0] = rxmd::ring_probe_ms(e, 10); break;   // ring matrix pass alone (experiments)
       case 104: n = 2; if (capacity < 2) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_isolated_ms(e, out); break;   // real window pass / row pass back to back (experiments)
-      case 103: n = 9; if (capacity < 9) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_winprobe_ms(e, out); break;   // window pass, synthetic timing probe (experiments)
       case 102: n = 7; if (capacity < 7) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_bisect_ms(e, out); break;   // stripped-down forms of the row kernel (experiments)
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");
     }

@@ -146,7 +146,6 @@ struct Engine {
   // capacities
   int NB = 0, MAXNB = 30, S10 = 0, rows10 = 0;
   int max_row10 = 0, min_row10 = 0;   // longest / shortest row of the current 10 A list
-  int2 *rsched[3] = {nullptr, nullptr, nullptr}; bool rsched_valid[3] = {false, false, false};   // ring matrix pass: (row, length) in streaming order per workgroup: all rows / interior / boundary (qeq.hip)
   int num_cu = 256;               // compute units of the device: grid of the persistent kernels (one workgroup per CU)
   int N = 0, G = 0, copyptr[7] = {0};
   int cc[3] = {1, 1, 1};          // reference bonded cell counts, only to derive the ghost shell (init.F90:656)

@@ -507,6 +507,13 @@ __global__ void k_split_groups(int ng, const int *__restrict__ flag, const int *
 void Engine::build_windows() {
   win_groups = 0;
   if (std::getenv("RXMD_SPMV_NO_WIN") || (S10 & 3) || N <= 0 || S10 > 1024) return;
+  // The build costs about as much as four to seven matrix passes save: not for the extended-Lagrangian mode (one iteration per step, qeq.F90:51-57), a
+  // small NMAXQEq, or when the previous call converged in a few iterations (RXMD_SPMV_WIN=2 builds regardless)
+  {
+    const char *wv = std::getenv("RXMD_SPMV_WIN");
+    const int expect = (cfg.isQEq == 1) ? (st.qeq_calls > 0 ? std::min(cfg.NMAXQEq, st.qeq_iters_last) : cfg.NMAXQEq) : (cfg.isQEq == 2 ? 1 : 0);
+    if (expect < 5 && !(wv && std::atoi(wv) == 2)) return;
+  }
   k_resident_flags<<<nblk(G + 1, 256), 256, 0, stream>>>(G, N, perm, flags2);
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, G + 1, stream));
@@ -544,7 +551,6 @@ void Engine::build_list10() {
   if (const char *pv = std::getenv("RXMD_LIST_PROBE")) grid.probe = std::atoi(pv);
   RX_HIP(hipMemsetAsync(d_err + 3, 0, sizeof(int), stream));
   RX_HIP(hipMemsetAsync(d_err + 4, 0x7f, sizeof(int), stream));      // 0x7f7f7f7f: larger than any row
-  rsched_valid[0] = rsched_valid[1] = rsched_valid[2] = false;
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);
 #define RX_LIST10(SC, PQF) do { if (grid.ortho) RX_LIST10_O(SC, PQF, true); else RX_LIST10_O(SC, PQF, false); } while (0)

