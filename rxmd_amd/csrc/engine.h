@@ -260,6 +260,7 @@ struct Engine {
   int *win_gint = nullptr, *win_gbnd = nullptr; int win_nbnd = 0;     // multi-rank: groups without / with a row that has a ghost partner
   unsigned short *sl10 = nullptr;
   int win_groups = 0, win_maxunits = 0;
+  double qeq_iters_smooth = -1.0;               // running mean of the CG iterations per QEq call (the exit test of qeq.F90:114-115 lets single calls stop after two or three)
   bool win_valid = false, win_used = false;    // win_used: the last matrix pass was a window pass
   void halo_refresh(double2 *v2, double *v1);       // QCOPY1/QCOPY2: ghosts <- owners (self exchange, resolved roots)
   void halo_staged(double *v, int ncomp);           // the same through the six-stage exchange (multi-rank)

@@ -508,11 +508,11 @@ void Engine::build_windows() {
   win_groups = 0;
   if (std::getenv("RXMD_SPMV_NO_WIN") || (S10 & 3) || N <= 0 || S10 > 1024) return;
   // The build costs about as much as four to seven matrix passes save: not for the extended-Lagrangian mode (one iteration per step, qeq.F90:51-57), a
-  // small NMAXQEq, or when the previous call converged in a few iterations (RXMD_SPMV_WIN=2 builds regardless)
+  // small NMAXQEq, or when the calls so far converged in a few iterations on average (RXMD_SPMV_WIN=2 builds regardless)
   {
     const char *wv = std::getenv("RXMD_SPMV_WIN");
-    const int expect = (cfg.isQEq == 1) ? (st.qeq_calls > 0 ? std::min(cfg.NMAXQEq, st.qeq_iters_last) : cfg.NMAXQEq) : (cfg.isQEq == 2 ? 1 : 0);
-    if (expect < 5 && !(wv && std::atoi(wv) == 2)) return;
+    const double expect = (cfg.isQEq == 1) ? (qeq_iters_smooth >= 0.0 ? std::min<double>(cfg.NMAXQEq, qeq_iters_smooth) : cfg.NMAXQEq) : (cfg.isQEq == 2 ? 1.0 : 0.0);
+    if (expect < 5.0 && !(wv && std::atoi(wv) == 2)) return;
   }
   k_resident_flags<<<nblk(G + 1, 256), 256, 0, stream>>>(G, N, perm, flags2);
   size_t tb = cubtmp_bytes;

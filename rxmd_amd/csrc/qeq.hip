@@ -187,7 +187,10 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   if (stopflag && *stopflag != 0.0) return;
   extern __shared__ double2 s_x[];                  // the window: slot -> (xs, xt)
   __shared__ double s_row[WIN_ROWS][4];
-  constexpr int STEPS = 2;                          // 2 x 128 entries of the row in flight
+#ifndef WIN_STEPS
+#define WIN_STEPS 2
+#endif
+  constexpr int STEPS = WIN_STEPS;                  // 2 x 128 entries of the row in flight
   constexpr int NT = 64 * WIN_ROWS;
   typedef double d2v __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63;
@@ -832,7 +835,7 @@ void Engine::qeq() {
     }
     if (ff.pqeq) pqeq_update_shells();
     nstep_qeq = it; last_est = Est;
-    st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1;
+    st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1; qeq_iters_smooth = qeq_iters_smooth < 0.0 ? it : 0.75 * qeq_iters_smooth + 0.25 * it;
     sync_stream();                                 // the kernels of an iteration that did not happen are still in the queue: cheap, but they read scal
     collect_timers();
     st.ms_qeq += toc(6, 7);
@@ -924,7 +927,7 @@ void Engine::qeq() {
   if (halo_in_flight) join_comm_stream();             // the loop ended while a halo it will not use was still in flight
   if (ff.pqeq) pqeq_update_shells();                  // pqeq.F90:169
   nstep_qeq = it; last_est = Est;
-  st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1;
+  st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1; qeq_iters_smooth = qeq_iters_smooth < 0.0 ? it : 0.75 * qeq_iters_smooth + 0.25 * it;
   st.ms_qeq += toc(6, 7);
 }
 
