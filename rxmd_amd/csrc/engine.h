@@ -353,7 +353,10 @@ constexpr unsigned NB10_GHOST = 1u << 30, NB10_SELF = 1u << 31;
 // n10[row] = entries of the row; bit 30: the row has a ghost partner (a boundary row of the domain).  The matrix pass needs the sums over
 // ghost columns only there (74 % of the rows of a 979,776-atom domain have none) and reads the flag with the length it needs anyway.
 constexpr int N10_GHOST_ROW = 1 << 30, N10_COUNT = N10_GHOST_ROW - 1;
-constexpr int WIN_ROWS = 16;        // rows of a window group = wavefronts of a workgroup of the window pass
+#ifndef WIN_ROWS_DEF
+#define WIN_ROWS_DEF 16
+#endif
+constexpr int WIN_ROWS = WIN_ROWS_DEF;   // rows of a window group = wavefronts of a workgroup of the window pass (measured: 8 -> see DESIGN.md 3)
 constexpr int WIN_UNIT = 8;         // cell-sorted positions per window unit (8 x 16 bytes = one 128-byte line of the sorted vector)
 constexpr int WIN_MAXUNITS = 448;   // units a group's descriptor holds: 3,584 slots = 56 KB of LDS (two workgroups per CU)
 constexpr int WIN_BMW = 2048;       // 64-bit words of the coverage map the build kernel keeps in LDS: a group's positions may span 2048 x 64 x 8 = 1 M
