@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     s0 = e.stats(); e.step(4); s1 = e.stats(); nl = s1["spmv_launches"] - s0["spmv_launches"]
     print("%-6s back to back: window %.4f row %.4f | in the CG loop %.4f ms (%d passes) | winbuild %.3f" % (sys.argv[2], iso[0], iso[1], (s1["ms_qeq_spmv"] - s0["ms_qeq_spmv"]) / nl, nl, (s1["ms_k_winbuild"] - s0["ms_k_winbuild"]) / 4), flush=True)
     e.close(); sys.exit(0)
-for rep in range(2):
+for rep in range(int(os.environ.get("AB_REPS", "2"))):
     for t in sys.argv[1:]:
         env = dict(os.environ)
         if t != "base": env["RXMD_HIP_LIB"] = os.path.join(root, "rxmd_amd", "librxmd_hip_%s.so" % t)
