@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   if (stopflag && *stopflag != 0.0) return;
   extern __shared__ double2 s_x[];                  // the window: slot -> (xs, xt)
   __shared__ double s_row[WIN_ROWS][4];
+  __shared__ int s_arrived;
 #ifndef WIN_STEPS
 #define WIN_STEPS 2
 #endif
@@ -199,15 +200,13 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   const int grp = grouplist ? (gidx < ngroups ? grouplist[gidx] : -1) : (gidx < ngroups ? gidx : -1);
   if (grp < 0) return;                              // (whole workgroup)
   // Round trip 1: everything that needs only the group number -- the row of this wavefront, the window's size, the first positions of the
-  // window units this thread will copy (two rounds of 1,024 slots cover 256 units; the descriptor row is WIN_MAXUNITS long whatever the
-  // count), and for wavefront 0 the rows whose tails it runs at the end.
+  // window units this thread will copy (two rounds of 1,024 slots cover 256 units; the descriptor row is WIN_MAXUNITS long whatever the count).
   const int ridx = grp * WIN_ROWS + wave;
   const int row = ridx < N ? rows_sorted[ridx] : N;
   const int nslots = WIN_UNIT * win_cnt[grp];
   const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
   const int t0 = threadIdx.x, t1 = threadIdx.x + NT;
   const int wk0 = wk[t0 / WIN_UNIT], wk1 = wk[t1 / WIN_UNIT];                      // (t1 / 8 < 256 <= WIN_MAXUNITS)
-  const int r_tail = (wave == 0 && lane < WIN_ROWS && grp * WIN_ROWS + lane < N) ? rows_sorted[grp * WIN_ROWS + lane] : N;
   const bool live = row < N;
   const size_t base = static_cast<size_t>(live ? row : 0) * S10;
   const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
@@ -225,23 +224,18 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
     }
   };
   // Round trip 2: the window's vector entries FIRST (they return first, and the workgroup's barrier waits for them only), then the row's
-  // first batch -- before the row length is known: it lies inside the row's slot whatever the length -- the length, the tail operands.
+  // first batch -- before the row length is known: it lies inside the row's slot whatever the length -- the length, and the operands of the
+  // row's tail (the row is the same for the 64 lanes: scalar loads, no vector registers).
   double2 x0 = make_double2(0.0, 0.0), x1 = x0;
   if (t0 < nslots) x0 = xv[min(wk0 + (t0 & (WIN_UNIT - 1)), G - 1)];
   if (t1 < nslots) x1 = xv[min(wk1 + (t1 & (WIN_UNIT - 1)), G - 1)];
   request(0, live ? S10 : 0);
   const int n = live ? (n10[row] & N10_COUNT) : 0;
-  constexpr bool EARLY_TAIL = !PQ;                  // (the PQEq instances have no registers to spare: their tail operands are requested at the end)
-  int tl_t = 0; double2 tl_a = make_double2(0.0, 0.0), tl_b = tl_a; double4 tl_p = make_double4(0.0, 0.0, 0.0, 0.0);
-  auto tail_operands = [&]() {
-    if (r_tail < N) {
-      tl_t = type[r_tail];
-      tl_a = (MODE == MODE_HSH) ? hst[r_tail] : qst[r_tail];
-      tl_b = (MODE == MODE_HSH) ? gst[r_tail] : make_double2(q[r_tail], 0.0);
-      if (PQ && MODE == MODE_GRAD) tl_p = pqrow[r_tail];
-    }
-  };
-  if (EARLY_TAIL) tail_operands();
+  const int rowc = live ? row : 0;
+  const int tl_t = type[rowc];
+  const double2 tl_a = (MODE == MODE_HSH) ? hst[rowc] : qst[rowc];
+  const double2 tl_b = (MODE == MODE_HSH) ? const_cast<const double2 *>(gst)[rowc] : make_double2(q[rowc], 0.0);
+  if (threadIdx.x == 0) s_arrived = 0;
   if (t0 < nslots) s_x[t0] = x0;
   if (t1 < nslots) s_x[t1] = x1;
   for (int t = threadIdx.x + 2 * NT; t < nslots; t += NT) s_x[t] = xv[min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1)];   // a window of more than 256 units
@@ -268,41 +262,44 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   }
   as = wave_sum(as); at = wave_sum(at);
   if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-  if (lane == 0) { s_row[wave][0] = as; s_row[wave][1] = at; s_row[wave][2] = gs_; s_row[wave][3] = gt_; }
-  __syncthreads();
-  if (wave != 0) return;
-  {                                                 // the row tails of the group, lane r = the row of wavefront r (as k_spmv); operands are here already
-    const int r = r_tail;
-    if (!EARLY_TAIL) tail_operands();
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (r < N) {
-      const double ras = s_row[lane][0], rat = s_row[lane][1], rgs = s_row[lane][2], rgt = s_row[lane][3];
-      const double2 pa = tl_a;
-      const DevAtomP ap = ff.atom[tl_t];
-      if (STORE) { rs_all[r] = make_double2(ras, rat); rs_gh[r] = make_double2(rgs, rgt); }
-      if (MODE == MODE_HSH) {
-        const double2 pb = tl_b;
-        const double ts = ap.eta * pa.x + ras, tt = ap.eta * pa.y + rat;        // qeq.F90:294-302
-        a0 = ts * pa.x; a1 = tt * pa.y;                                         // hshs_sum, hsht_sum (:309-310)
-        a2 = pb.x * pa.x; a3 = pb.y * pa.y;                                     // g.h (:119,123)
-      } else {
-        const double mu = scal[S_MU];
-        const double fpq = PQ ? tl_p.x : 0.0;
-        const double g1 = -ap.chi - ap.eta * pa.x - ras - fpq;                  // qeq.F90:349-350 (pqeq.F90:466)
-        const double g2 = -1.0 - ap.eta * pa.y - rat;
-        gst[r] = make_double2(g1, g2);
-        a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
-        const double qi = tl_b.x;
-        const double hq_all = ras - mu * rat, hq_res = (ras - rgs) - mu * (rat - rgt);
-        if (PQ) a2 = pq_est_row(ap, ff.Zpq[tl_t], tl_p, qi, hq_all, rgs - mu * rgt);
-        else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
-      }
+  // The row's tail by its own wavefront (the rows of a group are scattered residents: nothing would coalesce if one wavefront ran all of them,
+  // and a workgroup whose last wavefront works alone keeps 15 wavefront slots of the CU empty); a wavefront leaves when it is done.  The
+  // workgroup's four partial sums: every wavefront leaves its terms in LDS, the LAST one to arrive adds them in wavefront order.
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (live) {
+    const DevAtomP ap = ff.atom[tl_t];
+    if (MODE == MODE_HSH) {
+      const double ts = ap.eta * tl_a.x + as, tt = ap.eta * tl_a.y + at;      // qeq.F90:294-302
+      a0 = ts * tl_a.x; a1 = tt * tl_a.y;                                     // hshs_sum, hsht_sum (:309-310)
+      a2 = tl_b.x * tl_a.x; a3 = tl_b.y * tl_a.y;                             // g.h (:119,123)
+      if (STORE && lane == 0) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+    } else {
+      const double mu = scal[S_MU];
+      const double4 pr = PQ ? pqrow[row] : make_double4(0.0, 0.0, 0.0, 0.0);
+      const double g1 = -ap.chi - ap.eta * tl_a.x - as - pr.x;                // qeq.F90:349-350 (pqeq.F90:466)
+      const double g2 = -1.0 - ap.eta * tl_a.y - at;
+      a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
+      const double qi = tl_b.x;
+      const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+      if (PQ) a2 = pq_est_row(ap, ff.Zpq[tl_t], pr, qi, hq_all, gs_ - mu * gt_);
+      else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
+      if (lane == 0) { gst[row] = make_double2(g1, g2); if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); } }
     }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);           // fixed order over the group's rows
-    if (lane < 4) {
-      const double val = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
-      __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  }
+  int arrived = 0;
+  if (lane == 0) {
+    s_row[wave][0] = a0; s_row[wave][1] = a1; s_row[wave][2] = a2; s_row[wave][3] = a3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    arrived = __hip_atomic_fetch_add(&s_arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  arrived = __builtin_amdgcn_readfirstlane(arrived);
+  if (arrived != WIN_ROWS - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane < 4) {
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < WIN_ROWS; ++w) sum += s_row[w][lane];                 // fixed order: the result does not depend on which wavefront is last
+    __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
