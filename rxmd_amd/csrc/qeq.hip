@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // entries per lane and request (16-byte / 4-byte loads), 256 entries of a row in flight.  Same sums in the same per-row roles as k_spmv; the
 // order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
 // Timing probe with synthetic slots before it was built (debug tap 103): 0.76 ms against 0.93 ms of k_spmv on the same box.
-template <int MODE, bool STORE, bool PQ>
+template <int MODE, bool STORE, bool PQ, int VAR = 0>      // VAR: variants under measurement are compiled side by side and timed by debug tap 104 (none now); 0 = the pass
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
@@ -382,9 +382,10 @@ void spmv_bisect_ms(Engine &e, double *out4) {
   (void)hipFree(buf32);
 }
 
-// the real window pass and the real row pass back to back, ten launches each (debug tap 104; experiments only)
+// the real window pass and the real row pass back to back, alternating in ONE process (timings repeat to 0.1 % inside a process and differ
+// by +-6 % between processes on the same box, so variants are compared here, compiled side by side) (debug tap 104; experiments only)
 void spmv_isolated_ms(Engine &e, double *out) {
-  out[0] = out[1] = -1.0;
+  for (int k = 0; k < 4; ++k) out[k] = -1.0;
   const int reps = std::getenv("RXMD_ISO_REPS") ? std::max(1, std::atoi(std::getenv("RXMD_ISO_REPS"))) : 10;
   auto timed = [&](auto launch) {
     for (int r = 0; r < reps + 1; ++r) {
@@ -396,11 +397,17 @@ void spmv_isolated_ms(Engine &e, double *out) {
     return static_cast<double>(ms) / reps;
   };
   if (e.ff.pqeq) return;
-  if (e.win_valid) {
-    const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
-    out[0] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const int rounds = 3;                             // the three kernels alternate: one state of the box for all of them
+  for (int rd = 0; rd < rounds; ++rd) {
+    if (e.win_valid) {
+      const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
+      acc[0] += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+    }
+    acc[1] += timed([&] { k_spmv<MODE_HSH, true, false, 1><<<nblk(e.N, 16), 1024, 0, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, 1, nullptr, e.N, 0, nullptr); });
   }
-  out[1] = timed([&] { k_spmv<MODE_HSH, true, false, 1><<<nblk(e.N, 16), 1024, 0, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, 1, nullptr, e.N, 0, nullptr); });
+  out[1] = acc[1] / rounds;
+  if (e.win_valid) out[0] = acc[0] / rounds;      // out[2], out[3]: variants of the window pass (template parameter VAR) when some are being compared
 }
 
 __global__ void __launch_bounds__(256) k_stream_probe(size_t n16, const f64x2 *__restrict__ a, double *__restrict__ out) {

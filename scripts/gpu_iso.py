@@ -8,11 +8,9 @@ def loop(tag, nsteps=4):
     s0 = e.stats(); e.step(nsteps); s1 = e.stats()
     nl = s1["spmv_launches"] - s0["spmv_launches"]
     print("%-28s in the CG loop: %.4f ms per pass (%d passes, %.1f per step)" % (tag, (s1["ms_qeq_spmv"] - s0["ms_qeq_spmv"]) / nl, nl, nl / nsteps))
-for rep in range(2):
+for rep in range(3):
     os.environ["RXMD_ISO_REPS"] = "100"
-    iso = e.debug(104, cap=4); print('back to back: window pass %.4f ms, row pass %.4f ms' % (iso[0], iso[1]))
+    iso = e.debug(104, cap=8); print('back to back, alternating: window pass %.4f ms, row pass %.4f ms (variants: %.4f %.4f)' % (iso[0], iso[1], iso[2], iso[3]))
     os.environ["RXMD_SPMV_WIN"] = "1"; loop("window pass")
     os.environ["RXMD_SPMV_WIN"] = "0"; loop("row pass")
-    os.environ["RXMD_SPMV_WIN"] = "1"; os.environ["RXMD_CG_NO_RUNAHEAD"] = "1"; loop("window, no run-ahead"); del os.environ["RXMD_CG_NO_RUNAHEAD"]
-    os.environ["RXMD_CG_NO_SCATTER"] = "1"; loop("window, no scatter"); del os.environ["RXMD_CG_NO_SCATTER"]
 e.close()
