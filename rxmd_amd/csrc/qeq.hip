@@ -385,7 +385,7 @@ void spmv_bisect_ms(Engine &e, double *out4) {
 // the real window pass and the real row pass back to back, alternating in ONE process (timings repeat to 0.1 % inside a process and differ
 // by +-6 % between processes on the same box, so variants are compared here, compiled side by side) (debug tap 104; experiments only)
 void spmv_isolated_ms(Engine &e, double *out) {
-  for (int k = 0; k < 4; ++k) out[k] = -1.0;
+  for (int k = 0; k < 10; ++k) out[k] = -1.0;
   const int reps = std::getenv("RXMD_ISO_REPS") ? std::max(1, std::atoi(std::getenv("RXMD_ISO_REPS"))) : 10;
   auto timed = [&](auto launch) {
     for (int r = 0; r < reps + 1; ++r) {
@@ -407,6 +407,25 @@ void spmv_isolated_ms(Engine &e, double *out) {
     acc[1] += timed([&] { k_spmv<MODE_HSH, true, false, 1><<<nblk(e.N, 16), 1024, 0, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, 1, nullptr, e.N, 0, nullptr); });
   }
   out[1] = acc[1] / rounds;
+  // RXMD_ISO_COPIES=1: does the pass time depend on WHERE its streams lie?  Two fresh copies of the value and slot arrays, the pass on each
+  // (out[2], out[3]; addresses in out[4..9]).  It does: same virtual addresses, 0.77 / 0.80 / 0.86 ms in one process.
+  if (e.win_valid && std::getenv("RXMD_ISO_COPIES")) {
+    const size_t ne = static_cast<size_t>(e.rows10) * e.S10;
+    const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
+    out[4] = static_cast<double>(reinterpret_cast<size_t>(e.hess)); out[5] = static_cast<double>(reinterpret_cast<size_t>(e.sl10));
+    for (int c = 0; c < 2; ++c) {
+      double *h2 = nullptr; unsigned short *s2 = nullptr;
+      if (hipMalloc(reinterpret_cast<void **>(&h2), ne * sizeof(double)) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&s2), ne * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); if (h2) (void)hipFree(h2); break; }
+      hipMemcpyAsync(h2, e.hess, ne * sizeof(double), hipMemcpyDeviceToDevice, e.stream);
+      hipMemcpyAsync(s2, e.sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, e.stream);
+      double a = 0.0;
+      for (int rd = 0; rd < rounds; ++rd)
+        a += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2, h2, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+      out[2 + c] = a / rounds;
+      out[6 + 2 * c] = static_cast<double>(reinterpret_cast<size_t>(h2)); out[7 + 2 * c] = static_cast<double>(reinterpret_cast<size_t>(s2));
+      (void)hipFree(h2); (void)hipFree(s2);
+    }
+  }
   if (e.win_valid) out[0] = acc[0] / rounds;      // out[2], out[3]: variants of the window pass (template parameter VAR) when some are being compared
 }
 

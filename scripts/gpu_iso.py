@@ -10,7 +10,7 @@ def loop(tag, nsteps=4):
     print("%-28s in the CG loop: %.4f ms per pass (%d passes, %.1f per step)" % (tag, (s1["ms_qeq_spmv"] - s0["ms_qeq_spmv"]) / nl, nl, nl / nsteps))
 for rep in range(3):
     os.environ["RXMD_ISO_REPS"] = "100"
-    iso = e.debug(104, cap=8); print('back to back, alternating: window pass %.4f ms, row pass %.4f ms (variants: %.4f %.4f)' % (iso[0], iso[1], iso[2], iso[3]))
+    iso = e.debug(104, cap=12); print('back to back, alternating: window pass %.4f ms, row pass %.4f ms (variants: %.4f %.4f)' % (iso[0], iso[1], iso[2], iso[3]))
     os.environ["RXMD_SPMV_WIN"] = "1"; loop("window pass")
     os.environ["RXMD_SPMV_WIN"] = "0"; loop("row pass")
 e.close()
