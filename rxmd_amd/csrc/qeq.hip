@@ -12,6 +12,7 @@
 // iteration: sum_j H_ij q_j = sum_j H_ij qs_j - mu sum_j H_ij qt_j, with the reference's
 // "count resident partners twice" rule kept through a second accumulator over ghost columns.
 #include "engine.h"
+#include <cstdio>
 
 #include <cmath>
 #include <cstdlib>
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   const int t0 = threadIdx.x, t1 = threadIdx.x + NT;
   const int wk0 = wk[t0 / WIN_UNIT], wk1 = wk[t1 / WIN_UNIT];                      // (t1 / 8 < 256 <= WIN_MAXUNITS)
   const bool live = row < N;
-  const size_t base = static_cast<size_t>(live ? row : 0) * S10;
+  const size_t base = static_cast<size_t>(live ? ((VAR & 1) ? ridx : row) : 0) * S10;       // (VAR & 1, experiment: the streams' rows in cell-sorted order)
   const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
   const d2v *cv2 = reinterpret_cast<const d2v *>((PQ ? hsc : hess) + base);
   const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
@@ -382,10 +383,16 @@ void spmv_bisect_ms(Engine &e, double *out4) {
   (void)hipFree(buf32);
 }
 
+__global__ void k_rows_to_rank_order(int N, int S10, const int *__restrict__ rows_sorted, const double *__restrict__ h, const unsigned short *__restrict__ sl, double *__restrict__ h2, unsigned short *__restrict__ s2) {
+  const int r = blockIdx.x;                          // destination row = rank
+  if (r >= N) return;
+  const size_t src = static_cast<size_t>(rows_sorted[r]) * S10, dst = static_cast<size_t>(r) * S10;
+  for (int k = threadIdx.x; k < S10; k += blockDim.x) { h2[dst + k] = h[src + k]; s2[dst + k] = sl[src + k]; }
+}
 // the real window pass and the real row pass back to back, alternating in ONE process (timings repeat to 0.1 % inside a process and differ
 // by +-6 % between processes on the same box, so variants are compared here, compiled side by side) (debug tap 104; experiments only)
 void spmv_isolated_ms(Engine &e, double *out) {
-  for (int k = 0; k < 10; ++k) out[k] = -1.0;
+  for (int k = 0; k < 12; ++k) out[k] = -1.0;
   const int reps = std::getenv("RXMD_ISO_REPS") ? std::max(1, std::atoi(std::getenv("RXMD_ISO_REPS"))) : 10;
   auto timed = [&](auto launch) {
     for (int r = 0; r < reps + 1; ++r) {
@@ -407,24 +414,33 @@ void spmv_isolated_ms(Engine &e, double *out) {
     acc[1] += timed([&] { k_spmv<MODE_HSH, true, false, 1><<<nblk(e.N, 16), 1024, 0, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, 1, nullptr, e.N, 0, nullptr); });
   }
   out[1] = acc[1] / rounds;
-  // RXMD_ISO_COPIES=1: does the pass time depend on WHERE its streams lie?  Two fresh copies of the value and slot arrays, the pass on each
-  // (out[2], out[3]; addresses in out[4..9]).  It does: same virtual addresses, 0.77 / 0.80 / 0.86 ms in one process.
+  // RXMD_ISO_COPIES=1: does the pass time depend on WHERE its streams lie?  Four copies of the value and slot arrays held at the same time, the
+  // pass on each, twice round (out[2..9]): a property of the buffer repeats in the second round, a drift in time does not.  out[10]: the last
+  // copy with its rows in cell-sorted order, read without the row indirection.
   if (e.win_valid && std::getenv("RXMD_ISO_COPIES")) {
     const size_t ne = static_cast<size_t>(e.rows10) * e.S10;
     const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
-    out[4] = static_cast<double>(reinterpret_cast<size_t>(e.hess)); out[5] = static_cast<double>(reinterpret_cast<size_t>(e.sl10));
-    for (int c = 0; c < 2; ++c) {
-      double *h2 = nullptr; unsigned short *s2 = nullptr;
-      if (hipMalloc(reinterpret_cast<void **>(&h2), ne * sizeof(double)) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&s2), ne * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); if (h2) (void)hipFree(h2); break; }
-      hipMemcpyAsync(h2, e.hess, ne * sizeof(double), hipMemcpyDeviceToDevice, e.stream);
-      hipMemcpyAsync(s2, e.sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, e.stream);
-      double a = 0.0;
-      for (int rd = 0; rd < rounds; ++rd)
-        a += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2, h2, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-      out[2 + c] = a / rounds;
-      out[6 + 2 * c] = static_cast<double>(reinterpret_cast<size_t>(h2)); out[7 + 2 * c] = static_cast<double>(reinterpret_cast<size_t>(s2));
-      (void)hipFree(h2); (void)hipFree(s2);
+    double *h2[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned short *s2[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = true;
+    for (int c = 0; c < 4 && ok; ++c) {
+      if (c >= 2) {                                  // copies C and D: physically contiguous, if the driver grants it
+        ok = hipExtMallocWithFlags(reinterpret_cast<void **>(&h2[c]), ne * sizeof(double), hipDeviceMallocContiguous) == hipSuccess &&
+             hipExtMallocWithFlags(reinterpret_cast<void **>(&s2[c]), ne * sizeof(unsigned short), hipDeviceMallocContiguous) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); std::fprintf(stderr, "contiguous allocation refused\n"); if (h2[c]) { (void)hipFree(h2[c]); h2[c] = nullptr; } if (s2[c]) { (void)hipFree(s2[c]); s2[c] = nullptr; } }
+      }
+      if (c < 2 || !ok)
+      ok = hipMalloc(reinterpret_cast<void **>(&h2[c]), ne * sizeof(double)) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&s2[c]), ne * sizeof(unsigned short)) == hipSuccess;
+      if (ok) { hipMemcpyAsync(h2[c], e.hess, ne * sizeof(double), hipMemcpyDeviceToDevice, e.stream); hipMemcpyAsync(s2[c], e.sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, e.stream); }
     }
+    if (ok) {
+      for (int round2 = 0; round2 < 2; ++round2)
+        for (int c = 0; c < 4; ++c)
+          out[2 + 4 * round2 + c] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2[c], h2[c], e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+      k_rows_to_rank_order<<<e.N, 256, 0, e.stream>>>(e.N, e.S10, e.rows_sorted, e.hess, e.sl10, h2[3], s2[3]);
+      out[10] = timed([&] { k_spmv_win<MODE_HSH, true, false, 1><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2[3], h2[3], e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+      out[11] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+    } else (void)hipGetLastError();
+    for (int c = 0; c < 4; ++c) { if (h2[c]) (void)hipFree(h2[c]); if (s2[c]) (void)hipFree(s2[c]); }
   }
   if (e.win_valid) out[0] = acc[0] / rounds;      // out[2], out[3]: variants of the window pass (template parameter VAR) when some are being compared
 }

@@ -1,4 +1,5 @@
-"""does the pass time depend on where its streams lie?  several processes, in each: the pass on the engine's arrays and on two fresh copies"""
+"""does the pass time depend on where its streams lie?  several processes; in each: the pass on the engine's arrays, on four copies held at the
+same time (twice round: a property of the buffer repeats, a drift in time does not), on a copy with its rows in cell-sorted order"""
 import os, sys, subprocess
 here = os.path.dirname(os.path.abspath(__file__)); root = os.path.join(here, "..")
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -8,7 +9,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     e.QEq(); e.FORCE()
     os.environ["RXMD_ISO_REPS"] = "50"; os.environ["RXMD_ISO_COPIES"] = "1"
     for rep in range(2):
-        iso = e.debug(104, cap=12); print("process %s: window pass %.4f (hess %x sl10 %x) | fresh copy %.4f (%x %x) | another fresh copy %.4f (%x %x) | row pass %.4f ms" % (sys.argv[2], iso[0], int(iso[4]), int(iso[5]), iso[2], int(iso[6]), int(iso[7]), iso[3], int(iso[8]), int(iso[9]), iso[1]), flush=True)
+        iso = e.debug(104, cap=16)
+        print("process %s: engine's arrays %.4f | copies A B (plain) C D (contiguous) %.4f %.4f %.4f %.4f | again %.4f %.4f %.4f %.4f | D in cell-sorted row order %.4f | engine's arrays again %.4f | row pass %.4f ms"
+              % ((sys.argv[2], iso[0]) + tuple(iso[2:10]) + (iso[10], iso[11], iso[1])), flush=True)
     e.close(); sys.exit(0)
-for k in range(5):
-    subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(k)])
+for k in range(4):
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(k)], stderr=subprocess.STDOUT)
