@@ -462,6 +462,8 @@ def main():
                          "pass": pinfo["pass"], "bytes_per_entry_streamed": pinfo["bytes_per_entry_streamed"], "streamed_bytes_per_launch": pinfo["streamed_bytes_per_launch"],
                          "streamed_GBs": (pinfo["streamed_bytes_per_launch"] / (ms_spmv * 1e-3) / 1e9) if ms_spmv > 0 else 0.0,
                          "window_groups": pinfo["window_groups"], "largest_window_slots": pinfo["largest_window_slots"],
+                         "placement_search": {"pass_ms_first_placement": st.get("place_ms_first", 0.0), "pass_ms_kept_placement": st.get("place_ms_kept", 0.0),
+                                              "note": "where the pass's streams lie in physical memory is worth up to 15 % of its time; the engine times a few placements once and keeps the fastest (RXMD_PLACE_TRIES)"},
                          "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"], "launches_that_returned_at_once": st.get("spmv_noop_launches", 0),
                          "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,
                          "spmv_launches_per_step": passes,

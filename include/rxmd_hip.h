@@ -170,6 +170,9 @@ typedef struct rxmd_stats {
    * the number of groups, the largest window in units of 8 cell-sorted positions, 1 when the matrix pass uses it (0: the row pass) */
   double ms_k_winbuild;
   int win_groups, win_max_units, win_in_use, reserved2;
+  /* the window pass timed on the first placement of its streams in memory and on the one that was kept (0: no search ran; see
+   * Engine::tune_window_placement, RXMD_PLACE_TRIES) */
+  double place_ms_first, place_ms_kept;
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);

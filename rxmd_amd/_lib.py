@@ -29,7 +29,8 @@ class RxmdStats(C.Structure):
                 ("ms_allreduce", C.c_double), ("ms_fold", C.c_double), ("halo_calls", C.c_longlong), ("allreduce_calls", C.c_longlong),
                 ("ms_k_list10", C.c_double), ("ms_k_nonbond", C.c_double), ("ms_k_e3b", C.c_double), ("ms_k_e4b", C.c_double), ("ms_k_ehb", C.c_double),
                 ("ms_k_bondorder", C.c_double), ("ms_k_assemble", C.c_double), ("ms_k_winbuild", C.c_double),
-                ("win_groups", C.c_int), ("win_max_units", C.c_int), ("win_in_use", C.c_int), ("reserved2", C.c_int)]
+                ("win_groups", C.c_int), ("win_max_units", C.c_int), ("win_in_use", C.c_int), ("reserved2", C.c_int),
+                ("place_ms_first", C.c_double), ("place_ms_kept", C.c_double)]
 
     def asdict(self):
         d = {}

@@ -256,6 +256,8 @@ struct Engine {
   // win_cnt: units); per list entry a 16-bit slot in that window (sl10, bit 15 = ghost column).  The matrix pass stages the window's vector
   // entries in LDS with coalesced loads and reads them from there instead of gathering 16 bytes per entry.
   void build_windows();
+  void tune_window_placement();   // qeq.hip: a few placements of the pass's streams in physical memory, the fastest kept (once per engine)
+  bool place_tuned = false;
   int *rows_sorted = nullptr, *win_k = nullptr, *win_cnt = nullptr;
   int *win_gint = nullptr, *win_gbnd = nullptr; int win_nbnd = 0;     // multi-rank: groups without / with a row that has a ghost partner
   unsigned short *sl10 = nullptr;

@@ -738,6 +738,47 @@ void Engine::allreduce_scal4(int n) {
   RX_HIP(hipMemcpyAsync(scal + S_RAW0, h_scal + 48, sizeof(double) * n, hipMemcpyHostToDevice, stream));
 }
 
+// Where the streams of the window pass lie in physical memory is worth up to 15 % of its time (the same pass on copies of the same
+// arrays runs 0.77 ... 0.90 ms, a property of the buffer, repeatable to 0.1-0.5 %, drawn anew by every hipMalloc).  So, once per engine, after the
+// first QEq call that used the window pass: a few more placements of the value / slot (/ shell-core) arrays are tried, each timed with 30 launches
+// of the real pass, and the fastest is kept.  RXMD_PLACE_TRIES=<n> (default 6 placements including the first; 1 switches the search off).
+// One-time cost ~35 ms per placement, +6.3 GB of memory while a candidate is alive (979,776 atoms).  Measured, fresh processes alternating on one
+// box, default bench: 52.4-54.1 ms/step with the search against 53.4-55.6 without (the pass in the loop follows the kept placement + 0.03-0.04 ms).
+void Engine::tune_window_placement() {
+  place_tuned = true;
+  const char *ev_t = std::getenv("RXMD_PLACE_TRIES");
+  const int tries = ev_t ? std::atoi(ev_t) : 6;
+  if (tries <= 1 || !win_valid || N < 65536) return;              // (small systems: nothing to gain)
+  const size_t ne = static_cast<size_t>(rows10) * S10;
+  const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
+  auto time_pass = [&](const double *h, const unsigned short *sl, const double *hc) {
+    float ms = 0;
+    for (int r = 0; r < 35; ++r) {
+      if (r == 5) hipEventRecord(ev[2], stream);
+      if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
+      else k_spmv_win<MODE_HSH, true, false><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
+    }
+    hipEventRecord(ev[3], stream); hipEventSynchronize(ev[3]);
+    hipEventElapsedTime(&ms, ev[2], ev[3]);
+    return static_cast<double>(ms) / 30.0;
+  };
+  double best = time_pass(hess, sl10, hsc);
+  st.place_ms_first = best;
+  for (int c = 1; c < tries; ++c) {
+    double *h2 = nullptr, *c2 = nullptr; unsigned short *s2 = nullptr;
+    bool ok = hipMalloc(reinterpret_cast<void **>(&h2), ne * sizeof(double)) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&s2), ne * sizeof(unsigned short)) == hipSuccess;
+    if (ok && ff.pqeq) ok = hipMalloc(reinterpret_cast<void **>(&c2), ne * sizeof(double)) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); if (h2) (void)hipFree(h2); if (s2) (void)hipFree(s2); if (c2) (void)hipFree(c2); break; }
+    RX_HIP(hipMemcpyAsync(h2, hess, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    RX_HIP(hipMemcpyAsync(s2, sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, stream));
+    if (ff.pqeq) RX_HIP(hipMemcpyAsync(c2, hsc, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    const double t = time_pass(h2, s2, ff.pqeq ? c2 : hsc);
+    if (t < 0.99 * best) { best = t; std::swap(hess, h2); std::swap(sl10, s2); if (ff.pqeq) std::swap(hsc, c2); }
+    (void)hipFree(h2); (void)hipFree(s2); if (c2) (void)hipFree(c2);              // (the stream is idle: time_pass waited for its last launch)
+  }
+  st.place_ms_kept = best;
+}
+
 void Engine::qeq() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   if (cfg.isQEq != 1 && cfg.isQEq != 2) { nstep_qeq = 0; return; }   // qeq.F90:60-61
@@ -878,6 +919,7 @@ void Engine::qeq() {
     sync_stream();                                 // the kernels of an iteration that did not happen are still in the queue: cheap, but they read scal
     collect_timers();
     st.ms_qeq += toc(6, 7);
+    if (!place_tuned && win_used && it >= 1) tune_window_placement();
     return;
   }
   for (it = 0; it <= nmax - 1; ++it) {
@@ -968,6 +1010,7 @@ void Engine::qeq() {
   nstep_qeq = it; last_est = Est;
   st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1; qeq_iters_smooth = qeq_iters_smooth < 0.0 ? it : 0.75 * qeq_iters_smooth + 0.25 * it;
   st.ms_qeq += toc(6, 7);
+  if (!place_tuned && win_used && it >= 1) { sync_stream(); tune_window_placement(); }
 }
 
 }  // namespace rxmd

@@ -349,6 +349,9 @@ def test_full_size_properties_rdx_1m(qeq_mode):
         assert abs(pe[k] - ncell * pe1[k]) <= 1e-7 * abs(ncell * pe1[k]) + 1e-6
     st = e.stats()
     assert st["max_n10"] == 447 and st["max_nb"] == 12          # RDX crystal statistics
+    # the matrix passes were window passes, and the one-time search for a placement of their streams ran and kept the fastest it saw
+    assert st["win_in_use"] == 1 and st["win_groups"] == (st["natoms"] + 15) // 16
+    assert 0.0 < st["place_ms_kept"] <= st["place_ms_first"] < 5.0, (st["place_ms_first"], st["place_ms_kept"])
     e.close()
 
 
