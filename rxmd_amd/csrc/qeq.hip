@@ -766,6 +766,8 @@ void Engine::tune_window_placement() {
   st.place_ms_first = best;
   for (int c = 1; c < tries; ++c) {
     double *h2 = nullptr, *c2 = nullptr; unsigned short *s2 = nullptr;
+    // (plain hipMalloc: memory from hipExtMallocWithFlags(hipDeviceMallocContiguous) was the fast kind more often in the copies experiment, but
+    // an engine that allocated its streams that way failed 15 unrelated tests of the suite with corrupted results -- not used anywhere)
     bool ok = hipMalloc(reinterpret_cast<void **>(&h2), ne * sizeof(double)) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&s2), ne * sizeof(unsigned short)) == hipSuccess;
     if (ok && ff.pqeq) ok = hipMalloc(reinterpret_cast<void **>(&c2), ne * sizeof(double)) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); if (h2) (void)hipFree(h2); if (s2) (void)hipFree(s2); if (c2) (void)hipFree(c2); break; }

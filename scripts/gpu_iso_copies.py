@@ -13,5 +13,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         print("process %s: engine's arrays %.4f | copies A B (plain) C D (contiguous) %.4f %.4f %.4f %.4f | again %.4f %.4f %.4f %.4f | D in cell-sorted row order %.4f | engine's arrays again %.4f | row pass %.4f ms"
               % ((sys.argv[2], iso[0]) + tuple(iso[2:10]) + (iso[10], iso[11], iso[1])), flush=True)
     e.close(); sys.exit(0)
-for k in range(4):
+for k in range(int(os.environ.get("ISO_PROCS", "3"))):
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(k)], stderr=subprocess.STDOUT)
