@@ -186,7 +186,8 @@ int rxmd_hip_get_cutoffs(rxmd_handle h, double *rc, int capacity, double *maxrc)
 /* debugging taps on device state after rxmd_hip_force (residents+ghosts, engine order):
  * what: 0 delta  1 deltap  2 bonded neighbour count  3 real pos (x3)  4 gid  5 type  6 n10 count (residents)
  *       7 hessian row sums (residents)  8 cdbnd gathered per atom  9 charges incl. ghosts
- *       10 ccbnd as ForceBondedTerms consumes it (pot.F90:129-135)  100 read-bandwidth probe
+ *       10 ccbnd as ForceBondedTerms consumes it (pot.F90:129-135)  11 window form of the 10 A matrix: entries per resident whose 16-bit slot
+ *       leads back to the entry's own position and ghost flag (== what 6 returns; -1 without windows)  100 read-bandwidth probe
  *       102 stripped-down forms of the row pass, 104 the real window pass / row pass back to back: {ms, ms} (experiments, after rxmd_hip_qeq) */
 int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity);
 

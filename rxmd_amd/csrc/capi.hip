@@ -471,6 +471,32 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
       case 8: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.cd, G, 1, 0); break;
       case 9: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.q, G, 1, 0); break;
       case 10: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.cc_, G, 1, 0); break;
+      case 11: {   // window form of the 10 A matrix, checked on the host: per resident (atom order) the number of list entries whose 16-bit slot leads
+                   // back to the entry's own cell-sorted position and ghost flag through the group's window (== n10 when the window is right; -1: no windows)
+        n = N; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity");
+        if (!e.win_valid) { for (int i = 0; i < N; ++i) out[i] = -1.0; break; }
+        RX_HIP(hipStreamSynchronize(e.stream));
+        std::vector<int> c(N), rs(N), wc(e.win_groups), wk(static_cast<size_t>(e.win_groups) * rxmd::WIN_MAXUNITS);
+        RX_HIP(hipMemcpy(c.data(), e.n10, sizeof(int) * N, hipMemcpyDeviceToHost));
+        RX_HIP(hipMemcpy(rs.data(), e.rows_sorted, sizeof(int) * N, hipMemcpyDeviceToHost));
+        RX_HIP(hipMemcpy(wc.data(), e.win_cnt, sizeof(int) * e.win_groups, hipMemcpyDeviceToHost));
+        RX_HIP(hipMemcpy(wk.data(), e.win_k, sizeof(int) * wk.size(), hipMemcpyDeviceToHost));
+        std::vector<int> ent(e.S10); std::vector<unsigned short> sl(e.S10);
+        for (int r = 0; r < N; ++r) {
+          const int i = rs[r], g = r / rxmd::WIN_ROWS, cnt = c[i] & rxmd::N10_COUNT;
+          RX_HIP(hipMemcpy(ent.data(), e.nb10 + static_cast<size_t>(i) * e.S10, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+          RX_HIP(hipMemcpy(sl.data(), e.sl10 + static_cast<size_t>(i) * e.S10, sizeof(unsigned short) * cnt, hipMemcpyDeviceToHost));
+          int good = 0;
+          for (int k = 0; k < cnt; ++k) {
+            const unsigned en = static_cast<unsigned>(ent[k]);
+            const int slot = sl[k] & 0x7fff, unit = slot / rxmd::WIN_UNIT;
+            const bool gh = (sl[k] & 0x8000) != 0;
+            if (unit < wc[g] && wk[static_cast<size_t>(g) * rxmd::WIN_MAXUNITS + unit] + (slot % rxmd::WIN_UNIT) == static_cast<int>(en & rxmd::NB10_IDX_MASK) && gh == ((en & rxmd::NB10_GHOST) != 0)) ++good;
+          }
+          out[i] = good;
+        }
+        break;
+      }
       case 100: {   // read-bandwidth probe over the whole value array: out = {ms, bytes} for a few grid sizes
         n = 4; if (capacity < 8) throw EngineError(RXMD_E_ARG, "capacity");
         const int grids[4] = {2048, 8192, 32768, 131072};

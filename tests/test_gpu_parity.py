@@ -450,6 +450,20 @@ def test_window_pass_and_row_pass_are_the_same_operator(case, mc, qeq_mode, monk
     assert e_err(res["1"][2], res["0"][2]) <= 1e-8
 
 
+@pytest.mark.parametrize("case,mc", [("rdx168", (1, 1, 1)), ("rdx222", (2, 2, 2)), ("rdx168", (6, 6, 6)), ("ice644", (6, 4, 4)), ("sicnp547", (1, 1, 1)), ("pbt2272", (1, 1, 1)), ("mos2_tri324", (3, 3, 2))])
+def test_window_slots_lead_back_to_the_list_entries(case, mc):
+    """The window form of the 10 A matrix, structurally: every list entry's 16-bit slot, looked up in the window of its row's group (win_k / win_cnt,
+    rows_sorted), is the entry's own cell-sorted position with the same ghost flag -- for boxes of one cut-off (every partner a periodic image, groups
+    that straddle cell columns), a 36k-atom box, water, a nanoparticle in vacuum, an amorphous polymer and a hexagonal cell."""
+    e = _engine(case, mc)
+    e.QEq()
+    n10 = e.debug(6).astype(int); ok = e.debug(11).astype(int)
+    st = e.stats()
+    assert st["win_in_use"] == 1 and st["win_groups"] == (st["natoms"] + 15) // 16
+    assert n10.sum() == st["nnz10"] and (ok == n10).all(), (int((ok != n10).sum()), ok[:8], n10[:8])
+    e.close()
+
+
 @pytest.mark.parametrize("case,mc", [("rdx222", (2, 2, 2)), ("ice644", (6, 4, 4)), ("example1", (2, 3, 5))])
 def test_torsion_kernel_instances_give_the_same_forces(case, mc, monkeypatch):
     """k_e4b has four instances: eight centre atoms per wavefront with their bond slots laid end to end (default when no bond list of
