@@ -503,7 +503,7 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
         for (int g = 0; g < 4; ++g) { out[2 * g] = rxmd::stream_probe_ms(e, grids[g]); out[2 * g + 1] = static_cast<double>(e.rows10) * e.S10 * 8.0; }
         n = 8; break;
       }
-      case 104: n = 12; if (capacity < 12) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_isolated_ms(e, out); break;   // real window pass / row pass back to back (experiments)
+      case 104: n = 20; if (capacity < 20) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_isolated_ms(e, out); break;   // real window pass / row pass back to back (experiments)
       case 102: n = 7; if (capacity < 7) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_bisect_ms(e, out); break;   // stripped-down forms of the row kernel (experiments)
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");
     }

@@ -392,7 +392,7 @@ __global__ void k_rows_to_rank_order(int N, int S10, const int *__restrict__ row
 // the real window pass and the real row pass back to back, alternating in ONE process (timings repeat to 0.1 % inside a process and differ
 // by +-6 % between processes on the same box, so variants are compared here, compiled side by side) (debug tap 104; experiments only)
 void spmv_isolated_ms(Engine &e, double *out) {
-  for (int k = 0; k < 12; ++k) out[k] = -1.0;
+  for (int k = 0; k < 20; ++k) out[k] = -1.0;
   const int reps = std::getenv("RXMD_ISO_REPS") ? std::max(1, std::atoi(std::getenv("RXMD_ISO_REPS"))) : 10;
   auto timed = [&](auto launch) {
     for (int r = 0; r < reps + 1; ++r) {
@@ -441,6 +441,19 @@ void spmv_isolated_ms(Engine &e, double *out) {
       out[11] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
     } else (void)hipGetLastError();
     for (int c = 0; c < 4; ++c) { if (h2[c]) (void)hipFree(h2[c]); if (s2[c]) (void)hipFree(s2[c]); }
+    // ... and on ONE allocation with the value array at different offsets inside it (out[12..19]): a dependence on low address bits would show here
+    {
+      static const size_t offs[8] = {0, 4096, 65536, size_t(1) << 20, (size_t(2) << 20) + 4096, size_t(16) << 20, (size_t(37) << 20) + 8192, size_t(64) << 20};
+      char *big = nullptr;
+      if (hipMalloc(reinterpret_cast<void **>(&big), ne * sizeof(double) + (size_t(65) << 20)) == hipSuccess) {
+        for (int c = 0; c < 8; ++c) {
+          double *hh = reinterpret_cast<double *>(big + offs[c]);
+          hipMemcpyAsync(hh, e.hess, ne * sizeof(double), hipMemcpyDeviceToDevice, e.stream);
+          out[12 + c] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, hh, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+        }
+        (void)hipFree(big);
+      } else (void)hipGetLastError();
+    }
   }
   if (e.win_valid) out[0] = acc[0] / rounds;      // out[2], out[3]: variants of the window pass (template parameter VAR) when some are being compared
 }
