@@ -175,7 +175,8 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // the 4-byte entry and the 16-byte gather per entry through the vector memory path disappears.  Streams: value 8 + slot 2 bytes per entry, two
 // entries per lane and request (16-byte / 4-byte loads), 256 entries of a row in flight.  Same sums in the same per-row roles as k_spmv; the
 // order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
-// Timing probe with synthetic slots before it was built (debug tap 103): 0.76 ms against 0.93 ms of k_spmv on the same box.
+// (A timing probe with synthetic slots promised 0.76 against 0.93 ms of k_spmv before anything real was built; the real pass: 0.80 against 0.89 ms
+// back to back in one process, DESIGN.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
 template <int MODE, bool STORE, bool PQ, int VAR = 0>      // VAR: variants under measurement are compiled side by side and timed by debug tap 104 (none now); 0 = the pass
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
