@@ -617,6 +617,24 @@ def test_extended_lagrangian_charges_isQEq2(qeq_mode):
     e.close()
 
 
+@pytest.mark.parametrize("force_windows", [False, True])
+def test_window_build_follows_the_expected_iteration_count(force_windows, monkeypatch):
+    """The window form of the matrix costs about as much as four to seven passes save: with isQEq = 2 (one CG step per MD step) it is not built and
+    the row pass runs; RXMD_SPMV_WIN=2 builds it regardless -- same trajectory either way (the reference's dump of 10 steps)."""
+    if force_windows:
+        monkeypatch.setenv("RXMD_SPMV_WIN", "2")
+    g = np.load(os.path.join(oa.GOLD, "rdx168_lex_md10.npz"))
+    e = _engine("rdx168", (1, 1, 1), isQEq=2, qeq_mode=1)
+    e.QEq(); e.FORCE(); e.step(10)
+    a = e.atoms(); st = e.stats()
+    assert st["win_in_use"] == (1 if force_windows else 0) and (st["win_groups"] > 0) == force_windows, st
+    o = np.argsort(a["gid"]); go = np.argsort(g["gid"])
+    assert np.abs(a["pos"][o] - g["pos"][go]).max() <= 1e-9
+    assert q_err(a["q"][o], g["charge"][go]) <= QTOL
+    assert f_err(a["f"][o], g["force"][go]) <= FTOL
+    e.close()
+
+
 @pytest.mark.parametrize("mode,kw", [(4, dict(vsfact=0.9)), (5, dict(treq=300.0)), (7, dict(treq=300.0)), (8, dict(treq=300.0))])
 def test_velocity_scaling_modes_from_a_restart_file(mode, kw):
     """mdmode 4/5/7/8 on the device (rxmd_hip_thermostat) continued from the reference's own restart file (rxff.bin after 20 NVE
