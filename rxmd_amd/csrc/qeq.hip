@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
 // (A timing probe with synthetic slots promised 0.76 against 0.93 ms of k_spmv before anything real was built; the real pass: 0.80 against 0.89 ms
 // back to back in one process, DESIGN.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
-template <int MODE, bool STORE, bool PQ, int VAR = 0>      // VAR: variants under measurement are compiled side by side and timed by debug tap 104 (none now); 0 = the pass
+template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
@@ -190,10 +190,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   extern __shared__ double2 s_x[];                  // the window: slot -> (xs, xt)
   __shared__ double s_row[WIN_ROWS][4];
   __shared__ int s_arrived;
-#ifndef WIN_STEPS
-#define WIN_STEPS 2
-#endif
-  constexpr int STEPS = WIN_STEPS;                  // 2 x 128 entries of the row in flight
+  constexpr int STEPS = NSTEP;
   constexpr int NT = 64 * WIN_ROWS;
   typedef double d2v __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63;
@@ -415,6 +412,13 @@ void spmv_isolated_ms(Engine &e, double *out) {
     acc[1] += timed([&] { k_spmv<MODE_HSH, true, false, 1><<<nblk(e.N, 16), 1024, 0, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, 1, nullptr, e.N, 0, nullptr); });
   }
   out[1] = acc[1] / rounds;
+  if (e.win_valid) {                               // variant: 384 entries in flight
+    const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
+    double a3 = 0.0;
+    for (int rd = 0; rd < rounds; ++rd)
+      a3 += timed([&] { k_spmv_win<MODE_HSH, true, false, 3><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+    out[2] = a3 / rounds;
+  }
   // RXMD_ISO_COPIES=1: does the pass time depend on WHERE its streams lie?  Four copies of the value and slot arrays held at the same time, the
   // pass on each, twice round (out[2..9]): a property of the buffer repeats in the second round, a drift in time does not.  out[10]: the last
   // copy with its rows in cell-sorted order, read without the row indirection.
@@ -438,7 +442,7 @@ void spmv_isolated_ms(Engine &e, double *out) {
         for (int c = 0; c < 4; ++c)
           out[2 + 4 * round2 + c] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2[c], h2[c], e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
       k_rows_to_rank_order<<<e.N, 256, 0, e.stream>>>(e.N, e.S10, e.rows_sorted, e.hess, e.sl10, h2[3], s2[3]);
-      out[10] = timed([&] { k_spmv_win<MODE_HSH, true, false, 1><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2[3], h2[3], e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+      out[10] = timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 1><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2[3], h2[3], e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
       out[11] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
     } else (void)hipGetLastError();
     for (int c = 0; c < 4; ++c) { if (h2[c]) (void)hipFree(h2[c]); if (s2[c]) (void)hipFree(s2[c]); }
@@ -770,6 +774,7 @@ void Engine::tune_window_placement() {
     for (int r = 0; r < 35; ++r) {
       if (r == 5) hipEventRecord(ev[2], stream);
       if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
+      else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
       else k_spmv_win<MODE_HSH, true, false><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
     }
     hipEventRecord(ev[3], stream); hipEventSynchronize(ev[3]);
@@ -826,7 +831,9 @@ void Engine::qeq() {
       const int ng = !rowlist ? win_groups : (rowlist == rows_int ? win_groups - win_nbnd : win_nbnd);
       if (ng == 0) return 0;
       const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
-#define RX_WIN3(M, S, P) k_spmv_win<M, S, P><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag)
+      const bool one_trip = !ff.pqeq && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
+#define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag); \
+                              else k_spmv_win<M, S, P, 2><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag); } while (0)
 #define RX_WIN(M, S) do { if (ff.pqeq) RX_WIN3(M, S, true); else RX_WIN3(M, S, false); } while (0)
       if (mode == MODE_HSH) { if (store) RX_WIN(MODE_HSH, true); else RX_WIN(MODE_HSH, false); }
       else { if (store) RX_WIN(MODE_GRAD, true); else RX_WIN(MODE_GRAD, false); }
