@@ -188,8 +188,45 @@ def compact_leg(workload, ncells, steps, warmup, device, **kw):
         eng.close()
 
 
+def spawn_ranks(n):
+    """start `n` ranks of this script under torch.distributed.run as a child process; returns its exit code"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    last_json = None
+    for line in p.stdout:                      # relay; the ranks' JSON line is printed once more as the LAST line of this process
+        if line.startswith("{") and '"metric"' in line:
+            last_json = line.rstrip("\n")
+        else:
+            sys.stdout.write(line)
+    rc = p.wait()
+    sys.stdout.flush()
+    if last_json is not None:
+        print(last_json, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the %d ranks printed no result line\n" % n)
+        rc = 1
+    return rc
+
+
 def vprocs_for(n):
-    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[n]
+    """the rank grid of n ranks: 1, 2, 4, 8 -> the grids SURVEY 8d names (2 1 1 / 2 2 1 / 2 2 2); any other n -> its prime factors dealt to
+    the currently smallest axis, x first (6 -> 3 2 1)"""
+    vp = [1, 1, 1]
+    f, m = 2, n
+    fac = []
+    while m > 1:
+        while m % f == 0:
+            fac.append(f); m //= f
+        f += 1
+    for p in sorted(fac, reverse=True):
+        vp[vp.index(min(vp))] *= p
+    return tuple(sorted(vp, reverse=True))
 
 
 def main():
@@ -208,6 +245,17 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of BASELINE configs[2] (water) and configs[4] (SiC nanoparticle, PQEq) and the isQEq 2 leg")
     a = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher (the reference is started as `mpirun -np N rxmd`, examples/2-reaxff-dc/Makefile): this
+    # process touches neither torch nor HIP; it starts the N ranks as a CHILD (torch.distributed.run, one rank per GPU), relays what they
+    # print and leaves with their exit code.  Launched by a launcher (WORLD_SIZE set) --gpus must name the same N: never a silent 1-rank run.
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus and "RXMD_BENCH_FORCE_DIST" not in os.environ:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: the launcher and the flag must agree" % (a.gpus, os.environ.get("WORLD_SIZE", "1")))
+    probes = [k for k in os.environ if k.startswith("RXMD_") and k.endswith("_PROBE")]
+    if probes:
+        raise SystemExit("bench.py: refusing to run with work-skipping switches set: %s" % ", ".join(sorted(probes)))
+
     # the CPU baseline first: rank 0 of a 1-GPU run, before torch / HIP exist in this process
     cb = None
     if not a.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.workload == "rdx" and "RXMD_BENCH_FORCE_DIST" not in os.environ:
@@ -218,8 +266,6 @@ def main():
     from rxmd_amd import system
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
     use_dist = world > 1 or "RXMD_BENCH_FORCE_DIST" in os.environ     # the latter: drive the N > 1 code path with one rank (tests)
     backend = os.environ.get("RXMD_BENCH_BACKEND", "nccl")       # "gloo": host-staged messages (several ranks on one GPU, debugging)
     if "RXMD_BENCH_DEVICE" in os.environ:
@@ -454,7 +500,7 @@ def main():
             "config": {"workload": "%s = %d atoms/GPU, QEq tol %g, dt %g fs, mdmode 1 (NVE)" % (wname, natoms, cfg["QEq_tol"], cfg["dt"]),
                        "atoms_total": natoms * world, "parallelism": "1 GPU" if world == 1 else ("%d independent replicas" % world if a.replicas else
                                        "vprocs %dx%dx%d domain decomposition, six-stage halo, %s" % (vp[0], vp[1], vp[2], transport_mode)),
-                       "qeq_mode": a.qeq_mode},
+                       "qeq_mode": a.qeq_mode, "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("RXMD_")}},
             "steps_per_s_wall": steps_per_s, "ns_per_day": steps_per_s * cfg["dt"] * 86400e-6, "atom_steps_per_s": steps_per_s * natoms * world,
             "qeq_iters_per_step": iters, "ms_qeq_per_iter": st["ms_qeq"] / max(st["qeq_iters_total"], 1), "n10": n10, "nb": nb,
             "roofline": {"bound": "hbm", "kernel": ("k_spmv_win" if st.get("win_in_use") else "k_spmv") + " (QEq matrix pass, qeq.hip)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

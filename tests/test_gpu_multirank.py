@@ -171,3 +171,25 @@ def test_pqeq_through_the_multi_rank_path_self_loop(monkeypatch):
     assert f_err(a["f"][ie], o.forces()[io]) <= 1e-6
     assert np.abs(e.shells()[ie] - o.spos()[io]).max() <= 1e-7
     e.close()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver may call it; the reference is started as `mpirun -np N rxmd`,
+    examples/2-reaxff-dc/Makefile): the script starts its two ranks itself as a child process before anything touches HIP, relays their JSON
+    line and leaves with their exit code.  Both ranks share the one GPU of the test box (RXMD_BENCH_DEVICE), messages host-staged over gloo."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RXMD_BENCH_BACKEND="gloo", RXMD_BENCH_DEVICE="0", RXMD_SINGLE_STREAM="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "6", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.split("\n") if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["config"]["ranks_in_communicator"] == 2
+    assert r["config"]["atoms_total"] == 2 * 36288 and "vprocs 2x1x1" in r["config"]["parallelism"]
+    pr = r["per_rank"]
+    assert len(pr["natoms"]) == 2 and sum(pr["natoms"]) == 2 * 36288 and min(pr["nghost"]) > 0
+    assert r["config"]["env"]["RXMD_BENCH_BACKEND"] == "gloo"
+    assert r["value"] > 0 and abs(r["value"] * r["ms_per_step"] - 1e3) < 1e-6 * 1e3

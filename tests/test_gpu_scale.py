@@ -195,34 +195,44 @@ def test_forces_of_the_979776_atom_crystal_by_periodicity():
     assert f_err(inner(a["f"], (3,)), fref) <= FTOL
 
 
-@pytest.mark.parametrize("direct", [False, True])
-def test_perturbed_rdx_36k_on_two_ranks_against_the_two_rank_oracle(direct, monkeypatch):
-    """the 36,288-atom perturbed crystal as a 2 x 1 x 1 decomposition: two engine ranks (one GPU, messages host-staged over gloo) against the
-    oracle run with the same vprocs -- per-rank local order after three migrations, charges, forces, positions.  Both halves of the box
-    have interior rows (the two-launch matrix pass under the halo) and boundary rows; `direct`: the owner-to-ghost vector halo."""
+@pytest.mark.parametrize("vp,direct", [((2, 1, 1), False), ((2, 1, 1), True), ((2, 2, 2), False), ((2, 2, 2), True)])
+def test_perturbed_rdx_36k_on_several_ranks_against_the_multi_rank_oracle(vp, direct, monkeypatch):
+    """the 36,288-atom perturbed crystal as a 2 x 1 x 1 and as a 2 x 2 x 2 decomposition: engine ranks (one GPU, messages host-staged over
+    gloo) against the oracle run with the same vprocs -- per-rank local order after three migrations, charges, forces, positions.  Every
+    domain has interior rows (the two-launch matrix pass under the halo) and boundary rows; on 2 x 2 x 2 (domains of 39 x 35 x 32 A) ghosts
+    reach a rank through the edge / corner forwarding of comm.F90:68-86 (x, then y carrying x's ghosts, then z carrying both) while interior
+    groups run under the halo.  `direct`: the owner-to-ghost vector halo (7 peers per rank on 2 x 2 x 2)."""
     import socket
     import torch.multiprocessing as mp
     import mr_worker
+    world = vp[0] * vp[1] * vp[2]
     if direct:
         monkeypatch.setenv("RXMD_HALO_DIRECT", "1")
-    vp = (2, 1, 1)
+    if world > 2:                                 # 8 processes on ONE GPU: a second hardware queue each would be time-sliced (DESIGN 6)
+        monkeypatch.setenv("RXMD_SINGLE_STREAM", "1")
     ff, lat2, ranks, vs = _perturbed_rdx(vp)
     nmax = max(len(r["type"]) for r in ranks)
-    o = oa.Oracle(ff, lat2, ranks, vprocs=vp, nbuffer=10 * nmax, v0=vs, **KW)
+    o = oa.Oracle(ff, lat2, ranks, vprocs=vp, nbuffer=(10 if world == 2 else 12) * nmax, v0=vs, **KW)
     o.qeq(); o.force(); o.step(NSTEPS)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as m:
         out = m.dict()
-        ps = [ctx.Process(target=mr_worker.engine_rank_perturbed, args=(r, 2, port, vp, NSTEPS, 1, out)) for r in range(2)]
-        [p.start() for p in ps]; [p.join(900) for p in ps]
-        assert len(out) == 2, "a rank died"
-        res = [out[r] for r in range(2)]
+        ps = [ctx.Process(target=mr_worker.engine_rank_perturbed, args=(r, world, port, vp, NSTEPS, 1, out)) for r in range(world)]
+        [p.start() for p in ps]; [p.join(1200) for p in ps]
+        for p in ps:
+            if p.is_alive():
+                p.kill()
+        assert len(out) == world, "a rank died or hung"
+        res = [out[r] for r in range(world)]
+    moved = 0
     for r, x in enumerate(res):
         assert "error" not in x, x.get("error")
         assert x["err"] == "None"
         assert 0 < x["n_boundary_rows"] < x["natoms"]
         assert np.array_equal(x["gid"], o.gids(r))
+        moved += int(not np.array_equal(np.sort(x["gid"]), np.sort(ranks[r]["gid"])))
         assert np.abs(x["pos"] - o.pos(r)).max() <= 1e-9
         assert q_err(x["q"], o.charges(r)) <= QTOL
         assert f_err(x["f"], o.forces(r)) <= FTOL
+    assert moved > 0, "the test needs atoms that changed their rank"

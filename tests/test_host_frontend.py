@@ -221,3 +221,18 @@ def test_fortran_binding_module_compiles_against_the_reference_modules(tmp_path)
         r = subprocess.run([flang, "-cpp", "-DNOMPI", "-I" + mods, "-c", os.path.join(ROOT, "bindings", src), "-o", str(tmp_path / (src + ".o")),
                             "-module-dir", str(tmp_path)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_bench_refuses_a_launcher_mismatch_and_probe_switches():
+    """bench.py --gpus N under a launcher of another size is an error, never a silent 1-rank run; work-skipping switches are refused"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "must agree" in p.stderr and "{" not in p.stdout
+    env = dict(os.environ, RXMD_E4B_PROBE="1"); env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "refusing" in p.stderr and "{" not in p.stdout
+    sys.path.insert(0, root)
+    import bench
+    assert [bench.vprocs_for(n) for n in (1, 2, 4, 8)] == [(1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2)]
