@@ -381,7 +381,7 @@ def main():
     probe = None
     if world == 1:                               # plain 16-B/lane read of the matrix value array on this very box: the ceiling the pass is quoted next to
         try:
-            pr = eng.debug(100, cap=16)
+            pr = eng.debug(12, cap=16)
             rates = [pr[2 * g + 1] / (pr[2 * g] * 1e-3) / 1e9 for g in range(4) if pr[2 * g] > 0]
             probe = max(rates) if rates else None
         except Exception:

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
   block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
 }
 
-struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // probe (timing experiments only, RXMD_E4B_PROBE): 1 = set-up only, 2 = phase B skipped, 5 = PE(8), PE(9) count batches and entries    // lattice vectors for the image test of the torsion's stress correction
+struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // lattice vectors for the image test of the torsion's stress correction; probe: RXMD_EXPERIMENTS builds only (RXMD_E4B_PROBE: 1 = set-up only, 2 = phase B skipped, 5 = PE(8), PE(9) count batches and entries)
 // Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to i,j,k,l.
 // Here ONE WAVEFRONT owns several consecutive centre atoms; every bond slot of an atom has a lane that owns its accumulators, and
 // one more lane stands for the atom itself.  Four layouts (template LSL, chosen per step from the longest bond list, see
@@ -414,8 +414,10 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   int qn = 0;
 
   auto evaluate = [&](int cnt) {                  // phase B: the first cnt (<= 64) queue entries, one per lane
+#ifdef RXMD_EXPERIMENTS
     if (bx.probe == 2) return;
     if (bx.probe == 5) { if (lane == 0) { atomicAdd(pe + 8, 1.0); atomicAdd(pe + 9, static_cast<double>(cnt)); } return; }
+#endif
     double o[7] = {0, 0, 0, 0, 0, 0, 0};
     V3 fself = {0.0, 0.0, 0.0};
     double cd_self = 0.0;
@@ -553,7 +555,9 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     wave_lds_sync();
   };
 
+#ifdef RXMD_EXPERIMENTS
   if (bx.probe == 1) return;                      // timing experiment: set-up only
+#endif
   // phase A: enumerate, filter, compact.  The centre bonds of the pass (every slot above the cut-off, in (atom, slot) order) are taken
   // CPB at a time: the lanes stage the qualifying slots of their k atoms (pot.F90:1072: bond order, atom l, its type -- three
   // dependent loads) side by side, KW lanes per centre bond, so that a wavefront of eight atoms with ~40 centre bonds waits for ~10
@@ -691,7 +695,11 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
   // (coalesced slot-major reads; in RDX one atom in fourteen is) and leaves a bit mask of those slots; then the wavefront sweeps the
   // 10 A rows of the atoms that have one, one after the other.  (One wavefront per atom spent most of the kernel starting a million
   // wavefronts that found nothing: 1.5 ms, of which the sweeps themselves were about a third.)
+#ifdef RXMD_EXPERIMENTS
   const int apw = (probe >> 8) ? (probe >> 8) : EHB_APW; // atoms per wavefront (probe bits 8..: experiment)
+#else
+  constexpr int apw = EHB_APW;
+#endif
   const int a0 = (xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w) * apw;
   double e10 = 0.0;
   unsigned hslots = 0u;
@@ -787,7 +795,10 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
             const V3 ff3 = {CEhb3 * rjk.x, CEhb3 * rjk.y, CEhb3 * rjk.z};   // f(j) -= ff ; f(k) += ff
             fi_s.x += fi.x; fi_s.y += fi.y; fi_s.z += fi.z;
             fj_s.x += -(fi.x + fk.x) - ff3.x; fj_s.y += -(fi.y + fk.y) - ff3.y; fj_s.z += -(fi.z + fk.z) - ff3.z;
-            if ((probe & 255) != 1) { atomicAdd(fx + k, fk.x + ff3.x); atomicAdd(fy + k, fk.y + ff3.y); atomicAdd(fz + k, fk.z + ff3.z); }
+#ifdef RXMD_EXPERIMENTS
+            if ((probe & 255) == 1) continue;                                // (timing probe: the kernel without its acceptor atomics)
+#endif
+            atomicAdd(fx + k, fk.x + ff3.x); atomicAdd(fy + k, fk.y + ff3.y); atomicAdd(fz + k, fk.z + ff3.z);
           }
           cfs = wave_sum_b(cfs); nterm = wave_sum_b(nterm);
           fi_s.x = wave_sum_b(fi_s.x); fi_s.y = wave_sum_b(fi_s.y); fi_s.z = wave_sum_b(fi_s.z);
@@ -814,7 +825,10 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
   kt_end(kt3);
   BoxImg bx;
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
-  bx.ortho = grid.ortho; bx.probe = std::getenv("RXMD_E4B_PROBE") ? std::atoi(std::getenv("RXMD_E4B_PROBE")) : 0;
+  bx.ortho = grid.ortho; bx.probe = 0;
+#ifdef RXMD_EXPERIMENTS
+  if (const char *pv = std::getenv("RXMD_E4B_PROBE")) bx.probe = std::atoi(pv);
+#endif
   // four atoms per wavefront when every bond list of this step fits 15 slots (h_err[2] = the largest list, read with the error word
   // after the list build); RXMD_E4B_SLOTS=32 forces the general kernel (tests)
   // instances (RXMD_E4B_SLOTS forces one, tests): packed eight atoms (default when no list of the step is longer than 15), two atoms
@@ -831,7 +845,10 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
   else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                  cds, frc[0], frc[1], frc[2], pe_d, bx);
-  const int ehb_probe = std::getenv("RXMD_EHB_PROBE") ? std::atoi(std::getenv("RXMD_EHB_PROBE")) : 0;
+  int ehb_probe = 0;
+#ifdef RXMD_EXPERIMENTS
+  if (const char *pv = std::getenv("RXMD_EHB_PROBE")) ehb_probe = std::atoi(pv);
+#endif
   const int ehb_apw = (ehb_probe >> 8) ? (ehb_probe >> 8) : 16;    // = EHB_APW of k_ehb
   kt_end(kt4);
   const bool kth = kt_begin(&st.ms_k_ehb);

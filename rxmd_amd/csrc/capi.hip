@@ -280,7 +280,12 @@ static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const do
   for (int a = 0; a < 3; ++a) e.last_pos[a].assign(pos + a * static_cast<size_t>(nbuffer), pos + a * static_cast<size_t>(nbuffer) + natoms);
   // every call after the first (the engine is sized, its tables exist): the caller's arrays go to the device as they are -- no
   // 10-double records, no second copy of the coordinates; the packed type is split there (k_split_atype)
-  if (e.tables_ready && natoms <= e.rows10 && natoms < e.NB && std::getenv("RXMD_LEVEL1_RECORDS") == nullptr) {
+#ifdef RXMD_EXPERIMENTS
+  const bool level1_records = std::getenv("RXMD_LEVEL1_RECORDS") != nullptr;     // (A/B: the old path through 10-double host records)
+#else
+  constexpr bool level1_records = false;
+#endif
+  if (e.tables_ready && natoms <= e.rows10 && natoms < e.NB && !level1_records) {
     e.set_atoms_arrays(natoms, atype, pos, pos + static_cast<size_t>(nbuffer), pos + 2 * static_cast<size_t>(nbuffer), q,
                        lex ? e.lex_p.data() : nullptr, lex ? e.lex_v.data() : nullptr);
     return;
@@ -497,14 +502,16 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
         }
         break;
       }
-      case 100: {   // read-bandwidth probe over the whole value array: out = {ms, bytes} for a few grid sizes
+      case 12: {   // read-bandwidth probe over the whole value array (a plain 16-byte-per-lane read; bench.py quotes the matrix pass next to it): out = {ms, bytes} for a few grid sizes
         n = 4; if (capacity < 8) throw EngineError(RXMD_E_ARG, "capacity");
         const int grids[4] = {2048, 8192, 32768, 131072};
         for (int g = 0; g < 4; ++g) { out[2 * g] = rxmd::stream_probe_ms(e, grids[g]); out[2 * g + 1] = static_cast<double>(e.rows10) * e.S10 * 8.0; }
         n = 8; break;
       }
+#ifdef RXMD_EXPERIMENTS
       case 104: n = 20; if (capacity < 20) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_isolated_ms(e, out); break;   // real window pass / row pass back to back (experiments)
       case 102: n = 7; if (capacity < 7) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_bisect_ms(e, out); break;   // stripped-down forms of the row kernel (experiments)
+#endif
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");
     }
   });

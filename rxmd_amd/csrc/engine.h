@@ -117,10 +117,12 @@ __device__ inline int xcd_swizzle(int bid, int nwg) {
 template <int CTRL, int ROW_MASK>
 __device__ inline double dpp_move(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  // v_mov_dpp with NO defined `old` value (mov_dpp, not update_dpp(0, ...)): a defined one costs a v_mov per DPP move to initialise the
-  // destination (48 of the ~300 vector instructions of a matrix-pass row).  Only the two row broadcasts leave lanes unwritten (rows 0 / 2, rows 0 / 1), and what those lanes
-  // hold afterwards is never read again: the total is taken from lane 63.
-  return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, false), __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, false));
+  // The four full-row permutes write every lane: v_mov_dpp with NO defined `old` value (mov_dpp, not update_dpp(0, ...)) -- a defined one costs
+  // a v_mov per DPP move to initialise the destination (48 of the ~300 vector instructions of a matrix-pass row).  The two masked row
+  // broadcasts leave rows unwritten (rows 0 / 2, rows 0 / 1): there `old` is a defined 0, so the lanes they skip add 0.0 and every lane of the
+  // wavefront holds a well-defined partial sum whatever the compiler does with the move (4 v_mov more per sum).
+  if (ROW_MASK == 0xf) return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, false), __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, false));
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false));
 }
 __device__ inline double wave_sum64(double v) {
   v += dpp_move<0xb1, 0xf>(v);     // quad_perm:[1,0,3,2]
@@ -230,6 +232,7 @@ struct Engine {
   // the packed type is split on the device.  Only once the engine is sized (after a first set_atoms_rxff); velocities are zeroed.
   void set_atoms_arrays(int natoms, const double *atype, const double *x, const double *y, const double *z, const double *q, const double *lexp, const double *lexv);
   int get_atoms_rxff(double *rec10, int capacity);
+  void poison_step_scratch();   // RXMD_POISON_ALLOC=1 (engine.hip): the per-step scratch holds 0xFF bytes again before every rebuild
   void build_ghosts_and_lists(bool qeq_prepass = false);   // COPYATOMS(MODE_COPY) + LINKEDLIST + NEIGHBORLIST + 10 A list/hessian, once per step
   void qeq_start_vectors();        // qs, qt, hs, ht of qeq.F90:36-63 and their cell-sorted copy (before the list sweep that uses them)
   int *rows_int = nullptr, *rows_bnd = nullptr; int n_bnd = 0; bool rows_split_pending = false;   // interior / boundary rows (multi-rank)

@@ -18,8 +18,21 @@ static const int NMINCELL = 4;             // reference src/module.F90:84
 static const int cptridx_[7] = {0, 0, 0, 2, 2, 4, 4};  // comm.F90:61
 static const int dinv_[7] = {0, 2, 1, 4, 3, 6, 5};     // comm.F90:60
 
+// RXMD_POISON_ALLOC=1 (diagnostic; changes nothing that is computed): every buffer starts as 0xFF bytes -- a NaN for doubles, -1 for
+// indices and counts -- instead of zeros, and the per-step scratch (ghost slots of the per-atom arrays, bonded tables, the 10 A list and its
+// window form) is filled with the pattern again before every rebuild (Engine::poison_step_scratch), so that a kernel which reads an element
+// nobody wrote this step shows as a NaN / an index trap instead of silently using a stale or zero value.  The reference's own allocator does not
+// clear (module.F90:732-744); what it clears explicitly -- ccbnd, cdbnd, f, PE per FORCE call (pot.F90:20-26), spos and qtfp/qtfv at
+// allocation (init.F90:117-131) -- the kernels here clear too.  Buffers whose ZERO is part of a protocol (arrival counters, error words,
+// device scalars) are allocated with dzalloc.
+static const bool g_poison = std::getenv("RXMD_POISON_ALLOC") != nullptr && std::atoi(std::getenv("RXMD_POISON_ALLOC")) != 0;
 template <class T>
 static void dmalloc(T *&p, size_t n) {
+  RX_HIP(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)));
+  RX_HIP(hipMemset(p, g_poison ? 0xFF : 0, std::max<size_t>(n, 1) * sizeof(T)));
+}
+template <class T>
+static void dzalloc(T *&p, size_t n) {
   RX_HIP(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)));
   RX_HIP(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
 }
@@ -327,7 +340,7 @@ void Engine::alloc_device() {
     for (int a = 0; a < 3; ++a) dmalloc(shl[a], nb);
     dmalloc(sorted_shl, nb); dmalloc(hsc, static_cast<size_t>(rows10) * S10); dmalloc(pqrow, static_cast<size_t>(rows10));
   }
-  dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb); dmalloc(hst2, nb); dmalloc(tickets, 16);
+  dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb); dmalloc(hst2, nb); dzalloc(tickets, 16);
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(gowner, nb); dmalloc(dh_ghost, nb); dmalloc(dh_keys, nb); dmalloc(dh_keys2, nb); dmalloc(dh_vals, nb); dmalloc(dh_off, 1100); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(invpos, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.nfine) + 2);
@@ -344,9 +357,9 @@ void Engine::alloc_device() {
   { const size_t ng = (static_cast<size_t>(rows10) + WIN_ROWS - 1) / WIN_ROWS + 1;
     dmalloc(rows_sorted, static_cast<size_t>(rows10) + WIN_ROWS); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
-  dmalloc(partials, partials_cap + 1024); dmalloc(scal, 80);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
+  dmalloc(partials, partials_cap + 1024); dzalloc(scal, 80);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 192 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip)
-  dmalloc(d_err, 8);
+  dzalloc(d_err, 8);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 16 * sizeof(int)));
   h_cnt = h_err + 8;
   // hipcub scratch sized for the largest scan / sort we issue
@@ -420,7 +433,9 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
     const double vloc = box.volume / nprocs;
     const double est10 = nsize / vloc * (4.0 / 3.0) * 3.14159265358979 * ff.rctap * ff.rctap2;
     int s10 = cfg.maxneighbs10 > 0 ? cfg.maxneighbs10 : static_cast<int>(est10 * 1.35 + 64);
+#ifdef RXMD_EXPERIMENTS
     if (const char *ev_s10 = std::getenv("RXMD_S10")) { const int v = std::atoi(ev_s10); if (v > 0 && cfg.maxneighbs10 <= 0) s10 = v; }   // experiment: row stride of the 10 A list
+#endif
     S10 = (s10 + 63) / 64 * 64;
     rows10 = std::min<long long>(NB, nsize + nsize / 8 + 1024);
     if (ff.nso > 15) throw EngineError(RXMD_E_ARG, "more than 15 atom types do not fit the packed 10 A list entry");
@@ -1265,9 +1280,36 @@ void Engine::sorted_copy(const double2 *v) {
   k_sorted_vec<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, v, xs);
 }
 
+// RXMD_POISON_ALLOC: what a step rebuilds from scratch holds the pattern again before the rebuild
+void Engine::poison_step_scratch() {
+  if (!g_poison) return;
+  auto fill = [&](void *p, size_t off_bytes, size_t bytes) { if (p && bytes) RX_HIP(hipMemsetAsync(static_cast<char *>(p) + off_bytes, 0xFF, bytes, stream)); };
+  const size_t nb = NB, ng = nb - N, ns = nb * MAXNB, nl = static_cast<size_t>(rows10) * S10;
+  for (int a = 0; a < 3; ++a) { fill(pos[a], sizeof(double) * N, sizeof(double) * ng); fill(spos[a], sizeof(double) * N, sizeof(double) * ng); fill(frc[a], sizeof(double) * N, sizeof(double) * ng); }
+  fill(q, sizeof(double) * N, sizeof(double) * ng); fill(type, sizeof(int) * N, sizeof(int) * ng); fill(gid, sizeof(long long) * N, sizeof(long long) * ng);
+  fill(gsrc, 0, sizeof(int) * nb); fill(groot, 0, sizeof(int) * nb); fill(rootperm, 0, sizeof(int) * nb); fill(invpos, 0, sizeof(int) * nb); fill(xs, 0, sizeof(double2) * nb);
+  fill(cellid, 0, sizeof(int) * nb); fill(cellid_sorted, 0, sizeof(int) * nb); fill(perm, 0, sizeof(int) * nb); fill(perm_in, 0, sizeof(int) * nb);
+  fill(cellstart, 0, sizeof(int) * (static_cast<size_t>(grid.nfine) + 2)); fill(sorted_xyzi, 0, sizeof(double4) * nb);
+  if (ff.pqeq) { fill(sorted_shl, 0, sizeof(double4) * nb); fill(hsc, 0, sizeof(double) * nl); fill(pqrow, 0, sizeof(double4) * rows10); for (int a = 0; a < 3; ++a) fill(shl[a], sizeof(double) * N, sizeof(double) * ng); }
+  fill(nbr, 0, sizeof(int) * ns); fill(nbrcnt, 0, sizeof(int) * nb); fill(nbrindx, 0, ns);
+  for (double *t : {bo0, bo1, bo2, bo3, dln2, dln3, dBOp, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen, ecoa}) fill(t, 0, sizeof(double) * ns);
+  for (double *t : {deltap, delta, nlp, dDlp, deltalp, cds, cd, cc_}) fill(t, 0, sizeof(double) * nb);
+  fill(nb10, 0, sizeof(int) * nl); fill(hess, 0, sizeof(double) * nl); fill(sl10, 0, sizeof(unsigned short) * nl); fill(n10, 0, sizeof(int) * rows10);
+  fill(rows_int, 0, sizeof(int) * rows10); fill(rows_bnd, 0, sizeof(int) * rows10);
+  { const size_t ngr = (static_cast<size_t>(rows10) + WIN_ROWS - 1) / WIN_ROWS + 1;
+    fill(rows_sorted, 0, sizeof(int) * (static_cast<size_t>(rows10) + WIN_ROWS)); fill(win_k, 0, sizeof(int) * ngr * WIN_MAXUNITS); fill(win_cnt, 0, sizeof(int) * ngr);
+    fill(win_gint, 0, sizeof(int) * ngr); fill(win_gbnd, 0, sizeof(int) * ngr); }
+  fill(sall, 0, sizeof(double2) * rows10); fill(sgh, 0, sizeof(double2) * rows10); fill(wall, 0, sizeof(double2) * rows10); fill(wgh, 0, sizeof(double2) * rows10);
+  fill(partials, 0, sizeof(double) * (partials_cap + 1024));
+  fill(flags, 0, sizeof(int) * (nb + 1)); fill(scanout, 0, sizeof(int) * (nb + 1)); fill(flags2, 0, sizeof(int) * (nb + 1)); fill(scanout2, 0, sizeof(int) * (nb + 1));
+  for (double2 *t : {qst, hst, gst, hst2}) fill(t, sizeof(double2) * N, sizeof(double2) * ng);
+  if (xbuf_owned) { fill(xbuf_send, 0, sizeof(double) * xbuf_doubles); fill(xbuf_recv, 0, sizeof(double) * xbuf_doubles); }
+}
+
 void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   tic(0);
+  poison_step_scratch();
   { const bool kt = kt_begin(&st.ms_ghost_build); ghost_build(); kt_end(kt); }
   bin_cells();
   build_bonded_list();

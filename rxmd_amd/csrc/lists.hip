@@ -229,7 +229,9 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   // Phase 2, dense: one queued candidate per lane -> table interpolation, list entry, hessian value.  Only a third of the
   // candidates pass the distance test, so doing this work on compacted batches keeps every lane busy.
   auto emit = [&](int nproc) {
+#ifdef RXMD_EXPERIMENTS
     if (g.probe == 2) { cnt += nproc; return; }
+#endif
     if (lane < nproc) {
       const int k = sq[lane], slot = cnt + lane;
       if (slot < S10) {
@@ -310,7 +312,9 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
     L = __shfl(lpre, 31, 64);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef RXMD_EXPERIMENTS
   if (g.probe == 1) { if (lane == 0) n10[i] = L; return; }
+#endif
   for (int c0 = 0; c0 < L; c0 += 256) {
     // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
     int kk[4];
@@ -443,7 +447,9 @@ __global__ void __launch_bounds__(512) k_win_build(int N, int S10, const int *__
   const int kmin = s_min & ~(WIN_UNIT - 1);
   const int nwords = (((s_max - kmin) / WIN_UNIT + 1) + 63) >> 6;
   if (nwords > WIN_BMW) { if (tid == 0) { win_cnt[g] = 0; atomicExch(&err[6], 1); } return; }
+#ifdef RXMD_EXPERIMENTS
   if (probe == 1) { if (tid == 0) win_cnt[g] = nwords; return; }
+#endif
 #pragma unroll
   for (int j = 0; j < RPW; ++j)
 #pragma unroll
@@ -455,7 +461,9 @@ __global__ void __launch_bounds__(512) k_win_build(int N, int S10, const int *__
       if (o >= 0 && o != oprev) atomicOr(&bm[o >> 6], 1ULL << (o & 63));
     }
   __syncthreads();
+#ifdef RXMD_EXPERIMENTS
   if (probe == 2) { if (tid == 0) win_cnt[g] = static_cast<int>(bm[0]); return; }
+#endif
   if (wave == 0) {                                    // exclusive prefix of the words' populations: lane l takes the words [l per, (l + 1) per)
     const int per = (nwords + 63) >> 6;
     int sum = 0;
@@ -468,14 +476,18 @@ __global__ void __launch_bounds__(512) k_win_build(int N, int S10, const int *__
   }
   __syncthreads();
   const int nunits = s_total;
+#ifdef RXMD_EXPERIMENTS
   if (probe == 3) { if (tid == 0) win_cnt[g] = nunits; return; }
+#endif
   if (nunits > WIN_MAXUNITS) { if (tid == 0) { win_cnt[g] = 0; atomicExch(&err[6], 1); atomicMax(&err[5], nunits); } return; }
   for (int w = tid; w < nwords; w += 64 * NWAVES) {   // unit list: most words of the range are empty (25 runs of ~8 units in ~170 words)
     unsigned long long m = bm[w];
     int r = pre[w];
     while (m) { const int b = __ffsll(static_cast<long long>(m)) - 1; m &= m - 1ULL; win_k[static_cast<size_t>(g) * WIN_MAXUNITS + r++] = kmin + WIN_UNIT * (64 * w + b); }
   }
+#ifdef RXMD_EXPERIMENTS
   if (probe == 4) { if (tid == 0) win_cnt[g] = nunits; return; }
+#endif
   if (tid == 0) { win_cnt[g] = nunits; if (__hip_atomic_load(&err[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) atomicMax(&err[5], nunits); }
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
@@ -521,7 +533,10 @@ void Engine::build_windows() {
   RX_HIP(hipMemsetAsync(d_err + 5, 0, 2 * sizeof(int), stream));
   win_groups = (N + WIN_ROWS - 1) / WIN_ROWS;
   int *gflag = multi() ? flags2 : nullptr;           // (the resident flags are used up)
-  const int wprobe = std::getenv("RXMD_WINB_PROBE") ? std::atoi(std::getenv("RXMD_WINB_PROBE")) : 0;   // timing probes: stop after a phase (the pass must be off then)
+  int wprobe = 0;
+#ifdef RXMD_EXPERIMENTS
+  if (const char *pv = std::getenv("RXMD_WINB_PROBE")) wprobe = std::atoi(pv);   // timing probes: stop after a phase (the pass must be off then)
+#endif
   const bool ktw = kt_begin(&st.ms_k_winbuild);
   // entries per lane the kernel keeps in registers: by the longest row of the PREVIOUS build plus a margin (this build's is not known on the
   // host yet); a row that outgrows it sets the failure word and this step's passes are row passes
@@ -548,7 +563,9 @@ void Engine::build_bonded_list() {
 }
 
 void Engine::build_list10() {
+#ifdef RXMD_EXPERIMENTS
   if (const char *pv = std::getenv("RXMD_LIST_PROBE")) grid.probe = std::atoi(pv);
+#endif
   RX_HIP(hipMemsetAsync(d_err + 3, 0, sizeof(int), stream));
   RX_HIP(hipMemsetAsync(d_err + 4, 0x7f, sizeof(int), stream));      // 0x7f7f7f7f: larger than any row
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap

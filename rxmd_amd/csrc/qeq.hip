@@ -207,7 +207,11 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   const int t0 = threadIdx.x, t1 = threadIdx.x + NT;
   const int wk0 = wk[t0 / WIN_UNIT], wk1 = wk[t1 / WIN_UNIT];                      // (t1 / 8 < 256 <= WIN_MAXUNITS)
   const bool live = row < N;
+#ifdef RXMD_EXPERIMENTS
   const size_t base = static_cast<size_t>(live ? ((VAR & 1) ? ridx : row) : 0) * S10;       // (VAR & 1, experiment: the streams' rows in cell-sorted order)
+#else
+  const size_t base = static_cast<size_t>(live ? row : 0) * S10;
+#endif
   const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
   const d2v *cv2 = reinterpret_cast<const d2v *>((PQ ? hsc : hess) + base);
   const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
@@ -302,6 +306,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   }
 }
 
+#ifdef RXMD_EXPERIMENTS
 // ---- where does the row kernel's time go?  Stripped-down forms of k_spmv, timed in isolation (debug tap 102; experiments only) -------
 //   LEVEL 0: the two streams of a row only (4 x 64 entries per trip as k_spmv), one sum, one wavefront reduction, no store
 //   LEVEL 1: + the 16-byte gather per entry and the two FMAs
@@ -462,6 +467,8 @@ void spmv_isolated_ms(Engine &e, double *out) {
   }
   if (e.win_valid) out[0] = acc[0] / rounds;      // out[2], out[3]: variants of the window pass (template parameter VAR) when some are being compared
 }
+
+#endif   // RXMD_EXPERIMENTS
 
 __global__ void __launch_bounds__(256) k_stream_probe(size_t n16, const f64x2 *__restrict__ a, double *__restrict__ out) {
   double s = 0.0;
@@ -768,6 +775,14 @@ void Engine::tune_window_placement() {
   const int tries = ev_t ? std::atoi(ev_t) : 6;
   if (tries <= 1 || !win_valid || N < 65536) return;              // (small systems: nothing to gain)
   const size_t ne = static_cast<size_t>(rows10) * S10;
+  {   // a candidate needs a second copy of the streams while it is timed (6.3 GB at 979,776 atoms): not on a device that is nearly full
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 2 * ne * (ff.pqeq ? 18 : 10)) { (void)hipGetLastError(); return; }
+  }
+  struct Cand {                                                    // freed on every way out, an exception of a copy included
+    double *h = nullptr, *c = nullptr; unsigned short *s = nullptr;
+    ~Cand() { if (h) (void)hipFree(h); if (s) (void)hipFree(s); if (c) (void)hipFree(c); }
+  };
   const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
   auto time_pass = [&](const double *h, const unsigned short *sl, const double *hc) {
     float ms = 0;
@@ -784,18 +799,19 @@ void Engine::tune_window_placement() {
   double best = time_pass(hess, sl10, hsc);
   st.place_ms_first = best;
   for (int c = 1; c < tries; ++c) {
-    double *h2 = nullptr, *c2 = nullptr; unsigned short *s2 = nullptr;
+    Cand cd_;
+    double *&h2 = cd_.h, *&c2 = cd_.c; unsigned short *&s2 = cd_.s;
     // (plain hipMalloc: memory from hipExtMallocWithFlags(hipDeviceMallocContiguous) was the fast kind more often in the copies experiment, but
     // an engine that allocated its streams that way failed 15 unrelated tests of the suite with corrupted results -- not used anywhere)
     bool ok = hipMalloc(reinterpret_cast<void **>(&h2), ne * sizeof(double)) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&s2), ne * sizeof(unsigned short)) == hipSuccess;
     if (ok && ff.pqeq) ok = hipMalloc(reinterpret_cast<void **>(&c2), ne * sizeof(double)) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); if (h2) (void)hipFree(h2); if (s2) (void)hipFree(s2); if (c2) (void)hipFree(c2); break; }
+    if (!ok) { (void)hipGetLastError(); break; }
     RX_HIP(hipMemcpyAsync(h2, hess, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
     RX_HIP(hipMemcpyAsync(s2, sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, stream));
     if (ff.pqeq) RX_HIP(hipMemcpyAsync(c2, hsc, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
     const double t = time_pass(h2, s2, ff.pqeq ? c2 : hsc);
     if (t < 0.99 * best) { best = t; std::swap(hess, h2); std::swap(sl10, s2); if (ff.pqeq) std::swap(hsc, c2); }
-    (void)hipFree(h2); (void)hipFree(s2); if (c2) (void)hipFree(c2);              // (the stream is idle: time_pass waited for its last launch)
+    // (cd_ frees the loser; the stream is idle: time_pass waited for its last launch)
   }
   st.place_ms_kept = best;
 }
@@ -805,7 +821,11 @@ void Engine::qeq() {
   if (cfg.isQEq != 1 && cfg.isQEq != 2) { nstep_qeq = 0; return; }   // qeq.F90:60-61
   tic(6);
   // the list sweep of this step can form the row sums of the start vector on the way (saves the matrix pass of qeq.F90:87)
+#ifdef RXMD_EXPERIMENTS
   static const bool prepass_on = (std::getenv("RXMD_QEQ_NO_PREPASS") == nullptr);
+#else
+  constexpr bool prepass_on = true;
+#endif
   sums_from_list = false;
   if (!lists_valid) build_ghosts_and_lists(prepass_on);
   const int nmax = (cfg.isQEq == 1) ? cfg.NMAXQEq : 1;
@@ -818,7 +838,11 @@ void Engine::qeq() {
   // workgroup per CU that tail is short -- 45.8 / 39.3 / 33.8 / 32.6 us per launch at 2048 / 1024 / 512 / 256 workgroups, 68 at 4096
   const int vb_upd = std::min(nblk(N, 256), 256);
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
+#ifdef RXMD_EXPERIMENTS
   static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
+#else
+  constexpr int swz = 1;
+#endif
   const bool pipe = (std::getenv("RXMD_SPMV_NO_PIPE") == nullptr);        // read per call: the tests switch it
   const bool win_env = std::getenv("RXMD_SPMV_WIN") == nullptr || std::atoi(std::getenv("RXMD_SPMV_WIN")) != 0;   // read per call: the tests switch it
   // returns the number of partial-sum sets (of four) the launch leaves behind partials[pbase * 4]
@@ -886,8 +910,12 @@ void Engine::qeq() {
   float ms = 0;
   bool xs_current = false;       // the fused direction kernel leaves the sorted copy of the new (hs,ht) in xs
   const bool overlap_on = (std::getenv("RXMD_NO_HALO_OVERLAP") == nullptr);     // read per call: the tests switch it
+#ifdef RXMD_EXPERIMENTS
   const bool est_with_update = (std::getenv("RXMD_EST_SEPARATE") == nullptr);
   const bool cg_scatter = (std::getenv("RXMD_CG_NO_SCATTER") == nullptr);
+#else
+  constexpr bool est_with_update = true, cg_scatter = true;
+#endif
   const bool overlap = overlap_on && multi() && onepass && !rows_split_pending_invalid();
   bool halo_in_flight = false;
   // ---- run-ahead loop (single rank, qeq_mode 1, plain QEq; RXMD_CG_NO_RUNAHEAD=1 switches it off) ------------------------------------

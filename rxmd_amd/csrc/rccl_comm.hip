@@ -68,7 +68,18 @@ void Engine::sync_event(hipEvent_t ev_) {
   if (!nccl) {
     // the per-iteration wait of the CG loop: on some hosts a blocking wait wakes up 50-100 us after the event (the GPU then idles between
     // the iterations); spin_wait polls instead (RXMD_SPIN_WAIT=0: the blocking wait)
-    if (spin_wait) { hipError_t r; while ((r = hipEventQuery(ev_)) == hipErrorNotReady) {} if (r != hipSuccess) RX_HIP(r); return; }
+    // -- for a bounded time (2 ms: twice a matrix pass), then it blocks: ranks that share host cores with a callback transport's threads, or a
+    // hung GPU, do not burn a core for good.  With a callback transport of several ranks the spin is off by default (has_comm && nprocs > 1).
+    if (spin_wait && !(has_comm && nprocs > 1)) {
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      for (;;) {
+        const hipError_t r = hipEventQuery(ev_);
+        if (r == hipSuccess) return;
+        if (r != hipErrorNotReady) RX_HIP(r);
+        if ((++spins & 255u) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) break;
+      }
+    }
     RX_HIP(hipEventSynchronize(ev_)); return;
   }
   watched_wait(*this, [&] { return hipEventQuery(ev_); }, "event synchronisation");

@@ -236,3 +236,11 @@ def test_bench_refuses_a_launcher_mismatch_and_probe_switches():
     sys.path.insert(0, root)
     import bench
     assert [bench.vprocs_for(n) for n in (1, 2, 4, 8)] == [(1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2)]
+
+
+def test_default_library_carries_no_work_skipping_switch():
+    """timing probes that skip work, stripped-down kernels and variant taps are compiled only with -DRXMD_EXPERIMENTS (`make experiments` ->
+    librxmd_hip_exp.so): the product library has no environment switch that changes what is computed"""
+    blob = open(os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "librxmd_hip.so"), "rb").read()
+    for word in (b"_PROBE", b"RXMD_S10", b"RXMD_LEVEL1_RECORDS", b"RXMD_ISO_", b"RXMD_NO_XCD_SWIZZLE", b"RXMD_QEQ_NO_PREPASS", b"k_spmv_bisect"):
+        assert word not in blob, word
