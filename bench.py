@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 INP = os.path.join(ROOT, "tests", "golden", "inputs")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SIMDS, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs, peak engine clock: a wave64 vector instruction occupies its SIMD for 4 cycles
 ATOMS_PER_GPU_CELLS = 18
 
 
@@ -243,6 +244,7 @@ def main():
                          "sicnp: configs[4], SiC nanoparticle + O2 with PQEq, 547-atom cell replicated --cells (default 12) per edge")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent periodic replicas instead of one decomposed box")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of BASELINE configs[2] (water) and configs[4] (SiC nanoparticle, PQEq) and the isQEq 2 leg")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state leg (SURVEY 8d: 100 timed steps after 10 warm-up steps from the same cold start)")
     a = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher (the reference is started as `mpirun -np N rxmd`, examples/2-reaxff-dc/Makefile): this
@@ -405,7 +407,25 @@ def main():
                "spmv_launches_per_step": sa["spmv_launches"] / a.steps}
         eng.set_qeq_mode(a.qeq_mode)
 
-    other, alt_lex = None, None
+    steady = None
+    if not a.no_steady and world == 1:
+        # SURVEY 8(d) protocol: 100 timed steps after 10 warm-up steps from the same cold start (q0 = 0, v0 = 0).  The headline window (--steps after
+        # --warmup) sits in the first steps, where the charges start from zero and the CG needs ~36 iterations per step; here it has settled (K ~ 24).
+        eng.set_atoms_rxff(rec)
+        eng.QEq(); eng.FORCE()
+        eng.step(10)
+        eng.reset_timers()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        eng.step(100)
+        torch.cuda.synchronize(); dts = time.perf_counter() - t1
+        ss = eng.stats()
+        steady = {"protocol": "SURVEY 8(d): 100 timed steps after 10 warm-up steps from the cold start of the headline leg", "steps": 100, "warmup": 10,
+                  "ms_per_step": 1e3 * dts / 100, "steps_per_s": 100 / dts, "ns_per_day": 100 / dts * cfg["dt"] * 86400e-6,
+                  "qeq_iters_per_step": ss["qeq_iters_total"] / max(ss["qeq_calls"], 1), "spmv_launches_per_step": ss["spmv_launches"] / 100,
+                  "avg_pass_ms": ss["ms_qeq_spmv"] / max(ss["spmv_launches"], 1),
+                  "breakdown_ms_per_step": {k: ss[k] / 100 for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_winbuild")}}
+
+    other, alt_lex, noplace = None, None, None
     if world == 1 and not a.no_other_configs and a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS:
         eng.close(); eng = None                                   # the 979,776-atom engine gives its memory back first
         # isQEq = 2 (qeq.F90:51-57, main.F90:67-68,98): the reference's own production mode -- extended-Lagrangian charges, ONE CG step per MD
@@ -414,6 +434,15 @@ def main():
             alt_lex = compact_leg("rdx", ATOMS_PER_GPU_CELLS, a.steps, a.warmup, local, isQEq=2)
         except Exception as ex:
             alt_lex = {"error": str(ex)}
+        # the placement search of the window pass's streams (qeq.hip: tune_window_placement) switched off: what the headline gains from it
+        try:
+            os.environ["RXMD_PLACE_TRIES"] = "1"
+            noplace = compact_leg("rdx", ATOMS_PER_GPU_CELLS, a.steps, a.warmup, local)
+            noplace["note"] = "the headline configuration in a second engine of this process with RXMD_PLACE_TRIES=1 (first placement kept)"
+        except Exception as ex:
+            noplace = {"error": str(ex)}
+        finally:
+            os.environ.pop("RXMD_PLACE_TRIES", None)
         other = []
         for w in ("water", "sicnp"):                              # BASELINE configs[2] and configs[4] at their one-GPU sizes
             try:
@@ -432,33 +461,33 @@ def main():
         bytes_pass = pass_bytes(st, pqeq is not None)
         achieved = bytes_pass / (ms_spmv * 1e-3) / 1e9 if ms_spmv > 0 else 0.0
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                if tj.get("natoms") == st["natoms"]:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
-        # (filled below from profiles/kernel_traffic.json when that file is newer)
         # per-atom-step byte models with the measured n10, nb, K:
         #  (i) SURVEY 8d's formula as written: TWO matrix passes per CG iteration (the reference algebra, qeq_mode 0)
         # (ii) the bytes of the passes this run actually launched (qeq_mode 1: one pass per iteration + ~300 B of vector kernels)
         passes = st["spmv_launches"] / a.steps
         pinfo = pass_info(st, pqeq is not None)
-        b_fixed = n10 * 12 + 40 + n10 * 4 + 64 + nb * 104 * 5 + (n10 * 6 if st.get("win_in_use") else 0)      # window build: entries read, slots written
+        b_fixed = n10 * 14 + 40 + n10 * 4 + 64 + nb * 104 * 5      # the sweep writes the 16-bit window slot next to entry and value
         b_step_exec = b_fixed + passes * (n10 * pinfo["bytes_per_entry_streamed"] + 56) + iters * (300 if a.qeq_mode == 1 else 112)
         # the kernels behind the ~21 ms of a step that are not the matrix pass: HIP-event time per launch (rxmd_stats.ms_k_*), algorithmic bytes
         # per launch (SURVEY 8d / DESIGN.md 3), PMC bytes per launch where profiles/kernel_traffic.json holds them for this workload
-        ktraffic = {}
+        # PMC numbers are NOT measured in this run: they come from profiles/kernel_traffic.json (scripts/gpu_pmc_kernels.sh: one rocprofv3 --pmc pass per
+        # counter set over a bench step), which records the commit and the kernels' full template signatures it was taken at.  A kernel whose
+        # signature is not in the file gets null, never another instance's bytes.
+        ktraffic, kvalu, ksource = {}, {}, None
         kfile = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(kfile):
             try:
                 kj = json.load(open(kfile))
                 if kj.get("natoms") == st["natoms"]:
                     ktraffic = kj.get("hbm_bytes_per_launch", {})
+                    kvalu = {k: v.get("SQ_INSTS_VALU") for k, v in kj.get("kernels", {}).items() if v.get("SQ_INSTS_VALU") is not None}
+                    ksource = {"file": "profiles/kernel_traffic.json", "measured_at_commit": kj.get("commit"), "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), gfx950 correction FETCH_SIZE x 2; SQ_INSTS_VALU for the issue floor"}
             except Exception:
                 pass
+        def valu_floor_ms(*parts):
+            """issue floor of the vector unit: SQ_INSTS_VALU (wave instructions per launch) x 4 cycles / 1,024 SIMDs / clock"""
+            hit = [v for k, v in kvalu.items() if any(k == p_ or k.startswith(p_ + "<") for p_ in parts)]
+            return (sum(hit) * 4.0 / SIMDS / CLOCK_HZ * 1e3) if hit else None
         def traffic_for(*parts):
             """PMC bytes per launch of the kernels whose names start with one of `parts` (template instances included), summed; None if absent"""
             hit = [v for k, v in ktraffic.items() if any(k == p_ or k.startswith(p_ + "<") for p_ in parts)]
@@ -466,7 +495,7 @@ def main():
         G = st["natoms"] + st["nghost_force"]
         ncg = max(st["qeq_iters_total"], 1)
         ms_cg_vec = max(st["ms_qeq"] - st["ms_qeq_spmv"] - st["ms_lists"], 0.0) / ncg       # per CG iteration: update + direction + sorted copy (+ reduction)
-        kdefs = [("k_list10", "ms_k_list10", st["nnz10"] * 12.0 + st["natoms"] * 40.0, a.steps, "10 A sweep: entry + value written once (qeq.F90:183-268, main.F90:420-477)"),
+        kdefs = [("k_list10", "ms_k_list10", st["nnz10"] * 14.0 + st["natoms"] * 40.0, a.steps, "10 A sweep: entry + value + 16-bit window slot written once (qeq.F90:183-268, main.F90:420-477)"),
                  ("k_nonbond", "ms_k_nonbond", st["nnz10"] * 4.0 + st["natoms"] * 64.0, a.steps, "ENbond: the entry stream (pot.F90:676-781)"),
                  ("k_bo_prime+k_bo_full", "ms_k_bondorder", G * nb * 104.0, a.steps, "BOPRIM + BOFULL over residents and ghosts (bo.F90:28-298)"),
                  ("k_e3b", "ms_k_e3b", st["natoms"] * nb * 104.0, a.steps, "E3b (pot.F90:319-557): FP64 chains, not bytes, bound it"),
@@ -477,20 +506,20 @@ def main():
         for name, key, byts, cnt, note in kdefs:
             ms = st.get(key, 0.0) / max(cnt, 1)
             ach_k = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": traffic_for(*name.split("+")), "note": note})
+            tr_k = traffic_for(*name.split("+"))
+            kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": tr_k,
+                            "frac_real_traffic": (tr_k / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr_k and ms > 0) else None, "valu_floor_ms": valu_floor_ms(*name.split("+")), "note": note})
         kernels.append({"name": "CG vector kernels (k_cg_update, k_cg_direction, k_sorted_vec, k_reduce_fused)", "ms": ms_cg_vec, "algorithmic_bytes": st["natoms"] * 300.0,
                         "achieved_GBs": st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 if ms_cg_vec > 0 else 0.0,
                         "frac": (st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_cg_vec > 0 else 0.0, "traffic": traffic_for("k_cg_update", "k_cg_direction", "k_sorted_vec", "k_reduce_fused"),
                         "note": "per CG iteration, everything of qeq() that is neither the matrix pass nor the list build"})
-        t_pass = traffic_for("k_spmv_win" if st.get("win_in_use") else "k_spmv")
-        if t_pass is not None:
-            traffic = t_pass
-        elif st.get("win_in_use"):
-            traffic = None                           # (profiles/spmv_traffic.json is the row pass)
-        kernels.append({"name": "k_win_build", "ms": st.get("ms_k_winbuild", 0.0) / max(a.steps, 1), "algorithmic_bytes": st["nnz10"] * 6.0,
-                        "achieved_GBs": (st["nnz10"] * 6.0 / (st["ms_k_winbuild"] / a.steps * 1e-3) / 1e9) if st.get("ms_k_winbuild", 0.0) > 0 else 0.0,
-                        "frac": (st["nnz10"] * 6.0 / (st["ms_k_winbuild"] / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS) if st.get("ms_k_winbuild", 0.0) > 0 else 0.0,
-                        "traffic": traffic_for("k_win_build"), "note": "window form of the matrix, once per list build: entries read, 16-bit slots written"})
+        # the pass that ran, by its full template signature (MODE_HSH, STORE, PQ, NSTEP, VAR -- qeq.hip): only that instance's counters count
+        one_trip = (not pqeq) and 256 < st.get("max_n10", 0) <= 384
+        if st.get("win_in_use"):
+            sig = "k_spmv_win<0, true, %s, %d, %d>" % ("true" if pqeq else "false", 3 if one_trip else 2, 0 if one_trip else 2)
+        else:
+            sig = "k_spmv<0, true, %s, 1>" % ("true" if pqeq else "false")
+        traffic = ktraffic.get(sig)                  # None when the file was taken with another instance of the kernel
         out = {
             "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; one step advances every GPU's domain: weak scaling, wall-clock steps/s of the whole job)" if a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS
                       else "MD steps/sec (%s, %d atoms/GPU; wall-clock steps/s of the whole job)" % (a.workload, natoms),
@@ -504,7 +533,12 @@ def main():
             "steps_per_s_wall": steps_per_s, "ns_per_day": steps_per_s * cfg["dt"] * 86400e-6, "atom_steps_per_s": steps_per_s * natoms * world,
             "qeq_iters_per_step": iters, "ms_qeq_per_iter": st["ms_qeq"] / max(st["qeq_iters_total"], 1), "n10": n10, "nb": nb,
             "roofline": {"bound": "hbm", "kernel": ("k_spmv_win" if st.get("win_in_use") else "k_spmv") + " (QEq matrix pass, qeq.hip)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_pass,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_is": "algorithmic bytes of SURVEY 8(d) (12 B per entry; 20 with PQEq) / time / peak", "traffic": traffic,
+                         "traffic_source": dict(ksource, kernel_signature=sig) if (ksource and traffic is not None) else None,
+                         "frac_real_traffic": (traffic / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and ms_spmv > 0) else None,
+                         "frac_streamed": (pinfo["streamed_bytes_per_launch"] / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_spmv > 0 else None,
+                         "valu_floor_ms": (kvalu[sig] * 4.0 / SIMDS / CLOCK_HZ * 1e3) if sig in kvalu else None,
+                         "algorithmic_bytes_per_launch": bytes_pass,
                          "pass": pinfo["pass"], "bytes_per_entry_streamed": pinfo["bytes_per_entry_streamed"], "streamed_bytes_per_launch": pinfo["streamed_bytes_per_launch"],
                          "streamed_GBs": (pinfo["streamed_bytes_per_launch"] / (ms_spmv * 1e-3) / 1e9) if ms_spmv > 0 else 0.0,
                          "window_groups": pinfo["window_groups"], "largest_window_slots": pinfo["largest_window_slots"],
@@ -527,6 +561,10 @@ def main():
             out["alt"] = alt
         if alt_lex:
             out["alt_lex"] = alt_lex
+        if steady:
+            out["steady"] = steady
+        if noplace:
+            out["alt_no_placement_search"] = noplace
         if other:
             out["other_configs"] = other
         if cb:

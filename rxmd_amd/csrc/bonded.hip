@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tid = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;   // an XCD's workgroups own one contiguous eighth of the atoms: the neighbours they gather stay in its L2
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
   if (tid < N) {
     const int j = tid;
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
     if (threadIdx.x < 128) s_tor[threadIdx.x] = ff.tor_bits[threadIdx.x];      // built once on the host (upload_ff)
     __syncthreads();
   }
-  const int jbase = (blockIdx.x * 4 + w) * NG;
+  const int jbase = (xcd_swizzle(blockIdx.x, gridDim.x) * 4 + w) * NG;
   if (jbase >= N) return;                        // whole wavefront leaves together; no block-level barrier below
   double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
   int npass = 1, c_me = 0, cpre = 0;

@@ -476,6 +476,17 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
       case 8: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.cd, G, 1, 0); break;
       case 9: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.q, G, 1, 0); break;
       case 10: n = G; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity"); pull_d(e.cc_, G, 1, 0); break;
+      case 14: {   // RXMD_POISON_ALLOC: {1 if the pattern is on, the LAST entry of row 0 of the 10 A value array} -- an element no kernel writes (rows are shorter than their slot)
+        n = 2; if (capacity < 2) throw EngineError(RXMD_E_ARG, "capacity");
+        out[0] = e.poison_on() ? 1.0 : 0.0;
+        RX_HIP(hipMemcpy(out + 1, e.hess + (e.S10 - 1), sizeof(double), hipMemcpyDeviceToHost));
+        break;
+      }
+      case 13: {   // Est of the start vector and after every CG iteration of the last QEq call (what the reference prints with -DQEQDUMP, qeq.F90:117)
+        n = static_cast<int>(e.est_trace.size()); if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity");
+        for (int k = 0; k < n; ++k) out[k] = e.est_trace[k];
+        break;
+      }
       case 11: {   // window form of the 10 A matrix, checked on the host: per resident (atom order) the number of list entries whose 16-bit slot leads
                    // back to the entry's own cell-sorted position and ghost flag through the group's window (== n10 when the window is right; -1: no windows)
         n = N; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity");

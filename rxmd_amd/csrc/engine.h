@@ -176,6 +176,8 @@ struct Engine {
   // cell binning
   int *cellid = nullptr, *cellid_sorted = nullptr, *perm = nullptr, *perm_in = nullptr, *cellstart = nullptr;
   double4 *sorted_xyzi = nullptr;   // cell-sorted (x,y,z,index-as-bits) copy of real positions
+  unsigned char *sorted_type = nullptr;   // cell-sorted atom types (the window form of ENbond stages them next to the positions)
+  bool list_selfcheck = false;      // this list build: some box edge is shorter than two cut-offs, an atom can meet its own image
   void *cubtmp = nullptr; size_t cubtmp_bytes = 0;
   int *flags = nullptr, *scanout = nullptr;
   // bonded tables, slot-major
@@ -219,6 +221,7 @@ struct Engine {
   std::vector<double> lex_p, lex_v; bool lex_pending = false;   // qsfp/qsfv handed over by rxmd_hip_put_lex for the next array-shaped QEq/PQEq
   rxmd_stats st{};
   int nstep_qeq = 0; double last_est = 0;
+  std::vector<double> est_trace;   // Est of the start vector and of every CG iteration of the last QEq call (host side, a few hundred doubles)
   double atype_resid = 0.0;        // geninit packs atype = type + gid*1e-13 + 1e-14 (geninit.F90:459), ReadXYZ without it (fileio.F90:421): what came in goes out
   long long step_count = 0;
   unsigned long long velocity_draws = 0;    // INITVELOCITY calls so far: the draw index of the counter-based generator (assemble.hip)
@@ -232,6 +235,7 @@ struct Engine {
   // the packed type is split on the device.  Only once the engine is sized (after a first set_atoms_rxff); velocities are zeroed.
   void set_atoms_arrays(int natoms, const double *atype, const double *x, const double *y, const double *z, const double *q, const double *lexp, const double *lexv);
   int get_atoms_rxff(double *rec10, int capacity);
+  bool poison_on() const;
   void poison_step_scratch();   // RXMD_POISON_ALLOC=1 (engine.hip): the per-step scratch holds 0xFF bytes again before every rebuild
   void build_ghosts_and_lists(bool qeq_prepass = false);   // COPYATOMS(MODE_COPY) + LINKEDLIST + NEIGHBORLIST + 10 A list/hessian, once per step
   void qeq_start_vectors();        // qs, qt, hs, ht of qeq.F90:36-63 and their cell-sorted copy (before the list sweep that uses them)

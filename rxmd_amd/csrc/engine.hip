@@ -26,10 +26,20 @@ static const int dinv_[7] = {0, 2, 1, 4, 3, 6, 5};     // comm.F90:60
 // allocation (init.F90:117-131) -- the kernels here clear too.  Buffers whose ZERO is part of a protocol (arrival counters, error words,
 // device scalars) are allocated with dzalloc.
 static const bool g_poison = std::getenv("RXMD_POISON_ALLOC") != nullptr && std::atoi(std::getenv("RXMD_POISON_ALLOC")) != 0;
+#ifdef RXMD_EXPERIMENTS
+// RXMD_CONTIG_ALLOC=<bytes>: buffers of at most that many bytes (0: every buffer) come from hipExtMallocWithFlags(hipDeviceMallocContiguous) -- the
+// configuration that failed 15 unrelated tests in round 3; with RXMD_POISON_ALLOC=1 a read of stale memory shows as a NaN
+static const long long g_contig = std::getenv("RXMD_CONTIG_ALLOC") ? std::atoll(std::getenv("RXMD_CONTIG_ALLOC")) : -1;
+#endif
 template <class T>
 static void dmalloc(T *&p, size_t n) {
-  RX_HIP(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)));
-  RX_HIP(hipMemset(p, g_poison ? 0xFF : 0, std::max<size_t>(n, 1) * sizeof(T)));
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+#ifdef RXMD_EXPERIMENTS
+  if (g_contig == 0 || (g_contig > 0 && bytes <= static_cast<size_t>(g_contig))) RX_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p), bytes, hipDeviceMallocContiguous));
+  else
+#endif
+  RX_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+  RX_HIP(hipMemset(p, g_poison ? 0xFF : 0, bytes));
 }
 template <class T>
 static void dzalloc(T *&p, size_t n) {
@@ -344,7 +354,7 @@ void Engine::alloc_device() {
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(gowner, nb); dmalloc(dh_ghost, nb); dmalloc(dh_keys, nb); dmalloc(dh_keys2, nb); dmalloc(dh_vals, nb); dmalloc(dh_off, 1100); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(invpos, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.nfine) + 2);
-  dmalloc(sorted_xyzi, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
+  dmalloc(sorted_xyzi, nb); dmalloc(sorted_type, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
   dmalloc(nbr, ns); dmalloc(nbrcnt, nb); dmalloc(nbrindx, ns);
   dmalloc(bo0, ns); dmalloc(bo1, ns); dmalloc(bo2, ns); dmalloc(bo3, ns); dmalloc(dln2, ns); dmalloc(dln3, ns); dmalloc(dBOp, ns);
   dmalloc(A0, ns); dmalloc(A1, ns); dmalloc(A2, ns); dmalloc(A3, ns);
@@ -378,7 +388,7 @@ void Engine::free_device() {
   dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst); dfree(hst2); dfree(tickets); dfree(sall); dfree(sgh); dfree(wall); dfree(wgh);
   dfree(gowner); dfree(dh_ghost); dfree(dh_keys); dfree(dh_keys2); dfree(dh_vals); dfree(dh_off); dfree(dh_serve);
   dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(invpos); dfree(xs); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
-  dfree(sorted_xyzi); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
+  dfree(sorted_xyzi); dfree(sorted_type); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
   dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
   dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
   dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
@@ -1280,6 +1290,7 @@ void Engine::sorted_copy(const double2 *v) {
   k_sorted_vec<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, v, xs);
 }
 
+bool Engine::poison_on() const { return g_poison; }
 // RXMD_POISON_ALLOC: what a step rebuilds from scratch holds the pattern again before the rebuild
 void Engine::poison_step_scratch() {
   if (!g_poison) return;
@@ -1289,7 +1300,7 @@ void Engine::poison_step_scratch() {
   fill(q, sizeof(double) * N, sizeof(double) * ng); fill(type, sizeof(int) * N, sizeof(int) * ng); fill(gid, sizeof(long long) * N, sizeof(long long) * ng);
   fill(gsrc, 0, sizeof(int) * nb); fill(groot, 0, sizeof(int) * nb); fill(rootperm, 0, sizeof(int) * nb); fill(invpos, 0, sizeof(int) * nb); fill(xs, 0, sizeof(double2) * nb);
   fill(cellid, 0, sizeof(int) * nb); fill(cellid_sorted, 0, sizeof(int) * nb); fill(perm, 0, sizeof(int) * nb); fill(perm_in, 0, sizeof(int) * nb);
-  fill(cellstart, 0, sizeof(int) * (static_cast<size_t>(grid.nfine) + 2)); fill(sorted_xyzi, 0, sizeof(double4) * nb);
+  fill(cellstart, 0, sizeof(int) * (static_cast<size_t>(grid.nfine) + 2)); fill(sorted_xyzi, 0, sizeof(double4) * nb); fill(sorted_type, 0, nb);
   if (ff.pqeq) { fill(sorted_shl, 0, sizeof(double4) * nb); fill(hsc, 0, sizeof(double) * nl); fill(pqrow, 0, sizeof(double4) * rows10); for (int a = 0; a < 3; ++a) fill(shl[a], sizeof(double) * N, sizeof(double) * ng); }
   fill(nbr, 0, sizeof(int) * ns); fill(nbrcnt, 0, sizeof(int) * nb); fill(nbrindx, 0, ns);
   for (double *t : {bo0, bo1, bo2, bo3, dln2, dln3, dBOp, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen, ecoa}) fill(t, 0, sizeof(double) * ns);
@@ -1333,7 +1344,7 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     check_device_error("list build");
   }
   max_row10 = h_err[3]; min_row10 = std::min(h_err[4], h_err[3]);   // longest / shortest 10 A row of this build (k_list10)
-  win_maxunits = h_err[5]; win_valid = win_groups > 0 && h_err[6] == 0 && win_maxunits > 0 && (!multi() || (win_nbnd >= 0 && win_nbnd <= win_groups));   // window form of the matrix (build_windows)
+  win_maxunits = h_err[5]; win_valid = win_groups > 0 && h_err[6] == 0 && win_maxunits > 0 && (!multi() || (win_nbnd >= 0 && win_nbnd <= win_groups)) && std::getenv("RXMD_SPMV_NO_WIN") == nullptr;   // window form of the matrix (build_windows)
   collect_timers();
   st.ms_lists += toc(0, 1);
   lists_valid = true;

@@ -16,12 +16,13 @@ namespace rxmd {
 static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
 // w component of sorted_xyzi: low 32 bits atom index, bits 32.. type
-__global__ void k_pack_type(int G, const int *perm, const int *type, double4 *s) {
+__global__ void k_pack_type(int G, const int *perm, const int *type, double4 *s, unsigned char *st) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= G) return;
   const int i = perm[k];
   const long long w = (static_cast<long long>(type[i]) << 32) | static_cast<unsigned int>(i);
   s[k].w = __longlong_as_double(w);
+  st[k] = static_cast<unsigned char>(type[i]);
 }
 
 // ---- geometry of a sweep over the engine's grid ---------------------------------------------------------------------------
@@ -186,8 +187,18 @@ __device__ inline double wave_sum_l(double v) { return wave_sum64(v); }   // DPP
 // instead of 64 scattered ones.  Bits: see NB10_* in engine.h.
 // PQ: PQEq variant of qeq_initialize (pqeq.F90:262-353): core-core hessian from the pcc table, the shell-core matrix hsc of
 // get_hsh's Csicj term, and per row (fpqeq Eq. 30, sum_j H Z_j, sum_j hsc Z_j, shell-shell energy) -> pqrow
+// Round 4: the sweep also writes the WINDOW FORM of the matrix (engine.h WIN_*; until then a second kernel, k_win_build, re-read the entries it had
+// just written: 0.8 ms and 2.5 GB per build).  One workgroup = one window group = WIN_ROWS rows that are neighbours in CELL-SORTED order
+// (rows_sorted), one wavefront per row.  The window of a group is the union of its rows' CANDIDATE runs, known after the per-row set-up and before any
+// distance test: per absolute stencil column (x2, y2) the interval [smallest first position, largest end) over the rows, rounded to units of
+// WIN_UNIT positions -- the rows of a group share their 25 columns or straddle two neighbouring cells, so this is ~150 units of 8 (the exact
+// marking of k_win_build came to ~190: it counted a whole unit for every position some row accepted).  The columns are collected in a small LDS
+// hash table (256 entries; more distinct columns than that -- a group strung over many near-empty cells -- fails the window form for this build and
+// the row pass runs, as a window of more than WIN_MAXUNITS units always did), ordered by column id so that the numbering does not depend on which
+// wavefront came first, and an entry's 16-bit slot is  8 x (first unit of its column) + (position - first position of the column)  | ghost bit.
+constexpr int WIN_COLS = 256;           // entries of the column hash table of a group
 template <bool SELFCHECK, bool PQ, bool ORTHO>
-__global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+__global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted,
                                                  const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                  const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz,
@@ -195,21 +206,29 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
                                                  int *__restrict__ nb10, double *__restrict__ hess, int *__restrict__ n10, int *err,
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
-                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag) {
-  __shared__ int s_q[4][128];            // accepted candidates: sorted position ...
-  __shared__ double s_r2[4][128];        // ... their squared distance (the exact FP64 value of the test) ...
-  __shared__ long long s_w[4][128];      // ... and (type << 32 | atom index): the dense phase needs no second gather of the candidate
-  __shared__ int s_P[4][32], s_K[4][32];  // per stencil column: candidates before it / first sorted position of its run
+                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag,
+                                                 const int *__restrict__ rows_sorted, unsigned short *__restrict__ sl10, int *__restrict__ win_k, int *__restrict__ win_cnt, int *__restrict__ gflag) {
+  __shared__ int s_q[WIN_ROWS][128];            // accepted candidates: sorted position ...
+  __shared__ double s_r2[WIN_ROWS][128];        // ... their squared distance (the exact FP64 value of the test) ...
+  __shared__ long long s_w[WIN_ROWS][128];      // ... and (column of the row << 40 | type << 32 | atom index): the dense phase needs no second gather of the candidate
+  __shared__ int s_P[WIN_ROWS][32], s_K[WIN_ROWS][32], s_E[WIN_ROWS][32];  // per stencil column of a row: candidates before it / first sorted position of its run / its entry in the group's column table
   __shared__ int s_ix2[256];             // inxn2 row of the row's type would do; the whole (n1 x n1) table is 64-256 words
+  // the group's column table: absolute column id -> [first position, end) over the rows; then (in column order) its first window unit
+  __shared__ int t_key[WIN_COLS], t_lo[WIN_COLS], t_hi[WIN_COLS], t_ub[WIN_COLS], t_nu[WIN_COLS], t_ord[WIN_COLS];
+  __shared__ int s_fail, s_total, s_bnd;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
   for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) s_ix2[t] = ff.inxn2[t];
+  for (int t = threadIdx.x; t < WIN_COLS; t += blockDim.x) { t_key[t] = -1; t_lo[t] = 0x7fffffff; t_hi[t] = -1; }
+  if (threadIdx.x == 0) { s_fail = 0; s_total = 0; s_bnd = 0; }
   __syncthreads();
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
-  if (i >= N) return;
+  const int grp = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ridx = grp * WIN_ROWS + w;
+  const bool live = ridx < N;                 // (the last group may be short: its idle wavefronts still meet the barriers)
+  const int i = live ? rows_sorted[ridx] : 0;
   int *sq = s_q[w];
   double *sr2 = s_r2[w];
   long long *sw = s_w[w];
-  int *cP = s_P[w], *cK = s_K[w];
+  int *cP = s_P[w], *cK = s_K[w], *cE = s_E[w];
   const int c = cellid[i];
   const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
@@ -236,7 +255,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
       const int k = sq[lane], slot = cnt + lane;
       if (slot < S10) {
         const long long wv = sw[lane];
-        const int j = static_cast<int>(wv & 0xffffffffLL), tj = static_cast<int>(wv >> 32);
+        const int j = static_cast<int>(wv & 0xffffffffLL), tj = static_cast<int>((wv >> 32) & 255);
         const double r2 = sr2[lane];
         double d0 = 0.0, d1 = 0.0, d2 = 0.0;
         if (PQ) { const double4 p = sorted[k]; d0 = xi - p.x; d1 = yi - p.y; d2 = zi - p.z; }   // the shell terms need the vector
@@ -282,6 +301,10 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
           const double *T = ff.tabQEq + static_cast<size_t>(inxn) * (NTABLE + 2);
           h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
         }
+        {   // window slot: the candidate's column (of this row) -> the group's table entry -> first unit of the column + offset inside it
+          const int e_ = cE[static_cast<int>((wv >> 40) & 31)];
+          sl10[row + slot] = static_cast<unsigned short>((WIN_UNIT * t_ub[e_] + (k - (t_lo[e_] & ~(WIN_UNIT - 1)))) | (j >= N ? 0x8000 : 0));
+        }
         unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
         if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
         if (xs0) {
@@ -301,23 +324,79 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   int L;
   {
     int k0 = 0, len = 0;
-    if (lane < 25) column_run<ORTHO>(g, cellstart, spx[i], spy[i], spz[i], cx, cy, cx + lane / 5 - 2, cy + lane % 5 - 2, ff.rctap_pad, k0, len);
+    const int x2 = cx + lane / 5 - 2, y2 = cy + lane % 5 - 2;
+    if (live && lane < 25) column_run<ORTHO>(g, cellstart, spx[i], spy[i], spz[i], cx, cy, x2, y2, ff.rctap_pad, k0, len);
     int lpre = len;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {
       const int l2 = __shfl_up(lpre, o, 64);
       if (lane >= o) lpre += l2;
     }
-    if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; }
+    int e_ = 0;
+    if (len > 0) {                                // this row's run of column (x2, y2) joins the group's interval of that column
+      const int key = x2 * g.n[1] + y2;
+      e_ = static_cast<int>((static_cast<unsigned>(key) * 0x9E3779B1u) >> 24) & (WIN_COLS - 1);
+      int probes = 0;
+      for (; probes < WIN_COLS; ++probes) {
+        const int prev = atomicCAS(&t_key[e_], -1, key);
+        if (prev == -1 || prev == key) break;
+        e_ = (e_ + 1) & (WIN_COLS - 1);
+      }
+      if (probes == WIN_COLS) { s_fail = 1; e_ = 0; }
+      else { atomicMin(&t_lo[e_], k0); atomicMax(&t_hi[e_], k0 + len); }
+    }
+    if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; cE[lane] = e_; }
     L = __shfl(lpre, 31, 64);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __syncthreads();
+  {   // units per column; the columns in the order of their ids (the numbering must not depend on which wavefront claimed an entry first)
+    const int t = threadIdx.x;
+    if (t < WIN_COLS) {
+      const int key = t_key[t];
+      int nu = 0, rank = 0;
+      if (key != -1) {
+        nu = (t_hi[t] - (t_lo[t] & ~(WIN_UNIT - 1)) + WIN_UNIT - 1) / WIN_UNIT;
+        for (int o = 0; o < WIN_COLS; ++o) { const int ko = t_key[o]; rank += (ko != -1 && ko < key) ? 1 : 0; }
+        t_ord[rank] = t;
+      }
+      t_nu[t] = nu;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {                                   // exclusive prefix of the units in column order: lane l takes the ordered columns 4 l .. 4 l + 3
+    int ncol = 0;
+    for (int o = lane; o < WIN_COLS; o += 64) ncol += (t_key[o] != -1) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) ncol += __shfl_xor(ncol, o, 64);
+    int mine[4], sum = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int r = 4 * lane + c; mine[c] = r < ncol ? t_nu[t_ord[r]] : 0; sum += mine[c]; }
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
+    int run = inc - sum;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int r = 4 * lane + c; if (r < ncol) t_ub[t_ord[r]] = run; run += mine[c]; }
+    if (lane == 63) s_total = inc;
+  }
+  __syncthreads();
+  {
+    const int nunits = s_total;
+    const bool fail = s_fail != 0 || nunits > WIN_MAXUNITS;
+    if (threadIdx.x == 0) {
+      win_cnt[grp] = fail ? 0 : nunits;
+      if (fail) atomicExch(&err[6], 1);
+      if (__hip_atomic_load(&err[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) atomicMax(&err[5], nunits);
+    }
+    if (!fail && threadIdx.x < WIN_COLS && t_key[threadIdx.x] != -1) {
+      const int lo8 = t_lo[threadIdx.x] & ~(WIN_UNIT - 1), ub = t_ub[threadIdx.x], nu = t_nu[threadIdx.x];
+      for (int u = 0; u < nu; ++u) win_k[static_cast<size_t>(grp) * WIN_MAXUNITS + ub + u] = lo8 + WIN_UNIT * u;
+    }
+  }
 #ifdef RXMD_EXPERIMENTS
   if (g.probe == 1) { if (lane == 0) n10[i] = L; return; }
 #endif
   for (int c0 = 0; c0 < L; c0 += 256) {
     // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
-    int kk[4];
+    int kk[4], tcol[4];
     bool ok[4];
     double4 pd[4];
 #pragma unroll
@@ -328,6 +407,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
 #pragma unroll
       for (int st = 16; st > 0; st >>= 1) t += (cP[t + st] <= cc) ? st : 0;
       kk[u] = ok[u] ? cK[t] + (cc - cP[t]) : 0;
+      tcol[u] = t;
       pd[u] = ok[u] ? sorted[kk[u]] : make_double4(0, 0, 0, 0);
     }
 #pragma unroll
@@ -343,7 +423,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
         if (!ORTHO && in) { double sj[3]; ref_norm(rm, pd[u].x, pd[u].y, pd[u].z, sj); in = ref_nb_cells_in_mesh(rm, sni, sj, ff.rctap2); }
       }
       const unsigned long long m = __ballot(in);
-      if (in) { const int qp = qn + __popcll(m & ((1ULL << lane) - 1ULL)); sq[qp] = kk[u]; sr2[qp] = r2q; sw[qp] = __double_as_longlong(pd[u].w); }
+      if (in) { const int qp = qn + __popcll(m & ((1ULL << lane) - 1ULL)); sq[qp] = kk[u]; sr2[qp] = r2q; sw[qp] = __double_as_longlong(pd[u].w) | (static_cast<long long>(tcol[u]) << 40); }
       qn += __popcll(m);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (qn >= 64) {
@@ -359,8 +439,9 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
     }
   }
   if (qn > 0) emit(qn);
+  if (live) {
   if (cnt > S10) { if (lane == 0) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); } cnt = S10; }  // qeq.F90:248-252
-  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; }   // zero-pad the row to a multiple of 4
+  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; sl10[row + cnt + lane] = 0; }   // zero-pad the row to a multiple of 4 (value 0, slot 0)
   if (xs0) {
     ra = wave_sum_l(ra); rg = wave_sum_l(rg);
     if (lane == 0) { s_all[i] = make_double2(ra, 0.0); s_gh[i] = make_double2(rg, 0.0); }
@@ -378,6 +459,12 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
     // read with the error word the host waits for anyway).  One atomic per new maximum, not per row.
     if (__hip_atomic_load(&err[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[3], cnt);
     if (__hip_atomic_load(&err[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cnt) atomicMin(&err[4], cnt);     // ... and the shortest
+    if (mg != 0ULL) s_bnd = 1;                    // (every writer writes 1)
+  }
+  }   // live
+  if (gflag) {                                    // multi-rank: a group with a row that has a ghost partner waits for the vector halo (the pass's second launch)
+    __syncthreads();
+    if (threadIdx.x == 0) gflag[grp] = s_bnd;
   }
 }
 
@@ -397,165 +484,24 @@ __global__ void k_rows_sorted(int G, int N, const int *__restrict__ perm, const 
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < G && perm[k] < N) rows_sorted[rank[k]] = perm[k];
 }
-// One workgroup of eight wavefronts per group of WIN_ROWS rows, two rows per wavefront with their entries in registers (NE x 64 >= the row
-// stride; one round trip for all of them): the positions the rows couple to are marked in an LDS map, one bit per unit of WIN_UNIT positions
-// counted from the group's smallest; a unit's rank among the marked ones is its place in the window; an entry's slot is 8 x rank + position
-// inside the unit.  Whatever order k_list10 left the entries in, and whether or not the group's rows sit in one cell column.
-template <int NE>
-__global__ void __launch_bounds__(512) k_win_build(int N, int S10, const int *__restrict__ rows_sorted, const int *__restrict__ nb10, const int *__restrict__ n10,
-                                                   unsigned short *__restrict__ sl10, int *__restrict__ win_k, int *__restrict__ win_cnt, int *__restrict__ gflag, int *err, int probe) {
-  __shared__ unsigned long long bm[WIN_BMW];
-  __shared__ int pre[WIN_BMW];
-  __shared__ int s_min, s_max, s_total, s_bnd;
-  constexpr int NWAVES = 8, RPW = WIN_ROWS / NWAVES;  // rows per wavefront
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
-  int row[RPW], n[RPW];
-  unsigned ent[RPW][NE];
-#pragma unroll
-  for (int j = 0; j < RPW; ++j) {
-    const int ridx = g * WIN_ROWS + wave * RPW + j;
-    row[j] = ridx < N ? rows_sorted[ridx] : -1;
-  }
-  bool bnd = false;                                   // does a row of the group have a ghost partner? (multi-rank: the group waits for the vector halo)
-#pragma unroll
-  for (int j = 0; j < RPW; ++j) { const int nraw = row[j] >= 0 ? n10[row[j]] : 0; n[j] = nraw & N10_COUNT; bnd |= (nraw & N10_GHOST_ROW) != 0; }
-  bool toolong = false;
-#pragma unroll
-  for (int j = 0; j < RPW; ++j) toolong |= n[j] > 64 * NE;
-  if (toolong) { if (lane == 0) atomicExch(&err[6], 1); }    // (uniform per wavefront; the group still completes with the entries it holds)
-#pragma unroll
-  for (int j = 0; j < RPW; ++j) {
-    const size_t base = static_cast<size_t>(row[j] >= 0 ? row[j] : 0) * S10;
-#pragma unroll
-    for (int u = 0; u < NE; ++u) { const int e = lane + 64 * u; ent[j][u] = e < n[j] ? static_cast<unsigned>(nb10[base + e]) : 0xffffffffu; }
-  }
-  for (int w = tid; w < WIN_BMW; w += 64 * NWAVES) bm[w] = 0ULL;
-  if (tid == 0) { s_min = 0x7fffffff; s_max = -1; s_bnd = 0; }
-  __syncthreads();
-  if (gflag && bnd && lane == 0) atomicOr(&s_bnd, 1);
-  int kmn = 0x7fffffff, kmx = -1;
-#pragma unroll
-  for (int j = 0; j < RPW; ++j)
-#pragma unroll
-    for (int u = 0; u < NE; ++u)
-      if (ent[j][u] != 0xffffffffu) { const int k = static_cast<int>(ent[j][u] & NB10_IDX_MASK); kmn = min(kmn, k); kmx = max(kmx, k); }
-  for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, __shfl_xor(kmn, o, 64)); kmx = max(kmx, __shfl_xor(kmx, o, 64)); }
-  if (lane == 0 && kmx >= 0) { atomicMin(&s_min, kmn); atomicMax(&s_max, kmx); }
-  __syncthreads();
-  if (tid == 0 && gflag) gflag[g] = s_bnd;
-  if (s_max < 0) { if (tid == 0) win_cnt[g] = 0; return; }                       // no entries at all (isolated atoms)
-  const int kmin = s_min & ~(WIN_UNIT - 1);
-  const int nwords = (((s_max - kmin) / WIN_UNIT + 1) + 63) >> 6;
-  if (nwords > WIN_BMW) { if (tid == 0) { win_cnt[g] = 0; atomicExch(&err[6], 1); } return; }
-#ifdef RXMD_EXPERIMENTS
-  if (probe == 1) { if (tid == 0) win_cnt[g] = nwords; return; }
-#endif
-#pragma unroll
-  for (int j = 0; j < RPW; ++j)
-#pragma unroll
-    for (int u = 0; u < NE; ++u)
-    {   // the entries of a row ascend: a lane marks its unit only if the lane before it (in its row of 16 lanes) has a different one --
-        // atomics of one wavefront instruction to the same LDS word are serialised, and three entries in four are repeats
-      const int o = ent[j][u] != 0xffffffffu ? (static_cast<int>(ent[j][u] & NB10_IDX_MASK) - kmin) / WIN_UNIT : -1;
-      const int oprev = __builtin_amdgcn_update_dpp(-2, o, 0x111, 0xf, 0xf, false);     // row_shr:1; lane 0 of a row keeps -2
-      if (o >= 0 && o != oprev) atomicOr(&bm[o >> 6], 1ULL << (o & 63));
-    }
-  __syncthreads();
-#ifdef RXMD_EXPERIMENTS
-  if (probe == 2) { if (tid == 0) win_cnt[g] = static_cast<int>(bm[0]); return; }
-#endif
-  if (wave == 0) {                                    // exclusive prefix of the words' populations: lane l takes the words [l per, (l + 1) per)
-    const int per = (nwords + 63) >> 6;
-    int sum = 0;
-    for (int w = lane * per; w < min(nwords, (lane + 1) * per); ++w) sum += __popcll(bm[w]);
-    int inc = sum;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    int run = inc - sum;
-    for (int w = lane * per; w < min(nwords, (lane + 1) * per); ++w) { pre[w] = run; run += __popcll(bm[w]); }
-    if (lane == 63) s_total = inc;
-  }
-  __syncthreads();
-  const int nunits = s_total;
-#ifdef RXMD_EXPERIMENTS
-  if (probe == 3) { if (tid == 0) win_cnt[g] = nunits; return; }
-#endif
-  if (nunits > WIN_MAXUNITS) { if (tid == 0) { win_cnt[g] = 0; atomicExch(&err[6], 1); atomicMax(&err[5], nunits); } return; }
-  for (int w = tid; w < nwords; w += 64 * NWAVES) {   // unit list: most words of the range are empty (25 runs of ~8 units in ~170 words)
-    unsigned long long m = bm[w];
-    int r = pre[w];
-    while (m) { const int b = __ffsll(static_cast<long long>(m)) - 1; m &= m - 1ULL; win_k[static_cast<size_t>(g) * WIN_MAXUNITS + r++] = kmin + WIN_UNIT * (64 * w + b); }
-  }
-#ifdef RXMD_EXPERIMENTS
-  if (probe == 4) { if (tid == 0) win_cnt[g] = nunits; return; }
-#endif
-  if (tid == 0) { win_cnt[g] = nunits; if (__hip_atomic_load(&err[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) atomicMax(&err[5], nunits); }
-#pragma unroll
-  for (int j = 0; j < RPW; ++j) {
-    if (row[j] < 0) continue;
-    const size_t base = static_cast<size_t>(row[j]) * S10;
-    const int npad = (n[j] + 3) & ~3;                 // k_list10 zero-pads a row to a multiple of 4: those entries get slot 0
-#pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      const int e = lane + 64 * u;
-      if (e >= npad) continue;
-      unsigned short sl = 0;
-      if (e < n[j]) {
-        const int d = static_cast<int>(ent[j][u] & NB10_IDX_MASK) - kmin, o = d / WIN_UNIT;
-        const unsigned long long m = bm[o >> 6];
-        const int r = pre[o >> 6] + __popcll(m & ((1ULL << (o & 63)) - 1ULL));
-        sl = static_cast<unsigned short>((WIN_UNIT * r + (d & (WIN_UNIT - 1))) | ((ent[j][u] & NB10_GHOST) ? 0x8000 : 0));
-      }
-      sl10[base + e] = sl;
-    }
-  }
-}
-
 __global__ void k_split_groups(int ng, const int *__restrict__ flag, const int *__restrict__ scan, int *__restrict__ g_int, int *__restrict__ g_bnd) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   if (flag[g]) g_bnd[scan[g]] = g; else g_int[g - scan[g]] = g;
 }
 
+// the residents in cell-sorted order (rows_sorted): the rows of a window group, and the work order of the 10 A sweep that builds the windows
 void Engine::build_windows() {
-  win_groups = 0;
-  if (std::getenv("RXMD_SPMV_NO_WIN") || (S10 & 3) || N <= 0 || S10 > 1024) return;
-  // The build costs about as much as four to seven matrix passes save: not for the extended-Lagrangian mode (one iteration per step, qeq.F90:51-57), a
-  // small NMAXQEq, or when the calls so far converged in a few iterations on average (RXMD_SPMV_WIN=2 builds regardless)
-  {
-    const char *wv = std::getenv("RXMD_SPMV_WIN");
-    const double expect = (cfg.isQEq == 1) ? (qeq_iters_smooth >= 0.0 ? std::min<double>(cfg.NMAXQEq, qeq_iters_smooth) : cfg.NMAXQEq) : (cfg.isQEq == 2 ? 1.0 : 0.0);
-    if (expect < 5.0 && !(wv && std::atoi(wv) == 2)) return;
-  }
   k_resident_flags<<<nblk(G + 1, 256), 256, 0, stream>>>(G, N, perm, flags2);
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, G + 1, stream));
   k_rows_sorted<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, scanout2, rows_sorted);
   RX_HIP(hipMemsetAsync(d_err + 5, 0, 2 * sizeof(int), stream));
   win_groups = (N + WIN_ROWS - 1) / WIN_ROWS;
-  int *gflag = multi() ? flags2 : nullptr;           // (the resident flags are used up)
-  int wprobe = 0;
-#ifdef RXMD_EXPERIMENTS
-  if (const char *pv = std::getenv("RXMD_WINB_PROBE")) wprobe = std::atoi(pv);   // timing probes: stop after a phase (the pass must be off then)
-#endif
-  const bool ktw = kt_begin(&st.ms_k_winbuild);
-  // entries per lane the kernel keeps in registers: by the longest row of the PREVIOUS build plus a margin (this build's is not known on the
-  // host yet); a row that outgrows it sets the failure word and this step's passes are row passes
-  const int need = max_row10 > 0 ? std::min(S10, max_row10 + max_row10 / 16 + 8) : S10;
-  if (need <= 512) k_win_build<8><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
-  else if (need <= 768) k_win_build<12><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
-  else k_win_build<16><<<win_groups, 512, 0, stream>>>(N, S10, rows_sorted, nb10, n10, sl10, win_k, win_cnt, gflag, d_err, wprobe);
-  kt_end(ktw);
-  if (multi()) {                                     // interior groups (no row with a ghost partner) / boundary groups: the two launches of an overlapped pass
-    RX_HIP(hipMemsetAsync(flags2 + win_groups, 0, sizeof(int), stream));
-    tb = cubtmp_bytes;
-    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, win_groups + 1, stream));
-    k_split_groups<<<nblk(win_groups, 256), 256, 0, stream>>>(win_groups, flags2, scanout2, win_gint, win_gbnd);
-    RX_HIP(hipMemcpyAsync(&win_nbnd, scanout2 + win_groups, sizeof(int), hipMemcpyDeviceToHost, stream));   // valid after the synchronisation of the list build's error check
-  }
 }
 
 void Engine::build_bonded_list() {
-  k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi);
+  k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi, sorted_type);
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
   if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
   else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
@@ -570,18 +516,28 @@ void Engine::build_list10() {
   RX_HIP(hipMemsetAsync(d_err + 4, 0x7f, sizeof(int), stream));      // 0x7f7f7f7f: larger than any row
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);
+  list_selfcheck = selfcheck;
 #define RX_LIST10(SC, PQF) do { if (grid.ortho) RX_LIST10_O(SC, PQF, true); else RX_LIST10_O(SC, PQF, false); } while (0)
 #define RX_LIST10_O(SC, PQF, OR)                                                                                                               \
-  k_list10<SC, PQF, OR><<<nblk(N, 4), 256, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
-                                                    nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr)
+  k_list10<SC, PQF, OR><<<nblk(N, WIN_ROWS), 64 * WIN_ROWS, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
+                                                    nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr, \
+                                                    rows_sorted, sl10, win_k, win_cnt, gflag)
+  win_valid = false;
+  build_windows();
+  int *gflag = multi() ? flags2 : nullptr;           // (the resident flags are used up)
   const bool kt10 = kt_begin(&st.ms_k_list10);
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
   kt_end(kt10);
 #undef RX_LIST10
 #undef RX_LIST10_O
-  win_valid = false;
-  build_windows();
+  if (multi()) {                                     // interior groups (no row with a ghost partner) / boundary groups: the two launches of an overlapped pass
+    RX_HIP(hipMemsetAsync(flags2 + win_groups, 0, sizeof(int), stream));
+    size_t tb = cubtmp_bytes;
+    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, win_groups + 1, stream));
+    k_split_groups<<<nblk(win_groups, 256), 256, 0, stream>>>(win_groups, flags2, scanout2, win_gint, win_gbnd);
+    RX_HIP(hipMemcpyAsync(&win_nbnd, scanout2 + win_groups, sizeof(int), hipMemcpyDeviceToHost, stream));   // valid after the synchronisation of the list build's error check
+  }
   if (multi()) {     // interior rows (no ghost partner) and boundary rows: the matrix pass does the former while the vector halo is in flight
     RX_HIP(hipMemsetAsync(flags + N, 0, sizeof(int), stream));
     size_t tb = cubtmp_bytes;

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace rxmd {
 
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
 // (A timing probe with synthetic slots promised 0.76 against 0.93 ms of k_spmv before anything real was built; the real pass: 0.80 against 0.89 ms
 // back to back in one process, DESIGN.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
-template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
+template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR & 2: the second batch of a row is requested before the workgroup's barrier (below).  NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
@@ -248,10 +249,30 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
     if (k >= n) { v[u].x = 0.0; ss[u] &= 0xffff0000u; if (PQ) c[u].x = 0.0; }
     if (k + 1 >= n) { v[u].y = 0.0; ss[u] &= 0x0000ffffu; if (PQ) c[u].y = 0.0; }
   }
+  // VAR & 2 (plain QEq): the row's NEXT batch is requested before the barrier, behind the window's data (a wavefront's loads return in order:
+  // the window does not wait for it) -- the round trip of the second batch runs under the barrier and the first batch's arithmetic instead of
+  // after it; the batch after that is requested before the current one is used, and so on.
+  constexpr bool PRE = (VAR & 2) != 0 && !PQ;
+  double2 vn[STEPS]; unsigned sn[STEPS];
+  auto request_next = [&](int kb) {
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      const int k = kb + 128 * u + 2 * lane;
+      const bool ok = k < n;
+      if (ok) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); vn[u] = make_double2(t2.x, t2.y); } else vn[u] = make_double2(0.0, 0.0);
+      sn[u] = ok ? __builtin_nontemporal_load(sl2 + (k >> 1)) : 0u;
+    }
+  };
+  if (PRE && n > 128 * STEPS) request_next(128 * STEPS);
   __syncthreads();
   double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
   for (int kb = 0; kb < n; kb += 128 * STEPS) {     // wave-uniform trip count
-    if (kb > 0) request(kb, n);                     // (an odd row end: entry n is the zero padding of the row, slot 0)
+    if (!PRE && kb > 0) request(kb, n);             // (an odd row end: entry n is the zero padding of the row, slot 0)
+    if (PRE && kb > 0) {
+#pragma unroll
+      for (int u = 0; u < STEPS; ++u) { v[u] = vn[u]; ss[u] = sn[u]; }
+      if (kb + 128 * STEPS < n) request_next(kb + 128 * STEPS);
+    }
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
       const double2 y0 = s_x[ss[u] & 0x7fffu], y1 = s_x[(ss[u] >> 16) & 0x7fffu];
@@ -268,6 +289,155 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   // The row's tail by its own wavefront (the rows of a group are scattered residents: nothing would coalesce if one wavefront ran all of them,
   // and a workgroup whose last wavefront works alone keeps 15 wavefront slots of the CU empty); a wavefront leaves when it is done.  The
   // workgroup's four partial sums: every wavefront leaves its terms in LDS, the LAST one to arrive adds them in wavefront order.
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (live) {
+    const DevAtomP ap = ff.atom[tl_t];
+    if (MODE == MODE_HSH) {
+      const double ts = ap.eta * tl_a.x + as, tt = ap.eta * tl_a.y + at;      // qeq.F90:294-302
+      a0 = ts * tl_a.x; a1 = tt * tl_a.y;                                     // hshs_sum, hsht_sum (:309-310)
+      a2 = tl_b.x * tl_a.x; a3 = tl_b.y * tl_a.y;                             // g.h (:119,123)
+      if (STORE && lane == 0) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+    } else {
+      const double mu = scal[S_MU];
+      const double4 pr = PQ ? pqrow[row] : make_double4(0.0, 0.0, 0.0, 0.0);
+      const double g1 = -ap.chi - ap.eta * tl_a.x - as - pr.x;                // qeq.F90:349-350 (pqeq.F90:466)
+      const double g2 = -1.0 - ap.eta * tl_a.y - at;
+      a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
+      const double qi = tl_b.x;
+      const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
+      if (PQ) a2 = pq_est_row(ap, ff.Zpq[tl_t], pr, qi, hq_all, gs_ - mu * gt_);
+      else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
+      if (lane == 0) { gst[row] = make_double2(g1, g2); if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); } }
+    }
+  }
+  int arrived = 0;
+  if (lane == 0) {
+    s_row[wave][0] = a0; s_row[wave][1] = a1; s_row[wave][2] = a2; s_row[wave][3] = a3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    arrived = __hip_atomic_fetch_add(&s_arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  arrived = __builtin_amdgcn_readfirstlane(arrived);
+  if (arrived != WIN_ROWS - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane < 4) {
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < WIN_ROWS; ++w) sum += s_row[w][lane];                 // fixed order: the result does not depend on which wavefront is last
+    __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---- window pass, early-issue form (k_spmv_win2) ------------------------------------------------------------------------------------------
+// Same sums as k_spmv_win; what changes is WHEN the wavefront's requests leave.  k_spmv_win lives through three dependent round trips before its
+// first product -- descriptors (row of the group, window size, unit starts), then window + first batch, then the second batch after the first was
+// used -- and a CU holds two such workgroups: throughput = bytes of a group / that lifetime x 2.  Here
+//   * the value and slot ROWS lie in cell-sorted rank order (row of wavefront w of group g = g * 16 + w: no look-up in front of the stream), so the
+//     first batch is requested at the very start;
+//   * everything the window needs is WAVE-UNIFORM and comes by scalar loads (their own counter, not queued behind the stream's vector loads): the
+//     window size and the 8 + 8 unit starts this wavefront copies (a wavefront's 64 threads cover 8 consecutive units of each round);
+//   * the second batch is requested before the barrier, behind the window's loads.
+// One workgroup per group, 16 wavefronts, as before.
+template <int MODE, bool STORE, bool PQ>
+__global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win2(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
+                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
+                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
+                                                             const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
+                                                             const double *__restrict__ scal, double *__restrict__ partials,
+                                                             double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
+                                                             const double *__restrict__ hsc, const double4 *__restrict__ pqrow,
+                                                             const int *__restrict__ grouplist, int ngroups, int pbase, const double *__restrict__ stopflag) {
+  if (stopflag && *stopflag != 0.0) return;
+  extern __shared__ double2 s_x[];
+  __shared__ double s_row[WIN_ROWS][4];
+  __shared__ int s_arrived;
+  constexpr int NT = 64 * WIN_ROWS;
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int gidx = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int grp = grouplist ? (gidx < ngroups ? grouplist[gidx] : -1) : (gidx < ngroups ? gidx : -1);
+  if (grp < 0) return;
+  const int ridx = grp * WIN_ROWS + wave;
+  const bool live = ridx < N;
+  const size_t base = static_cast<size_t>(live ? ridx : 0) * S10;
+  const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
+  const d2v *cv2 = reinterpret_cast<const d2v *>((PQ ? hsc : hess) + base);
+  const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
+  double2 v[2], c[2], vn[2], cn[2]; unsigned ss[2], sn[2];
+  // first batch: 256 entries, two per lane and request -- inside the row's slot whatever the row's length
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = 128 * u + 2 * lane;
+    if (live && k < S10) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); v[u] = make_double2(t2.x, t2.y); ss[u] = __builtin_nontemporal_load(sl2 + (k >> 1)); }
+    else { v[u] = make_double2(0.0, 0.0); ss[u] = 0u; }
+    if (PQ && (MODE == MODE_GRAD || STORE)) { if (live && k < S10) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); c[u] = make_double2(t2.x, t2.y); } else c[u] = make_double2(0.0, 0.0); }
+  }
+  // wave-uniform descriptors: scalar loads
+  const int row = live ? rows_sorted[ridx] : N;
+  const int nslots = WIN_UNIT * win_cnt[grp];
+  const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
+  int ua[8], ub[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ua[j] = wk[wave * 8 + j]; ub[j] = wk[NT / WIN_UNIT + wave * 8 + j]; }
+  const int n = live ? (n10[row] & N10_COUNT) : 0;
+  const int rowc = live ? row : 0;
+  const int tl_t = type[rowc];
+  const double2 tl_a = (MODE == MODE_HSH) ? hst[rowc] : qst[rowc];
+  const double2 tl_b = (MODE == MODE_HSH) ? const_cast<const double2 *>(gst)[rowc] : make_double2(q[rowc], 0.0);
+  const int t0 = threadIdx.x, t1 = threadIdx.x + NT;
+  int wk0 = ua[0], wk1 = ub[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) { const bool m = (lane >> 3) == j; wk0 = m ? ua[j] : wk0; wk1 = m ? ub[j] : wk1; }
+  double2 x0 = make_double2(0.0, 0.0), x1 = x0;
+  if (t0 < nslots) x0 = xv[min(wk0 + (t0 & (WIN_UNIT - 1)), G - 1)];
+  if (t1 < nslots) x1 = xv[min(wk1 + (t1 & (WIN_UNIT - 1)), G - 1)];
+  // second batch, behind the window's loads (a wavefront's vector loads return in order: the window does not wait for it)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = 256 + 128 * u + 2 * lane;
+    if (k < n) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); vn[u] = make_double2(t2.x, t2.y); sn[u] = __builtin_nontemporal_load(sl2 + (k >> 1)); }
+    else { vn[u] = make_double2(0.0, 0.0); sn[u] = 0u; }
+    if (PQ && (MODE == MODE_GRAD || STORE)) { if (k < n) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); cn[u] = make_double2(t2.x, t2.y); } else cn[u] = make_double2(0.0, 0.0); }
+  }
+  if (threadIdx.x == 0) s_arrived = 0;
+  if (t0 < nslots) s_x[t0] = x0;
+  if (t1 < nslots) s_x[t1] = x1;
+  for (int t = threadIdx.x + 2 * NT; t < nslots; t += NT) s_x[t] = xv[min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1)];   // a window of more than 256 units
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {                     // entries behind the row's end: weight 0, slot 0
+    const int k = 128 * u + 2 * lane;
+    if (k >= n) { v[u].x = 0.0; ss[u] &= 0xffff0000u; if (PQ) c[u].x = 0.0; }
+    if (k + 1 >= n) { v[u].y = 0.0; ss[u] &= 0x0000ffffu; if (PQ) c[u].y = 0.0; }
+  }
+  __syncthreads();
+  double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
+  for (int kb = 0; kb < n; kb += 256) {             // wave-uniform trip count
+    if (kb > 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { v[u] = vn[u]; ss[u] = sn[u]; if (PQ) c[u] = cn[u]; }
+      if (kb + 256 < n) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = kb + 256 + 128 * u + 2 * lane;
+          if (k < n) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); vn[u] = make_double2(t2.x, t2.y); sn[u] = __builtin_nontemporal_load(sl2 + (k >> 1)); }
+          else { vn[u] = make_double2(0.0, 0.0); sn[u] = 0u; }
+          if (PQ && (MODE == MODE_GRAD || STORE)) { if (k < n) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); cn[u] = make_double2(t2.x, t2.y); } else cn[u] = make_double2(0.0, 0.0); }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const double2 y0 = s_x[ss[u] & 0x7fffu], y1 = s_x[(ss[u] >> 16) & 0x7fffu];
+      as += v[u].x * y0.x; at += v[u].x * y0.y; as += v[u].y * y1.x; at += v[u].y * y1.y;
+      if ((MODE == MODE_GRAD || STORE) && !PQ) {
+        const double g0 = (ss[u] & 0x8000u) ? v[u].x : 0.0, g1 = (ss[u] & 0x80000000u) ? v[u].y : 0.0;     // select the weight, not the sums
+        gs_ += g0 * y0.x; gt_ += g0 * y0.y; gs_ += g1 * y1.x; gt_ += g1 * y1.y;
+      }
+      if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * y0.x; gt_ += c[u].x * y0.y; gs_ += c[u].y * y1.x; gt_ += c[u].y * y1.y; }
+    }
+  }
+  as = wave_sum(as); at = wave_sum(at);
+  if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (live) {
     const DevAtomP ap = ff.atom[tl_t];
@@ -423,6 +593,40 @@ void spmv_isolated_ms(Engine &e, double *out) {
     for (int rd = 0; rd < rounds; ++rd)
       a3 += timed([&] { k_spmv_win<MODE_HSH, true, false, 3><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
     out[2] = a3 / rounds;
+    double a4 = 0.0;                                // variant: second batch requested before the barrier (VAR & 2)
+    for (int rd = 0; rd < rounds; ++rd)
+      a4 += timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 2><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+    out[3] = a4 / rounds;
+    double a5 = 0.0;                                // the default once more, after the variants (drift of the box)
+    for (int rd = 0; rd < rounds; ++rd)
+      a5 += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+    out[4] = a5 / rounds;
+    {   // k_spmv_win2 on copies of the value / slot arrays with their rows in cell-sorted rank order
+      const size_t ne = static_cast<size_t>(e.rows10) * e.S10;
+      double *h2 = nullptr; unsigned short *s2 = nullptr;
+      if (hipMalloc(reinterpret_cast<void **>(&h2), ne * sizeof(double)) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&s2), ne * sizeof(unsigned short)) == hipSuccess) {
+        k_rows_to_rank_order<<<e.N, 256, 0, e.stream>>>(e.N, e.S10, e.rows_sorted, e.hess, e.sl10, h2, s2);
+        double a6 = 0.0, a7 = 0.0;
+        for (int rd = 0; rd < rounds; ++rd) {
+          a6 += timed([&] { k_spmv_win2<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2, h2, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+          a7 += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+        }
+        out[5] = a6 / rounds; out[6] = a7 / rounds;
+        // same sums? row sums of the two kernels side by side (wall holds the last launch's: the default's); compare through a second buffer
+        double2 *w2 = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&w2), sizeof(double2) * e.N) == hipSuccess) {
+          k_spmv_win2<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2, h2, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, w2, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr);
+          std::vector<double> ha(2 * static_cast<size_t>(e.N)), hb(2 * static_cast<size_t>(e.N));
+          hipMemcpy(ha.data(), e.wall, sizeof(double2) * e.N, hipMemcpyDeviceToHost); hipMemcpy(hb.data(), w2, sizeof(double2) * e.N, hipMemcpyDeviceToHost);
+          double md = 0.0, mx = 0.0;
+          for (size_t k = 0; k < ha.size(); ++k) { md = std::max(md, std::fabs(ha[k] - hb[k])); mx = std::max(mx, std::fabs(ha[k])); }
+          out[7] = md; out[8] = mx;
+          (void)hipFree(w2);
+        }
+      } else (void)hipGetLastError();
+      if (h2) (void)hipFree(h2);
+      if (s2) (void)hipFree(s2);
+    }
   }
   // RXMD_ISO_COPIES=1: does the pass time depend on WHERE its streams lie?  Four copies of the value and slot arrays held at the same time, the
   // pass on each, twice round (out[2..9]): a property of the buffer repeats in the second round, a drift in time does not.  out[10]: the last
@@ -658,6 +862,9 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
 }
 // B: new direction h = g + beta h written to the other (hs,ht) buffer; q = qs - mu qt and the Est term (qeq.F90:150,160-164,297-306)
 //    -> tail: Est (stage 5), sums only (0) or no reduction at all (-1: Est came with the update kernel's sums)
+//    QEST = false (Est came with the update kernel's sums, stage -1): only the direction -- the charges q = qs - mu qt are formed once, behind the
+//    last iteration (k_apply_q), instead of in every iteration: three 16-byte reads and an 8-byte write per atom and iteration less
+template <bool QEST>
 __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type,
                                                        const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new,
                                                        const double2 *__restrict__ qst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double *__restrict__ q,
@@ -671,6 +878,7 @@ __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *_
     const double2 hn = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
     hst_new[i] = hn;
     if (xs) xs[invpos[i]] = hn;                      // single rank: the cell-sorted gather copy of the next matrix pass (QCOPY2, qeq.F90:164) is written here ...
+    if (!QEST) continue;
     const DevAtomP ap = ff.atom[type[i]];
     const double2 qv = qst[i], a = sall[i], gh = sgh[i];
     const double qi = qv.x - mu * qv.y;
@@ -685,7 +893,7 @@ __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *_
       const double2 g = gst[r], h = hst[r];
       xs[invpos[t]] = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
     }
-  if (stage < 0) return;
+  if (!QEST || stage < 0) return;
   double acc[4] = {wave_sum(es), 0.0, 0.0, 0.0};
   block_store_partials<4>(acc, partials, 4);
   block_finish(gridDim.x, partials, ticket, stage, scal);     // stage 5 or 0
@@ -790,7 +998,7 @@ void Engine::tune_window_placement() {
       if (r == 5) hipEventRecord(ev[2], stream);
       if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
       else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
-      else k_spmv_win<MODE_HSH, true, false><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
+      else k_spmv_win<MODE_HSH, true, false, 2, 2><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
     }
     hipEventRecord(ev[3], stream); hipEventSynchronize(ev[3]);
     hipEventElapsedTime(&ms, ev[2], ev[3]);
@@ -857,7 +1065,7 @@ void Engine::qeq() {
       const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
       const bool one_trip = !ff.pqeq && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
 #define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag); \
-                              else k_spmv_win<M, S, P, 2><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag); } while (0)
+                              else k_spmv_win<M, S, P, 2, 2><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag); } while (0)
 #define RX_WIN(M, S) do { if (ff.pqeq) RX_WIN3(M, S, true); else RX_WIN3(M, S, false); } while (0)
       if (mode == MODE_HSH) { if (store) RX_WIN(MODE_HSH, true); else RX_WIN(MODE_HSH, false); }
       else { if (store) RX_WIN(MODE_GRAD, true); else RX_WIN(MODE_GRAD, false); }
@@ -906,6 +1114,7 @@ void Engine::qeq() {
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
   sync_stream();
   double GEst2 = 1e99, Est = h_scal[S_EST];
+  est_trace.clear(); est_trace.push_back(Est);      // Est of the start vector, then of every iteration (debug tap 13: the reference's QEQDUMP trace)
   int it = 0;
   float ms = 0;
   bool xs_current = false;       // the fused direction kernel leaves the sorted copy of the new (hs,ht) in xs
@@ -917,7 +1126,7 @@ void Engine::qeq() {
   constexpr bool est_with_update = true, cg_scatter = true;
 #endif
   const bool overlap = overlap_on && multi() && onepass && !rows_split_pending_invalid();
-  bool halo_in_flight = false;
+  bool halo_in_flight = false, q_pending = false;
   // ---- run-ahead loop (single rank, qeq_mode 1, plain QEq; RXMD_CG_NO_RUNAHEAD=1 switches it off) ------------------------------------
   // The host is one iteration BEHIND the device: iteration it is queued in full before the host has seen the Est that decides whether it
   // happens.  The decision (qeq.F90:114-115) is made on the device where Est becomes final (scalar_algebra stage 6 -> scal[S_STOP]); the
@@ -941,7 +1150,7 @@ void Engine::qeq() {
       RX_HIP(hipMemcpyAsync(h_scal + 64 + 64 * (k & 1), scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
       RX_HIP(hipEventRecord(ev_spec[k & 1], stream));
       const bool scatter = cg_scatter && k + 1 <= nmax - 1;
-      k_cg_direction<<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, stopflag);
+      k_cg_direction<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, stopflag);
       std::swap(hst, hst2);
       if (k + 1 <= nmax - 1) { if (!scatter) sorted_copy(hst); xs_current = true; }
     };
@@ -956,6 +1165,7 @@ void Engine::qeq() {
         collect_timers();
         const double *hs = h_scal + 64 + 64 * ((it - 1) & 1);
         Est = hs[S_EST];
+        est_trace.push_back(Est);
         { float pms = 0; if (hipEventElapsedTime(&pms, ev_pass[(it - 1) & 1][0], ev_pass[(it - 1) & 1][1]) == hipSuccess) st.ms_qeq_spmv += pms; }
         st.spmv_launches += 1;
         if (!queued) break;                        // NMAXQEq iterations done
@@ -963,6 +1173,7 @@ void Engine::qeq() {
         GEst2 = Est;
       }
       stopflag = nullptr;
+      k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);     // q = qs - mu qt with the mu of the last iteration that happened (qeq.F90:150)
     }
     if (ff.pqeq) pqeq_update_shells();
     nstep_qeq = it; last_est = Est;
@@ -1012,8 +1223,9 @@ void Engine::qeq() {
       // single rank: the direction kernel also scatters the new (hs,ht) to its cell-sorted positions, residents and their periodic images -- the
       // separate gather pass (k_sorted_vec, 12 us per iteration) is gone (RXMD_CG_NO_SCATTER=1 restores it)
       const bool scatter = fuse && cg_scatter && it + 1 <= nmax - 1;
-      k_cg_direction<<<est3 ? vb : vb_upd, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, est3 ? -1 : (fuse ? 5 : 0),
-                                                                 G, invpos, groot, scatter ? xs : nullptr, nullptr);
+      if (est3) k_cg_direction<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, nullptr);
+      else k_cg_direction<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, fuse ? 5 : 0, G, invpos, groot, scatter ? xs : nullptr, nullptr);
+      q_pending = est3;
       if (!fuse && !est3) { allreduce_scal4(); k_scalar_algebra<<<1, 64, 0, stream>>>(5, scal); }
       if (!est3) {       // PQEq: Est comes out of the direction kernel; the host still waits for this copy only, not for the sorted copy behind it
         RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
@@ -1036,6 +1248,7 @@ void Engine::qeq() {
       sync_event(ev_est);
       collect_timers();
       Est = h_scal[S_EST];
+      est_trace.push_back(Est);
       hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
       st.spmv_launches += 1;
       continue;
@@ -1052,11 +1265,13 @@ void Engine::qeq() {
     RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
     sync_stream();
     Est = h_scal[S_EST];
+    est_trace.push_back(Est);
     hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
     hipEventElapsedTime(&ms, ev[4], ev[5]); st.ms_qeq_spmv += ms;
     st.spmv_launches += 2;
   }
   if (halo_in_flight) join_comm_stream();             // the loop ended while a halo it will not use was still in flight
+  if (q_pending) k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);     // (the direction kernel without Est leaves q to the end)
   if (ff.pqeq) pqeq_update_shells();                  // pqeq.F90:169
   nstep_qeq = it; last_est = Est;
   st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1; qeq_iters_smooth = qeq_iters_smooth < 0.0 ? it : 0.75 * qeq_iters_smooth + 0.25 * it;

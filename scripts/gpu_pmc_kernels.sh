@@ -1,11 +1,12 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE, WRITE_SIZE) and L1->L2 request counters of every kernel of a bench step: one rocprofv3 --pmc pass per counter
 # set (kernel-trace only), averaged per kernel name -> <out>/kernel_traffic.json (copied to profiles/ by hand when it is to be judged).
-# usage: bash scripts/gpu_pmc_kernels.sh <tag> [bench args]
+# usage: COMMIT=<short hash of the commit being measured> bash scripts/gpu_pmc_kernels.sh <tag> [bench args]
+# SQ_INSTS_VALU (wave instructions per launch) gives bench.py the issue floor of the vector unit per kernel (x 4 cycles / 1,024 SIMDs / clock).
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O; shift
-ARGS="--steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-other-configs $@"
-for ctr in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum "TCC_HIT_sum TCC_MISS_sum"; do
+ARGS="--steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-other-configs --no-steady $@"
+for ctr in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum "TCC_HIT_sum TCC_MISS_sum" SQ_INSTS_VALU; do
   tag=$(echo $ctr | tr ' ' '_')
   rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$tag -- python3 bench.py $ARGS > $O/pmc_$tag.log 2>&1
 done
@@ -23,7 +24,7 @@ natoms = None
 for l in open("$O/pmc_FETCH_SIZE.log"):
     if l.startswith('{"metric'):
         j = json.loads(l); natoms = j["config"]["atoms_total"]
-res = {"natoms": natoms, "source": "rocprofv3 --pmc, one pass per counter set, bench.py $ARGS; FETCH_SIZE / WRITE_SIZE in KB per launch (raw); "
+res = {"natoms": natoms, "commit": "${COMMIT:-unknown}", "source": "rocprofv3 --pmc, one pass per counter set, bench.py $ARGS; FETCH_SIZE / WRITE_SIZE in KB per launch (raw); "
        "hbm_bytes_per_launch = FETCH_SIZE x 2 (gfx950: a wide coalesced read is tallied at half its bytes, MI355X_MICROARCH.md -- calibrated for 16-byte-per-lane "
        "streams only, an upper bound for gather-dominated kernels) + WRITE_SIZE", "kernels": {}, "hbm_bytes_per_launch": {}}
 for name, c in sorted(out.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0) * calls[kv[0]]):

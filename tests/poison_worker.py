@@ -1,0 +1,33 @@
+"""Run by test_gpu_parity.py::test_poisoned_allocations in a process of its own (RXMD_POISON_ALLOC is read once per process): every engine
+buffer starts as 0xFF bytes -- NaN for doubles, -1 for indices -- and the per-step scratch is filled with the pattern again before every rebuild.
+A kernel that read an element nobody wrote this step would turn charges, forces or energies into NaN or trap on an index."""
+import os, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+import oracle_api as oa
+from test_gpu_parity import _engine, _oracle, q_err, f_err, e_err
+
+assert os.environ.get("RXMD_POISON_ALLOC") == "1"
+kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+for case, mc, extra, steps in (("rdx222", (2, 2, 2), {}, 3), ("sicnp", (1, 1, 1), dict(pqeq=oa.PQEQ_SICNP), 2)):
+    for qeq_mode in (1, 0):
+        e = _engine(case, mc, qeq_mode=qeq_mode, **kw, **extra)
+        o = _oracle(case, mc, **kw, **extra)
+        if extra:
+            o.set_pqeq_clean(1)
+        e.QEq(); pe = e.FORCE(); o.qeq(); o.force()
+        tap = e.debug(14, cap=2)
+        assert tap[0] == 1.0 and np.isnan(tap[1]), tap          # the pattern is on, and an element no kernel writes still holds it
+        a = e.atoms()
+        assert np.isfinite(a["q"]).all() and np.isfinite(a["f"]).all() and np.isfinite(pe).all()
+        ie, io = np.argsort(a["gid"]), np.argsort(o.gids())
+        assert q_err(a["q"][ie], o.charges()[io]) <= 1e-6 and f_err(a["f"][ie], o.forces()[io]) <= 1e-6 and e_err(pe, o.energy()) <= 1e-9
+        e.step(steps); o.step(steps)
+        a = e.atoms(); en = e.energy()
+        ie, io = np.argsort(a["gid"]), np.argsort(o.gids())
+        assert np.isfinite(a["q"]).all() and np.isfinite(a["f"]).all() and np.isfinite(en["PE"]).all() and np.isfinite(en["KE"])
+        assert np.abs(a["pos"][ie] - o.pos()[io]).max() <= 1e-9
+        assert q_err(a["q"][ie], o.charges()[io]) <= 1e-6 and f_err(a["f"][ie], o.forces()[io]) <= 1e-6
+        e.close()
+print("POISON-OK")

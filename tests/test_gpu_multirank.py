@@ -18,9 +18,14 @@ def _port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("case,steps", [("rdx222_v211_tight", 0), ("rdx222_v222_tight", 0), ("rdx222_v222_md3", 3),
-                                        ("example2_v211_md3", 3)])        # the last: the reference's examples/2-reaxff-dc (mc 4 3 5, -v 2 1 1, 2 ranks)
-def test_vprocs_parity_vs_mpi_reference(case, steps):
+@pytest.mark.parametrize("case,steps,win", [("rdx222_v211_tight", 0, "1"), ("rdx222_v222_tight", 0, "1"), ("rdx222_v222_md3", 3, "1"), ("rdx222_v222_md3", 3, "0"),
+                                            ("example2_v211_md3", 3, "1"), ("example2_v211_md3", 3, "0")])   # example2: the reference's examples/2-reaxff-dc (mc 4 3 5, -v 2 1 1, 2 ranks)
+def test_vprocs_parity_vs_mpi_reference(case, steps, win, monkeypatch):
+    """win "1": the default window pass; "0": the wavefront-per-row pass (RXMD_SPMV_WIN=0), which keeps the iteration-count gate of 25 % it had before
+    the window pass existed.  The window pass stops the LAST step of example2 after 32 iterations where the reference's own run took 47 (its re-ordering
+    spread is 31..39 of 35 at step 0): that the earlier exit is REAL(4) noise on the relative-change test of qeq.F90:115 and not another operator is what
+    test_window_pass_and_row_pass_are_the_same_operator shows iteration by iteration on the Est trace; its gate here is wider for that reason only."""
+    monkeypatch.setenv("RXMD_SPMV_WIN", win)
     g = np.load(os.path.join(oa.GOLD, case + ".npz"))
     vp = tuple(int(x) for x in g["vprocs"]); world = vp[0] * vp[1] * vp[2]
     ctx = mp.get_context("spawn")
@@ -44,7 +49,7 @@ def test_vprocs_parity_vs_mpi_reference(case, steps):
         # re-ordering): same neighbourhood, not the same count; charges and forces above are the gate
         # (round 3: 32 against the reference's 47 in the last step of example2 with the window pass -- the relative-change test of qeq.F90:115
         #  fires by chance; the charges of that step agree to 1e-6 all the same)
-        assert abs(o["iters"] - int(g["qeq_iters"][-1])) <= 0.4 * int(g["qeq_iters"][-1])
+        assert abs(o["iters"] - int(g["qeq_iters"][-1])) <= (0.25 if win == "0" else 0.4) * int(g["qeq_iters"][-1])
         assert o["nex"] > 0 and o["nar"] > 0
 
 
@@ -56,7 +61,7 @@ def test_direct_vector_halo_vs_mpi_reference(case, steps, monkeypatch):
     the host-staged callbacks (np - 1 shifted send_recv rounds).  Same goldens of the real MPI reference as the staged halo: per-rank
     order, charges, forces, positions after 3 MD steps."""
     monkeypatch.setenv("RXMD_HALO_DIRECT", "1")
-    test_vprocs_parity_vs_mpi_reference(case, steps)
+    test_vprocs_parity_vs_mpi_reference(case, steps, "1", monkeypatch)
 
 
 @pytest.mark.parametrize("case,steps,qeq_mode", [("rdx222_v211_tight", 0, 0), ("example2_v211_md3", 3, 1)])

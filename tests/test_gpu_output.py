@@ -66,13 +66,15 @@ def test_bond_file_and_pdb_frame_written_from_engine_state_are_the_references_fi
     assert same >= 0.97 * 168, same
 
 
+@pytest.mark.parametrize("win", ["1", "0"])
 @pytest.mark.parametrize("mode,kw", [(4, dict(vsfact=0.9)), (5, dict(treq=300.0)), (7, dict(treq=300.0)), (8, dict(treq=300.0))])
-def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, tmp_path):
+def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, win, tmp_path, monkeypatch):
     """Continue the reference's own restart file (rxff.bin after 20 NVE steps) for 7 steps with velocity scaling every 3rd step, then
     RxmdEngine.write_rxff: the header as bytes (process grid, atom count, step counter 27, lattice), and every record field against
     the rxff.bin the reference wrote at the end of the same run -- normalised positions, velocities, charge, packed type+id, and the
     fictitious charges qsfp / qsfv that main.F90:67-68,98 integrates in every mode."""
     import rxmd_amd
+    monkeypatch.setenv("RXMD_SPMV_WIN", win)       # "0": the wavefront-per-row pass keeps the velocity gate it had before the window pass (1e-8)
     g = np.load(os.path.join(oa.GOLD, "rdx168_thermo%d.npz" % mode))
     ff = oa.make_system("rdx168")[0]
     lat, vp, step0, recs = oa.parse_rxff(g["restart_rxff"])
@@ -98,12 +100,14 @@ def test_checkpoint_written_from_engine_state_is_the_references_file(mode, kw, t
     assert np.abs(a[:, 0:3] - b[:, 0:3]).max() <= 1e-10                       # normalised positions (1e-9 A)
     # (velocities carry the charges' path dependence: a CG that stops one of seven steps at 54 instead of ~70 iterations leaves 1e-9 in q and
     #  1.4e-8 here; the row pass and the window pass stop at different counts, the reference's own spread under re-ordering is of this size)
-    assert np.abs(a[:, 3:6] - b[:, 3:6]).max() <= 5e-8 * np.abs(b[:, 3:6]).max()
+    assert np.abs(a[:, 3:6] - b[:, 3:6]).max() <= (1e-8 if win == "0" else 5e-8) * np.abs(b[:, 3:6]).max()
     qrms = np.sqrt((b[:, 6] ** 2).mean())
     assert (np.abs(a[:, 6] - b[:, 6]) / np.maximum(np.abs(b[:, 6]), qrms)).max() <= 1e-6
     assert (np.abs(a[:, 8] - b[:, 8]) / np.maximum(np.abs(b[:, 8]), qrms)).max() <= 1e-6
-    # qsfv += 0.5 dt Lex_w2 (q - qsfp) with 0.5 dt Lex_w2 = Lex_k / dt = 391 in the reference's time unit: the 1e-7 CG noise of the charges, amplified
-    assert np.abs(a[:, 9] - b[:, 9]).max() <= 2e-5 * np.abs(b[:, 9]).max()
+    # qsfv += 0.5 dt Lex_w2 (q - qsfp) with 0.5 dt Lex_w2 = Lex_k / dt = 391 in the reference's time unit: the truncation noise of the charges (two CG
+    # runs that each stop on a 1e-12 relative change of Est differ by 1e-9 .. 3e-9 in q, whichever pass: measured 1.8e-7 with the window pass,
+    # 7.0e-7 with the row pass in mode 4) times 391 -- an absolute gate at that size, not one relative to the largest qsfv of the frame
+    assert np.abs(a[:, 9] - b[:, 9]).max() <= 391.0 * 3e-9
 
 
 def test_device_resident_minimiser_against_the_references_line_search_and_the_oracle():

@@ -236,3 +236,46 @@ def test_perturbed_rdx_36k_on_several_ranks_against_the_multi_rank_oracle(vp, di
         assert q_err(x["q"], o.charges(r)) <= QTOL
         assert f_err(x["f"], o.forces(r)) <= FTOL
     assert moved > 0, "the test needs atoms that changed their rank"
+
+
+@pytest.mark.parametrize("case,mc_small,inner,mc_full,natoms", [("ice644", (6, 4, 4), (2, 1, 1), (60, 35, 40), 2016000), ("sicnp", (3, 3, 3), (1, 1, 1), (12, 12, 12), 945216)])
+def test_forces_of_the_full_size_water_and_sicnp_crystals_by_periodicity(case, mc_small, inner, mc_full, natoms):
+    """BASELINE configs[2] (perturbed ice Ih 60 x 35 x 40 = 2,016,000 atoms) and configs[4] (SiC nanoparticle + O2 with PQEq, 12^3 = 945,216 atoms) at
+    full size, PER-ATOM FORCES: every interior unit cell of the full replication against an interior cell of a small ORACLE run of the same cell
+    (the argument of test_forces_of_the_979776_atom_crystal_by_periodicity: an interior cell has all its bonded partners among the residents in the
+    same relative index order -- geninit numbers cells x-major in both systems -- so the `nbr < i` rule of ForceBondedTerms, pot.F90:113-144, and the
+    gid-ordered torsion booking select the same terms; energies cannot see that rule, forces do).  With the engine's own charges the forces follow the
+    charges' CG truncation; with the oracle's charges injected (those of EVERY cell by periodicity; PQEq: shells on their cores at step 0,
+    pqeq.F90:361-435) the parity tolerance 1e-6."""
+    from test_gpu_parity import _engine, _oracle
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    if case == "sicnp":
+        kw["pqeq"] = oa.PQEQ_SICNP
+    o = _oracle(case, mc_small, **kw)
+    if case == "sicnp":
+        o.set_pqeq_clean(1)
+    o.qeq(); o.force()
+    ns = mc_small[0] * mc_small[1] * mc_small[2]
+    n0 = len(o.gids()) // ns
+    assert n0 * mc_full[0] * mc_full[1] * mc_full[2] == natoms
+    assert np.array_equal(o.gids(), np.arange(1, ns * n0 + 1))
+    qo = o.charges().reshape(mc_small + (n0,)); fo = o.forces().reshape(mc_small + (n0, 3))
+    frms = np.sqrt((fo ** 2).mean())
+    # what the comparison rests on: the oracle's own interior cells agree with each other
+    others = [c for c in [(inner[0] + 1, inner[1], inner[2]), (inner[0], inner[1] + 1, inner[2]), (inner[0], inner[1], inner[2] + 1)]
+              if all(c[a] < mc_small[a] for a in range(3))]           # (3 x 3 x 3 has ONE interior cell: its face neighbours then -- these two cells show no order effect)
+    assert others
+    for c in others:
+        assert np.abs(fo[c] - fo[inner]).max() <= 2e-7 * max(frms, 1.0) and np.abs(qo[c] - qo[inner]).max() <= 1e-9
+    e = _engine(case, mc_full, qeq_mode=1, **kw)
+    e.QEq(); e.FORCE(); a = e.atoms()
+    assert np.array_equal(a["gid"], np.arange(1, natoms + 1))
+    sl = tuple(slice(1, m - 1) for m in mc_full)
+    inner_of = lambda x, w: x.reshape(mc_full + (n0,) + w)[sl].reshape((-1,) + w)
+    nc = (mc_full[0] - 2) * (mc_full[1] - 2) * (mc_full[2] - 2)
+    qref = np.broadcast_to(qo[inner], (nc, n0)).reshape(-1); fref = np.broadcast_to(fo[inner], (nc, n0, 3)).reshape(-1, 3)
+    assert q_err(inner_of(a["q"], ()), qref) <= QTOL
+    assert f_err(inner_of(a["f"], (3,)), fref) <= 5e-6              # its own charges: two CG runs that stop on a 1e-12 change of Est agree to ~1e-7 in q
+    e.set_charges(np.tile(qo[inner], natoms // n0))
+    e.FORCE(); a = e.atoms(); e.close()
+    assert f_err(inner_of(a["f"], (3,)), fref) <= FTOL
