@@ -24,80 +24,82 @@ namespace rxmd {
 
 static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
-__global__ void __launch_bounds__(256) k_cd_gather(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
+// Bond tables are compact (CSR, engine.h): bond o = boff[i] + s, its mirror image -- the same bond in the partner's list -- is brev[o].
+__global__ void __launch_bounds__(256) k_cd_gather(int G, const int *__restrict__ boff, const int *__restrict__ brev,
                                                     const double *__restrict__ cds, const double *__restrict__ cdn, double *__restrict__ cd) {
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
-  const int cnt = nbrcnt[i];
   double s = cds[i];
-  for (int t = 0; t < cnt; ++t) {
-    const size_t o = static_cast<size_t>(t) * NB + i;
-    const int j = nbr[o];
-    s += cdn[static_cast<size_t>(nbrindx[o]) * NB + j];
-  }
+  for (int o = boff[i], o1 = boff[i + 1]; o < o1; ++o) s += cdn[brev[o]];
   cd[i] = s;
 }
 
-__global__ void __launch_bounds__(256) k_ccbnd(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
-                                                const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
-                                                const double *__restrict__ A2, const double *__restrict__ A3,
-                                                const double *__restrict__ cf1, const double *__restrict__ cf2, const double *__restrict__ cf3,
-                                                const double *__restrict__ cd, double *__restrict__ cc) {
+// ccbnd and the bond forces in two steps each: ONE LANE PER BOND forms the bond's terms (every per-bond array read coalesced, the mirror bond's
+// accumulators gathered through brev), then a thread per atom adds its bonds' terms in slot order -- the order of the thread-per-atom loops these
+// replace, so cc(i) and the forces keep their bits.  (A thread per atom over the compact tables reads 13 arrays with a stride of ~5 entries
+// between neighbouring lanes: 1.6 ms for the three kernels against 1.2 ms slot-major; in this form the strided reads are the two or three term
+// arrays only.)
+__global__ void __launch_bounds__(256) k_ccbnd_terms(int nbonds, const int *__restrict__ bown, const int *__restrict__ nbr, const int *__restrict__ brev,
+                                                      const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
+                                                      const double *__restrict__ A2, const double *__restrict__ A3,
+                                                      const double *__restrict__ cf1, const double *__restrict__ cf2, const double *__restrict__ cf3,
+                                                      const double *__restrict__ cd, double *__restrict__ tu, double *__restrict__ tv) {
+  const int o = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (o >= nbonds) return;
+  const int i = bown[o], j = nbr[o], oj = brev[o];
+  const double c1 = cf1[o] + cf1[oj], c2 = cf2[o] + cf2[oj], c3 = cf3[o] + cf3[oj];
+  const double B0 = bo0[o];
+  // ForceBbo: Cbond(2) = cBO(1) A2 + (cBO(2)+cBO(3)) A3   (pot.F90:1354-1357)
+  tu[o] = (c1 * B0) * A2[o] + (c2 * bo2[o] + c3 * bo3[o]) * A3[o];
+  // ForceD(i): Cbond(2) ; ForceD(j) with j < i: Cbond(3)   (pot.F90:1262-1268, 125-138)
+  tv[o] = B0 * A2[o] * (cd[i] + ((j < i) ? cd[j] : 0.0));
+}
+__global__ void __launch_bounds__(256) k_ccbnd_sum(int G, const int *__restrict__ boff, const double *__restrict__ tu, const double *__restrict__ tv, double *__restrict__ cc) {
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
-  const int cnt = nbrcnt[i];
-  const double cdi = cd[i];
   double s = 0.0;
-  for (int t = 0; t < cnt; ++t) {
-    const size_t o = static_cast<size_t>(t) * NB + i;
-    const int j = nbr[o];
-    const size_t oj = static_cast<size_t>(nbrindx[o]) * NB + j;
-    const double c1 = cf1[o] + cf1[oj], c2 = cf2[o] + cf2[oj], c3 = cf3[o] + cf3[oj];
-    const double B0 = bo0[o];
-    // ForceBbo: Cbond(2) = cBO(1) A2 + (cBO(2)+cBO(3)) A3   (pot.F90:1354-1357)
-    s += (c1 * B0) * A2[o] + (c2 * bo2[o] + c3 * bo3[o]) * A3[o];
-    // ForceD(i): Cbond(2) ; ForceD(j) with j < i: Cbond(3)   (pot.F90:1262-1268, 125-138)
-    s += B0 * A2[o] * (cdi + ((j < i) ? cd[j] : 0.0));
-  }
+  for (int o = boff[i], o1 = boff[i + 1]; o < o1; ++o) { s += tu[o]; s += tv[o]; }
   cc[i] = s;
 }
 
-__global__ void __launch_bounds__(256) k_bond_forces(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const unsigned char *__restrict__ nbrindx,
-                                                      const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                                                      const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
-                                                      const double *__restrict__ dln2, const double *__restrict__ dln3, const double *__restrict__ dBOp,
-                                                      const double *__restrict__ A0, const double *__restrict__ A1,
-                                                      const double *__restrict__ cf1, const double *__restrict__ cf2, const double *__restrict__ cf3,
-                                                      const double *__restrict__ fnx, const double *__restrict__ fny, const double *__restrict__ fnz,
-                                                      const double *__restrict__ cd, const double *__restrict__ cc,
-                                                      double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
+__global__ void __launch_bounds__(256) k_bond_force_terms(int nbonds, const int *__restrict__ bown, const int *__restrict__ nbr, const int *__restrict__ brev,
+                                                           const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                           const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
+                                                           const double *__restrict__ dln2, const double *__restrict__ dln3, const double *__restrict__ dBOp,
+                                                           const double *__restrict__ A0, const double *__restrict__ A1,
+                                                           const double *__restrict__ cf1, const double *__restrict__ cf2, const double *__restrict__ cf3,
+                                                           const double *__restrict__ fnx, const double *__restrict__ fny, const double *__restrict__ fnz,
+                                                           const double *__restrict__ cd, const double *__restrict__ cc,
+                                                           double *__restrict__ tx, double *__restrict__ ty, double *__restrict__ tz) {
+  const int o = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (o >= nbonds) return;
+  const int i = bown[o], j = nbr[o], oj = brev[o];
+  const double c1 = cf1[o] + cf1[oj], c2 = cf2[o] + cf2[oj], c3 = cf3[o] + cf3[oj];
+  const double B0 = bo0[o], dB = dBOp[o], a1 = A1[o];
+  const double a01 = A0[o] + B0 * a1;
+  // ForceBbo Cbond(1) (pot.F90:1333-1335) + ForceD of both ends (pot.F90:1244-1246) + ccbnd of both ends (pot.F90:129-135)
+  const double cb = c1 * a01 * dB + c2 * bo2[o] * (dln2[o] + a1 * dB) + c3 * bo3[o] * (dln3[o] + a1 * dB)
+                  + (cd[i] + cd[j]) * a01 * dB + (cc[i] + cc[j]) * dB;
+  tx[o] = fnx[oj] - cb * (x[i] - x[j]);
+  ty[o] = fny[oj] - cb * (y[i] - y[j]);
+  tz[o] = fnz[oj] - cb * (z[i] - z[j]);
+}
+__global__ void __launch_bounds__(256) k_bond_force_sum(int G, const int *__restrict__ boff, const double *__restrict__ tx, const double *__restrict__ ty, const double *__restrict__ tz,
+                                                         double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
-  const int cnt = nbrcnt[i];
-  const double xi = x[i], yi = y[i], zi = z[i], cdi = cd[i], cci = cc[i];
   double f0 = fx[i], f1 = fy[i], f2 = fz[i];
-  for (int t = 0; t < cnt; ++t) {
-    const size_t o = static_cast<size_t>(t) * NB + i;
-    const int j = nbr[o];
-    const size_t oj = static_cast<size_t>(nbrindx[o]) * NB + j;
-    const double c1 = cf1[o] + cf1[oj], c2 = cf2[o] + cf2[oj], c3 = cf3[o] + cf3[oj];
-    const double B0 = bo0[o], dB = dBOp[o], a1 = A1[o];
-    const double a01 = A0[o] + B0 * a1;
-    // ForceBbo Cbond(1) (pot.F90:1333-1335) + ForceD of both ends (pot.F90:1244-1246) + ccbnd of both ends (pot.F90:129-135)
-    const double cb = c1 * a01 * dB + c2 * bo2[o] * (dln2[o] + a1 * dB) + c3 * bo3[o] * (dln3[o] + a1 * dB)
-                    + (cdi + cd[j]) * a01 * dB + (cci + cc[j]) * dB;
-    f0 += fnx[oj] - cb * (xi - x[j]);
-    f1 += fny[oj] - cb * (yi - y[j]);
-    f2 += fnz[oj] - cb * (zi - z[j]);
-  }
+  for (int o = boff[i], o1 = boff[i + 1]; o < o1; ++o) { f0 += tx[o]; f1 += ty[o]; f2 += tz[o]; }
   fx[i] = f0; fy[i] = f1; fz[i] = f2;
 }
 
 void Engine::assemble_forces() {
-  k_cd_gather<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, cds, cdn, cd);
-  k_ccbnd<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, bo0, bo2, bo3, A2, A3, cf1, cf2, cf3, cd, cc_);
-  k_bond_forces<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, pos[0], pos[1], pos[2], bo0, bo2, bo3, dln2, dln3, dBOp, A0, A1, cf1, cf2, cf3,
-                                                  fnx, fny, fnz, cd, cc_, frc[0], frc[1], frc[2]);
+  k_cd_gather<<<nblk(G, 256), 256, 0, stream>>>(G, boff, brev, cds, cdn, cd);
+  k_ccbnd_terms<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, bown, nbr, brev, bo0, bo2, bo3, A2, A3, cf1, cf2, cf3, cd, bt1, bt2);
+  k_ccbnd_sum<<<nblk(G, 256), 256, 0, stream>>>(G, boff, bt1, bt2, cc_);
+  k_bond_force_terms<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, bown, nbr, brev, pos[0], pos[1], pos[2], bo0, bo2, bo3, dln2, dln3, dBOp, A0, A1, cf1, cf2, cf3,
+                                                             fnx, fny, fnz, cd, cc_, bt1, bt2, bt3);
+  k_bond_force_sum<<<nblk(G, 256), 256, 0, stream>>>(G, boff, bt1, bt2, bt3, frc[0], frc[1], frc[2]);
 }
 
 // ------------------------------------------------------------------------------------------------

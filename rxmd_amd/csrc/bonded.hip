@@ -1,5 +1,5 @@
 // bonded.hip -- bonded energy terms of FORCE (reference src/pot.F90) as own-slot accumulation kernels.
-//   Ebond (pot.F90:926-977) + Elnpr (pot.F90:148-316) -> k_ebond_elnpr
+//   Ebond (pot.F90:926-977) + Elnpr (pot.F90:148-316) -> k_ebond_terms, k_elnpr_atoms, k_elnpr_bonds
 //   E3b   (pot.F90:319-557)                           -> k_e3b   (thread per centre atom)
 //   E4b   (pot.F90:980-1227)                          -> k_e4b   (wavefront per eight / four / two centre atoms, ballot-compacted work queue;
 //                                                                  every torsion visited from both ends)
@@ -59,37 +59,52 @@ __device__ inline void angle_forces(double coeff, const V3 &rij, double nij, con
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ebond_elnpr(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+// Ebond + Elnpr in three steps over the compact bond tables (round 4; one thread per atom looping over its bonds read nine per-bond arrays with a
+// stride of ~5 entries between neighbouring lanes: 0.81 ms):
+//   A  one lane per bond of a resident: the bond's terms of the two over-coordination sums (pot.F90:223-224), exp_coa3 * exp_coa4 of the bond as seen
+//      from i (pot.F90:484-487), and Ebond with its coefficients where gid(j) < gid(i) (pot.F90:949)
+//   B  one thread per resident: the sums in slot order (the order of the loop this replaces), the lone-pair / over- / under-coordination energies
+//      and the six coefficients every bond of the atom needs (pot.F90:226-281)
+//   C  one lane per bond of a resident: the coefficients applied to the bond (pot.F90:282-305)
+__global__ void __launch_bounds__(256) k_ebond_terms(int nb_res, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const int *__restrict__ type,
                                                       const long long *__restrict__ gid, const double *__restrict__ bo0, const double *__restrict__ bo1,
-                                                      const double *__restrict__ bo2, const double *__restrict__ bo3, const double *__restrict__ delta,
-                                                      const double *__restrict__ deltalp, const double *__restrict__ dDlp,
-                                                      double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn, double *__restrict__ ecoa, double *__restrict__ pe) {
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  double e1 = 0.0, e2 = 0.0, e3 = 0.0, e4 = 0.0;
-  if (i < N) {
-    const int ti = type[i], cnt = nbrcnt[i];
-    const DevAtomP ai = ff.atom[ti];
-    const long long iid = gid[i];
-    double sum_ovun1 = 0.0, sum_ovun2 = 0.0;
-    for (int s = 0; s < cnt; ++s) {
-      const size_t o = static_cast<size_t>(s) * NB + i;
-      const int j = nbr[o];
-      const DevBondP bp = ff.bond[ff.inxn2[ti * ff.n1 + type[j]]];
-      sum_ovun1 += bp.povun1 * bp.Desig * bo0[o];                         // pot.F90:223
-      sum_ovun2 += (delta[j] - deltalp[j]) * (bo2[o] + bo3[o]);           // pot.F90:224
-      {                                                                   // exp_coa3 * exp_coa4 of this bond as seen from i (pot.F90:484-487)
-        const double bs = bo0[o] - cutof2_esub, u = -bs + (delta[j] + ff.atom[type[j]].Val);
-        ecoa[o] = exp(-ff.pcoa3 * (u * u)) * exp(-ff.pcoa4 * ((bs - 1.5) * (bs - 1.5)));
-      }
-      if (gid[j] < iid) {                                                 // Ebond, pot.F90:949
-        const double B1 = bo1[o];
-        const double pw = pow(B1, bp.pbe2);
-        const double ex = exp(bp.pbe1 * (1.0 - pw));
-        e1 += -bp.Desig * B1 * ex - bp.Depi * bo2[o] - bp.Depipi * bo3[o];
-        const double CEbo = -bp.Desig * ex * (1.0 - bp.pbe1 * bp.pbe2 * pw);
-        cf1[o] += CEbo; cf2[o] += (-bp.Depi - CEbo); cf3[o] += (-bp.Depipi - CEbo);   // coeff = (CEbo,-Depi,-Depipi)
-      }
+                                                      const double *__restrict__ bo2, const double *__restrict__ bo3, const double *__restrict__ delta, const double *__restrict__ deltalp,
+                                                      double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ ecoa,
+                                                      double *__restrict__ t1, double *__restrict__ t2, double *__restrict__ pe) {
+  const int o = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  double e1 = 0.0;
+  if (o < nb_res) {
+    const int i = bown[o], j = nbr[o];
+    const int tj = type[j];
+    const DevBondP bp = ff.bond[ff.inxn2[type[i] * ff.n1 + tj]];
+    const double B0 = bo0[o], dj = delta[j];
+    t1[o] = bp.povun1 * bp.Desig * B0;                                  // pot.F90:223
+    t2[o] = (dj - deltalp[j]) * (bo2[o] + bo3[o]);                      // pot.F90:224
+    {                                                                   // exp_coa3 * exp_coa4 of this bond as seen from i (pot.F90:484-487)
+      const double bs = B0 - cutof2_esub, u = -bs + (dj + ff.atom[tj].Val);
+      ecoa[o] = exp(-ff.pcoa3 * (u * u)) * exp(-ff.pcoa4 * ((bs - 1.5) * (bs - 1.5)));
     }
+    if (gid[j] < gid[i]) {                                              // Ebond, pot.F90:949
+      const double B1 = bo1[o];
+      const double pw = pow(B1, bp.pbe2);
+      const double ex = exp(bp.pbe1 * (1.0 - pw));
+      e1 = -bp.Desig * B1 * ex - bp.Depi * bo2[o] - bp.Depipi * bo3[o];
+      const double CEbo = -bp.Desig * ex * (1.0 - bp.pbe1 * bp.pbe2 * pw);
+      cf1[o] += CEbo; cf2[o] += (-bp.Depi - CEbo); cf3[o] += (-bp.Depipi - CEbo);   // coeff = (CEbo,-Depi,-Depipi)
+    }
+  }
+  block_energy_add(e1, pe + 1);
+}
+
+__global__ void __launch_bounds__(256) k_elnpr_atoms(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ type, const double *__restrict__ t1, const double *__restrict__ t2,
+                                                      const double *__restrict__ delta, const double *__restrict__ deltalp, const double *__restrict__ dDlp,
+                                                      double *__restrict__ ecoef, double *__restrict__ pe) {
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  double e2 = 0.0, e3 = 0.0, e4 = 0.0;
+  if (i < N) {
+    const DevAtomP ai = ff.atom[type[i]];
+    double sum_ovun1 = 0.0, sum_ovun2 = 0.0;
+    for (int o = boff[i], o1 = boff[i + 1]; o < o1; ++o) { sum_ovun1 += t1[o]; sum_ovun2 += t2[o]; }
     const double dlp = deltalp[i], dl = delta[i], dD = dDlp[i];
     const double expvd2 = exp(-75.0 * dlp);
     const double dElp = ai.plp2 * ((1.0 + expvd2) + 75.0 * dlp * expvd2) / ((1.0 + expvd2) * (1.0 + expvd2));
@@ -114,19 +129,28 @@ __global__ void __launch_bounds__(256) k_ebond_elnpr(int N, int NB, DevFF ff, co
     const double CEu2 = -PEunder * ff.povun8 * expovun8 * d8;
     const double CEu3 = CEu1 * (1.0 - dD * d1);
     const double CEu4 = CEu1 * dlp * ff.povun4 * expovun1 * (d1 * d1) + CEu2;
-    for (int s = 0; s < cnt; ++s) {                                        // pot.F90:282-305
-      const size_t o = static_cast<size_t>(s) * NB + i;
-      const int j = nbr[o];
-      const DevBondP bp = ff.bond[ff.inxn2[ti * ff.n1 + type[j]]];
-      const double bpp = bo2[o] + bo3[o], dj = delta[j] - deltalp[j], oneD = 1.0 - dDlp[j];
-      const double CEo5 = CEo1 * bp.povun1 * bp.Desig;
-      const double CElp_b = CElp1 + CEo3 + CEo5 + CEu3;
-      const double CElp_bpp = CEo4 * dj + CEu4 * dj;
-      cf1[o] += CElp_b; cf2[o] += CElp_bpp; cf3[o] += CElp_bpp;           // coeff = CElp_b + (0,bpp,bpp)
-      cdn[o] += CEo4 * oneD * bpp + CEu4 * oneD * bpp;                     // cdbnd(j) += CElp_d
-    }
+    double *c = ecoef + 6 * static_cast<size_t>(i);
+    c[0] = CElp1; c[1] = CEo3; c[2] = CEo1; c[3] = CEu3; c[4] = CEo4; c[5] = CEu4;
   }
-  block_energy_add(e1, pe + 1); block_energy_add(e2, pe + 2); block_energy_add(e3, pe + 3); block_energy_add(e4, pe + 4);
+  block_energy_add(e2, pe + 2); block_energy_add(e3, pe + 3); block_energy_add(e4, pe + 4);
+}
+
+__global__ void __launch_bounds__(256) k_elnpr_bonds(int nb_res, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const int *__restrict__ type,
+                                                      const double *__restrict__ bo2, const double *__restrict__ bo3, const double *__restrict__ delta, const double *__restrict__ deltalp,
+                                                      const double *__restrict__ dDlp, const double *__restrict__ ecoef,
+                                                      double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn) {
+  const int o = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (o >= nb_res) return;
+  const int i = bown[o], j = nbr[o];
+  const double *c = ecoef + 6 * static_cast<size_t>(i);
+  const double CElp1 = c[0], CEo3 = c[1], CEo1 = c[2], CEu3 = c[3], CEo4 = c[4], CEu4 = c[5];
+  const DevBondP bp = ff.bond[ff.inxn2[type[i] * ff.n1 + type[j]]];
+  const double bpp = bo2[o] + bo3[o], dj = delta[j] - deltalp[j], oneD = 1.0 - dDlp[j];
+  const double CEo5 = CEo1 * bp.povun1 * bp.Desig;
+  const double CElp_b = CElp1 + CEo3 + CEo5 + CEu3;
+  const double CElp_bpp = CEo4 * dj + CEu4 * dj;
+  cf1[o] += CElp_b; cf2[o] += CElp_bpp; cf3[o] += CElp_bpp;           // coeff = CElp_b + (0,bpp,bpp)
+  cdn[o] += CEo4 * oneD * bpp + CEu4 * oneD * bpp;                     // cdbnd(j) += CElp_d
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -153,7 +177,7 @@ constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages
 // above the cut-off -- 3.5 -> 2.8 ms while the loops walked slots; once they walk set bits (below) a lane's trip count is its own
 // pair count, and the sorted order only scatters the slot-major accesses, one 64-byte line per lane: 2.7 ms sorted, 1.8 ms in atom
 // order, sorted inside tiles of 128 / 256 / 512 / 1024 atoms 1.84 / 1.97 / 2.86 / 4.19 ms.)
-__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
                                               const double *__restrict__ delta, const double *__restrict__ nlp, const double *__restrict__ dDlp,
@@ -165,13 +189,13 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
   if (tid < N) {
     const int j = tid;
-    const int tj = type[j], nj = nbrcnt[j];
+    const int tj = type[j], ob = boff[j], nj = min(boff[j + 1] - ob, 32);
     const DevAtomP aj = ff.atom[tj];
     const double xj = x[j], yj = y[j], zj = z[j];
     double sum_BO8 = 0.0, sum_SBO1 = 0.0;
     unsigned capmask = 0u;
     for (int n1 = 0; n1 < nj; ++n1) {
-      const size_t o = static_cast<size_t>(n1) * NB + j;
+      const int o = ob + n1;
       const double b = bo0[o], b2 = b * b, b4 = b2 * b2;
       sum_BO8 -= b4 * b4;                                                  // BO**8, pot.F90:362
       sum_SBO1 += bo2[o] + bo3[o];
@@ -204,7 +228,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
     for (unsigned mi = capmask; mi & (mi - 1u);) {
       const int i1 = __ffs(mi) - 1;
       mi &= mi - 1u;
-      const size_t oi = static_cast<size_t>(i1) * NB + j;
+      const int oi = ob + i1;
       const double BOij_f = bo0[oi], BOij = BOij_f - cutof2_esub;
       const int i = nbr[oi], ti = type[i];
       const V3 rij = {x[i] - xj, y[i] - yj, z[i] - zj};
@@ -212,7 +236,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
       double ai_cf = 0.0, ai_cd = 0.0, ai_fx = 0.0, ai_fy = 0.0, ai_fz = 0.0;      // the i-j bond's own sums over k1: one write after the loop
       for (unsigned mk = mi; mk; mk &= mk - 1u) {
         const int k1 = __ffs(mk) - 1;
-        const size_t ok = static_cast<size_t>(k1) * NB + j;
+        const int ok = ob + k1;
         const double BOjk_f = bo0[ok], BOjk = BOjk_f - cutof2_esub;
         if (!(BOij_f * BOjk_f > cutof2_esub)) continue;
         const int k = nbr[ok], tk = type[k];
@@ -272,7 +296,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, int NB, DevFF ff, 
     }
     if (S_d1 != 0.0 || S_v6 != 0.0 || S_v5 != 0.0)
       for (int n1 = 0; n1 < nj; ++n1) {
-        const size_t o = static_cast<size_t>(n1) * NB + j;
+        const int o = ob + n1;
         cf1[o] += S_d1 + S_v6 * ipow7(bo0[o]); cf2[o] += S_v5; cf3[o] += S_v5;
       }
     fx[j] += fself.x; fy[j] += fself.y; fz[j] += fself.z;
@@ -296,7 +320,7 @@ struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // lattice 
 // evaluating lane adding its results to the (atom, slot) accumulators in LDS (ds_add_f64): no global atomics, and the order of the
 // additions is fixed by the queue order and the lane order inside one LDS instruction.
 template <int LSL>
-__global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+__global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
                                               const double *__restrict__ etor, const double *__restrict__ econ,
@@ -306,6 +330,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   // per (atom g, slot): the bond as seen from the centre
   __shared__ double s_bo[4][64], s_et[4][64], s_ec[4][64], s_rx[4][64], s_ry[4][64], s_rz[4][64], s_rn[4][64];
   __shared__ int s_nb[4][64], s_meta[4][64];     // s_meta: type of the neighbour | its bond count << 8 | "this centre owns the bond" << 16
+  __shared__ int s_bofn[4][64];                  // first bond (CSR offset) of the neighbour in this slot: its list is bonds s_bofn .. + count
   // per (atom g, slot) as CENTRE bond k1: factors shared by all torsions around it; a bond count of 0 marks "no torsion through this bond"
   __shared__ double s_btb2[4][64], s_dfn11[4][64];
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
@@ -377,10 +402,11 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   const bool self_me = has_me && (PACK ? sl_me == nj_me : sl_me == SL - 1);   // the lane that stands for the atom itself (never a bond)
   const int tj_me = has_me ? type[j_me] : 1;
   const double xj_me = has_me ? x[j_me] : 0.0, yj_me = has_me ? y[j_me] : 0.0, zj_me = has_me ? z[j_me] : 0.0;
+  const int ob_me = has_me ? boff[j_me] : 0;      // bonds of an atom are consecutive (CSR): the lanes of this wavefront read consecutive addresses
   s_meta[w][lane] = 0;
   bool cap_me = false;
   if (sl_me < nj_me) {
-    const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
+    const int o = ob_me + sl_me;
     const int i = nbr[o], ti = type[i];
     const double rx = x[i] - xj_me, ry = y[i] - yj_me, rz = z[i] - zj_me;      // r_i - r_j
     const double b = bo0[o];
@@ -398,6 +424,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
       s_dfn11[w][lane] = (-ff.ptor3 * exp_tor3 + (ff.ptor3 * exp_tor3 - ff.ptor4 * exp_tor4) * (2.0 + exp_tor3) * exp_tor34_i) * exp_tor34_i;
       s_btb2[w][lane] = 2.0 - bo2[o] - fn11;
       meta |= (min(nbrcnt[i], 255) << 8) | (gid[j_me] < gid[i] ? 1 << 16 : 0);
+      s_bofn[w][lane] = boff[i];
     }
     s_meta[w][lane] = meta;
   }
@@ -431,7 +458,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
       const double BOjk_f = s_bo[w][sk], BOij_f = s_bo[w][si];
       const double BOjk = BOjk_f - cutof2_esub, BOij = BOij_f - cutof2_esub;
       const bool own = (mk_ >> 16) != 0;
-      const size_t ol = static_cast<size_t>(l1) * NB + k;
+      const int ol = s_bofn[w][sk] + l1;
       const int l = nbr[ol];
       const int inxn = ff.inxn4[(((s_meta[w][si] & 255) * ff.n1 + tj) * ff.n1 + tk) * ff.n1 + type[l]];
       const DevTorsP tp = ff.tors[inxn];
@@ -573,17 +600,17 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
       const int cbl = lane / KW, ks = lane % KW, r = r0 + cbl;
       double bl = 0.0;
       bool capl = false;
-      int kk = 0;
+      int bk = 0;                                   // first bond of atom k (the far end of centre bond r): its slots are bonds bk, bk + 1, ...
       if (r < ncb) {
         const int sk = s_cb[w][r] & 255;
-        kk = s_nb[w][sk];
-        if (ks < min((s_meta[w][sk] >> 8) & 255, KW == 32 ? WSLOT : KW)) { bl = bo0[static_cast<size_t>(ks) * NB + kk]; capl = bl > cutof2_esub; }
+        bk = s_bofn[w][sk];
+        if (ks < min((s_meta[w][sk] >> 8) & 255, KW == 32 ? WSLOT : KW)) { bl = bo0[bk + ks]; capl = bl > cutof2_esub; }
       }
       ml = __ballot(capl);
       if (capl) {
         const unsigned sub = static_cast<unsigned>(ml >> (cbl * KW)) & ((KW == 32) ? 0xffffffffu : 0xffffu);
         const int pos = cbl * KW + __popc(sub & ((1u << ks) - 1u));
-        const int l = nbr[static_cast<size_t>(ks) * NB + kk];
+        const int l = nbr[bk + ks];
         s_capl[w][pos] = ks; s_bokl[w][pos] = bl; s_ll[w][pos] = l; s_tl[w][pos] = type[l];
       }
     }
@@ -657,7 +684,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
   const double a_cf = s_acc[w][lane][0], a_fx = s_acc[w][lane][1], a_fy = s_acc[w][lane][2], a_fz = s_acc[w][lane][3];
   const double a_cjk1 = s_acc[w][lane][4], a_cjk2 = s_acc[w][lane][5], a_cdk = s_acc[w][lane][6];
   if (sl_me < nj_me) {
-    const size_t o = static_cast<size_t>(sl_me) * NB + j_me;
+    const int o = ob_me + sl_me;
     if (a_cf != 0.0 || a_cjk1 != 0.0) cf1[o] += a_cf + a_cjk1;
     if (a_cjk2 != 0.0) cf2[o] += a_cjk2;
     if (a_cdk != 0.0) cdn[o] += a_cdk;
@@ -679,7 +706,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, int NB, DevFF ff, 
 // ------------------------------------------------------------------------------------------------
 // Hydrogen bonds.  The lanes of a wavefront sweep the 10 A row of a donor atom i for acceptors k.
 // Hydrogen is atom type 2, hard-coded in the reference (pot.F90:595) and kept.
-__global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+__global__ void __launch_bounds__(256) k_ehb(int N, int S10, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10,
                                               const double4 *__restrict__ pk, const int *__restrict__ perm,
@@ -711,9 +738,9 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
     if (ff.nso >= 2)
       for (int t = 1; t <= ff.nso; ++t) donor_l |= (ff.inxn3hb[(ti_l * ff.n1 + 2) * ff.n1 + t] != 0);
     if (donor_l) {
-      const int cnt_l = min(nbrcnt[ia], 32);
+      const int cnt_l = min(nbrcnt[ia], 32), ob_l = boff[ia];
       for (int sl = 0; sl < cnt_l; ++sl) {
-        const size_t ol = static_cast<size_t>(sl) * NB + ia;
+        const int ol = ob_l + sl;
         if (type[nbr[ol]] == 2 && bo0[ol] > MINBO0) hslots |= 1u << sl;      // pot.F90:595
       }
     }
@@ -730,7 +757,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
       const int inx_l = (lane >= 1 && lane <= ff.nso) ? ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + lane] : 0;
       int jl = 0; double bl = 0.0;                       // lane s holds atom and bond order of slot s
       if (lane < 32 && ((hmask >> lane) & 1ULL)) {
-        const size_t ol = static_cast<size_t>(lane) * NB + i;
+        const int ol = boff[i] + lane;
         jl = nbr[ol]; bl = bo0[ol];
       }
       // The acceptor candidates of the row depend on the types only, not on the hydrogen: they are compacted once into LDS (the 64
@@ -756,7 +783,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
         wave_lds_sync();
         for (unsigned long long hm = hmask; hm; hm &= hm - 1) {
           const int s = __ffsll(static_cast<long long>(hm)) - 1;
-          const size_t o = static_cast<size_t>(s) * NB + i;
+          const int o = boff[i] + s;
           const int j = __shfl(jl, s, 64);
           const double BOij = __shfl(bl, s, 64);
           const double xj = x[j], yj = y[j], zj = z[j];
@@ -818,9 +845,11 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int NB, int S10, DevFF ff, c
 
 void Engine::bonded_energies() {
   double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
-  k_ebond_elnpr<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, dDlp, cf1, cf2, cf3, cdn, ecoa, pe_d);
+  k_ebond_terms<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, cf1, cf2, cf3, ecoa, bt1, bt2, pe_d);
+  k_elnpr_atoms<<<nblk(N, 256), 256, 0, stream>>>(N, dff, boff, type, bt1, bt2, delta, deltalp, dDlp, ecoef, pe_d);
+  k_elnpr_bonds<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, type, bo2, bo3, delta, deltalp, dDlp, ecoef, cf1, cf2, cf3, cdn);
 const bool kt3 = kt_begin(&st.ms_k_e3b);
-    k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+    k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, dff, boff, nbr, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
   kt_end(kt3);
   BoxImg bx;
@@ -837,13 +866,13 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
   const int want = std::getenv("RXMD_E4B_SLOTS") ? std::atoi(std::getenv("RXMD_E4B_SLOTS")) : 0;
   const bool narrow = h_err[2] <= 15 && want != 32 && want != 4;
   const bool kt4 = kt_begin(&st.ms_k_e4b);
-  if (want == 4) k_e4b<1><<<nblk(N, 16), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  if (want == 4) k_e4b<1><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                                        cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  else if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, dff, boff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  else if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, NB, dff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, dff, boff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                  cds, frc[0], frc[1], frc[2], pe_d, bx);
   int ehb_probe = 0;
 #ifdef RXMD_EXPERIMENTS
@@ -852,7 +881,7 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
   const int ehb_apw = (ehb_probe >> 8) ? (ehb_probe >> 8) : 16;    // = EHB_APW of k_ehb
   kt_end(kt4);
   const bool kth = kt_begin(&st.ms_k_ehb);
-  k_ehb<<<nblk(N, 4 * ehb_apw), 256, 0, stream>>>(N, NB, S10, dff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_probe);
+  k_ehb<<<nblk(N, 4 * ehb_apw), 256, 0, stream>>>(N, S10, dff, boff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_probe);
   kt_end(kth);
 }
 

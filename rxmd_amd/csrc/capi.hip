@@ -144,21 +144,20 @@ int rxmd_hip_get_bonds(rxmd_handle h, int capacity, int maxnb, int *count, long 
     if (!e.lists_valid) throw EngineError(RXMD_E_STATE, "no bond lists: call rxmd_hip_force first");
     RX_HIP(hipStreamSynchronize(e.stream));
     const int N = e.N, G = e.G;
-    std::vector<int> cnt(N), nb(static_cast<size_t>(e.MAXNB) * N);
-    std::vector<double> b(static_cast<size_t>(e.MAXNB) * N);
+    std::vector<int> off(static_cast<size_t>(N) + 1);
     std::vector<long long> g(G);
-    RX_HIP(hipMemcpy(cnt.data(), e.nbrcnt, sizeof(int) * N, hipMemcpyDeviceToHost));
+    RX_HIP(hipMemcpy(off.data(), e.boff, sizeof(int) * (static_cast<size_t>(N) + 1), hipMemcpyDeviceToHost));
     RX_HIP(hipMemcpy(g.data(), e.gid, sizeof(long long) * G, hipMemcpyDeviceToHost));
-    for (int s = 0; s < e.MAXNB; ++s) {            // the tables are slot-major with stride NB
-      RX_HIP(hipMemcpy(nb.data() + static_cast<size_t>(s) * N, e.nbr + static_cast<size_t>(s) * e.NB, sizeof(int) * N, hipMemcpyDeviceToHost));
-      RX_HIP(hipMemcpy(b.data() + static_cast<size_t>(s) * N, e.bo0 + static_cast<size_t>(s) * e.NB, sizeof(double) * N, hipMemcpyDeviceToHost));
-    }
+    const size_t nbd = static_cast<size_t>(off[N]);                 // the residents' bonds are the first boff[N] entries of the compact tables
+    std::vector<int> nb(nbd); std::vector<double> b(nbd);
+    RX_HIP(hipMemcpy(nb.data(), e.nbr, sizeof(int) * nbd, hipMemcpyDeviceToHost));
+    RX_HIP(hipMemcpy(b.data(), e.bo0, sizeof(double) * nbd, hipMemcpyDeviceToHost));
     for (int i = 0; i < N; ++i) {
-      const int c = std::min(cnt[i], e.MAXNB);
+      const int c = std::min(off[i + 1] - off[i], e.MAXNB);
       count[i] = c;
       for (int s = 0; s < c; ++s) {
-        partner_gid[static_cast<size_t>(i) * maxnb + s] = g[nb[static_cast<size_t>(s) * N + i]];
-        bo[static_cast<size_t>(i) * maxnb + s] = b[static_cast<size_t>(s) * N + i];
+        partner_gid[static_cast<size_t>(i) * maxnb + s] = g[nb[static_cast<size_t>(off[i]) + s]];
+        bo[static_cast<size_t>(i) * maxnb + s] = b[static_cast<size_t>(off[i]) + s];
       }
     }
     n = N;
@@ -492,14 +491,18 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
         n = N; if (capacity < n) throw EngineError(RXMD_E_ARG, "capacity");
         if (!e.win_valid) { for (int i = 0; i < N; ++i) out[i] = -1.0; break; }
         RX_HIP(hipStreamSynchronize(e.stream));
-        std::vector<int> c(N), rs(N), wc(e.win_groups), wk(static_cast<size_t>(e.win_groups) * rxmd::WIN_MAXUNITS);
+        const size_t nrs = static_cast<size_t>(e.win_groups) * rxmd::WIN_ROWS;
+        std::vector<int> c(N), rs(nrs), wc(e.win_groups), wk(static_cast<size_t>(e.win_groups) * rxmd::WIN_MAXUNITS);
         RX_HIP(hipMemcpy(c.data(), e.n10, sizeof(int) * N, hipMemcpyDeviceToHost));
-        RX_HIP(hipMemcpy(rs.data(), e.rows_sorted, sizeof(int) * N, hipMemcpyDeviceToHost));
+        RX_HIP(hipMemcpy(rs.data(), e.rows_sorted, sizeof(int) * nrs, hipMemcpyDeviceToHost));
         RX_HIP(hipMemcpy(wc.data(), e.win_cnt, sizeof(int) * e.win_groups, hipMemcpyDeviceToHost));
         RX_HIP(hipMemcpy(wk.data(), e.win_k, sizeof(int) * wk.size(), hipMemcpyDeviceToHost));
         std::vector<int> ent(e.S10); std::vector<unsigned short> sl(e.S10);
-        for (int r = 0; r < N; ++r) {
-          const int i = rs[r], g = r / rxmd::WIN_ROWS, cnt = c[i] & rxmd::N10_COUNT;
+        for (int i = 0; i < N; ++i) out[i] = -2.0;                 // a resident that is in no group
+        for (size_t r = 0; r < nrs; ++r) {
+          const int i = rs[r], g = static_cast<int>(r / rxmd::WIN_ROWS);
+          if (i < 0 || i >= N) continue;                           // unused row of a cell column's last group
+          const int cnt = c[i] & rxmd::N10_COUNT;
           RX_HIP(hipMemcpy(ent.data(), e.nb10 + static_cast<size_t>(i) * e.S10, sizeof(int) * cnt, hipMemcpyDeviceToHost));
           RX_HIP(hipMemcpy(sl.data(), e.sl10 + static_cast<size_t>(i) * e.S10, sizeof(unsigned short) * cnt, hipMemcpyDeviceToHost));
           int good = 0;

@@ -5,7 +5,8 @@
 //   then ghosts in exchange-stage order, reference src/comm.F90:414-446,494-518).  The force
 //   semantics depend on this order, so atoms are never physically re-sorted;
 //   spatial sorting exists only as an index permutation for the list builds.
-//   bonded tables are slot-major  [slot * NB + atom]  (coalesced for thread-per-atom kernels)
+//   bonded tables are COMPACT (CSR): bond o = boff[i] + s is slot s of atom i, its mirror image in the partner's list is brev[o]
+//   (round 4; until then slot-major [slot * NB + atom]: 30-slot strides for 5.3 bonds per atom, half-empty cache lines in every kernel)
 //   the 10 A list is row-major ELL [row * S10 + k]    (coalesced for wave-per-row kernels),
 //   S10 a multiple of 64 so that every row starts on a 512-byte boundary.
 #pragma once
@@ -134,6 +135,14 @@ __device__ inline double wave_sum64(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+#ifndef WIN_ROWS_DEF
+#define WIN_ROWS_DEF 16
+#endif
+constexpr int WIN_ROWS = WIN_ROWS_DEF;   // rows of a window group = wavefronts of a workgroup of the window pass (measured: 8 -> see DESIGN.md 3)
+constexpr int WIN_UNIT = 8;         // cell-sorted positions per window unit (8 x 16 bytes = one 128-byte line of the sorted vector)
+constexpr int WIN_MAXUNITS = 448;   // units a group's descriptor holds: 3,584 slots = 56 KB of LDS (two workgroups per CU)
+constexpr int WIN_BMW = 2048;       // 64-bit words of the coverage map the build kernel keeps in LDS: a group's positions may span 2048 x 64 x 8 = 1 M
+
 struct Engine {
   rxmd_config cfg{};
   std::string ffield_path, pqeq_path, err;
@@ -180,12 +189,19 @@ struct Engine {
   bool list_selfcheck = false;      // this list build: some box edge is shorter than two cut-offs, an atom can meet its own image
   void *cubtmp = nullptr; size_t cubtmp_bytes = 0;
   int *flags = nullptr, *scanout = nullptr;
-  // bonded tables, slot-major
-  int *nbr = nullptr, *nbrcnt = nullptr; unsigned char *nbrindx = nullptr;
+  // bonded tables, compact: boff[i] .. boff[i + 1] are the bonds of atom i (residents and ghosts) in list order; per bond its partner (nbr), its owner
+  // (bown) and its mirror image, the same bond in the partner's list (brev = the reference's nbrindx, main.F90:383-399, as a direct index)
+  int *nbr = nullptr, *nbrcnt = nullptr, *boff = nullptr, *brev = nullptr, *bown = nullptr;
+  int *nbr_sm = nullptr;          // slot-major staging of the list sweep [slot * NB + atom] (a thread appends without knowing the totals)
+  size_t bcap = 0; int nbonds = 0; // capacity of the per-bond arrays (grown on demand) / bonds of the current build
+  void alloc_bond_tables(size_t cap); void free_bond_tables();
   double *bo0 = nullptr, *bo1 = nullptr, *bo2 = nullptr, *bo3 = nullptr, *dln2 = nullptr, *dln3 = nullptr, *dBOp = nullptr;
   double *A0 = nullptr, *A1 = nullptr, *A2 = nullptr, *A3 = nullptr;
   double *cf1 = nullptr, *cf2 = nullptr, *cf3 = nullptr, *cdn = nullptr, *fnx = nullptr, *fny = nullptr, *fnz = nullptr;
   double *etor = nullptr, *econ = nullptr, *epen = nullptr, *ecoa = nullptr;   // per-bond exponentials shared by many angles/torsions
+  double *bt1 = nullptr, *bt2 = nullptr, *bt3 = nullptr;                        // per-bond scratch: terms a lane-per-bond kernel leaves for the per-atom sum behind it
+  double *ecoef = nullptr;                                                      // 6 per-atom coefficients of Elnpr (bonded.hip)
+  int nbonds_res = 0;                                                           // bonds of the residents = boff[N]: the first nbonds_res entries of the tables
   double *deltap = nullptr, *delta = nullptr, *nlp = nullptr, *dDlp = nullptr, *deltalp = nullptr;
   double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
   // 10 A list
@@ -269,6 +285,8 @@ struct Engine {
   int *win_gint = nullptr, *win_gbnd = nullptr; int win_nbnd = 0;     // multi-rank: groups without / with a row that has a ghost partner
   unsigned short *sl10 = nullptr;
   int win_groups = 0, win_maxunits = 0;
+  // upper bound of the window groups of n rows: a group holds WIN_ROWS rows of ONE cell column (x, y) of the grid, every column may end in a short group
+  size_t win_groups_bound(long long n) const { return static_cast<size_t>(n) / WIN_ROWS + static_cast<size_t>(grid.n[0]) * grid.n[1] + 1; }
   double qeq_iters_smooth = -1.0;               // running mean of the CG iterations per QEq call (the exit test of qeq.F90:114-115 lets single calls stop after two or three)
   bool win_valid = false, win_used = false;    // win_used: the last matrix pass was a window pass
   void halo_refresh(double2 *v2, double *v1);       // QCOPY1/QCOPY2: ghosts <- owners (self exchange, resolved roots)
@@ -362,13 +380,6 @@ constexpr unsigned NB10_GHOST = 1u << 30, NB10_SELF = 1u << 31;
 // n10[row] = entries of the row; bit 30: the row has a ghost partner (a boundary row of the domain).  The matrix pass needs the sums over
 // ghost columns only there (74 % of the rows of a 979,776-atom domain have none) and reads the flag with the length it needs anyway.
 constexpr int N10_GHOST_ROW = 1 << 30, N10_COUNT = N10_GHOST_ROW - 1;
-#ifndef WIN_ROWS_DEF
-#define WIN_ROWS_DEF 16
-#endif
-constexpr int WIN_ROWS = WIN_ROWS_DEF;   // rows of a window group = wavefronts of a workgroup of the window pass (measured: 8 -> see DESIGN.md 3)
-constexpr int WIN_UNIT = 8;         // cell-sorted positions per window unit (8 x 16 bytes = one 128-byte line of the sorted vector)
-constexpr int WIN_MAXUNITS = 448;   // units a group's descriptor holds: 3,584 slots = 56 KB of LDS (two workgroups per CU)
-constexpr int WIN_BMW = 2048;       // 64-bit words of the coverage map the build kernel keeps in LDS: a group's positions may span 2048 x 64 x 8 = 1 M
 
 // device error codes written by kernels into Engine::d_err
 enum { DERR_NONE = 0, DERR_MAXNB = 1, DERR_MAXN10 = 2, DERR_GRID = 3, DERR_NBRINDX = 4, DERR_TYPE = 5 };

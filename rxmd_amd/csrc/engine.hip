@@ -192,7 +192,7 @@ void Engine::collect_timers() {
 }
 
 void Engine::check_device_error(const char *where) {
-  RX_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+  RX_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int) * 16, hipMemcpyDeviceToHost, stream));
   sync_stream();
   const int e = h_err[0];
   if (e == DERR_NONE) return;
@@ -355,29 +355,37 @@ void Engine::alloc_device() {
   dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(gowner, nb); dmalloc(dh_ghost, nb); dmalloc(dh_keys, nb); dmalloc(dh_keys2, nb); dmalloc(dh_vals, nb); dmalloc(dh_off, 1100); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(invpos, nb); dmalloc(xs, nb);
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.nfine) + 2);
   dmalloc(sorted_xyzi, nb); dmalloc(sorted_type, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
-  dmalloc(nbr, ns); dmalloc(nbrcnt, nb); dmalloc(nbrindx, ns);
-  dmalloc(bo0, ns); dmalloc(bo1, ns); dmalloc(bo2, ns); dmalloc(bo3, ns); dmalloc(dln2, ns); dmalloc(dln3, ns); dmalloc(dBOp, ns);
-  dmalloc(A0, ns); dmalloc(A1, ns); dmalloc(A2, ns); dmalloc(A3, ns);
-  dmalloc(cf1, ns); dmalloc(cf2, ns); dmalloc(cf3, ns); dmalloc(cdn, ns); dmalloc(fnx, ns); dmalloc(fny, ns); dmalloc(fnz, ns);
-  dmalloc(etor, ns); dmalloc(econ, ns); dmalloc(epen, ns); dmalloc(ecoa, ns);
-  dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
+  dmalloc(nbr_sm, ns); dmalloc(nbrcnt, nb + 1); dmalloc(boff, nb + 2);
+  alloc_bond_tables(std::min<size_t>(ns, nb * 12));      // 5.3 bonds per RDX atom, ~16 in SiC: grown when a build needs more (build_ghosts_and_lists)
+  dmalloc(ecoef, 6 * nb); dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
-  { const size_t ng = (static_cast<size_t>(rows10) + WIN_ROWS - 1) / WIN_ROWS + 1;
-    dmalloc(rows_sorted, static_cast<size_t>(rows10) + WIN_ROWS); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
+  { const size_t ng = win_groups_bound(rows10) + 1;       // groups never straddle a cell column of the grid: up to one short group per column
+    dmalloc(rows_sorted, ng * WIN_ROWS); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dzalloc(scal, 80);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 192 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip)
-  dzalloc(d_err, 8);
-  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 16 * sizeof(int)));
-  h_cnt = h_err + 8;
+  dzalloc(d_err, 16);
+  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 32 * sizeof(int)));
+  h_cnt = h_err + 16;
   // hipcub scratch sized for the largest scan / sort we issue
   size_t b1 = 0, b2 = 0;
   hipcub::DeviceScan::ExclusiveSum(nullptr, b1, flags, scanout, NB + 1, stream);
   hipcub::DeviceRadixSort::SortPairs(nullptr, b2, cellid, cellid_sorted, perm_in, perm, NB, 0, 32, stream);
   cubtmp_bytes = std::max(b1, b2) + 256;
   RX_HIP(hipMalloc(&cubtmp, cubtmp_bytes));
+}
+
+void Engine::alloc_bond_tables(size_t cap) {
+  bcap = std::max<size_t>(cap, 1024);
+  dmalloc(nbr, bcap); dmalloc(brev, bcap); dmalloc(bown, bcap);
+  for (double **t : {&bo0, &bo1, &bo2, &bo3, &dln2, &dln3, &dBOp, &A0, &A1, &A2, &A3, &cf1, &cf2, &cf3, &cdn, &fnx, &fny, &fnz, &etor, &econ, &epen, &ecoa, &bt1, &bt2, &bt3}) dmalloc(*t, bcap);
+}
+void Engine::free_bond_tables() {
+  dfree(nbr); dfree(brev); dfree(bown);
+  for (double **t : {&bo0, &bo1, &bo2, &bo3, &dln2, &dln3, &dBOp, &A0, &A1, &A2, &A3, &cf1, &cf2, &cf3, &cdn, &fnx, &fny, &fnz, &etor, &econ, &epen, &ecoa, &bt1, &bt2, &bt3}) dfree(*t);
+  bcap = 0;
 }
 
 void Engine::free_device() {
@@ -388,10 +396,9 @@ void Engine::free_device() {
   dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst); dfree(hst2); dfree(tickets); dfree(sall); dfree(sgh); dfree(wall); dfree(wgh);
   dfree(gowner); dfree(dh_ghost); dfree(dh_keys); dfree(dh_keys2); dfree(dh_vals); dfree(dh_off); dfree(dh_serve);
   dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(invpos); dfree(xs); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
-  dfree(sorted_xyzi); dfree(sorted_type); dfree(flags); dfree(scanout); dfree(nbr); dfree(nbrcnt); dfree(nbrindx);
-  dfree(bo0); dfree(bo1); dfree(bo2); dfree(bo3); dfree(dln2); dfree(dln3); dfree(dBOp); dfree(A0); dfree(A1); dfree(A2); dfree(A3);
-  dfree(cf1); dfree(cf2); dfree(cf3); dfree(cdn); dfree(fnx); dfree(fny); dfree(fnz); dfree(etor); dfree(econ); dfree(epen); dfree(ecoa);
-  dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
+  dfree(sorted_xyzi); dfree(sorted_type); dfree(flags); dfree(scanout); dfree(nbr_sm); dfree(nbrcnt); dfree(boff);
+  free_bond_tables();
+  dfree(ecoef); dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(rows_int); dfree(rows_bnd); dfree(rows_sorted); dfree(win_k); dfree(win_cnt); dfree(win_gint); dfree(win_gbnd); dfree(sl10);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
@@ -1302,13 +1309,15 @@ void Engine::poison_step_scratch() {
   fill(cellid, 0, sizeof(int) * nb); fill(cellid_sorted, 0, sizeof(int) * nb); fill(perm, 0, sizeof(int) * nb); fill(perm_in, 0, sizeof(int) * nb);
   fill(cellstart, 0, sizeof(int) * (static_cast<size_t>(grid.nfine) + 2)); fill(sorted_xyzi, 0, sizeof(double4) * nb); fill(sorted_type, 0, nb);
   if (ff.pqeq) { fill(sorted_shl, 0, sizeof(double4) * nb); fill(hsc, 0, sizeof(double) * nl); fill(pqrow, 0, sizeof(double4) * rows10); for (int a = 0; a < 3; ++a) fill(shl[a], sizeof(double) * N, sizeof(double) * ng); }
-  fill(nbr, 0, sizeof(int) * ns); fill(nbrcnt, 0, sizeof(int) * nb); fill(nbrindx, 0, ns);
-  for (double *t : {bo0, bo1, bo2, bo3, dln2, dln3, dBOp, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen, ecoa}) fill(t, 0, sizeof(double) * ns);
+  fill(nbr_sm, 0, sizeof(int) * ns); fill(nbrcnt, 0, sizeof(int) * (nb + 1)); fill(boff, 0, sizeof(int) * (nb + 2));
+  fill(nbr, 0, sizeof(int) * bcap); fill(brev, 0, sizeof(int) * bcap); fill(bown, 0, sizeof(int) * bcap);
+  for (double *t : {bo0, bo1, bo2, bo3, dln2, dln3, dBOp, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen, ecoa, bt1, bt2, bt3}) fill(t, 0, sizeof(double) * bcap);
+  fill(ecoef, 0, sizeof(double) * 6 * nb);
   for (double *t : {deltap, delta, nlp, dDlp, deltalp, cds, cd, cc_}) fill(t, 0, sizeof(double) * nb);
   fill(nb10, 0, sizeof(int) * nl); fill(hess, 0, sizeof(double) * nl); fill(sl10, 0, sizeof(unsigned short) * nl); fill(n10, 0, sizeof(int) * rows10);
   fill(rows_int, 0, sizeof(int) * rows10); fill(rows_bnd, 0, sizeof(int) * rows10);
-  { const size_t ngr = (static_cast<size_t>(rows10) + WIN_ROWS - 1) / WIN_ROWS + 1;
-    fill(rows_sorted, 0, sizeof(int) * (static_cast<size_t>(rows10) + WIN_ROWS)); fill(win_k, 0, sizeof(int) * ngr * WIN_MAXUNITS); fill(win_cnt, 0, sizeof(int) * ngr);
+  { const size_t ngr = win_groups_bound(rows10) + 1;
+    fill(rows_sorted, 0, sizeof(int) * ngr * WIN_ROWS); fill(win_k, 0, sizeof(int) * ngr * WIN_MAXUNITS); fill(win_cnt, 0, sizeof(int) * ngr);
     fill(win_gint, 0, sizeof(int) * ngr); fill(win_gbnd, 0, sizeof(int) * ngr); }
   fill(sall, 0, sizeof(double2) * rows10); fill(sgh, 0, sizeof(double2) * rows10); fill(wall, 0, sizeof(double2) * rows10); fill(wgh, 0, sizeof(double2) * rows10);
   fill(partials, 0, sizeof(double) * (partials_cap + 1024));
@@ -1343,6 +1352,14 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     build_list10();
     check_device_error("list build");
   }
+  if (static_cast<size_t>(h_err[7]) > bcap) {          // more bonds than the compact tables hold: grow them and pack the lists again (the staging array is intact)
+    free_bond_tables();
+    alloc_bond_tables(static_cast<size_t>(h_err[7]) + static_cast<size_t>(h_err[7]) / 4 + 4096);
+    build_bonded_list();
+    check_device_error("bond tables");
+  }
+  nbonds = h_err[7]; nbonds_res = h_err[9];
+  win_groups = h_err[8];                               // groups of this build (build_windows; the sweep ran over the host-side bound)
   max_row10 = h_err[3]; min_row10 = std::min(h_err[4], h_err[3]);   // longest / shortest 10 A row of this build (k_list10)
   win_maxunits = h_err[5]; win_valid = win_groups > 0 && h_err[6] == 0 && win_maxunits > 0 && (!multi() || (win_nbnd >= 0 && win_nbnd <= win_groups)) && std::getenv("RXMD_SPMV_NO_WIN") == nullptr;   // window form of the matrix (build_windows)
   collect_timers();

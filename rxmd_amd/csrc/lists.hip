@@ -93,7 +93,7 @@ template <bool ORTHO>
 __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                       const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ z, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
-                                                      const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {
+                                                      const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {   // nbr: the slot-major staging array (nbr_sm)
   // squared bond cut-off of every type pair in LDS (0 = the pair has no bond row): one LDS read per candidate instead of two
   // dependent global look-ups (inxn2, then bond[inxn].rc2); and per type the largest cut-off it has with any partner
   __shared__ double s_rc2[256], s_rmax[16];
@@ -144,19 +144,24 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
   if (cnt > 15 && __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[2], cnt);
 }
 
-// nbrindx(i,i1) = j1 such that nbrlist(j,j1) == i   (main.F90:383-399)
-__global__ void k_reverse_index(int G, int NB, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, unsigned char *__restrict__ nbrindx, int *err) {
+// The sweep above leaves the lists in a slot-major staging array (slot s of atom i at s * NB + i: a thread appends without knowing the
+// totals).  This pass packs them: bond o = boff[i] + s (boff = exclusive prefix of the counts) carries its partner nbr[o], its owner bown[o] = i
+// and its MIRROR brev[o] = boff[j] + j1 with nbrlist(j, j1) == i -- the reference's nbrindx (main.F90:383-399) as a direct index into the
+// compact tables.  Every per-bond array of the engine is indexed by o: 5.3 entries per RDX atom instead of a 30-slot stride.
+__global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict__ nbr_sm, const int *__restrict__ nbrcnt, const int *__restrict__ boff,
+                           int *__restrict__ nbr, int *__restrict__ brev, int *__restrict__ bown, int *err) {
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= G) return;
-  const int ni = nbrcnt[i];
+  const int ni = nbrcnt[i], ob = boff[i];
+  if (static_cast<long long>(ob) + ni > bcap) return;             // the tables are too small for this build: the host sees boff[G] and grows them
   for (int s = 0; s < ni; ++s) {
-    const int j = nbr[static_cast<size_t>(s) * NB + i];
+    const int j = nbr_sm[static_cast<size_t>(s) * NB + i];
     const int nj = nbrcnt[j];
     int found = -1;
     for (int t = 0; t < nj; ++t)
-      if (nbr[static_cast<size_t>(t) * NB + j] == i) found = t;
+      if (nbr_sm[static_cast<size_t>(t) * NB + j] == i) found = t;
     if (found < 0) { atomicCAS(&err[0], DERR_NONE, DERR_NBRINDX); found = 0; }
-    nbrindx[static_cast<size_t>(s) * NB + i] = static_cast<unsigned char>(found);
+    nbr[ob + s] = j; brev[ob + s] = boff[j] + found; bown[ob + s] = i;
   }
 }
 
@@ -188,15 +193,13 @@ __device__ inline double wave_sum_l(double v) { return wave_sum64(v); }   // DPP
 // PQ: PQEq variant of qeq_initialize (pqeq.F90:262-353): core-core hessian from the pcc table, the shell-core matrix hsc of
 // get_hsh's Csicj term, and per row (fpqeq Eq. 30, sum_j H Z_j, sum_j hsc Z_j, shell-shell energy) -> pqrow
 // Round 4: the sweep also writes the WINDOW FORM of the matrix (engine.h WIN_*; until then a second kernel, k_win_build, re-read the entries it had
-// just written: 0.8 ms and 2.5 GB per build).  One workgroup = one window group = WIN_ROWS rows that are neighbours in CELL-SORTED order
-// (rows_sorted), one wavefront per row.  The window of a group is the union of its rows' CANDIDATE runs, known after the per-row set-up and before any
-// distance test: per absolute stencil column (x2, y2) the interval [smallest first position, largest end) over the rows, rounded to units of
-// WIN_UNIT positions -- the rows of a group share their 25 columns or straddle two neighbouring cells, so this is ~150 units of 8 (the exact
-// marking of k_win_build came to ~190: it counted a whole unit for every position some row accepted).  The columns are collected in a small LDS
-// hash table (256 entries; more distinct columns than that -- a group strung over many near-empty cells -- fails the window form for this build and
-// the row pass runs, as a window of more than WIN_MAXUNITS units always did), ordered by column id so that the numbering does not depend on which
-// wavefront came first, and an entry's 16-bit slot is  8 x (first unit of its column) + (position - first position of the column)  | ghost bit.
-constexpr int WIN_COLS = 256;           // entries of the column hash table of a group
+// just written: 0.8 ms and 2.5 GB per build).  One workgroup = one window group = WIN_ROWS residents of ONE cell column (x, y) of the grid that are
+// neighbours in cell-sorted order (rows_sorted, build_windows), one wavefront per row.  All rows of a group therefore have the SAME 25 stencil
+// columns, and the window of the group is, per stencil column, the union of the rows' CANDIDATE runs -- [smallest first position, largest end),
+// known after the per-row set-up and before any distance test -- rounded to units of WIN_UNIT positions: ~2,000 slots (the exact marking of
+// k_win_build came to ~1,500: it counted only units with an accepted position).  One barrier: every row's lanes 0..24 put their run into the
+// group's 25 intervals with LDS atomics; behind the barrier every wavefront forms the prefix of the unit counts itself.  An entry's 16-bit slot is
+// 8 x (first unit of its stencil column) + (position - first position of the column's interval) | ghost bit.
 template <bool SELFCHECK, bool PQ, bool ORTHO>
 __global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted,
@@ -213,18 +216,20 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list1
   __shared__ long long s_w[WIN_ROWS][128];      // ... and (column of the row << 40 | type << 32 | atom index): the dense phase needs no second gather of the candidate
   __shared__ int s_P[WIN_ROWS][32], s_K[WIN_ROWS][32], s_E[WIN_ROWS][32];  // per stencil column of a row: candidates before it / first sorted position of its run / its entry in the group's column table
   __shared__ int s_ix2[256];             // inxn2 row of the row's type would do; the whole (n1 x n1) table is 64-256 words
-  // the group's column table: absolute column id -> [first position, end) over the rows; then (in column order) its first window unit
-  __shared__ int t_key[WIN_COLS], t_lo[WIN_COLS], t_hi[WIN_COLS], t_ub[WIN_COLS], t_nu[WIN_COLS], t_ord[WIN_COLS];
-  __shared__ int s_fail, s_total, s_bnd;
+  // the group's 25 stencil columns: [first position, end) over the rows
+  __shared__ int t_lo[32], t_hi[32];
+  __shared__ int s_bnd;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
   for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) s_ix2[t] = ff.inxn2[t];
-  for (int t = threadIdx.x; t < WIN_COLS; t += blockDim.x) { t_key[t] = -1; t_lo[t] = 0x7fffffff; t_hi[t] = -1; }
-  if (threadIdx.x == 0) { s_fail = 0; s_total = 0; s_bnd = 0; }
+  if (threadIdx.x < 32) { t_lo[threadIdx.x] = 0x7fffffff; t_hi[threadIdx.x] = -1; }
+  if (threadIdx.x == 0) s_bnd = 0;
   __syncthreads();
   const int grp = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (grp >= err[8]) return;                  // the launch covers the host's bound of the group count; err[8] = the groups of this build (whole workgroup leaves)
   const int ridx = grp * WIN_ROWS + w;
-  const bool live = ridx < N;                 // (the last group may be short: its idle wavefronts still meet the barriers)
-  const int i = live ? rows_sorted[ridx] : 0;
+  const int i_raw = rows_sorted[ridx];
+  const bool live = i_raw < N;                // (the last group of a cell column may be short: its idle wavefronts still meet the barriers)
+  const int i = live ? i_raw : 0;
   int *sq = s_q[w];
   double *sr2 = s_r2[w];
   long long *sw = s_w[w];
@@ -302,8 +307,8 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list1
           h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
         }
         {   // window slot: the candidate's column (of this row) -> the group's table entry -> first unit of the column + offset inside it
-          const int e_ = cE[static_cast<int>((wv >> 40) & 31)];
-          sl10[row + slot] = static_cast<unsigned short>((WIN_UNIT * t_ub[e_] + (k - (t_lo[e_] & ~(WIN_UNIT - 1)))) | (j >= N ? 0x8000 : 0));
+          const int t_ = static_cast<int>((wv >> 40) & 31);
+          sl10[row + slot] = static_cast<unsigned short>((k - cE[t_]) | (j >= N ? 0x8000 : 0));     // cE: first position of the column's interval - 8 x its first unit
         }
         unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
         if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
@@ -332,65 +337,31 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list1
       const int l2 = __shfl_up(lpre, o, 64);
       if (lane >= o) lpre += l2;
     }
-    int e_ = 0;
-    if (len > 0) {                                // this row's run of column (x2, y2) joins the group's interval of that column
-      const int key = x2 * g.n[1] + y2;
-      e_ = static_cast<int>((static_cast<unsigned>(key) * 0x9E3779B1u) >> 24) & (WIN_COLS - 1);
-      int probes = 0;
-      for (; probes < WIN_COLS; ++probes) {
-        const int prev = atomicCAS(&t_key[e_], -1, key);
-        if (prev == -1 || prev == key) break;
-        e_ = (e_ + 1) & (WIN_COLS - 1);
-      }
-      if (probes == WIN_COLS) { s_fail = 1; e_ = 0; }
-      else { atomicMin(&t_lo[e_], k0); atomicMax(&t_hi[e_], k0 + len); }
-    }
-    if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; cE[lane] = e_; }
+    if (len > 0) { atomicMin(&t_lo[lane], k0); atomicMax(&t_hi[lane], k0 + len); }     // (lane < 25; every row of the group has the same stencil columns)
+    if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; }
     L = __shfl(lpre, 31, 64);
   }
   __syncthreads();
-  {   // units per column; the columns in the order of their ids (the numbering must not depend on which wavefront claimed an entry first)
-    const int t = threadIdx.x;
-    if (t < WIN_COLS) {
-      const int key = t_key[t];
-      int nu = 0, rank = 0;
-      if (key != -1) {
-        nu = (t_hi[t] - (t_lo[t] & ~(WIN_UNIT - 1)) + WIN_UNIT - 1) / WIN_UNIT;
-        for (int o = 0; o < WIN_COLS; ++o) { const int ko = t_key[o]; rank += (ko != -1 && ko < key) ? 1 : 0; }
-        t_ord[rank] = t;
+  {   // every wavefront: units per stencil column, their exclusive prefix (lanes 0..24), and what an entry's slot needs of its column
+    int lo8 = 0, nu = 0;
+    if (lane < 25 && t_hi[lane] >= 0) { lo8 = t_lo[lane] & ~(WIN_UNIT - 1); nu = (t_hi[lane] - lo8 + WIN_UNIT - 1) / WIN_UNIT; }
+    int inc = nu;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const int t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
+    const int ub = inc - nu, nunits = __shfl(inc, 31, 64);
+    if (lane < 32) cE[lane] = lo8 - WIN_UNIT * ub;                  // slot = position - cE
+    const bool fail = nunits > WIN_MAXUNITS;
+    if (w == 0) {
+      if (lane == 0) {
+        win_cnt[grp] = fail ? 0 : nunits;
+        if (fail) atomicExch(&err[6], 1);
+        if (__hip_atomic_load(&err[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) atomicMax(&err[5], nunits);
       }
-      t_nu[t] = nu;
+      if (!fail && lane < 25)
+        for (int u = 0; u < nu; ++u) win_k[static_cast<size_t>(grp) * WIN_MAXUNITS + ub + u] = lo8 + WIN_UNIT * u;
     }
   }
-  __syncthreads();
-  if (w == 0) {                                   // exclusive prefix of the units in column order: lane l takes the ordered columns 4 l .. 4 l + 3
-    int ncol = 0;
-    for (int o = lane; o < WIN_COLS; o += 64) ncol += (t_key[o] != -1) ? 1 : 0;
-    for (int o = 32; o > 0; o >>= 1) ncol += __shfl_xor(ncol, o, 64);
-    int mine[4], sum = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { const int r = 4 * lane + c; mine[c] = r < ncol ? t_nu[t_ord[r]] : 0; sum += mine[c]; }
-    int inc = sum;
-    for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
-    int run = inc - sum;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { const int r = 4 * lane + c; if (r < ncol) t_ub[t_ord[r]] = run; run += mine[c]; }
-    if (lane == 63) s_total = inc;
-  }
-  __syncthreads();
-  {
-    const int nunits = s_total;
-    const bool fail = s_fail != 0 || nunits > WIN_MAXUNITS;
-    if (threadIdx.x == 0) {
-      win_cnt[grp] = fail ? 0 : nunits;
-      if (fail) atomicExch(&err[6], 1);
-      if (__hip_atomic_load(&err[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) atomicMax(&err[5], nunits);
-    }
-    if (!fail && threadIdx.x < WIN_COLS && t_key[threadIdx.x] != -1) {
-      const int lo8 = t_lo[threadIdx.x] & ~(WIN_UNIT - 1), ub = t_ub[threadIdx.x], nu = t_nu[threadIdx.x];
-      for (int u = 0; u < nu; ++u) win_k[static_cast<size_t>(grp) * WIN_MAXUNITS + ub + u] = lo8 + WIN_UNIT * u;
-    }
-  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #ifdef RXMD_EXPERIMENTS
   if (g.probe == 1) { if (lane == 0) n10[i] = L; return; }
 #endif
@@ -480,9 +451,22 @@ __global__ void k_resident_flags(int G, int N, const int *__restrict__ perm, int
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k <= G) flag[k] = (k < G && perm[k] < N) ? 1 : 0;
 }
-__global__ void k_rows_sorted(int G, int N, const int *__restrict__ perm, const int *__restrict__ rank, int *__restrict__ rows_sorted) {
+// Window groups never straddle a cell column (x, y) of the grid: the rows of a group then share their 25 stencil columns, and what each of those
+// contributes to the group's window is ONE short z-interval.  (A group that ran over into the next cell column held rows from the top of one
+// column and the bottom of the next: the union interval of a shared stencil column covered the whole box height.)  Per column: groups =
+// ceil(residents / WIN_ROWS); rows_sorted is laid out by groups, the unused rows of a column's last group hold a sentinel >= N.
+__global__ void k_col_groups(int ncol, int nzf, const int *__restrict__ cellstart, const int *__restrict__ rank, int *__restrict__ colg) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > ncol) return;
+  colg[c] = c < ncol ? (rank[cellstart[(c + 1) * nzf]] - rank[cellstart[c * nzf]] + WIN_ROWS - 1) / WIN_ROWS : 0;
+}
+__global__ void k_rows_sorted(int G, int N, int nzf, const int *__restrict__ perm, const int *__restrict__ rank, const int *__restrict__ cid_sorted, const int *__restrict__ cellstart,
+                              const int *__restrict__ colgo, int *__restrict__ rows_sorted) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < G && perm[k] < N) rows_sorted[rank[k]] = perm[k];
+  if (k >= G || perm[k] >= N) return;
+  const int c = cid_sorted[k] / nzf;
+  const int r = rank[k] - rank[cellstart[c * nzf]];              // this resident's place among the residents of its column
+  rows_sorted[(colgo[c] + r / WIN_ROWS) * WIN_ROWS + (r % WIN_ROWS)] = perm[k];
 }
 __global__ void k_split_groups(int ng, const int *__restrict__ flag, const int *__restrict__ scan, int *__restrict__ g_int, int *__restrict__ g_bnd) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -495,17 +479,30 @@ void Engine::build_windows() {
   k_resident_flags<<<nblk(G + 1, 256), 256, 0, stream>>>(G, N, perm, flags2);
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, G + 1, stream));
-  k_rows_sorted<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, scanout2, rows_sorted);
+  const int ncol = grid.n[0] * grid.n[1];
+  k_col_groups<<<nblk(ncol + 1, 256), 256, 0, stream>>>(ncol, grid.nzf, cellstart, scanout2, flags);     // (flags / scanout: free until the sweep writes its row flags)
+  tb = cubtmp_bytes;
+  RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, ncol + 1, stream));
+  RX_HIP(hipMemcpyAsync(d_err + 8, scanout + ncol, sizeof(int), hipMemcpyDeviceToDevice, stream));         // groups of this build: the sweep's workgroups beyond it leave at once; the host reads it with the error word
+  win_groups = static_cast<int>(win_groups_bound(N));                                                         // until then: the bound (launch size of the sweep)
+  RX_HIP(hipMemsetAsync(rows_sorted, 0x7f, sizeof(int) * static_cast<size_t>(win_groups) * WIN_ROWS, stream));   // 0x7f7f7f7f >= N: not a row
+  k_rows_sorted<<<nblk(G, 256), 256, 0, stream>>>(G, N, grid.nzf, perm, scanout2, cellid_sorted, cellstart, scanout, rows_sorted);
   RX_HIP(hipMemsetAsync(d_err + 5, 0, 2 * sizeof(int), stream));
-  win_groups = (N + WIN_ROWS - 1) / WIN_ROWS;
+  RX_HIP(hipMemsetAsync(win_cnt, 0, sizeof(int) * static_cast<size_t>(win_groups), stream));               // (groups between the count and the bound: empty windows)
+  if (multi()) RX_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * (static_cast<size_t>(win_groups) + 1), stream));   // ... and interior (the resident flags are used up)
 }
 
 void Engine::build_bonded_list() {
   k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi, sorted_type);
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
-  if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
-  else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr, nbrcnt, d_err);
-  k_reverse_index<<<nblk(G, 256), 256, 0, stream>>>(G, NB, nbr, nbrcnt, nbrindx, d_err);
+  if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
+  else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
+  RX_HIP(hipMemsetAsync(nbrcnt + G, 0, sizeof(int), stream));                       // (G < NB always: the scan below runs over G + 1 counts)
+  size_t tb = cubtmp_bytes;
+  RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, nbrcnt, boff, G + 1, stream));
+  RX_HIP(hipMemcpyAsync(d_err + 7, boff + G, sizeof(int), hipMemcpyDeviceToDevice, stream));   // bonds of this build: read with the error word the host waits for anyway
+  RX_HIP(hipMemcpyAsync(d_err + 9, boff + N, sizeof(int), hipMemcpyDeviceToDevice, stream));   // ... and the residents' share of them
+  k_bond_csr<<<nblk(G, 256), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, d_err);
 }
 
 void Engine::build_list10() {
@@ -519,7 +516,7 @@ void Engine::build_list10() {
   list_selfcheck = selfcheck;
 #define RX_LIST10(SC, PQF) do { if (grid.ortho) RX_LIST10_O(SC, PQF, true); else RX_LIST10_O(SC, PQF, false); } while (0)
 #define RX_LIST10_O(SC, PQF, OR)                                                                                                               \
-  k_list10<SC, PQF, OR><<<nblk(N, WIN_ROWS), 64 * WIN_ROWS, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
+  k_list10<SC, PQF, OR><<<std::max(win_groups, 1), 64 * WIN_ROWS, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
                                                     nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr, \
                                                     rows_sorted, sl10, win_k, win_cnt, gflag)
   win_valid = false;

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_nonbond_win(int N, int G, 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int grp = xcd_swizzle(blockIdx.x, gridDim.x);
   const int ridx = grp * WIN_ROWS + w;
-  const int i = ridx < N ? rows_sorted[ridx] : N;
+  const int i = min(rows_sorted[ridx], N);          // (sentinel >= N: an unused row of a cell column's last group)
   const int nslots = WIN_UNIT * win_cnt[grp];
   const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
   for (int t = threadIdx.x; t < nslots; t += NT) {
@@ -195,9 +195,10 @@ void Engine::nonbonded() {
   // over the windows of the matrix pass when this list build has them and no atom can meet its own image (RXMD_NONBOND_WIN=0: the row form)
   static const bool win_env = std::getenv("RXMD_NONBOND_WIN") == nullptr || std::atoi(std::getenv("RXMD_NONBOND_WIN")) != 0;
   const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * (sizeof(double4) + 1) + 16;
-  if (win_valid && win_env && !list_selfcheck && lds <= 72 * 1024) {
+  if (win_valid && win_env && !list_selfcheck && lds <= 120 * 1024) {     // (two workgroups per CU up to ~79 KB = 300 units; above that one)
     k_nonbond_win<<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, n10, rows_sorted, win_k, win_cnt, win_maxunits, sorted_xyzi, sorted_type, pos[0], pos[1], pos[2], q, type,
                                                              frc[0], frc[1], frc[2], scal + 32);
+    RX_HIP(hipGetLastError());
     return;
   }
   k_nonbond<<<nblk(N, NB_WPB), 64 * NB_WPB, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, pos[0], pos[1], pos[2], q, type, frc[0], frc[1], frc[2], scal + 32);

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   // Round trip 1: everything that needs only the group number -- the row of this wavefront, the window's size, the first positions of the
   // window units this thread will copy (two rounds of 1,024 slots cover 256 units; the descriptor row is WIN_MAXUNITS long whatever the count).
   const int ridx = grp * WIN_ROWS + wave;
-  const int row = ridx < N ? rows_sorted[ridx] : N;
+  const int row = min(rows_sorted[ridx], N);        // (a cell column's last group may be short: those slots hold a sentinel >= N)
   const int nslots = WIN_UNIT * win_cnt[grp];
   const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
   const int t0 = threadIdx.x, t1 = threadIdx.x + NT;
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win2(int N, int G, in
   const int grp = grouplist ? (gidx < ngroups ? grouplist[gidx] : -1) : (gidx < ngroups ? gidx : -1);
   if (grp < 0) return;
   const int ridx = grp * WIN_ROWS + wave;
-  const bool live = ridx < N;
+  const bool live = rows_sorted[ridx] < N;
   const size_t base = static_cast<size_t>(live ? ridx : 0) * S10;
   const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
   const d2v *cv2 = reinterpret_cast<const d2v *>((PQ ? hsc : hess) + base);
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win2(int N, int G, in
     if (PQ && (MODE == MODE_GRAD || STORE)) { if (live && k < S10) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); c[u] = make_double2(t2.x, t2.y); } else c[u] = make_double2(0.0, 0.0); }
   }
   // wave-uniform descriptors: scalar loads
-  const int row = live ? rows_sorted[ridx] : N;
+  const int row = min(rows_sorted[ridx], N);
   const int nslots = WIN_UNIT * win_cnt[grp];
   const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
   int ua[8], ub[8];
