@@ -192,16 +192,57 @@ __device__ inline double wave_sum_l(double v) { return wave_sum64(v); }   // DPP
 // instead of 64 scattered ones.  Bits: see NB10_* in engine.h.
 // PQ: PQEq variant of qeq_initialize (pqeq.F90:262-353): core-core hessian from the pcc table, the shell-core matrix hsc of
 // get_hsh's Csicj term, and per row (fpqeq Eq. 30, sum_j H Z_j, sum_j hsc Z_j, shell-shell energy) -> pqrow
-// Round 4: the sweep also writes the WINDOW FORM of the matrix (engine.h WIN_*; until then a second kernel, k_win_build, re-read the entries it had
-// just written: 0.8 ms and 2.5 GB per build).  One workgroup = one window group = WIN_ROWS residents of ONE cell column (x, y) of the grid that are
-// neighbours in cell-sorted order (rows_sorted, build_windows), one wavefront per row.  All rows of a group therefore have the SAME 25 stencil
-// columns, and the window of the group is, per stencil column, the union of the rows' CANDIDATE runs -- [smallest first position, largest end),
-// known after the per-row set-up and before any distance test -- rounded to units of WIN_UNIT positions: ~2,000 slots (the exact marking of
-// k_win_build came to ~1,500: it counted only units with an accepted position).  One barrier: every row's lanes 0..24 put their run into the
-// group's 25 intervals with LDS atomics; behind the barrier every wavefront forms the prefix of the unit counts itself.  An entry's 16-bit slot is
-// 8 x (first unit of its stencil column) + (position - first position of the column's interval) | ghost bit.
+// Round 4: the sweep also writes the WINDOW FORM of the matrix (engine.h WIN_*; until then a second kernel, k_win_build, re-read the entries the
+// sweep had just written: 0.8 ms and 2.5 GB per build).  A window group = WIN_ROWS residents of ONE cell column (x, y) of the grid that are
+// neighbours in cell-sorted order (rows_sorted, build_windows): all rows of a group have the SAME 25 stencil columns, and the window of the group
+// is, per stencil column, the union of the rows' CANDIDATE runs -- [smallest first position, largest end), known from the per-row set-up before
+// any distance test -- rounded to units of WIN_UNIT positions: ~2,000 slots (the exact marking of k_win_build came to ~1,500: it counted only
+// units with an accepted position).  k_win_columns (one workgroup per group, one wavefront per row) does that set-up once: it leaves every row's
+// 25 runs for the sweep (rowcols), the group's unit list (win_k, win_cnt) and per stencil column what an entry's slot needs (grp_base = first
+// position of the interval - 8 x its first unit): slot = position - grp_base | ghost bit.  The sweep itself stays four rows per workgroup
+// with no barrier: as ONE kernel of 16-wavefront workgroups it lost 0.8 ms to wavefront slots that idle until the last row of a group is done.
+template <bool ORTHO>
+__global__ void __launch_bounds__(64 * WIN_ROWS) k_win_columns(int N, Grid g, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+                                                               const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz, double rcp,
+                                                               const int *__restrict__ rows_sorted, int *__restrict__ rowcols, int *__restrict__ grp_base,
+                                                               int *__restrict__ win_k, int *__restrict__ win_cnt, int *err) {
+  __shared__ int t_lo[32], t_hi[32];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int grp = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (grp >= err[8]) return;                  // the launch covers the host's bound of the group count; err[8] = the groups of this build (whole workgroup leaves)
+  if (threadIdx.x < 32) { t_lo[threadIdx.x] = 0x7fffffff; t_hi[threadIdx.x] = -1; }
+  __syncthreads();
+  const int ridx = grp * WIN_ROWS + w;
+  const int i = rows_sorted[ridx];
+  if (i < N) {                                // (the last group of a cell column may be short)
+    const int c = cellid[i];
+    const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
+    int k0 = 0, len = 0;
+    if (lane < 25) column_run<ORTHO>(g, cellstart, spx[i], spy[i], spz[i], cx, cy, cx + lane / 5 - 2, cy + lane % 5 - 2, rcp, k0, len);
+    if (len > 0) { atomicMin(&t_lo[lane], k0); atomicMax(&t_hi[lane], k0 + len); }
+    if (lane < 32) { rowcols[static_cast<size_t>(ridx) * 64 + lane] = k0; rowcols[static_cast<size_t>(ridx) * 64 + 32 + lane] = len; }
+  }
+  __syncthreads();
+  if (w != 0) return;
+  int lo8 = 0, nu = 0;                         // units per stencil column and their exclusive prefix (lanes 0..24)
+  if (lane < 25 && t_hi[lane] >= 0) { lo8 = t_lo[lane] & ~(WIN_UNIT - 1); nu = (t_hi[lane] - lo8 + WIN_UNIT - 1) / WIN_UNIT; }
+  int inc = nu;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) { const int t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
+  const int ub = inc - nu, nunits = __shfl(inc, 31, 64);
+  if (lane < 32) grp_base[static_cast<size_t>(grp) * 32 + lane] = lo8 - WIN_UNIT * ub;
+  const bool fail = nunits > WIN_MAXUNITS;
+  if (lane == 0) {
+    win_cnt[grp] = fail ? 0 : nunits;
+    if (fail) atomicExch(&err[6], 1);
+    if (__hip_atomic_load(&err[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) atomicMax(&err[5], nunits);
+  }
+  if (!fail && lane < 25)
+    for (int u = 0; u < nu; ++u) win_k[static_cast<size_t>(grp) * WIN_MAXUNITS + ub + u] = lo8 + WIN_UNIT * u;
+}
+
 template <bool SELFCHECK, bool PQ, bool ORTHO>
-__global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+__global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted,
                                                  const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                  const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz,
@@ -210,26 +251,23 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list1
                                                  const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
                                                  double *__restrict__ hsc, double4 *__restrict__ pqrow,
                                                  const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag,
-                                                 const int *__restrict__ rows_sorted, unsigned short *__restrict__ sl10, int *__restrict__ win_k, int *__restrict__ win_cnt, int *__restrict__ gflag) {
-  __shared__ int s_q[WIN_ROWS][128];            // accepted candidates: sorted position ...
-  __shared__ double s_r2[WIN_ROWS][128];        // ... their squared distance (the exact FP64 value of the test) ...
-  __shared__ long long s_w[WIN_ROWS][128];      // ... and (column of the row << 40 | type << 32 | atom index): the dense phase needs no second gather of the candidate
-  __shared__ int s_P[WIN_ROWS][32], s_K[WIN_ROWS][32], s_E[WIN_ROWS][32];  // per stencil column of a row: candidates before it / first sorted position of its run / its entry in the group's column table
+                                                 const int *__restrict__ rows_sorted, unsigned short *__restrict__ sl10, const int *__restrict__ rowcols, const int *__restrict__ grp_base, int *__restrict__ gflag) {
+  __shared__ int s_q[4][128];            // accepted candidates: sorted position ...
+  __shared__ double s_r2[4][128];        // ... their squared distance (the exact FP64 value of the test) ...
+  __shared__ long long s_w[4][128];      // ... and (column of the row << 40 | type << 32 | atom index): the dense phase needs no second gather of the candidate
+  __shared__ int s_P[4][32], s_K[4][32], s_E[4][32];  // per stencil column of a row: candidates before it / first sorted position of its run / slot base of the column in the group's window
   __shared__ int s_ix2[256];             // inxn2 row of the row's type would do; the whole (n1 x n1) table is 64-256 words
-  // the group's 25 stencil columns: [first position, end) over the rows
-  __shared__ int t_lo[32], t_hi[32];
-  __shared__ int s_bnd;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
   for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) s_ix2[t] = ff.inxn2[t];
-  if (threadIdx.x < 32) { t_lo[threadIdx.x] = 0x7fffffff; t_hi[threadIdx.x] = -1; }
-  if (threadIdx.x == 0) s_bnd = 0;
   __syncthreads();
-  const int grp = xcd_swizzle(blockIdx.x, gridDim.x);
-  if (grp >= err[8]) return;                  // the launch covers the host's bound of the group count; err[8] = the groups of this build (whole workgroup leaves)
-  const int ridx = grp * WIN_ROWS + w;
-  const int i_raw = rows_sorted[ridx];
-  const bool live = i_raw < N;                // (the last group of a cell column may be short: its idle wavefronts still meet the barriers)
-  const int i = live ? i_raw : 0;
+  // rows in the order of the window groups (cell-sorted: the four rows of a workgroup test nearly the same candidates); the launch covers the
+  // host's bound of the group count, err[8] = the groups of this build
+  const int ridx = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
+  if (ridx >= err[8] * WIN_ROWS) return;
+  const int i = rows_sorted[ridx];
+  if (i >= N) return;                         // unused row of a cell column's last group
+  const int grp = ridx / WIN_ROWS;
+  constexpr bool live = true;
   int *sq = s_q[w];
   double *sr2 = s_r2[w];
   long long *sw = s_w[w];
@@ -327,39 +365,17 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list1
 
   // the 25 stencil columns: lane t < 25 owns column t; an inclusive scan over the lanes lays the runs end to end
   int L;
-  {
-    int k0 = 0, len = 0;
-    const int x2 = cx + lane / 5 - 2, y2 = cy + lane % 5 - 2;
-    if (live && lane < 25) column_run<ORTHO>(g, cellstart, spx[i], spy[i], spz[i], cx, cy, x2, y2, ff.rctap_pad, k0, len);
+  {   // the row's 25 candidate runs and the slot bases of its group's stencil columns, as k_win_columns left them
+    int k0 = 0, len = 0, gb = 0;
+    if (lane < 32) { k0 = rowcols[static_cast<size_t>(ridx) * 64 + lane]; len = rowcols[static_cast<size_t>(ridx) * 64 + 32 + lane]; gb = grp_base[static_cast<size_t>(grp) * 32 + lane]; }
     int lpre = len;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {
       const int l2 = __shfl_up(lpre, o, 64);
       if (lane >= o) lpre += l2;
     }
-    if (len > 0) { atomicMin(&t_lo[lane], k0); atomicMax(&t_hi[lane], k0 + len); }     // (lane < 25; every row of the group has the same stencil columns)
-    if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; }
+    if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; cE[lane] = gb; }
     L = __shfl(lpre, 31, 64);
-  }
-  __syncthreads();
-  {   // every wavefront: units per stencil column, their exclusive prefix (lanes 0..24), and what an entry's slot needs of its column
-    int lo8 = 0, nu = 0;
-    if (lane < 25 && t_hi[lane] >= 0) { lo8 = t_lo[lane] & ~(WIN_UNIT - 1); nu = (t_hi[lane] - lo8 + WIN_UNIT - 1) / WIN_UNIT; }
-    int inc = nu;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) { const int t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
-    const int ub = inc - nu, nunits = __shfl(inc, 31, 64);
-    if (lane < 32) cE[lane] = lo8 - WIN_UNIT * ub;                  // slot = position - cE
-    const bool fail = nunits > WIN_MAXUNITS;
-    if (w == 0) {
-      if (lane == 0) {
-        win_cnt[grp] = fail ? 0 : nunits;
-        if (fail) atomicExch(&err[6], 1);
-        if (__hip_atomic_load(&err[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nunits) atomicMax(&err[5], nunits);
-      }
-      if (!fail && lane < 25)
-        for (int u = 0; u < nu; ++u) win_k[static_cast<size_t>(grp) * WIN_MAXUNITS + ub + u] = lo8 + WIN_UNIT * u;
-    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #ifdef RXMD_EXPERIMENTS
@@ -430,13 +446,9 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, (PQ || !ORTHO) ? 4 : 8) k_list1
     // read with the error word the host waits for anyway).  One atomic per new maximum, not per row.
     if (__hip_atomic_load(&err[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[3], cnt);
     if (__hip_atomic_load(&err[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cnt) atomicMin(&err[4], cnt);     // ... and the shortest
-    if (mg != 0ULL) s_bnd = 1;                    // (every writer writes 1)
+    if (gflag && mg != 0ULL) gflag[grp] = 1;      // multi-rank: a group with a row that has a ghost partner waits for the vector halo (every writer writes 1; cleared by build_windows)
   }
   }   // live
-  if (gflag) {                                    // multi-rank: a group with a row that has a ghost partner waits for the vector halo (the pass's second launch)
-    __syncthreads();
-    if (threadIdx.x == 0) gflag[grp] = s_bnd;
-  }
 }
 
 // boundary rows keep their order, interior rows too: index lists for the two launches of the matrix pass
@@ -516,13 +528,15 @@ void Engine::build_list10() {
   list_selfcheck = selfcheck;
 #define RX_LIST10(SC, PQF) do { if (grid.ortho) RX_LIST10_O(SC, PQF, true); else RX_LIST10_O(SC, PQF, false); } while (0)
 #define RX_LIST10_O(SC, PQF, OR)                                                                                                               \
-  k_list10<SC, PQF, OR><<<std::max(win_groups, 1), 64 * WIN_ROWS, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
+  k_list10<SC, PQF, OR><<<std::max(win_groups, 1) * (WIN_ROWS / 4), 256, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
                                                     nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr, \
-                                                    rows_sorted, sl10, win_k, win_cnt, gflag)
+                                                    rows_sorted, sl10, rowcols, grp_base, gflag)
   win_valid = false;
   build_windows();
   int *gflag = multi() ? flags2 : nullptr;           // (the resident flags are used up)
   const bool kt10 = kt_begin(&st.ms_k_list10);
+  if (grid.ortho) k_win_columns<true><<<std::max(win_groups, 1), 64 * WIN_ROWS, 0, stream>>>(N, grid, cellid, cellstart, spos[0], spos[1], spos[2], dff.rctap_pad, rows_sorted, rowcols, grp_base, win_k, win_cnt, d_err);
+  else k_win_columns<false><<<std::max(win_groups, 1), 64 * WIN_ROWS, 0, stream>>>(N, grid, cellid, cellstart, spos[0], spos[1], spos[2], dff.rctap_pad, rows_sorted, rowcols, grp_base, win_k, win_cnt, d_err);
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
   kt_end(kt10);
