@@ -170,6 +170,9 @@ constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages
 #ifndef E3B_MINB
 #define E3B_MINB 2
 #endif
+#ifndef E3B_CAP
+#define E3B_CAP 448     // bonds of a wavefront's 64 atoms whose accumulators k_e3b keeps in LDS (RDX: ~340 per wavefront; 4 x 5 x 448 x 8 B = 70 KB per workgroup)
+#endif
 #ifndef E4B_MINB
 #define E4B_MINB 3
 #endif
@@ -186,6 +189,21 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const in
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
   const int tid = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;   // an XCD's workgroups own one contiguous eighth of the atoms: the neighbours they gather stay in its L2
+  // Round 4: the five accumulators of the bonds of a wavefront's 64 atoms -- one contiguous stretch of the compact tables -- live in LDS while the
+  // angles are walked.  Every angle adds to the j-k bond's coefficient, cdbnd term and neighbour force: five read-modify-writes of global memory per
+  // angle, each a dependent round trip inside the loop (the compiler must assume that a later iteration hits the same bond).  The stretch is loaded
+  // with the values the earlier kernels left (coalesced), updated in LDS by the thread that owns the atom (no atomics: a thread touches only its own
+  // bonds), and stored back at the end: the same additions in the same order, bit for bit.  Bonds beyond E3B_CAP of a wavefront (SiC: 16 bonds per
+  // atom) take the global path as before.
+  extern __shared__ double s_e3b[];
+  const int lane_ = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  double *l_cf = s_e3b + static_cast<size_t>(wv_) * 5 * E3B_CAP, *l_cd = l_cf + E3B_CAP, *l_fx = l_cd + E3B_CAP, *l_fy = l_fx + E3B_CAP, *l_fz = l_fy + E3B_CAP;
+  const int a0_ = tid - lane_;                                     // first atom of this wavefront
+  const int ob_w = a0_ < N ? boff[a0_] : 0, oe_w = a0_ < N ? boff[min(a0_ + 64, N)] : 0;
+  const int nst = min(oe_w - ob_w, E3B_CAP);                       // staged bonds
+  for (int t = lane_; t < nst; t += 64) { l_cf[t] = cf1[ob_w + t]; l_cd[t] = cdn[ob_w + t]; l_fx[t] = fnx[ob_w + t]; l_fy[t] = fny[ob_w + t]; l_fz[t] = fnz[ob_w + t]; }
+  wave_lds_sync();
+  auto acc1 = [&](double *__restrict__ gl, double *ld, int o, double v) { const int r = o - ob_w; if (r < nst) ld[r] += v; else gl[o] += v; };
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
   if (tid < N) {
     const int j = tid;
@@ -281,26 +299,28 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const in
         const double CEcoa4 = -2.0 * ff.pcoa3 * ui * PEcoa, CEcoa5 = -2.0 * ff.pcoa3 * uk * PEcoa;
         // accumulate, pot.F90:509-541
         ai_cf += CEpen2 + CEcoa1 - CEcoa4 + CEval1;        // ForceB on bond i-j
-        cf1[ok] += CEpen3 + CEcoa2 - CEcoa5 + CEval2;      // ForceB on bond j-k
+        acc1(cf1, l_cf, ok, CEpen3 + CEcoa2 - CEcoa5 + CEval2);      // ForceB on bond j-k
         S_d1 += CEpen1 + CEcoa3 + CEval3 + CEval7; S_v6 += CEval6; S_v5 += CEval5;
-        ai_cd += CEcoa4; cdn[ok] += CEcoa5;                // cdbnd(i), cdbnd(k)
+        ai_cd += CEcoa4; acc1(cdn, l_cd, ok, CEcoa5);      // cdbnd(i), cdbnd(k)
         V3 fi, fk;
         angle_forces(CEval8, rij, nij, rjk, njk, fi, fk);
         ai_fx += fi.x; ai_fy += fi.y; ai_fz += fi.z;
-        fnx[ok] += fk.x; fny[ok] += fk.y; fnz[ok] += fk.z;
+        acc1(fnx, l_fx, ok, fk.x); acc1(fny, l_fy, ok, fk.y); acc1(fnz, l_fz, ok, fk.z);
         fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z;
       }
-      if (ai_cf != 0.0) cf1[oi] += ai_cf;
-      if (ai_cd != 0.0) cdn[oi] += ai_cd;
-      if (ai_fx != 0.0 || ai_fy != 0.0 || ai_fz != 0.0) { fnx[oi] += ai_fx; fny[oi] += ai_fy; fnz[oi] += ai_fz; }
+      if (ai_cf != 0.0) acc1(cf1, l_cf, oi, ai_cf);
+      if (ai_cd != 0.0) acc1(cdn, l_cd, oi, ai_cd);
+      if (ai_fx != 0.0 || ai_fy != 0.0 || ai_fz != 0.0) { acc1(fnx, l_fx, oi, ai_fx); acc1(fny, l_fy, oi, ai_fy); acc1(fnz, l_fz, oi, ai_fz); }
     }
     if (S_d1 != 0.0 || S_v6 != 0.0 || S_v5 != 0.0)
       for (int n1 = 0; n1 < nj; ++n1) {
         const int o = ob + n1;
-        cf1[o] += S_d1 + S_v6 * ipow7(bo0[o]); cf2[o] += S_v5; cf3[o] += S_v5;
+        acc1(cf1, l_cf, o, S_d1 + S_v6 * ipow7(bo0[o])); cf2[o] += S_v5; cf3[o] += S_v5;
       }
     fx[j] += fself.x; fy[j] += fself.y; fz[j] += fself.z;
   }
+  wave_lds_sync();
+  for (int t = lane_; t < nst; t += 64) { cf1[ob_w + t] = l_cf[t]; cdn[ob_w + t] = l_cd[t]; fnx[ob_w + t] = l_fx[t]; fny[ob_w + t] = l_fy[t]; fnz[ob_w + t] = l_fz[t]; }
   block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
 }
 
@@ -849,7 +869,7 @@ void Engine::bonded_energies() {
   k_elnpr_atoms<<<nblk(N, 256), 256, 0, stream>>>(N, dff, boff, type, bt1, bt2, delta, deltalp, dDlp, ecoef, pe_d);
   k_elnpr_bonds<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, type, bo2, bo3, delta, deltalp, dDlp, ecoef, cf1, cf2, cf3, cdn);
 const bool kt3 = kt_begin(&st.ms_k_e3b);
-    k_e3b<<<nblk(N, 256), 256, 0, stream>>>(N, dff, boff, nbr, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+    k_e3b<<<nblk(N, 256), 256, 4 * 5 * E3B_CAP * sizeof(double), stream>>>(N, dff, boff, nbr, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
   kt_end(kt3);
   BoxImg bx;

@@ -346,6 +346,9 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
         }
         {   // window slot: the candidate's column (of this row) -> the group's table entry -> first unit of the column + offset inside it
           const int t_ = static_cast<int>((wv >> 40) & 31);
+#ifdef RXMD_EXPERIMENTS
+          if (!(g.probe & 4))
+#endif
           sl10[row + slot] = static_cast<unsigned short>((k - cE[t_]) | (j >= N ? 0x8000 : 0));     // cE: first position of the column's interval - 8 x its first unit
         }
         unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
@@ -356,7 +359,13 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
           if (PQ) rg += hc * qsj; else if (j >= N) rg += h * qsj;
         }
         anyghost |= (j >= N);
+#ifdef RXMD_EXPERIMENTS
+        if (!(g.probe & 8))
+#endif
         nb10[row + slot] = static_cast<int>(ent);
+#ifdef RXMD_EXPERIMENTS
+        if (!(g.probe & 16))
+#endif
         hess[row + slot] = h;
       }
     }

@@ -115,6 +115,8 @@ __global__ void __launch_bounds__(64 * NB_WPB) k_nonbond(int N, int S10, DevFF f
 // (x, y, z, q) and the type of those positions into LDS once, with coalesced loads, and every pair reads its partner from there through the 16-bit
 // window slot of the list entry (2 bytes streamed instead of 4).  Same lane <-> entry assignment, same arithmetic (nb_pair), same reductions as
 // k_nonbond: forces and energies are bit for bit the same.  Not for boxes in which an atom meets its own image (the slot has no bit for that).
+// LDS holds the first `maxunits` units of a window (33 bytes per slot; 296 units = 78 KB: two workgroups per CU); the few groups with a larger
+// window (328 units is the largest of the RDX run, ~250 the mean) fetch the partners beyond it from the cell-sorted arrays as k_nonbond does.
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_nonbond_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const int *__restrict__ n10,
                                                                 const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt, int maxunits,
                                                                 const double4 *__restrict__ pk, const unsigned char *__restrict__ stype,
@@ -131,7 +133,8 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_nonbond_win(int N, int G, 
   const int i = min(rows_sorted[ridx], N);          // (sentinel >= N: an unused row of a cell column's last group)
   const int nslots = WIN_UNIT * win_cnt[grp];
   const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
-  for (int t = threadIdx.x; t < nslots; t += NT) {
+  const int capslots = WIN_UNIT * maxunits;
+  for (int t = threadIdx.x; t < min(nslots, capslots); t += NT) {
     const int pos = min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1);
     s_p[t] = pk[pos]; s_t[t] = stype[pos];
   }
@@ -153,7 +156,8 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_nonbond_win(int N, int G, 
       for (int u = 0; u < NB_UNR; ++u) {
         if (ee[u] == 0xffffu) continue;                                  // behind the row's end (no slot is that large)
         const int sl = static_cast<int>(ee[u] & 0x7fffu);
-        nb_pair(ff, ix2, xi, yi, zi, qi, s_p[sl], static_cast<int>(s_t[sl]), acc);
+        if (sl < capslots) nb_pair(ff, ix2, xi, yi, zi, qi, s_p[sl], static_cast<int>(s_t[sl]), acc);
+        else { const int pos = min(wk[sl / WIN_UNIT] + (sl & (WIN_UNIT - 1)), G - 1); nb_pair(ff, ix2, xi, yi, zi, qi, pk[pos], static_cast<int>(stype[pos]), acc); }
       }
     }
     e11 = acc.e11; e12 = acc.e12;
@@ -194,9 +198,10 @@ void Engine::charge_halo() {
 void Engine::nonbonded() {
   // over the windows of the matrix pass when this list build has them and no atom can meet its own image (RXMD_NONBOND_WIN=0: the row form)
   static const bool win_env = std::getenv("RXMD_NONBOND_WIN") == nullptr || std::atoi(std::getenv("RXMD_NONBOND_WIN")) != 0;
-  const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * (sizeof(double4) + 1) + 16;
-  if (win_valid && win_env && !list_selfcheck && lds <= 120 * 1024) {     // (two workgroups per CU up to ~79 KB = 300 units; above that one)
-    k_nonbond_win<<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, n10, rows_sorted, win_k, win_cnt, win_maxunits, sorted_xyzi, sorted_type, pos[0], pos[1], pos[2], q, type,
+  const int units = std::min(win_maxunits, 296);                         // 296 units x 8 slots x 33 bytes = 78 KB: two workgroups per CU
+  const size_t lds = static_cast<size_t>(units) * WIN_UNIT * (sizeof(double4) + 1) + 16;
+  if (win_valid && win_env && !list_selfcheck) {
+    k_nonbond_win<<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, n10, rows_sorted, win_k, win_cnt, units, sorted_xyzi, sorted_type, pos[0], pos[1], pos[2], q, type,
                                                              frc[0], frc[1], frc[2], scal + 32);
     RX_HIP(hipGetLastError());
     return;
