@@ -218,7 +218,7 @@ struct Engine {
   hipStream_t stream = nullptr;
   // second stream for the halo exchanges that overlap with compute (multi-rank): pack / RCCL send-recv / unpack run here while
   // the main stream works on what does not need the ghosts yet; events order the two (engine.hip: on_comm_stream)
-  hipStream_t comm_stream = nullptr; hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_est = nullptr, ev_spec[2] = {nullptr, nullptr}, ev_pass[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // ev_est: Est of a CG iteration has reached the host
+  hipStream_t comm_stream = nullptr; hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_est = nullptr, ev_spec[2] = {nullptr, nullptr}, ev_upd[2] = {nullptr, nullptr}, ev_pass[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // ev_est: Est of a CG iteration has reached the host
   template <class F> void on_comm_stream(F &&body) {          // body runs with `stream` == comm_stream, after everything queued on the main stream so far
     RX_HIP(hipEventRecord(ev_main, stream));
     RX_HIP(hipStreamWaitEvent(comm_stream, ev_main, 0));

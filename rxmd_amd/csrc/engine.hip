@@ -134,6 +134,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   RX_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   RX_HIP(hipEventCreateWithFlags(&ev_est, hipEventDisableTiming));
   RX_HIP(hipEventCreateWithFlags(&ev_spec[0], hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_spec[1], hipEventDisableTiming));
+  RX_HIP(hipEventCreateWithFlags(&ev_upd[0], hipEventDisableTiming)); RX_HIP(hipEventCreateWithFlags(&ev_upd[1], hipEventDisableTiming));
   for (auto &pr : ev_pass) for (auto &e2 : pr) RX_HIP(hipEventCreate(&e2));
   for (auto &e : ev) RX_HIP(hipEventCreate(&e));
 }
@@ -147,6 +148,7 @@ Engine::~Engine() {
   if (ev_comm) (void)hipEventDestroy(ev_comm);
   if (ev_est) (void)hipEventDestroy(ev_est);
   for (auto &e2 : ev_spec) if (e2) (void)hipEventDestroy(e2);
+  for (auto &e2 : ev_upd) if (e2) (void)hipEventDestroy(e2);
   for (auto &pr : ev_pass) for (auto &e2 : pr) if (e2) (void)hipEventDestroy(e2);
   if (comm_stream && comm_stream != stream) (void)hipStreamDestroy(comm_stream);
   if (stream) (void)hipStreamDestroy(stream);
@@ -364,7 +366,7 @@ void Engine::alloc_device() {
   { const size_t ng = win_groups_bound(rows10) + 1;       // groups never straddle a cell column of the grid: up to one short group per column
     dmalloc(rows_sorted, ng * WIN_ROWS); dmalloc(rowcols, ng * WIN_ROWS * 64); dmalloc(grp_base, ng * 32); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
-  dmalloc(partials, partials_cap + 1024); dzalloc(scal, 80);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
+  dmalloc(partials, partials_cap + 1024); dzalloc(scal, 192);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 192 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip)
   dzalloc(d_err, 16);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 32 * sizeof(int)));

@@ -197,12 +197,12 @@ __device__ inline double wave_sum_l(double v) { return wave_sum64(v); }   // DPP
 // neighbours in cell-sorted order (rows_sorted, build_windows): all rows of a group have the SAME 25 stencil columns, and the window of the group
 // is, per stencil column, the union of the rows' CANDIDATE runs -- [smallest first position, largest end), known from the per-row set-up before
 // any distance test -- rounded to units of WIN_UNIT positions: ~2,000 slots (the exact marking of k_win_build came to ~1,500: it counted only
-// units with an accepted position).  k_win_columns (one workgroup per group, one wavefront per row) does that set-up once: it leaves every row's
+// units with an accepted position).  k_win_columns (one workgroup per group, two rows per wavefront) does that set-up once: it leaves every row's
 // 25 runs for the sweep (rowcols), the group's unit list (win_k, win_cnt) and per stencil column what an entry's slot needs (grp_base = first
 // position of the interval - 8 x its first unit): slot = position - grp_base | ghost bit.  The sweep itself stays four rows per workgroup
 // with no barrier: as ONE kernel of 16-wavefront workgroups it lost 0.8 ms to wavefront slots that idle until the last row of a group is done.
 template <bool ORTHO>
-__global__ void __launch_bounds__(64 * WIN_ROWS) k_win_columns(int N, Grid g, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+__global__ void __launch_bounds__(32 * WIN_ROWS) k_win_columns(int N, Grid g, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                                const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz, double rcp,
                                                                const int *__restrict__ rows_sorted, int *__restrict__ rowcols, int *__restrict__ grp_base,
                                                                int *__restrict__ win_k, int *__restrict__ win_cnt, int *err) {
@@ -212,15 +212,16 @@ __global__ void __launch_bounds__(64 * WIN_ROWS) k_win_columns(int N, Grid g, co
   if (grp >= err[8]) return;                  // the launch covers the host's bound of the group count; err[8] = the groups of this build (whole workgroup leaves)
   if (threadIdx.x < 32) { t_lo[threadIdx.x] = 0x7fffffff; t_hi[threadIdx.x] = -1; }
   __syncthreads();
-  const int ridx = grp * WIN_ROWS + w;
+  const int l5 = lane & 31;                   // two rows per wavefront (25 of 32 lanes each: a row has 25 stencil columns)
+  const int ridx = grp * WIN_ROWS + 2 * w + (lane >> 5);
   const int i = rows_sorted[ridx];
   if (i < N) {                                // (the last group of a cell column may be short)
     const int c = cellid[i];
     const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
     int k0 = 0, len = 0;
-    if (lane < 25) column_run<ORTHO>(g, cellstart, spx[i], spy[i], spz[i], cx, cy, cx + lane / 5 - 2, cy + lane % 5 - 2, rcp, k0, len);
-    if (len > 0) { atomicMin(&t_lo[lane], k0); atomicMax(&t_hi[lane], k0 + len); }
-    if (lane < 32) { rowcols[static_cast<size_t>(ridx) * 64 + lane] = k0; rowcols[static_cast<size_t>(ridx) * 64 + 32 + lane] = len; }
+    if (l5 < 25) column_run<ORTHO>(g, cellstart, spx[i], spy[i], spz[i], cx, cy, cx + l5 / 5 - 2, cy + l5 % 5 - 2, rcp, k0, len);
+    if (len > 0) { atomicMin(&t_lo[l5], k0); atomicMax(&t_hi[l5], k0 + len); }
+    rowcols[static_cast<size_t>(ridx) * 64 + l5] = k0; rowcols[static_cast<size_t>(ridx) * 64 + 32 + l5] = len;
   }
   __syncthreads();
   if (w != 0) return;
@@ -544,8 +545,8 @@ void Engine::build_list10() {
   build_windows();
   int *gflag = multi() ? flags2 : nullptr;           // (the resident flags are used up)
   const bool kt10 = kt_begin(&st.ms_k_list10);
-  if (grid.ortho) k_win_columns<true><<<std::max(win_groups, 1), 64 * WIN_ROWS, 0, stream>>>(N, grid, cellid, cellstart, spos[0], spos[1], spos[2], dff.rctap_pad, rows_sorted, rowcols, grp_base, win_k, win_cnt, d_err);
-  else k_win_columns<false><<<std::max(win_groups, 1), 64 * WIN_ROWS, 0, stream>>>(N, grid, cellid, cellstart, spos[0], spos[1], spos[2], dff.rctap_pad, rows_sorted, rowcols, grp_base, win_k, win_cnt, d_err);
+  if (grid.ortho) k_win_columns<true><<<std::max(win_groups, 1), 32 * WIN_ROWS, 0, stream>>>(N, grid, cellid, cellstart, spos[0], spos[1], spos[2], dff.rctap_pad, rows_sorted, rowcols, grp_base, win_k, win_cnt, d_err);
+  else k_win_columns<false><<<std::max(win_groups, 1), 32 * WIN_ROWS, 0, stream>>>(N, grid, cellid, cellstart, spos[0], spos[1], spos[2], dff.rctap_pad, rows_sorted, rowcols, grp_base, win_k, win_cnt, d_err);
   if (ff.pqeq) { if (selfcheck) RX_LIST10(true, true); else RX_LIST10(false, true); }
   else { if (selfcheck) RX_LIST10(true, false); else RX_LIST10(false, false); }
   kt_end(kt10);

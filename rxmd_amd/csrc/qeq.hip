@@ -26,6 +26,7 @@ static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n 
 
 enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_RAW0, S_RAW1, S_RAW2, S_RAW3, S_RAW4, S_RAW5, S_RAW6, S_RAW7, S_STOP, S_STOP1, S_TOL, S_COUNT };
 enum { MODE_HSH = 0, MODE_GRAD = 1 };
+constexpr int S_SNAP = 128;      // scal[S_SNAP + 32 p ..]: snapshot of the scalars of an iteration of parity p (scalar_algebra stage 6)
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef SPMV_UNR
 #define SPMV_UNR 4
@@ -745,6 +746,10 @@ __device__ inline void scalar_algebra(int stage, double *__restrict__ scal) {
       const double tol = scal[S_TOL];
       const bool stop = (0.5 * (fabs(prev) + fabs(est)) < tol) || (fabs(prev) > 0.0 && fabs(est / prev - 1.0) < tol);
       scal[S_STOP + par] = stop ? 1.0 : 0.0;      // two flags, by iteration parity: the kernels of iteration k read flag k & 1, which only update(k - 1) writes
+      // a snapshot of the scalars of THIS iteration (parity par ^ 1) for the host: copied by a second stream while the main stream goes on with the
+      // direction kernel; the slot is rewritten two iterations later, after the host has read it (run-ahead loop of Engine::qeq)
+      double *snap = scal + S_SNAP + 32 * (par ^ 1);
+      for (int c = 0; c < S_COUNT; ++c) snap[c] = scal[c];
     }
   } else {
     scal[S_EST] = r[0];
@@ -1147,8 +1152,12 @@ void Engine::qeq() {
       hipEventRecord(ev_pass[k & 1][1], stream);
       reduce(1, np1);
       k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag);
-      RX_HIP(hipMemcpyAsync(h_scal + 64 + 64 * (k & 1), scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipEventRecord(ev_spec[k & 1], stream));
+      // Est and the stop flags of this iteration travel to the host on the second stream, from the snapshot the update kernel's tail left: the
+      // copy (a 4 us blit kernel) no longer sits between the update and the direction kernel
+      RX_HIP(hipEventRecord(ev_upd[k & 1], stream));
+      RX_HIP(hipStreamWaitEvent(comm_stream, ev_upd[k & 1], 0));
+      RX_HIP(hipMemcpyAsync(h_scal + 64 + 64 * (k & 1), scal + S_SNAP + 32 * (k & 1), sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, comm_stream));
+      RX_HIP(hipEventRecord(ev_spec[k & 1], comm_stream));
       const bool scatter = cg_scatter && k + 1 <= nmax - 1;
       k_cg_direction<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, stopflag);
       std::swap(hst, hst2);
