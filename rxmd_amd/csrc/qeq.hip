@@ -328,155 +328,6 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   }
 }
 
-// ---- window pass, early-issue form (k_spmv_win2) ------------------------------------------------------------------------------------------
-// Same sums as k_spmv_win; what changes is WHEN the wavefront's requests leave.  k_spmv_win lives through three dependent round trips before its
-// first product -- descriptors (row of the group, window size, unit starts), then window + first batch, then the second batch after the first was
-// used -- and a CU holds two such workgroups: throughput = bytes of a group / that lifetime x 2.  Here
-//   * the value and slot ROWS lie in cell-sorted rank order (row of wavefront w of group g = g * 16 + w: no look-up in front of the stream), so the
-//     first batch is requested at the very start;
-//   * everything the window needs is WAVE-UNIFORM and comes by scalar loads (their own counter, not queued behind the stream's vector loads): the
-//     window size and the 8 + 8 unit starts this wavefront copies (a wavefront's 64 threads cover 8 consecutive units of each round);
-//   * the second batch is requested before the barrier, behind the window's loads.
-// One workgroup per group, 16 wavefronts, as before.
-template <int MODE, bool STORE, bool PQ>
-__global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win2(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
-                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
-                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
-                                                             const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
-                                                             const double *__restrict__ scal, double *__restrict__ partials,
-                                                             double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
-                                                             const double *__restrict__ hsc, const double4 *__restrict__ pqrow,
-                                                             const int *__restrict__ grouplist, int ngroups, int pbase, const double *__restrict__ stopflag) {
-  if (stopflag && *stopflag != 0.0) return;
-  extern __shared__ double2 s_x[];
-  __shared__ double s_row[WIN_ROWS][4];
-  __shared__ int s_arrived;
-  constexpr int NT = 64 * WIN_ROWS;
-  typedef double d2v __attribute__((ext_vector_type(2)));
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int gidx = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int grp = grouplist ? (gidx < ngroups ? grouplist[gidx] : -1) : (gidx < ngroups ? gidx : -1);
-  if (grp < 0) return;
-  const int ridx = grp * WIN_ROWS + wave;
-  const bool live = rows_sorted[ridx] < N;
-  const size_t base = static_cast<size_t>(live ? ridx : 0) * S10;
-  const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
-  const d2v *cv2 = reinterpret_cast<const d2v *>((PQ ? hsc : hess) + base);
-  const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
-  double2 v[2], c[2], vn[2], cn[2]; unsigned ss[2], sn[2];
-  // first batch: 256 entries, two per lane and request -- inside the row's slot whatever the row's length
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int k = 128 * u + 2 * lane;
-    if (live && k < S10) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); v[u] = make_double2(t2.x, t2.y); ss[u] = __builtin_nontemporal_load(sl2 + (k >> 1)); }
-    else { v[u] = make_double2(0.0, 0.0); ss[u] = 0u; }
-    if (PQ && (MODE == MODE_GRAD || STORE)) { if (live && k < S10) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); c[u] = make_double2(t2.x, t2.y); } else c[u] = make_double2(0.0, 0.0); }
-  }
-  // wave-uniform descriptors: scalar loads
-  const int row = min(rows_sorted[ridx], N);
-  const int nslots = WIN_UNIT * win_cnt[grp];
-  const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
-  int ua[8], ub[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { ua[j] = wk[wave * 8 + j]; ub[j] = wk[NT / WIN_UNIT + wave * 8 + j]; }
-  const int n = live ? (n10[row] & N10_COUNT) : 0;
-  const int rowc = live ? row : 0;
-  const int tl_t = type[rowc];
-  const double2 tl_a = (MODE == MODE_HSH) ? hst[rowc] : qst[rowc];
-  const double2 tl_b = (MODE == MODE_HSH) ? const_cast<const double2 *>(gst)[rowc] : make_double2(q[rowc], 0.0);
-  const int t0 = threadIdx.x, t1 = threadIdx.x + NT;
-  int wk0 = ua[0], wk1 = ub[0];
-#pragma unroll
-  for (int j = 1; j < 8; ++j) { const bool m = (lane >> 3) == j; wk0 = m ? ua[j] : wk0; wk1 = m ? ub[j] : wk1; }
-  double2 x0 = make_double2(0.0, 0.0), x1 = x0;
-  if (t0 < nslots) x0 = xv[min(wk0 + (t0 & (WIN_UNIT - 1)), G - 1)];
-  if (t1 < nslots) x1 = xv[min(wk1 + (t1 & (WIN_UNIT - 1)), G - 1)];
-  // second batch, behind the window's loads (a wavefront's vector loads return in order: the window does not wait for it)
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int k = 256 + 128 * u + 2 * lane;
-    if (k < n) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); vn[u] = make_double2(t2.x, t2.y); sn[u] = __builtin_nontemporal_load(sl2 + (k >> 1)); }
-    else { vn[u] = make_double2(0.0, 0.0); sn[u] = 0u; }
-    if (PQ && (MODE == MODE_GRAD || STORE)) { if (k < n) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); cn[u] = make_double2(t2.x, t2.y); } else cn[u] = make_double2(0.0, 0.0); }
-  }
-  if (threadIdx.x == 0) s_arrived = 0;
-  if (t0 < nslots) s_x[t0] = x0;
-  if (t1 < nslots) s_x[t1] = x1;
-  for (int t = threadIdx.x + 2 * NT; t < nslots; t += NT) s_x[t] = xv[min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1)];   // a window of more than 256 units
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {                     // entries behind the row's end: weight 0, slot 0
-    const int k = 128 * u + 2 * lane;
-    if (k >= n) { v[u].x = 0.0; ss[u] &= 0xffff0000u; if (PQ) c[u].x = 0.0; }
-    if (k + 1 >= n) { v[u].y = 0.0; ss[u] &= 0x0000ffffu; if (PQ) c[u].y = 0.0; }
-  }
-  __syncthreads();
-  double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-  for (int kb = 0; kb < n; kb += 256) {             // wave-uniform trip count
-    if (kb > 0) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) { v[u] = vn[u]; ss[u] = sn[u]; if (PQ) c[u] = cn[u]; }
-      if (kb + 256 < n) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int k = kb + 256 + 128 * u + 2 * lane;
-          if (k < n) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); vn[u] = make_double2(t2.x, t2.y); sn[u] = __builtin_nontemporal_load(sl2 + (k >> 1)); }
-          else { vn[u] = make_double2(0.0, 0.0); sn[u] = 0u; }
-          if (PQ && (MODE == MODE_GRAD || STORE)) { if (k < n) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); cn[u] = make_double2(t2.x, t2.y); } else cn[u] = make_double2(0.0, 0.0); }
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const double2 y0 = s_x[ss[u] & 0x7fffu], y1 = s_x[(ss[u] >> 16) & 0x7fffu];
-      as += v[u].x * y0.x; at += v[u].x * y0.y; as += v[u].y * y1.x; at += v[u].y * y1.y;
-      if ((MODE == MODE_GRAD || STORE) && !PQ) {
-        const double g0 = (ss[u] & 0x8000u) ? v[u].x : 0.0, g1 = (ss[u] & 0x80000000u) ? v[u].y : 0.0;     // select the weight, not the sums
-        gs_ += g0 * y0.x; gt_ += g0 * y0.y; gs_ += g1 * y1.x; gt_ += g1 * y1.y;
-      }
-      if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * y0.x; gt_ += c[u].x * y0.y; gs_ += c[u].y * y1.x; gt_ += c[u].y * y1.y; }
-    }
-  }
-  as = wave_sum(as); at = wave_sum(at);
-  if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  if (live) {
-    const DevAtomP ap = ff.atom[tl_t];
-    if (MODE == MODE_HSH) {
-      const double ts = ap.eta * tl_a.x + as, tt = ap.eta * tl_a.y + at;      // qeq.F90:294-302
-      a0 = ts * tl_a.x; a1 = tt * tl_a.y;                                     // hshs_sum, hsht_sum (:309-310)
-      a2 = tl_b.x * tl_a.x; a3 = tl_b.y * tl_a.y;                             // g.h (:119,123)
-      if (STORE && lane == 0) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
-    } else {
-      const double mu = scal[S_MU];
-      const double4 pr = PQ ? pqrow[row] : make_double4(0.0, 0.0, 0.0, 0.0);
-      const double g1 = -ap.chi - ap.eta * tl_a.x - as - pr.x;                // qeq.F90:349-350 (pqeq.F90:466)
-      const double g2 = -1.0 - ap.eta * tl_a.y - at;
-      a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
-      const double qi = tl_b.x;
-      const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
-      if (PQ) a2 = pq_est_row(ap, ff.Zpq[tl_t], pr, qi, hq_all, gs_ - mu * gt_);
-      else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
-      if (lane == 0) { gst[row] = make_double2(g1, g2); if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); } }
-    }
-  }
-  int arrived = 0;
-  if (lane == 0) {
-    s_row[wave][0] = a0; s_row[wave][1] = a1; s_row[wave][2] = a2; s_row[wave][3] = a3;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    arrived = __hip_atomic_fetch_add(&s_arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  arrived = __builtin_amdgcn_readfirstlane(arrived);
-  if (arrived != WIN_ROWS - 1) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (lane < 4) {
-    double sum = 0.0;
-#pragma unroll
-    for (int w = 0; w < WIN_ROWS; ++w) sum += s_row[w][lane];                 // fixed order: the result does not depend on which wavefront is last
-    __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 #ifdef RXMD_EXPERIMENTS
 // ---- where does the row kernel's time go?  Stripped-down forms of k_spmv, timed in isolation (debug tap 102; experiments only) -------
 //   LEVEL 0: the two streams of a row only (4 x 64 entries per trip as k_spmv), one sum, one wavefront reduction, no store
@@ -602,32 +453,6 @@ void spmv_isolated_ms(Engine &e, double *out) {
     for (int rd = 0; rd < rounds; ++rd)
       a5 += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
     out[4] = a5 / rounds;
-    {   // k_spmv_win2 on copies of the value / slot arrays with their rows in cell-sorted rank order
-      const size_t ne = static_cast<size_t>(e.rows10) * e.S10;
-      double *h2 = nullptr; unsigned short *s2 = nullptr;
-      if (hipMalloc(reinterpret_cast<void **>(&h2), ne * sizeof(double)) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&s2), ne * sizeof(unsigned short)) == hipSuccess) {
-        k_rows_to_rank_order<<<e.N, 256, 0, e.stream>>>(e.N, e.S10, e.rows_sorted, e.hess, e.sl10, h2, s2);
-        double a6 = 0.0, a7 = 0.0;
-        for (int rd = 0; rd < rounds; ++rd) {
-          a6 += timed([&] { k_spmv_win2<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2, h2, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-          a7 += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-        }
-        out[5] = a6 / rounds; out[6] = a7 / rounds;
-        // same sums? row sums of the two kernels side by side (wall holds the last launch's: the default's); compare through a second buffer
-        double2 *w2 = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&w2), sizeof(double2) * e.N) == hipSuccess) {
-          k_spmv_win2<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2, h2, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, w2, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr);
-          std::vector<double> ha(2 * static_cast<size_t>(e.N)), hb(2 * static_cast<size_t>(e.N));
-          hipMemcpy(ha.data(), e.wall, sizeof(double2) * e.N, hipMemcpyDeviceToHost); hipMemcpy(hb.data(), w2, sizeof(double2) * e.N, hipMemcpyDeviceToHost);
-          double md = 0.0, mx = 0.0;
-          for (size_t k = 0; k < ha.size(); ++k) { md = std::max(md, std::fabs(ha[k] - hb[k])); mx = std::max(mx, std::fabs(ha[k])); }
-          out[7] = md; out[8] = mx;
-          (void)hipFree(w2);
-        }
-      } else (void)hipGetLastError();
-      if (h2) (void)hipFree(h2);
-      if (s2) (void)hipFree(s2);
-    }
   }
   // RXMD_ISO_COPIES=1: does the pass time depend on WHERE its streams lie?  Four copies of the value and slot arrays held at the same time, the
   // pass on each, twice round (out[2..9]): a property of the buffer repeats in the second round, a drift in time does not.  out[10]: the last
@@ -1154,10 +979,12 @@ void Engine::qeq() {
       k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag);
       // Est and the stop flags of this iteration travel to the host on the second stream, from the snapshot the update kernel's tail left: the
       // copy (a 4 us blit kernel) no longer sits between the update and the direction kernel
-      RX_HIP(hipEventRecord(ev_upd[k & 1], stream));
-      RX_HIP(hipStreamWaitEvent(comm_stream, ev_upd[k & 1], 0));
-      RX_HIP(hipMemcpyAsync(h_scal + 64 + 64 * (k & 1), scal + S_SNAP + 32 * (k & 1), sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, comm_stream));
-      RX_HIP(hipEventRecord(ev_spec[k & 1], comm_stream));
+      // (large systems only: where an iteration is shorter than the host's own work per iteration -- small boxes, tight tolerance -- the host
+      // waits for every copy, and a wait on the second stream's event costs it milliseconds: the suite's 168-atom trajectories ran ten times longer)
+      hipStream_t cs = (N >= 65536) ? comm_stream : stream;
+      if (cs != stream) { RX_HIP(hipEventRecord(ev_upd[k & 1], stream)); RX_HIP(hipStreamWaitEvent(cs, ev_upd[k & 1], 0)); }
+      RX_HIP(hipMemcpyAsync(h_scal + 64 + 64 * (k & 1), scal + S_SNAP + 32 * (k & 1), sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, cs));
+      RX_HIP(hipEventRecord(ev_spec[k & 1], cs));
       const bool scatter = cg_scatter && k + 1 <= nmax - 1;
       k_cg_direction<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, stopflag);
       std::swap(hst, hst2);
