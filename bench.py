@@ -495,13 +495,13 @@ def main():
         G = st["natoms"] + st["nghost_force"]
         ncg = max(st["qeq_iters_total"], 1)
         ms_cg_vec = max(st["ms_qeq"] - st["ms_qeq_spmv"] - st["ms_lists"], 0.0) / ncg       # per CG iteration: update + direction + sorted copy (+ reduction)
-        kdefs = [("k_list10", "ms_k_list10", st["nnz10"] * 14.0 + st["natoms"] * 40.0, a.steps, "10 A sweep: entry + value + 16-bit window slot written once (qeq.F90:183-268, main.F90:420-477)"),
-                 ("k_nonbond", "ms_k_nonbond", st["nnz10"] * 4.0 + st["natoms"] * 64.0, a.steps, "ENbond: the entry stream (pot.F90:676-781)"),
-                 ("k_bo_prime+k_bo_full", "ms_k_bondorder", G * nb * 104.0, a.steps, "BOPRIM + BOFULL over residents and ghosts (bo.F90:28-298)"),
+        kdefs = [("k_win_columns+k_list10", "ms_k_list10", st["nnz10"] * 14.0 + st["natoms"] * 40.0, a.steps, "10 A sweep: entry + value + 16-bit window slot written once (qeq.F90:183-268, main.F90:420-477)"),
+                 ("k_nonbond_win+k_nonbond", "ms_k_nonbond", st["nnz10"] * 4.0 + st["natoms"] * 64.0, a.steps, "ENbond: the entry stream (pot.F90:676-781)"),
+                 ("k_bo_prime+k_deltap+k_bo_full+k_delta_lp", "ms_k_bondorder", G * nb * 104.0, a.steps, "BOPRIM + BOFULL over residents and ghosts (bo.F90:28-298)"),
                  ("k_e3b", "ms_k_e3b", st["natoms"] * nb * 104.0, a.steps, "E3b (pot.F90:319-557): FP64 chains, not bytes, bound it"),
                  ("k_e4b", "ms_k_e4b", st["natoms"] * nb * 104.0, a.steps, "E4b (pot.F90:980-1227): FP64 chains"),
                  ("k_ehb", "ms_k_ehb", st["natoms"] * nb * 104.0, a.steps, "Ehb (pot.F90:559-673)"),
-                 ("k_cd_gather+k_ccbnd+k_bond_forces", "ms_k_assemble", G * nb * 104.0, a.steps, "ForceBondedTerms as gathers (pot.F90:113-144)")]
+                 ("k_cd_gather+k_ccbnd_terms+k_ccbnd_sum+k_bond_force_terms+k_bond_force_sum", "ms_k_assemble", G * nb * 104.0, a.steps, "ForceBondedTerms as gathers (pot.F90:113-144)")]
         kernels = []
         for name, key, byts, cnt, note in kdefs:
             ms = st.get(key, 0.0) / max(cnt, 1)

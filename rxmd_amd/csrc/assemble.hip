@@ -1,5 +1,5 @@
 // assemble.hip -- turns the per-slot accumulators of bonded.hip into forces, and the MD step.
-//   ForceBondedTerms + ForceD   reference src/pot.F90:113-144, 1230-1273  -> k_cd_gather, k_ccbnd, k_bond_forces
+//   ForceBondedTerms + ForceD   reference src/pot.F90:113-144, 1230-1273  -> k_cd_gather, k_ccbnd_terms / _sum, k_bond_force_terms / _sum
 //   COPYATOMS(MODE_CPBK)        reference src/comm.F90:385-396, 474-482   -> Engine::fold_ghost_forces (engine.hip)
 //   FORCE driver                reference src/pot.F90:2-90                -> Engine::force
 //   MD loop body                reference src/main.F90:64-98              -> Engine::step

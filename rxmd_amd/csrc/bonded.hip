@@ -6,13 +6,13 @@
 //   Ehb   (pot.F90:559-673)                           -> k_ehb   (a wavefront finds the donors among 64 atoms, then sweeps their rows)
 // The reference scatters every derivative at once with atomics (ForceB/ForceBbo/ForceA3/ForceA4,
 // pot.F90:1276-1521).  Here a thread owns one centre atom and accumulates ONLY into that atom's own
-// rows of the slot-major tables:
+// stretch of the compact bond tables (bond o = boff[centre] + slot, engine.h):
 //     cf1,cf2,cf3[slot]  dE/dBO of the bond in that slot, in ForceBbo's cf() form (pot.F90:1331):
 //                        full BO, pi-minus-full, pipi-minus-full.  ForceB(c) == cf (c,0,0).
 //     cdn[slot]          contribution to cdbnd of the NEIGHBOUR in that slot (pot.F90:304,536,539,1183)
 //     fnx,fny,fnz[slot]  angle/torsion force on the neighbour in that slot
 //     cds, f (self)      contribution to the centre's own cdbnd / force
-// assemble.hip turns these into forces by pure gathers through nbrindx: deterministic, no FP64 atomics
+// assemble.hip turns these into forces by pure gathers through the mirror-bond index brev: deterministic, no FP64 atomics
 // (except the acceptor atom of a hydrogen bond, which is a 10 A partner and has no slot).
 #include "engine.h"
 
@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int S10, DevFF ff, const int
   __shared__ unsigned s_cand[4][EHB_CHUNK];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   // A wavefront takes EHB_APW consecutive atoms.  First every lane decides for its own atom whether it is a donor with a hydrogen partner
-  // (coalesced slot-major reads; in RDX one atom in fourteen is) and leaves a bit mask of those slots; then the wavefront sweeps the
+  // (in RDX one atom in fourteen is) and leaves a bit mask of those slots; then the wavefront sweeps the
   // 10 A rows of the atoms that have one, one after the other.  (One wavefront per atom spent most of the kernel starting a million
   // wavefronts that found nothing: 1.5 ms, of which the sweeps themselves were about a third.)
 #ifdef RXMD_EXPERIMENTS

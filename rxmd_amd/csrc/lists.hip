@@ -1,6 +1,6 @@
 // lists.hip -- bonded (3 A) neighbour list with reverse index, and the 10 A pair list with the QEq
 // "hessian" (shielded-Coulomb matrix) built in the same sweep.
-//   NEIGHBORLIST            reference src/main.F90:321-417   -> k_bonded_list + k_reverse_index
+//   NEIGHBORLIST            reference src/main.F90:321-417   -> k_bonded_list + k_bond_csr
 //   qeq_initialize          reference src/qeq.F90:183-268    \  one sweep: k_list10
 //   GetNonbondingPairList   reference src/main.F90:420-477   /  (the reference walks the stencil twice)
 // Candidates come from the engine's own cell grid (cells >= max(rctap/2, maxrc) wide, perpendicular to their faces), sorted by

@@ -893,3 +893,18 @@ def test_poisoned_allocations():
     env = dict(os.environ, RXMD_POISON_ALLOC="1")
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "poison_worker.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0 and "POISON-OK" in p.stdout, p.stderr[-3000:]
+
+
+def test_bond_tables_grow_on_demand(monkeypatch):
+    """The compact bond tables start at 12 bonds per atom slot and grow to what a list build reports (Engine::build_ghosts_and_lists): with a
+    capacity of 1,024 bonds (RXMD_BOND_CAP) RDX 2 x 2 x 2 -- ~40,000 bonds with its ghosts -- has to grow them in its first build, and must
+    give the same charges, forces and energies as the run that never grew."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    ref = _engine("rdx222", (2, 2, 2), qeq_mode=1, **kw); ref.QEq(); pe0 = ref.FORCE(); ref.step(2); a0 = ref.atoms(); ref.close()
+    monkeypatch.setenv("RXMD_BOND_CAP", "1024")
+    e = _engine("rdx222", (2, 2, 2), qeq_mode=1, **kw); e.QEq(); pe = e.FORCE()
+    assert e.stats()["nbonds"] > 1024
+    e.step(2); a = e.atoms(); e.close()
+    # (to the order of the energy sums and of the acceptor atomics of Ehb, the only additions whose order is not fixed)
+    assert e_err(pe, pe0) <= 1e-12
+    assert q_err(a["q"], a0["q"]) <= 1e-12 and f_err(a["f"], a0["f"]) <= 1e-11 and np.abs(a["pos"] - a0["pos"]).max() <= 1e-12
