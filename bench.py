@@ -516,7 +516,7 @@ def main():
         # the pass that ran, by its full template signature (MODE_HSH, STORE, PQ, NSTEP, VAR -- qeq.hip): only that instance's counters count
         one_trip = (not pqeq) and 256 < st.get("max_n10", 0) <= 384
         if st.get("win_in_use"):
-            sig = "k_spmv_win<0, true, %s, %d, %d>" % ("true" if pqeq else "false", 3 if one_trip else 2, 0 if one_trip else 2)
+            sig = "k_spmv_win<0, true, %s, %d, %d>" % ("true" if pqeq else "false", 3 if one_trip else 2, 4 if one_trip else 6)
         else:
             sig = "k_spmv<0, true, %s, 1>" % ("true" if pqeq else "false")
         traffic = ktraffic.get(sig)                  # None when the file was taken with another instance of the kernel

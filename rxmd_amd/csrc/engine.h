@@ -282,6 +282,7 @@ struct Engine {
   void tune_window_placement();   // qeq.hip: a few placements of the pass's streams in physical memory, the fastest kept (once per engine)
   bool place_tuned = false;
   int *rows_sorted = nullptr, *win_k = nullptr, *win_cnt = nullptr;
+  int *win_flag = nullptr;                       // per group: 1 when one of its rows has a ghost partner (the sweep sets it; multi-rank: the boundary groups)
   int *rowcols = nullptr, *grp_base = nullptr;   // per row: first position and length of its 25 candidate runs (64 ints) ; per group: slot base of its 25 stencil columns (32 ints)
   int *win_gint = nullptr, *win_gbnd = nullptr; int win_nbnd = 0;     // multi-rank: groups without / with a row that has a ghost partner
   unsigned short *sl10 = nullptr;

@@ -369,7 +369,7 @@ void Engine::alloc_device() {
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
   { const size_t ng = win_groups_bound(rows10) + 1;       // groups never straddle a cell column of the grid: up to one short group per column
-    dmalloc(rows_sorted, ng * WIN_ROWS); dmalloc(rowcols, ng * WIN_ROWS * 64); dmalloc(grp_base, ng * 32); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
+    dmalloc(rows_sorted, ng * WIN_ROWS); dmalloc(rowcols, ng * WIN_ROWS * 64); dmalloc(grp_base, ng * 32); dmalloc(win_flag, ng + 1); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dzalloc(scal, 192);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 192 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip)
@@ -406,7 +406,7 @@ void Engine::free_device() {
   dfree(sorted_xyzi); dfree(sorted_type); dfree(flags); dfree(scanout); dfree(nbr_sm); dfree(nbrcnt); dfree(boff);
   free_bond_tables();
   dfree(ecoef); dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
-  dfree(rows_int); dfree(rows_bnd); dfree(rows_sorted); dfree(rowcols); dfree(grp_base); dfree(win_k); dfree(win_cnt); dfree(win_gint); dfree(win_gbnd); dfree(sl10);
+  dfree(rows_int); dfree(rows_bnd); dfree(rows_sorted); dfree(rowcols); dfree(grp_base); dfree(win_flag); dfree(win_k); dfree(win_cnt); dfree(win_gint); dfree(win_gbnd); dfree(sl10);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
@@ -1324,7 +1324,7 @@ void Engine::poison_step_scratch() {
   fill(nb10, 0, sizeof(int) * nl); fill(hess, 0, sizeof(double) * nl); fill(sl10, 0, sizeof(unsigned short) * nl); fill(n10, 0, sizeof(int) * rows10);
   fill(rows_int, 0, sizeof(int) * rows10); fill(rows_bnd, 0, sizeof(int) * rows10);
   { const size_t ngr = win_groups_bound(rows10) + 1;
-    fill(rows_sorted, 0, sizeof(int) * ngr * WIN_ROWS); fill(rowcols, 0, sizeof(int) * ngr * WIN_ROWS * 64); fill(grp_base, 0, sizeof(int) * ngr * 32); fill(win_k, 0, sizeof(int) * ngr * WIN_MAXUNITS); fill(win_cnt, 0, sizeof(int) * ngr);
+    fill(rows_sorted, 0, sizeof(int) * ngr * WIN_ROWS); fill(rowcols, 0, sizeof(int) * ngr * WIN_ROWS * 64); fill(grp_base, 0, sizeof(int) * ngr * 32); fill(win_flag, 0, sizeof(int) * (ngr + 1)); fill(win_k, 0, sizeof(int) * ngr * WIN_MAXUNITS); fill(win_cnt, 0, sizeof(int) * ngr);
     fill(win_gint, 0, sizeof(int) * ngr); fill(win_gbnd, 0, sizeof(int) * ngr); }
   fill(sall, 0, sizeof(double2) * rows10); fill(sgh, 0, sizeof(double2) * rows10); fill(wall, 0, sizeof(double2) * rows10); fill(wgh, 0, sizeof(double2) * rows10);
   fill(partials, 0, sizeof(double) * (partials_cap + 1024));

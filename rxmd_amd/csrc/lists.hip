@@ -512,7 +512,7 @@ void Engine::build_windows() {
   k_rows_sorted<<<nblk(G, 256), 256, 0, stream>>>(G, N, grid.nzf, perm, scanout2, cellid_sorted, cellstart, scanout, rows_sorted);
   RX_HIP(hipMemsetAsync(d_err + 5, 0, 2 * sizeof(int), stream));
   RX_HIP(hipMemsetAsync(win_cnt, 0, sizeof(int) * static_cast<size_t>(win_groups), stream));               // (groups between the count and the bound: empty windows)
-  if (multi()) RX_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * (static_cast<size_t>(win_groups) + 1), stream));   // ... and interior (the resident flags are used up)
+  RX_HIP(hipMemsetAsync(win_flag, 0, sizeof(int) * (static_cast<size_t>(win_groups) + 1), stream));              // ... and interior until the sweep finds a row with a ghost partner
 }
 
 void Engine::build_bonded_list() {
@@ -544,7 +544,7 @@ void Engine::build_list10() {
                                                     rows_sorted, sl10, rowcols, grp_base, gflag)
   win_valid = false;
   build_windows();
-  int *gflag = multi() ? flags2 : nullptr;           // (the resident flags are used up)
+  int *gflag = win_flag;
   const bool kt10 = kt_begin(&st.ms_k_list10);
   if (grid.ortho) k_win_columns<true><<<std::max(win_groups, 1), 32 * WIN_ROWS, 0, stream>>>(N, grid, cellid, cellstart, spos[0], spos[1], spos[2], dff.rctap_pad, rows_sorted, rowcols, grp_base, win_k, win_cnt, d_err);
   else k_win_columns<false><<<std::max(win_groups, 1), 32 * WIN_ROWS, 0, stream>>>(N, grid, cellid, cellstart, spos[0], spos[1], spos[2], dff.rctap_pad, rows_sorted, rowcols, grp_base, win_k, win_cnt, d_err);
@@ -554,10 +554,9 @@ void Engine::build_list10() {
 #undef RX_LIST10
 #undef RX_LIST10_O
   if (multi()) {                                     // interior groups (no row with a ghost partner) / boundary groups: the two launches of an overlapped pass
-    RX_HIP(hipMemsetAsync(flags2 + win_groups, 0, sizeof(int), stream));
     size_t tb = cubtmp_bytes;
-    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, win_groups + 1, stream));
-    k_split_groups<<<nblk(win_groups, 256), 256, 0, stream>>>(win_groups, flags2, scanout2, win_gint, win_gbnd);
+    RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, win_flag, scanout2, win_groups + 1, stream));
+    k_split_groups<<<nblk(win_groups, 256), 256, 0, stream>>>(win_groups, win_flag, scanout2, win_gint, win_gbnd);
     RX_HIP(hipMemcpyAsync(&win_nbnd, scanout2 + win_groups, sizeof(int), hipMemcpyDeviceToHost, stream));   // valid after the synchronisation of the list build's error check
   }
   if (multi()) {     // interior rows (no ghost partner) and boundary rows: the matrix pass does the former while the vector halo is in flight

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
 // (A timing probe with synthetic slots promised 0.76 against 0.93 ms of k_spmv before anything real was built; the real pass: 0.80 against 0.89 ms
 // back to back in one process, DESIGN.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
-template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR & 2: the second batch of a row is requested before the workgroup's barrier (below).  NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
+template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR & 2: the second batch of a row is requested before the workgroup's barrier (below); VAR & 4: groups without a ghost partner skip the ghost-column sums (below); the default of plain QEq is 6.  NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
@@ -187,7 +187,8 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
                                                             const double *__restrict__ scal, double *__restrict__ partials,
                                                             double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
                                                             const double *__restrict__ hsc, const double4 *__restrict__ pqrow,
-                                                            const int *__restrict__ grouplist, int ngroups, int pbase, const double *__restrict__ stopflag) {
+                                                            const int *__restrict__ grouplist, int ngroups, int pbase, const double *__restrict__ stopflag,
+                                                            const int *__restrict__ gflags = nullptr) {
   if (stopflag && *stopflag != 0.0) return;
   extern __shared__ double2 s_x[];                  // the window: slot -> (xs, xt)
   __shared__ double s_row[WIN_ROWS][4];
@@ -267,26 +268,34 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   if (PRE && n > 128 * STEPS) request_next(128 * STEPS);
   __syncthreads();
   double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-  for (int kb = 0; kb < n; kb += 128 * STEPS) {     // wave-uniform trip count
-    if (!PRE && kb > 0) request(kb, n);             // (an odd row end: entry n is the zero padding of the row, slot 0)
-    if (PRE && kb > 0) {
+  // VAR & 4: a group none of whose rows has a ghost partner (gflags[grp] == 0: three groups in four of a large domain) takes a loop WITHOUT the
+  // ghost-column sums -- two selects and four FMAs of the twelve vector instructions per pair of entries, and two of the four reductions.  The
+  // choice is one scalar branch per workgroup around two straight-line loops, not a branch per row inside one (round 3: that lost).
+  const bool gh = !((VAR & 4) != 0 && !PQ && gflags != nullptr) || gflags[grp] != 0;
+  auto products = [&](auto ghc) {
+    constexpr bool GHC = decltype(ghc)::value;
+    for (int kb = 0; kb < n; kb += 128 * STEPS) {     // wave-uniform trip count
+      if (!PRE && kb > 0) request(kb, n);             // (an odd row end: entry n is the zero padding of the row, slot 0)
+      if (PRE && kb > 0) {
 #pragma unroll
-      for (int u = 0; u < STEPS; ++u) { v[u] = vn[u]; ss[u] = sn[u]; }
-      if (kb + 128 * STEPS < n) request_next(kb + 128 * STEPS);
-    }
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-      const double2 y0 = s_x[ss[u] & 0x7fffu], y1 = s_x[(ss[u] >> 16) & 0x7fffu];
-      as += v[u].x * y0.x; at += v[u].x * y0.y; as += v[u].y * y1.x; at += v[u].y * y1.y;
-      if ((MODE == MODE_GRAD || STORE) && !PQ) {
-        const double g0 = (ss[u] & 0x8000u) ? v[u].x : 0.0, g1 = (ss[u] & 0x80000000u) ? v[u].y : 0.0;     // select the weight, not the sums
-        gs_ += g0 * y0.x; gt_ += g0 * y0.y; gs_ += g1 * y1.x; gt_ += g1 * y1.y;
+        for (int u = 0; u < STEPS; ++u) { v[u] = vn[u]; ss[u] = sn[u]; }
+        if (kb + 128 * STEPS < n) request_next(kb + 128 * STEPS);
       }
-      if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * y0.x; gt_ += c[u].x * y0.y; gs_ += c[u].y * y1.x; gt_ += c[u].y * y1.y; }
+#pragma unroll
+      for (int u = 0; u < STEPS; ++u) {
+        const double2 y0 = s_x[ss[u] & 0x7fffu], y1 = s_x[(ss[u] >> 16) & 0x7fffu];
+        as += v[u].x * y0.x; at += v[u].x * y0.y; as += v[u].y * y1.x; at += v[u].y * y1.y;
+        if (GHC && (MODE == MODE_GRAD || STORE) && !PQ) {
+          const double g0 = (ss[u] & 0x8000u) ? v[u].x : 0.0, g1 = (ss[u] & 0x80000000u) ? v[u].y : 0.0;     // select the weight, not the sums
+          gs_ += g0 * y0.x; gt_ += g0 * y0.y; gs_ += g1 * y1.x; gt_ += g1 * y1.y;
+        }
+        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * y0.x; gt_ += c[u].x * y0.y; gs_ += c[u].y * y1.x; gt_ += c[u].y * y1.y; }
+      }
     }
-  }
+  };
+  if (gh) products(std::true_type{}); else products(std::false_type{});
   as = wave_sum(as); at = wave_sum(at);
-  if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+  if ((MODE == MODE_GRAD || STORE) && gh) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
   // The row's tail by its own wavefront (the rows of a group are scattered residents: nothing would coalesce if one wavefront ran all of them,
   // and a workgroup whose last wavefront works alone keeps 15 wavefront slots of the CU empty); a wavefront leaves when it is done.  The
   // workgroup's four partial sums: every wavefront leaves its terms in LDS, the LAST one to arrive adds them in wavefront order.
@@ -453,6 +462,15 @@ void spmv_isolated_ms(Engine &e, double *out) {
     for (int rd = 0; rd < rounds; ++rd)
       a5 += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
     out[4] = a5 / rounds;
+    {   // interior groups without the ghost-column sums (VAR & 4), with and without the prefetch; default after them once more
+      double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+      for (int rd = 0; rd < rounds; ++rd) {
+        b0 += timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 6><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr, e.win_flag); });
+        b1 += timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 2><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
+        b2 += timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 4><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr, e.win_flag); });
+      }
+      out[5] = b0 / rounds; out[6] = b1 / rounds; out[7] = b2 / rounds;
+    }
   }
   // RXMD_ISO_COPIES=1: does the pass time depend on WHERE its streams lie?  Four copies of the value and slot arrays held at the same time, the
   // pass on each, twice round (out[2..9]): a property of the buffer repeats in the second round, a drift in time does not.  out[10]: the last
@@ -827,8 +845,8 @@ void Engine::tune_window_placement() {
     for (int r = 0; r < 35; ++r) {
       if (r == 5) hipEventRecord(ev[2], stream);
       if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
-      else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
-      else k_spmv_win<MODE_HSH, true, false, 2, 2><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
+      else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3, 4><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
+      else k_spmv_win<MODE_HSH, true, false, 2, 6><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
     }
     hipEventRecord(ev[3], stream); hipEventSynchronize(ev[3]);
     hipEventElapsedTime(&ms, ev[2], ev[3]);
@@ -894,8 +912,8 @@ void Engine::qeq() {
       if (ng == 0) return 0;
       const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
       const bool one_trip = !ff.pqeq && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
-#define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag); \
-                              else k_spmv_win<M, S, P, 2, 2><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag); } while (0)
+#define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3, 4><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); \
+                              else k_spmv_win<M, S, P, 2, 6><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); } while (0)
 #define RX_WIN(M, S) do { if (ff.pqeq) RX_WIN3(M, S, true); else RX_WIN3(M, S, false); } while (0)
       if (mode == MODE_HSH) { if (store) RX_WIN(MODE_HSH, true); else RX_WIN(MODE_HSH, false); }
       else { if (store) RX_WIN(MODE_GRAD, true); else RX_WIN(MODE_GRAD, false); }

@@ -8,5 +8,5 @@ e.QEq(); e.FORCE(); e.step(2)
 os.environ["RXMD_ISO_REPS"] = "100"
 for rep in range(4):
     iso = e.debug(104, cap=20)
-    print("window(2,0) %.4f  row %.4f  win(3,0) %.4f  win(2,pre) %.4f  window again %.4f || win8 (two rows per wavefront) %.4f  win(2,pre) %.4f  win(3,pre) %.4f  max |row-sum diff win8 - win| %.3e" % (iso[0], iso[1], iso[2], iso[3], iso[4], iso[9], iso[10], iso[11], iso[12]), flush=True)
+    print("window(2,0) %.4f  row %.4f  win(3,0) %.4f  win(2,pre) %.4f  window again %.4f || lean interior groups + pre %.4f  win(2,pre) %.4f  lean without pre %.4f" % (iso[0], iso[1], iso[2], iso[3], iso[4], iso[5], iso[6], iso[7]), flush=True)
 e.close()
