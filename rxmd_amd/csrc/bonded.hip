@@ -66,7 +66,7 @@ __device__ inline void angle_forces(double coeff, const V3 &rij, double nij, con
 //   B  one thread per resident: the sums in slot order (the order of the loop this replaces), the lone-pair / over- / under-coordination energies
 //      and the six coefficients every bond of the atom needs (pot.F90:226-281)
 //   C  one lane per bond of a resident: the coefficients applied to the bond (pot.F90:282-305)
-__global__ void __launch_bounds__(256) k_ebond_terms(int nb_res, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const int *__restrict__ type,
+__global__ void __launch_bounds__(256) k_ebond_terms(int nb_res, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ type,
                                                       const long long *__restrict__ gid, const double *__restrict__ bo0, const double *__restrict__ bo1,
                                                       const double *__restrict__ bo2, const double *__restrict__ bo3, const double *__restrict__ delta, const double *__restrict__ deltalp,
                                                       double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ ecoa,
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) k_ebond_terms(int nb_res, DevFF ff, const
   double e1 = 0.0;
   if (o < nb_res) {
     const int i = bown[o], j = nbr[o];
-    const int tj = type[j];
+    const int tj = btype[o];
     const DevBondP bp = ff.bond[ff.inxn2[type[i] * ff.n1 + tj]];
     const double B0 = bo0[o], dj = delta[j];
     t1[o] = bp.povun1 * bp.Desig * B0;                                  // pot.F90:223
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_elnpr_atoms(int N, DevFF ff, const int 
   block_energy_add(e2, pe + 2); block_energy_add(e3, pe + 3); block_energy_add(e4, pe + 4);
 }
 
-__global__ void __launch_bounds__(256) k_elnpr_bonds(int nb_res, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const int *__restrict__ type,
+__global__ void __launch_bounds__(256) k_elnpr_bonds(int nb_res, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ type,
                                                       const double *__restrict__ bo2, const double *__restrict__ bo3, const double *__restrict__ delta, const double *__restrict__ deltalp,
                                                       const double *__restrict__ dDlp, const double *__restrict__ ecoef,
                                                       double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn) {
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) k_elnpr_bonds(int nb_res, DevFF ff, const
   const int i = bown[o], j = nbr[o];
   const double *c = ecoef + 6 * static_cast<size_t>(i);
   const double CElp1 = c[0], CEo3 = c[1], CEo1 = c[2], CEu3 = c[3], CEo4 = c[4], CEu4 = c[5];
-  const DevBondP bp = ff.bond[ff.inxn2[type[i] * ff.n1 + type[j]]];
+  const DevBondP bp = ff.bond[ff.inxn2[type[i] * ff.n1 + btype[o]]];
   const double bpp = bo2[o] + bo3[o], dj = delta[j] - deltalp[j], oneD = 1.0 - dDlp[j];
   const double CEo5 = CEo1 * bp.povun1 * bp.Desig;
   const double CElp_b = CElp1 + CEo3 + CEo5 + CEu3;
@@ -180,7 +180,7 @@ constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages
 // above the cut-off -- 3.5 -> 2.8 ms while the loops walked slots; once they walk set bits (below) a lane's trip count is its own
 // pair count, and the sorted order only scatters the slot-major accesses, one 64-byte line per lane: 2.7 ms sorted, 1.8 ms in atom
 // order, sorted inside tiles of 128 / 256 / 512 / 1024 atoms 1.84 / 1.97 / 2.86 / 4.19 ms.)
-__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const int *__restrict__ type,
+__global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
                                               const double *__restrict__ delta, const double *__restrict__ nlp, const double *__restrict__ dDlp,
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const in
       mi &= mi - 1u;
       const int oi = ob + i1;
       const double BOij_f = bo0[oi], BOij = BOij_f - cutof2_esub;
-      const int i = nbr[oi], ti = type[i];
+      const int i = nbr[oi], ti = btype[oi];
       const V3 rij = {x[i] - xj, y[i] - yj, z[i] - zj};
       const double nij = sqrt(dot(rij, rij));
       double ai_cf = 0.0, ai_cd = 0.0, ai_fx = 0.0, ai_fy = 0.0, ai_fz = 0.0;      // the i-j bond's own sums over k1: one write after the loop
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const in
         const int ok = ob + k1;
         const double BOjk_f = bo0[ok], BOjk = BOjk_f - cutof2_esub;
         if (!(BOij_f * BOjk_f > cutof2_esub)) continue;
-        const int k = nbr[ok], tk = type[k];
+        const int k = nbr[ok], tk = btype[ok];
         const int inxn = ff.inxn3[(ti * ff.n1 + tj) * ff.n1 + tk];
         if (inxn == 0) continue;
         const DevAngleP ap = ff.angle[inxn];
@@ -340,7 +340,7 @@ struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // lattice 
 // evaluating lane adding its results to the (atom, slot) accumulators in LDS (ds_add_f64): no global atomics, and the order of the
 // additions is fixed by the queue order and the lane order inside one LDS instruction.
 template <int LSL>
-__global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+__global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
                                               const double *__restrict__ etor, const double *__restrict__ econ,
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
   bool cap_me = false;
   if (sl_me < nj_me) {
     const int o = ob_me + sl_me;
-    const int i = nbr[o], ti = type[i];
+    const int i = nbr[o], ti = btype[o];
     const double rx = x[i] - xj_me, ry = y[i] - yj_me, rz = z[i] - zj_me;      // r_i - r_j
     const double b = bo0[o];
     cap_me = b > cutof2_esub;
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
         const unsigned sub = static_cast<unsigned>(ml >> (cbl * KW)) & ((KW == 32) ? 0xffffffffu : 0xffffu);
         const int pos = cbl * KW + __popc(sub & ((1u << ks) - 1u));
         const int l = nbr[bk + ks];
-        s_capl[w][pos] = ks; s_bokl[w][pos] = bl; s_ll[w][pos] = l; s_tl[w][pos] = type[l];
+        s_capl[w][pos] = ks; s_bokl[w][pos] = bl; s_ll[w][pos] = l; s_tl[w][pos] = btype[bk + ks];      // (no gather behind the load of l)
       }
     }
     // what the combinations of each centre bond of the round need, written by lanes 0..CPB-1: the combinations of all of them are
@@ -865,11 +865,11 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int S10, DevFF ff, const int
 
 void Engine::bonded_energies() {
   double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
-  k_ebond_terms<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, cf1, cf2, cf3, ecoa, bt1, bt2, pe_d);
+  k_ebond_terms<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, btype, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, cf1, cf2, cf3, ecoa, bt1, bt2, pe_d);
   k_elnpr_atoms<<<nblk(N, 256), 256, 0, stream>>>(N, dff, boff, type, bt1, bt2, delta, deltalp, dDlp, ecoef, pe_d);
-  k_elnpr_bonds<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, type, bo2, bo3, delta, deltalp, dDlp, ecoef, cf1, cf2, cf3, cdn);
+  k_elnpr_bonds<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, btype, type, bo2, bo3, delta, deltalp, dDlp, ecoef, cf1, cf2, cf3, cdn);
 const bool kt3 = kt_begin(&st.ms_k_e3b);
-    k_e3b<<<nblk(N, 256), 256, 4 * 5 * E3B_CAP * sizeof(double), stream>>>(N, dff, boff, nbr, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+    k_e3b<<<nblk(N, 256), 256, 4 * 5 * E3B_CAP * sizeof(double), stream>>>(N, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
   kt_end(kt3);
   BoxImg bx;
@@ -886,13 +886,13 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
   const int want = std::getenv("RXMD_E4B_SLOTS") ? std::atoi(std::getenv("RXMD_E4B_SLOTS")) : 0;
   const bool narrow = h_err[2] <= 15 && want != 32 && want != 4;
   const bool kt4 = kt_begin(&st.ms_k_e4b);
-  if (want == 4) k_e4b<1><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  if (want == 4) k_e4b<1><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                                        cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, dff, boff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  else if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  else if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, dff, boff, nbr, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+  else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                  cds, frc[0], frc[1], frc[2], pe_d, bx);
   int ehb_probe = 0;
 #ifdef RXMD_EXPERIMENTS

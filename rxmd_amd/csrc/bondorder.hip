@@ -14,7 +14,7 @@ namespace rxmd {
 
 static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
-__global__ void __launch_bounds__(256) k_bo_prime(int nbonds, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr,
+__global__ void __launch_bounds__(256) k_bo_prime(int nbonds, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const unsigned char *__restrict__ btype,
                                                    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, const int *__restrict__ type,
                                                    double *__restrict__ bo0, double *__restrict__ bo2, double *__restrict__ bo3,
                                                    double *__restrict__ dln2, double *__restrict__ dln3, double *__restrict__ dBOp) {
@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256) k_bo_prime(int nbonds, DevFF ff, const in
   if (o >= nbonds) return;
   const int i = bown[o], j = nbr[o];
   const double cut = ff.cutoff_vpar30;
-  const DevBondP bp = ff.bond[ff.inxn2[type[i] * ff.n1 + type[j]]];
+  const DevBondP bp = ff.bond[ff.inxn2[type[i] * ff.n1 + btype[o]]];
   const double d0 = x[i] - x[j], d1 = y[i] - y[j], d2 = z[i] - z[j];
   const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
   const double a1 = bp.cBOp1 * pow(r2, bp.pbo2h), a2 = bp.cBOp3 * pow(r2, bp.pbo4h), a3 = bp.cBOp5 * pow(r2, bp.pbo6h);  // bo.F90:67-69
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) k_deltap(int G, DevFF ff, const int *__re
   deltap[i] = sum;
 }
 
-__global__ void __launch_bounds__(256) k_bo_full(int nbonds, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const int *__restrict__ type,
+__global__ void __launch_bounds__(256) k_bo_full(int nbonds, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ type,
                                                   const double *__restrict__ deltap, double *__restrict__ bo0, double *__restrict__ bo1, double *__restrict__ bo2, double *__restrict__ bo3,
                                                   double *__restrict__ A0, double *__restrict__ A1, double *__restrict__ A2, double *__restrict__ A3,
                                                   double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_bo_full(int nbonds, DevFF ff, const int
   const int o = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (o >= nbonds) return;
   const int i = bown[o], j = nbr[o];
-  const int ti = type[i], tj = type[j];
+  const int ti = type[i], tj = btype[o];
   const DevAtomP ai = ff.atom[ti], aj = ff.atom[tj];
   const double dpi = deltap[i];
   const double dp2i = dpi + ai.Val - ai.Valval;        // deltap(i,2), bo.F90:151
@@ -134,9 +134,9 @@ __global__ void __launch_bounds__(256) k_delta_lp(int G, DevFF ff, const int *__
 }
 
 void Engine::bond_orders() {
-  k_bo_prime<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, dff, bown, nbr, pos[0], pos[1], pos[2], type, bo0, bo2, bo3, dln2, dln3, dBOp);
+  k_bo_prime<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, dff, bown, nbr, btype, pos[0], pos[1], pos[2], type, bo0, bo2, bo3, dln2, dln3, dBOp);
   k_deltap<<<nblk(G, 256), 256, 0, stream>>>(G, dff, boff, type, bo0, deltap);
-  k_bo_full<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, dff, bown, nbr, type, deltap, bo0, bo1, bo2, bo3, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen);
+  k_bo_full<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, dff, bown, nbr, btype, type, deltap, bo0, bo1, bo2, bo3, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen);
   k_delta_lp<<<nblk(G, 256), 256, 0, stream>>>(G, dff, boff, type, bo0, delta, nlp, dDlp, deltalp, cds, frc[0], frc[1], frc[2]);
 }
 

@@ -192,6 +192,7 @@ struct Engine {
   // bonded tables, compact: boff[i] .. boff[i + 1] are the bonds of atom i (residents and ghosts) in list order; per bond its partner (nbr), its owner
   // (bown) and its mirror image, the same bond in the partner's list (brev = the reference's nbrindx, main.F90:383-399, as a direct index)
   int *nbr = nullptr, *nbrcnt = nullptr, *boff = nullptr, *brev = nullptr, *bown = nullptr;
+  unsigned char *btype = nullptr; // per bond: type of the partner atom
   int *nbr_sm = nullptr;          // slot-major staging of the list sweep [slot * NB + atom] (a thread appends without knowing the totals)
   size_t bcap = 0; int nbonds = 0; // capacity of the per-bond arrays (grown on demand) / bonds of the current build
   void alloc_bond_tables(size_t cap); void free_bond_tables();

@@ -386,11 +386,11 @@ void Engine::alloc_device() {
 
 void Engine::alloc_bond_tables(size_t cap) {
   bcap = std::max<size_t>(cap, 1024);
-  dmalloc(nbr, bcap); dmalloc(brev, bcap); dmalloc(bown, bcap);
+  dmalloc(nbr, bcap); dmalloc(brev, bcap); dmalloc(bown, bcap); dmalloc(btype, bcap);
   for (double **t : {&bo0, &bo1, &bo2, &bo3, &dln2, &dln3, &dBOp, &A0, &A1, &A2, &A3, &cf1, &cf2, &cf3, &cdn, &fnx, &fny, &fnz, &etor, &econ, &epen, &ecoa, &bt1, &bt2, &bt3}) dmalloc(*t, bcap);
 }
 void Engine::free_bond_tables() {
-  dfree(nbr); dfree(brev); dfree(bown);
+  dfree(nbr); dfree(brev); dfree(bown); dfree(btype);
   for (double **t : {&bo0, &bo1, &bo2, &bo3, &dln2, &dln3, &dBOp, &A0, &A1, &A2, &A3, &cf1, &cf2, &cf3, &cdn, &fnx, &fny, &fnz, &etor, &econ, &epen, &ecoa, &bt1, &bt2, &bt3}) dfree(*t);
   bcap = 0;
 }
@@ -1317,7 +1317,7 @@ void Engine::poison_step_scratch() {
   fill(cellstart, 0, sizeof(int) * (static_cast<size_t>(grid.nfine) + 2)); fill(sorted_xyzi, 0, sizeof(double4) * nb); fill(sorted_type, 0, nb);
   if (ff.pqeq) { fill(sorted_shl, 0, sizeof(double4) * nb); fill(hsc, 0, sizeof(double) * nl); fill(pqrow, 0, sizeof(double4) * rows10); for (int a = 0; a < 3; ++a) fill(shl[a], sizeof(double) * N, sizeof(double) * ng); }
   fill(nbr_sm, 0, sizeof(int) * ns); fill(nbrcnt, 0, sizeof(int) * (nb + 1)); fill(boff, 0, sizeof(int) * (nb + 2));
-  fill(nbr, 0, sizeof(int) * bcap); fill(brev, 0, sizeof(int) * bcap); fill(bown, 0, sizeof(int) * bcap);
+  fill(nbr, 0, sizeof(int) * bcap); fill(brev, 0, sizeof(int) * bcap); fill(bown, 0, sizeof(int) * bcap); fill(btype, 0, bcap);
   for (double *t : {bo0, bo1, bo2, bo3, dln2, dln3, dBOp, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen, ecoa, bt1, bt2, bt3}) fill(t, 0, sizeof(double) * bcap);
   fill(ecoef, 0, sizeof(double) * 6 * nb);
   for (double *t : {deltap, delta, nlp, dDlp, deltalp, cds, cd, cc_}) fill(t, 0, sizeof(double) * nb);

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, G
 // and its MIRROR brev[o] = boff[j] + j1 with nbrlist(j, j1) == i -- the reference's nbrindx (main.F90:383-399) as a direct index into the
 // compact tables.  Every per-bond array of the engine is indexed by o: 5.3 entries per RDX atom instead of a 30-slot stride.
 __global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict__ nbr_sm, const int *__restrict__ nbrcnt, const int *__restrict__ boff,
-                           int *__restrict__ nbr, int *__restrict__ brev, int *__restrict__ bown, int *err) {
+                           int *__restrict__ nbr, int *__restrict__ brev, int *__restrict__ bown, const int *__restrict__ type, unsigned char *__restrict__ btype, int *err) {
   // one thread per (atom, slot): blockIdx.y = slot; the blocks of slots no atom of theirs uses leave after one coalesced read of the counts
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x, s = blockIdx.y;
   if (i >= G) return;
@@ -163,7 +163,7 @@ __global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict_
   for (int t = 0; t < nj; ++t)
     if (nbr_sm[static_cast<size_t>(t) * NB + j] == i) found = t;
   if (found < 0) { atomicCAS(&err[0], DERR_NONE, DERR_NBRINDX); found = 0; }
-  nbr[ob + s] = j; brev[ob + s] = boff[j] + found; bown[ob + s] = i;
+  nbr[ob + s] = j; brev[ob + s] = boff[j] + found; bown[ob + s] = i; btype[ob + s] = static_cast<unsigned char>(type[j]);   // the partner's type rides with the bond: one dependent gather less where a kernel walks another atom's list
 }
 
 // get_coulomb_and_dcoulomb_pqeq (reference src/module.F90:401-418): energy kernel and (1/r) dE/dr at squared distance r2.
@@ -525,7 +525,7 @@ void Engine::build_bonded_list() {
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, nbrcnt, boff, G + 1, stream));
   RX_HIP(hipMemcpyAsync(d_err + 7, boff + G, sizeof(int), hipMemcpyDeviceToDevice, stream));   // bonds of this build: read with the error word the host waits for anyway
   RX_HIP(hipMemcpyAsync(d_err + 9, boff + N, sizeof(int), hipMemcpyDeviceToDevice, stream));   // ... and the residents' share of them
-  k_bond_csr<<<dim3(nblk(G, 256), MAXNB), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, d_err);
+  k_bond_csr<<<dim3(nblk(G, 256), MAXNB), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, type, btype, d_err);
 }
 
 void Engine::build_list10() {
