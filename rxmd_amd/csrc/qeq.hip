@@ -827,13 +827,13 @@ void Engine::allreduce_scal4(int n) {
 // Where the streams of the window pass lie in physical memory is worth up to 15 % of its time (the same pass on copies of the same
 // arrays runs 0.77 ... 0.90 ms, a property of the buffer, repeatable to 0.1-0.5 %, drawn anew by every hipMalloc).  So, once per engine, after the
 // first QEq call that used the window pass: a few more placements of the value / slot (/ shell-core) arrays are tried, each timed with 30 launches
-// of the real pass, and the fastest is kept.  RXMD_PLACE_TRIES=<n> (default 6 placements including the first; 1 switches the search off).
+// of the real pass, and the fastest is kept.  RXMD_PLACE_TRIES=<n> (default: up to 10 placements including the first, stopping once one is 8 % faster than the slowest seen; 1 switches the search off).
 // One-time cost ~35 ms per placement, +6.3 GB of memory while a candidate is alive (979,776 atoms).  Measured, fresh processes alternating on one
 // box, default bench: 52.4-54.1 ms/step with the search against 53.4-55.6 without (the pass in the loop follows the kept placement + 0.03-0.04 ms).
 void Engine::tune_window_placement() {
   place_tuned = true;
   const char *ev_t = std::getenv("RXMD_PLACE_TRIES");
-  const int tries = ev_t ? std::atoi(ev_t) : 6;
+  const int tries = ev_t ? std::atoi(ev_t) : 10;       // (round 4: the draws of one box lie between 0.80 and 0.93 ms, a third of them fast: ten draws miss the fast kind in 3 % of the processes, six in 12 %)
   if (tries <= 1 || !win_valid || N < 65536) return;              // (small systems: nothing to gain)
   const size_t ne = static_cast<size_t>(rows10) * S10;
   {   // a candidate needs a second copy of the streams while it is timed (6.3 GB at 979,776 atoms): not on a device that is nearly full
@@ -859,6 +859,7 @@ void Engine::tune_window_placement() {
   };
   double best = time_pass(hess, sl10, hsc);
   st.place_ms_first = best;
+  double worst = best;
   for (int c = 1; c < tries; ++c) {
     Cand cd_;
     double *&h2 = cd_.h, *&c2 = cd_.c; unsigned short *&s2 = cd_.s;
@@ -871,8 +872,10 @@ void Engine::tune_window_placement() {
     RX_HIP(hipMemcpyAsync(s2, sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, stream));
     if (ff.pqeq) RX_HIP(hipMemcpyAsync(c2, hsc, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
     const double t = time_pass(h2, s2, ff.pqeq ? c2 : hsc);
+    worst = std::max(worst, t);
     if (t < 0.99 * best) { best = t; std::swap(hess, h2); std::swap(sl10, s2); if (ff.pqeq) std::swap(hsc, c2); }
     // (cd_ frees the loser; the stream is idle: time_pass waited for its last launch)
+    if (best < 0.92 * worst && c >= 3) break;          // a placement of the fast kind is in hand (and a slow one was seen): stop drawing
   }
   st.place_ms_kept = best;
 }
