@@ -179,7 +179,10 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
 // (A timing probe with synthetic slots promised 0.76 against 0.93 ms of k_spmv before anything real was built; the real pass: 0.80 against 0.89 ms
 // back to back in one process, DESIGN.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
-template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR & 2: the second batch of a row is requested before the workgroup's barrier (below); VAR & 4: groups without a ghost partner skip the ghost-column sums (below); the default of plain QEq is 6.  NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
+// FORM (bit set): WIN_PREFETCH = the second batch of a row is requested before the workgroup's barrier; WIN_LEAN = groups without a ghost partner skip the
+// ghost-column sums; WIN_RANKROWS = experiments build only.  Plain QEq runs WIN_PREFETCH | WIN_LEAN (one-trip rows: WIN_LEAN), PQEq 0.
+constexpr int WIN_RANKROWS = 1, WIN_PREFETCH = 2, WIN_LEAN = 4;
+template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR = FORM bits; VAR & 2: the second batch of a row is requested before the workgroup's barrier (below); VAR & 4: groups without a ghost partner skip the ghost-column sums (below); the default of plain QEq is 6.  NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   const int wk0 = wk[t0 / WIN_UNIT], wk1 = wk[t1 / WIN_UNIT];                      // (t1 / 8 < 256 <= WIN_MAXUNITS)
   const bool live = row < N;
 #ifdef RXMD_EXPERIMENTS
-  const size_t base = static_cast<size_t>(live ? ((VAR & 1) ? ridx : row) : 0) * S10;       // (VAR & 1, experiment: the streams' rows in cell-sorted order)
+  const size_t base = static_cast<size_t>(live ? ((VAR & WIN_RANKROWS) ? ridx : row) : 0) * S10;       // (VAR & 1, experiment: the streams' rows in cell-sorted order)
 #else
   const size_t base = static_cast<size_t>(live ? row : 0) * S10;
 #endif
@@ -254,7 +257,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   // VAR & 2 (plain QEq): the row's NEXT batch is requested before the barrier, behind the window's data (a wavefront's loads return in order:
   // the window does not wait for it) -- the round trip of the second batch runs under the barrier and the first batch's arithmetic instead of
   // after it; the batch after that is requested before the current one is used, and so on.
-  constexpr bool PRE = (VAR & 2) != 0 && !PQ;
+  constexpr bool PRE = (VAR & WIN_PREFETCH) != 0 && !PQ;
   double2 vn[STEPS]; unsigned sn[STEPS];
   auto request_next = [&](int kb) {
 #pragma unroll
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   // VAR & 4: a group none of whose rows has a ghost partner (gflags[grp] == 0: three groups in four of a large domain) takes a loop WITHOUT the
   // ghost-column sums -- two selects and four FMAs of the twelve vector instructions per pair of entries, and two of the four reductions.  The
   // choice is one scalar branch per workgroup around two straight-line loops, not a branch per row inside one (round 3: that lost).
-  const bool gh = !((VAR & 4) != 0 && !PQ && gflags != nullptr) || gflags[grp] != 0;
+  const bool gh = !((VAR & WIN_LEAN) != 0 && !PQ && gflags != nullptr) || gflags[grp] != 0;
   auto products = [&](auto ghc) {
     constexpr bool GHC = decltype(ghc)::value;
     for (int kb = 0; kb < n; kb += 128 * STEPS) {     // wave-uniform trip count
@@ -850,8 +853,8 @@ void Engine::tune_window_placement() {
     for (int r = 0; r < 35; ++r) {
       if (r == 5) hipEventRecord(ev[2], stream);
       if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
-      else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3, 4><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
-      else k_spmv_win<MODE_HSH, true, false, 2, 6><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
+      else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
+      else k_spmv_win<MODE_HSH, true, false, 2, WIN_PREFETCH | WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
     }
     hipEventRecord(ev[3], stream); hipEventSynchronize(ev[3]);
     hipEventElapsedTime(&ms, ev[2], ev[3]);
@@ -920,8 +923,8 @@ void Engine::qeq() {
       if (ng == 0) return 0;
       const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
       const bool one_trip = !ff.pqeq && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
-#define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3, 4><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); \
-                              else k_spmv_win<M, S, P, 2, 6><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); } while (0)
+#define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3, WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); \
+                              else k_spmv_win<M, S, P, 2, WIN_PREFETCH | WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); } while (0)
 #define RX_WIN(M, S) do { if (ff.pqeq) RX_WIN3(M, S, true); else RX_WIN3(M, S, false); } while (0)
       if (mode == MODE_HSH) { if (store) RX_WIN(MODE_HSH, true); else RX_WIN(MODE_HSH, false); }
       else { if (store) RX_WIN(MODE_GRAD, true); else RX_WIN(MODE_GRAD, false); }
