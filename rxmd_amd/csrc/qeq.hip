@@ -688,8 +688,8 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
     const double2 hv = hst[i];
     qv.x = qv.x + l1 * hv.x; qv.y = qv.y + l2 * hv.y;
     qst[i] = qv;
-    // plain QEq (n10 given): the ghost-column sums of a row without a ghost partner are identically zero -- three rows in four of a large
-    // domain -- and are neither read nor written (48 of the 164 bytes the kernel moves per row)
+    // (n10 given: the ghost-column sums of a row without a ghost partner -- identically zero -- are neither read nor written.  Measured: 38 against
+    //  33 us per launch, the predicated accesses cost more than the 48 of 164 bytes per row they save; no caller passes n10.)
     const bool ghr = n10 == nullptr || (n10[i] & N10_GHOST_ROW) != 0;
     double2 a = sall[i], g = make_double2(0.0, 0.0);
     const double2 wa = wall[i];
@@ -1005,7 +1005,7 @@ void Engine::qeq() {
       const int np1 = pass(MODE_HSH, true, wall, wgh);
       hipEventRecord(ev_pass[k & 1][1], stream);
       reduce(1, np1);
-      k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag, n10);
+      k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag);
       // Est and the stop flags of this iteration travel to the host on the second stream, from the snapshot the update kernel's tail left: the
       // copy (a 4 us blit kernel) no longer sits between the update and the direction kernel
       // (large systems only: where an iteration is shorter than the host's own work per iteration -- small boxes, tight tolerance -- the host
@@ -1078,7 +1078,7 @@ void Engine::qeq() {
       // iteration instead of three; any rank count: Est is final BEFORE the direction kernel, so its copy to the host, the host's exit
       // test and the launch of the next matrix pass all run underneath the direction update and the sorted copy / halo
       const bool est3 = !ff.pqeq && est_with_update;
-      if (est3) k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 6 : 0, nullptr, n10);
+      if (est3) k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 6 : 0, nullptr);
       else k_cg_update<false><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, fuse ? 4 : 0, nullptr);
       if (!fuse) { allreduce_scal4(est3 ? 8 : 4); k_scalar_algebra<<<1, 64, 0, stream>>>(est3 ? 6 : 4, scal); }
       if (est3) { RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream)); RX_HIP(hipEventRecord(ev_est, stream)); }
