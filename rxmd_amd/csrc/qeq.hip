@@ -678,8 +678,7 @@ __global__ void __launch_bounds__(256) k_update_qst(int N, const double *__restr
 template <bool EST3>
 __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ hst, double2 *__restrict__ qst,
                                                     const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
-                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage, const double *__restrict__ stopflag,
-                                                    const int *__restrict__ n10 = nullptr) {
+                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage, const double *__restrict__ stopflag) {
   if (stopflag && *stopflag != 0.0) return;
   const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
   double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0;
@@ -688,14 +687,12 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
     const double2 hv = hst[i];
     qv.x = qv.x + l1 * hv.x; qv.y = qv.y + l2 * hv.y;
     qst[i] = qv;
-    // (n10 given: the ghost-column sums of a row without a ghost partner -- identically zero -- are neither read nor written.  Measured: 38 against
-    //  33 us per launch, the predicated accesses cost more than the 48 of 164 bytes per row they save; no caller passes n10.)
-    const bool ghr = n10 == nullptr || (n10[i] & N10_GHOST_ROW) != 0;
-    double2 a = sall[i], g = make_double2(0.0, 0.0);
-    const double2 wa = wall[i];
-    a.x += l1 * wa.x; a.y += l2 * wa.y;
-    sall[i] = a;
-    if (ghr) { g = sgh[i]; const double2 wg = wgh[i]; g.x += l1 * wg.x; g.y += l2 * wg.y; sgh[i] = g; }
+    // (skipping the ghost-column sums of rows without a ghost partner -- identically zero, 48 of the 164 bytes per row -- behind a per-row flag was
+    //  measured: 38 against 33 us per launch, the predicated accesses cost more than they save)
+    double2 a = sall[i], g = sgh[i];
+    const double2 wa = wall[i], wg = wgh[i];
+    a.x += l1 * wa.x; a.y += l2 * wa.y; g.x += l1 * wg.x; g.y += l2 * wg.y;
+    sall[i] = a; sgh[i] = g;
     const DevAtomP ap = ff.atom[type[i]];
     const double g1 = -ap.chi - ap.eta * qv.x - a.x - (pqrow ? pqrow[i].x : 0.0), g2 = -1.0 - ap.eta * qv.y - a.y;
     gst[i] = make_double2(g1, g2);

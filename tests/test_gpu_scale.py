@@ -279,3 +279,18 @@ def test_forces_of_the_full_size_water_and_sicnp_crystals_by_periodicity(case, m
     e.set_charges(np.tile(qo[inner], natoms // n0))
     e.FORCE(); a = e.atoms(); e.close()
     assert f_err(inner_of(a["f"], (3,)), fref) <= FTOL
+
+
+def test_without_the_window_form_every_consumer_falls_back(oracle36k, monkeypatch):
+    """RXMD_SPMV_NO_WIN=1: what a list build whose windows do not fit does (more than 448 units in a group) -- the QEq passes run as row passes
+    (k_spmv) and ENbond as one wavefront per row with its 32-byte gather (k_nonbond) from the 4-byte entries.  Same step-0 state and the same
+    three MD steps as the default against the oracle."""
+    s0, s1 = oracle36k
+    monkeypatch.setenv("RXMD_SPMV_NO_WIN", "1")
+    e = _engine36k(1)
+    it, est = e.QEq(); pe = e.FORCE()
+    assert e.stats()["win_in_use"] == 0
+    _check_step0(e, s0, it, est, pe)
+    e.step(NSTEPS)
+    _check_trajectory(e, s1, s0)
+    e.close()
