@@ -274,8 +274,6 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   double *sr2 = s_r2[w];
   long long *sw = s_w[w];
   int *cP = s_P[w], *cK = s_K[w], *cE = s_E[w];
-  const int c = cellid[i];
-  const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
   const double xi = x[i], yi = y[i], zi = z[i];
   const int ti = type[i];
   const size_t row = static_cast<size_t>(i) * S10;

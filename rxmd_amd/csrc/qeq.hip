@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // back to back in one process, DESIGN.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
 // FORM (bit set): WIN_PREFETCH = the second batch of a row is requested before the workgroup's barrier; WIN_LEAN = groups without a ghost partner skip the
 // ghost-column sums; WIN_RANKROWS = experiments build only.  Plain QEq runs WIN_PREFETCH | WIN_LEAN (one-trip rows: WIN_LEAN), PQEq 0.
-constexpr int WIN_RANKROWS = 1, WIN_PREFETCH = 2, WIN_LEAN = 4;
+[[maybe_unused]] constexpr int WIN_RANKROWS = 1;
+constexpr int WIN_PREFETCH = 2, WIN_LEAN = 4;
 template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR = FORM bits; VAR & 2: the second batch of a row is requested before the workgroup's barrier (below); VAR & 4: groups without a ghost partner skip the ghost-column sums (below); the default of plain QEq is 6.  NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
