@@ -231,6 +231,7 @@ def vprocs_for(n):
 
 
 def main():
+    t_bench0 = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -569,6 +570,7 @@ def main():
             out["other_configs"] = other
         if cb:
             out["cpu_baseline"] = cb
+        out["bench_wall_s"] = round(time.time() - t_bench0, 1)      # the whole run: every leg, the CPU baseline, set-up (not part of `value`)
         import ctypes
         ctypes.CDLL(None).fflush(None)          # C-level stdout first (RCCL prints a version banner there): the JSON line stays last
         sys.stdout.flush()
