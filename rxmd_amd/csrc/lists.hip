@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   __shared__ int s_q[4][128];            // accepted candidates: sorted position ...
   __shared__ double s_r2[4][128];        // ... their squared distance (the exact FP64 value of the test) ...
   __shared__ long long s_w[4][128];      // ... and (column of the row << 40 | type << 32 | atom index): the dense phase needs no second gather of the candidate
-  __shared__ int s_P[4][32], s_K[4][32], s_E[4][32];  // per stencil column of a row: candidates before it / first sorted position of its run / slot base of the column in the group's window
+  __shared__ int s_K[4][32], s_E[4][32];  // per stencil column of a row: first sorted position of its run - candidates before it / slot base of the column in the group's window
   __shared__ int s_ix2[256];             // inxn2 row of the row's type would do; the whole (n1 x n1) table is 64-256 words
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
   for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) s_ix2[t] = ff.inxn2[t];
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   int *sq = s_q[w];
   double *sr2 = s_r2[w];
   long long *sw = s_w[w];
-  int *cP = s_P[w], *cK = s_K[w], *cE = s_E[w];
+  int *cK = s_K[w], *cE = s_E[w];
   const double xi = x[i], yi = y[i], zi = z[i];
   const int ti = type[i];
   const size_t row = static_cast<size_t>(i) * S10;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   };
 
   // the 25 stencil columns: lane t < 25 owns column t; an inclusive scan over the lanes lays the runs end to end
-  int L;
+  int L, myP;
   {   // the row's 25 candidate runs and the slot bases of its group's stencil columns, as k_win_columns left them
     int k0 = 0, len = 0, gb = 0;
     if (lane < 32) { k0 = rowcols[static_cast<size_t>(ridx) * 64 + lane]; len = rowcols[static_cast<size_t>(ridx) * 64 + 32 + lane]; gb = grp_base[static_cast<size_t>(grp) * 32 + lane]; }
@@ -383,13 +383,19 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
       const int l2 = __shfl_up(lpre, o, 64);
       if (lane >= o) lpre += l2;
     }
-    if (lane < 32) { cP[lane] = lpre - len; cK[lane] = k0; cE[lane] = gb; }
+    if (lane < 32) { cK[lane] = k0 - (lpre - len); cE[lane] = gb; }
+    myP = (lane < 32) ? lpre - len : 0x7fffffff;   // candidates before column `lane` (columns 25..31: L)
     L = __shfl(lpre, 31, 64);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #ifdef RXMD_EXPERIMENTS
   if (g.probe == 1) { if (lane == 0) n10[i] = L; return; }
 #endif
+  // The column of a candidate = the last one that starts at or before it.  Candidates are walked in order, so the wavefront keeps the next column
+  // boundary it has not passed (tn, a scalar; the boundaries sit one per lane in myP and are read with v_readlane): a batch of 64 candidates
+  // starts in column tn - 1 and a lane adds one for every boundary of the batch at or below its candidate -- 1.2 boundaries per batch on
+  // average, where a binary search over the 32 entries in LDS took five dependent reads per candidate.
+  int tn = 1;
   for (int c0 = 0; c0 < L; c0 += 256) {
     // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
     int kk[4], tcol[4];
@@ -399,10 +405,14 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
     for (int u = 0; u < 4; ++u) {
       const int cc = c0 + 64 * u + lane;
       ok[u] = cc < L;
-      int t = 0;                                 // the column of candidate cc: the last one that starts at or before it
-#pragma unroll
-      for (int st = 16; st > 0; st >>= 1) t += (cP[t + st] <= cc) ? st : 0;
-      kk[u] = ok[u] ? cK[t] + (cc - cP[t]) : 0;
+      int t = tn - 1;                            // the column of candidate cc
+      for (;;) {
+        const int pm = __builtin_amdgcn_readlane(myP, tn);
+        if (pm > c0 + 64 * u + 63) break;        // (lanes 32.. hold INT_MAX: tn stops at 32)
+        t += (pm <= cc) ? 1 : 0;
+        ++tn;
+      }
+      kk[u] = ok[u] ? cK[t] + cc : 0;
       tcol[u] = t;
       pd[u] = ok[u] ? sorted[kk[u]] : make_double4(0, 0, 0, 0);
     }
