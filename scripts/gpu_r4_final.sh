@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4 final: PMC passes of the head commit (67fb1cb) -> profiles/kernel_traffic.json, then the default bench line (CPU baseline and all legs) and the same GPU legs under the kernel trace
+# round 4 final: PMC passes of the head commit (0b94490) -> profiles/kernel_traffic.json, then the default bench line (CPU baseline and all legs) and the same GPU legs under the kernel trace
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O
-COMMIT=67fb1cb bash scripts/gpu_pmc_kernels.sh $1/pmc > $O/pmc.log 2>&1; tail -30 $O/pmc.log | cut -c1-170
+COMMIT=0b94490 bash scripts/gpu_pmc_kernels.sh $1/pmc > $O/pmc.log 2>&1; tail -30 $O/pmc.log | cut -c1-170
 find $O/pmc -name '*.csv' -size +2M -delete; find $O/pmc -name '*.db' -delete
 cp $O/pmc/kernel_traffic.json profiles/kernel_traffic.json
 python3 bench.py > $O/bench_default.log 2>&1; grep '^{"metric' $O/bench_default.log > $O/bench_default.json
