@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -861,8 +862,20 @@ void Engine::tune_window_placement() {
   double best = time_pass(hess, sl10, hsc);
   st.place_ms_first = best;
   double worst = best;
+  const bool verbose = std::getenv("RXMD_PLACE_VERBOSE") != nullptr;
+  if (verbose) std::fprintf(stderr, "[rxmd_hip] placement draw 0: %.4f ms  hess %p sl10 %p\n", best, static_cast<void *>(hess), static_cast<void *>(sl10));
+  const bool draw_all = std::getenv("RXMD_PLACE_ALL") != nullptr;      // diagnosis: no early stop
+  // The losers stay allocated until the search is over: a block that is freed comes straight back from the next hipMalloc of its size, and the
+  // "next draw" would be the same physical placement again (round 4: a process that kept its first placement at 0.90 ms after ten such draws,
+  // while a second process on the same box found 0.82 ms).  Each draw costs a copy of the streams while the search runs, bounded by free memory.
+  std::vector<std::unique_ptr<Cand>> drawn;
   for (int c = 1; c < tries; ++c) {
-    Cand cd_;
+    {
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 2 * ne * (ff.pqeq ? 18 : 10)) { (void)hipGetLastError(); break; }
+    }
+    drawn.push_back(std::make_unique<Cand>());
+    Cand &cd_ = *drawn.back();
     double *&h2 = cd_.h, *&c2 = cd_.c; unsigned short *&s2 = cd_.s;
     // (plain hipMalloc: memory from hipExtMallocWithFlags(hipDeviceMallocContiguous) was the fast kind more often in the copies experiment, but
     // an engine that allocated its streams that way failed 15 unrelated tests of the suite with corrupted results -- not used anywhere)
@@ -874,10 +887,11 @@ void Engine::tune_window_placement() {
     if (ff.pqeq) RX_HIP(hipMemcpyAsync(c2, hsc, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
     const double t = time_pass(h2, s2, ff.pqeq ? c2 : hsc);
     worst = std::max(worst, t);
-    if (t < 0.99 * best) { best = t; std::swap(hess, h2); std::swap(sl10, s2); if (ff.pqeq) std::swap(hsc, c2); }
-    // (cd_ frees the loser; the stream is idle: time_pass waited for its last launch)
-    if (best < 0.92 * worst && c >= 3) break;          // a placement of the fast kind is in hand (and a slow one was seen): stop drawing
+    if (verbose) std::fprintf(stderr, "[rxmd_hip] placement draw %d: %.4f ms  hess %p sl10 %p\n", c, t, static_cast<void *>(h2), static_cast<void *>(s2));
+    if (t < 0.99 * best) { best = t; std::swap(hess, h2); std::swap(sl10, s2); if (ff.pqeq) std::swap(hsc, c2); }   // (cd_ now holds the previous best)
+    if (best < 0.92 * worst && c >= 3 && !draw_all) break;          // a placement of the fast kind is in hand (and a slow one was seen): stop drawing
   }
+  drawn.clear();                                        // frees every loser; the stream is idle: time_pass waited for its last launch
   st.place_ms_kept = best;
 }
 
