@@ -863,6 +863,159 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int S10, DevFF ff, const int
   block_energy_add(e10, pe + 10);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Hydrogen bonds, round 5: two kernels instead of one search-and-sweep.  The counters of the one-kernel form (profiles/r05_a_sq_*): 61,240
+// wavefronts that each live ~60 us, 87 % of it parked on s_waitcnt behind ~66 dependent loads (the donor search walks type[nbr[o]] and
+// bo0[o] slot by slot; then position, row, hydrogen, candidates one round trip after the other), the vector unit busy 6 % of the time, and
+// 22 M atomic requests at the memory side for the 51 M acceptor-force additions.
+//   k_ehb_donors  one thread per resident: the slots of its bond list that hold a hydrogen (type 2, pot.F90:595) with BO > MINBO0, from the
+//                 CSR tables (the partner's type rides with the bond: no gather); atoms with one are appended to a donor list (ballot + one
+//                 atomic per wavefront; the order of the list is arbitrary -- every sum behind it is an atomic or owned by one wavefront).
+//   k_ehb_sweep   a persistent grid; a wavefront takes whole donors: the row's acceptor candidates are compacted into LDS (<= EHB_CAP at a time),
+//                 their positions gathered ONCE into LDS, then every hydrogen slot of the donor walks the staged candidates four dense batches
+//                 at a time out of LDS -- no load inside the evaluation -- and the acceptor's force is summed over the hydrogen slots in
+//                 registers before its three atomics (an RDX carbon-bound... nitrogen sees two hydrogens: half the atomic requests).
+constexpr int EHB_CAP = 256;                              // candidates staged per flush (a 447-entry RDX row has <= 255 N / O partners)
+__global__ void __launch_bounds__(256) k_ehb_donors(int N, unsigned donor_types, const int *__restrict__ boff, const unsigned char *__restrict__ btype, const double *__restrict__ bo0,
+                                                     const int *__restrict__ type, int2 *__restrict__ don, int *__restrict__ cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  unsigned hm = 0u;
+  if (i < N && ((donor_types >> (type[i] & 31)) & 1u)) {
+    const int ob = boff[i], n = min(boff[i + 1] - ob, 32);
+    for (int s = 0; s < n; ++s)
+      if (btype[ob + s] == 2 && bo0[ob + s] > MINBO0) hm |= 1u << s;   // pot.F90:595
+  }
+  const unsigned long long m = __ballot(hm != 0u);
+  if (m == 0ULL) return;
+  const int first = __ffsll(static_cast<long long>(m)) - 1;
+  int base = 0;
+  if (lane == first) base = atomicAdd(cnt, __popcll(m));
+  base = __shfl(base, first, 64);
+  if (hm != 0u) don[base + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(i, static_cast<int>(hm));
+}
+
+__global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2 *__restrict__ don, const int *__restrict__ ndon, const int *__restrict__ boff, const int *__restrict__ nbr,
+                                                    const int *__restrict__ type, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                    const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10, const double4 *__restrict__ pk,
+                                                    double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
+                                                    double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+  __shared__ unsigned s_cand[4][EHB_CAP];                 // compacted list entries of the row (type bits select the parameter row)
+  __shared__ double s_px[4][EHB_CAP], s_py[4][EHB_CAP], s_pz[4][EHB_CAP];
+  __shared__ int s_k[4][EHB_CAP];
+  __shared__ double s_hp[4][16][4];                       // (ti, H, type k) parameter rows of the current donor, by acceptor type
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nw = gridDim.x * 4, nd = *ndon;
+  double e10 = 0.0;
+  for (int d = blockIdx.x * 4 + w; d < nd; d += nw) {
+    const int2 rec = don[d];
+    const int i = __builtin_amdgcn_readfirstlane(rec.x);
+    const unsigned hmask = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(rec.y));
+    const int ti = type[i], ob = boff[i], n = n10[i] & N10_COUNT;
+    const double xi = x[i], yi = y[i], zi = z[i];
+    const size_t row = static_cast<size_t>(i) * S10;
+    const int inx_l = (lane >= 1 && lane <= ff.nso && lane < 16) ? ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + lane] : 0;
+    if (lane < 16) { const DevHbP hp = ff.hb[inx_l]; s_hp[w][lane][0] = hp.r0hb; s_hp[w][lane][1] = hp.phb1; s_hp[w][lane][2] = hp.phb2; s_hp[w][lane][3] = hp.phb3; }   // (row 0 is never used: the compaction drops its candidates)
+    int jl = 0; double bl = 0.0, xjl = 0.0, yjl = 0.0, zjl = 0.0;        // lane s holds atom, bond order and position of hydrogen slot s
+    if (lane < 32 && ((hmask >> lane) & 1u)) { jl = nbr[ob + lane]; bl = bo0[ob + lane]; xjl = x[jl]; yjl = y[jl]; zjl = z[jl]; }
+    V3 fi_t = {0, 0, 0};
+    int qn = 0;
+
+    auto flush = [&]() {                                    // the staged candidates against every hydrogen slot of the donor
+      wave_lds_sync();
+      for (int q = lane; q < qn; q += 64) {
+        const double4 p = pk[s_cand[w][q] & NB10_IDX_MASK];                  // list entries are cell-sorted positions; w = type << 32 | atom index
+        s_px[w][q] = p.x; s_py[w][q] = p.y; s_pz[w][q] = p.z; s_k[w][q] = static_cast<int>(__double_as_longlong(p.w) & 0xffffffffLL);
+      }
+      wave_lds_sync();
+      double akx[EHB_CAP / 64], aky[EHB_CAP / 64], akz[EHB_CAP / 64];       // acceptor force of this lane's candidate of each batch, summed over the hydrogen slots
+#pragma unroll
+      for (int b = 0; b < EHB_CAP / 64; ++b) { akx[b] = 0.0; aky[b] = 0.0; akz[b] = 0.0; }
+      for (unsigned hm = hmask; hm; hm &= hm - 1u) {
+        const int s = __ffs(hm) - 1;
+        const int j = __shfl(jl, s, 64);
+        const double BOij = __shfl(bl, s, 64);
+        const double xj = __shfl(xjl, s, 64), yj = __shfl(yjl, s, 64), zj = __shfl(zjl, s, 64);
+        const V3 rij = {xi - xj, yi - yj, zi - zj};
+        const double nij = sqrt(dot(rij, rij));
+        double cfs = 0.0, nterm = 0.0;
+        V3 fi_s = {0, 0, 0}, fj_s = {0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < EHB_CAP / 64; ++b) {
+          const int qq = 64 * b + lane;
+          if (qq >= qn) continue;
+          const int k = s_k[w][qq];
+          if (k == j || k == i) continue;
+          const double *hp = s_hp[w][(s_cand[w][qq] >> NB10_IDX_BITS) & 15u];
+          const double r0hb = hp[0], phb1 = hp[1], phb2 = hp[2], phb3 = hp[3];
+          const double pxk = s_px[w][qq], pyk = s_py[w][qq], pzk = s_pz[w][qq];
+          const V3 rik = {xi - pxk, yi - pyk, zi - pzk};
+          if (!(dot(rik, rik) < 100.0)) continue;                          // rchb2, pot.F90:610
+          const V3 rjk = {xj - pxk, yj - pyk, zj - pzk};
+          const double njk = sqrt(dot(rjk, rjk));
+          double cos_ijk = -dot(rij, rjk) / (nij * njk);
+          if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
+          if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
+          const double sh2 = 0.5 * (1.0 - cos_ijk);                        // sin^2(theta/2)
+          const double sin_xhz4 = sh2 * sh2, cos_xhz1 = 1.0 - cos_ijk;
+          const double exp_hb2 = exp(-phb2 * BOij);
+          const double exp_hb3 = exp(-phb3 * (r0hb / njk + njk / r0hb - 2.0));
+          const double PEhb = phb1 * (1.0 - exp_hb2) * exp_hb3 * sin_xhz4;
+          e10 += PEhb; nterm += 1.0;
+          cfs += phb1 * phb2 * exp_hb2 * exp_hb3 * sin_xhz4;               // CEhb(1) -> ForceB(i,j)
+          const double CEhb2 = -0.5 * phb1 * (1.0 - exp_hb2) * exp_hb3 * cos_xhz1;
+          const double CEhb3 = -PEhb * phb3 * (-r0hb / (njk * njk) + 1.0 / r0hb) * (1.0 / njk);
+          V3 fi, fk;
+          angle_forces(CEhb2, rij, nij, rjk, njk, fi, fk);
+          const V3 ff3 = {CEhb3 * rjk.x, CEhb3 * rjk.y, CEhb3 * rjk.z};   // f(j) -= ff ; f(k) += ff
+          fi_s.x += fi.x; fi_s.y += fi.y; fi_s.z += fi.z;
+          fj_s.x += -(fi.x + fk.x) - ff3.x; fj_s.y += -(fi.y + fk.y) - ff3.y; fj_s.z += -(fi.z + fk.z) - ff3.z;
+          akx[b] += fk.x + ff3.x; aky[b] += fk.y + ff3.y; akz[b] += fk.z + ff3.z;
+        }
+        cfs = wave_sum_b(cfs); nterm = wave_sum_b(nterm);
+        fj_s.x = wave_sum_b(fj_s.x); fj_s.y = wave_sum_b(fj_s.y); fj_s.z = wave_sum_b(fj_s.z);
+        fi_t.x += fi_s.x; fi_t.y += fi_s.y; fi_t.z += fi_s.z;
+        if (lane == 0 && nterm > 0.0) {                     // the donor's bonds belong to this wavefront alone
+          const int o = ob + s;
+          cf1[o] += cfs;
+          fnx[o] += fj_s.x; fny[o] += fj_s.y; fnz[o] += fj_s.z;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < EHB_CAP / 64; ++b) {
+        const int qq = 64 * b + lane;
+        if (qq < qn && (akx[b] != 0.0 || aky[b] != 0.0 || akz[b] != 0.0)) {
+          const int k = s_k[w][qq];
+          atomicAdd(fx + k, akx[b]); atomicAdd(fy + k, aky[b]); atomicAdd(fz + k, akz[b]);
+        }
+      }
+      wave_lds_sync();
+      qn = 0;
+    };
+
+    for (int c0 = 0; c0 < n; c0 += 256) {                   // four batches of entry words requested together
+      unsigned ent[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int kk = c0 + 64 * u + lane; ent[u] = kk < n ? static_cast<unsigned>(nb10[row + kk]) : 0xffffffffu; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (c0 + 64 * u >= n) break;                                        // wave-uniform
+        const int inx = __shfl(inx_l, static_cast<int>((ent[u] >> NB10_IDX_BITS) & 15u), 64);   // (ti, H, type k) row, held by lane = type k
+        const bool keep = ent[u] != 0xffffffffu && inx != 0;
+        const unsigned long long m = __ballot(keep);
+        if (keep) s_cand[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = ent[u];
+        qn += __popcll(m);
+        if (qn > EHB_CAP - 64) flush();
+      }
+    }
+    if (qn > 0) flush();
+    fi_t.x = wave_sum_b(fi_t.x); fi_t.y = wave_sum_b(fi_t.y); fi_t.z = wave_sum_b(fi_t.z);
+    if (lane == 0 && (fi_t.x != 0.0 || fi_t.y != 0.0 || fi_t.z != 0.0)) { atomicAdd(fx + i, fi_t.x); atomicAdd(fy + i, fi_t.y); atomicAdd(fz + i, fi_t.z); }
+    wave_lds_sync();                                        // the next donor rewrites the parameter rows
+  }
+  block_energy_add(e10, pe + 10);
+}
+
 void Engine::bonded_energies() {
   double *pe_d = scal + 32;   // 14 energy accumulators live behind the CG scalars
   k_ebond_terms<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, btype, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, cf1, cf2, cf3, ecoa, bt1, bt2, pe_d);
@@ -871,6 +1024,7 @@ void Engine::bonded_energies() {
 const bool kt3 = kt_begin(&st.ms_k_e3b);
     k_e3b<<<nblk(N, 256), 256, 4 * 5 * E3B_CAP * sizeof(double), stream>>>(N, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
+  RX_HIP(hipGetLastError());                       // 70 KB of dynamic LDS: a refused launch must not pass for "no valence angles"
   kt_end(kt3);
   BoxImg bx;
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
@@ -894,14 +1048,22 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
                                                          cds, frc[0], frc[1], frc[2], pe_d, bx);
   else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
                                                  cds, frc[0], frc[1], frc[2], pe_d, bx);
-  int ehb_probe = 0;
-#ifdef RXMD_EXPERIMENTS
-  if (const char *pv = std::getenv("RXMD_EHB_PROBE")) ehb_probe = std::atoi(pv);
-#endif
-  const int ehb_apw = (ehb_probe >> 8) ? (ehb_probe >> 8) : 16;    // = EHB_APW of k_ehb
   kt_end(kt4);
   const bool kth = kt_begin(&st.ms_k_ehb);
-  k_ehb<<<nblk(N, 4 * ehb_apw), 256, 0, stream>>>(N, S10, dff, boff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_probe);
+#ifdef RXMD_EHB_ROWSWEEP
+  k_ehb<<<nblk(N, 4 * 16), 256, 0, stream>>>(N, S10, dff, boff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, 0);
+#else
+  if (ehb_donor_types != 0u) {                    // (a force field without a hydrogen-bond row for hydrogen = type 2 has no donors: water, pot.F90:595)
+    RX_HIP(hipMemsetAsync(ehb_cnt, 0, sizeof(int), stream));
+    k_ehb_donors<<<nblk(N, 256), 256, 0, stream>>>(N, ehb_donor_types, boff, btype, bo0, type, ehb_don, ehb_cnt);
+    if (ehb_blocks_per_cu == 0) {                 // the persistent grid fills the device exactly: workgroups per CU from the kernel's own register / LDS footprint
+      int nbk = 0;
+      RX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, k_ehb_sweep, 256, 0));
+      ehb_blocks_per_cu = std::max(nbk, 1);
+    }
+    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
+  }
+#endif
   kt_end(kth);
 }
 

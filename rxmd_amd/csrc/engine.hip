@@ -122,7 +122,10 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw EngineError(RXMD_E_HIP, "no HIP device visible: this engine has no CPU path");
   RX_HIP(hipSetDevice(cfg.device));
-  { hipDeviceProp_t pr; RX_HIP(hipGetDeviceProperties(&pr, cfg.device)); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+  { hipDeviceProp_t pr; RX_HIP(hipGetDeviceProperties(&pr, cfg.device)); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    // the angle kernel and the window kernels ask for up to 78 KB of LDS per workgroup (gfx950: 160 KB per CU, 64 KB on every earlier arch): a
+    // device that cannot give it is refused here -- a launch that fails later would leave energy terms out without a word
+    if (pr.sharedMemPerBlock < size_t(80) * 1024) throw EngineError(RXMD_E_HIP, "device " + std::to_string(cfg.device) + " offers " + std::to_string(pr.sharedMemPerBlock) + " bytes of LDS per workgroup; the kernels are written for gfx950 (MI355X, 160 KB per CU) and need 80 KB"); }
   RX_HIP(hipStreamCreate(&stream));
   for (int k = 0; k < 64; ++k) { KtPair p; RX_HIP(hipEventCreate(&p.a)); RX_HIP(hipEventCreate(&p.b)); kt_free.push_back(p); }
   if (std::getenv("RXMD_SINGLE_STREAM")) comm_stream = stream;   // diagnostic: the halo work queues on the main stream (no second hardware queue)
@@ -330,6 +333,11 @@ void Engine::upload_ff() {
   dff.pval6 = ff.pval6; dff.pval8 = ff.pval8; dff.pval9 = ff.pval9; dff.pval10 = ff.pval10; dff.ppen2 = ff.ppen2; dff.ppen3 = ff.ppen3; dff.ppen4 = ff.ppen4;
   dff.pcoa2 = ff.pcoa2; dff.pcoa3 = ff.pcoa3; dff.pcoa4 = ff.pcoa4; dff.ptor2 = ff.ptor2; dff.ptor3 = ff.ptor3; dff.ptor4 = ff.ptor4; dff.pcot2 = ff.pcot2;
   dff.pqeq = ff.pqeq ? 1 : 0; dff.npq1 = ff.npq + 1;
+  ehb_donor_types = 0u;                            // types X for which some hydrogen-bond row (X, 2, k) exists (hydrogen = type 2, pot.F90:595)
+  if (ff.nso >= 2)
+    for (int t = 1; t <= ff.nso && t < 32; ++t)
+      for (int k = 1; k <= ff.nso; ++k)
+        if (ff.inxn3hb[(t * n1 + 2) * n1 + k] != 0) ehb_donor_types |= 1u << t;
   if (ff.pqeq) {
     const size_t b0 = al(zk.size() * 8), b1 = al(ff.inxnpq.size() * 4), bt = al(pt[0].size() * sizeof(double4));
     if (pqblob) { (void)hipFree(pqblob); pqblob = nullptr; }
@@ -364,6 +372,7 @@ void Engine::alloc_device() {
     if (const char *bc = std::getenv("RXMD_BOND_CAP")) { const long long v = std::atoll(bc); if (v > 0) cap = static_cast<size_t>(v); }
     alloc_bond_tables(cap);
   }
+  dmalloc(ehb_don, static_cast<size_t>(rows10)); dzalloc(ehb_cnt, 4);
   dmalloc(ecoef, 6 * nb); dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
@@ -405,6 +414,7 @@ void Engine::free_device() {
   dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(invpos); dfree(xs); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
   dfree(sorted_xyzi); dfree(sorted_type); dfree(flags); dfree(scanout); dfree(nbr_sm); dfree(nbrcnt); dfree(boff);
   free_bond_tables();
+  dfree(ehb_don); dfree(ehb_cnt);
   dfree(ecoef); dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(rows_int); dfree(rows_bnd); dfree(rows_sorted); dfree(rowcols); dfree(grp_base); dfree(win_flag); dfree(win_k); dfree(win_cnt); dfree(win_gint); dfree(win_gbnd); dfree(sl10);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
@@ -1319,7 +1329,7 @@ void Engine::poison_step_scratch() {
   fill(nbr_sm, 0, sizeof(int) * ns); fill(nbrcnt, 0, sizeof(int) * (nb + 1)); fill(boff, 0, sizeof(int) * (nb + 2));
   fill(nbr, 0, sizeof(int) * bcap); fill(brev, 0, sizeof(int) * bcap); fill(bown, 0, sizeof(int) * bcap); fill(btype, 0, bcap);
   for (double *t : {bo0, bo1, bo2, bo3, dln2, dln3, dBOp, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen, ecoa, bt1, bt2, bt3}) fill(t, 0, sizeof(double) * bcap);
-  fill(ecoef, 0, sizeof(double) * 6 * nb);
+  fill(ecoef, 0, sizeof(double) * 6 * nb); fill(ehb_don, 0, sizeof(int2) * rows10);
   for (double *t : {deltap, delta, nlp, dDlp, deltalp, cds, cd, cc_}) fill(t, 0, sizeof(double) * nb);
   fill(nb10, 0, sizeof(int) * nl); fill(hess, 0, sizeof(double) * nl); fill(sl10, 0, sizeof(unsigned short) * nl); fill(n10, 0, sizeof(int) * rows10);
   fill(rows_int, 0, sizeof(int) * rows10); fill(rows_bnd, 0, sizeof(int) * rows10);
