@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 INP = os.path.join(ROOT, "tests", "golden", "inputs")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0  # aggregate L2 -> L1 rate of the 8 XCDs, same guide
 SIMDS, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs, peak engine clock: a wave64 vector instruction occupies its SIMD for 4 cycles
 ATOMS_PER_GPU_CELLS = 18
 
@@ -60,7 +61,7 @@ def physical_cores():
         return os.cpu_count() or 1, 1
 
 
-def cpu_baseline():
+def cpu_baseline(sample="full"):
     """Times the REAL reference (oracle/_ref: Fortran + OpenMP, built by oracle/Makefile from the sources where they lie) on the PHYSICAL
     host cores of this box (OMP_NUM_THREADS = sockets x cores per socket, lscpu), on bounded samples of the same workload, same rxmd.in:
       * rxmd_omp_huge: the reference with ONLY its compiled-in capacity NBUFFER raised to 600,000 (module.F90:80), RDX 12x12x12 = 290,304
@@ -82,9 +83,12 @@ def cpu_baseline():
     except Exception:
         mem_gb = 0
     plan = []
+    if sample == "small":                  # --cpu-baseline-sample small (tests of the hand-off): only the unmodified reference on its 4,536-atom cube
+        mem_gb = 0
     if mem_gb >= 40:                       # NBUFFER 600,000: nbplist + hessian alone are 10.8 GB
         plan.append((os.path.join(ref, "rxmd_omp_huge"), 12, 5, "USCCACS/RXMD Fortran+OpenMP with NBUFFER raised to 600000 (oracle/_ref/rxmd_omp_huge)"))
-    plan.append((os.path.join(ref, "rxmd_omp_big"), 6, 10, "USCCACS/RXMD Fortran+OpenMP with NBUFFER raised to 150000 (oracle/_ref/rxmd_omp_big)"))
+    if sample != "small":
+        plan.append((os.path.join(ref, "rxmd_omp_big"), 6, 10, "USCCACS/RXMD Fortran+OpenMP with NBUFFER raised to 150000 (oracle/_ref/rxmd_omp_big)"))
     plan.append((os.path.join(ref, "rxmd_omp"), 3, 60, "USCCACS/RXMD Fortran+OpenMP unmodified (oracle/_ref/rxmd_omp)"))
     for exe, mc, nsteps, what in plan:
         if not os.path.exists(exe):
@@ -246,13 +250,30 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N>1: independent periodic replicas instead of one decomposed box")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of BASELINE configs[2] (water) and configs[4] (SiC nanoparticle, PQEq) and the isQEq 2 leg")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state leg (SURVEY 8d: 100 timed steps after 10 warm-up steps from the same cold start)")
+    ap.add_argument("--cpu-baseline-sample", default="full", choices=["full", "small"], help="small: only the unmodified reference on RDX 3x3x3 (seconds; the tests of the hand-off)")
     a = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher (the reference is started as `mpirun -np N rxmd`, examples/2-reaxff-dc/Makefile): this
     # process touches neither torch nor HIP; it starts the N ranks as a CHILD (torch.distributed.run, one rank per GPU), relays what they
     # print and leaves with their exit code.  Launched by a launcher (WORLD_SIZE set) --gpus must name the same N: never a silent 1-rank run.
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        raise SystemExit(spawn_ranks(a.gpus))
+        # the parent touches no GPU: it times the reference on the host cores BEFORE the ranks exist (nothing competes for the cores) and hands
+        # the record to rank 0 through a file, so that an N > 1 line carries `cpu_baseline` like the N = 1 line does (the reference prints its
+        # timer table on every rank count, main.F90:135-182)
+        tmpf = None
+        if not a.no_cpu_baseline and a.workload == "rdx":
+            cbp = cpu_baseline(a.cpu_baseline_sample)
+            if cbp is not None:
+                fd, tmpf = tempfile.mkstemp(prefix="rxmd_cpu_baseline_", suffix=".json")
+                with os.fdopen(fd, "w") as fh:
+                    json.dump(cbp, fh)
+                os.environ["RXMD_BENCH_CPU_BASELINE_FILE"] = tmpf
+        try:
+            rc = spawn_ranks(a.gpus)
+        finally:
+            if tmpf:
+                os.unlink(tmpf)
+        raise SystemExit(rc)
     if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus and "RXMD_BENCH_FORCE_DIST" not in os.environ:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: the launcher and the flag must agree" % (a.gpus, os.environ.get("WORLD_SIZE", "1")))
     probes = [k for k in os.environ if k.startswith("RXMD_") and k.endswith("_PROBE")]
@@ -262,7 +283,13 @@ def main():
     # the CPU baseline first: rank 0 of a 1-GPU run, before torch / HIP exist in this process
     cb = None
     if not a.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.workload == "rdx" and "RXMD_BENCH_FORCE_DIST" not in os.environ:
-        cb = cpu_baseline()
+        cb = cpu_baseline(a.cpu_baseline_sample)
+    elif os.environ.get("RXMD_BENCH_CPU_BASELINE_FILE") and int(os.environ.get("RANK", "0")) == 0:
+        try:                                  # measured by the parent of a self-spawned N > 1 run (above)
+            cb = json.load(open(os.environ["RXMD_BENCH_CPU_BASELINE_FILE"]))
+            cb["measured_by"] = "the parent process of bench.py --gpus N, before it started the ranks"
+        except Exception:
+            cb = None
 
     import torch
     import rxmd_amd
@@ -373,7 +400,9 @@ def main():
     if use_dist:          # every rank's residents, ghosts, CG iterations and exchange timers: a decomposition that silently lost a neighbour, or a rank
         # that waits for its halo, shows here
         tkeys = ("ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold", "ms_qeq", "ms_force", "ms_lists")
-        mine = torch.tensor([st["natoms"], st["nghost_force"], st["qeq_iters_total"], st["n_boundary_rows"]] + [st[k] / a.steps for k in tkeys],
+        launches_r = max(st["spmv_launches"], 1)
+        mine = torch.tensor([st["natoms"], st["nghost_force"], st["qeq_iters_total"], st["n_boundary_rows"]] + [st[k] / a.steps for k in tkeys]
+                            + [st.get("place_ms_first", 0.0), st.get("place_ms_kept", 0.0), float(st.get("place_draws", 0)), st["ms_qeq_spmv"] / launches_r],
                             dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -381,6 +410,9 @@ def main():
                     "boundary_rows": [int(t[3]) for t in allr]}
         for j, k in enumerate(tkeys):
             per_rank[k + "_per_step"] = [round(float(t[4 + j]), 4) for t in allr]
+        # every rank draws its own placement of the pass's streams (qeq.hip: tune_window_placement) and the slowest rank sets the step
+        for j, k in enumerate(("place_ms_first", "place_ms_kept", "place_draws", "pass_ms_in_the_loop")):
+            per_rank[k] = [round(float(t[4 + len(tkeys) + j]), 4) for t in allr]
     probe = None
     if world == 1:                               # plain 16-B/lane read of the matrix value array on this very box: the ceiling the pass is quoted next to
         try:
@@ -474,7 +506,7 @@ def main():
         # PMC numbers are NOT measured in this run: they come from profiles/kernel_traffic.json (scripts/gpu_pmc_kernels.sh: one rocprofv3 --pmc pass per
         # counter set over a bench step), which records the commit and the kernels' full template signatures it was taken at.  A kernel whose
         # signature is not in the file gets null, never another instance's bytes.
-        ktraffic, kvalu, ksource = {}, {}, None
+        ktraffic, kvalu, kl2, ksource = {}, {}, {}, None
         kfile = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(kfile):
             try:
@@ -482,6 +514,7 @@ def main():
                 if kj.get("natoms") == st["natoms"]:
                     ktraffic = kj.get("hbm_bytes_per_launch", {})
                     kvalu = {k: v.get("SQ_INSTS_VALU") for k, v in kj.get("kernels", {}).items() if v.get("SQ_INSTS_VALU") is not None}
+                    kl2 = {k: v.get("l1_to_l2_read_bytes_at_128B") for k, v in kj.get("kernels", {}).items() if v.get("l1_to_l2_read_bytes_at_128B") is not None}
                     ksource = {"file": "profiles/kernel_traffic.json", "measured_at_commit": kj.get("commit"), "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), gfx950 correction FETCH_SIZE x 2; SQ_INSTS_VALU for the issue floor"}
             except Exception:
                 pass
@@ -503,24 +536,45 @@ def main():
                  ("k_e4b", "ms_k_e4b", st["natoms"] * nb * 104.0, a.steps, "E4b (pot.F90:980-1227): FP64 chains"),
                  ("k_ehb", "ms_k_ehb", st["natoms"] * nb * 104.0, a.steps, "Ehb (pot.F90:559-673)"),
                  ("k_cd_gather+k_ccbnd_terms+k_ccbnd_sum+k_bond_force_terms+k_bond_force_sum", "ms_k_assemble", G * nb * 104.0, a.steps, "ForceBondedTerms as gathers (pot.F90:113-144)")]
+        def l2_bytes_for(*parts):
+            """L1 <- L2 read bytes per launch: TCP_TCC_READ_REQ x 128 B (one request = one 128-byte line), summed over the named kernels; None if absent"""
+            hit = [v for k, v in kl2.items() if any(k == p_ or k.startswith(p_ + "<") for p_ in parts)]
+            return sum(hit) if hit else None
+        def bound_of(ms, hbm_bytes, l2_bytes, valu_ms):
+            """the ceiling that binds a kernel: the largest of (HBM bytes / 8 TB/s, L1<-L2 bytes / 34.5 TB/s, vector issue floor) over its time; below 0.35 of
+            every one of them the kernel waits on dependent round trips: `latency`, quoted with its best fraction"""
+            if not ms or ms <= 0:
+                return None, None, {}
+            fr = {}
+            if hbm_bytes: fr["hbm"] = hbm_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if l2_bytes: fr["l2"] = l2_bytes / (ms * 1e-3) / 1e9 / L2_PEAK_GBS
+            if valu_ms: fr["valu"] = valu_ms / ms
+            if not fr:
+                return None, None, fr
+            b = max(fr, key=fr.get)
+            return (b if fr[b] >= 0.35 else "latency"), fr[b], fr
         kernels = []
         for name, key, byts, cnt, note in kdefs:
             ms = st.get(key, 0.0) / max(cnt, 1)
             ach_k = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             tr_k = traffic_for(*name.split("+"))
+            vf_k = valu_floor_ms(*name.split("+"))
+            bnd, fb, fr_all = bound_of(ms, tr_k, l2_bytes_for(*name.split("+")), vf_k)
             kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": tr_k,
-                            "frac_real_traffic": (tr_k / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr_k and ms > 0) else None, "valu_floor_ms": valu_floor_ms(*name.split("+")), "note": note})
+                            "frac_real_traffic": (tr_k / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr_k and ms > 0) else None, "valu_floor_ms": vf_k,
+                            "bound": bnd, "frac_of_bound": fb, "frac_of_each_ceiling": fr_all, "note": note})
         kernels.append({"name": "CG vector kernels (k_cg_update, k_cg_direction, k_sorted_vec, k_reduce_fused)", "ms": ms_cg_vec, "algorithmic_bytes": st["natoms"] * 300.0,
                         "achieved_GBs": st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 if ms_cg_vec > 0 else 0.0,
                         "frac": (st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_cg_vec > 0 else 0.0, "traffic": traffic_for("k_cg_update", "k_cg_direction", "k_sorted_vec", "k_reduce_fused"),
                         "note": "per CG iteration, everything of qeq() that is neither the matrix pass nor the list build"})
         # the pass that ran, by its full template signature (MODE_HSH, STORE, PQ, NSTEP, VAR -- qeq.hip): only that instance's counters count
-        one_trip = (not pqeq) and 256 < st.get("max_n10", 0) <= 384
-        if st.get("win_in_use"):
-            sig = "k_spmv_win<0, true, %s, %d, %d>" % ("true" if pqeq else "false", 3 if one_trip else 2, 4 if one_trip else 6)
+        if st.get("win_in_use"):                     # the engine reports the instance it dispatched (rxmd_stats.spmv_nstep / spmv_var, qeq.hip)
+            sig = "k_spmv_win<0, true, %s, %d, %d>" % ("true" if pqeq else "false", st.get("spmv_nstep", 0), st.get("spmv_var", 0))
         else:
             sig = "k_spmv<0, true, %s, 1>" % ("true" if pqeq else "false")
         traffic = ktraffic.get(sig)                  # None when the file was taken with another instance of the kernel
+        if ktraffic and traffic is None:
+            sys.stderr.write("bench.py: profiles/kernel_traffic.json holds this atom count but not the dispatched instance %s: roofline.traffic stays null\n" % sig)
         out = {
             "metric": "MD steps/sec (RDX, 979,776 atoms/GPU; one step advances every GPU's domain: weak scaling, wall-clock steps/s of the whole job)" if a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS
                       else "MD steps/sec (%s, %d atoms/GPU; wall-clock steps/s of the whole job)" % (a.workload, natoms),
@@ -544,6 +598,8 @@ def main():
                          "streamed_GBs": (pinfo["streamed_bytes_per_launch"] / (ms_spmv * 1e-3) / 1e9) if ms_spmv > 0 else 0.0,
                          "window_groups": pinfo["window_groups"], "largest_window_slots": pinfo["largest_window_slots"],
                          "placement_search": {"pass_ms_first_placement": st.get("place_ms_first", 0.0), "pass_ms_kept_placement": st.get("place_ms_kept", 0.0),
+                                              "draws": st.get("place_draws", 0), "total_ms": st.get("place_total_ms", 0.0), "bytes_held": st.get("place_bytes_held", 0.0),
+                                              "in_timed_region": False,
                                               "note": "where the pass's streams lie in physical memory is worth up to 15 % of its time; the engine times a few placements once and keeps the fastest (RXMD_PLACE_TRIES)"},
                          "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"], "launches_that_returned_at_once": st.get("spmv_noop_launches", 0),
                          "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,

@@ -173,6 +173,13 @@ typedef struct rxmd_stats {
   /* the window pass timed on the first placement of its streams in memory and on the one that was kept (0: no search ran; see
    * Engine::tune_window_placement, RXMD_PLACE_TRIES) */
   double place_ms_first, place_ms_kept;
+  /* (round 5, append-only) the placement search itself: placements timed including the first, its wall time, the bytes of device memory it
+   * held at its peak beyond the engine's own streams (0 draws: it did not run -- RXMD_PLACE_TRIES=1, a small system, a nearly full device,
+   * or the first placement was already within 3 % of the best this process has seen for the same matrix shape) */
+  double place_total_ms, place_bytes_held;
+  int place_draws;
+  /* the instance of the matrix pass the engine dispatched last: k_spmv_win<MODE, STORE, PQ, spmv_nstep, spmv_var> (qeq.hip); 0, 0 = the row pass k_spmv */
+  int spmv_nstep, spmv_var, reserved3;
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);

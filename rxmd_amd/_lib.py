@@ -30,14 +30,16 @@ class RxmdStats(C.Structure):
                 ("ms_k_list10", C.c_double), ("ms_k_nonbond", C.c_double), ("ms_k_e3b", C.c_double), ("ms_k_e4b", C.c_double), ("ms_k_ehb", C.c_double),
                 ("ms_k_bondorder", C.c_double), ("ms_k_assemble", C.c_double), ("ms_k_winbuild", C.c_double),
                 ("win_groups", C.c_int), ("win_max_units", C.c_int), ("win_in_use", C.c_int), ("reserved2", C.c_int),
-                ("place_ms_first", C.c_double), ("place_ms_kept", C.c_double)]
+                ("place_ms_first", C.c_double), ("place_ms_kept", C.c_double),
+                ("place_total_ms", C.c_double), ("place_bytes_held", C.c_double), ("place_draws", C.c_int),
+                ("spmv_nstep", C.c_int), ("spmv_var", C.c_int), ("reserved3", C.c_int)]
 
     def asdict(self):
         d = {}
         for name, _ in self._fields_:
             v = getattr(self, name)
             d[name] = list(v) if hasattr(v, "__len__") else v
-        d.pop("reserved"); d.pop("reserved2")
+        d.pop("reserved"); d.pop("reserved2"); d.pop("reserved3")
         return d
 
 

@@ -138,7 +138,7 @@ __device__ inline double wave_sum64(double v) {
 #ifndef WIN_ROWS_DEF
 #define WIN_ROWS_DEF 16
 #endif
-constexpr int WIN_ROWS = WIN_ROWS_DEF;   // rows of a window group = wavefronts of a workgroup of the window pass (measured: 8 -> see DESIGN.md 3)
+constexpr int WIN_ROWS = WIN_ROWS_DEF;   // rows of a window group = wavefronts of a workgroup of the window pass (measured: 8 -> see NOTES.md 3)
 constexpr int WIN_UNIT = 8;         // cell-sorted positions per window unit (8 x 16 bytes = one 128-byte line of the sorted vector)
 constexpr int WIN_MAXUNITS = 448;   // units a group's descriptor holds: 3,584 slots = 56 KB of LDS (two workgroups per CU)
 constexpr int WIN_BMW = 2048;       // 64-bit words of the coverage map the build kernel keeps in LDS: a group's positions may span 2048 x 64 x 8 = 1 M
@@ -193,7 +193,7 @@ struct Engine {
   // (bown) and its mirror image, the same bond in the partner's list (brev = the reference's nbrindx, main.F90:383-399, as a direct index)
   int *nbr = nullptr, *nbrcnt = nullptr, *boff = nullptr, *brev = nullptr, *bown = nullptr;
   unsigned char *btype = nullptr; // per bond: type of the partner atom
-  int *nbr_sm = nullptr;          // slot-major staging of the list sweep [slot * NB + atom] (a thread appends without knowing the totals)
+  int *nbr_sm = nullptr;          // atom-major staging of the list sweep [atom * 32 + slot] (a thread appends without knowing the totals; one 128-byte line per atom)
   size_t bcap = 0; int nbonds = 0; // capacity of the per-bond arrays (grown on demand) / bonds of the current build
   void alloc_bond_tables(size_t cap); void free_bond_tables();
   double *bo0 = nullptr, *bo1 = nullptr, *bo2 = nullptr, *bo3 = nullptr, *dln2 = nullptr, *dln3 = nullptr, *dBOp = nullptr;
@@ -273,6 +273,8 @@ struct Engine {
   void alloc_device();
   void free_device();
   void ghost_build();
+  void ghost_build_fused(); void migrate_fused(); void ensure_seg_buffers(int nblocks);   // single rank: the six-stage self exchange as 26 image segments (engine.hip)
+  int *seg_cnt = nullptr, *seg_tot = nullptr, *h_seg = nullptr; unsigned char *seg_code_ = nullptr; int seg_blocks_cap = 0;
   void bin_cells();
   void build_bonded_list();
   void build_list10();

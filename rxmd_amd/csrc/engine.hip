@@ -28,7 +28,7 @@ static const int dinv_[7] = {0, 2, 1, 4, 3, 6, 5};     // comm.F90:60
 static const bool g_poison = std::getenv("RXMD_POISON_ALLOC") != nullptr && std::atoi(std::getenv("RXMD_POISON_ALLOC")) != 0;
 #ifdef RXMD_EXPERIMENTS
 // RXMD_CONTIG_ALLOC=<bytes>: buffers of at most that many bytes (0: every buffer) come from hipExtMallocWithFlags(hipDeviceMallocContiguous) -- the
-// configuration that failed 15 unrelated tests in round 3; with RXMD_POISON_ALLOC=1 a read of stale memory shows as a NaN
+// configuration that failed 15 unrelated tests in round 3 (NOTES.md 3); with RXMD_POISON_ALLOC=1 a read of stale memory shows as a NaN
 static const long long g_contig = std::getenv("RXMD_CONTIG_ALLOC") ? std::atoll(std::getenv("RXMD_CONTIG_ALLOC")) : -1;
 #endif
 template <class T>
@@ -353,7 +353,7 @@ void Engine::upload_ff() {
 }
 
 void Engine::alloc_device() {
-  const size_t nb = NB, ns = static_cast<size_t>(NB) * MAXNB;
+  const size_t nb = NB, ns = static_cast<size_t>(NB) * 32;      // staging of the bonded sweep: one 128-byte line of 32 slots per atom (lists.hip, BL_STRIDE; MAXNB <= 31)
   for (int a = 0; a < 3; ++a) { dmalloc(pos[a], nb); dmalloc(vel[a], nb); dmalloc(frc[a], nb); dmalloc(spos[a], nb); }
   dmalloc(q, nb); dmalloc(qsfp, nb); dmalloc(qsfv, nb); dmalloc(type, nb); dmalloc(gid, nb);
   if (ff.pqeq) {
@@ -421,6 +421,8 @@ void Engine::free_device() {
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
+  dfree(seg_cnt); dfree(seg_tot); dfree(seg_code_); seg_blocks_cap = 0;
+  if (h_seg) { (void)hipHostFree(h_seg); h_seg = nullptr; }
   if (cubtmp) { (void)hipFree(cubtmp); cubtmp = nullptr; }
   if (ffblob) { (void)hipFree(ffblob); ffblob = nullptr; }
 }
@@ -634,6 +636,7 @@ static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n 
 
 void Engine::ghost_build() {
   if (multi()) { ghost_build_staged(); return; }
+  if (stage_pairs) { ghost_build_fused(); return; }          // single rank: three kernels, one host wait (RXMD_NO_STAGE_PAIRS=1: the staged form below)
   const BoxDev B = boxdev(box);
   k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
   copyptr[0] = N;
@@ -683,6 +686,231 @@ void Engine::ghost_build() {
   if (G > N) k_to_real<<<nblk(G - N, 256), 256, 0, stream>>>(B, N, G, spos[0], spos[1], spos[2], pos[0], pos[1], pos[2]);
   ghosts_valid = true;
   st.nghost_force = G - N; st.nghost_qeq = G - N;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single rank, round 5: COPYATOMS(MODE_COPY) and COPYATOMS(MODE_MOVE) without the per-axis host waits.
+// The six-stage exchange of a rank that is its own neighbour on every axis (comm.F90:55-100 with self copies) is a fixed function of each
+// RESIDENT's normalised coordinates: stage d scans everything the stages of the earlier axes appended, and an image inherits the
+// coordinates of its source on the other axes, so whether "the x-image of atom n" is flagged by the y stage is a property of n.  The
+// ghost array of the staged build is therefore 26 SEGMENTS laid end to end -- one per non-empty combination (ex, ey, ez), e in
+// {none, U: near the upper face, shifted by -lbox, L: near the lower face, shifted by +lbox} -- in stage order and, inside a stage,
+// in the order the stage scans its sources (residents, then the segments of the earlier stages in their order); inside a segment the
+// residents keep their index order.  That is what the index-ordered force rule (pot.F90:113-144) needs, and it is exactly what
+// flag -> scan -> append per stage produced (tests: ghost order against the CPU restatement of the reference, and against the staged path of this file,
+// RXMD_NO_STAGE_PAIRS=1).  Three kernels: per-workgroup counts of the 26 predicates (+ normalised coordinates), one scan per
+// segment over the workgroups, placement.  One host wait (the totals) instead of three; migration: none.
+// MODE_MOVE is the same structure with EXCLUSIVE predicates (an atom leaves through at most one face per axis: its segment is the
+// triple of faces it crossed) and dr = 0; a mover's final slot = (atoms that stay) + (movers of earlier segments) + (its rank).
+__constant__ unsigned char c_seg_need[26] = {1, 2, 4, 5, 6, 8, 9, 10, 16, 17, 18, 20, 21, 22, 24, 25, 26, 32, 33, 34, 36, 37, 38, 40, 41, 42};   // bit 0/1: x U/L, 2/3: y, 4/5: z
+__constant__ signed char c_seg_of[43] = {-1, 0, 1, -1, 2, 3, 4, -1, 5, 6, 7, -1, -1, -1, -1, -1, 8, 9, 10, -1, 11, 12, 13, -1, 14, 15, 16, -1, -1, -1, -1, -1, 17, 18, 19, -1, 20, 21, 22, -1, 23, 24, 25};
+static const int seg_stage_first_[8] = {0, 0, 1, 2, 5, 8, 17, 26};     // first segment of stage d (1..6), [7] = end
+struct SegGeom { double lbox[3], dr[3]; };
+__device__ inline unsigned seg_code(const SegGeom &sg, double s0, double s1, double s2) {     // inBuffer, comm.F90:551-576, both faces of the three axes
+  unsigned c = 0u;
+  c |= (sg.lbox[0] - sg.dr[0] < s0) ? 1u : 0u;  c |= (s0 <= sg.dr[0]) ? 2u : 0u;
+  c |= (sg.lbox[1] - sg.dr[1] < s1) ? 4u : 0u;  c |= (s1 <= sg.dr[1]) ? 8u : 0u;
+  c |= (sg.lbox[2] - sg.dr[2] < s2) ? 16u : 0u; c |= (s2 <= sg.dr[2]) ? 32u : 0u;
+  return c;
+}
+template <bool MOVE> __device__ inline bool seg_pred(unsigned code, unsigned need) { return MOVE ? code == need : (code & need) == need; }
+
+// pass 1: normalised coordinates of the residents (xu2xs), their face code, and per workgroup how many of its atoms each segment takes
+// (MOVE: slot 26 = the atoms that stay).  cnt[seg * nblocks + block].
+template <bool MOVE>
+__global__ void __launch_bounds__(256) k_seg_count(int N, BoxDev B, SegGeom sg, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                   double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz, const int *__restrict__ type,
+                                                   unsigned char *__restrict__ code_out, int *__restrict__ cnt) {
+  __shared__ int s_w[27][4];
+  const int n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned code = 0u; bool live = false;
+  if (n < N) {
+    const double r0 = x[n], r1 = y[n], r2 = z[n];
+    const double a = (B.Hi[0] * r0 + B.Hi[1] * r1 + B.Hi[2] * r2) - B.obox[0], b = (B.Hi[3] * r0 + B.Hi[4] * r1 + B.Hi[5] * r2) - B.obox[1],
+                 c = (B.Hi[6] * r0 + B.Hi[7] * r1 + B.Hi[8] * r2) - B.obox[2];
+    sx[n] = a; sy[n] = b; sz[n] = c;
+    live = !MOVE || type[n] > 0;
+    if (live) code = seg_code(sg, a, b, c);
+    code_out[n] = static_cast<unsigned char>(code | (live ? 0u : 128u));
+  }
+  const unsigned long long any = __ballot(code != 0u);
+  for (int s = 0; s < 26; ++s) {
+    int c_ = 0;
+    if (any) c_ = __popcll(__ballot(live && seg_pred<MOVE>(code, c_seg_need[s])));
+    if (lane == 0) s_w[s][w] = c_;
+  }
+  if (MOVE) { const int c_ = __popcll(__ballot(live && code == 0u)); if (lane == 0) s_w[26][w] = c_; }
+  __syncthreads();
+  if (threadIdx.x < (MOVE ? 27 : 26)) cnt[static_cast<size_t>(threadIdx.x) * gridDim.x + blockIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
+}
+// pass 2: one workgroup per segment: exclusive prefix of its per-workgroup counts in place, its total -> tot[seg]
+__global__ void __launch_bounds__(256) k_seg_scan(int nblocks, int *__restrict__ cnt, int *__restrict__ tot) {
+  __shared__ int s_p[256];
+  int *c = cnt + static_cast<size_t>(blockIdx.x) * nblocks;
+  const int per = (nblocks + 255) / 256, b0 = threadIdx.x * per, b1 = min(b0 + per, nblocks);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += c[b];
+  s_p[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = threadIdx.x >= o ? s_p[threadIdx.x - o] : 0;
+    __syncthreads();
+    s_p[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = s_p[threadIdx.x] - sum;
+  for (int b = b0; b < b1; ++b) { const int v = c[b]; c[b] = run; run += v; }
+  if (threadIdx.x == 255) tot[blockIdx.x] = s_p[255];
+}
+// rank of this thread's atom among the atoms of its workgroup that segment `need` takes (lanes before it + wavefronts before it), from the
+// per-wavefront counts in LDS
+template <bool MOVE>
+__device__ inline int seg_rank_in_block(const int (*s_w)[4], int s, bool pred, int lane, int w) {
+  const unsigned long long m = __ballot(pred);
+  int r = __popcll(m & ((1ULL << lane) - 1ULL));
+  for (int q = 0; q < w; ++q) r += s_w[s][q];
+  return r;
+}
+// pass 3 (MODE_COPY): every resident writes its images: shifted normalised and real coordinates (xshift comm.F90:531-548, xs2xu), type, gid,
+// charge, its source in the stage scan (gsrc: the image of the same atom in the parent segment, or the resident), its root, the send list
+__global__ void __launch_bounds__(256) k_seg_place_ghosts(int N, int NB, BoxDev B, SegGeom sg, const unsigned char *__restrict__ code_in, const int *__restrict__ cnt, const int *__restrict__ tot,
+                                                          double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz, double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                                                          int *__restrict__ type, long long *__restrict__ gid, double *__restrict__ q, int *__restrict__ gsrc, int *__restrict__ groot, int *__restrict__ sendidx) {
+  __shared__ int s_w[26][4], s_base[27];
+  const int n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned code = n < N ? code_in[n] : 0u;
+  if (threadIdx.x == 0) { int o = N; for (int s = 0; s < 26; ++s) { s_base[s] = o; o += tot[s]; } s_base[26] = o; }
+  const unsigned long long any = __ballot(code != 0u);
+  if (__syncthreads_or(any != 0ULL) == 0) return;                       // an interior workgroup: nothing to place
+  for (int s = 0; s < 26; ++s) {
+    const int c_ = any ? __popcll(__ballot(seg_pred<false>(code, c_seg_need[s]))) : 0;
+    if (lane == 0) s_w[s][w] = c_;
+  }
+  __syncthreads();
+  if (!any) return;                                                      // (wave-uniform)
+  double a0 = 0.0, b0 = 0.0, c0 = 0.0, qn = 0.0; int tn = 0; long long gn = 0;
+  if (code) { a0 = sx[n]; b0 = sy[n]; c0 = sz[n]; qn = q[n]; tn = type[n]; gn = gid[n]; }
+  for (int s = 0; s < 26; ++s) {
+    const unsigned need = c_seg_need[s];
+    const bool p = seg_pred<false>(code, need);
+    const int r = seg_rank_in_block<false>(s_w, s, p, lane, w);
+    const unsigned pneed = need >= 16u ? (need & 15u) : (need >= 4u ? (need & 3u) : 0u);      // the same atom one stage earlier
+    int src = n;
+    if (pneed) { const int ps = c_seg_of[pneed]; const int rp = seg_rank_in_block<false>(s_w, ps, seg_pred<false>(code, pneed), lane, w); src = s_base[ps] + cnt[static_cast<size_t>(ps) * gridDim.x + blockIdx.x] + rp; }
+    if (!p) continue;
+    const int m = s_base[s] + cnt[static_cast<size_t>(s) * gridDim.x + blockIdx.x] + r;
+    if (m >= NB) continue;                                               // over capacity: the host sees the totals and raises the reference's trap
+    double a = a0, b = b0, c = c0;
+    if (need & 1u) a += -sg.lbox[0]; if (need & 2u) a += sg.lbox[0];
+    if (need & 4u) b += -sg.lbox[1]; if (need & 8u) b += sg.lbox[1];
+    if (need & 16u) c += -sg.lbox[2]; if (need & 32u) c += sg.lbox[2];
+    sx[m] = a; sy[m] = b; sz[m] = c;
+    const double r0 = a + B.obox[0], r1 = b + B.obox[1], r2 = c + B.obox[2];
+    x[m] = B.H[0] * r0 + B.H[1] * r1 + B.H[2] * r2; y[m] = B.H[3] * r0 + B.H[4] * r1 + B.H[5] * r2; z[m] = B.H[6] * r0 + B.H[7] * r1 + B.H[8] * r2;
+    type[m] = tn; gid[m] = gn; q[m] = qn;
+    gsrc[m] = src; groot[m] = n; sendidx[m - N] = src;
+  }
+}
+
+void Engine::ghost_build_fused() {
+  const BoxDev B = boxdev(box);
+  SegGeom sg;
+  for (int a = 0; a < 3; ++a) { sg.lbox[a] = box.lbox[a]; sg.dr[a] = shell[a]; }
+  const int nbk = nblk(N, 256);
+  ensure_seg_buffers(nbk);
+  k_seg_count<false><<<nbk, 256, 0, stream>>>(N, B, sg, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, seg_code_, seg_cnt);
+  k_seg_scan<<<26, 256, 0, stream>>>(nbk, seg_cnt, seg_tot);
+  k_seg_place_ghosts<<<nbk, 256, 0, stream>>>(N, NB, B, sg, seg_code_, seg_cnt, seg_tot, spos[0], spos[1], spos[2], pos[0], pos[1], pos[2], type, gid, q, gsrc, groot, sendidx);
+  RX_HIP(hipMemcpyAsync(h_seg, seg_tot, sizeof(int) * 26, hipMemcpyDeviceToHost, stream));
+  sync_stream();                                                         // the one host wait of the build: the ghost count sizes every launch behind it
+  copyptr[0] = N; sendoff[1] = 0;
+  for (int d = 1; d <= 6; ++d) {
+    long long t = 0;
+    for (int s = seg_stage_first_[d]; s < seg_stage_first_[d + 1]; ++s) t += h_seg[s];
+    if (static_cast<long long>(copyptr[d - 1]) + t > NB)
+      throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms: residents+ghosts exceed NBUFFER=" + std::to_string(NB));
+    copyptr[d] = copyptr[d - 1] + static_cast<int>(t); sendoff[d + 1] = sendoff[d] + static_cast<int>(t);
+  }
+  G = copyptr[6];
+  ghosts_valid = true;
+  st.nghost_force = G - N; st.nghost_qeq = G - N;
+}
+
+// pass 3 (MODE_MOVE): every atom goes to its final slot of scratch copies (atoms that stay keep their order, movers follow segment by segment),
+// shifted on the axes it crossed; pass 4 copies back and forms the real coordinates of everything (xs2xu).  Both leave at once when nobody moved.
+struct MoveArrays { double *d[12]; double *t[12]; int nd; long long *gid, *gid_t; int *type, *type_t; };
+__global__ void __launch_bounds__(256) k_seg_place_move(int N, SegGeom sg, const unsigned char *__restrict__ code_in, const int *__restrict__ cnt, const int *__restrict__ tot, MoveArrays A) {
+  __shared__ int s_w[27][4], s_base[27];
+  int movers = 0;
+  for (int s = 0; s < 26; ++s) movers += tot[s];
+  if (movers == 0) return;                                               // (uniform over the whole launch)
+  const int n = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned cf = n < N ? code_in[n] : 128u;
+  const bool live = (cf & 128u) == 0u; const unsigned code = cf & 63u;
+  if (threadIdx.x == 0) { int o = tot[26]; for (int s = 0; s < 26; ++s) { s_base[s] = o; o += tot[s]; } s_base[26] = 0; }
+  for (int s = 0; s < 27; ++s) {
+    const int c_ = __popcll(__ballot(live && (s < 26 ? code == c_seg_need[s] : code == 0u)));
+    if (lane == 0) s_w[s][w] = c_;
+  }
+  __syncthreads();
+  if (!live) return;
+  const int s = code ? c_seg_of[code] : 26;                              // (a code with both faces of an axis cannot occur: lbox < s and s <= 0 exclude each other)
+  if (s < 0) return;
+  // rank among the atoms of this workgroup with the same segment: every lane needs the ballot of ITS segment; segments are few, walk the ones present
+  int r = 0;
+  for (int t_ = 0; t_ < 27; ++t_) {
+    const unsigned long long m = __ballot(s == t_);
+    if (s == t_) { r = __popcll(m & ((1ULL << lane) - 1ULL)); for (int q = 0; q < w; ++q) r += s_w[t_][q]; }
+  }
+  const int m = s_base[s] + cnt[static_cast<size_t>(s) * gridDim.x + blockIdx.x] + r;
+  for (int a = 0; a < A.nd; ++a) {
+    double v = A.d[a][n];
+    if (a < 3) { const unsigned up = 1u << (2 * a), lo = 2u << (2 * a); if (code & up) v += -sg.lbox[a]; if (code & lo) v += sg.lbox[a]; }   // d[0..2] = normalised x, y, z
+    A.t[a][m] = v;
+  }
+  A.gid_t[m] = A.gid[n]; A.type_t[m] = A.type[n];
+}
+__global__ void __launch_bounds__(256) k_seg_finish_move(int N, BoxDev B, const int *__restrict__ tot, MoveArrays A, double *__restrict__ x, double *__restrict__ y, double *__restrict__ z) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  int movers = 0;
+  for (int s = 0; s < 26; ++s) movers += tot[s];
+  if (movers) {
+    for (int a = 0; a < A.nd; ++a) A.d[a][n] = A.t[a][n];
+    A.gid[n] = A.gid_t[n]; A.type[n] = A.type_t[n];
+  }
+  const double r0 = A.d[0][n] + B.obox[0], r1 = A.d[1][n] + B.obox[1], r2 = A.d[2][n] + B.obox[2];
+  x[n] = B.H[0] * r0 + B.H[1] * r1 + B.H[2] * r2; y[n] = B.H[3] * r0 + B.H[4] * r1 + B.H[5] * r2; z[n] = B.H[6] * r0 + B.H[7] * r1 + B.H[8] * r2;
+}
+
+void Engine::migrate_fused() {
+  const BoxDev B = boxdev(box);
+  SegGeom sg;
+  for (int a = 0; a < 3; ++a) { sg.lbox[a] = box.lbox[a]; sg.dr[a] = 0.0; }
+  const int nbk = nblk(N, 256);
+  ensure_seg_buffers(nbk);
+  k_seg_count<true><<<nbk, 256, 0, stream>>>(N, B, sg, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, seg_code_, seg_cnt);
+  k_seg_scan<<<27, 256, 0, stream>>>(nbk, seg_cnt, seg_tot);
+  // scratch: force + bonded scratch arrays as targets (they are recomputed every step), as the staged path does
+  MoveArrays A{};
+  double *src[12] = {spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], q, qsfp, qsfv, shl[0], shl[1], shl[2]};
+  double *tmp[12] = {frc[0], frc[1], frc[2], cds, cd, cc_, deltap, delta, nlp, A0, A1, A2};
+  A.nd = ff.pqeq ? 12 : 9;
+  for (int a = 0; a < 12; ++a) { A.d[a] = src[a]; A.t[a] = tmp[a]; }
+  A.gid = gid; A.gid_t = reinterpret_cast<long long *>(dDlp); A.type = type; A.type_t = perm_in;
+  k_seg_place_move<<<nbk, 256, 0, stream>>>(N, sg, seg_code_, seg_cnt, seg_tot, A);
+  k_seg_finish_move<<<nbk, 256, 0, stream>>>(N, B, seg_tot, A, pos[0], pos[1], pos[2]);
+  G = N;
+  lists_valid = false; ghosts_valid = false;
+  st.natoms = N;
+}
+
+void Engine::ensure_seg_buffers(int nbk) {
+  if (nbk <= seg_blocks_cap) return;
+  dfree(seg_cnt); dfree(seg_tot); dfree(seg_code_);
+  seg_blocks_cap = nbk + nbk / 4 + 16;
+  dmalloc(seg_cnt, static_cast<size_t>(27) * seg_blocks_cap); dzalloc(seg_tot, 32); dmalloc(seg_code_, static_cast<size_t>(NB));
+  if (!h_seg) RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_seg), 32 * sizeof(int)));
 }
 
 void Engine::halo_refresh(double2 *v2, double *v1) {
@@ -1113,6 +1341,7 @@ __global__ void k_unpack_move(int cnt, int base, const double *buf, double *sx, 
 }
 
 void Engine::migrate() {
+  if (!multi() && stage_pairs) { migrate_fused(); return; }     // single rank: four kernels, no host wait
   const BoxDev B = boxdev(box);
   k_to_normalised<<<nblk(N, 256), 256, 0, stream>>>(B, 0, N, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2]);
   int cp[7];
@@ -1319,7 +1548,7 @@ bool Engine::poison_on() const { return g_poison; }
 void Engine::poison_step_scratch() {
   if (!g_poison) return;
   auto fill = [&](void *p, size_t off_bytes, size_t bytes) { if (p && bytes) RX_HIP(hipMemsetAsync(static_cast<char *>(p) + off_bytes, 0xFF, bytes, stream)); };
-  const size_t nb = NB, ng = nb - N, ns = nb * MAXNB, nl = static_cast<size_t>(rows10) * S10;
+  const size_t nb = NB, ng = nb - N, ns = nb * 32, nl = static_cast<size_t>(rows10) * S10;
   for (int a = 0; a < 3; ++a) { fill(pos[a], sizeof(double) * N, sizeof(double) * ng); fill(spos[a], sizeof(double) * N, sizeof(double) * ng); fill(frc[a], sizeof(double) * N, sizeof(double) * ng); }
   fill(q, sizeof(double) * N, sizeof(double) * ng); fill(type, sizeof(int) * N, sizeof(int) * ng); fill(gid, sizeof(long long) * N, sizeof(long long) * ng);
   fill(gsrc, 0, sizeof(int) * nb); fill(groot, 0, sizeof(int) * nb); fill(rootperm, 0, sizeof(int) * nb); fill(invpos, 0, sizeof(int) * nb); fill(xs, 0, sizeof(double2) * nb);

@@ -88,6 +88,7 @@ __device__ inline void column_run(const Grid &g, const int *__restrict__ cellsta
   len = cellstart[cbf + hi + 1] - k0;
 }
 
+#ifdef RXMD_BLIST_ROUND4
 // ORTHO = false: the instance for skewed boxes carries the reference's cell-mesh tests (RefMesh); the orthogonal one does not pay for them
 template <bool ORTHO>
 __global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
@@ -166,6 +167,143 @@ __global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict_
   nbr[ob + s] = j; brev[ob + s] = boff[j] + found; bown[ob + s] = i; btype[ob + s] = static_cast<unsigned char>(type[j]);   // the partner's type rides with the bond: one dependent gather less where a kernel walks another atom's list
 }
 
+#else
+// Round 5.  The thread-per-atom sweep of rounds 1-4 walked ~135 candidates per atom one dependent 32-byte load after the other (counters,
+// profiles/r05_a_sq_*: 81 % of the wave cycles parked, each wavefront alive for a third of the kernel, L1 <- L2 11.2 GB for 0.55 GB of HBM) and
+// its slot-major staging made the mirror search of the packing pass touch one cache line per slot of the partner.  Now:
+//   * a workgroup owns BL_TILE consecutive cell-sorted atoms of ONE cell column (x, y) -- neighbours in space -- and stages the union of their
+//     candidate runs (9 stencil columns, z-trimmed per atom as before, union by LDS min / max) in LDS once, coalesced: ~1,300 positions of
+//     28 bytes for 128 centres instead of 128 x 135 gathers; the distance tests then read LDS only (same candidates, same order, same test);
+//   * the lists are staged ATOM-major (32 ints = one 128-byte line per atom): the packing pass finds the mirror slot in ONE line of the partner.
+// ORTHO = false: the instance for skewed boxes carries the reference's cell-mesh tests (RefMesh); the orthogonal one does not pay for them.
+constexpr int BL_TILE = 128, BL_CAP = 1536, BL_STRIDE = 32;          // centres per workgroup; staged candidates (43 KB: three workgroups per CU); ints per atom of the staging array
+template <bool ORTHO>
+__global__ void __launch_bounds__(BL_TILE) k_bonded_list(int G, int MAXNB, int tiles_y, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellstart,
+                                                          const double4 *__restrict__ sorted, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
+                                                          int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {   // nbr: the atom-major staging array (nbr_sm)
+  // squared bond cut-off of every type pair in LDS (0 = the pair has no bond row): one LDS read per candidate instead of two
+  // dependent global look-ups (inxn2, then bond[inxn].rc2); and per type the largest cut-off it has with any partner
+  __shared__ double s_rc2[256], s_rmax[16];
+  __shared__ double s_x[BL_CAP], s_y[BL_CAP], s_z[BL_CAP];
+  __shared__ int s_j[BL_CAP];
+  __shared__ unsigned char s_t[BL_CAP];
+  __shared__ int t_lo[9], t_hi[9], t_off[10];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < ff.n1 * ff.n1 && t < 256; t += BL_TILE) { const int ix = ff.inxn2[t]; s_rc2[t] = ix ? ff.bond[ix].rc2 : 0.0; }
+  __syncthreads();
+  if (tid < ff.n1 && tid < 16) {
+    double m = 0.0;
+    for (int t = 0; t < ff.n1; ++t) m = fmax(m, s_rc2[tid * ff.n1 + t]);
+    s_rmax[tid] = sqrt(m) + SWEEP_PAD;
+  }
+  // an XCD's workgroups own a contiguous eighth of the (column, tile) pairs: neighbouring columns share their candidate runs in its L2
+  const int lin = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int col = lin / tiles_y, ty = lin % tiles_y;
+  const int cx = col / g.n[1], cy = col % g.n[1];
+  const int kb = cellstart[col * g.nzf], ke = cellstart[(col + 1) * g.nzf];
+  for (int t0 = ty * BL_TILE; kb + t0 < ke; t0 += tiles_y * BL_TILE) {      // (a column with more atoms than tiles_y tiles: the workgroups take turns)
+    __syncthreads();                                                           // the previous tile is done with the staged candidates
+    if (tid < 9) { t_lo[tid] = 0x7fffffff; t_hi[tid] = -1; }
+    __syncthreads();
+    const int k = kb + t0 + tid;
+    const bool act = k < ke;
+    int i = 0, ti = 0, r_k0[9], r_len[9];
+    double xi = 0.0, yi = 0.0, zi = 0.0, si[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { r_k0[c] = 0; r_len[c] = 0; }
+    if (act) {
+      const double4 p = sorted[k];
+      const long long w = __double_as_longlong(p.w);
+      i = static_cast<int>(w & 0xffffffffLL); ti = static_cast<int>(w >> 32);
+      xi = p.x; yi = p.y; zi = p.z;
+      const double sxi = sx[i], syi = sy[i], szi = sz[i], rcp = s_rmax[ti];
+      if (!ORTHO) ref_norm(rm, xi, yi, zi, si);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        column_run<ORTHO>(g, cellstart, sxi, syi, szi, cx, cy, cx + c / 3 - 1, cy + c % 3 - 1, rcp, r_k0[c], r_len[c]);
+        if (r_len[c] > 0) { atomicMin(&t_lo[c], r_k0[c]); atomicMax(&t_hi[c], r_k0[c] + r_len[c]); }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int c = 0; c < 9; ++c) { t_off[c] = o; o += t_hi[c] >= 0 ? t_hi[c] - t_lo[c] : 0; }
+      t_off[9] = o;
+    }
+    __syncthreads();
+    const int total = t_off[9];
+    const bool staged = total <= BL_CAP;                                       // a denser system than the LDS tile holds: this tile gathers as before
+    if (staged)
+      for (int idx = tid; idx < total; idx += BL_TILE) {
+        int c = 0;
+#pragma unroll
+        for (int q = 1; q < 9; ++q) c += (idx >= t_off[q]) ? 1 : 0;
+        const double4 p = sorted[t_lo[c] + (idx - t_off[c])];
+        const long long w = __double_as_longlong(p.w);
+        s_x[idx] = p.x; s_y[idx] = p.y; s_z[idx] = p.z; s_j[idx] = static_cast<int>(w & 0xffffffffLL); s_t[idx] = static_cast<unsigned char>(w >> 32);
+      }
+    __syncthreads();
+    if (!act) continue;
+    const double *rc2row = s_rc2 + ti * ff.n1;
+    int *mine = nbr + static_cast<size_t>(i) * BL_STRIDE;
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {                                             // the order of rounds 1-4: dx outer, dy inner, sorted position ascending
+      const int base = staged ? t_off[c] - t_lo[c] : 0;
+      for (int kk = r_k0[c]; kk < r_k0[c] + r_len[c]; ++kk) {
+        double px, py, pz; int j, tj;
+        if (staged) { const int li = base + kk; px = s_x[li]; py = s_y[li]; pz = s_z[li]; j = s_j[li]; tj = s_t[li]; }
+        else { const double4 p = sorted[kk]; const long long w = __double_as_longlong(p.w); px = p.x; py = p.y; pz = p.z; j = static_cast<int>(w & 0xffffffffLL); tj = static_cast<int>(w >> 32); }
+        if (j == i) continue;
+        const double d0 = px - xi, d1 = py - yi, d2 = pz - zi;
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        bool in = r2 < rc2row[tj];                // dr2 < rc2(inxn), main.F90:366 (no bond row: cut-off 0)
+        if (!ORTHO && in) { double sj[3]; ref_norm(rm, px, py, pz, sj); in = ref_bonded_cells_adjacent(rm, si, sj); }
+        if (in) {
+          if (cnt < MAXNB) mine[cnt] = j;
+          ++cnt;
+        }
+      }
+    }
+    if (cnt > MAXNB) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXNB); cnt = MAXNB; }  // main.F90:402-407
+    nbrcnt[i] = cnt;
+    // err[2] = the longest list of this build if any is longer than 15 (the torsion kernel packs four atoms into a wavefront otherwise)
+    if (cnt > 15 && __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[2], cnt);
+  }
+}
+
+// The sweep above leaves the lists in an atom-major staging array (slot s of atom i at i * 32 + s: a thread appends without knowing the
+// totals).  This pass packs them: bond o = boff[i] + s (boff = exclusive prefix of the counts) carries its partner nbr[o], its owner bown[o] = i
+// and its MIRROR brev[o] = boff[j] + j1 with nbrlist(j, j1) == i -- the reference's nbrindx (main.F90:383-399) as a direct index into the
+// compact tables.  Every per-bond array of the engine is indexed by o: 5.3 entries per RDX atom instead of a 30-slot stride.
+__global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict__ nbr_sm, const int *__restrict__ nbrcnt, const int *__restrict__ boff,
+                           int *__restrict__ nbr, int *__restrict__ brev, int *__restrict__ bown, const int *__restrict__ type, unsigned char *__restrict__ btype, int *err) {
+  // one thread per (atom, slot): blockIdx.y = slot; the blocks of slots no atom of theirs uses leave after one coalesced read of the counts
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x, s = blockIdx.y;
+  if (i >= G) return;
+  const int ni = nbrcnt[i];
+  if (s >= ni) return;
+  const int ob = boff[i];
+  if (static_cast<long long>(ob) + ni > bcap) return;             // the tables are too small for this build: the host sees boff[G] and grows them
+  const int j = nbr_sm[static_cast<size_t>(i) * BL_STRIDE + s];
+  const int nj = nbrcnt[j];
+  const int4 *lj = reinterpret_cast<const int4 *>(nbr_sm + static_cast<size_t>(j) * BL_STRIDE);     // the partner's whole list: one 128-byte line, eight independent loads
+  int4 v[BL_STRIDE / 4];
+#pragma unroll
+  for (int q = 0; q < BL_STRIDE / 4; ++q) v[q] = (4 * q < nj) ? lj[q] : make_int4(-1, -1, -1, -1);
+  int found = -1;
+#pragma unroll
+  for (int q = 0; q < BL_STRIDE / 4; ++q) {
+    if (4 * q + 0 < nj && v[q].x == i) found = 4 * q + 0;
+    if (4 * q + 1 < nj && v[q].y == i) found = 4 * q + 1;
+    if (4 * q + 2 < nj && v[q].z == i) found = 4 * q + 2;
+    if (4 * q + 3 < nj && v[q].w == i) found = 4 * q + 3;
+  }
+  if (found < 0) { atomicCAS(&err[0], DERR_NONE, DERR_NBRINDX); found = 0; }
+  nbr[ob + s] = j; brev[ob + s] = boff[j] + found; bown[ob + s] = i; btype[ob + s] = static_cast<unsigned char>(type[j]);   // the partner's type rides with the bond: one dependent gather less where a kernel walks another atom's list
+}
+#endif
+
 // get_coulomb_and_dcoulomb_pqeq (reference src/module.F90:401-418): energy kernel and (1/r) dE/dr at squared distance r2.
 // Beyond the taper cutoff the reference returns without touching its outputs (callers then see the previous pair's
 // values); here such a lookup contributes nothing -- see DESIGN.md "PQEq beyond-cutoff lookups".
@@ -243,6 +381,7 @@ __global__ void __launch_bounds__(32 * WIN_ROWS) k_win_columns(int N, Grid g, co
     for (int u = 0; u < nu; ++u) win_k[static_cast<size_t>(grp) * WIN_MAXUNITS + ub + u] = lo8 + WIN_UNIT * u;
 }
 
+#ifdef RXMD_LIST10_ROUND4
 template <bool SELFCHECK, bool PQ, bool ORTHO>
 __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
                                                  const double4 *__restrict__ sorted,
@@ -470,6 +609,275 @@ __global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh 
   }   // live
 }
 
+#else
+constexpr int L10_ROWS = 8;      // rows (wavefronts) of a workgroup of the 10 A sweep: half a window group
+constexpr int L10_CAP = 1600;    // staged candidate positions of a workgroup (28 B each: 44.8 KB + 8 KB of queues and tables = three workgroups per CU; RDX: ~1,500 per 8 rows)
+template <bool SELFCHECK, bool PQ, bool ORTHO>
+__global__ void __launch_bounds__(64 * L10_ROWS) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+                                                 const double4 *__restrict__ sorted,
+                                                 const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                 const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz,
+                                                 const int *__restrict__ type, const long long *__restrict__ gid,
+                                                 int *__restrict__ nb10, double *__restrict__ hess, int *__restrict__ n10, int *err,
+                                                 const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
+                                                 double *__restrict__ hsc, double4 *__restrict__ pqrow,
+                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag,
+                                                 const int *__restrict__ rows_sorted, unsigned short *__restrict__ sl10, const int *__restrict__ rowcols, const int *__restrict__ grp_base, int *__restrict__ gflag) {
+  __shared__ int s_q[L10_ROWS][128];     // accepted candidates: (stencil column of the row << 20 | candidate number in the row): position, atom, type and distance come back from the staged copy
+  __shared__ int s_K[L10_ROWS][32], s_E[L10_ROWS][32], s_L[L10_ROWS][32];  // per stencil column of a row: first sorted position of its run - candidates before it / slot base of the column in the group's window / the same as s_K for the staged copy
+  __shared__ int s_ix2[256];             // inxn2 row of the row's type would do; the whole (n1 x n1) table is 64-256 words
+  // Round 5: the candidates of the workgroup's rows, staged ONCE.  The L10_ROWS rows of a workgroup are neighbours in cell-sorted order inside one
+  // window group: per stencil column their candidate runs overlap almost entirely.  Until round 4 every row gathered its ~1,300 candidates (32 B
+  // each) from L2 on its own -- 41 of the kernel's 82 GB of L1 <- L2 traffic, the wavefronts parked 62 % of their cycles -- now the union of the
+  // runs (per column [smallest first position, largest end), LDS min / max over the rows) is copied to LDS with coalesced loads and both phases
+  // read it from there.  A union that does not fit (a denser system) leaves the workgroup on the gather path.
+  __shared__ double s_x[L10_CAP], s_y[L10_CAP], s_z[L10_CAP];
+  __shared__ int s_j[L10_CAP];           // atom index | type << 26 (indices and cell-sorted positions stay below 2^26, NB10_IDX_BITS)
+  __shared__ int t_lo[32], t_hi[32], t_off[33];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
+  for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) s_ix2[t] = ff.inxn2[t];
+  if (threadIdx.x < 32) { t_lo[threadIdx.x] = 0x7fffffff; t_hi[threadIdx.x] = -1; }
+  __syncthreads();
+  // rows in the order of the window groups (cell-sorted: the rows of a workgroup test nearly the same candidates); the launch covers the
+  // host's bound of the group count, err[8] = the groups of this build
+  const int ridx = xcd_swizzle(blockIdx.x, gridDim.x) * L10_ROWS + w;
+  if (ridx - w >= err[8] * WIN_ROWS) return;  // (the whole workgroup: WIN_ROWS is a multiple of L10_ROWS)
+  const int i_raw = rows_sorted[ridx];
+  const bool rowlive = i_raw < N;             // false: unused row of a cell column's last group -- the wavefront stays for the barriers and the staging
+  const int i = rowlive ? i_raw : 0;
+  const int grp = ridx / WIN_ROWS;
+  constexpr bool live = true;
+  int *sq = s_q[w];
+  int *cK = s_K[w], *cE = s_E[w], *cL = s_L[w];
+  const double xi = x[i], yi = y[i], zi = z[i];
+  const int ti = type[i];
+  const size_t row = static_cast<size_t>(i) * S10;
+  double sni[3] = {0.0, 0.0, 0.0};
+  if (!ORTHO) ref_norm(rm, xi, yi, zi, sni);
+  double sxi = 0.0, syi = 0.0, szi = 0.0, Zi = 0.0, p_f = 0.0, p_hz = 0.0, p_bz = 0.0, p_ss = 0.0;
+  if (PQ) { sxi = shx[i]; syi = shy[i]; szi = shz[i]; Zi = ff.Zpq[ti]; }
+  // xs0 != nullptr: the sweep also forms the row sums H.(qs,qt) of the CG start vector (qt = 0) -- the matrix pass that
+  // get_gradient would need before the first iteration (qeq.F90:87) comes for free while the entries are in registers
+  double ra = 0.0, rg = 0.0;
+  bool anyghost = false;                          // does the row have a ghost partner (boundary row of the domain)?
+  int cnt = 0;      // entries written so far
+  int qn = 0;       // accepted candidates waiting in the queue
+  bool staged = false;   // the workgroup's candidates are in LDS (decided after the set-up below)
+
+  // Phase 2, dense: one queued candidate per lane -> table interpolation, list entry, hessian value.  Only a third of the
+  // candidates pass the distance test, so doing this work on compacted batches keeps every lane busy.
+  auto emit = [&](int nproc) {
+#ifdef RXMD_EXPERIMENTS
+    if (g.probe == 2) { cnt += nproc; return; }
+#endif
+    if (lane < nproc) {
+      const int qw = sq[lane], slot = cnt + lane;
+      if (slot < S10) {
+        const int t_ = qw >> 20, cc_ = qw & 0xfffff;
+        const int k = cK[t_] + cc_;                                    // cell-sorted position of the partner
+        double px, py, pz; int j, tj;
+        if (staged) { const int li = cL[t_] + cc_; px = s_x[li]; py = s_y[li]; pz = s_z[li]; const int jw = s_j[li]; j = jw & static_cast<int>(NB10_IDX_MASK); tj = (jw >> NB10_IDX_BITS) & 31; }
+        else { const double4 p = sorted[k]; const long long wv = __double_as_longlong(p.w); px = p.x; py = p.y; pz = p.z; j = static_cast<int>(wv & 0xffffffffLL); tj = static_cast<int>((wv >> 32) & 255); }
+        const double d0 = xi - px, d1 = yi - py, d2 = zi - pz;          // the arithmetic of the test, again: the same bits
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        // hessian entry as qeq_initialize computes it: r^2 rounded to REAL(4) first (qeq.F90:191,222-240)
+        const float r2f = static_cast<float>(r2);
+        double h = 0.0, hc = 0.0;
+        const int inxn = s_ix2[ti * ff.n1 + tj];
+        // skewed box: a ghost partner beyond the reference's QEq ghost shell is in its FORCE list but not in its QEq matrix
+        bool inq = true;
+        if (!ORTHO && j >= N) {
+          const double g0 = spx[j], g1 = spy[j], g2 = spz[j];
+          inq = g0 > rm.qlo[0] && g0 <= rm.qhi[0] && g1 > rm.qlo[1] && g1 <= rm.qhi[1] && g2 > rm.qlo[2] && g2 <= rm.qhi[2];
+        }
+        if (PQ) {
+          if (inq && static_cast<double>(r2f) < ff.rctap2) {                  // the pair is in PQEq's own list (real(4) test, pqeq.F90:305)
+            const double C0q = 14.4;                                   // Cclmb0_qeq, module.F90:682
+            const double4 sj = sorted_shl[k];
+            const double Zj = ff.Zpq[tj];
+            const int prow = ff.inxnpq[ti * ff.npq1 + tj];
+            double E, F;
+            pq_lookup(ff, ff.tabPcc, prow, r2, E, F);                  // core(i)-core(j)
+            h = C0q * E;
+            p_hz += h * Zj;
+            // Eq. 30: field of core(j) minus field of shell(j) at core(i); table row (jty,ity), pqeq.F90:328-334
+            double e0 = d0 - sj.x, e1 = d1 - sj.y, e2 = d2 - sj.z;
+            pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+            p_f += h * Zj - C0q * E * Zj;
+            // shell(i)-core(j): Csicj = -hsc * (q_j + Z_j), pqeq.F90:392-395
+            e0 = d0 + sxi; e1 = d1 + syi; e2 = d2 + szi;
+            pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+            hc = C0q * E * Zi;
+            p_bz += hc * Zj;
+            // shell(i)-shell(j): Csisj, pqeq.F90:397-401 (half of it per row, :409)
+            e0 -= sj.x; e1 -= sj.y; e2 -= sj.z;
+            pq_lookup(ff, ff.tabPss, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
+            p_ss += 0.5 * C0q * E * Zi * Zj;
+          }
+          hsc[row + slot] = hc;
+        } else if (inq && static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
+          const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
+          double drtb = static_cast<double>(r2f) - itb * ff.UDR;
+          drtb = drtb * ff.UDRi;
+          const double *T = ff.tabQEq + static_cast<size_t>(inxn) * (NTABLE + 2);
+          h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
+        }
+        {   // window slot: the candidate's column (of this row) -> the group's table entry -> first unit of the column + offset inside it
+#ifdef RXMD_EXPERIMENTS
+          if (!(g.probe & 4))
+#endif
+          sl10[row + slot] = static_cast<unsigned short>((k - cE[t_]) | (j >= N ? 0x8000 : 0));     // cE: first position of the column's interval - 8 x its first unit
+        }
+        unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
+        if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
+        if (xs0) {
+          const double qsj = xs0[k].x;
+          ra += h * qsj;
+          if (PQ) rg += hc * qsj; else if (j >= N) rg += h * qsj;
+        }
+        anyghost |= (j >= N);
+#ifdef RXMD_EXPERIMENTS
+        if (!(g.probe & 8))
+#endif
+        nb10[row + slot] = static_cast<int>(ent);
+#ifdef RXMD_EXPERIMENTS
+        if (!(g.probe & 16))
+#endif
+        hess[row + slot] = h;
+      }
+    }
+    cnt += nproc;
+  };
+
+  // the 25 stencil columns: lane t < 25 owns column t; an inclusive scan over the lanes lays the runs end to end
+  int L, myP;
+  {   // the row's 25 candidate runs and the slot bases of its group's stencil columns, as k_win_columns left them
+    int k0 = 0, len = 0, gb = 0;
+    if (lane < 32) { k0 = rowcols[static_cast<size_t>(ridx) * 64 + lane]; len = rowcols[static_cast<size_t>(ridx) * 64 + 32 + lane]; gb = grp_base[static_cast<size_t>(grp) * 32 + lane]; }
+    int lpre = len;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int l2 = __shfl_up(lpre, o, 64);
+      if (lane >= o) lpre += l2;
+    }
+    if (!rowlive) { len = 0; lpre = 0; }
+    if (lane < 32) { cK[lane] = k0 - (lpre - len); cE[lane] = gb; if (len > 0) { atomicMin(&t_lo[lane], k0); atomicMax(&t_hi[lane], k0 + len); } }
+    myP = (lane < 32) ? lpre - len : 0x7fffffff;   // candidates before column `lane` (columns 25..31: L)
+    L = __shfl(lpre, 31, 64);
+  }
+  __syncthreads();
+  if (w == 0) {                                    // the union of the workgroup's runs, column by column, laid end to end in the staged copy
+    const int nu = (lane < 32 && t_hi[lane] >= 0) ? t_hi[lane] - t_lo[lane] : 0;
+    int inc = nu;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const int t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
+    if (lane < 32) t_off[lane] = inc - nu;
+    if (lane == 31) t_off[32] = inc;
+  }
+  __syncthreads();
+  staged = t_off[32] <= L10_CAP;                   // (uniform over the workgroup)
+  if (staged) {
+    for (int c = w; c < 25; c += L10_ROWS) {       // a wavefront copies whole columns: consecutive lanes, consecutive positions
+      const int lo = t_lo[c], n_ = t_hi[c] >= 0 ? t_hi[c] - lo : 0, o_ = t_off[c];
+      for (int p_ = lane; p_ < n_; p_ += 64) {
+        const double4 pp = sorted[lo + p_];
+        const long long wv = __double_as_longlong(pp.w);
+        s_x[o_ + p_] = pp.x; s_y[o_ + p_] = pp.y; s_z[o_ + p_] = pp.z; s_j[o_ + p_] = static_cast<int>(wv & 0xffffffffLL) | (static_cast<int>((wv >> 32) & 31) << NB10_IDX_BITS);
+      }
+    }
+    if (lane < 32) cL[lane] = cK[lane] - t_lo[lane] + t_off[lane];
+  }
+  __syncthreads();
+  if (!rowlive) return;                            // (no barrier below)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef RXMD_EXPERIMENTS
+  if (g.probe == 1) { if (lane == 0) n10[i] = L; return; }
+#endif
+  // The column of a candidate = the last one that starts at or before it.  Candidates are walked in order, so the wavefront keeps the next column
+  // boundary it has not passed (tn, a scalar; the boundaries sit one per lane in myP and are read with v_readlane): a batch of 64 candidates
+  // starts in column tn - 1 and a lane adds one for every boundary of the batch at or below its candidate -- 1.2 boundaries per batch on
+  // average, where a binary search over the 32 entries in LDS took five dependent reads per candidate.
+  int tn = 1;
+  for (int c0 = 0; c0 < L; c0 += 256) {
+    // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
+    int kk[4], tcol[4], pj[4];
+    bool ok[4];
+    double pdx[4], pdy[4], pdz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cc = c0 + 64 * u + lane;
+      ok[u] = cc < L;
+      int t = tn - 1;                            // the column of candidate cc
+      for (;;) {
+        const int pm = __builtin_amdgcn_readlane(myP, tn);
+        if (pm > c0 + 64 * u + 63) break;        // (lanes 32.. hold INT_MAX: tn stops at 32)
+        t += (pm <= cc) ? 1 : 0;
+        ++tn;
+      }
+      kk[u] = ok[u] ? cc : 0;                      // candidate number in the row (the position is cK[column] + it)
+      tcol[u] = t;
+      pdx[u] = 0.0; pdy[u] = 0.0; pdz[u] = 0.0; pj[u] = 0;
+      if (ok[u]) {
+        if (staged) { const int li = cL[t] + cc; pdx[u] = s_x[li]; pdy[u] = s_y[li]; pdz[u] = s_z[li]; pj[u] = s_j[li] & static_cast<int>(NB10_IDX_MASK); }
+        else { const double4 p = sorted[cK[t] + cc]; pdx[u] = p.x; pdy[u] = p.y; pdz[u] = p.z; pj[u] = static_cast<int>(__double_as_longlong(p.w) & 0xffffffffLL); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bool in = false;
+      double r2q = 0.0;
+      if (ok[u]) {
+        const int j = pj[u];
+        const double d0 = xi - pdx[u], d1 = yi - pdy[u], d2 = zi - pdz[u];
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        r2q = r2;
+        in = (j != i) && (r2 <= ff.rctap2);     // dr2 <= rctap2, main.F90:458
+        if (!ORTHO && in) { double sj[3]; ref_norm(rm, pdx[u], pdy[u], pdz[u], sj); in = ref_nb_cells_in_mesh(rm, sni, sj, ff.rctap2); }
+      }
+      (void)r2q;
+      const unsigned long long m = __ballot(in);
+      if (in) { const int qp = qn + __popcll(m & ((1ULL << lane) - 1ULL)); sq[qp] = kk[u] | (tcol[u] << 20); }
+      qn += __popcll(m);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if (qn >= 64) {
+        emit(64);
+        const int rest = qn - 64;
+        int v = 0;
+        if (lane < rest) v = sq[64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane < rest) sq[lane] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        qn = rest;
+      }
+    }
+  }
+  if (qn > 0) emit(qn);
+  if (live) {
+  if (cnt > S10) { if (lane == 0) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); } cnt = S10; }  // qeq.F90:248-252
+  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; sl10[row + cnt + lane] = 0; }   // zero-pad the row to a multiple of 4 (value 0, slot 0)
+  if (xs0) {
+    ra = wave_sum_l(ra); rg = wave_sum_l(rg);
+    if (lane == 0) { s_all[i] = make_double2(ra, 0.0); s_gh[i] = make_double2(rg, 0.0); }
+  }
+  if (PQ) {
+    p_f = wave_sum_l(p_f); p_hz = wave_sum_l(p_hz); p_bz = wave_sum_l(p_bz); p_ss = wave_sum_l(p_ss);
+    if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) hsc[row + cnt + lane] = 0.0;
+    if (lane == 0) pqrow[i] = make_double4(p_f, p_hz, p_bz, p_ss);
+  }
+  const unsigned long long mg = __ballot(anyghost);
+  if (lane == 0 && rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0;
+  if (lane == 0) {
+    n10[i] = cnt | (mg != 0ULL ? N10_GHOST_ROW : 0);
+    // err[3] = the longest 10 A row of this build (the ring matrix pass issues a fixed number of DMA instructions per row and needs the bound;
+    // read with the error word the host waits for anyway).  One atomic per new maximum, not per row.
+    if (__hip_atomic_load(&err[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[3], cnt);
+    if (__hip_atomic_load(&err[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cnt) atomicMin(&err[4], cnt);     // ... and the shortest
+    if (gflag && mg != 0ULL) gflag[grp] = 1;      // multi-rank: a group with a row that has a ghost partner waits for the vector halo (every writer writes 1; cleared by build_windows)
+  }
+  }   // live
+}
+
+#endif
 // boundary rows keep their order, interior rows too: index lists for the two launches of the matrix pass
 __global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__restrict__ scan, int *__restrict__ rows_int, int *__restrict__ rows_bnd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -526,8 +934,17 @@ void Engine::build_windows() {
 void Engine::build_bonded_list() {
   k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi, sorted_type);
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
+#ifdef RXMD_BLIST_ROUND4
   if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
   else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
+#else
+  {   // one workgroup per (cell column, tile of BL_TILE atoms of it); a column of the mean population needs tiles_y - 1 tiles, fuller ones take turns
+    const int ncol = grid.n[0] * grid.n[1];
+    const int tiles_y = std::max(1, static_cast<int>((static_cast<long long>(G) / std::max(ncol, 1) + BL_TILE - 1) / BL_TILE)) + 1;
+    if (grid.ortho) k_bonded_list<true><<<ncol * tiles_y, BL_TILE, 0, stream>>>(G, MAXNB, tiles_y, grid, rmesh, dff, cellstart, sorted_xyzi, spos[0], spos[1], spos[2], nbr_sm, nbrcnt, d_err);
+    else k_bonded_list<false><<<ncol * tiles_y, BL_TILE, 0, stream>>>(G, MAXNB, tiles_y, grid, rmesh, dff, cellstart, sorted_xyzi, spos[0], spos[1], spos[2], nbr_sm, nbrcnt, d_err);
+  }
+#endif
   RX_HIP(hipMemsetAsync(nbrcnt + G, 0, sizeof(int), stream));                       // (G < NB always: the scan below runs over G + 1 counts)
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, nbrcnt, boff, G + 1, stream));
@@ -536,6 +953,11 @@ void Engine::build_bonded_list() {
   k_bond_csr<<<dim3(nblk(G, 256), MAXNB), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, type, btype, d_err);
 }
 
+#ifdef RXMD_LIST10_ROUND4
+constexpr int L10_ROWS_LAUNCH = 4;
+#else
+constexpr int L10_ROWS_LAUNCH = L10_ROWS;
+#endif
 void Engine::build_list10() {
 #ifdef RXMD_EXPERIMENTS
   if (const char *pv = std::getenv("RXMD_LIST_PROBE")) grid.probe = std::atoi(pv);
@@ -547,7 +969,7 @@ void Engine::build_list10() {
   list_selfcheck = selfcheck;
 #define RX_LIST10(SC, PQF) do { if (grid.ortho) RX_LIST10_O(SC, PQF, true); else RX_LIST10_O(SC, PQF, false); } while (0)
 #define RX_LIST10_O(SC, PQF, OR)                                                                                                               \
-  k_list10<SC, PQF, OR><<<std::max(win_groups, 1) * (WIN_ROWS / 4), 256, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
+  k_list10<SC, PQF, OR><<<std::max(win_groups, 1) * (WIN_ROWS / L10_ROWS_LAUNCH), 64 * L10_ROWS_LAUNCH, 0, stream>>>(N, S10, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, gid, \
                                                     nb10, hess, n10, d_err, sorted_shl, shl[0], shl[1], shl[2], hsc, pqrow, sums_from_list ? xs : nullptr, sall, sgh, multi() ? flags : nullptr, \
                                                     rows_sorted, sl10, rowcols, grp_base, gflag)
   win_valid = false;

@@ -12,6 +12,11 @@
 // iteration: sum_j H_ij q_j = sum_j H_ij qs_j - mu sum_j H_ij qt_j, with the reference's
 // "count resident partners twice" rule kept through a second accumulator over ghost columns.
 #include "engine.h"
+
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <cstdio>
 
 #include <cmath>
@@ -73,7 +78,7 @@ __device__ inline double pq_est_row(const DevAtomP &ap, double Zi, const double4
 // (stencil column + offset in the column's run, 10 instead of 12 bytes per entry) gave 0.968 vs 0.988 ms without the early request and
 // 0.931 vs 0.921 ms with it; requesting every batch ahead of the previous one's gathers, a tighter row stride (448 or 512 instead of
 // 640 entries) and skipping the ghost-column sums on the three rows in four that have no ghost partner (7 % SLOWER: the flag is one
-// more scalar round trip in front of the loop) changed nothing or lost.  All were dropped again; see DESIGN.md 3.
+// more scalar round trip in front of the loop) changed nothing or lost.  All were dropped again; see NOTES.md 3.
 template <int MODE, bool STORE, bool PQ, int PIPE>
 __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // entries per lane and request (16-byte / 4-byte loads), 256 entries of a row in flight.  Same sums in the same per-row roles as k_spmv; the
 // order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
 // (A timing probe with synthetic slots promised 0.76 against 0.93 ms of k_spmv before anything real was built; the real pass: 0.80 against 0.89 ms
-// back to back in one process, DESIGN.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
+// back to back in one process, NOTES.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
 // FORM (bit set): WIN_PREFETCH = the second batch of a row is requested before the workgroup's barrier; WIN_LEAN = groups without a ghost partner skip the
 // ghost-column sums; WIN_RANKROWS = experiments build only.  Plain QEq runs WIN_PREFETCH | WIN_LEAN (one-trip rows: WIN_LEAN), PQEq 0.
 [[maybe_unused]] constexpr int WIN_RANKROWS = 1;
@@ -826,7 +831,7 @@ void Engine::allreduce_scal4(int n) {
   RX_HIP(hipMemcpyAsync(scal + S_RAW0, h_scal + 48, sizeof(double) * n, hipMemcpyHostToDevice, stream));
 }
 
-// Where the streams of the window pass lie in physical memory is worth up to 15 % of its time (the same pass on copies of the same
+// Where the streams of the window pass lie in physical memory is worth up to 15 % of its time (NOTES.md 3: the same pass on copies of the same
 // arrays runs 0.77 ... 0.90 ms, a property of the buffer, repeatable to 0.1-0.5 %, drawn anew by every hipMalloc).  So, once per engine, after the
 // first QEq call that used the window pass: a few more placements of the value / slot (/ shell-core) arrays are tried, each timed with 30 launches
 // of the real pass, and the fastest is kept.  RXMD_PLACE_TRIES=<n> (default: up to 10 placements including the first, stopping once one is 8 % faster than the slowest seen; 1 switches the search off).
@@ -859,9 +864,27 @@ void Engine::tune_window_placement() {
     hipEventElapsedTime(&ms, ev[2], ev[3]);
     return static_cast<double>(ms) / 30.0;
   };
+  const auto t_search0 = std::chrono::steady_clock::now();
   double best = time_pass(hess, sl10, hsc);
   st.place_ms_first = best;
   double worst = best;
+  st.place_draws = 1; st.place_bytes_held = 0.0;
+  // Bounds of the search (round 5).  (1) What a fast placement looks like is a property of the matrix shape on this device: the best time any
+  // engine of this process has kept for the same (rows, stride, PQEq) is remembered, and an engine whose FIRST placement is within 3 % of it
+  // does not search at all.  (2) At most three losers stay allocated (each a copy of the streams: 4.2 GB at 979,776 atoms, 7.6 GB with PQEq);
+  // the oldest is freed only AFTER the next candidate has been allocated, so a freed block cannot come straight back as the "new" draw.
+  static std::mutex seen_mx; static std::map<std::tuple<int, int, int>, double> seen_best;
+  const auto shape = std::make_tuple(N, S10, ff.pqeq ? 1 : 0);
+  {
+    std::lock_guard<std::mutex> lk(seen_mx);
+    auto it = seen_best.find(shape);
+    if (it != seen_best.end() && best <= 1.03 * it->second && std::getenv("RXMD_PLACE_ALL") == nullptr) {
+      st.place_ms_kept = best;
+      st.place_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search0).count();
+      return;
+    }
+  }
+  constexpr size_t PLACE_MAX_HELD = 3;
   const bool verbose = std::getenv("RXMD_PLACE_VERBOSE") != nullptr;
   if (verbose) std::fprintf(stderr, "[rxmd_hip] placement draw 0: %.4f ms  hess %p sl10 %p\n", best, static_cast<void *>(hess), static_cast<void *>(sl10));
   const bool draw_all = std::getenv("RXMD_PLACE_ALL") != nullptr;      // diagnosis: no early stop
@@ -876,12 +899,15 @@ void Engine::tune_window_placement() {
     }
     drawn.push_back(std::make_unique<Cand>());
     Cand &cd_ = *drawn.back();
+    st.place_draws = c + 1;
     double *&h2 = cd_.h, *&c2 = cd_.c; unsigned short *&s2 = cd_.s;
     // (plain hipMalloc: memory from hipExtMallocWithFlags(hipDeviceMallocContiguous) was the fast kind more often in the copies experiment, but
     // an engine that allocated its streams that way failed 15 unrelated tests of the suite with corrupted results -- not used anywhere)
     bool ok = hipMalloc(reinterpret_cast<void **>(&h2), ne * sizeof(double)) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&s2), ne * sizeof(unsigned short)) == hipSuccess;
     if (ok && ff.pqeq) ok = hipMalloc(reinterpret_cast<void **>(&c2), ne * sizeof(double)) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); break; }
+    st.place_bytes_held = std::max(st.place_bytes_held, static_cast<double>(drawn.size()) * static_cast<double>(ne) * (ff.pqeq ? 18.0 : 10.0));
+    if (drawn.size() > PLACE_MAX_HELD + 1) drawn.erase(drawn.begin());      // the oldest loser goes, now that the new block exists (cd_ stays valid: unique_ptr elements)
     RX_HIP(hipMemcpyAsync(h2, hess, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
     RX_HIP(hipMemcpyAsync(s2, sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, stream));
     if (ff.pqeq) RX_HIP(hipMemcpyAsync(c2, hsc, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -893,6 +919,8 @@ void Engine::tune_window_placement() {
   }
   drawn.clear();                                        // frees every loser; the stream is idle: time_pass waited for its last launch
   st.place_ms_kept = best;
+  st.place_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search0).count();
+  { std::lock_guard<std::mutex> lk(seen_mx); auto it = seen_best.find(shape); if (it == seen_best.end() || best < it->second) seen_best[shape] = best; }
 }
 
 void Engine::qeq() {
@@ -909,7 +937,7 @@ void Engine::qeq() {
   if (!lists_valid) build_ghosts_and_lists(prepass_on);
   const int nmax = (cfg.isQEq == 1) ? cfg.NMAXQEq : 1;
   // one wavefront per row, sixteen rows per workgroup: measured faster than a persistent grid-stride launch (1.10 vs 1.28 ms
-  // per pass at 979,776 rows) -- many short waves overlap each other's load / gather / reduce phases
+  // per pass at 979,776 rows) -- many short waves overlap each other's load / gather / reduce phases (NOTES.md 3, K4/K5)
   constexpr int SPMV_WPB = 16;                   // wavefronts (= rows) per workgroup of the matrix pass
   const int rb = nblk(N, SPMV_WPB);
   const int vb = std::min(nblk(N, 256), 2048);
@@ -935,6 +963,7 @@ void Engine::qeq() {
       if (ng == 0) return 0;
       const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
       const bool one_trip = !ff.pqeq && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
+      st.spmv_nstep = one_trip ? 3 : 2; st.spmv_var = one_trip ? WIN_LEAN : (WIN_PREFETCH | WIN_LEAN);   // what the line below dispatches (bench.py names the instance whose counters it quotes)
 #define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3, WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); \
                               else k_spmv_win<M, S, P, 2, WIN_PREFETCH | WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); } while (0)
 #define RX_WIN(M, S) do { if (ff.pqeq) RX_WIN3(M, S, true); else RX_WIN3(M, S, false); } while (0)
@@ -946,6 +975,7 @@ void Engine::qeq() {
     }
     const int rbl = rowlist ? nblk(nrows, SPMV_WPB) : rb;
     if (rbl == 0) return 0;
+    st.spmv_nstep = 0; st.spmv_var = 0;
 #define RX_PASS3(M, S, P, PI) k_spmv<M, S, P, PI><<<rbl, 64 * SPMV_WPB, 0, stream>>>(N, S10, dff, nb10, hess, n10, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, swz, rowlist, nrows, pbase, stopflag)
 #define RX_PASS(M, S)                                                                                                  \
   do {                                                                                                                 \

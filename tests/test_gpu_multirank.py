@@ -187,7 +187,7 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ, RXMD_BENCH_BACKEND="gloo", RXMD_BENCH_DEVICE="0", RXMD_SINGLE_STREAM="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "6", "--steps", "3", "--warmup", "1"],
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "6", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.split("\n") if l.startswith("{")][-1]
@@ -198,3 +198,30 @@ def test_bench_launches_its_own_ranks():
     assert len(pr["natoms"]) == 2 and sum(pr["natoms"]) == 2 * 36288 and min(pr["nghost"]) > 0
     assert r["config"]["env"]["RXMD_BENCH_BACKEND"] == "gloo"
     assert r["value"] > 0 and abs(r["value"] * r["ms_per_step"] - 1e3) < 1e-6 * 1e3
+    assert "cpu_baseline" not in r
+
+
+def test_bench_launches_eight_ranks_on_the_2x2x2_grid_and_carries_the_cpu_baseline():
+    """The 8-rank form of the line above (BASELINE configs[3]: vprocs 2 2 2): `bench.py --gpus 8 --cells 3`, eight ranks sharing the one GPU, gloo, no
+    second stream.  The first 8-GPU run must not be the first time this launch path, the 2x2x2 rank grid and the per-rank record run at all.
+    The parent times the reference on the host cores before it starts the ranks (the small sample here) and rank 0 prints it in the line."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RXMD_BENCH_BACKEND="gloo", RXMD_BENCH_DEVICE="0", RXMD_SINGLE_STREAM="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RXMD_BENCH_CPU_BASELINE_FILE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--cells", "3", "--steps", "2", "--warmup", "1", "--cpu-baseline-sample", "small"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.split("\n") if l.startswith("{")][-1])
+    assert r["n_gpus"] == 8 and r["config"]["ranks_in_communicator"] == 8
+    assert r["config"]["atoms_total"] == 8 * 4536 and "vprocs 2x2x2" in r["config"]["parallelism"]
+    pr = r["per_rank"]
+    for key in ("natoms", "nghost", "qeq_iters_total", "ms_halo_per_step", "ms_ghost_build_per_step", "place_ms_kept", "pass_ms_in_the_loop"):
+        assert len(pr[key]) == 8, key
+    assert sum(pr["natoms"]) == 8 * 4536 and min(pr["nghost"]) > 0
+    assert len(set(pr["qeq_iters_total"])) == 1                      # the exit test is a global decision: every rank runs the same iterations
+    if os.path.exists(os.path.join(root, "oracle", "_ref", "rxmd_omp")):
+        cb = r["cpu_baseline"]
+        assert cb["kind"] == "reference" and cb["value"] > 0 and cb["cores"] >= 1 and "parent process" in cb["measured_by"]
+

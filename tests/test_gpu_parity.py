@@ -283,6 +283,41 @@ def test_migration_across_periodic_boundary_keeps_reference_order():
     e.close()
 
 
+@pytest.mark.parametrize("case,mc", [("rdx168", (1, 1, 1)), ("rdx168", (5, 5, 5)), ("sicnp", (1, 1, 1))])
+def test_fused_self_exchange_gives_the_staged_order_bit_for_bit(case, mc, monkeypatch):
+    """Single rank, round 5: the ghost build and the migration as 26 image segments (three / four kernels, one host wait; engine.hip) against the
+    six-stage flag -> scan -> append form they replace (RXMD_NO_STAGE_PAIRS=1 keeps it reachable), which is the reference's own procedure
+    (comm.F90:55-100,238-257).  Hot atoms so that some cross the faces in every step; compared after 4 steps: the WHOLE local arrays, residents and
+    ghosts in local order -- gid, type, positions -- bit for bit, charges bit for bit (the QEq sums have a fixed order), forces to the 1e-13 the
+    hydrogen-bond atomics leave.  13 A boxes (every atom has up to 26 images, both faces of an axis at once) and a 65 A box (interior atoms)."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    if case == "sicnp":
+        kw["pqeq"] = oa.PQEQ_SICNP
+    res = []
+    for staged in (False, True):
+        if staged:
+            monkeypatch.setenv("RXMD_NO_STAGE_PAIRS", "1")
+        else:
+            monkeypatch.delenv("RXMD_NO_STAGE_PAIRS", raising=False)
+        e = _engine(case, mc, **kw)
+        n = e.stats()["natoms"]
+        rng = np.random.default_rng(11)
+        e.set_velocities(rng.normal(0, 0.08, (n, 3)))
+        e.QEq(); e.FORCE(); e.step(4)
+        a = e.atoms()
+        res.append(dict(gid_all=e.debug(4).copy(), type_all=e.debug(5).copy(), pos_all=e.debug(3, width=3).copy(), q_all=e.debug(9).copy(),
+                        gid=a["gid"].copy(), pos=a["pos"].copy(), q=a["q"].copy(), f=a["f"].copy(), v=a["v"].copy() if "v" in a else None, st=e.stats()))
+        e.close()
+    f, s = res
+    assert not (f["gid"] == np.arange(1, len(f["gid"]) + 1)).all(), "test needs at least one migration"
+    assert f["st"]["nghost_force"] == s["st"]["nghost_force"] > 0
+    for k in ("gid_all", "type_all", "pos_all", "q_all", "gid", "pos", "q"):
+        assert np.array_equal(f[k], s[k]), k
+    if f["v"] is not None:
+        assert np.array_equal(f["v"], s["v"])
+    assert np.abs(f["f"] - s["f"]).max() <= 1e-13 * np.abs(s["f"]).max()
+
+
 def test_reference_shaped_entry_points():
     """rxmd_hip_QEq / rxmd_hip_FORCE take atype(NBUFFER), pos(NBUFFER,3) column-major like the Fortran subroutines"""
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
