@@ -897,9 +897,20 @@ __global__ void __launch_bounds__(256) k_ehb_donors(int N, unsigned donor_types,
 
 __global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2 *__restrict__ don, const int *__restrict__ ndon, const int *__restrict__ boff, const int *__restrict__ nbr,
                                                     const int *__restrict__ type, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                                                    const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10, const double4 *__restrict__ pk,
+                                                    const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10, const double4 *__restrict__ pk, const int *__restrict__ perm,
                                                     double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                                    double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+                                                    double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe
+#ifdef RXMD_EHB_DEBUG
+                                                    , int *dbg, int lim_n, int lim_b, int lim_nb
+#endif
+                                                    ) {
+#ifdef RXMD_EHB_DEBUG
+#define EHB_CHECK(code, v, lim, aux) if ((v) < 0 || (v) >= (lim)) { if (atomicCAS(dbg, 0, (code)) == 0) { dbg[1] = (v); dbg[2] = (aux); dbg[3] = (lim); } return; }
+#define EHB_CHECKC(code, v, lim, aux) if ((v) < 0 || (v) >= (lim)) { if (atomicCAS(dbg, 0, (code)) == 0) { dbg[1] = (v); dbg[2] = (aux); dbg[3] = (lim); } continue; }
+#else
+#define EHB_CHECK(code, v, lim, aux)
+#define EHB_CHECKC(code, v, lim, aux)
+#endif
   __shared__ unsigned s_cand[4][EHB_CAP];                 // compacted list entries of the row (type bits select the parameter row)
   __shared__ double s_px[4][EHB_CAP], s_py[4][EHB_CAP], s_pz[4][EHB_CAP];
   __shared__ int s_k[4][EHB_CAP];
@@ -911,21 +922,30 @@ __global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2
     const int2 rec = don[d];
     const int i = __builtin_amdgcn_readfirstlane(rec.x);
     const unsigned hmask = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(rec.y));
+    EHB_CHECK(1, i, lim_n, d)
     const int ti = type[i], ob = boff[i], n = n10[i] & N10_COUNT;
+    EHB_CHECK(2, ob, lim_b - 32, i)
+    EHB_CHECK(3, n, S10 + 1, i)
     const double xi = x[i], yi = y[i], zi = z[i];
     const size_t row = static_cast<size_t>(i) * S10;
     const int inx_l = (lane >= 1 && lane <= ff.nso && lane < 16) ? ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + lane] : 0;
     if (lane < 16) { const DevHbP hp = ff.hb[inx_l]; s_hp[w][lane][0] = hp.r0hb; s_hp[w][lane][1] = hp.phb1; s_hp[w][lane][2] = hp.phb2; s_hp[w][lane][3] = hp.phb3; }   // (row 0 is never used: the compaction drops its candidates)
     int jl = 0; double bl = 0.0, xjl = 0.0, yjl = 0.0, zjl = 0.0;        // lane s holds atom, bond order and position of hydrogen slot s
-    if (lane < 32 && ((hmask >> lane) & 1u)) { jl = nbr[ob + lane]; bl = bo0[ob + lane]; xjl = x[jl]; yjl = y[jl]; zjl = z[jl]; }
+    if (lane < 32 && ((hmask >> lane) & 1u)) { jl = nbr[ob + lane];
+#ifdef RXMD_EHB_DEBUG
+      if (jl < 0 || jl >= lim_nb) { if (atomicCAS(dbg, 0, 4) == 0) { dbg[1] = jl; dbg[2] = i; dbg[3] = lane; } jl = 0; }
+#endif
+      bl = bo0[ob + lane]; xjl = x[jl]; yjl = y[jl]; zjl = z[jl]; }
     V3 fi_t = {0, 0, 0};
     int qn = 0;
 
     auto flush = [&]() {                                    // the staged candidates against every hydrogen slot of the donor
       wave_lds_sync();
       for (int q = lane; q < qn; q += 64) {
-        const double4 p = pk[s_cand[w][q] & NB10_IDX_MASK];                  // list entries are cell-sorted positions; w = type << 32 | atom index
-        s_px[w][q] = p.x; s_py[w][q] = p.y; s_pz[w][q] = p.z; s_k[w][q] = static_cast<int>(__double_as_longlong(p.w) & 0xffffffffLL);
+        EHB_CHECKC(5, static_cast<int>(s_cand[w][q] & NB10_IDX_MASK), lim_nb, i)
+        const int ks = static_cast<int>(s_cand[w][q] & NB10_IDX_MASK);       // list entries are cell-sorted positions (by now the w component of the packed copy holds the charge: the atom comes from perm)
+        const double4 p = pk[ks];
+        s_px[w][q] = p.x; s_py[w][q] = p.y; s_pz[w][q] = p.z; s_k[w][q] = perm[ks];
       }
       wave_lds_sync();
       double akx[EHB_CAP / 64], aky[EHB_CAP / 64], akz[EHB_CAP / 64];       // acceptor force of this lane's candidate of each batch, summed over the hydrogen slots
@@ -986,6 +1006,7 @@ __global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2
         const int qq = 64 * b + lane;
         if (qq < qn && (akx[b] != 0.0 || aky[b] != 0.0 || akz[b] != 0.0)) {
           const int k = s_k[w][qq];
+          EHB_CHECKC(6, k, lim_nb, qq)
           atomicAdd(fx + k, akx[b]); atomicAdd(fy + k, aky[b]); atomicAdd(fz + k, akz[b]);
         }
       }
@@ -1061,7 +1082,14 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
       RX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, k_ehb_sweep, 256, 0));
       ehb_blocks_per_cu = std::max(nbk, 1);
     }
-    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
+#ifdef RXMD_EHB_DEBUG
+    RX_HIP(hipMemsetAsync(ehb_cnt + 4, 0, 4 * sizeof(int), stream));
+    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_cnt + 4, N, static_cast<int>(bcap), NB);
+    { int hd[8]; RX_HIP(hipMemcpyAsync(hd, ehb_cnt, sizeof(hd), hipMemcpyDeviceToHost, stream)); RX_HIP(hipStreamSynchronize(stream));
+      std::fprintf(stderr, "[ehb debug] donors %d  blocks/CU %d  first violation: code %d value %d aux %d lim %d   (N %d bcap %zu NB %d S10 %d rows10 %d)\n", hd[0], ehb_blocks_per_cu, hd[4], hd[5], hd[6], hd[7], N, bcap, NB, S10, rows10); }
+#else
+    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
+#endif
   }
 #endif
   kt_end(kth);

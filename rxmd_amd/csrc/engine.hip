@@ -372,7 +372,7 @@ void Engine::alloc_device() {
     if (const char *bc = std::getenv("RXMD_BOND_CAP")) { const long long v = std::atoll(bc); if (v > 0) cap = static_cast<size_t>(v); }
     alloc_bond_tables(cap);
   }
-  dmalloc(ehb_don, static_cast<size_t>(rows10)); dzalloc(ehb_cnt, 4);
+  dmalloc(ehb_don, static_cast<size_t>(rows10)); dzalloc(ehb_cnt, 8);
   dmalloc(ecoef, 6 * nb); dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
