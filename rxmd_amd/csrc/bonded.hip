@@ -875,7 +875,10 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int S10, DevFF ff, const int
 //   k_ehb_sweep   a persistent grid; a wavefront takes whole donors: the row's acceptor candidates are compacted into LDS (<= EHB_CAP at a time),
 //                 their positions gathered ONCE into LDS, then every hydrogen slot of the donor walks the staged candidates four dense batches
 //                 at a time out of LDS -- no load inside the evaluation -- and the acceptor's force is summed over the hydrogen slots in
-//                 registers before its three atomics (an RDX carbon-bound... nitrogen sees two hydrogens: half the atomic requests).
+//                 registers before its three atomics.
+// Measured (979,776 atoms, profiles/r05_*): without the acceptor atomics the sweep takes 0.40 ms (the one-kernel form: 0.70), with them 1.07 --
+// 51 M FP64 adds at the memory side are 0.67 ms whatever the wavefronts do around them (candidates sorted by atom index so that the acceptors of
+// one molecule sit in neighbouring lanes: 1.00; RDX donors have ONE hydrogen, so summing over slots saves nothing there).  The atomics are the floor.
 constexpr int EHB_CAP = 256;                              // candidates staged per flush (a 447-entry RDX row has <= 255 N / O partners)
 __global__ void __launch_bounds__(256) k_ehb_donors(int N, unsigned donor_types, const int *__restrict__ boff, const unsigned char *__restrict__ btype, const double *__restrict__ bo0,
                                                      const int *__restrict__ type, int2 *__restrict__ don, int *__restrict__ cnt) {
@@ -883,8 +886,12 @@ __global__ void __launch_bounds__(256) k_ehb_donors(int N, unsigned donor_types,
   unsigned hm = 0u;
   if (i < N && ((donor_types >> (type[i] & 31)) & 1u)) {
     const int ob = boff[i], n = min(boff[i + 1] - ob, 32);
-    for (int s = 0; s < n; ++s)
-      if (btype[ob + s] == 2 && bo0[ob + s] > MINBO0) hm |= 1u << s;   // pot.F90:595
+    unsigned hs = 0u;                                                   // the slots that hold a hydrogen: one pass over the type bytes (independent loads) ...
+    for (int s = 0; s < n; ++s) hs |= (btype[ob + s] == 2 ? 1u : 0u) << s;
+    for (unsigned m_ = hs; m_; m_ &= m_ - 1u) {                         // ... then the bond order of those only (most N / O atoms have none or one)
+      const int s = __ffs(m_) - 1;
+      if (bo0[ob + s] > MINBO0) hm |= 1u << s;                          // pot.F90:595
+    }
   }
   const unsigned long long m = __ballot(hm != 0u);
   if (m == 0ULL) return;

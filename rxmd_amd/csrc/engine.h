@@ -53,6 +53,7 @@ struct DevFF {
   const unsigned *tor_bits;     // inxn4 != 0 as a bit table of 4096 bits (valid when n1 <= 8): k_e4b keeps it in LDS
   const DevNBTab *tabNB;   // [inxn * (NTABLE+2) + i]
   const double *tabQEq;    // [inxn * (NTABLE+2) + i]
+  const double2 *tabQEq2;  // the same as pairs (T[i], T[i+1])
   double UDR, UDRi, rctap2, rctap_pad, cutoff_vpar30, vpar1, vpar2;   // rctap_pad: taper cutoff + the sweep padding (lists.hip)
   double plp1, povun3, povun4, povun6, povun7, povun8;
   double pval6, pval8, pval9, pval10, ppen2, ppen3, ppen4, pcoa2, pcoa3, pcoa4, ptor2, ptor3, ptor4, pcot2;

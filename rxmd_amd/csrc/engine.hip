@@ -308,16 +308,19 @@ void Engine::upload_ff() {
   if (n1 <= 8)
     for (size_t i = 0; i < ff.inxn4.size(); ++i)
       if (ff.inxn4[i] != 0) inxn4x[ff.inxn4.size() + (i >> 5)] |= static_cast<int>(1u << (i & 31));
+  // the QEq table once more as pairs (T[i], T[i+1]): the interpolation of a list entry is ONE 16-byte load instead of two 8-byte gathers
+  std::vector<double2> tq2(ff.tblQEq.size());
+  for (size_t i = 0; i < tq2.size(); ++i) tq2[i] = make_double2(ff.tblQEq[i], i + 1 < tq2.size() ? ff.tblQEq[i + 1] : 0.0);
   auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
-  size_t off[12], tot = 0;
-  const size_t sz[11] = {a.size() * sizeof(DevAtomP), b.size() * sizeof(DevBondP), an.size() * sizeof(DevAngleP), to.size() * sizeof(DevTorsP),
+  size_t off[13], tot = 0;
+  const size_t sz[12] = {a.size() * sizeof(DevAtomP), b.size() * sizeof(DevBondP), an.size() * sizeof(DevAngleP), to.size() * sizeof(DevTorsP),
                          hb.size() * sizeof(DevHbP), ff.inxn2.size() * 4, ff.inxn3.size() * 4, ff.inxn3hb.size() * 4, inxn4x.size() * 4,
-                         nb.size() * sizeof(DevNBTab), ff.tblQEq.size() * 8};
-  const void *src[11] = {a.data(), b.data(), an.data(), to.data(), hb.data(), ff.inxn2.data(), ff.inxn3.data(), ff.inxn3hb.data(), inxn4x.data(), nb.data(), ff.tblQEq.data()};
-  for (int i = 0; i < 11; ++i) { off[i] = tot; tot += al(sz[i]); }
+                         nb.size() * sizeof(DevNBTab), ff.tblQEq.size() * 8, tq2.size() * sizeof(double2)};
+  const void *src[12] = {a.data(), b.data(), an.data(), to.data(), hb.data(), ff.inxn2.data(), ff.inxn3.data(), ff.inxn3hb.data(), inxn4x.data(), nb.data(), ff.tblQEq.data(), tq2.data()};
+  for (int i = 0; i < 12; ++i) { off[i] = tot; tot += al(sz[i]); }
   if (ffblob) { (void)hipFree(ffblob); ffblob = nullptr; }
   RX_HIP(hipMalloc(&ffblob, tot));
-  for (int i = 0; i < 11; ++i) RX_HIP(hipMemcpy(static_cast<char *>(ffblob) + off[i], src[i], sz[i], hipMemcpyHostToDevice));
+  for (int i = 0; i < 12; ++i) RX_HIP(hipMemcpy(static_cast<char *>(ffblob) + off[i], src[i], sz[i], hipMemcpyHostToDevice));
   char *base = static_cast<char *>(ffblob);
   dff.nso = ff.nso; dff.n1 = n1; dff.nboty = ff.nboty;
   dff.atom = reinterpret_cast<DevAtomP *>(base + off[0]); dff.bond = reinterpret_cast<DevBondP *>(base + off[1]);
@@ -326,7 +329,7 @@ void Engine::upload_ff() {
   dff.inxn2 = reinterpret_cast<int *>(base + off[5]); dff.inxn3 = reinterpret_cast<int *>(base + off[6]);
   dff.inxn3hb = reinterpret_cast<int *>(base + off[7]); dff.inxn4 = reinterpret_cast<int *>(base + off[8]);
   dff.tor_bits = reinterpret_cast<unsigned *>(base + off[8]) + ff.inxn4.size();
-  dff.tabNB = reinterpret_cast<DevNBTab *>(base + off[9]); dff.tabQEq = reinterpret_cast<double *>(base + off[10]);
+  dff.tabNB = reinterpret_cast<DevNBTab *>(base + off[9]); dff.tabQEq = reinterpret_cast<double *>(base + off[10]); dff.tabQEq2 = reinterpret_cast<double2 *>(base + off[11]);
   dff.rctap_pad = ff.rctap + 1e-6;
   dff.UDR = ff.UDR; dff.UDRi = ff.UDRi; dff.rctap2 = ff.rctap2; dff.cutoff_vpar30 = ff.cutoff_vpar30; dff.vpar1 = ff.vpar1; dff.vpar2 = ff.vpar2;
   dff.plp1 = ff.plp1; dff.povun3 = ff.povun3; dff.povun4 = ff.povun4; dff.povun6 = ff.povun6; dff.povun7 = ff.povun7; dff.povun8 = ff.povun8;
@@ -1506,12 +1509,15 @@ __global__ void k_cell_starts(int G, int nfine, const int *__restrict__ cid_sort
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (cid_sorted[mid] < b) lo = mid + 1; else hi = mid; }
   cellstart[b] = lo;
 }
-__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, double4 *out, int *rootperm, int *invpos) {
+// w component of the packed copy: low 32 bits atom index, bits 32.. type (the list sweeps read both from it; k_sorted_charge later puts the charge there)
+__global__ void k_sorted_pos(int G, int N, const int *perm, const int *groot, const double *x, const double *y, const double *z, const int *type, double4 *out, unsigned char *st, int *rootperm, int *invpos) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= G) return;
   const int i = perm[k];
   const double xi = x[i], yi = y[i], zi = z[i];
-  out[k] = make_double4(xi, yi, zi, __longlong_as_double(static_cast<long long>(i)));
+  const int ti = type[i];
+  out[k] = make_double4(xi, yi, zi, __longlong_as_double((static_cast<long long>(ti) << 32) | static_cast<unsigned int>(i)));
+  st[k] = static_cast<unsigned char>(ti);
   rootperm[k] = (i < N) ? i : groot[i];
   invpos[i] = k;
 }
@@ -1530,7 +1536,7 @@ void Engine::bin_cells() {
   while ((1LL << bits) < grid.nfine + 1 && bits < 31) ++bits;
   RX_HIP(hipcub::DeviceRadixSort::SortPairs(cubtmp, tb, cellid, cellid_sorted, perm_in, perm, G, 0, bits, stream));
   k_cell_starts<<<nblk(grid.nfine + 1, 256), 256, 0, stream>>>(G, grid.nfine, cellid_sorted, cellstart);
-  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], sorted_xyzi, rootperm, invpos);
+  k_sorted_pos<<<nblk(G, 256), 256, 0, stream>>>(G, N, perm, groot, pos[0], pos[1], pos[2], type, sorted_xyzi, sorted_type, rootperm, invpos);
   if (ff.pqeq) pqeq_sorted_shells();
 }
 

@@ -15,15 +15,6 @@ namespace rxmd {
 
 static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
 
-// w component of sorted_xyzi: low 32 bits atom index, bits 32.. type
-__global__ void k_pack_type(int G, const int *perm, const int *type, double4 *s, unsigned char *st) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= G) return;
-  const int i = perm[k];
-  const long long w = (static_cast<long long>(type[i]) << 32) | static_cast<unsigned int>(i);
-  s[k].w = __longlong_as_double(w);
-  st[k] = static_cast<unsigned char>(type[i]);
-}
 
 // ---- geometry of a sweep over the engine's grid ---------------------------------------------------------------------------
 // The atoms are sorted by (cell x, cell y, z-slice): column (x, y) is one contiguous run, ordered in z to the width of a slice
@@ -168,108 +159,73 @@ __global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict_
 }
 
 #else
-// Round 5.  The thread-per-atom sweep of rounds 1-4 walked ~135 candidates per atom one dependent 32-byte load after the other (counters,
-// profiles/r05_a_sq_*: 81 % of the wave cycles parked, each wavefront alive for a third of the kernel, L1 <- L2 11.2 GB for 0.55 GB of HBM) and
-// its slot-major staging made the mirror search of the packing pass touch one cache line per slot of the partner.  Now:
-//   * a workgroup owns BL_TILE consecutive cell-sorted atoms of ONE cell column (x, y) -- neighbours in space -- and stages the union of their
-//     candidate runs (9 stencil columns, z-trimmed per atom as before, union by LDS min / max) in LDS once, coalesced: ~1,300 positions of
-//     28 bytes for 128 centres instead of 128 x 135 gathers; the distance tests then read LDS only (same candidates, same order, same test);
-//   * the lists are staged ATOM-major (32 ints = one 128-byte line per atom): the packing pass finds the mirror slot in ONE line of the partner.
+// Round 5.  Counters of the round-4 form (profiles/r05_a_sq_*): 81 % of the wave cycles parked -- every thread walked its ~135 candidates one
+// dependent 32-byte gather after the other -- and the slot-major staging made the mirror search of the packing pass touch one cache line per slot of
+// the partner (0.34 ms).  Now four candidates are in flight per thread (tested together, appended in order: same lists), and the lists are staged
+// ATOM-major: 32 ints = one 128-byte line per atom, so the packing pass finds the mirror slot in ONE line of the partner.
+// (Measured and dropped, NOTES.md round 5: a workgroup per 128 cell-sorted atoms of one cell column with the union of their candidate runs staged in
+// LDS -- 43 KB per workgroup leave two wavefronts per SIMD, and 1.05 ms against 0.57 for this kernel's predecessor: the gathers were never the
+// cost, the serial dependence was, and 32 wavefronts per CU hide it better than LDS does at 6.)
 // ORTHO = false: the instance for skewed boxes carries the reference's cell-mesh tests (RefMesh); the orthogonal one does not pay for them.
-constexpr int BL_TILE = 128, BL_CAP = 1536, BL_STRIDE = 32;          // centres per workgroup; staged candidates (43 KB: three workgroups per CU); ints per atom of the staging array
+constexpr int BL_STRIDE = 32;          // ints per atom of the staging array (MAXNB <= 31)
 template <bool ORTHO>
-__global__ void __launch_bounds__(BL_TILE) k_bonded_list(int G, int MAXNB, int tiles_y, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellstart,
-                                                          const double4 *__restrict__ sorted, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
-                                                          int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {   // nbr: the atom-major staging array (nbr_sm)
+__global__ void __launch_bounds__(256) k_bonded_list(int G, int MAXNB, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
+                                                      const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
+                                                      const double *__restrict__ z, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
+                                                      const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {   // nbr: the atom-major staging array (nbr_sm)
   // squared bond cut-off of every type pair in LDS (0 = the pair has no bond row): one LDS read per candidate instead of two
   // dependent global look-ups (inxn2, then bond[inxn].rc2); and per type the largest cut-off it has with any partner
   __shared__ double s_rc2[256], s_rmax[16];
-  __shared__ double s_x[BL_CAP], s_y[BL_CAP], s_z[BL_CAP];
-  __shared__ int s_j[BL_CAP];
-  __shared__ unsigned char s_t[BL_CAP];
-  __shared__ int t_lo[9], t_hi[9], t_off[10];
-  const int tid = threadIdx.x;
-  for (int t = tid; t < ff.n1 * ff.n1 && t < 256; t += BL_TILE) { const int ix = ff.inxn2[t]; s_rc2[t] = ix ? ff.bond[ix].rc2 : 0.0; }
+  for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) { const int ix = ff.inxn2[t]; s_rc2[t] = ix ? ff.bond[ix].rc2 : 0.0; }
   __syncthreads();
-  if (tid < ff.n1 && tid < 16) {
+  if (threadIdx.x < ff.n1 && threadIdx.x < 16) {
     double m = 0.0;
-    for (int t = 0; t < ff.n1; ++t) m = fmax(m, s_rc2[tid * ff.n1 + t]);
-    s_rmax[tid] = sqrt(m) + SWEEP_PAD;
+    for (int t = 0; t < ff.n1; ++t) m = fmax(m, s_rc2[threadIdx.x * ff.n1 + t]);
+    s_rmax[threadIdx.x] = sqrt(m) + SWEEP_PAD;
   }
-  // an XCD's workgroups own a contiguous eighth of the (column, tile) pairs: neighbouring columns share their candidate runs in its L2
-  const int lin = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int col = lin / tiles_y, ty = lin % tiles_y;
-  const int cx = col / g.n[1], cy = col % g.n[1];
-  const int kb = cellstart[col * g.nzf], ke = cellstart[(col + 1) * g.nzf];
-  for (int t0 = ty * BL_TILE; kb + t0 < ke; t0 += tiles_y * BL_TILE) {      // (a column with more atoms than tiles_y tiles: the workgroups take turns)
-    __syncthreads();                                                           // the previous tile is done with the staged candidates
-    if (tid < 9) { t_lo[tid] = 0x7fffffff; t_hi[tid] = -1; }
-    __syncthreads();
-    const int k = kb + t0 + tid;
-    const bool act = k < ke;
-    int i = 0, ti = 0, r_k0[9], r_len[9];
-    double xi = 0.0, yi = 0.0, zi = 0.0, si[3] = {0.0, 0.0, 0.0};
+  __syncthreads();
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (i >= G) return;
+  const int c = cellid[i];
+  const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
+  const double xi = x[i], yi = y[i], zi = z[i];
+  const double sxi = sx[i], syi = sy[i], szi = sz[i];
+  const int ti = type[i];
+  const double *rc2row = s_rc2 + ti * ff.n1;
+  const double rcp = s_rmax[ti];
+  double si[3] = {0.0, 0.0, 0.0};
+  if (!ORTHO) ref_norm(rm, xi, yi, zi, si);
+  int *mine = nbr + static_cast<size_t>(i) * BL_STRIDE;
+  int cnt = 0;
+  for (int dx = -1; dx <= 1; ++dx) {
+    for (int dy = -1; dy <= 1; ++dy) {
+      int k0, len;
+      column_run<ORTHO>(g, cellstart, sxi, syi, szi, cx, cy, cx + dx, cy + dy, rcp, k0, len);
+      const int kend = k0 + len;
+      for (int kk0 = k0; kk0 < kend; kk0 += 4) {                             // four candidates in flight, appended in order
+        double4 p[4];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { r_k0[c] = 0; r_len[c] = 0; }
-    if (act) {
-      const double4 p = sorted[k];
-      const long long w = __double_as_longlong(p.w);
-      i = static_cast<int>(w & 0xffffffffLL); ti = static_cast<int>(w >> 32);
-      xi = p.x; yi = p.y; zi = p.z;
-      const double sxi = sx[i], syi = sy[i], szi = sz[i], rcp = s_rmax[ti];
-      if (!ORTHO) ref_norm(rm, xi, yi, zi, si);
+        for (int u = 0; u < 4; ++u) p[u] = sorted[min(kk0 + u, kend - 1)];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        column_run<ORTHO>(g, cellstart, sxi, syi, szi, cx, cy, cx + c / 3 - 1, cy + c % 3 - 1, rcp, r_k0[c], r_len[c]);
-        if (r_len[c] > 0) { atomicMin(&t_lo[c], r_k0[c]); atomicMax(&t_hi[c], r_k0[c] + r_len[c]); }
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int o = 0;
-      for (int c = 0; c < 9; ++c) { t_off[c] = o; o += t_hi[c] >= 0 ? t_hi[c] - t_lo[c] : 0; }
-      t_off[9] = o;
-    }
-    __syncthreads();
-    const int total = t_off[9];
-    const bool staged = total <= BL_CAP;                                       // a denser system than the LDS tile holds: this tile gathers as before
-    if (staged)
-      for (int idx = tid; idx < total; idx += BL_TILE) {
-        int c = 0;
-#pragma unroll
-        for (int q = 1; q < 9; ++q) c += (idx >= t_off[q]) ? 1 : 0;
-        const double4 p = sorted[t_lo[c] + (idx - t_off[c])];
-        const long long w = __double_as_longlong(p.w);
-        s_x[idx] = p.x; s_y[idx] = p.y; s_z[idx] = p.z; s_j[idx] = static_cast<int>(w & 0xffffffffLL); s_t[idx] = static_cast<unsigned char>(w >> 32);
-      }
-    __syncthreads();
-    if (!act) continue;
-    const double *rc2row = s_rc2 + ti * ff.n1;
-    int *mine = nbr + static_cast<size_t>(i) * BL_STRIDE;
-    int cnt = 0;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {                                             // the order of rounds 1-4: dx outer, dy inner, sorted position ascending
-      const int base = staged ? t_off[c] - t_lo[c] : 0;
-      for (int kk = r_k0[c]; kk < r_k0[c] + r_len[c]; ++kk) {
-        double px, py, pz; int j, tj;
-        if (staged) { const int li = base + kk; px = s_x[li]; py = s_y[li]; pz = s_z[li]; j = s_j[li]; tj = s_t[li]; }
-        else { const double4 p = sorted[kk]; const long long w = __double_as_longlong(p.w); px = p.x; py = p.y; pz = p.z; j = static_cast<int>(w & 0xffffffffLL); tj = static_cast<int>(w >> 32); }
-        if (j == i) continue;
-        const double d0 = px - xi, d1 = py - yi, d2 = pz - zi;
-        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-        bool in = r2 < rc2row[tj];                // dr2 < rc2(inxn), main.F90:366 (no bond row: cut-off 0)
-        if (!ORTHO && in) { double sj[3]; ref_norm(rm, px, py, pz, sj); in = ref_bonded_cells_adjacent(rm, si, sj); }
-        if (in) {
-          if (cnt < MAXNB) mine[cnt] = j;
-          ++cnt;
+        for (int u = 0; u < 4; ++u) {
+          const long long w = __double_as_longlong(p[u].w);
+          const int j = static_cast<int>(w & 0xffffffffLL), tj = static_cast<int>(w >> 32);
+          const double d0 = p[u].x - xi, d1 = p[u].y - yi, d2 = p[u].z - zi;
+          const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+          bool in = (kk0 + u < kend) && (j != i) && (r2 < rc2row[tj]);         // dr2 < rc2(inxn), main.F90:366 (no bond row: cut-off 0)
+          if (!ORTHO && in) { double sj[3]; ref_norm(rm, p[u].x, p[u].y, p[u].z, sj); in = ref_bonded_cells_adjacent(rm, si, sj); }
+          if (in) {
+            if (cnt < MAXNB) mine[cnt] = j;
+            ++cnt;
+          }
         }
       }
     }
-    if (cnt > MAXNB) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXNB); cnt = MAXNB; }  // main.F90:402-407
-    nbrcnt[i] = cnt;
-    // err[2] = the longest list of this build if any is longer than 15 (the torsion kernel packs four atoms into a wavefront otherwise)
-    if (cnt > 15 && __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[2], cnt);
   }
+  if (cnt > MAXNB) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXNB); cnt = MAXNB; }  // main.F90:402-407
+  nbrcnt[i] = cnt;
+  // err[2] = the longest list of this build if any is longer than 15 (the torsion kernel packs four atoms into a wavefront otherwise)
+  if (cnt > 15 && __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[2], cnt);
 }
 
 // The sweep above leaves the lists in an atom-major staging array (slot s of atom i at i * 32 + s: a thread appends without knowing the
@@ -278,8 +234,9 @@ __global__ void __launch_bounds__(BL_TILE) k_bonded_list(int G, int MAXNB, int t
 // compact tables.  Every per-bond array of the engine is indexed by o: 5.3 entries per RDX atom instead of a 30-slot stride.
 __global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict__ nbr_sm, const int *__restrict__ nbrcnt, const int *__restrict__ boff,
                            int *__restrict__ nbr, int *__restrict__ brev, int *__restrict__ bown, const int *__restrict__ type, unsigned char *__restrict__ btype, int *err) {
-  // one thread per (atom, slot): blockIdx.y = slot; the blocks of slots no atom of theirs uses leave after one coalesced read of the counts
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x, s = blockIdx.y;
+  // one thread per (atom, slot): eight neighbouring lanes take eight consecutive slots of ONE atom (its staging line is read as a 32-byte piece, not by 8 workgroups),
+  // a workgroup 32 consecutive atoms; blockIdx.y = the block of eight slots -- the workgroups of slots no atom of theirs uses leave after one read of the counts
+  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 3) + (threadIdx.x >> 3), s = 8 * blockIdx.y + (threadIdx.x & 7);
   if (i >= G) return;
   const int ni = nbrcnt[i];
   if (s >= ni) return;
@@ -719,8 +676,8 @@ __global__ void __launch_bounds__(64 * L10_ROWS) k_list10(int N, int S10, Grid g
           const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
           double drtb = static_cast<double>(r2f) - itb * ff.UDR;
           drtb = drtb * ff.UDRi;
-          const double *T = ff.tabQEq + static_cast<size_t>(inxn) * (NTABLE + 2);
-          h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
+          const double2 T = ff.tabQEq2[static_cast<size_t>(inxn) * (NTABLE + 2) + itb];        // (T[itb], T[itb + 1]) in one 16-byte load
+          h = (1.0 - drtb) * T.x + drtb * T.y;
         }
         {   // window slot: the candidate's column (of this row) -> the group's table entry -> first unit of the column + offset inside it
 #ifdef RXMD_EXPERIMENTS
@@ -932,25 +889,24 @@ void Engine::build_windows() {
 }
 
 void Engine::build_bonded_list() {
-  k_pack_type<<<nblk(G, 256), 256, 0, stream>>>(G, perm, type, sorted_xyzi, sorted_type);
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
 #ifdef RXMD_BLIST_ROUND4
   if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
   else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
 #else
-  {   // one workgroup per (cell column, tile of BL_TILE atoms of it); a column of the mean population needs tiles_y - 1 tiles, fuller ones take turns
-    const int ncol = grid.n[0] * grid.n[1];
-    const int tiles_y = std::max(1, static_cast<int>((static_cast<long long>(G) / std::max(ncol, 1) + BL_TILE - 1) / BL_TILE)) + 1;
-    if (grid.ortho) k_bonded_list<true><<<ncol * tiles_y, BL_TILE, 0, stream>>>(G, MAXNB, tiles_y, grid, rmesh, dff, cellstart, sorted_xyzi, spos[0], spos[1], spos[2], nbr_sm, nbrcnt, d_err);
-    else k_bonded_list<false><<<ncol * tiles_y, BL_TILE, 0, stream>>>(G, MAXNB, tiles_y, grid, rmesh, dff, cellstart, sorted_xyzi, spos[0], spos[1], spos[2], nbr_sm, nbrcnt, d_err);
-  }
+  if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
+  else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
 #endif
   RX_HIP(hipMemsetAsync(nbrcnt + G, 0, sizeof(int), stream));                       // (G < NB always: the scan below runs over G + 1 counts)
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, nbrcnt, boff, G + 1, stream));
   RX_HIP(hipMemcpyAsync(d_err + 7, boff + G, sizeof(int), hipMemcpyDeviceToDevice, stream));   // bonds of this build: read with the error word the host waits for anyway
   RX_HIP(hipMemcpyAsync(d_err + 9, boff + N, sizeof(int), hipMemcpyDeviceToDevice, stream));   // ... and the residents' share of them
+#ifdef RXMD_BLIST_ROUND4
   k_bond_csr<<<dim3(nblk(G, 256), MAXNB), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, type, btype, d_err);
+#else
+  k_bond_csr<<<dim3(nblk(G, 32), (MAXNB + 7) / 8), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, type, btype, d_err);
+#endif
 }
 
 #ifdef RXMD_LIST10_ROUND4

@@ -6,9 +6,9 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O; shift
 ARGS="--steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-other-configs --no-steady $@"
-for ctr in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum "TCC_HIT_sum TCC_MISS_sum" SQ_INSTS_VALU; do
+for ctr in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum "TCC_HIT_sum TCC_MISS_sum" SQ_INSTS_VALU; do   # (each pass under its own time limit)
   tag=$(echo $ctr | tr ' ' '_')
-  rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$tag -- python3 bench.py $ARGS > $O/pmc_$tag.log 2>&1
+  RXMD_PLACE_TRIES=1 timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$tag -- python3 bench.py $ARGS > $O/pmc_$tag.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections, re
