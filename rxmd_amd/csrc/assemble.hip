@@ -125,19 +125,20 @@ __global__ void __launch_bounds__(256) k_stress_partial(int n, const double *__r
     __syncthreads();
   }
 }
-__global__ void k_stress_final(int nblocks, const double *__restrict__ partials, double *__restrict__ acc6) {
-  const int c = threadIdx.x;
-  if (c >= 6) return;
+// one wavefront per component: a lane adds every 64th partial sum, then the wavefront's fixed-order sum (240 dependent loads by one thread were 29 us)
+__global__ void __launch_bounds__(384) k_stress_final(int nblocks, const double *__restrict__ partials, double *__restrict__ acc6) {
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partials[b * 6 + c];
-  acc6[c] += s;
+  for (int b = lane; b < nblocks; b += 64) s += partials[b * 6 + c];
+  s = wave_sum64(s);
+  if (lane == 0) acc6[c] += s;
 }
 
 void Engine::accumulate_stress(bool kinetic) {
   const int n = kinetic ? N : G, nb = 240;
   if (kinetic) k_stress_partial<<<nb, 256, 0, stream>>>(n, vel[0], vel[1], vel[2], vel[0], vel[1], vel[2], type, dff, 1, partials);
   else k_stress_partial<<<nb, 256, 0, stream>>>(n, pos[0], pos[1], pos[2], frc[0], frc[1], frc[2], type, dff, 0, partials);
-  k_stress_final<<<1, 64, 0, stream>>>(nb, partials, scal + 48);
+  k_stress_final<<<1, 384, 0, stream>>>(nb, partials, scal + 48);
 }
 
 void Engine::force() {

@@ -880,9 +880,12 @@ __global__ void __launch_bounds__(256) k_ehb(int N, int S10, DevFF ff, const int
 // 51 M FP64 adds at the memory side are 0.67 ms whatever the wavefronts do around them (candidates sorted by atom index so that the acceptors of
 // one molecule sit in neighbouring lanes: 1.00; RDX donors have ONE hydrogen, so summing over slots saves nothing there).  The atomics are the floor.
 constexpr int EHB_CAP = 256;                              // candidates staged per flush (a 447-entry RDX row has <= 255 N / O partners)
+constexpr int EHB_REGIONS = 64;                           // sub-lists of the donor list, each with its own counter
 __global__ void __launch_bounds__(256) k_ehb_donors(int N, unsigned donor_types, const int *__restrict__ boff, const unsigned char *__restrict__ btype, const double *__restrict__ bo0,
-                                                     const int *__restrict__ type, int2 *__restrict__ don, int *__restrict__ cnt) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+                                                     const int *__restrict__ type, int2 *__restrict__ don, int *__restrict__ cnt, int region_cap) {
+  // the list is EHB_REGIONS lists (workgroup b appends to region b mod EHB_REGIONS, region_cap entries each): 15,000 returning atomics on ONE
+  // counter were 0.15 ms of this 0.18 ms kernel
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, reg = blockIdx.x & (EHB_REGIONS - 1);
   unsigned hm = 0u;
   if (i < N && ((donor_types >> (type[i] & 31)) & 1u)) {
     const int ob = boff[i], n = min(boff[i + 1] - ob, 32);
@@ -897,12 +900,12 @@ __global__ void __launch_bounds__(256) k_ehb_donors(int N, unsigned donor_types,
   if (m == 0ULL) return;
   const int first = __ffsll(static_cast<long long>(m)) - 1;
   int base = 0;
-  if (lane == first) base = atomicAdd(cnt, __popcll(m));
+  if (lane == first) base = atomicAdd(cnt + reg, __popcll(m));
   base = __shfl(base, first, 64);
-  if (hm != 0u) don[base + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(i, static_cast<int>(hm));
+  if (hm != 0u) don[static_cast<size_t>(reg) * region_cap + base + __popcll(m & ((1ULL << lane) - 1ULL))] = make_int2(i, static_cast<int>(hm));
 }
 
-__global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2 *__restrict__ don, const int *__restrict__ ndon, const int *__restrict__ boff, const int *__restrict__ nbr,
+__global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2 *__restrict__ don, const int *__restrict__ ndon, int region_cap, const int *__restrict__ boff, const int *__restrict__ nbr,
                                                     const int *__restrict__ type, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                     const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10, const double4 *__restrict__ pk, const int *__restrict__ perm,
                                                     double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
@@ -923,10 +926,16 @@ __global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2
   __shared__ int s_k[4][EHB_CAP];
   __shared__ double s_hp[4][16][4];                       // (ti, H, type k) parameter rows of the current donor, by acceptor type
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int nw = gridDim.x * 4, nd = *ndon;
+  // the donor list is EHB_REGIONS sub-lists: lane r holds the inclusive prefix of their lengths; donor d lives in the first region whose prefix exceeds d
+  int pre = ndon[lane & (EHB_REGIONS - 1)];
+#pragma unroll
+  for (int o = 1; o < EHB_REGIONS; o <<= 1) { const int t = __shfl_up(pre, o, 64); if (lane >= o) pre += t; }
+  const int nw = gridDim.x * 4, nd = __shfl(pre, EHB_REGIONS - 1, 64);
   double e10 = 0.0;
   for (int d = blockIdx.x * 4 + w; d < nd; d += nw) {
-    const int2 rec = don[d];
+    const int reg = __popcll(__ballot(pre <= d));                       // (EHB_REGIONS == 64: one lane per region)
+    const int before = reg > 0 ? __shfl(pre, reg - 1, 64) : 0;
+    const int2 rec = don[static_cast<size_t>(reg) * region_cap + (d - before)];
     const int i = __builtin_amdgcn_readfirstlane(rec.x);
     const unsigned hmask = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(rec.y));
     EHB_CHECK(1, i, lim_n, d)
@@ -1082,20 +1091,24 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
   k_ehb<<<nblk(N, 4 * 16), 256, 0, stream>>>(N, S10, dff, boff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, 0);
 #else
   if (ehb_donor_types != 0u) {                    // (a force field without a hydrogen-bond row for hydrogen = type 2 has no donors: water, pot.F90:595)
-    RX_HIP(hipMemsetAsync(ehb_cnt, 0, sizeof(int), stream));
-    k_ehb_donors<<<nblk(N, 256), 256, 0, stream>>>(N, ehb_donor_types, boff, btype, bo0, type, ehb_don, ehb_cnt);
+    const int region_cap = (nblk(N, 256) + EHB_REGIONS - 1) / EHB_REGIONS * 256;            // every atom of the workgroups of a region a donor: cannot overflow
+    if (static_cast<size_t>(region_cap) * EHB_REGIONS > ehb_don_cap) throw EngineError(RXMD_E_STATE, "hydrogen-bond donor list: capacity");
+    RX_HIP(hipMemsetAsync(ehb_cnt, 0, sizeof(int) * EHB_REGIONS, stream));
+    k_ehb_donors<<<nblk(N, 256), 256, 0, stream>>>(N, ehb_donor_types, boff, btype, bo0, type, ehb_don, ehb_cnt, region_cap);
     if (ehb_blocks_per_cu == 0) {                 // the persistent grid fills the device exactly: workgroups per CU from the kernel's own register / LDS footprint
       int nbk = 0;
       RX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, k_ehb_sweep, 256, 0));
       ehb_blocks_per_cu = std::max(nbk, 1);
     }
 #ifdef RXMD_EHB_DEBUG
-    RX_HIP(hipMemsetAsync(ehb_cnt + 4, 0, 4 * sizeof(int), stream));
-    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_cnt + 4, N, static_cast<int>(bcap), NB);
-    { int hd[8]; RX_HIP(hipMemcpyAsync(hd, ehb_cnt, sizeof(hd), hipMemcpyDeviceToHost, stream)); RX_HIP(hipStreamSynchronize(stream));
+    RX_HIP(hipMemsetAsync(ehb_cnt + EHB_REGIONS, 0, 4 * sizeof(int), stream));
+    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, region_cap, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_cnt + EHB_REGIONS, N, static_cast<int>(bcap), NB);
+    { int hd[EHB_REGIONS + 4]; RX_HIP(hipMemcpyAsync(hd, ehb_cnt, sizeof(hd), hipMemcpyDeviceToHost, stream)); RX_HIP(hipStreamSynchronize(stream));
+      for (int r = 1; r < EHB_REGIONS; ++r) hd[0] += hd[r];
+      hd[4] = hd[EHB_REGIONS]; hd[5] = hd[EHB_REGIONS + 1]; hd[6] = hd[EHB_REGIONS + 2]; hd[7] = hd[EHB_REGIONS + 3];
       std::fprintf(stderr, "[ehb debug] donors %d  blocks/CU %d  first violation: code %d value %d aux %d lim %d   (N %d bcap %zu NB %d S10 %d rows10 %d)\n", hd[0], ehb_blocks_per_cu, hd[4], hd[5], hd[6], hd[7], N, bcap, NB, S10, rows10); }
 #else
-    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
+    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, region_cap, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
 #endif
   }
 #endif

@@ -204,7 +204,7 @@ struct Engine {
   double *bt1 = nullptr, *bt2 = nullptr, *bt3 = nullptr;                        // per-bond scratch: terms a lane-per-bond kernel leaves for the per-atom sum behind it
   double *ecoef = nullptr;                                                      // 6 per-atom coefficients of Elnpr (bonded.hip)
   int nbonds_res = 0;                                                           // bonds of the residents = boff[N]: the first nbonds_res entries of the tables
-  int2 *ehb_don = nullptr; int *ehb_cnt = nullptr; unsigned ehb_donor_types = 0u; int ehb_blocks_per_cu = 0; // hydrogen bonds (bonded.hip): donor list (atom, mask of its hydrogen slots), its length, types X with a row (X, H = 2, any)
+  int2 *ehb_don = nullptr; size_t ehb_don_cap = 0; int *ehb_cnt = nullptr; unsigned ehb_donor_types = 0u; int ehb_blocks_per_cu = 0; // hydrogen bonds (bonded.hip): donor list (atom, mask of its hydrogen slots), its length, types X with a row (X, H = 2, any)
   double *deltap = nullptr, *delta = nullptr, *nlp = nullptr, *dDlp = nullptr, *deltalp = nullptr;
   double *cds = nullptr, *cd = nullptr, *cc_ = nullptr;
   // 10 A list

@@ -375,7 +375,7 @@ void Engine::alloc_device() {
     if (const char *bc = std::getenv("RXMD_BOND_CAP")) { const long long v = std::atoll(bc); if (v > 0) cap = static_cast<size_t>(v); }
     alloc_bond_tables(cap);
   }
-  dmalloc(ehb_don, static_cast<size_t>(rows10)); dzalloc(ehb_cnt, 8);
+  ehb_don_cap = static_cast<size_t>(rows10) + 64 * 256 + 256; dmalloc(ehb_don, ehb_don_cap); dzalloc(ehb_cnt, 72);   // 64 sub-lists (bonded.hip EHB_REGIONS) + debug words
   dmalloc(ecoef, 6 * nb); dmalloc(deltap, nb); dmalloc(delta, nb); dmalloc(nlp, nb); dmalloc(dDlp, nb); dmalloc(deltalp, nb); dmalloc(cds, nb); dmalloc(cd, nb); dmalloc(cc_, nb);
   dmalloc(nb10, static_cast<size_t>(rows10) * S10);
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
@@ -1564,7 +1564,7 @@ void Engine::poison_step_scratch() {
   fill(nbr_sm, 0, sizeof(int) * ns); fill(nbrcnt, 0, sizeof(int) * (nb + 1)); fill(boff, 0, sizeof(int) * (nb + 2));
   fill(nbr, 0, sizeof(int) * bcap); fill(brev, 0, sizeof(int) * bcap); fill(bown, 0, sizeof(int) * bcap); fill(btype, 0, bcap);
   for (double *t : {bo0, bo1, bo2, bo3, dln2, dln3, dBOp, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen, ecoa, bt1, bt2, bt3}) fill(t, 0, sizeof(double) * bcap);
-  fill(ecoef, 0, sizeof(double) * 6 * nb); fill(ehb_don, 0, sizeof(int2) * rows10);
+  fill(ecoef, 0, sizeof(double) * 6 * nb); fill(ehb_don, 0, sizeof(int2) * ehb_don_cap);
   for (double *t : {deltap, delta, nlp, dDlp, deltalp, cds, cd, cc_}) fill(t, 0, sizeof(double) * nb);
   fill(nb10, 0, sizeof(int) * nl); fill(hess, 0, sizeof(double) * nl); fill(sl10, 0, sizeof(unsigned short) * nl); fill(n10, 0, sizeof(int) * rows10);
   fill(rows_int, 0, sizeof(int) * rows10); fill(rows_bnd, 0, sizeof(int) * rows10);

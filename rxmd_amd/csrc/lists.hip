@@ -683,7 +683,7 @@ __global__ void __launch_bounds__(64 * L10_ROWS) k_list10(int N, int S10, Grid g
 #ifdef RXMD_EXPERIMENTS
           if (!(g.probe & 4))
 #endif
-          sl10[row + slot] = static_cast<unsigned short>((k - cE[t_]) | (j >= N ? 0x8000 : 0));     // cE: first position of the column's interval - 8 x its first unit
+          __builtin_nontemporal_store(static_cast<unsigned short>((k - cE[t_]) | (j >= N ? 0x8000 : 0)), sl10 + row + slot);     // cE: first position of the column's interval - 8 x its first unit
         }
         unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
         if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
@@ -696,11 +696,11 @@ __global__ void __launch_bounds__(64 * L10_ROWS) k_list10(int N, int S10, Grid g
 #ifdef RXMD_EXPERIMENTS
         if (!(g.probe & 8))
 #endif
-        nb10[row + slot] = static_cast<int>(ent);
+        __builtin_nontemporal_store(static_cast<int>(ent), nb10 + row + slot);      // the three streams are written once and read by other kernels: past the L2, which holds the table nodes
 #ifdef RXMD_EXPERIMENTS
         if (!(g.probe & 16))
 #endif
-        hess[row + slot] = h;
+        __builtin_nontemporal_store(h, hess + row + slot);
       }
     }
     cnt += nproc;

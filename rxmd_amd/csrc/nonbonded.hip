@@ -24,19 +24,15 @@ __device__ inline double wave_sum_n(double v) { return wave_sum64(v); }   // DPP
 
 // one pair of a row: r^2, the table node of the type pair, energies (half of the pair from each side), force on the row's atom, pair virial
 struct NbAcc { double f0, f1, f2, v0, v1, v2, v3, v4, v5, e11, e12; };
-// INXN_IN_LANES: the bond row of (type of the row's atom, t) is held by lane t of the wavefront (ixl) and fetched with a lane permute -- no
-// dependent global look-up in front of the table node (every lane must call this: the permute reads inactive lanes' registers but not their results)
-template <bool INXN_IN_LANES = false>
-__device__ inline void nb_pair(const DevFF &ff, const int *__restrict__ ix2, double xi, double yi, double zi, double qi, const double4 &pj, int tj, NbAcc &a, int ixl = 0) {
+__device__ inline void nb_pair(const DevFF &ff, const int *__restrict__ ix2, double xi, double yi, double zi, double qi, const double4 &pj, int tj, NbAcc &a) {
   const double d0 = xi - pj.x, d1 = yi - pj.y, d2 = zi - pj.z;
   const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-  const int inxn = INXN_IN_LANES ? __shfl(ixl, tj, 64) : 0;
   if (r2 > ff.rctap2) return;                                     // pot.F90:720
-  const int inxn_ = INXN_IN_LANES ? inxn : ix2[tj];
+  const int inxn = ix2[tj];
   const int itb = static_cast<int>(r2 * ff.UDRi);                 // pot.F90:729-733
   double t = r2 - itb * ff.UDR;
   t = t * ff.UDRi;
-  const DevNBTab nd = ff.tabNB[static_cast<size_t>(inxn_) * (NTABLE + 2) + itb];
+  const DevNBTab nd = ff.tabNB[static_cast<size_t>(inxn) * (NTABLE + 2) + itb];
   const double qij = qi * pj.w;
   const double CEvdw = nd.CEvdw + t * nd.dCEvdw_;
   const double CEclmb = (nd.CEclmb + t * nd.dCEclmb_) * qij;
@@ -151,22 +147,17 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_nonbond_win(int N, int G, 
     const int n = n10[i] & N10_COUNT;
     const size_t row = static_cast<size_t>(i) * S10;
     const int *ix2 = ff.inxn2 + ti * ff.n1;
-    const int ixl = lane < ff.n1 ? ix2[lane] : 0;                         // lane t: the bond row of (ti, t) -- one load per row instead of one dependent gather per pair
     NbAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < n; k0 += 64 * NB_UNR) {                          // (wave-uniform trip count: every lane takes part in the lane permutes)
+    for (int k0 = lane; k0 < n; k0 += 64 * NB_UNR) {
       unsigned ee[NB_UNR];
 #pragma unroll
-      for (int u = 0; u < NB_UNR; ++u) { const int k = k0 + lane + 64 * u; ee[u] = (k < n) ? static_cast<unsigned>(__builtin_nontemporal_load(sl10 + row + k)) : 0xffffu; }
+      for (int u = 0; u < NB_UNR; ++u) { const int k = k0 + 64 * u; ee[u] = (k < n) ? static_cast<unsigned>(__builtin_nontemporal_load(sl10 + row + k)) : 0xffffu; }
 #pragma unroll
       for (int u = 0; u < NB_UNR; ++u) {
-        if (k0 + 64 * u >= n) break;                                     // (wave-uniform)
-        const bool ok = ee[u] != 0xffffu;                                // behind the row's end (no slot is that large)
-        const int sl = ok ? static_cast<int>(ee[u] & 0x7fffu) : 0;
-        double4 pj; int tj;
-        if (sl < capslots) { pj = s_p[sl]; tj = static_cast<int>(s_t[sl]); }
-        else { const int pos = min(wk[sl / WIN_UNIT] + (sl & (WIN_UNIT - 1)), G - 1); pj = pk[pos]; tj = static_cast<int>(stype[pos]); }
-        if (!ok) pj.x = 1e30;                                            // (far beyond the cut-off: the pair books nothing)
-        nb_pair<true>(ff, ix2, xi, yi, zi, qi, pj, tj & 31, acc, ixl);
+        if (ee[u] == 0xffffu) continue;                                  // behind the row's end (no slot is that large)
+        const int sl = static_cast<int>(ee[u] & 0x7fffu);
+        if (sl < capslots) nb_pair(ff, ix2, xi, yi, zi, qi, s_p[sl], static_cast<int>(s_t[sl]), acc);
+        else { const int pos = min(wk[sl / WIN_UNIT] + (sl & (WIN_UNIT - 1)), G - 1); nb_pair(ff, ix2, xi, yi, zi, qi, pk[pos], static_cast<int>(stype[pos]), acc); }
       }
     }
     e11 = acc.e11; e12 = acc.e12;

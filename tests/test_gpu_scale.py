@@ -158,7 +158,7 @@ def test_perturbed_rdx_36k_through_the_multi_rank_path(qeq_mode, overlap, direct
     nb = st["n_boundary_rows"]
     assert 0 < nb < 0.9 * st["natoms"], "interior rows expected: %d boundary rows of %d" % (nb, st["natoms"])
     # the matrix passes were window passes (groups of 16 cell-sorted rows; with overlap: interior groups under the halo, boundary groups behind it)
-    assert st["win_in_use"] == 1 and st["win_groups"] >= (st["natoms"] + 15) // 16, st
+    assert st["win_in_use"] == 1 and (st["natoms"] + 15) // 16 <= st["win_groups"] <= st["natoms"] // 16 + st["cells10"][0] * st["cells10"][1] + 1, st
     e.step(NSTEPS)
     _check_trajectory(e, s1, s0)
     assert e.stats()["win_in_use"] == 1
