@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(32 * WIN_ROWS) k_win_columns(int N, Grid g, co
     int k0 = 0, len = 0;
     if (l5 < 25) column_run<ORTHO>(g, cellstart, spx[i], spy[i], spz[i], cx, cy, cx + l5 / 5 - 2, cy + l5 % 5 - 2, rcp, k0, len);
     if (len > 0) { atomicMin(&t_lo[l5], k0); atomicMax(&t_hi[l5], k0 + len); }
-    rowcols[static_cast<size_t>(ridx) * 64 + l5] = k0; rowcols[static_cast<size_t>(ridx) * 64 + 32 + l5] = len;
+    __builtin_nontemporal_store(k0, rowcols + static_cast<size_t>(ridx) * 64 + l5); __builtin_nontemporal_store(len, rowcols + static_cast<size_t>(ridx) * 64 + 32 + l5);   // (read once, by the sweep)
   }
   __syncthreads();
   if (w != 0) return;
@@ -671,7 +671,7 @@ __global__ void __launch_bounds__(64 * L10_ROWS) k_list10(int N, int S10, Grid g
             pq_lookup(ff, ff.tabPss, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
             p_ss += 0.5 * C0q * E * Zi * Zj;
           }
-          hsc[row + slot] = hc;
+          __builtin_nontemporal_store(hc, hsc + row + slot);
         } else if (inq && static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
           const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
           double drtb = static_cast<double>(r2f) - itb * ff.UDR;
