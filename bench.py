@@ -534,7 +534,8 @@ def main():
                  ("k_bo_prime+k_deltap+k_bo_full+k_delta_lp", "ms_k_bondorder", G * nb * 104.0, a.steps, "BOPRIM + BOFULL over residents and ghosts (bo.F90:28-298)"),
                  ("k_e3b", "ms_k_e3b", st["natoms"] * nb * 104.0, a.steps, "E3b (pot.F90:319-557): FP64 chains, not bytes, bound it"),
                  ("k_e4b", "ms_k_e4b", st["natoms"] * nb * 104.0, a.steps, "E4b (pot.F90:980-1227): FP64 chains"),
-                 ("k_ehb", "ms_k_ehb", st["natoms"] * nb * 104.0, a.steps, "Ehb (pot.F90:559-673)"),
+                 ("k_ehb_donors+k_ehb_sweep+k_ehb", "ms_k_ehb", st["natoms"] * nb * 104.0, a.steps, "Ehb (pot.F90:559-673): bound by the 51 M memory-side FP64 atomics of the acceptor forces"),
+                 ("k_bonded_list+k_bond_csr", "ms_k_blist", G * (32.0 + nb * 13.0), a.steps, "NEIGHBORLIST + nbrindx (main.F90:321-417): positions read once, partner / owner / mirror / type written per bond"),
                  ("k_cd_gather+k_ccbnd_terms+k_ccbnd_sum+k_bond_force_terms+k_bond_force_sum", "ms_k_assemble", G * nb * 104.0, a.steps, "ForceBondedTerms as gathers (pot.F90:113-144)")]
         def l2_bytes_for(*parts):
             """L1 <- L2 read bytes per launch: TCP_TCC_READ_REQ x 128 B (one request = one 128-byte line), summed over the named kernels; None if absent"""
@@ -607,7 +608,7 @@ def main():
                          "bytes_per_entry": 20 if pqeq else 12,
                          "step_bytes_per_atom_executed": b_step_exec, "step_frac_of_hbm_roofline": (b_step_exec * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9),
                          "kernels": kernels},
-            "breakdown_ms_per_step": {k: st[k] / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded",
+            "breakdown_ms_per_step": {k: st.get(k, 0.0) / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_blist",
                                                                     "ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold", "ms_k_winbuild")},
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
         }

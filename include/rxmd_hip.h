@@ -180,6 +180,7 @@ typedef struct rxmd_stats {
   int place_draws;
   /* the instance of the matrix pass the engine dispatched last: k_spmv_win<MODE, STORE, PQ, spmv_nstep, spmv_var> (qeq.hip); 0, 0 = the row pass k_spmv */
   int spmv_nstep, spmv_var, reserved3;
+  double ms_k_blist;                    /* the bonded list: sweep + prefix sum + packing into the compact tables (k_bonded_list, k_bond_csr) */
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);

@@ -204,6 +204,16 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const in
   for (int t = lane_; t < nst; t += 64) { l_cf[t] = cf1[ob_w + t]; l_cd[t] = cdn[ob_w + t]; l_fx[t] = fnx[ob_w + t]; l_fy[t] = fny[ob_w + t]; l_fz[t] = fnz[ob_w + t]; }
   wave_lds_sync();
   auto acc1 = [&](double *__restrict__ gl, double *ld, int o, double v) { const int r = o - ob_w; if (r < nst) ld[r] += v; else gl[o] += v; };
+  // the angle row of a type triple and its seven parameters from LDS (round 5): inxn3 -> angle[] were two dependent look-ups in front of every
+  // angle's arithmetic, at two wavefronts per SIMD nothing hides them.  Force fields with more than 7 atom types or 63 angle rows keep the global path.
+  __shared__ int s_ix3[512];
+  __shared__ double s_ang[64][7];
+  const bool ang_lds = ff.n1 <= 8 && ff.nvaty <= 63;
+  if (ang_lds) {
+    for (int t = threadIdx.x; t < ff.n1 * ff.n1 * ff.n1; t += 256) s_ix3[t] = ff.inxn3[t];
+    for (int t = threadIdx.x; t < 7 * (ff.nvaty + 1); t += 256) s_ang[t / 7][t % 7] = reinterpret_cast<const double *>(ff.angle)[t];
+    __syncthreads();
+  }
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
   if (tid < N) {
     const int j = tid;
@@ -258,9 +268,11 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const in
         const double BOjk_f = bo0[ok], BOjk = BOjk_f - cutof2_esub;
         if (!(BOij_f * BOjk_f > cutof2_esub)) continue;
         const int k = nbr[ok], tk = btype[ok];
-        const int inxn = ff.inxn3[(ti * ff.n1 + tj) * ff.n1 + tk];
+        const int inxn = ang_lds ? s_ix3[(ti * ff.n1 + tj) * ff.n1 + tk] : ff.inxn3[(ti * ff.n1 + tj) * ff.n1 + tk];
         if (inxn == 0) continue;
-        const DevAngleP ap = ff.angle[inxn];
+        DevAngleP ap;
+        if (ang_lds) { const double *a_ = s_ang[inxn]; ap = DevAngleP{a_[0], a_[1], a_[2], a_[3], a_[4], a_[5], a_[6]}; }
+        else ap = ff.angle[inxn];
         const V3 rjk = {xj - x[k], yj - y[k], zj - z[k]};
         const double njk = sqrt(dot(rjk, rjk));
         double cos_ijk = -dot(rij, rjk) / (nij * njk);
@@ -354,6 +366,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
   // per (atom g, slot) as CENTRE bond k1: factors shared by all torsions around it; a bond count of 0 marks "no torsion through this bond"
   __shared__ double s_btb2[4][64], s_dfn11[4][64];
   __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
+  __shared__ int s_ql[4][128]; __shared__ unsigned short s_qx[4][128];     // ... with atom l and the torsion row of (i, j, k, l): phase A has both at hand (round 5: phase B fetched them again, four dependent round trips in front of its arithmetic)
   // phase A walks only bonds above the cut-off: the slots of each centre atom that qualify, and per centre bond the qualifying slots
   // of k with what the filter needs of them (bond order, atom l, its type) -- staged once per centre bond by the lanes side by side
   __shared__ int s_cap[4][64], s_capl[4][64], s_ll[4][64], s_tl[4][64], s_gj[4][8][2];   // s_gj: bond count and type of each centre atom
@@ -377,10 +390,11 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
   // "is there a torsion row for these four types" (pot.F90:1078) as a bit table in LDS when the ffield has at most 7 atom types
   // (n1^4 <= 4096 bits): the enumeration asks it for every candidate, and a look-up in global memory is a dependent round trip
   // per centre bond
-  __shared__ unsigned s_tor[128];
-  const bool tor_lds = ff.n1 <= 8;
+  __shared__ unsigned char s_tor[4096];           // the torsion row of every type quadruple (0: none), n1^4 <= 4096 entries of a force field with at most 255 rows
+  const bool tor_lds = ff.n1 <= 8 && ff.ntoty <= 255;
   if (tor_lds) {
-    if (threadIdx.x < 128) s_tor[threadIdx.x] = ff.tor_bits[threadIdx.x];      // built once on the host (upload_ff)
+    const int n4 = ff.n1 * ff.n1 * ff.n1 * ff.n1;
+    for (int t = threadIdx.x; t < n4; t += 256) s_tor[t] = static_cast<unsigned char>(ff.inxn4[t]);
     __syncthreads();
   }
   const int jbase = (xcd_swizzle(blockIdx.x, gridDim.x) * 4 + w) * NG;
@@ -479,9 +493,9 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
       const double BOjk = BOjk_f - cutof2_esub, BOij = BOij_f - cutof2_esub;
       const bool own = (mk_ >> 16) != 0;
       const int ol = s_bofn[w][sk] + l1;
-      const int l = nbr[ol];
-      const int inxn = ff.inxn4[(((s_meta[w][si] & 255) * ff.n1 + tj) * ff.n1 + tk) * ff.n1 + type[l]];
-      const DevTorsP tp = ff.tors[inxn];
+      const int l = s_ql[w][lane];
+      const DevTorsP tp = ff.tors[s_qx[w][lane]];
+      (void)tj; (void)tk;
       const V3 rjk = {-s_rx[w][sk], -s_ry[w][sk], -s_rz[w][sk]};          // r_j - r_k
       const double njk = s_rn[w][sk];
       const V3 rij = {s_rx[w][si], s_ry[w][si], s_rz[w][si]};
@@ -660,7 +674,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
     for (int c0 = 0; c0 < total; c0 += 64) {
       const int idx = c0 + lane;
       bool go = false;
-      int key = 0;
+      int key = 0, ql = 0, qx = 0;
       if (idx < total) {
         int cb = 0;
 #pragma unroll
@@ -678,20 +692,22 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
              (BOjk_f * BOkl_f > cutof2_esub) && (BOij_f * (BOjk_f * BOjk_f) * BOkl_f > MINBO0) && (l != i) && (l != j);
         if (go) {
           const int i4 = (((s_meta[w][gb + i1] & 255) * ff.n1 + tjc) * ff.n1 + (s_meta[w][sk] & 255)) * ff.n1 + s_tl[w][cl];
-          go = tor_lds ? ((s_tor[i4 >> 5] >> (i4 & 31)) & 1u) != 0u : ff.inxn4[i4] != 0;
+          qx = tor_lds ? static_cast<int>(s_tor[i4]) : ff.inxn4[i4];
+          go = qx != 0;
         }
         key = (g << 15) | (k1 << 10) | (i1 << 5) | l1;
+        ql = l;
       }
       const unsigned long long m = __ballot(go);
-      if (go) s_q[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = key;
+      if (go) { const int qp = qn + __popcll(m & ((1ULL << lane) - 1ULL)); s_q[w][qp] = key; s_ql[w][qp] = ql; s_qx[w][qp] = static_cast<unsigned short>(qx); }
       qn += __popcll(m);
       wave_lds_sync();
       if (qn >= 64) {
         evaluate(64);
         const int rest = qn - 64;
-        const int v = (lane < rest) ? s_q[w][64 + lane] : 0;
+        const int v = (lane < rest) ? s_q[w][64 + lane] : 0, vl = (lane < rest) ? s_ql[w][64 + lane] : 0, vx = (lane < rest) ? s_qx[w][64 + lane] : 0;
         wave_lds_sync();
-        if (lane < rest) s_q[w][lane] = v;
+        if (lane < rest) { s_q[w][lane] = v; s_ql[w][lane] = vl; s_qx[w][lane] = static_cast<unsigned short>(vx); }
         wave_lds_sync();
         qn = rest;
       }

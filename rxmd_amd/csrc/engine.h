@@ -47,7 +47,7 @@ struct DevHbP { double r0hb, phb1, phb2, phb3; };
 struct DevNBTab { double Evdw, dEvdw_, CEvdw, dCEvdw_, Eclmb, dEclmb_, CEclmb, dCEclmb_; };
 
 struct DevFF {
-  int nso, n1, nboty;
+  int nso, n1, nboty, ntoty, nvaty;
   const DevAtomP *atom; const DevBondP *bond; const DevAngleP *angle; const DevTorsP *tors; const DevHbP *hb;
   const int *inxn2, *inxn3, *inxn3hb, *inxn4;
   const unsigned *tor_bits;     // inxn4 != 0 as a bit table of 4096 bits (valid when n1 <= 8): k_e4b keeps it in LDS
@@ -277,7 +277,7 @@ struct Engine {
   void ghost_build_fused(); void migrate_fused(); void ensure_seg_buffers(int nblocks);   // single rank: the six-stage self exchange as 26 image segments (engine.hip)
   int *seg_cnt = nullptr, *seg_tot = nullptr, *h_seg = nullptr; unsigned char *seg_code_ = nullptr; int seg_blocks_cap = 0;
   void bin_cells();
-  void build_bonded_list();
+  void build_bonded_list(bool pack_only = false);
   void build_list10();
   // Window form of the 10 A matrix (lists.hip, qeq.hip k_spmv_win): the residents in cell-sorted order in groups of WIN_ROWS rows; per group the
   // set of cell-sorted positions its rows couple to, in units of WIN_UNIT consecutive positions (win_k: first position of each unit, ascending;
@@ -352,7 +352,8 @@ struct Engine {
   void remove_momentum();         // LinearMomentum, main.F90:766-797
   void assemble_forces();
   void accumulate_stress(bool kinetic);   // astr(1:6) on the device (scal[48..53])
-  void check_device_error(const char *where);
+  void check_device_error(const char *where, bool fetch = true);
+  void fetch_device_error();      // the error word and the counts that ride with it -> h_err (one host wait), nothing thrown
   double reduce_partials(int ncomp, int nblocks, double *out);  // host-side helper
   // Event pairs around single launches / exchanges, from a small pool; a finished pair is read back the next time the host has synchronised
   // with a stream anyway (collect_timers: only pairs whose end event has completed -- an exchange on the second stream may still be running),

@@ -196,9 +196,12 @@ void Engine::collect_timers() {
   kt_pending.resize(keep);
 }
 
-void Engine::check_device_error(const char *where) {
+void Engine::fetch_device_error() {
   RX_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int) * 16, hipMemcpyDeviceToHost, stream));
   sync_stream();
+}
+void Engine::check_device_error(const char *where, bool fetch) {
+  if (fetch) fetch_device_error();
   const int e = h_err[0];
   if (e == DERR_NONE) return;
   RX_HIP(hipMemsetAsync(d_err, 0, sizeof(int) * 2, stream));   // [2] (longest bond list of the build) stays: a retry rebuilds the 10 A list only
@@ -322,7 +325,7 @@ void Engine::upload_ff() {
   RX_HIP(hipMalloc(&ffblob, tot));
   for (int i = 0; i < 12; ++i) RX_HIP(hipMemcpy(static_cast<char *>(ffblob) + off[i], src[i], sz[i], hipMemcpyHostToDevice));
   char *base = static_cast<char *>(ffblob);
-  dff.nso = ff.nso; dff.n1 = n1; dff.nboty = ff.nboty;
+  dff.nso = ff.nso; dff.n1 = n1; dff.nboty = ff.nboty; dff.ntoty = ff.ntoty; dff.nvaty = ff.nvaty;
   dff.atom = reinterpret_cast<DevAtomP *>(base + off[0]); dff.bond = reinterpret_cast<DevBondP *>(base + off[1]);
   dff.angle = reinterpret_cast<DevAngleP *>(base + off[2]); dff.tors = reinterpret_cast<DevTorsP *>(base + off[3]);
   dff.hb = reinterpret_cast<DevHbP *>(base + off[4]);
@@ -1584,12 +1587,21 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   poison_step_scratch();
   { const bool kt = kt_begin(&st.ms_ghost_build); ghost_build(); kt_end(kt); }
   bin_cells();
-  build_bonded_list();
+  { const bool kt = kt_begin(&st.ms_k_blist); build_bonded_list(); kt_end(kt); }
   sums_from_list = qeq_prepass;
   if (qeq_prepass) qeq_start_vectors();             // the sweep below also forms H.(qs,qt) of the CG start vector
   build_list10();
+  // The host wait of the build.  First of all the bond tables: a build with more bonds than they hold left them partially packed (k_bond_csr skips
+  // the atoms beyond the capacity) -- they are grown and packed again from the intact staging lines BEFORE anything else can throw, so that no
+  // error path leaves undersized tables and stale counts behind.
+  fetch_device_error();
+  if (static_cast<size_t>(h_err[7]) > bcap) {
+    free_bond_tables();
+    alloc_bond_tables(static_cast<size_t>(h_err[7]) + static_cast<size_t>(h_err[7]) / 4 + 4096);
+    build_bonded_list(true);
+  }
   try {
-    check_device_error("list build");
+    check_device_error("list build", false);             // (the words are here already)
   } catch (const EngineError &er) {
     // The row stride of the 10 A list is sized from the MEAN density; a dense region inside a sparse box (a nanoparticle in
     // vacuum) can need more.  The reference stops (fixed MAXNEIGHBS10 = 1500, qeq.F90:248-252); here the list grows once to
@@ -1603,12 +1615,6 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     st.n10_stride = S10;
     build_list10();
     check_device_error("list build");
-  }
-  if (static_cast<size_t>(h_err[7]) > bcap) {          // more bonds than the compact tables hold: grow them and pack the lists again (the staging array is intact)
-    free_bond_tables();
-    alloc_bond_tables(static_cast<size_t>(h_err[7]) + static_cast<size_t>(h_err[7]) / 4 + 4096);
-    build_bonded_list();
-    check_device_error("bond tables");
   }
   nbonds = h_err[7]; nbonds_res = h_err[9];
   win_groups = h_err[8];                               // groups of this build (build_windows; the sweep ran over the host-side bound)

@@ -888,7 +888,9 @@ void Engine::build_windows() {
   RX_HIP(hipMemsetAsync(win_flag, 0, sizeof(int) * (static_cast<size_t>(win_groups) + 1), stream));              // ... and interior until the sweep finds a row with a ghost partner
 }
 
-void Engine::build_bonded_list() {
+void Engine::build_bonded_list(bool pack_only) {
+  // pack_only: the compact tables were too small for this build and have been re-allocated; the staging lines and the counts of the sweep are intact
+  if (!pack_only) {
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
 #ifdef RXMD_BLIST_ROUND4
   if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
@@ -897,6 +899,7 @@ void Engine::build_bonded_list() {
   if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
   else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
 #endif
+  }
   RX_HIP(hipMemsetAsync(nbrcnt + G, 0, sizeof(int), stream));                       // (G < NB always: the scan below runs over G + 1 counts)
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, nbrcnt, boff, G + 1, stream));

@@ -32,7 +32,7 @@ __device__ inline void nb_pair(const DevFF &ff, const int *__restrict__ ix2, dou
   const int itb = static_cast<int>(r2 * ff.UDRi);                 // pot.F90:729-733
   double t = r2 - itb * ff.UDR;
   t = t * ff.UDRi;
-  const DevNBTab nd = ff.tabNB[static_cast<size_t>(inxn) * (NTABLE + 2) + itb];
+  const DevNBTab nd = ff.tabNB[static_cast<size_t>(inxn) * (NTABLE + 2) + itb];   // (four non-temporal 16-byte loads instead: 12.5 ms against 3.1 -- the table must STAY in L2)
   const double qij = qi * pj.w;
   const double CEvdw = nd.CEvdw + t * nd.dCEvdw_;
   const double CEclmb = (nd.CEclmb + t * nd.dCEclmb_) * qij;
