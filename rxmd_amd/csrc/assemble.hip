@@ -141,37 +141,39 @@ void Engine::accumulate_stress(bool kinetic) {
   k_stress_final<<<1, 384, 0, stream>>>(nb, partials, scal + 48);
 }
 
-void Engine::force() {
+void Engine::force(bool defer_host_read) {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
-  tic(6);
+  const KtPair t_force = outer_begin(&st.ms_force);
   if (!lists_valid) build_ghosts_and_lists();
   double *pe_d = scal + 32;
   RX_HIP(hipMemsetAsync(pe_d, 0, sizeof(double) * 16, stream));
-  hipEventRecord(ev[2], stream);
   // the ghost-charge halo needs nothing from the bond orders and they need no charges: on a multi-rank run the exchange goes to
   // the second stream and meets the main stream again in front of the nonbonded kernel
   if (multi()) on_comm_stream([&] { charge_halo(); }); else charge_halo();
-  { const bool kt = kt_begin(&st.ms_k_bondorder); bond_orders(); kt_end(kt); }
-  hipEventRecord(ev[3], stream);
+  { const bool kt = kt_begin(&st.ms_k_bondorder, &st.ms_bo); bond_orders(); kt_end(kt); }
   if (multi()) join_comm_stream();
-  { const bool kt = kt_begin(&st.ms_k_nonbond); if (ff.pqeq) nonbonded_pqeq(); else nonbonded(); kt_end(kt); }     // pot.F90:48-52
-  hipEventRecord(ev[4], stream);
+  { const bool kt = kt_begin(&st.ms_k_nonbond, &st.ms_nonbond); if (ff.pqeq) nonbonded_pqeq(); else nonbonded(); kt_end(kt); }     // pot.F90:48-52
+  const KtPair t_bonded = outer_begin(&st.ms_bonded);
   bonded_energies();
   if (ff.pqeq) efield_force();                         // pot.F90:61, before ForceBondedTerms
   { const bool kt = kt_begin(&st.ms_k_assemble); assemble_forces(); kt_end(kt); }
   accumulate_stress(false);                            // pot.F90:65-72, before the ghost forces are folded back
   { const bool kt = kt_begin(&st.ms_fold); fold_ghost_forces(); kt_end(kt); }
-  hipEventRecord(ev[5], stream);
+  outer_end(t_bonded);
   RX_HIP(hipMemcpyAsync(h_scal + 32, pe_d, sizeof(double) * 16, hipMemcpyDeviceToHost, stream));
+  outer_end(t_force);
+  force_pending = true;
+  if (!defer_host_read) finish_force();
+}
+// the host side of FORCE: wait, energies, NaN trap.  step() calls it once behind its last step: the steps in between queue the next
+// step's kernels behind FORCE without a host round trip (50-60 us of idle GPU per step until round 5)
+void Engine::finish_force() {
+  if (!force_pending) return;
+  force_pending = false;
   sync_stream();
   pe[0] = 0.0;
   for (int k = 1; k < 14; ++k) { pe[k] = h_scal[32 + k]; pe[0] += pe[k]; }   // PE(0)=sum(PE(1:13)), main.F90:236
   collect_timers();
-  float ms = 0;
-  hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_bo += ms;
-  hipEventElapsedTime(&ms, ev[3], ev[4]); st.ms_nonbond += ms;
-  hipEventElapsedTime(&ms, ev[4], ev[5]); st.ms_bonded += ms;
-  st.ms_force += toc(6, 7);
   if (!std::isfinite(pe[0])) throw EngineError(RXMD_E_NAN, "non-finite potential energy (degenerate geometry?)");
 }
 
@@ -395,11 +397,12 @@ void Engine::step(int nsteps) {
     { const bool kt = kt_begin(&st.ms_migrate); migrate(); kt_end(kt); }                                 // main.F90:75
     const int qs = cfg.qstep > 0 ? cfg.qstep : 1;
     if (step_count % qs == 0) qeq();                                     // main.F90:77-83
-    force();                                                             // main.F90:84
+    force(true);                                                         // main.F90:84 (energies read once, behind the last step)
     accumulate_stress(true);                                             // main.F90:86-94
     k_kick<<<nblk(N, 256), 256, 0, stream>>>(N, dff, dt, Lex_w2, type, vel[0], vel[1], vel[2], frc[0], frc[1], frc[2], q, qsfp, qsfv);
     ++step_count;
   }
+  finish_force();
   sync_stream();
 }
 

@@ -262,7 +262,9 @@ struct Engine {
   bool rows_split_pending_invalid() const { return n_bnd < 0 || n_bnd > N; }
   bool sums_from_list = false;     // the list sweep left H.(qs,qt) of the CG start vector in sall / sgh
   void qeq();
-  void force();
+  void force(bool defer_host_read = false);   // defer: the energies stay in the pinned buffer until finish_force() (step(): no host wait between FORCE and the next step)
+  void finish_force();
+  bool force_pending = false; int spec_pending = -1;   // spec_pending: the Est copy of a queued-ahead CG iteration that the last QEq call did not wait for
   void step(int nsteps);
   void migrate();                  // COPYATOMS(MODE_MOVE)
   void thermostat(int mdmode, double treq_K, double vsfact, double gke);   // velocity scaling of the MD loop head (assemble.hip)
@@ -375,6 +377,16 @@ struct Engine {
     kt_pending.push_back(kt_cur);
     kt_cur = KtPair{};
   }
+  // the same for a section that CONTAINS begin ... end pairs (a whole QEq call, a whole FORCE): its own pair from the pool, handed back explicitly
+  KtPair outer_begin(double *dst) {
+    KtPair p{};
+    if (kt_free.empty()) return p;
+    p = kt_free.back(); kt_free.pop_back();
+    p.dst = dst; p.dst2 = nullptr; p.cnt = nullptr;
+    hipEventRecord(p.a, stream);
+    return p;
+  }
+  void outer_end(KtPair p) { if (!p.a) return; hipEventRecord(p.b, stream); kt_pending.push_back(p); }
   void collect_timers();          // after a stream synchronisation
   void tic(int k) { hipEventRecord(ev[k], stream); }
   double toc(int k0, int k1) { hipEventRecord(ev[k1], stream); hipEventSynchronize(ev[k1]); float ms = 0; hipEventElapsedTime(&ms, ev[k0], ev[k1]); return ms; }

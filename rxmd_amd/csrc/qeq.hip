@@ -926,7 +926,9 @@ void Engine::tune_window_placement() {
 void Engine::qeq() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   if (cfg.isQEq != 1 && cfg.isQEq != 2) { nstep_qeq = 0; return; }   // qeq.F90:60-61
+  if (spec_pending >= 0) { sync_event(ev_spec[spec_pending]); spec_pending = -1; }   // the Est copy of the iteration the last call queued ahead and did not need (long done; it writes the pinned slot this call reads)
   tic(6);
+  const KtPair t_qeq = outer_begin(&st.ms_qeq);
   // the list sweep of this step can form the row sums of the start vector on the way (saves the matrix pass of qeq.F90:87)
 #ifdef RXMD_EXPERIMENTS
   static const bool prepass_on = (std::getenv("RXMD_QEQ_NO_PREPASS") == nullptr);
@@ -1013,8 +1015,16 @@ void Engine::qeq() {
   }
   k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-  sync_stream();
-  double GEst2 = 1e99, Est = h_scal[S_EST];
+#ifdef RXMD_EXPERIMENTS
+  const bool est_with_update_ = (std::getenv("RXMD_EST_SEPARATE") == nullptr);
+#else
+  constexpr bool est_with_update_ = true;
+#endif
+  // run-ahead loop (below): iteration 0 always happens -- the exit tests of qeq.F90:114-115 compare Est with GEst2 = 1e99 -- so the host does not
+  // wait for Est of the start vector; it reads it (for the trace) when the first iteration's Est arrives, which is later in stream order
+  const bool start_async = !multi() && cfg.qeq_mode == 1 && !ff.pqeq && est_with_update_ && std::getenv("RXMD_CG_NO_RUNAHEAD") == nullptr && nmax >= 1;
+  if (!start_async) sync_stream();
+  double GEst2 = 1e99, Est = start_async ? 0.0 : h_scal[S_EST];
   est_trace.clear(); est_trace.push_back(Est);      // Est of the start vector, then of every iteration (debug tap 13: the reference's QEQDUMP trace)
   int it = 0;
   float ms = 0;
@@ -1062,13 +1072,14 @@ void Engine::qeq() {
       if (k + 1 <= nmax - 1) { if (!scatter) sorted_copy(hst); xs_current = true; }
     };
     it = 0;
-    if (nmax >= 1 && !exit_test(GEst2, Est)) {
+    if (nmax >= 1 && (start_async || !exit_test(GEst2, Est))) {
       GEst2 = Est;
       enqueue(0);
       for (it = 1;; ++it) {
         const bool queued = it <= nmax - 1;
         if (queued) enqueue(it);                   // ahead of the decision
         sync_event(ev_spec[(it - 1) & 1]);         // iteration it - 1 has produced its Est and the decision about iteration it
+        if (it == 1 && start_async) est_trace[0] = h_scal[S_EST];      // (the start vector's Est: copied before anything of iteration 0 ran)
         collect_timers();
         const double *hs = h_scal + 64 + 64 * ((it - 1) & 1);
         Est = hs[S_EST];
@@ -1085,10 +1096,11 @@ void Engine::qeq() {
     if (ff.pqeq) pqeq_update_shells();
     nstep_qeq = it; last_est = Est;
     st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1; qeq_iters_smooth = qeq_iters_smooth < 0.0 ? it : 0.75 * qeq_iters_smooth + 0.25 * it;
-    sync_stream();                                 // the kernels of an iteration that did not happen are still in the queue: cheap, but they read scal
-    collect_timers();
-    st.ms_qeq += toc(6, 7);
-    if (!place_tuned && win_used && it >= 1) tune_window_placement();
+    // No host wait here (round 5): the kernels of the iteration that did not happen are still in the queue and FORCE queues behind them in stream
+    // order; its Est copy on the second stream is waited for at the head of the next call.  (Until round 5 a sync here cost ~50 us of idle GPU per step.)
+    if (it >= 1 && it <= nmax - 1) spec_pending = it & 1;
+    outer_end(t_qeq);
+    if (!place_tuned && win_used && it >= 1) { sync_stream(); collect_timers(); tune_window_placement(); }
     return;
   }
   for (it = 0; it <= nmax - 1; ++it) {
@@ -1182,8 +1194,8 @@ void Engine::qeq() {
   if (ff.pqeq) pqeq_update_shells();                  // pqeq.F90:169
   nstep_qeq = it; last_est = Est;
   st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1; qeq_iters_smooth = qeq_iters_smooth < 0.0 ? it : 0.75 * qeq_iters_smooth + 0.25 * it;
-  st.ms_qeq += toc(6, 7);
-  if (!place_tuned && win_used && it >= 1) { sync_stream(); tune_window_placement(); }
+  outer_end(t_qeq);
+  if (!place_tuned && win_used && it >= 1) { sync_stream(); collect_timers(); tune_window_placement(); }
 }
 
 }  // namespace rxmd
