@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 INP = os.path.join(ROOT, "tests", "golden", "inputs")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0  # aggregate L2 -> L1 rate of the 8 XCDs, same guide
+ATOMIC_REQ_PER_S = 20e9  # scattered float atomics at the memory side: 0.08 TB/s of 4-byte adds, one 64-byte request each (same guide)
 SIMDS, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs, peak engine clock: a wave64 vector instruction occupies its SIMD for 4 cycles
 ATOMS_PER_GPU_CELLS = 18
 
@@ -506,7 +507,7 @@ def main():
         # PMC numbers are NOT measured in this run: they come from profiles/kernel_traffic.json (scripts/gpu_pmc_kernels.sh: one rocprofv3 --pmc pass per
         # counter set over a bench step), which records the commit and the kernels' full template signatures it was taken at.  A kernel whose
         # signature is not in the file gets null, never another instance's bytes.
-        ktraffic, kvalu, kl2, ksource = {}, {}, {}, None
+        ktraffic, kvalu, kl2, katom, ksource = {}, {}, {}, {}, None
         kfile = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(kfile):
             try:
@@ -515,6 +516,7 @@ def main():
                     ktraffic = kj.get("hbm_bytes_per_launch", {})
                     kvalu = {k: v.get("SQ_INSTS_VALU") for k, v in kj.get("kernels", {}).items() if v.get("SQ_INSTS_VALU") is not None}
                     kl2 = {k: v.get("l1_to_l2_read_bytes_at_128B") for k, v in kj.get("kernels", {}).items() if v.get("l1_to_l2_read_bytes_at_128B") is not None}
+                    katom = {k: v.get("atomic_requests") for k, v in kj.get("kernels", {}).items() if v.get("atomic_requests")}
                     ksource = {"file": "profiles/kernel_traffic.json", "measured_at_commit": kj.get("commit"), "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), gfx950 correction FETCH_SIZE x 2; SQ_INSTS_VALU for the issue floor"}
             except Exception:
                 pass
@@ -541,15 +543,21 @@ def main():
             """L1 <- L2 read bytes per launch: TCP_TCC_READ_REQ x 128 B (one request = one 128-byte line), summed over the named kernels; None if absent"""
             hit = [v for k, v in kl2.items() if any(k == p_ or k.startswith(p_ + "<") for p_ in parts)]
             return sum(hit) if hit else None
-        def bound_of(ms, hbm_bytes, l2_bytes, valu_ms):
-            """the ceiling that binds a kernel: the largest of (HBM bytes / 8 TB/s, L1<-L2 bytes / 34.5 TB/s, vector issue floor) over its time; below 0.35 of
-            every one of them the kernel waits on dependent round trips: `latency`, quoted with its best fraction"""
+        def atomics_for(*parts):
+            """memory-side atomic requests per launch (TCP_TCC_ATOMIC_WITHOUT_RET_REQ), summed over the named kernels; None if absent"""
+            hit = [v for k, v in katom.items() if any(k == p_ or k.startswith(p_ + "<") for p_ in parts)]
+            return sum(hit) if hit else None
+        def bound_of(ms, hbm_bytes, l2_bytes, valu_ms, atomic_req=None):
+            """the ceiling that binds a kernel: the largest of (HBM bytes / 8 TB/s, L1<-L2 bytes / 34.5 TB/s, vector issue floor, memory-side atomic
+            requests / 20 G per s -- the rate of scattered float atomics in MI355X_MICROARCH.md: 0.08 TB/s of 4-byte adds, one request each) over its
+            time; below 0.35 of every one of them the kernel waits on dependent round trips: `latency`, quoted with its best fraction"""
             if not ms or ms <= 0:
                 return None, None, {}
             fr = {}
             if hbm_bytes: fr["hbm"] = hbm_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             if l2_bytes: fr["l2"] = l2_bytes / (ms * 1e-3) / 1e9 / L2_PEAK_GBS
             if valu_ms: fr["valu"] = valu_ms / ms
+            if atomic_req: fr["atomics"] = atomic_req / ATOMIC_REQ_PER_S / (ms * 1e-3)
             if not fr:
                 return None, None, fr
             b = max(fr, key=fr.get)
@@ -560,7 +568,7 @@ def main():
             ach_k = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             tr_k = traffic_for(*name.split("+"))
             vf_k = valu_floor_ms(*name.split("+"))
-            bnd, fb, fr_all = bound_of(ms, tr_k, l2_bytes_for(*name.split("+")), vf_k)
+            bnd, fb, fr_all = bound_of(ms, tr_k, l2_bytes_for(*name.split("+")), vf_k, atomics_for(*name.split("+")))
             kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": tr_k,
                             "frac_real_traffic": (tr_k / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr_k and ms > 0) else None, "valu_floor_ms": vf_k,
                             "bound": bnd, "frac_of_bound": fb, "frac_of_each_ceiling": fr_all, "note": note})

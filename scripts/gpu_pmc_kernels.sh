@@ -6,7 +6,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O; shift
 ARGS="--steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-other-configs --no-steady $@"
-for ctr in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum "TCC_HIT_sum TCC_MISS_sum" SQ_INSTS_VALU; do   # (each pass under its own time limit)
+for ctr in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum "TCC_HIT_sum TCC_MISS_sum" SQ_INSTS_VALU TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum; do   # (each pass under its own time limit)
   tag=$(echo $ctr | tr ' ' '_')
   RXMD_PLACE_TRIES=1 timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$tag -- python3 bench.py $ARGS > $O/pmc_$tag.log 2>&1
 done
@@ -33,6 +33,7 @@ for name, c in sorted(out.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0) * 
         rec["hbm_bytes"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         res["hbm_bytes_per_launch"][name] = rec["hbm_bytes"]
     if "TCP_TCC_READ_REQ_sum" in c: rec["l1_to_l2_read_bytes_at_128B"] = c["TCP_TCC_READ_REQ_sum"] * 128.0
+    if c.get("TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum", 0) > 0: rec["atomic_requests"] = c["TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum"]
     res["kernels"][name] = rec
 json.dump(res, open("$O/kernel_traffic.json", "w"), indent=1)
 for name, rec in list(res["kernels"].items())[:24]:
