@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Where the torsion kernel's time goes (experiments build: RXMD_E4B_PROBE 1 = set-up only, 2 = set-up + enumeration, 0 = all), RDX 979,776 atoms.
+usage: RXMD_HIP_LIB=rxmd_amd/librxmd_hip_exp.so python3 scripts/gpu_e4b_phases.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import rxmd_amd
+from rxmd_amd import system
+INP = os.path.join(ROOT, "tests", "golden", "inputs")
+names, frac, lat = system.read_xyz(os.path.join(INP, "rdx.xyz"))
+ff = os.path.join(INP, "ffield_rdx")
+lat_s, rec = system.geninit(ff, names, frac, lat, mc=(18, 18, 18))
+for probe in ("0", "1", "2", "0"):
+    os.environ["RXMD_E4B_PROBE"] = probe
+    e = rxmd_amd.RxmdEngine(ff, lat_s, QEq_tol=1e-7, NMAXQEq=500, device=0, qeq_mode=1)
+    e.set_atoms_rxff(rec); e.QEq(); e.FORCE(); e.reset_timers()
+    for _ in range(5): e.FORCE()
+    st = e.stats()
+    print("probe %s: k_e4b %.3f ms  k_e3b %.3f  k_ehb %.3f" % (probe, st["ms_k_e4b"] / 5, st["ms_k_e3b"] / 5, st["ms_k_ehb"] / 5), flush=True)
+    e.close()
