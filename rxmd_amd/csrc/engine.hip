@@ -915,7 +915,7 @@ void Engine::ensure_seg_buffers(int nbk) {
   if (nbk <= seg_blocks_cap) return;
   dfree(seg_cnt); dfree(seg_tot); dfree(seg_code_);
   seg_blocks_cap = nbk + nbk / 4 + 16;
-  dmalloc(seg_cnt, static_cast<size_t>(27) * seg_blocks_cap); dzalloc(seg_tot, 32); dmalloc(seg_code_, static_cast<size_t>(NB));
+  dmalloc(seg_cnt, static_cast<size_t>(27) * seg_blocks_cap); dzalloc(seg_tot, 32); dmalloc(seg_code_, static_cast<size_t>(seg_blocks_cap) * 256);   // (one face code per RESIDENT: sized with the workgroup count, not with the NB of the day)
   if (!h_seg) RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_seg), 32 * sizeof(int)));
 }
 
