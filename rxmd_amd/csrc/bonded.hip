@@ -84,14 +84,16 @@ __global__ void __launch_bounds__(256) k_ebond_terms(int nb_res, DevFF ff, const
       const double bs = B0 - cutof2_esub, u = -bs + (dj + ff.atom[tj].Val);
       ecoa[o] = exp(-ff.pcoa3 * (u * u)) * exp(-ff.pcoa4 * ((bs - 1.5) * (bs - 1.5)));
     }
+    double c1 = 0.0, c2 = 0.0, c3 = 0.0;
     if (gid[j] < gid[i]) {                                              // Ebond, pot.F90:949
       const double B1 = bo1[o];
       const double pw = pow(B1, bp.pbe2);
       const double ex = exp(bp.pbe1 * (1.0 - pw));
       e1 = -bp.Desig * B1 * ex - bp.Depi * bo2[o] - bp.Depipi * bo3[o];
       const double CEbo = -bp.Desig * ex * (1.0 - bp.pbe1 * bp.pbe2 * pw);
-      cf1[o] += CEbo; cf2[o] += (-bp.Depi - CEbo); cf3[o] += (-bp.Depipi - CEbo);   // coeff = (CEbo,-Depi,-Depipi)
+      c1 = CEbo; c2 = -bp.Depi - CEbo; c3 = -bp.Depipi - CEbo;         // coeff = (CEbo,-Depi,-Depipi)
     }
+    cf1[o] = c1; cf2[o] = c2; cf3[o] = c3;                              // the first writer of these accumulators SETS them (k_bo_full clears only the ghosts' bonds): 0 + x == x, bit for bit
   }
   block_energy_add(e1, pe + 1);
 }
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(256) k_elnpr_bonds(int nb_res, DevFF ff, const
   const double CElp_b = CElp1 + CEo3 + CEo5 + CEu3;
   const double CElp_bpp = CEo4 * dj + CEu4 * dj;
   cf1[o] += CElp_b; cf2[o] += CElp_bpp; cf3[o] += CElp_bpp;           // coeff = CElp_b + (0,bpp,bpp)
-  cdn[o] += CEo4 * oneD * bpp + CEu4 * oneD * bpp;                     // cdbnd(j) += CElp_d
+  cdn[o] = CEo4 * oneD * bpp + CEu4 * oneD * bpp;                      // cdbnd(j) += CElp_d (first writer: sets)
 }
 
 // ------------------------------------------------------------------------------------------------

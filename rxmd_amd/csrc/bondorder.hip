@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) k_deltap(int G, DevFF ff, const int *__re
   deltap[i] = sum;
 }
 
-__global__ void __launch_bounds__(256) k_bo_full(int nbonds, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ type,
+__global__ void __launch_bounds__(256) k_bo_full(int nbonds, int nb_res, DevFF ff, const int *__restrict__ bown, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ type,
                                                   const double *__restrict__ deltap, double *__restrict__ bo0, double *__restrict__ bo1, double *__restrict__ bo2, double *__restrict__ bo3,
                                                   double *__restrict__ A0, double *__restrict__ A1, double *__restrict__ A2, double *__restrict__ A3,
                                                   double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
@@ -102,12 +102,14 @@ __global__ void __launch_bounds__(256) k_bo_full(int nbonds, DevFF ff, const int
   A1[o] = -2.0 * pboc34 * BOp0 * (Cf45i + Cf45j) * fn45_inv;
   A2[o] = a2v;
   A3[o] = a2v + Cf1i_div1;
-  cf1[o] = 0.0; cf2[o] = 0.0; cf3[o] = 0.0; cdn[o] = 0.0; fnx[o] = 0.0; fny[o] = 0.0; fnz[o] = 0.0;
+  // accumulators of pot.F90:20-26: cleared here -- except cf1..3 and cdn of the residents' bonds, which their first writers SET (k_ebond_terms, k_elnpr_bonds)
+  if (o >= nb_res) { cf1[o] = 0.0; cf2[o] = 0.0; cf3[o] = 0.0; cdn[o] = 0.0; }
+  fnx[o] = 0.0; fny[o] = 0.0; fnz[o] = 0.0;
   // exponentials of this bond that every angle / torsion through it re-uses (global parameters only):
   const double bs = B0 - 1e-4;                                   // BO - cutof2_esub, pot.F90:372,1022
-  etor[o] = exp(-ff.ptor2 * bs);                                 // exp_tor2, pot.F90:1086-1088
-  econ[o] = exp(-ff.pcot2 * ((bs - 1.5) * (bs - 1.5)));          // factor of fn12, pot.F90:1097-1099
-  epen[o] = exp(-ff.ppen2 * ((bs - 2.0) * (bs - 2.0)));          // exp_pen2, pot.F90:463-464
+  etor[o] = exp(-ff.ptor2 * bs);                           // exp_tor2, pot.F90:1086-1088
+  econ[o] = exp(-ff.pcot2 * ((bs - 1.5) * (bs - 1.5)));    // factor of fn12, pot.F90:1097-1099
+  epen[o] = exp(-ff.ppen2 * ((bs - 2.0) * (bs - 2.0)));    // exp_pen2, pot.F90:463-464
 }
 
 // Delta(i) (bo.F90:294) in slot order, and the lone-pair preparation (pot.F90:183-209); clears what FORCE clears per call (pot.F90:20-26)
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(256) k_delta_lp(int G, DevFF ff, const int *__
 void Engine::bond_orders() {
   k_bo_prime<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, dff, bown, nbr, btype, pos[0], pos[1], pos[2], type, bo0, bo2, bo3, dln2, dln3, dBOp);
   k_deltap<<<nblk(G, 256), 256, 0, stream>>>(G, dff, boff, type, bo0, deltap);
-  k_bo_full<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, dff, bown, nbr, btype, type, deltap, bo0, bo1, bo2, bo3, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen);
+  k_bo_full<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, nbonds_res, dff, bown, nbr, btype, type, deltap, bo0, bo1, bo2, bo3, A0, A1, A2, A3, cf1, cf2, cf3, cdn, fnx, fny, fnz, etor, econ, epen);
   k_delta_lp<<<nblk(G, 256), 256, 0, stream>>>(G, dff, boff, type, bo0, delta, nlp, dDlp, deltalp, cds, frc[0], frc[1], frc[2]);
 }
 
