@@ -3,7 +3,7 @@
 //   E3b   (pot.F90:319-557)                           -> k_e3b   (thread per centre atom)
 //   E4b   (pot.F90:980-1227)                          -> k_e4b   (wavefront per eight / four / two centre atoms, ballot-compacted work queue;
 //                                                                  every torsion visited from both ends)
-//   Ehb   (pot.F90:559-673)                           -> k_ehb   (a wavefront finds the donors among 64 atoms, then sweeps their rows)
+//   Ehb   (pot.F90:559-673)                           -> k_ehb_donors + k_ehb_sweep (donor list; a wavefront takes whole donors, acceptors staged in LDS)
 // The reference scatters every derivative at once with atomics (ForceB/ForceBbo/ForceA3/ForceA4,
 // pot.F90:1276-1521).  Here a thread owns one centre atom and accumulates ONLY into that atom's own
 // stretch of the compact bond tables (bond o = boff[centre] + slot, engine.h):
@@ -742,147 +742,6 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Hydrogen bonds.  The lanes of a wavefront sweep the 10 A row of a donor atom i for acceptors k.
-// Hydrogen is atom type 2, hard-coded in the reference (pot.F90:595) and kept.
-__global__ void __launch_bounds__(256) k_ehb(int N, int S10, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const int *__restrict__ nbrcnt, const int *__restrict__ type,
-                                              const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                                              const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10,
-                                              const double4 *__restrict__ pk, const int *__restrict__ perm,
-                                              double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                              double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, int probe) {
-  constexpr int EHB_CHUNK = 640;                          // row entries compacted at a time (a row of the default stride in one go)
-  // atoms per wavefront: the lanes beyond it idle in the (cheap) search for donors, but the sweeps of the donors found spread over
-  // more wavefronts -- 1.37 / 1.21 / 1.14 / 1.13 / 1.26 ms at 64 / 32 / 16 / 8 / 4 atoms
-  constexpr int EHB_APW = 16;
-  __shared__ unsigned s_cand[4][EHB_CHUNK];
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  // A wavefront takes EHB_APW consecutive atoms.  First every lane decides for its own atom whether it is a donor with a hydrogen partner
-  // (in RDX one atom in fourteen is) and leaves a bit mask of those slots; then the wavefront sweeps the
-  // 10 A rows of the atoms that have one, one after the other.  (One wavefront per atom spent most of the kernel starting a million
-  // wavefronts that found nothing: 1.5 ms, of which the sweeps themselves were about a third.)
-#ifdef RXMD_EXPERIMENTS
-  const int apw = (probe >> 8) ? (probe >> 8) : EHB_APW; // atoms per wavefront (probe bits 8..: experiment)
-#else
-  constexpr int apw = EHB_APW;
-#endif
-  const int a0 = (xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w) * apw;
-  double e10 = 0.0;
-  unsigned hslots = 0u;
-  int ti_l = 0;
-  if (lane < apw && a0 + lane < N) {
-    const int ia = a0 + lane;
-    ti_l = type[ia];
-    bool donor_l = false;                                // does any (ti, 2, k) hydrogen-bond row exist?
-    if (ff.nso >= 2)
-      for (int t = 1; t <= ff.nso; ++t) donor_l |= (ff.inxn3hb[(ti_l * ff.n1 + 2) * ff.n1 + t] != 0);
-    if (donor_l) {
-      const int cnt_l = min(nbrcnt[ia], 32), ob_l = boff[ia];
-      for (int sl = 0; sl < cnt_l; ++sl) {
-        const int ol = ob_l + sl;
-        if (type[nbr[ol]] == 2 && bo0[ol] > MINBO0) hslots |= 1u << sl;      // pot.F90:595
-      }
-    }
-  }
-  for (unsigned long long todo = __ballot(hslots != 0u); todo; todo &= todo - 1) {
-    const int src = __ffsll(static_cast<long long>(todo)) - 1;
-    const int i = a0 + src;                                // wave-uniform
-    const int ti = __shfl(ti_l, src, 64);
-    unsigned long long hmask = static_cast<unsigned long long>(__shfl(static_cast<int>(hslots), src, 64)) & 0xffffffffULL;
-    {
-      const double xi = x[i], yi = y[i], zi = z[i];
-      const int n = n10[i] & N10_COUNT;
-      const size_t row = static_cast<size_t>(i) * S10;
-      const int inx_l = (lane >= 1 && lane <= ff.nso) ? ff.inxn3hb[(ti * ff.n1 + 2) * ff.n1 + lane] : 0;
-      int jl = 0; double bl = 0.0;                       // lane s holds atom and bond order of slot s
-      if (lane < 32 && ((hmask >> lane) & 1ULL)) {
-        const int ol = boff[i] + lane;
-        jl = nbr[ol]; bl = bo0[ol];
-      }
-      // The acceptor candidates of the row depend on the types only, not on the hydrogen: they are compacted once into LDS (the 64
-      // entry words of every batch requested together, one round trip for the whole row), and every hydrogen slot then walks dense
-      // batches whose loads -- atom, position, parameter row -- are independent of each other.  Walking the row itself cost four
-      // dependent round trips per 64 entries, half of them without a parameter row (1.87 -> 1.48 ms).
-      for (int c0 = 0; hmask != 0ULL && c0 < n; c0 += EHB_CHUNK) {
-        const int cend = min(n, c0 + EHB_CHUNK);
-        unsigned ent[EHB_CHUNK / 64];
-#pragma unroll
-        for (int u = 0; u < EHB_CHUNK / 64; ++u) { const int kk = c0 + 64 * u + lane; ent[u] = kk < cend ? static_cast<unsigned>(nb10[row + kk]) : 0xffffffffu; }
-        int qn = 0;
-#pragma unroll
-        for (int u = 0; u < EHB_CHUNK / 64; ++u) {
-          if (c0 + 64 * u >= cend) break;                                    // wave-uniform
-          const bool valid = ent[u] != 0xffffffffu;
-          const int inx = __shfl(inx_l, static_cast<int>((ent[u] >> NB10_IDX_BITS) & 15u), 64);   // (ti, H, type k) row, held by lane = type k
-          const bool keep = valid && inx != 0;
-          const unsigned long long m = __ballot(keep);
-          if (keep) s_cand[w][qn + __popcll(m & ((1ULL << lane) - 1ULL))] = ent[u];
-          qn += __popcll(m);
-        }
-        wave_lds_sync();
-        for (unsigned long long hm = hmask; hm; hm &= hm - 1) {
-          const int s = __ffsll(static_cast<long long>(hm)) - 1;
-          const int o = boff[i] + s;
-          const int j = __shfl(jl, s, 64);
-          const double BOij = __shfl(bl, s, 64);
-          const double xj = x[j], yj = y[j], zj = z[j];
-          const V3 rij = {xi - xj, yi - yj, zi - zj};
-          const double nij = sqrt(dot(rij, rij));
-          double cfs = 0.0, nterm = 0.0;
-          V3 fi_s = {0, 0, 0}, fj_s = {0, 0, 0};
-          for (int q0 = 0; q0 < qn; q0 += 64) {                              // wave-uniform trip count: the shuffle below needs every lane
-            const int qq = q0 + lane;
-            const unsigned e = qq < qn ? s_cand[w][qq] : 0u;
-            const int inx = __shfl(inx_l, static_cast<int>((e >> NB10_IDX_BITS) & 15u), 64);
-            if (qq >= qn) continue;
-            const int ks = static_cast<int>(e & NB10_IDX_MASK);
-            const int k = perm[ks];                                          // list entries are cell-sorted positions
-            const double4 pk_ = pk[ks];
-            const DevHbP hp = ff.hb[inx];
-            if (k == j || k == i) continue;
-            const V3 rik = {xi - pk_.x, yi - pk_.y, zi - pk_.z};
-            if (!(dot(rik, rik) < 100.0)) continue;                          // rchb2, pot.F90:610
-            const V3 rjk = {xj - pk_.x, yj - pk_.y, zj - pk_.z};
-            const double njk = sqrt(dot(rjk, rjk));
-            double cos_ijk = -dot(rij, rjk) / (nij * njk);
-            if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
-            if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
-            const double sh2 = 0.5 * (1.0 - cos_ijk);                        // sin^2(theta/2)
-            const double sin_xhz4 = sh2 * sh2, cos_xhz1 = 1.0 - cos_ijk;
-            const double exp_hb2 = exp(-hp.phb2 * BOij);
-            const double exp_hb3 = exp(-hp.phb3 * (hp.r0hb / njk + njk / hp.r0hb - 2.0));
-            const double PEhb = hp.phb1 * (1.0 - exp_hb2) * exp_hb3 * sin_xhz4;
-            e10 += PEhb; nterm += 1.0;
-            cfs += hp.phb1 * hp.phb2 * exp_hb2 * exp_hb3 * sin_xhz4;         // CEhb(1) -> ForceB(i,j)
-            const double CEhb2 = -0.5 * hp.phb1 * (1.0 - exp_hb2) * exp_hb3 * cos_xhz1;
-            const double CEhb3 = -PEhb * hp.phb3 * (-hp.r0hb / (njk * njk) + 1.0 / hp.r0hb) * (1.0 / njk);
-            V3 fi, fk;
-            angle_forces(CEhb2, rij, nij, rjk, njk, fi, fk);
-            const V3 ff3 = {CEhb3 * rjk.x, CEhb3 * rjk.y, CEhb3 * rjk.z};   // f(j) -= ff ; f(k) += ff
-            fi_s.x += fi.x; fi_s.y += fi.y; fi_s.z += fi.z;
-            fj_s.x += -(fi.x + fk.x) - ff3.x; fj_s.y += -(fi.y + fk.y) - ff3.y; fj_s.z += -(fi.z + fk.z) - ff3.z;
-#ifdef RXMD_EXPERIMENTS
-            if ((probe & 255) == 1) continue;                                // (timing probe: the kernel without its acceptor atomics)
-#endif
-            atomicAdd(fx + k, fk.x + ff3.x); atomicAdd(fy + k, fk.y + ff3.y); atomicAdd(fz + k, fk.z + ff3.z);
-          }
-          cfs = wave_sum_b(cfs); nterm = wave_sum_b(nterm);
-          fi_s.x = wave_sum_b(fi_s.x); fi_s.y = wave_sum_b(fi_s.y); fi_s.z = wave_sum_b(fi_s.z);
-          fj_s.x = wave_sum_b(fj_s.x); fj_s.y = wave_sum_b(fj_s.y); fj_s.z = wave_sum_b(fj_s.z);
-          if (lane == 0 && nterm > 0.0) {
-            cf1[o] += cfs;
-            fnx[o] += fj_s.x; fny[o] += fj_s.y; fnz[o] += fj_s.z;
-            atomicAdd(fx + i, fi_s.x); atomicAdd(fy + i, fi_s.y); atomicAdd(fz + i, fi_s.z);
-          }
-        }
-        wave_lds_sync();
-      }
-    }
-  }
-  block_energy_add(e10, pe + 10);
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // Hydrogen bonds, round 5: two kernels instead of one search-and-sweep.  The counters of the one-kernel form (profiles/r05_a_sq_*): 61,240
 // wavefronts that each live ~60 us, 87 % of it parked on s_waitcnt behind ~66 dependent loads (the donor search walks type[nbr[o]] and
 // bo0[o] slot by slot; then position, row, hydrogen, candidates one round trip after the other), the vector unit busy 6 % of the time, and
@@ -1105,9 +964,6 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
                                                  cds, frc[0], frc[1], frc[2], pe_d, bx);
   kt_end(kt4);
   const bool kth = kt_begin(&st.ms_k_ehb);
-#ifdef RXMD_EHB_ROWSWEEP
-  k_ehb<<<nblk(N, 4 * 16), 256, 0, stream>>>(N, S10, dff, boff, nbr, nbrcnt, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, 0);
-#else
   if (ehb_donor_types != 0u) {                    // (a force field without a hydrogen-bond row for hydrogen = type 2 has no donors: water, pot.F90:595)
     const int region_cap = (nblk(N, 256) + EHB_REGIONS - 1) / EHB_REGIONS * 256;            // every atom of the workgroups of a region a donor: cannot overflow
     if (static_cast<size_t>(region_cap) * EHB_REGIONS > ehb_don_cap) throw EngineError(RXMD_E_STATE, "hydrogen-bond donor list: capacity");
@@ -1129,7 +985,6 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
     k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, region_cap, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
 #endif
   }
-#endif
   kt_end(kth);
 }
 

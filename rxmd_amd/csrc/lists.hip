@@ -79,86 +79,6 @@ __device__ inline void column_run(const Grid &g, const int *__restrict__ cellsta
   len = cellstart[cbf + hi + 1] - k0;
 }
 
-#ifdef RXMD_BLIST_ROUND4
-// ORTHO = false: the instance for skewed boxes carries the reference's cell-mesh tests (RefMesh); the orthogonal one does not pay for them
-template <bool ORTHO>
-__global__ void __launch_bounds__(256) k_bonded_list(int G, int NB, int MAXNB, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
-                                                      const double4 *__restrict__ sorted, const double *__restrict__ x, const double *__restrict__ y,
-                                                      const double *__restrict__ z, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
-                                                      const int *__restrict__ type, int *__restrict__ nbr, int *__restrict__ nbrcnt, int *err) {   // nbr: the slot-major staging array (nbr_sm)
-  // squared bond cut-off of every type pair in LDS (0 = the pair has no bond row): one LDS read per candidate instead of two
-  // dependent global look-ups (inxn2, then bond[inxn].rc2); and per type the largest cut-off it has with any partner
-  __shared__ double s_rc2[256], s_rmax[16];
-  for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) { const int ix = ff.inxn2[t]; s_rc2[t] = ix ? ff.bond[ix].rc2 : 0.0; }
-  __syncthreads();
-  if (threadIdx.x < ff.n1 && threadIdx.x < 16) {
-    double m = 0.0;
-    for (int t = 0; t < ff.n1; ++t) m = fmax(m, s_rc2[threadIdx.x * ff.n1 + t]);
-    s_rmax[threadIdx.x] = sqrt(m) + SWEEP_PAD;
-  }
-  __syncthreads();
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (i >= G) return;
-  const int c = cellid[i];
-  const int cy = (c / g.nzf) % g.n[1], cx = c / (g.nzf * g.n[1]);
-  const double xi = x[i], yi = y[i], zi = z[i];
-  const double sxi = sx[i], syi = sy[i], szi = sz[i];
-  const int ti = type[i];
-  const double *rc2row = s_rc2 + ti * ff.n1;
-  const double rcp = s_rmax[ti];
-  double si[3] = {0.0, 0.0, 0.0};
-  if (!ORTHO) ref_norm(rm, xi, yi, zi, si);
-  int cnt = 0;
-  for (int dx = -1; dx <= 1; ++dx) {
-    for (int dy = -1; dy <= 1; ++dy) {
-      int k0, len;
-      column_run<ORTHO>(g, cellstart, sxi, syi, szi, cx, cy, cx + dx, cy + dy, rcp, k0, len);
-      for (int k = k0; k < k0 + len; ++k) {
-        const double4 p = sorted[k];
-        const long long w = __double_as_longlong(p.w);
-        const int j = static_cast<int>(w & 0xffffffffLL);
-        if (j == i) continue;
-        const int tj = static_cast<int>(w >> 32);
-        const double d0 = p.x - xi, d1 = p.y - yi, d2 = p.z - zi;
-        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-        bool in = r2 < rc2row[tj];              // dr2 < rc2(inxn), main.F90:366 (no bond row: cut-off 0)
-        if (!ORTHO && in) { double sj[3]; ref_norm(rm, p.x, p.y, p.z, sj); in = ref_bonded_cells_adjacent(rm, si, sj); }
-        if (in) {
-          if (cnt < MAXNB) nbr[static_cast<size_t>(cnt) * NB + i] = j;
-          ++cnt;
-        }
-      }
-    }
-  }
-  if (cnt > MAXNB) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXNB); cnt = MAXNB; }  // main.F90:402-407
-  nbrcnt[i] = cnt;
-  // err[2] = the longest list of this build if any is longer than 15 (the torsion kernel packs four atoms into a wavefront otherwise)
-  if (cnt > 15 && __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[2], cnt);
-}
-
-// The sweep above leaves the lists in a slot-major staging array (slot s of atom i at s * NB + i: a thread appends without knowing the
-// totals).  This pass packs them: bond o = boff[i] + s (boff = exclusive prefix of the counts) carries its partner nbr[o], its owner bown[o] = i
-// and its MIRROR brev[o] = boff[j] + j1 with nbrlist(j, j1) == i -- the reference's nbrindx (main.F90:383-399) as a direct index into the
-// compact tables.  Every per-bond array of the engine is indexed by o: 5.3 entries per RDX atom instead of a 30-slot stride.
-__global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict__ nbr_sm, const int *__restrict__ nbrcnt, const int *__restrict__ boff,
-                           int *__restrict__ nbr, int *__restrict__ brev, int *__restrict__ bown, const int *__restrict__ type, unsigned char *__restrict__ btype, int *err) {
-  // one thread per (atom, slot): blockIdx.y = slot; the blocks of slots no atom of theirs uses leave after one coalesced read of the counts
-  const int i = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x, s = blockIdx.y;
-  if (i >= G) return;
-  const int ni = nbrcnt[i];
-  if (s >= ni) return;
-  const int ob = boff[i];
-  if (static_cast<long long>(ob) + ni > bcap) return;             // the tables are too small for this build: the host sees boff[G] and grows them
-  const int j = nbr_sm[static_cast<size_t>(s) * NB + i];
-  const int nj = nbrcnt[j];
-  int found = -1;
-  for (int t = 0; t < nj; ++t)
-    if (nbr_sm[static_cast<size_t>(t) * NB + j] == i) found = t;
-  if (found < 0) { atomicCAS(&err[0], DERR_NONE, DERR_NBRINDX); found = 0; }
-  nbr[ob + s] = j; brev[ob + s] = boff[j] + found; bown[ob + s] = i; btype[ob + s] = static_cast<unsigned char>(type[j]);   // the partner's type rides with the bond: one dependent gather less where a kernel walks another atom's list
-}
-
-#else
 // Round 5.  Counters of the round-4 form (profiles/r05_a_sq_*): 81 % of the wave cycles parked -- every thread walked its ~135 candidates one
 // dependent 32-byte gather after the other -- and the slot-major staging made the mirror search of the packing pass touch one cache line per slot of
 // the partner (0.34 ms).  Now four candidates are in flight per thread (tested together, appended in order: same lists), and the lists are staged
@@ -259,7 +179,6 @@ __global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict_
   if (found < 0) { atomicCAS(&err[0], DERR_NONE, DERR_NBRINDX); found = 0; }
   nbr[ob + s] = j; brev[ob + s] = boff[j] + found; bown[ob + s] = i; btype[ob + s] = static_cast<unsigned char>(type[j]);   // the partner's type rides with the bond: one dependent gather less where a kernel walks another atom's list
 }
-#endif
 
 // get_coulomb_and_dcoulomb_pqeq (reference src/module.F90:401-418): energy kernel and (1/r) dE/dr at squared distance r2.
 // Beyond the taper cutoff the reference returns without touching its outputs (callers then see the previous pair's
@@ -338,235 +257,6 @@ __global__ void __launch_bounds__(32 * WIN_ROWS) k_win_columns(int N, Grid g, co
     for (int u = 0; u < nu; ++u) win_k[static_cast<size_t>(grp) * WIN_MAXUNITS + ub + u] = lo8 + WIN_UNIT * u;
 }
 
-#ifdef RXMD_LIST10_ROUND4
-template <bool SELFCHECK, bool PQ, bool ORTHO>
-__global__ void __launch_bounds__(256) k_list10(int N, int S10, Grid g, RefMesh rm, DevFF ff, const int *__restrict__ cellid, const int *__restrict__ cellstart,
-                                                 const double4 *__restrict__ sorted,
-                                                 const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                                                 const double *__restrict__ spx, const double *__restrict__ spy, const double *__restrict__ spz,
-                                                 const int *__restrict__ type, const long long *__restrict__ gid,
-                                                 int *__restrict__ nb10, double *__restrict__ hess, int *__restrict__ n10, int *err,
-                                                 const double4 *__restrict__ sorted_shl, const double *__restrict__ shx, const double *__restrict__ shy, const double *__restrict__ shz,
-                                                 double *__restrict__ hsc, double4 *__restrict__ pqrow,
-                                                 const double2 *__restrict__ xs0, double2 *__restrict__ s_all, double2 *__restrict__ s_gh, int *__restrict__ rowflag,
-                                                 const int *__restrict__ rows_sorted, unsigned short *__restrict__ sl10, const int *__restrict__ rowcols, const int *__restrict__ grp_base, int *__restrict__ gflag) {
-  __shared__ int s_q[4][128];            // accepted candidates: sorted position ...
-  __shared__ double s_r2[4][128];        // ... their squared distance (the exact FP64 value of the test) ...
-  __shared__ long long s_w[4][128];      // ... and (column of the row << 40 | type << 32 | atom index): the dense phase needs no second gather of the candidate
-  __shared__ int s_K[4][32], s_E[4][32];  // per stencil column of a row: first sorted position of its run - candidates before it / slot base of the column in the group's window
-  __shared__ int s_ix2[256];             // inxn2 row of the row's type would do; the whole (n1 x n1) table is 64-256 words
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> the row's constants live in scalar registers
-  for (int t = threadIdx.x; t < ff.n1 * ff.n1 && t < 256; t += blockDim.x) s_ix2[t] = ff.inxn2[t];
-  __syncthreads();
-  // rows in the order of the window groups (cell-sorted: the four rows of a workgroup test nearly the same candidates); the launch covers the
-  // host's bound of the group count, err[8] = the groups of this build
-  const int ridx = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + w;
-  if (ridx >= err[8] * WIN_ROWS) return;
-  const int i = rows_sorted[ridx];
-  if (i >= N) return;                         // unused row of a cell column's last group
-  const int grp = ridx / WIN_ROWS;
-  constexpr bool live = true;
-  int *sq = s_q[w];
-  double *sr2 = s_r2[w];
-  long long *sw = s_w[w];
-  int *cK = s_K[w], *cE = s_E[w];
-  const double xi = x[i], yi = y[i], zi = z[i];
-  const int ti = type[i];
-  const size_t row = static_cast<size_t>(i) * S10;
-  double sni[3] = {0.0, 0.0, 0.0};
-  if (!ORTHO) ref_norm(rm, xi, yi, zi, sni);
-  double sxi = 0.0, syi = 0.0, szi = 0.0, Zi = 0.0, p_f = 0.0, p_hz = 0.0, p_bz = 0.0, p_ss = 0.0;
-  if (PQ) { sxi = shx[i]; syi = shy[i]; szi = shz[i]; Zi = ff.Zpq[ti]; }
-  // xs0 != nullptr: the sweep also forms the row sums H.(qs,qt) of the CG start vector (qt = 0) -- the matrix pass that
-  // get_gradient would need before the first iteration (qeq.F90:87) comes for free while the entries are in registers
-  double ra = 0.0, rg = 0.0;
-  bool anyghost = false;                          // does the row have a ghost partner (boundary row of the domain)?
-  int cnt = 0;      // entries written so far
-  int qn = 0;       // accepted candidates waiting in the queue
-
-  // Phase 2, dense: one queued candidate per lane -> table interpolation, list entry, hessian value.  Only a third of the
-  // candidates pass the distance test, so doing this work on compacted batches keeps every lane busy.
-  auto emit = [&](int nproc) {
-#ifdef RXMD_EXPERIMENTS
-    if (g.probe == 2) { cnt += nproc; return; }
-#endif
-    if (lane < nproc) {
-      const int k = sq[lane], slot = cnt + lane;
-      if (slot < S10) {
-        const long long wv = sw[lane];
-        const int j = static_cast<int>(wv & 0xffffffffLL), tj = static_cast<int>((wv >> 32) & 255);
-        const double r2 = sr2[lane];
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-        if (PQ) { const double4 p = sorted[k]; d0 = xi - p.x; d1 = yi - p.y; d2 = zi - p.z; }   // the shell terms need the vector
-        // hessian entry as qeq_initialize computes it: r^2 rounded to REAL(4) first (qeq.F90:191,222-240)
-        const float r2f = static_cast<float>(r2);
-        double h = 0.0, hc = 0.0;
-        const int inxn = s_ix2[ti * ff.n1 + tj];
-        // skewed box: a ghost partner beyond the reference's QEq ghost shell is in its FORCE list but not in its QEq matrix
-        bool inq = true;
-        if (!ORTHO && j >= N) {
-          const double g0 = spx[j], g1 = spy[j], g2 = spz[j];
-          inq = g0 > rm.qlo[0] && g0 <= rm.qhi[0] && g1 > rm.qlo[1] && g1 <= rm.qhi[1] && g2 > rm.qlo[2] && g2 <= rm.qhi[2];
-        }
-        if (PQ) {
-          if (inq && static_cast<double>(r2f) < ff.rctap2) {                  // the pair is in PQEq's own list (real(4) test, pqeq.F90:305)
-            const double C0q = 14.4;                                   // Cclmb0_qeq, module.F90:682
-            const double4 sj = sorted_shl[k];
-            const double Zj = ff.Zpq[tj];
-            const int prow = ff.inxnpq[ti * ff.npq1 + tj];
-            double E, F;
-            pq_lookup(ff, ff.tabPcc, prow, r2, E, F);                  // core(i)-core(j)
-            h = C0q * E;
-            p_hz += h * Zj;
-            // Eq. 30: field of core(j) minus field of shell(j) at core(i); table row (jty,ity), pqeq.F90:328-334
-            double e0 = d0 - sj.x, e1 = d1 - sj.y, e2 = d2 - sj.z;
-            pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
-            p_f += h * Zj - C0q * E * Zj;
-            // shell(i)-core(j): Csicj = -hsc * (q_j + Z_j), pqeq.F90:392-395
-            e0 = d0 + sxi; e1 = d1 + syi; e2 = d2 + szi;
-            pq_lookup(ff, ff.tabPsc, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
-            hc = C0q * E * Zi;
-            p_bz += hc * Zj;
-            // shell(i)-shell(j): Csisj, pqeq.F90:397-401 (half of it per row, :409)
-            e0 -= sj.x; e1 -= sj.y; e2 -= sj.z;
-            pq_lookup(ff, ff.tabPss, prow, e0 * e0 + e1 * e1 + e2 * e2, E, F);
-            p_ss += 0.5 * C0q * E * Zi * Zj;
-          }
-          hsc[row + slot] = hc;
-        } else if (inq && static_cast<double>(r2f) < ff.rctap2 && inxn != 0) {
-          const int itb = static_cast<int>(static_cast<double>(r2f) * ff.UDRi);
-          double drtb = static_cast<double>(r2f) - itb * ff.UDR;
-          drtb = drtb * ff.UDRi;
-          const double *T = ff.tabQEq + static_cast<size_t>(inxn) * (NTABLE + 2);
-          h = (1.0 - drtb) * T[itb] + drtb * T[itb + 1];
-        }
-        {   // window slot: the candidate's column (of this row) -> the group's table entry -> first unit of the column + offset inside it
-          const int t_ = static_cast<int>((wv >> 40) & 31);
-#ifdef RXMD_EXPERIMENTS
-          if (!(g.probe & 4))
-#endif
-          sl10[row + slot] = static_cast<unsigned short>((k - cE[t_]) | (j >= N ? 0x8000 : 0));     // cE: first position of the column's interval - 8 x its first unit
-        }
-        unsigned ent = static_cast<unsigned>(k) | (static_cast<unsigned>(tj) << NB10_IDX_BITS) | (j >= N ? NB10_GHOST : 0u);
-        if (SELFCHECK && gid[j] == gid[i]) ent |= NB10_SELF;           // an atom and its own periodic image (small boxes only)
-        if (xs0) {
-          const double qsj = xs0[k].x;
-          ra += h * qsj;
-          if (PQ) rg += hc * qsj; else if (j >= N) rg += h * qsj;
-        }
-        anyghost |= (j >= N);
-#ifdef RXMD_EXPERIMENTS
-        if (!(g.probe & 8))
-#endif
-        nb10[row + slot] = static_cast<int>(ent);
-#ifdef RXMD_EXPERIMENTS
-        if (!(g.probe & 16))
-#endif
-        hess[row + slot] = h;
-      }
-    }
-    cnt += nproc;
-  };
-
-  // the 25 stencil columns: lane t < 25 owns column t; an inclusive scan over the lanes lays the runs end to end
-  int L, myP;
-  {   // the row's 25 candidate runs and the slot bases of its group's stencil columns, as k_win_columns left them
-    int k0 = 0, len = 0, gb = 0;
-    if (lane < 32) { k0 = rowcols[static_cast<size_t>(ridx) * 64 + lane]; len = rowcols[static_cast<size_t>(ridx) * 64 + 32 + lane]; gb = grp_base[static_cast<size_t>(grp) * 32 + lane]; }
-    int lpre = len;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-      const int l2 = __shfl_up(lpre, o, 64);
-      if (lane >= o) lpre += l2;
-    }
-    if (lane < 32) { cK[lane] = k0 - (lpre - len); cE[lane] = gb; }
-    myP = (lane < 32) ? lpre - len : 0x7fffffff;   // candidates before column `lane` (columns 25..31: L)
-    L = __shfl(lpre, 31, 64);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#ifdef RXMD_EXPERIMENTS
-  if (g.probe == 1) { if (lane == 0) n10[i] = L; return; }
-#endif
-  // The column of a candidate = the last one that starts at or before it.  Candidates are walked in order, so the wavefront keeps the next column
-  // boundary it has not passed (tn, a scalar; the boundaries sit one per lane in myP and are read with v_readlane): a batch of 64 candidates
-  // starts in column tn - 1 and a lane adds one for every boundary of the batch at or below its candidate -- 1.2 boundaries per batch on
-  // average, where a binary search over the 32 entries in LDS took five dependent reads per candidate.
-  int tn = 1;
-  for (int c0 = 0; c0 < L; c0 += 256) {
-    // Phase 1, sparse: distance test of 4 x 64 candidates (all loads first), survivors appended to the queue in candidate order
-    int kk[4], tcol[4];
-    bool ok[4];
-    double4 pd[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int cc = c0 + 64 * u + lane;
-      ok[u] = cc < L;
-      int t = tn - 1;                            // the column of candidate cc
-      for (;;) {
-        const int pm = __builtin_amdgcn_readlane(myP, tn);
-        if (pm > c0 + 64 * u + 63) break;        // (lanes 32.. hold INT_MAX: tn stops at 32)
-        t += (pm <= cc) ? 1 : 0;
-        ++tn;
-      }
-      kk[u] = ok[u] ? cK[t] + cc : 0;
-      tcol[u] = t;
-      pd[u] = ok[u] ? sorted[kk[u]] : make_double4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      bool in = false;
-      double r2q = 0.0;
-      if (ok[u]) {
-        const int j = static_cast<int>(__double_as_longlong(pd[u].w) & 0xffffffffLL);
-        const double d0 = xi - pd[u].x, d1 = yi - pd[u].y, d2 = zi - pd[u].z;
-        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-        r2q = r2;
-        in = (j != i) && (r2 <= ff.rctap2);     // dr2 <= rctap2, main.F90:458
-        if (!ORTHO && in) { double sj[3]; ref_norm(rm, pd[u].x, pd[u].y, pd[u].z, sj); in = ref_nb_cells_in_mesh(rm, sni, sj, ff.rctap2); }
-      }
-      const unsigned long long m = __ballot(in);
-      if (in) { const int qp = qn + __popcll(m & ((1ULL << lane) - 1ULL)); sq[qp] = kk[u]; sr2[qp] = r2q; sw[qp] = __double_as_longlong(pd[u].w) | (static_cast<long long>(tcol[u]) << 40); }
-      qn += __popcll(m);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      if (qn >= 64) {
-        emit(64);
-        const int rest = qn - 64;
-        int v = 0; double vr = 0.0; long long vw = 0;
-        if (lane < rest) { v = sq[64 + lane]; vr = sr2[64 + lane]; vw = sw[64 + lane]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (lane < rest) { sq[lane] = v; sr2[lane] = vr; sw[lane] = vw; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        qn = rest;
-      }
-    }
-  }
-  if (qn > 0) emit(qn);
-  if (live) {
-  if (cnt > S10) { if (lane == 0) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXN10); } cnt = S10; }  // qeq.F90:248-252
-  if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) { nb10[row + cnt + lane] = 0; hess[row + cnt + lane] = 0.0; sl10[row + cnt + lane] = 0; }   // zero-pad the row to a multiple of 4 (value 0, slot 0)
-  if (xs0) {
-    ra = wave_sum_l(ra); rg = wave_sum_l(rg);
-    if (lane == 0) { s_all[i] = make_double2(ra, 0.0); s_gh[i] = make_double2(rg, 0.0); }
-  }
-  if (PQ) {
-    p_f = wave_sum_l(p_f); p_hz = wave_sum_l(p_hz); p_bz = wave_sum_l(p_bz); p_ss = wave_sum_l(p_ss);
-    if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) hsc[row + cnt + lane] = 0.0;
-    if (lane == 0) pqrow[i] = make_double4(p_f, p_hz, p_bz, p_ss);
-  }
-  const unsigned long long mg = __ballot(anyghost);
-  if (lane == 0 && rowflag) rowflag[i] = (mg != 0ULL) ? 1 : 0;
-  if (lane == 0) {
-    n10[i] = cnt | (mg != 0ULL ? N10_GHOST_ROW : 0);
-    // err[3] = the longest 10 A row of this build (the ring matrix pass issues a fixed number of DMA instructions per row and needs the bound;
-    // read with the error word the host waits for anyway).  One atomic per new maximum, not per row.
-    if (__hip_atomic_load(&err[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[3], cnt);
-    if (__hip_atomic_load(&err[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cnt) atomicMin(&err[4], cnt);     // ... and the shortest
-    if (gflag && mg != 0ULL) gflag[grp] = 1;      // multi-rank: a group with a row that has a ghost partner waits for the vector halo (every writer writes 1; cleared by build_windows)
-  }
-  }   // live
-}
-
-#else
 constexpr int L10_ROWS = 8;      // rows (wavefronts) of a workgroup of the 10 A sweep: half a window group
 constexpr int L10_CAP = 1600;    // staged candidate positions of a workgroup (28 B each: 44.8 KB + 8 KB of queues and tables = three workgroups per CU; RDX: ~1,500 per 8 rows)
 template <bool SELFCHECK, bool PQ, bool ORTHO>
@@ -834,7 +524,6 @@ __global__ void __launch_bounds__(64 * L10_ROWS) k_list10(int N, int S10, Grid g
   }   // live
 }
 
-#endif
 // boundary rows keep their order, interior rows too: index lists for the two launches of the matrix pass
 __global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__restrict__ scan, int *__restrict__ rows_int, int *__restrict__ rows_bnd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -892,31 +581,18 @@ void Engine::build_bonded_list(bool pack_only) {
   // pack_only: the compact tables were too small for this build and have been re-allocated; the staging lines and the counts of the sweep are intact
   if (!pack_only) {
   RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
-#ifdef RXMD_BLIST_ROUND4
-  if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
-  else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, NB, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
-#else
   if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
   else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
-#endif
   }
   RX_HIP(hipMemsetAsync(nbrcnt + G, 0, sizeof(int), stream));                       // (G < NB always: the scan below runs over G + 1 counts)
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, nbrcnt, boff, G + 1, stream));
   RX_HIP(hipMemcpyAsync(d_err + 7, boff + G, sizeof(int), hipMemcpyDeviceToDevice, stream));   // bonds of this build: read with the error word the host waits for anyway
   RX_HIP(hipMemcpyAsync(d_err + 9, boff + N, sizeof(int), hipMemcpyDeviceToDevice, stream));   // ... and the residents' share of them
-#ifdef RXMD_BLIST_ROUND4
-  k_bond_csr<<<dim3(nblk(G, 256), MAXNB), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, type, btype, d_err);
-#else
   k_bond_csr<<<dim3(nblk(G, 32), (MAXNB + 7) / 8), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, type, btype, d_err);
-#endif
 }
 
-#ifdef RXMD_LIST10_ROUND4
-constexpr int L10_ROWS_LAUNCH = 4;
-#else
 constexpr int L10_ROWS_LAUNCH = L10_ROWS;
-#endif
 void Engine::build_list10() {
 #ifdef RXMD_EXPERIMENTS
   if (const char *pv = std::getenv("RXMD_LIST_PROBE")) grid.probe = std::atoi(pv);
