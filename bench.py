@@ -189,7 +189,9 @@ def compact_leg(workload, ncells, steps, warmup, device, **kw):
                 "qeq_iters_per_step": st["qeq_iters_total"] / max(st["qeq_calls"], 1), "spmv_launches_per_step": st["spmv_launches"] / steps,
                 "roofline": dict({"bound": "hbm", "kernel": "k_spmv_win" if st.get("win_in_use") else "k_spmv", "bytes_per_entry": 20 if pqeq else 12, "algorithmic_bytes_per_launch": bp, "avg_launch_ms": ms_spmv, "achieved": ach,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}, **pass_info(st, pqeq is not None)),
-                "breakdown_ms_per_step": {k: st[k] / steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_winbuild")}}
+                "breakdown_ms_per_step": {k: st[k] / steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_winbuild", "ms_bond_exposed")},
+                "bond_overlap": st.get("bond_overlap", 0),
+                "kernel_ms_per_step": {k: st[k] / steps for k in st if k.startswith("ms_k_")}}
     finally:
         eng.close()
 
@@ -459,7 +461,7 @@ def main():
                   "avg_pass_ms": ss["ms_qeq_spmv"] / max(ss["spmv_launches"], 1),
                   "breakdown_ms_per_step": {k: ss[k] / 100 for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_winbuild")}}
 
-    other, alt_lex, noplace = None, None, None
+    other, alt_lex, noplace, one_stream = None, None, None, None
     if world == 1 and not a.no_other_configs and a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS:
         eng.close(); eng = None                                   # the 979,776-atom engine gives its memory back first
         # isQEq = 2 (qeq.F90:51-57, main.F90:67-68,98): the reference's own production mode -- extended-Lagrangian charges, ONE CG step per MD
@@ -477,6 +479,16 @@ def main():
             noplace = {"error": str(ex)}
         finally:
             os.environ.pop("RXMD_PLACE_TRIES", None)
+        # the charge-free part of FORCE on the main stream again (engine.h: bond_stream; RXMD_NO_BOND_OVERLAP=1): what the headline gains from running
+        # it next to ENbond -- and the per-kernel times of roofline.kernels[], which describe a kernel that has the GPU to itself
+        try:
+            os.environ["RXMD_NO_BOND_OVERLAP"] = "1"
+            one_stream = compact_leg("rdx", ATOMS_PER_GPU_CELLS, a.steps, a.warmup, local)
+            one_stream["note"] = "the headline configuration in another engine of this process with RXMD_NO_BOND_OVERLAP=1: bond orders, bonded terms and assembly queued on the main stream behind ENbond"
+        except Exception as ex:
+            one_stream = {"error": str(ex)}
+        finally:
+            os.environ.pop("RXMD_NO_BOND_OVERLAP", None)
         other = []
         for w in ("water", "sicnp"):                              # BASELINE configs[2] and configs[4] at their one-GPU sizes
             try:
@@ -563,15 +575,19 @@ def main():
             b = max(fr, key=fr.get)
             return (b if fr[b] >= 0.35 else "latency"), fr[b], fr
         kernels = []
+        # a kernel's time and ceilings are those of the kernel ALONE: when this engine ran the bonded chain next to ENbond (rxmd_stats.bond_overlap), the
+        # kernels of either side come from the one-stream leg of the same configuration
+        alone = (one_stream or {}).get("kernel_ms_per_step") if st.get("bond_overlap") else None
         for name, key, byts, cnt, note in kdefs:
-            ms = st.get(key, 0.0) / max(cnt, 1)
+            ms = alone[key] if (alone and key in alone and key not in ("ms_k_list10", "ms_k_blist")) else st.get(key, 0.0) / max(cnt, 1)
             ach_k = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             tr_k = traffic_for(*name.split("+"))
             vf_k = valu_floor_ms(*name.split("+"))
             bnd, fb, fr_all = bound_of(ms, tr_k, l2_bytes_for(*name.split("+")), vf_k, atomics_for(*name.split("+")))
             kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": tr_k,
                             "frac_real_traffic": (tr_k / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr_k and ms > 0) else None, "valu_floor_ms": vf_k,
-                            "bound": bnd, "frac_of_bound": fb, "frac_of_each_ceiling": fr_all, "note": note})
+                            "bound": bnd, "frac_of_bound": fb, "frac_of_each_ceiling": fr_all, "note": note,
+                            "timed": "alt_one_stream leg" if (alone and key in alone and key not in ("ms_k_list10", "ms_k_blist")) else "headline leg"})
         kernels.append({"name": "CG vector kernels (k_cg_update, k_cg_direction, k_sorted_vec, k_reduce_fused)", "ms": ms_cg_vec, "algorithmic_bytes": st["natoms"] * 300.0,
                         "achieved_GBs": st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 if ms_cg_vec > 0 else 0.0,
                         "frac": (st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_cg_vec > 0 else 0.0, "traffic": traffic_for("k_cg_update", "k_cg_direction", "k_sorted_vec", "k_reduce_fused"),
@@ -617,7 +633,8 @@ def main():
                          "step_bytes_per_atom_executed": b_step_exec, "step_frac_of_hbm_roofline": (b_step_exec * natoms * steps_per_s) / (HBM_PEAK_GBS * 1e9),
                          "kernels": kernels},
             "breakdown_ms_per_step": {k: st.get(k, 0.0) / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_blist",
-                                                                    "ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold", "ms_k_winbuild")},
+                                                                    "ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold", "ms_k_winbuild", "ms_bond_exposed")},
+            "bond_overlap": st.get("bond_overlap", 0),
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
         }
         if per_rank:
@@ -631,6 +648,8 @@ def main():
             out["steady"] = steady
         if noplace:
             out["alt_no_placement_search"] = noplace
+        if one_stream:
+            out["alt_one_stream"] = one_stream
         if other:
             out["other_configs"] = other
         if cb:

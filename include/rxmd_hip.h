@@ -181,6 +181,10 @@ typedef struct rxmd_stats {
   /* the instance of the matrix pass the engine dispatched last: k_spmv_win<MODE, STORE, PQ, spmv_nstep, spmv_var> (qeq.hip); 0, 0 = the row pass k_spmv */
   int spmv_nstep, spmv_var, reserved3;
   double ms_k_blist;                    /* the bonded list: sweep + prefix sum + packing into the compact tables (k_bonded_list, k_bond_csr) */
+  /* (append-only) the charge-free part of FORCE (bond orders, bonded terms, assembly: ms_bo, ms_bonded, ms_k_e3b ... are its stream times) runs on a
+   * stream of its own next to the QEq iterations and ENbond: what of it the main stream had to WAIT for in front of the stress sums, and 1 when it ran so */
+  double ms_bond_exposed;
+  int bond_overlap, reserved4;
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);

@@ -32,7 +32,8 @@ class RxmdStats(C.Structure):
                 ("win_groups", C.c_int), ("win_max_units", C.c_int), ("win_in_use", C.c_int), ("reserved2", C.c_int),
                 ("place_ms_first", C.c_double), ("place_ms_kept", C.c_double),
                 ("place_total_ms", C.c_double), ("place_bytes_held", C.c_double), ("place_draws", C.c_int),
-                ("spmv_nstep", C.c_int), ("spmv_var", C.c_int), ("reserved3", C.c_int), ("ms_k_blist", C.c_double)]
+                ("spmv_nstep", C.c_int), ("spmv_var", C.c_int), ("reserved3", C.c_int), ("ms_k_blist", C.c_double),
+                ("ms_bond_exposed", C.c_double), ("bond_overlap", C.c_int), ("reserved4", C.c_int)]
 
     def asdict(self):
         d = {}

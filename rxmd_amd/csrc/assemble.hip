@@ -141,11 +141,52 @@ void Engine::accumulate_stress(bool kinetic) {
   k_stress_final<<<1, 384, 0, stream>>>(nb, partials, scal + 48);
 }
 
+// The charge-free part of FORCE on the third stream (engine.h: bond_stream): bond orders, every bonded term, the assembly of the bonded forces, next
+// to the ghost-charge halo and ENbond (bound by L2 lines; the bonded kernels by FP64 chains).  Queued behind everything the main stream holds at this
+// point; joined by Engine::force in front of the stress sums.  The force
+// array belongs to this chain until then (k_delta_lp clears it, k_bond_force_sum finishes it); ENbond leaves its part in fnb.
+__global__ void k_add_force3(int n, const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { fx[i] += ax[i]; fy[i] += ay[i]; fz[i] += az[i]; }
+}
+void Engine::bonded_chain_begin() {
+  RX_HIP(hipMemsetAsync(scal + 32, 0, sizeof(double) * 16, stream));     // the energy accumulators: both chains add to them
+  RX_HIP(hipEventRecord(ev_fork, stream));
+  RX_HIP(hipStreamWaitEvent(bond_stream, ev_fork, 0));
+  std::swap(stream, bond_stream);
+  try {
+    { const bool kt = kt_begin(&st.ms_k_bondorder, &st.ms_bo); bond_orders(); kt_end(kt); }
+    const KtPair t_bonded = outer_begin(&st.ms_bonded);
+    bonded_energies();
+    { const bool kt = kt_begin(&st.ms_k_assemble); assemble_forces(); kt_end(kt); }
+    outer_end(t_bonded);
+  } catch (...) { std::swap(stream, bond_stream); throw; }
+  std::swap(stream, bond_stream);
+  RX_HIP(hipEventRecord(ev_bond, bond_stream));
+}
+
 void Engine::force(bool defer_host_read) {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   const KtPair t_force = outer_begin(&st.ms_force);
   if (!lists_valid) build_ghosts_and_lists();
   double *pe_d = scal + 32;
+  if (bond_overlap()) {
+    // (Starting the chain earlier, behind the list build and underneath the CG iterations, was measured: the matrix passes that share the GPU with it
+    //  slow down by exactly what the chain saves -- 48.2-48.5 against 48.0-48.7 ms per step, the pass 1.02 against 0.82 ms -- so it starts here.)
+    bonded_chain_begin();
+    if (multi()) { on_comm_stream([&] { charge_halo(); }); join_comm_stream(); } else charge_halo();
+    { const bool kt = kt_begin(&st.ms_k_nonbond, &st.ms_nonbond); nonbonded(true); kt_end(kt); }        // pot.F90:48-52
+    { const bool kt = kt_begin(&st.ms_bond_exposed); RX_HIP(hipStreamWaitEvent(stream, ev_bond, 0)); kt_end(kt); }   // what of the bonded chain the CG and ENbond did not hide
+    st.bond_overlap = 1;
+    k_add_force3<<<nblk(N, 256), 256, 0, stream>>>(N, fnb[0], fnb[1], fnb[2], frc[0], frc[1], frc[2]);
+    accumulate_stress(false);                            // pot.F90:65-72, before the ghost forces are folded back
+    { const bool kt = kt_begin(&st.ms_fold); fold_ghost_forces(); kt_end(kt); }
+    RX_HIP(hipMemcpyAsync(h_scal + 32, pe_d, sizeof(double) * 16, hipMemcpyDeviceToHost, stream));
+    outer_end(t_force);
+    force_pending = true;
+    if (!defer_host_read) finish_force();
+    return;
+  }
   RX_HIP(hipMemsetAsync(pe_d, 0, sizeof(double) * 16, stream));
   // the ghost-charge halo needs nothing from the bond orders and they need no charges: on a multi-rank run the exchange goes to
   // the second stream and meets the main stream again in front of the nonbonded kernel

@@ -233,6 +233,12 @@ struct Engine {
     RX_HIP(hipEventRecord(ev_comm, comm_stream));
   }
   bool in_comm_region = false;
+  // third stream: the part of FORCE that needs no charges (bond orders, every bonded term, the assembly of the bonded forces) runs next to the
+  // ghost-charge halo and the nonbonded sweep (assemble.hip: bonded_chain_begin).  RXMD_NO_BOND_OVERLAP=1: one stream, as until round 5.
+  hipStream_t bond_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_bond = nullptr;
+  double *fnb[3] = {nullptr, nullptr, nullptr};             // ENbond's force on the residents while the bonded chain owns frc; added behind the join
+  bool bond_overlap() const { return bond_stream != nullptr && !ff.pqeq; }
+  void bonded_chain_begin();
   // main stream waits for what on_comm_stream queued; the wait itself is timed: that is the part of the exchange the compute did not hide
   void join_comm_stream() { const bool kt = kt_begin(&st.ms_halo_exposed); RX_HIP(hipStreamWaitEvent(stream, ev_comm, 0)); kt_end(kt); }
   hipEvent_t ev[8] = {};
@@ -346,7 +352,7 @@ struct Engine {
   void bond_orders();
   void bonded_energies();
   void charge_halo();
-  void nonbonded();
+  void nonbonded(bool to_fnb = false);
   void pqeq_sorted_shells();      // ghost shells <- owners, cell-sorted copy (MODE_COPY payload of spos, comm.F90:129-131)
   void pqeq_update_shells();      // update_shell_positions, pqeq.F90:184-259
   void nonbonded_pqeq();          // ENbond_PQEq, pot.F90:784-923

@@ -54,7 +54,7 @@ __device__ inline void nb_pair(const DevFF &ff, const int *__restrict__ ix2, dou
 __global__ void __launch_bounds__(64 * NB_WPB) k_nonbond(int N, int S10, DevFF ff, const int *__restrict__ nb10, const int *__restrict__ n10,
                                                   const double4 *__restrict__ pk, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                   const double *__restrict__ q, const int *__restrict__ type,
-                                                  double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+                                                  double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, int assign) {
   __shared__ double sm[NB_WPB][3], sv[NB_WPB][6];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform -> scalar registers
   if (threadIdx.x < 6 * NB_WPB) sv[threadIdx.x / 6][threadIdx.x % 6] = 0.0;
@@ -87,7 +87,8 @@ __global__ void __launch_bounds__(64 * NB_WPB) k_nonbond(int N, int S10, DevFF f
     // difference  1/2 sum_j dr_ij f_ij - pos_i f_i  to the accumulators so that Engine::accumulate_stress sees the reference's sum
     v0 = wave_sum_n(v0); v1 = wave_sum_n(v1); v2 = wave_sum_n(v2); v3 = wave_sum_n(v3); v4 = wave_sum_n(v4); v5 = wave_sum_n(v5);
     if (lane == 0) {
-      fx[i] += f0; fy[i] += f1; fz[i] += f2;
+      if (assign) { fx[i] = f0; fy[i] = f1; fz[i] = f2; }                  // (the bonded chain owns the force array meanwhile: Engine::force adds these behind the join)
+      else { fx[i] += f0; fy[i] += f1; fz[i] += f2; }
       const DevAtomP ap = ff.atom[ti];
       e13 = CEchrge * (ap.chi * qi + 0.5 * ap.eta * qi * qi);           // pot.F90:708
       sv[w][0] = v0 - xi * f0; sv[w][1] = v1 - yi * f1; sv[w][2] = v2 - zi * f2; sv[w][3] = v3 - yi * f2; sv[w][4] = v4 - zi * f0; sv[w][5] = v5 - xi * f1;
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_nonbond_win(int N, int G, 
                                                                 const double4 *__restrict__ pk, const unsigned char *__restrict__ stype,
                                                                 const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                                 const double *__restrict__ q, const int *__restrict__ type,
-                                                                double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+                                                                double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, int assign) {
   extern __shared__ double4 s_p[];                 // window: slot -> (x, y, z, q) ...
   unsigned char *s_t = reinterpret_cast<unsigned char *>(s_p + static_cast<size_t>(maxunits) * WIN_UNIT);   // ... and the atom type
   __shared__ double sm[WIN_ROWS][3], sv[WIN_ROWS][6];
@@ -164,7 +165,8 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_nonbond_win(int N, int G, 
     const double f0 = wave_sum_n(acc.f0), f1 = wave_sum_n(acc.f1), f2 = wave_sum_n(acc.f2);
     const double v0 = wave_sum_n(acc.v0), v1 = wave_sum_n(acc.v1), v2 = wave_sum_n(acc.v2), v3 = wave_sum_n(acc.v3), v4 = wave_sum_n(acc.v4), v5 = wave_sum_n(acc.v5);
     if (lane == 0) {
-      fx[i] += f0; fy[i] += f1; fz[i] += f2;
+      if (assign) { fx[i] = f0; fy[i] = f1; fz[i] = f2; }                  // (the bonded chain owns the force array meanwhile: Engine::force adds these behind the join)
+      else { fx[i] += f0; fy[i] += f1; fz[i] += f2; }
       const DevAtomP ap = ff.atom[ti];
       e13 = CEchrge * (ap.chi * qi + 0.5 * ap.eta * qi * qi);           // pot.F90:708
       sv[w][0] = v0 - xi * f0; sv[w][1] = v1 - yi * f1; sv[w][2] = v2 - zi * f2; sv[w][3] = v3 - yi * f2; sv[w][4] = v4 - zi * f0; sv[w][5] = v5 - xi * f1;   // the stress note of k_nonbond
@@ -195,18 +197,20 @@ void Engine::charge_halo() {
     k_sorted_charge<<<nblk(G, 256), 256, 0, stream>>>(G, rootperm, q, sorted_xyzi);
 }
 
-void Engine::nonbonded() {
+void Engine::nonbonded(bool to_fnb) {
+  double *f0 = to_fnb ? fnb[0] : frc[0], *f1 = to_fnb ? fnb[1] : frc[1], *f2 = to_fnb ? fnb[2] : frc[2];
+  const int assign = to_fnb ? 1 : 0;
   // over the windows of the matrix pass when this list build has them and no atom can meet its own image (RXMD_NONBOND_WIN=0: the row form)
   static const bool win_env = std::getenv("RXMD_NONBOND_WIN") == nullptr || std::atoi(std::getenv("RXMD_NONBOND_WIN")) != 0;
   const int units = std::min(win_maxunits, 296);                         // 296 units x 8 slots x 33 bytes = 78 KB: two workgroups per CU
   const size_t lds = static_cast<size_t>(units) * WIN_UNIT * (sizeof(double4) + 1) + 16;
   if (win_valid && win_env && !list_selfcheck) {
     k_nonbond_win<<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, n10, rows_sorted, win_k, win_cnt, units, sorted_xyzi, sorted_type, pos[0], pos[1], pos[2], q, type,
-                                                             frc[0], frc[1], frc[2], scal + 32);
+                                                             f0, f1, f2, scal + 32, assign);
     RX_HIP(hipGetLastError());
     return;
   }
-  k_nonbond<<<nblk(N, NB_WPB), 64 * NB_WPB, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, pos[0], pos[1], pos[2], q, type, frc[0], frc[1], frc[2], scal + 32);
+  k_nonbond<<<nblk(N, NB_WPB), 64 * NB_WPB, 0, stream>>>(N, S10, dff, nb10, n10, sorted_xyzi, pos[0], pos[1], pos[2], q, type, f0, f1, f2, scal + 32, assign);
 }
 
 }  // namespace rxmd

@@ -823,6 +823,31 @@ def test_other_force_fields_and_systems_the_reference_ships(case, qeq_mode):
     e.close()
 
 
+@pytest.mark.parametrize("case,mc,kw", [("rdx222", (2, 2, 2), {}), ("rdx168", (5, 5, 5), {}), ("ice644", (6, 4, 4), {}), ("rdx222", (2, 2, 2), {"isQEq": 2}), ("rdx168", (1, 1, 1), {"qstep": 3})])
+def test_bonded_chain_on_its_own_stream_gives_the_same_trajectory(case, mc, kw, monkeypatch):
+    """The charge-free part of FORCE (bond orders, bonded terms, assembly of the bonded forces) runs on a stream of its own next to the QEq
+    iterations and ENbond (engine.h: bond_stream); RXMD_NO_BOND_OVERLAP=1 is the one-stream order.  Same kernels on the same inputs: what
+    differs is that ENbond's force is added behind the bonded forces instead of before them -- the last bit of a sum.  Standalone calls
+    (QEq, FORCE) and 8 steps through step(), with every QEq setting that changes what is in flight when the chain starts."""
+    res = {}
+    for overlap in (True, False):
+        if not overlap:
+            monkeypatch.setenv("RXMD_NO_BOND_OVERLAP", "1")
+        e = _engine(case, mc, QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=1, **kw)
+        e.QEq(); pe0 = np.array(e.FORCE()); a0 = e.atoms()
+        assert e.stats()["bond_overlap"] == int(overlap)
+        e.step(8)
+        en = e.energy(); a1 = e.atoms()
+        res[overlap] = (a0["f"].copy(), pe0, a1["pos"].copy(), a1["f"].copy(), a1["q"].copy(), np.array(en["PE"]), np.array(en["astr"]))
+        e.close()
+    on, off = res[True], res[False]
+    assert f_err(on[0], off[0]) <= 1e-13 and e_err(on[1], off[1]) <= 1e-12
+    assert np.abs(on[2] - off[2]).max() <= 1e-10                      # positions after 8 steps
+    assert f_err(on[3], off[3]) <= 1e-8 and q_err(on[4], off[4]) <= 1e-8
+    assert e_err(on[5][1:14], off[5][1:14]) <= 1e-9
+    assert np.abs(on[6] - off[6]).max() <= 1e-8 * max(np.abs(off[6]).max(), 1.0)        # the stress sums (both chains add to them)
+
+
 @pytest.mark.parametrize("qeq_mode", [0, 1])
 def test_charges_every_third_step_only(qeq_mode):
     """rxmd.in `QEq 1 2000 1.d-12 3` (qstep = 3, main.F90:77): 7 MD steps against the real reference"""
