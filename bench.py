@@ -575,11 +575,11 @@ def main():
             b = max(fr, key=fr.get)
             return (b if fr[b] >= 0.35 else "latency"), fr[b], fr
         kernels = []
-        # a kernel's time and ceilings are those of the kernel ALONE: when this engine ran the bonded chain next to ENbond (rxmd_stats.bond_overlap), the
-        # kernels of either side come from the one-stream leg of the same configuration
+        # a kernel's time and ceilings are those of the kernel ALONE: when this engine ran the bonded list next to the 10 A sweep and the bonded chain next to
+        # ENbond (rxmd_stats.bond_overlap), the per-kernel times come from the one-stream leg of the same configuration
         alone = (one_stream or {}).get("kernel_ms_per_step") if st.get("bond_overlap") else None
         for name, key, byts, cnt, note in kdefs:
-            ms = alone[key] if (alone and key in alone and key not in ("ms_k_list10", "ms_k_blist")) else st.get(key, 0.0) / max(cnt, 1)
+            ms = alone[key] if (alone and key in alone) else st.get(key, 0.0) / max(cnt, 1)
             ach_k = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             tr_k = traffic_for(*name.split("+"))
             vf_k = valu_floor_ms(*name.split("+"))
@@ -587,7 +587,7 @@ def main():
             kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": tr_k,
                             "frac_real_traffic": (tr_k / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr_k and ms > 0) else None, "valu_floor_ms": vf_k,
                             "bound": bnd, "frac_of_bound": fb, "frac_of_each_ceiling": fr_all, "note": note,
-                            "timed": "alt_one_stream leg" if (alone and key in alone and key not in ("ms_k_list10", "ms_k_blist")) else "headline leg"})
+                            "timed": "alt_one_stream leg" if (alone and key in alone) else "headline leg"})
         kernels.append({"name": "CG vector kernels (k_cg_update, k_cg_direction, k_sorted_vec, k_reduce_fused)", "ms": ms_cg_vec, "algorithmic_bytes": st["natoms"] * 300.0,
                         "achieved_GBs": st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 if ms_cg_vec > 0 else 0.0,
                         "frac": (st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_cg_vec > 0 else 0.0, "traffic": traffic_for("k_cg_update", "k_cg_direction", "k_sorted_vec", "k_reduce_fused"),

@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O
 timeout -k 10 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -x \
-  -k "bonded_chain_on_its_own or tight_tolerance_parity_vs_oracle or md_trajectory or bitwise_reproducible or migration_across or stress_accumulators or charges_every_third or poisoned" > $O/pytest.log 2>&1
+  -k "bonded_chain_on_its_own or tight_tolerance_parity_vs_oracle or md_trajectory or bitwise_reproducible or migration_across or stress_accumulators or charges_every_third or poisoned or bond_tables_grow or row_stride" > $O/pytest.log 2>&1
 echo "pytest rc=$?"; tail -8 $O/pytest.log | cut -c1-220
 for rep in 1 2; do
 for v in "RXMD_X=0" "RXMD_NO_BOND_OVERLAP=1"; do
