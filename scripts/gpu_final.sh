@@ -12,7 +12,7 @@ python3 -c "
 import json; d=json.load(open('$O/bench_default.json')); r=d['roofline']
 print('steps/s', round(d['value'],3), 'ms/step', round(d['ms_per_step'],2), 'pass', round(r['avg_launch_ms'],4), 'frac', round(r['frac'],3), 'frac_real', r.get('frac_real_traffic'), 'iters', d['qeq_iters_per_step'])
 print('steady', {k: (round(v,3) if isinstance(v,float) else v) for k,v in d.get('steady',{}).items() if k in ('ms_per_step','steps_per_s','qeq_iters_per_step','avg_pass_ms')})
-print('alt', d.get('alt',{}).get('ms_per_step'), 'lex', d.get('alt_lex',{}).get('ms_per_step'), 'noplace', d.get('alt_no_placement_search',{}).get('ms_per_step'), 'placement', r.get('placement_search'))
+print('alt', d.get('alt',{}).get('ms_per_step'), 'lex', d.get('alt_lex',{}).get('ms_per_step'), 'one_stream', d.get('alt_one_stream',{}).get('ms_per_step'), 'noplace', d.get('alt_no_placement_search',{}).get('ms_per_step'), 'placement', r.get('placement_search'))
 print('other', [(o.get('workload','')[:30], o.get('ms_per_step'), o.get('roofline',{}).get('avg_launch_ms'), o.get('roofline',{}).get('frac')) for o in d.get('other_configs',[])])
 print('cpu', d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('cores'))
 print({k: round(v,2) for k,v in d['breakdown_ms_per_step'].items() if v}); print([(k['name'][:14], round(k['ms'],3), k.get('bound'), k.get('frac_of_bound') and round(k['frac_of_bound'],2)) for k in r['kernels']])"
@@ -20,6 +20,11 @@ timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 grep '^{"metric' $O/bench_prof.log > $O/bench_prof.json
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats.csv; head -24 $O/kernel_stats.csv | cut -c1-130
 find $O/prof -name '*.csv' ! -name '*stats*' -delete; find $O/prof -name '*.db' -delete
+# the same trace with the charge-free part of FORCE on the main stream again: kernel durations that mean a kernel ALONE (the default run shares the GPU between ENbond and the bonded chain)
+RXMD_NO_BOND_OVERLAP=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_one -- python3 bench.py --no-cpu-baseline --no-other-configs --no-alt --no-steady > $O/bench_prof_one.log 2>&1
+grep '^{"metric' $O/bench_prof_one.log > $O/bench_prof_one.json
+f=$(find $O/prof_one -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats_one_stream.csv; head -12 $O/kernel_stats_one_stream.csv | cut -c1-130
+find $O/prof_one -name '*.csv' ! -name '*stats*' -delete; find $O/prof_one -name '*.db' -delete
 for w in water sicnp; do
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -- python3 bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-steady > $O/bench_$w.log 2>&1
   grep '^{"metric' $O/bench_$w.log > $O/bench_$w.json
