@@ -12,7 +12,7 @@
 
 #include "engine.h"
 
-namespace rxmd { double stream_probe_ms(Engine &e, int blocks); void spmv_bisect_ms(Engine &e, double *out4); void spmv_isolated_ms(Engine &e, double *out); }
+namespace rxmd { double stream_probe_ms(Engine &e, int blocks); void spmv_bisect_ms(Engine &e, double *out4); void spmv_isolated_ms(Engine &e, double *out); void spmv_tile_probe_ms(Engine &e, double *out); }
 using rxmd::Engine;
 using rxmd::EngineError;
 
@@ -524,6 +524,7 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
       }
 #ifdef RXMD_EXPERIMENTS
       case 104: n = 20; if (capacity < 20) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_isolated_ms(e, out); break;   // real window pass / row pass back to back (experiments)
+      case 105: n = 4; if (capacity < 4) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_tile_probe_ms(e, out); break;   // half-storage pass over 3-D tiles: timing probe (experiments)
       case 102: n = 7; if (capacity < 7) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_bisect_ms(e, out); break;   // stripped-down forms of the row kernel (experiments)
 #endif
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");

@@ -526,6 +526,104 @@ void spmv_isolated_ms(Engine &e, double *out) {
   if (e.win_valid) out[0] = acc[0] / rounds;      // out[2], out[3]: variants of the window pass (template parameter VAR) when some are being compared
 }
 
+
+// ---- timing probe: the symmetric matrix read ONCE over 3-D tiles (debug tap 105; experiments only) -----------------------------------
+// What a half-storage pass would cost before any of it is built: a workgroup of 16 wavefronts owns a tile of TILE_ROWS rows and holds the vector AND an
+// accumulator for TILE_WS window slots in LDS (x 16 B + y 16 B per slot: 147 KB, one workgroup per CU).  Per entry of a HALF row: value (8 B) + slot (2 B)
+// streamed as in the real pass, the partner's x from LDS, two FMAs into the row's sums and two LDS atomic adds H_ij x_i into the partner's accumulator;
+// at the end the accumulators leave as plain coalesced stores (a second kernel gathers a row's ~23 halo contributions in a fixed order: k_tile_gather_probe).
+// The bytes are real (the engine's own value / slot arrays, the first half of every row), the slots are scrambled into the tile's window (the LDS access
+// pattern of a 3-D tile: uniformly spread), the arithmetic is what the real pass would do.  Results mean nothing; times do.
+constexpr int TILE_ROWS = 416, TILE_WS = 4608;
+__global__ void __launch_bounds__(1024, 1) k_spmv_tile_probe(int N, int G, int S10, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
+                                                            const double2 *__restrict__ xv, double2 *__restrict__ rs_all, double2 *__restrict__ ybuf) {
+  extern __shared__ double2 s_xy[];                 // [0, TILE_WS): x ; [TILE_WS, 2 TILE_WS): y
+  double2 *s_x = s_xy, *s_y = s_xy + TILE_WS;
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int row0 = tile * TILE_ROWS;
+  const size_t wbase = (static_cast<size_t>(tile) * 1531u) % static_cast<size_t>(max(G - TILE_WS, 1));
+  for (int t = threadIdx.x; t < TILE_WS; t += 1024) { s_x[t] = xv[wbase + t]; s_y[t] = make_double2(0.0, 0.0); }
+  // two rows of a wavefront in flight: the next row's batch is requested before the current row's arithmetic (512 entries per wavefront in flight)
+  d2v v[2][2]; unsigned ss[2][2]; int nh[2] = {0, 0};
+  auto request = [&](int buf, int row) {
+    const bool live = row < N && row < row0 + TILE_ROWS;
+    const size_t base = static_cast<size_t>(live ? row : 0) * S10;
+    const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
+    const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
+    nh[buf] = live ? ((n10[row] & N10_COUNT) + 1) / 2 : 0;                       // half of the row's entries
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = 128 * u + 2 * lane;
+      const bool ok = live && k < S10 / 2;
+      v[buf][u] = ok ? __builtin_nontemporal_load(hv2 + (k >> 1)) : d2v{0.0, 0.0};
+      ss[buf][u] = ok ? __builtin_nontemporal_load(sl2 + (k >> 1)) : 0u;
+    }
+  };
+  request(0, row0 + wave);
+  __syncthreads();
+  int cur = 0;
+  for (int r = row0 + wave; r < row0 + TILE_ROWS; r += 16) {
+    request(cur ^ 1, r + 16);
+    const int n = nh[cur];
+    const double2 xi = s_x[(r * 11) % TILE_WS];
+    double as = 0.0, at = 0.0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = 128 * u + 2 * lane;
+      const unsigned s0 = ((ss[cur][u] & 0x7fffu) * 13u + lane * 71u) % TILE_WS, s1 = (((ss[cur][u] >> 16) & 0x7fffu) * 13u + lane * 71u + 37u) % TILE_WS;
+      const double h0 = k < n ? v[cur][u].x : 0.0, h1 = k + 1 < n ? v[cur][u].y : 0.0;
+      const double2 y0 = s_x[s0], y1 = s_x[s1];
+      as += h0 * y0.x; at += h0 * y0.y; as += h1 * y1.x; at += h1 * y1.y;
+      if (k < n) { __hip_atomic_fetch_add(&s_y[s0].x, h0 * xi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&s_y[s0].y, h0 * xi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      if (k + 1 < n) { __hip_atomic_fetch_add(&s_y[s1].x, h1 * xi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&s_y[s1].y, h1 * xi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    }
+    as = wave_sum(as); at = wave_sum(at);
+    if (lane == 0 && r < N) rs_all[r] = make_double2(as, at);
+    cur ^= 1;
+  }
+  __syncthreads();
+  double2 *yb = ybuf + static_cast<size_t>(blockIdx.x) * TILE_WS;
+  for (int t = threadIdx.x; t < TILE_WS; t += 1024) __builtin_nontemporal_store(s_y[t].x, &yb[t].x), __builtin_nontemporal_store(s_y[t].y, &yb[t].y);
+}
+// the second kernel of that scheme: a row adds the contributions its slot received in the ~23 tiles whose window holds it, in a fixed order
+__global__ void __launch_bounds__(256) k_tile_gather_probe(int N, int ntiles, const double2 *__restrict__ ybuf, double2 *__restrict__ rs_all) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  const int tile = r / TILE_ROWS;
+  double2 a = rs_all[r];
+  for (int c = 0; c < 23; ++c) {
+    const int t2 = (tile + (c % 3 - 1) + 3 * ((c / 3) % 3 - 1) * 7 + 9 * (c / 9 - 1) * 41 + ntiles) % ntiles;      // neighbours in a 3-D arrangement of the tiles
+    const double2 y = ybuf[static_cast<size_t>(t2) * TILE_WS + (static_cast<unsigned>(r) * 29u + c * 613u) % TILE_WS];
+    a.x += y.x; a.y += y.y;
+  }
+  rs_all[r] = a;
+}
+void spmv_tile_probe_ms(Engine &e, double *out) {
+  for (int k = 0; k < 4; ++k) out[k] = -1.0;
+  if (e.ff.pqeq || e.G < TILE_WS + 16) return;
+  const int ntiles = (e.N + TILE_ROWS - 1) / TILE_ROWS;
+  double2 *ybuf = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&ybuf), sizeof(double2) * static_cast<size_t>(ntiles) * TILE_WS) != hipSuccess) { (void)hipGetLastError(); return; }
+  const size_t lds = sizeof(double2) * 2 * TILE_WS;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spmv_tile_probe), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) { (void)hipGetLastError(); }
+  auto timed = [&](auto launch) {
+    for (int r = 0; r < 11; ++r) { if (r == 1) hipEventRecord(e.ev[2], e.stream); launch(); }
+    hipEventRecord(e.ev[3], e.stream); hipEventSynchronize(e.ev[3]);
+    float ms = 0; hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
+    return static_cast<double>(ms) / 10.0;
+  };
+  out[0] = timed([&] { k_spmv_tile_probe<<<ntiles, 1024, lds, e.stream>>>(e.N, e.G, e.S10, e.sl10, e.hess, e.n10, e.xs, e.wall, ybuf); });
+  out[1] = timed([&] { k_tile_gather_probe<<<nblk(e.N, 256), 256, 0, e.stream>>>(e.N, ntiles, ybuf, e.wall); });
+  if (e.win_valid) {                                 // the real pass in the same process, after the probes
+    const size_t ldsw = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
+    out[2] = timed([&] { k_spmv_win<MODE_HSH, true, false, 2, WIN_PREFETCH | WIN_LEAN><<<e.win_groups, 64 * WIN_ROWS, ldsw, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr, e.win_flag); });
+  }
+  out[3] = (hipGetLastError() == hipSuccess) ? 0.0 : 1.0;
+  (void)hipFree(ybuf);
+}
+
 #endif   // RXMD_EXPERIMENTS
 
 __global__ void __launch_bounds__(256) k_stream_probe(size_t n16, const f64x2 *__restrict__ a, double *__restrict__ out) {
