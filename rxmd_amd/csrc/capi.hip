@@ -524,7 +524,7 @@ int rxmd_hip_debug_get(rxmd_handle h, int what, double *out, int capacity) {
       }
 #ifdef RXMD_EXPERIMENTS
       case 104: n = 20; if (capacity < 20) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_isolated_ms(e, out); break;   // real window pass / row pass back to back (experiments)
-      case 105: n = 4; if (capacity < 4) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_tile_probe_ms(e, out); break;   // half-storage pass over 3-D tiles: timing probe (experiments)
+      case 105: n = 5; if (capacity < 5) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_tile_probe_ms(e, out); break;   // half-storage pass over 3-D tiles: timing probe (experiments)
       case 102: n = 7; if (capacity < 7) throw EngineError(RXMD_E_ARG, "capacity"); rxmd::spmv_bisect_ms(e, out); break;   // stripped-down forms of the row kernel (experiments)
 #endif
       default: throw EngineError(RXMD_E_ARG, "unknown debug tap");

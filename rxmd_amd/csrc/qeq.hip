@@ -535,6 +535,7 @@ void spmv_isolated_ms(Engine &e, double *out) {
 // The bytes are real (the engine's own value / slot arrays, the first half of every row), the slots are scrambled into the tile's window (the LDS access
 // pattern of a 3-D tile: uniformly spread), the arithmetic is what the real pass would do.  Results mean nothing; times do.
 constexpr int TILE_ROWS = 416, TILE_WS = 4608;
+template <bool TRANSPOSED>     // false: the forward products only (what the streams and the LDS reads cost at one workgroup per CU)
 __global__ void __launch_bounds__(1024, 1) k_spmv_tile_probe(int N, int G, int S10, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const double2 *__restrict__ xv, double2 *__restrict__ rs_all, double2 *__restrict__ ybuf) {
   extern __shared__ double2 s_xy[];                 // [0, TILE_WS): x ; [TILE_WS, 2 TILE_WS): y
@@ -576,8 +577,8 @@ __global__ void __launch_bounds__(1024, 1) k_spmv_tile_probe(int N, int G, int S
       const double h0 = k < n ? v[cur][u].x : 0.0, h1 = k + 1 < n ? v[cur][u].y : 0.0;
       const double2 y0 = s_x[s0], y1 = s_x[s1];
       as += h0 * y0.x; at += h0 * y0.y; as += h1 * y1.x; at += h1 * y1.y;
-      if (k < n) { __hip_atomic_fetch_add(&s_y[s0].x, h0 * xi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&s_y[s0].y, h0 * xi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      if (k + 1 < n) { __hip_atomic_fetch_add(&s_y[s1].x, h1 * xi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&s_y[s1].y, h1 * xi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      if (TRANSPOSED && k < n) { __hip_atomic_fetch_add(&s_y[s0].x, h0 * xi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&s_y[s0].y, h0 * xi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      if (TRANSPOSED && k + 1 < n) { __hip_atomic_fetch_add(&s_y[s1].x, h1 * xi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&s_y[s1].y, h1 * xi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     }
     as = wave_sum(as); at = wave_sum(at);
     if (lane == 0 && r < N) rs_all[r] = make_double2(as, at);
@@ -601,20 +602,22 @@ __global__ void __launch_bounds__(256) k_tile_gather_probe(int N, int ntiles, co
   rs_all[r] = a;
 }
 void spmv_tile_probe_ms(Engine &e, double *out) {
-  for (int k = 0; k < 4; ++k) out[k] = -1.0;
+  for (int k = 0; k < 5; ++k) out[k] = -1.0;
   if (e.ff.pqeq || e.G < TILE_WS + 16) return;
   const int ntiles = (e.N + TILE_ROWS - 1) / TILE_ROWS;
   double2 *ybuf = nullptr;
   if (hipMalloc(reinterpret_cast<void **>(&ybuf), sizeof(double2) * static_cast<size_t>(ntiles) * TILE_WS) != hipSuccess) { (void)hipGetLastError(); return; }
   const size_t lds = sizeof(double2) * 2 * TILE_WS;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spmv_tile_probe), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) { (void)hipGetLastError(); }
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spmv_tile_probe<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) { (void)hipGetLastError(); }
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spmv_tile_probe<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) { (void)hipGetLastError(); }
   auto timed = [&](auto launch) {
     for (int r = 0; r < 11; ++r) { if (r == 1) hipEventRecord(e.ev[2], e.stream); launch(); }
     hipEventRecord(e.ev[3], e.stream); hipEventSynchronize(e.ev[3]);
     float ms = 0; hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
     return static_cast<double>(ms) / 10.0;
   };
-  out[0] = timed([&] { k_spmv_tile_probe<<<ntiles, 1024, lds, e.stream>>>(e.N, e.G, e.S10, e.sl10, e.hess, e.n10, e.xs, e.wall, ybuf); });
+  out[0] = timed([&] { k_spmv_tile_probe<true><<<ntiles, 1024, lds, e.stream>>>(e.N, e.G, e.S10, e.sl10, e.hess, e.n10, e.xs, e.wall, ybuf); });
+  out[4] = timed([&] { k_spmv_tile_probe<false><<<ntiles, 1024, lds, e.stream>>>(e.N, e.G, e.S10, e.sl10, e.hess, e.n10, e.xs, e.wall, ybuf); });
   out[1] = timed([&] { k_tile_gather_probe<<<nblk(e.N, 256), 256, 0, e.stream>>>(e.N, ntiles, ybuf, e.wall); });
   if (e.win_valid) {                                 // the real pass in the same process, after the probes
     const size_t ldsw = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);

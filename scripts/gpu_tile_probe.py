@@ -15,5 +15,5 @@ e = rxmd_amd.RxmdEngine(ff, lat_s, QEq_tol=1e-7, NMAXQEq=500, device=0, qeq_mode
 e.set_atoms_rxff(rec); e.QEq()
 for rep in range(3):
     t = e.debug(105, cap=8)
-    print("tile probe: half-storage pass %.4f ms + halo gather %.4f ms = %.4f ms ; the real window pass in the same process %.4f ms ; launch error %d" % (t[0], t[1], t[0] + t[1], t[2], int(t[3])), flush=True)
+    print("tile probe: half-storage pass %.4f ms (without the transposed LDS adds %.4f) + halo gather %.4f ms = %.4f ms ; the real window pass in the same process %.4f ms ; launch error %d" % (t[0], t[4], t[1], t[0] + t[1], t[2], int(t[3])), flush=True)
 e.close()
