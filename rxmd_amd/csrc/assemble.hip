@@ -143,8 +143,7 @@ void Engine::accumulate_stress(bool kinetic) {
 
 // The charge-free part of FORCE on the third stream (engine.h: bond_stream): bond orders, every bonded term, the assembly of the bonded forces, next
 // to the ghost-charge halo and ENbond (bound by L2 lines; the bonded kernels by FP64 chains).  Queued behind everything the main stream holds at this
-// point; joined by Engine::force in front of the stress sums.  The force
-// array belongs to this chain until then (k_delta_lp clears it, k_bond_force_sum finishes it); ENbond leaves its part in fnb.
+// point; joined by Engine::force in front of the stress sums.  The force array belongs to this chain until then (k_delta_lp clears it, k_bond_force_sum finishes it); ENbond leaves its part in fnb.
 __global__ void k_add_force3(int n, const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { fx[i] += ax[i]; fy[i] += ay[i]; fz[i] += az[i]; }
@@ -176,7 +175,7 @@ void Engine::force(bool defer_host_read) {
     bonded_chain_begin();
     if (multi()) { on_comm_stream([&] { charge_halo(); }); join_comm_stream(); } else charge_halo();
     { const bool kt = kt_begin(&st.ms_k_nonbond, &st.ms_nonbond); nonbonded(true); kt_end(kt); }        // pot.F90:48-52
-    { const bool kt = kt_begin(&st.ms_bond_exposed); RX_HIP(hipStreamWaitEvent(stream, ev_bond, 0)); kt_end(kt); }   // what of the bonded chain the CG and ENbond did not hide
+    { const bool kt = kt_begin(&st.ms_bond_exposed); RX_HIP(hipStreamWaitEvent(stream, ev_bond, 0)); kt_end(kt); }   // what of the bonded chain ENbond did not hide
     st.bond_overlap = 1;
     k_add_force3<<<nblk(N, 256), 256, 0, stream>>>(N, fnb[0], fnb[1], fnb[2], frc[0], frc[1], frc[2]);
     accumulate_stress(false);                            // pot.F90:65-72, before the ghost forces are folded back

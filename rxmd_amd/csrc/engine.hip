@@ -134,7 +134,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
     RX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     RX_HIP(hipStreamCreateWithPriority(&comm_stream, hipStreamDefault, hi));
   }
-  if (!std::getenv("RXMD_SINGLE_STREAM") && !std::getenv("RXMD_NO_BOND_OVERLAP")) {   // the charge-free part of FORCE next to the CG (engine.h: bond_stream)
+  if (!std::getenv("RXMD_SINGLE_STREAM") && !std::getenv("RXMD_NO_BOND_OVERLAP")) {   // the charge-free part of FORCE next to ENbond (engine.h: bond_stream); lowest priority
     int lo = 0, hi = 0;
     RX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     RX_HIP(hipStreamCreateWithPriority(&bond_stream, hipStreamDefault, lo));
