@@ -2,7 +2,7 @@
 # the kernel sequence of one step with start times and idle gaps (kernel trace of 6 steps; prints the 4th step)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline --no-other-configs --no-alt --no-steady --steps 6 > $O/bench.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline --no-other-configs --no-alt --no-steady --steps 6 > $O/bench.log 2>&1
 f=$(find $O/prof -name '*kernel_trace.csv' | head -1); m=$(find $O/prof -name '*memory_copy_trace.csv' | head -1)
 python3 - "$f" "$m" <<'PY' > $O/stepseq.txt
 import csv, sys
