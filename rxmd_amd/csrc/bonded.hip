@@ -786,7 +786,8 @@ __global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2
                                                     const int *__restrict__ type, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                     const double *__restrict__ bo0, const int *__restrict__ nb10, const int *__restrict__ n10, const double4 *__restrict__ pk, const int *__restrict__ perm,
                                                     double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                                    double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe
+                                                    double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe,
+                                                    double *__restrict__ fsx, double *__restrict__ fsy, double *__restrict__ fsz
 #ifdef RXMD_EHB_DEBUG
                                                     , int *dbg, int lim_n, int lim_b, int lim_nb
 #endif
@@ -898,9 +899,11 @@ __global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2
       for (int b = 0; b < EHB_CAP / 64; ++b) {
         const int qq = 64 * b + lane;
         if (qq < qn && (akx[b] != 0.0 || aky[b] != 0.0 || akz[b] != 0.0)) {
-          const int k = s_k[w][qq];
-          EHB_CHECKC(6, k, lim_nb, qq)
-          atomicAdd(fx + k, akx[b]); atomicAdd(fy + k, aky[b]); atomicAdd(fz + k, akz[b]);
+          // the acceptor's force goes to its CELL-SORTED position: the candidates of a row are neighbours in that order, so the lanes of one atomic
+          // instruction hit neighbouring addresses and share memory-side requests (by atom index they are scattered: 2.2 lanes per request)
+          const int ks = static_cast<int>(s_cand[w][qq] & NB10_IDX_MASK);
+          EHB_CHECKC(6, ks, lim_nb, qq)
+          atomicAdd(fsx + ks, akx[b]); atomicAdd(fsy + ks, aky[b]); atomicAdd(fsz + ks, akz[b]);
         }
       }
       wave_lds_sync();
@@ -928,6 +931,19 @@ __global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2
     wave_lds_sync();                                        // the next donor rewrites the parameter rows
   }
   block_energy_add(e10, pe + 10);
+}
+
+__global__ void k_zero3(int n, double *__restrict__ a, double *__restrict__ b, double *__restrict__ c) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) { a[k] = 0.0; b[k] = 0.0; c[k] = 0.0; }
+}
+// frc[atom at sorted position k] += the acceptor forces the hydrogen-bond sweep left at position k (perm is a permutation: no two threads meet)
+__global__ void k_add_sorted3(int G, const int *__restrict__ perm, const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
+                              double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= G) return;
+  const double a = sx[k], b = sy[k], c = sz[k];
+  if (a != 0.0 || b != 0.0 || c != 0.0) { const int i = perm[k]; fx[i] += a; fy[i] += b; fz[i] += c; }
 }
 
 void Engine::bonded_energies() {
@@ -969,6 +985,7 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
     if (static_cast<size_t>(region_cap) * EHB_REGIONS > ehb_don_cap) throw EngineError(RXMD_E_STATE, "hydrogen-bond donor list: capacity");
     RX_HIP(hipMemsetAsync(ehb_cnt, 0, sizeof(int) * EHB_REGIONS, stream));
     k_ehb_donors<<<nblk(N, 256), 256, 0, stream>>>(N, ehb_donor_types, boff, btype, bo0, type, ehb_don, ehb_cnt, region_cap);
+    k_zero3<<<nblk(G, 256), 256, 0, stream>>>(G, fsort[0], fsort[1], fsort[2]);
     if (ehb_blocks_per_cu == 0) {                 // the persistent grid fills the device exactly: workgroups per CU from the kernel's own register / LDS footprint
       int nbk = 0;
       RX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, k_ehb_sweep, 256, 0));
@@ -976,14 +993,15 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
     }
 #ifdef RXMD_EHB_DEBUG
     RX_HIP(hipMemsetAsync(ehb_cnt + EHB_REGIONS, 0, 4 * sizeof(int), stream));
-    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, region_cap, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, ehb_cnt + EHB_REGIONS, N, static_cast<int>(bcap), NB);
+    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, region_cap, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, fsort[0], fsort[1], fsort[2], ehb_cnt + EHB_REGIONS, N, static_cast<int>(bcap), NB);
     { int hd[EHB_REGIONS + 4]; RX_HIP(hipMemcpyAsync(hd, ehb_cnt, sizeof(hd), hipMemcpyDeviceToHost, stream)); RX_HIP(hipStreamSynchronize(stream));
       for (int r = 1; r < EHB_REGIONS; ++r) hd[0] += hd[r];
       hd[4] = hd[EHB_REGIONS]; hd[5] = hd[EHB_REGIONS + 1]; hd[6] = hd[EHB_REGIONS + 2]; hd[7] = hd[EHB_REGIONS + 3];
       std::fprintf(stderr, "[ehb debug] donors %d  blocks/CU %d  first violation: code %d value %d aux %d lim %d   (N %d bcap %zu NB %d S10 %d rows10 %d)\n", hd[0], ehb_blocks_per_cu, hd[4], hd[5], hd[6], hd[7], N, bcap, NB, S10, rows10); }
 #else
-    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, region_cap, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d);
+    k_ehb_sweep<<<num_cu * ehb_blocks_per_cu, 256, 0, stream>>>(S10, dff, ehb_don, ehb_cnt, region_cap, boff, nbr, type, pos[0], pos[1], pos[2], bo0, nb10, n10, sorted_xyzi, perm, cf1, fnx, fny, fnz, frc[0], frc[1], frc[2], pe_d, fsort[0], fsort[1], fsort[2]);
 #endif
+    k_add_sorted3<<<nblk(G, 256), 256, 0, stream>>>(G, perm, fsort[0], fsort[1], fsort[2], frc[0], frc[1], frc[2]);
   }
   kt_end(kth);
 }

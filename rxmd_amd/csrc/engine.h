@@ -236,6 +236,7 @@ struct Engine {
   // third stream: the part of FORCE that needs no charges (bond orders, every bonded term, the assembly of the bonded forces) runs next to the
   // ghost-charge halo and the nonbonded sweep (assemble.hip: bonded_chain_begin).  RXMD_NO_BOND_OVERLAP=1: one stream, as until round 5.
   hipStream_t bond_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_bond = nullptr;
+  double *fsort[3] = {nullptr, nullptr, nullptr};           // hydrogen-bond acceptor forces by CELL-SORTED position (neighbouring candidates = neighbouring addresses: the atomics coalesce); added to frc behind the sweep
   double *fnb[3] = {nullptr, nullptr, nullptr};             // ENbond's force on the residents while the bonded chain owns frc; added behind the join
   bool bond_overlap() const { return bond_stream != nullptr && !ff.pqeq; }
   void bonded_chain_begin();

@@ -377,7 +377,7 @@ void Engine::alloc_device() {
   }
   dmalloc(qst, nb); dmalloc(hst, nb); dmalloc(gst, nb); dmalloc(hst2, nb); dzalloc(tickets, 16);
   { dmalloc(sall, static_cast<size_t>(rows10)); dmalloc(sgh, static_cast<size_t>(rows10)); dmalloc(wall, static_cast<size_t>(rows10)); dmalloc(wgh, static_cast<size_t>(rows10)); }
-  dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(gowner, nb); dmalloc(dh_ghost, nb); dmalloc(dh_keys, nb); dmalloc(dh_keys2, nb); dmalloc(dh_vals, nb); dmalloc(dh_off, 1100); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(invpos, nb); dmalloc(xs, nb); for (int a = 0; a < 3; ++a) dmalloc(fnb[a], nb);
+  dmalloc(gsrc, nb); dmalloc(groot, nb); dmalloc(gowner, nb); dmalloc(dh_ghost, nb); dmalloc(dh_keys, nb); dmalloc(dh_keys2, nb); dmalloc(dh_vals, nb); dmalloc(dh_off, 1100); dmalloc(sendidx, nb); dmalloc(rootperm, nb); dmalloc(invpos, nb); dmalloc(xs, nb); for (int a = 0; a < 3; ++a) { dmalloc(fnb[a], nb); dmalloc(fsort[a], nb); }
   dmalloc(cellid, nb); dmalloc(cellid_sorted, nb); dmalloc(perm, nb); dmalloc(perm_in, nb); dmalloc(cellstart, static_cast<size_t>(grid.nfine) + 2);
   dmalloc(sorted_xyzi, nb); dmalloc(sorted_type, nb); dmalloc(flags, nb + 1); dmalloc(scanout, nb + 1); dmalloc(flags2, nb + 1); dmalloc(scanout2, nb + 1);
   dmalloc(nbr_sm, ns); dmalloc(nbrcnt, nb + 1); dmalloc(boff, nb + 2);
@@ -426,7 +426,7 @@ void Engine::free_device() {
   if (pqblob) { (void)hipFree(pqblob); pqblob = nullptr; }
   dfree(q); dfree(qsfp); dfree(qsfv); dfree(type); dfree(gid); dfree(qst); dfree(hst); dfree(gst); dfree(hst2); dfree(tickets); dfree(sall); dfree(sgh); dfree(wall); dfree(wgh);
   dfree(gowner); dfree(dh_ghost); dfree(dh_keys); dfree(dh_keys2); dfree(dh_vals); dfree(dh_off); dfree(dh_serve);
-  dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(invpos); dfree(xs); for (int a = 0; a < 3; ++a) dfree(fnb[a]); dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
+  dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(invpos); dfree(xs); for (int a = 0; a < 3; ++a) { dfree(fnb[a]); dfree(fsort[a]); } dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
   dfree(sorted_xyzi); dfree(sorted_type); dfree(flags); dfree(scanout); dfree(nbr_sm); dfree(nbrcnt); dfree(boff);
   free_bond_tables();
   dfree(ehb_don); dfree(ehb_cnt);
