@@ -129,6 +129,17 @@ CASES = {
     "rdx222_v222_md3":   ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 2, 2)),
     # the reference's examples/2-reaxff-dc: polyethylene, geninit -mc 4 3 5 -v 2 1 1, mpirun -np 2
     "example2_v211_md3": ("example1/pe_cell.xyz", "example1/ffield_pe", (4, 3, 5), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 1, 1)),
+    # (round 6) the modes beyond plain isQEq 1 BETWEEN DISTINCT RANKS.  PQEq under MPI: three more doubles per COPY / MOVE record and the
+    # shell halo (comm.F90:122,129-131,149-185; pqeq.F90:2-182) -- the SiC nanoparticle replicated so that every rank owns one particle;
+    # step 0 at tight tolerance (every shell on its core: no beyond-cut-off look-up, the reference's numbers are clean PQEq numbers)
+    "sicnp211_v211_pqeq_tight": ("sicnp.xyz", "ffield_sicnp", (2, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 1, 1)),
+    "sicnp222_v222_pqeq_tight": ("sicnp.xyz", "ffield_sicnp", (2, 2, 2), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0, (2, 2, 2)),
+    # ... and 3 MD steps of the reference itself (faithful oracle mode reproduces them; the engine is compared with the clean oracle)
+    "sicnp211_v211_pqeq_md3": ("sicnp.xyz", "ffield_sicnp", (2, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 3, (2, 1, 1)),
+    # the field along x on two ranks: LinearMomentum's all-reduces every step (main.F90:70-71,766-797)
+    "sicnp211_v211_pqeq_efieldx_md3": ("sicnp.xyz", "ffield_sicnp", (2, 1, 1), ["--pqeq", "pqeq.in", "--QEq_tol", "1e-12", "--NMAXQEq", "2000", "RXMDIN:efield 1 0.05"], 3, (2, 1, 1)),
+    # extended-Lagrangian charges on two ranks, 10 steps: qsfp / qsfv migrate with their atom (comm.F90:159-163)
+    "rdx222_v211_lex_md10": ("rdx.xyz", "ffield_rdx", (2, 2, 2), ["--isQEq", "2"], 10, (2, 1, 1)),
 }
 
 
@@ -182,6 +193,8 @@ def parse_mdstep(out):
 
 def make_mpi(name):
     xyz, ff, mc, flags, nsteps, vp = CASES[name]
+    extra_in = [f[7:] for f in flags if f.startswith("RXMDIN:")]     # extra rxmd.in lines (see make())
+    flags = [f for f in flags if not f.startswith("RXMDIN:")]
     npr = vp[0] * vp[1] * vp[2]
     tmp = tempfile.mkdtemp(prefix="golden_")
     try:
@@ -189,6 +202,10 @@ def make_mpi(name):
         shutil.copy(os.path.join(INP, xyz), os.path.join(tmp, "input.xyz"))
         shutil.copy(os.path.join(INP, ff), os.path.join(tmp, "ffield"))
         shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        shutil.copy(os.path.join(INP, "pqeq_sicnp.in"), os.path.join(tmp, "pqeq.in"))
+        if extra_in:
+            with open(os.path.join(tmp, "rxmd.in"), "a") as f:
+                f.write("\n".join(extra_in) + "\n")
         run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", str(mc[0]), str(mc[1]), str(mc[2]),
              "-v", str(vp[0]), str(vp[1]), str(vp[2])], tmp)
         out = run(["/opt/conda/bin/mpiexec", "-np", str(npr), os.path.join(REFBIN, "rxmd_mpi"), "--ntime_step", str(nsteps), "--pstep", "1",
@@ -310,6 +327,37 @@ def make_thermo():
         shutil.rmtree(tmp)
 
 
+def make_thermo_mpi():
+    """(round 6) the same velocity-scaling modes BETWEEN TWO RANKS: RDX 2 x 2 x 2 on vprocs 2 1 1 under real MPI.  The sums of
+    ScaleTemperature / AdjustTemperature / LinearMomentum and the kinetic energy of mode 5 are MPI_ALLREDUCEd (main.F90:699,738,783,
+    PRINTE :225-244).  20 NVE steps from rest write the restart file (both ranks' records in one rxff.bin), every mode continues
+    from it for 7 steps with sstep 3; per-rank dumps of the last step."""
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        os.makedirs(os.path.join(tmp, "DAT"))
+        shutil.copy(os.path.join(INP, "rdx.xyz"), os.path.join(tmp, "input.xyz"))
+        shutil.copy(os.path.join(INP, "ffield_rdx"), os.path.join(tmp, "ffield"))
+        shutil.copy(os.path.join(INP, "rxmd.in"), os.path.join(tmp, "rxmd.in"))
+        run([os.path.join(REFBIN, "geninit"), "-i", "input.xyz", "-f", "ffield", "-o", "DAT", "-mc", "2", "2", "2", "-v", "2", "1", "1"], tmp)
+        mpi = ["/opt/conda/bin/mpiexec", "-np", "2", os.path.join(REFBIN, "rxmd_mpi"), "--vprocs", "2", "1", "1"]
+        tight = ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"]
+        run(mpi + ["--ntime_step", "20", "--pstep", "1", "--fstep", "100000", "--isBinary"] + tight, tmp)
+        restart = open(os.path.join(tmp, "DAT", "rxff.bin"), "rb").read()
+        for name, flags in THERMO.items():
+            open(os.path.join(tmp, "DAT", "rxff.bin"), "wb").write(restart)
+            run(mpi + ["--ntime_step", "7", "--pstep", "1", "--fstep", "100000", "--sstep", "3", "--isBinary"] + tight + flags, tmp)
+            d = dict(flags=np.array(" ".join(flags)), restart_rxff=np.frombuffer(restart, np.uint8), vprocs=np.array((2, 1, 1)),
+                     final_rxff=np.frombuffer(open(os.path.join(tmp, "DAT", "rxff.bin"), "rb").read(), np.uint8))
+            for r in range(2):
+                gid, typ, pos, frc, chg = parse_rfdump(os.path.join(tmp, "rfdump%d.txt" % r))
+                d["gid_%d" % r] = gid; d["type_%d" % r] = typ; d["pos_%d" % r] = pos; d["force_%d" % r] = frc; d["charge_%d" % r] = chg
+            out = name.replace("rdx168_", "rdx222_v211_")
+            np.savez_compressed(os.path.join(HERE, out + ".npz"), **d)
+            print(out, "natoms/rank", [len(d["gid_%d" % r]) for r in range(2)])
+    finally:
+        shutil.rmtree(tmp)
+
+
 def make_minimiser():
     """mdmode 10: the reference's geometry minimiser (src/cg.F90: bracket, golden-section line minimisation, Polak-Ribiere) on
     RDX-168; it calls QEq + FORCE some sixty times and writes DAT/000000000.xyz when the energy has converged."""
@@ -367,5 +415,7 @@ if __name__ == "__main__":
         make_minimiser(); sys.exit(0)
     if sys.argv[1:] == ["thermo"]:
         make_thermo(); sys.exit(0)
+    if sys.argv[1:] == ["thermo_mpi"]:
+        make_thermo_mpi(); sys.exit(0)
     for n in (sys.argv[1:] or list(CASES)):
         make(n)

@@ -133,6 +133,72 @@ def test_multirank_world_vs_real_mpi_reference(case, steps):
         assert np.abs(o.pos(r) - g["pos_%d" % r]).max() < 1e-11
 
 
+def _multirank_oracle(case, **kw):
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    vp = tuple(int(x) for x in g["vprocs"]); mc = tuple(int(x) for x in g["mc"])
+    ff, names, frac, lat = oa.make_system(case)
+    lat2, ranks = oa.geninit(names, frac, lat, oa.ffield_names(ff), mc=mc, vprocs=vp)
+    return g, oa.Oracle(ff, lat2, ranks, vprocs=vp, **kw), len(ranks)
+
+
+def _compare_ranks(g, o, nranks, qtol=1e-10, ftol=1e-9):
+    for r in range(nranks):
+        assert (o.gids(r) == g["gid_%d" % r]).all()
+        assert np.abs(o.charges(r) - g["charge_%d" % r]).max() < qtol
+        assert np.abs(o.forces(r) - g["force_%d" % r]).max() < ftol
+        assert np.abs(o.pos(r) - g["pos_%d" % r]).max() < 1e-11
+
+
+@pytest.mark.parametrize("case,steps,efield", [("sicnp211_v211_pqeq_tight", 0, None), ("sicnp222_v222_pqeq_tight", 0, None), ("sicnp211_v211_pqeq_md3", 3, None),
+                                               ("sicnp211_v211_pqeq_efieldx_md3", 3, (1, 0.05))])
+def test_multirank_pqeq_vs_real_mpi_reference(case, steps, efield):
+    """PQEq BETWEEN RANKS (round 6): the SiC nanoparticle replicated to one particle per rank, `mpiexec -np 2 / 8 rxmd_mpi --pqeq` --
+    shell displacements ride in the COPY and MOVE records (comm.F90:122,129-131,153,165-167), the shell halo and the CG vectors cross the
+    rank boundary and are forwarded x -> y -> z through edge and corner ranks on 2 x 2 x 2.  The faithful oracle mode reproduces the
+    reference's per-rank order, charges and forces, iteration counts included; with the field the per-step LinearMomentum sums
+    (main.F90:70-71,766-797) are all-reduced.  Step 0 has every shell on its core (no beyond-cut-off look-up): there the clean mode --
+    what the HIP engine computes -- must give the same numbers bit for bit."""
+    g, o, nr = _multirank_oracle(case, pqeq=oa.PQEQ_SICNP, QEq_tol=1e-12, NMAXQEq=2000)
+    if efield:
+        o.set_efield(*efield)
+    iters = [o.qeq()]; o.force()
+    for _ in range(steps):
+        o.step(1); iters.append(o.L.rxo_qeq_iters(o.w))
+    assert iters == [int(x) for x in g["qeq_iters"]]
+    _compare_ranks(g, o, nr)
+    if steps == 0:
+        assert o.pqeq_stale() == 0
+        g2, o2, _ = _multirank_oracle(case, pqeq=oa.PQEQ_SICNP, QEq_tol=1e-12, NMAXQEq=2000)
+        o2.set_pqeq_clean(1); o2.qeq(); o2.force()
+        for r in range(nr):
+            assert np.array_equal(o2.charges(r), o.charges(r)) and np.array_equal(o2.forces(r), o.forces(r))
+
+
+def test_multirank_extended_lagrangian_vs_real_mpi_reference():
+    """isQEq 2 on two ranks, 10 steps: one CG step per MD step, the fictitious charges qsfp / qsfv integrated by the driver and carried
+    by MODE_MOVE with their atom (comm.F90:159-163)"""
+    g, o, nr = _multirank_oracle("rdx222_v211_lex_md10", isQEq=2)
+    o.qeq(); o.force(); o.step(10)
+    _compare_ranks(g, o, nr)
+
+
+@pytest.mark.parametrize("mode,kw", [(4, dict(vsfact=0.9)), (5, dict(treq=300.0)), (7, dict(treq=300.0)), (8, dict(treq=300.0))])
+def test_multirank_velocity_scaling_modes_vs_real_mpi_reference(mode, kw):
+    """mdmode 4/5/7/8 on two ranks from the reference's own two-rank restart file: per-element counts and kinetic energies, the total
+    kinetic energy and the momentum removal are MPI_ALLREDUCEd (main.F90:699,738,783)"""
+    g = np.load(os.path.join(GOLD, "rdx222_v211_thermo%d.npz" % mode))
+    ff = oa.make_system("rdx222")[0]
+    o, recs, lat = oa.oracle_from_rxff(ff, g["restart_rxff"], QEq_tol=1e-12, NMAXQEq=2000)
+    assert len(recs) == 2
+    o.qeq(); o.force()
+    n = sum(len(r) for r in recs)
+    for nstep in range(7):
+        if nstep % 3 == 0:
+            o.thermostat(mode, gke=o.kinetic() / n, **kw)
+        o.step(1)
+    _compare_ranks(g, o, 2, qtol=1e-10, ftol=1e-8)
+
+
 @pytest.mark.parametrize("case,steps", [("sicnp547_pqeq_tol7", 0), ("sicnp547_pqeq_tight", 0), ("sicnp547_pqeq_md5", 5)])
 def test_pqeq_sicnp_against_reference(case, steps):
     """PQEq path (pqeq.F90, ENbond_PQEq, shell update) of the oracle against the reference run with --pqeq on conf/init.sicnp"""
