@@ -149,3 +149,56 @@ def engine_rank_perturbed(rank, world, port, vp, steps, qeq_mode, out):
         dist.barrier(); dist.destroy_process_group()
     except Exception:
         out[rank] = dict(error=traceback.format_exc())
+
+
+def mode_velocities(gid, seed, sigma, ntotal):
+    """seeded velocities that depend only on the GLOBAL atom id (the same atom gets the same draw on every decomposition)"""
+    v = np.random.default_rng(seed).normal(0.0, sigma, (ntotal + 1, 3))
+    return v[gid]
+
+
+def engine_rank_mode(rank, world, port, spec, out):
+    """one rank of a vprocs run in any MODE of the driver (round 6: PQEq, isQEq 2, the velocity-scaling modes, the electric field) -- all
+    ranks share GPU 0, messages host-staged over gloo.  spec: dict(case, mc, vp, steps, pqeq, isQEq, efield, qeq_mode, thermo=(mode, kw, every),
+    restart=<golden with restart_rxff>, v=(seed, sigma, natoms of the whole system), kw=engine keywords)"""
+    try:
+        dist = _init(rank, world, port)
+        import torch
+        import oracle_api as oa
+        import rxmd_amd
+        from rxmd_amd import system
+        from rxmd_amd.comm import TorchTransport
+        vp = tuple(spec["vp"])
+        kw = dict(spec["kw"]) if "kw" in spec else dict(QEq_tol=1e-12, NMAXQEq=2000)
+        if spec.get("restart"):
+            g = np.load(os.path.join(oa.GOLD, spec["restart"] + ".npz"))
+            ff = oa.make_system(spec["case"])[0]
+            lat_s, vp_file, _, recs = oa.parse_rxff(g["restart_rxff"])
+            assert tuple(vp_file) == vp
+            rec = recs[rank]
+        else:
+            ff, names, frac, lat = oa.make_system(spec["case"])
+            lat_s, rec = system.geninit(ff, names, frac, lat, mc=tuple(spec["mc"]), vprocs=vp, myid=rank)
+            if spec.get("v"):
+                ty = np.rint(rec[:, 7]).astype(np.int64); gid = np.rint((rec[:, 7] - ty) * 1e13).astype(np.int64)
+                rec[:, 3:6] = mode_velocities(gid, *spec["v"])
+        e = rxmd_amd.RxmdEngine(ff, lat_s, vprocs=vp, myid=rank, device=0, qeq_mode=spec.get("qeq_mode", 1), isQEq=spec.get("isQEq", 1),
+                                pqeq=oa.PQEQ_SICNP if spec.get("pqeq") else None, efield=spec.get("efield"), **kw)
+        tr = TorchTransport(mode="staged", device=torch.device("cuda", 0), capacity_doubles=1 << 21)
+        tr.attach(e)
+        e.set_atoms_rxff(rec)
+        e.QEq(); pe = e.FORCE()
+        a0 = e.atoms(); sh0 = e.shells() if spec.get("pqeq") else None          # the state after the pre-loop QEq + FORCE (main.F90:27-32)
+        th = spec.get("thermo")
+        for n in range(spec.get("steps", 0)):
+            if th and n % th[2] == 0:
+                e.thermostat(th[0], **th[1])
+            e.step(1)
+        a = e.atoms(); st = e.stats()
+        out[rank] = dict(gid0=a0["gid"], q0=a0["q"], f0=a0["f"], pos0=a0["pos"], shells0=sh0,
+                         gid=a["gid"], q=a["q"], f=a["f"], pos=a["pos"], v=a["v"], pe=pe, shells=e.shells() if spec.get("pqeq") else None,
+                         iters=st["qeq_iters_last"], nghost=st["nghost_force"], nex=tr.n_exchange, nar=tr.n_allreduce, err=repr(tr.error))
+        e.close()
+        dist.barrier(); dist.destroy_process_group()
+    except Exception:
+        out[rank] = dict(error=traceback.format_exc())
