@@ -237,6 +237,104 @@ def vprocs_for(n):
     return tuple(sorted(vp, reverse=True))
 
 
+# ---- what the first run between real peers is to be held against ----------------------------------------------------------------
+# The multi-rank code path has only ever run on ONE GPU (a rank pushed through the staged exchange with RCCL send/recv to itself:
+# profiles/r06_selfloop_*.json, RXMD_FORCE_STAGED=1 RXMD_FORCE_REMOTE=1).  That measurement holds every cost of N ranks except the wire: the
+# packing and unpacking kernels, the RCCL launches, the host's size messages, the split matrix pass.  The prediction adds the wire:
+#   bytes that cross a face of a split axis / the rate of ONE xGMI link (each stage talks to one face neighbour over its own link; the two stages of
+#   an axis with two ranks go to the same peer), for the exchanges nothing hides (ghost build 48 B, charge halo 8 B, force fold 24 B per ghost);
+#   the (hs,ht) halo of every CG iteration (16 B per ghost) runs under the interior window groups of the matrix pass and counts only beyond them;
+#   two small all-reduces per CG iteration at the latency of N peers instead of one.
+PREDICT = {
+    "source": "profiles/r06_selfloop_staged_overlap.json (single MI355X through the multi-rank code path) + assumed wire figures",
+    "selfloop_fixed_ms": 15.4,           # per step: exchange + lists + FORCE + kicks of the self-loop run (its ms per step minus its CG iterations)
+    "selfloop_ms_per_cg_iteration": 1.035,   # matrix pass (interior + boundary launch) + vector kernels + halo to itself + two all-reduces to itself
+    "allreduce_self_us": 5.5,            # an 8-double ncclAllReduce with one rank: its launch
+    "allreduce_us": {1: 5.5, 2: 10.0, 4: 15.0, 8: 20.0},   # ASSUMED small-message latency of RCCL over xGMI (no two-GPU lease inside a round to measure it)
+    "xgmi_link_GBs_per_direction": 60.0,  # ASSUMED achieved rate for MB-sized messages (7 links x ~153 GB/s bidirectional per GPU = 76.8 GB/s per direction and link at peak)
+    "interior_fraction_of_pass": 0.75,   # window groups without a ghost partner at 979,776 atoms per rank
+}
+
+
+def predict_ms_per_step(vp, K, nghost, pass_ms):
+    """predicted wall time of one MD step on the rank grid vp at K CG iterations per step (weak scaling, the per-rank size of the self-loop run)"""
+    nsplit = sum(1 for v in vp if v > 1)
+    world = vp[0] * vp[1] * vp[2]
+    link = PREDICT["xgmi_link_GBs_per_direction"] * 1e9
+    per_axis_ghosts = nghost / 3.0
+    wire_fixed_ms = nsplit * per_axis_ghosts * 80.0 / link * 1e3
+    halo_ms = nsplit * (per_axis_ghosts * 16.0 / link * 1e3 + 0.03)            # per CG iteration: the stages of the split axes one after the other, ~30 us of pack / launch / unpack each
+    halo_exposed_ms = max(0.0, halo_ms - PREDICT["interior_fraction_of_pass"] * pass_ms)
+    ar = PREDICT["allreduce_us"].get(world, 20.0 + 2.0 * max(world - 8, 0) ** 0.5)
+    allreduce_ms = 2.0 * K * (ar - PREDICT["allreduce_self_us"]) * 1e-3
+    total = PREDICT["selfloop_fixed_ms"] + K * PREDICT["selfloop_ms_per_cg_iteration"] + wire_fixed_ms + K * halo_exposed_ms + allreduce_ms
+    return {"ms_per_step": round(total, 2), "at_cg_iterations_per_step": round(K, 2), "self_loop_part_ms": round(PREDICT["selfloop_fixed_ms"] + K * PREDICT["selfloop_ms_per_cg_iteration"], 2),
+            "wire_ms": round(wire_fixed_ms, 3), "vector_halo_ms_per_iteration": round(halo_ms, 3), "vector_halo_exposed_ms_per_iteration": round(halo_exposed_ms, 3),
+            "allreduce_extra_ms": round(allreduce_ms, 3), "assumptions": PREDICT["source"] + "; link %g GB/s per direction, all-reduce %g us" % (PREDICT["xgmi_link_GBs_per_direction"], ar)}
+
+
+def leg_summary(name, rec):
+    """ms per step, CG iterations per step and the matrix pass's roofline fraction of one leg, as short as it gets"""
+    if not rec:
+        return None
+    if "error" in rec:
+        return {"leg": name, "error": str(rec["error"])[:120]}
+    r = rec.get("roofline") or {}
+    out = {"leg": name, "ms_per_step": round(rec["ms_per_step"], 3), "K": round(rec.get("qeq_iters_per_step", 0.0), 2)}
+    if r.get("avg_launch_ms"):
+        out["pass_ms"] = round(r["avg_launch_ms"], 4); out["frac"] = round(r["frac"], 4)
+    elif rec.get("avg_pass_ms"):
+        out["pass_ms"] = round(rec["avg_pass_ms"], 4)
+    if "ms_qeq_per_iter" in rec:
+        out["ms_qeq_per_iter"] = round(rec["ms_qeq_per_iter"], 4)
+    return out
+
+
+def compact_line(full, limit=7600):
+    """the line for stdout: every key of the driver's contract, `roofline` and `cpu_baseline` without their tables, the per-rank record of an N > 1
+    run, and -- LAST, so that a recorded tail holds it -- `legs`: one short record per leg (steady, isQEq 2, the other algebra, water, SiC-NP + PQEq ...)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "ns_per_day", "atom_steps_per_s", "qeq_iters_per_step", "ms_qeq_per_iter", "n10", "nb", "bond_overlap", "energy_per_atom", "bench_wall_s", "full_record")
+    out = {k: full[k] for k in keep if k in full}
+    r = dict(full["roofline"])
+    rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_real_traffic", "frac_streamed", "algorithmic_bytes_per_launch", "bytes_per_entry",
+          "bytes_per_entry_streamed", "avg_launch_ms", "launches", "launches_that_returned_at_once", "measured_read_stream_GBs", "frac_of_measured_read_stream",
+          "spmv_launches_per_step", "step_frac_of_hbm_roofline")
+    out["roofline"] = {k: r[k] for k in rk if k in r}
+    if r.get("traffic_source"):
+        out["roofline"]["traffic_source"] = {k: r["traffic_source"].get(k) for k in ("file", "measured_at_commit", "kernel_signature")}
+    ps = r.get("placement_search") or {}
+    out["roofline"]["placement_search"] = {k: ps.get(k) for k in ("pass_ms_first_placement", "pass_ms_kept_placement", "draws", "total_ms", "in_timed_region")}
+    out["roofline"]["kernels_ms"] = {k["name"].split("+")[0].split(" ")[0]: [round(k["ms"], 4), k.get("bound"), None if k.get("frac_of_bound") is None else round(k["frac_of_bound"], 3)] for k in r.get("kernels", [])}
+    out["breakdown_ms_per_step"] = {k: round(v, 4) for k, v in full.get("breakdown_ms_per_step", {}).items()}
+    if "per_rank" in full:
+        out["per_rank"] = full["per_rank"]
+    if "predicted" in full:
+        out["predicted"] = full["predicted"]
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "atom_steps_per_s", "measured_by") if k in cb}
+    legs = [leg_summary("headline", dict(full, roofline=r))]
+    for name, key in (("steady (100 steps after 10)", "steady"), ("isQEq 2", "alt_lex"), ("reference algebra (qeq_mode %d)" % (1 - full["config"].get("qeq_mode", 1)), "alt"),
+                      ("no placement search", "alt_no_placement_search"), ("one stream", "alt_one_stream")):
+        if full.get(key):
+            legs.append(leg_summary(name, full[key]))
+    for rec in full.get("other_configs") or []:
+        legs.append(leg_summary(str(rec.get("workload", "?")).split(" = ")[0].split(",")[0][:48], rec))
+    out["legs"] = [l for l in legs if l]
+    line = json.dumps(out)
+    for drop in ("energy_per_atom", "breakdown_ms_per_step", "per_rank"):        # never over the limit: the least important records go first
+        if len(line) <= limit:
+            break
+        if drop == "per_rank" and "per_rank" in out:
+            out["per_rank"] = {k: v for k, v in out["per_rank"].items() if k in ("natoms", "nghost", "qeq_iters_total", "ms_halo_exposed_per_step", "pass_ms_in_the_loop")}
+        else:
+            out.pop(drop, None)
+        legs_ = out.pop("legs"); out["legs"] = legs_                              # keep `legs` last
+        line = json.dumps(out)
+    return line
+
+
 def main():
     t_bench0 = time.time()
     ap = argparse.ArgumentParser()
@@ -254,6 +352,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of BASELINE configs[2] (water) and configs[4] (SiC nanoparticle, PQEq) and the isQEq 2 leg")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state leg (SURVEY 8d: 100 timed steps after 10 warm-up steps from the same cold start)")
     ap.add_argument("--cpu-baseline-sample", default="full", choices=["full", "small"], help="small: only the unmodified reference on RDX 3x3x3 (seconds; the tests of the hand-off)")
+    ap.add_argument("--full-line", default=os.environ.get("RXMD_BENCH_FULL_LINE"), metavar="FILE",
+                    help="write the FULL record (per-kernel roofline table, every leg with its breakdown) to FILE; the line on stdout is its compact form, "
+                         "kept under 8 KB so that a driver that records the tail of stdout sees all of it (default: the full record goes to stderr)")
     a = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher (the reference is started as `mpirun -np N rxmd`, examples/2-reaxff-dc/Makefile): this
@@ -380,6 +481,7 @@ def main():
     eng.QEq(); eng.FORCE()                       # main.F90:27-32
     eng.step(a.warmup)
     eng.reset_timers()
+    place_draws_before = eng.stats().get("place_draws", 0)      # the placement search runs inside the first QEq call that used the window pass: before this line
     import ctypes
     ctypes.CDLL(None).fflush(None)              # every rank: push out what RCCL / the runtime wrote to C stdout during set-up
 
@@ -584,6 +686,8 @@ def main():
             tr_k = traffic_for(*name.split("+"))
             vf_k = valu_floor_ms(*name.split("+"))
             bnd, fb, fr_all = bound_of(ms, tr_k, l2_bytes_for(*name.split("+")), vf_k, atomics_for(*name.split("+")))
+            if st.get("bond_overlap") and not (alone and key in alone):      # the kernel shared the GPU with another chain and no one-stream leg ran: its time says nothing about a ceiling
+                bnd, fb, fr_all = None, None, {}
             kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": tr_k,
                             "frac_real_traffic": (tr_k / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr_k and ms > 0) else None, "valu_floor_ms": vf_k,
                             "bound": bnd, "frac_of_bound": fb, "frac_of_each_ceiling": fr_all, "note": note,
@@ -624,7 +728,7 @@ def main():
                          "window_groups": pinfo["window_groups"], "largest_window_slots": pinfo["largest_window_slots"],
                          "placement_search": {"pass_ms_first_placement": st.get("place_ms_first", 0.0), "pass_ms_kept_placement": st.get("place_ms_kept", 0.0),
                                               "draws": st.get("place_draws", 0), "total_ms": st.get("place_total_ms", 0.0), "bytes_held": st.get("place_bytes_held", 0.0),
-                                              "in_timed_region": False,
+                                              "in_timed_region": bool(st.get("place_draws", 0) > place_draws_before),      # measured: draws counted after the timers were reset
                                               "note": "where the pass's streams lie in physical memory is worth up to 15 % of its time; the engine times a few placements once and keeps the fastest (RXMD_PLACE_TRIES)"},
                          "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"], "launches_that_returned_at_once": st.get("spmv_noop_launches", 0),
                          "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,
@@ -640,6 +744,10 @@ def main():
         if per_rank:
             out["per_rank"] = per_rank
             out["config"]["ranks_in_communicator"] = world      # rccl_init checks ncclCommCount against the vprocs grid
+            if not a.replicas and a.workload == "rdx" and a.cells == ATOMS_PER_GPU_CELLS:
+                # what this run is to be held against: the self-loop measurement of the same code path + the wire
+                out["predicted"] = predict_ms_per_step(vp, iters, max(per_rank["nghost"]), max(per_rank["pass_ms_in_the_loop"]))
+                out["predicted"]["measured_over_predicted"] = round(1e3 * dt / a.steps / out["predicted"]["ms_per_step"], 3)
         if alt:
             out["alt"] = alt
         if alt_lex:
@@ -658,7 +766,20 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)          # C-level stdout first (RCCL prints a version banner there): the JSON line stays last
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        # the full record (per-kernel roofline table, every leg with its breakdown: ~25 KB) goes to a file or to stderr; stdout gets its compact form
+        # with a `legs` summary as the LAST key, under 8 KB (a driver that keeps the tail of stdout had lost alt / alt_lex / energy_per_atom of the long line)
+        if a.full_line:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(a.full_line)), exist_ok=True)
+                with open(a.full_line, "w") as fh:
+                    fh.write(json.dumps(out) + "\n")
+                out["full_record"] = a.full_line
+            except Exception as ex:
+                sys.stderr.write("bench.py: could not write %s (%s)\n" % (a.full_line, ex))
+        if "full_record" not in out:
+            sys.stderr.write("bench.py full record: " + json.dumps(out) + "\n"); sys.stderr.flush()
+            out["full_record"] = "stderr of this run (line starting with `bench.py full record:`); --full-line FILE writes it to a file"
+        print(compact_line(out), flush=True)
     if eng is not None:
         eng.close()
     if use_dist:

@@ -148,6 +148,9 @@ __global__ void k_add_force3(int n, const double *__restrict__ ax, const double 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { fx[i] += ax[i]; fy[i] += ay[i]; fz[i] += az[i]; }
 }
+// INVARIANT of the two chains: from here to the join the bonded chain (this function, on bond_stream) may READ positions, types, bond tables and the
+// x, y, z of the cell-sorted packed copy, and WRITES frc, fsort, the bond accumulators and pe; the main stream meanwhile writes q of the ghosts, the
+// w component of sorted_xyzi (k_sorted_charge) and fnb.  No kernel of the bonded chain may decode sorted_xyzi[].w or read q.
 void Engine::bonded_chain_begin() {
   RX_HIP(hipMemsetAsync(scal + 32, 0, sizeof(double) * 16, stream));     // the energy accumulators: both chains add to them
   RX_HIP(hipEventRecord(ev_fork, stream));
@@ -247,24 +250,42 @@ __global__ void k_kick(int N, DevFF ff, double dt, double lex_w2, const int *__r
 
 // ------------------------------------------------------------------------------------------------
 // velocity scaling of the MD loop head (main.F90:45-61; ScaleTemperature :722-763, AdjustTemperature :684-719,
-// LinearMomentum :766-797).  Rare (every sstep steps): per type one masked reduction (count, kinetic energy, momentum, mass)
-// in a fixed order, factors on the host, one scaling kernel.
-__global__ void __launch_bounds__(256) k_type_sums(int n, int tsel, const int *__restrict__ type, DevFF ff, const double *__restrict__ vx, const double *__restrict__ vy,
+// LinearMomentum :766-797) and the momentum removal of every step under an electric field (main.F90:70-71).  Everything stays on the
+// device and in stream order (round 6; until then: per type two kernels + a copy + a host wait, then the factors on the host -- seven host
+// waits per e-field step of the SiC force field, which broke the run-ahead of the whole step):
+//   k_type_sums        ONE launch forms the 6 sums (count, kinetic energy, momentum x3, mass) of every atom type: per type a grid-stride
+//                      pass with a fixed per-thread order, a tree sum per workgroup, partials[(t * 6 + c) * nblocks + block]
+//   k_type_sums_final  a thread per (type, component) adds the workgroup partials in block order -> tsum[t * 6 + c]
+//   (vprocs > 1: one all-reduce of the 6 (nso + 1) sums -- MPI_ALLREDUCE of main.F90:699,738,783 -- RCCL in stream order)
+//   k_scale_coeffs     one thread: the per-type factors and the centre-of-mass velocity of the mode -> ScaleArgs in device memory
+//   k_scale_velocities v = c(type) v - vcm
+constexpr int TSUM_BLOCKS = 240;
+__global__ void __launch_bounds__(256) k_type_sums(int n, int nso, const int *__restrict__ type, DevFF ff, const double *__restrict__ vx, const double *__restrict__ vy,
                                                     const double *__restrict__ vz, double *__restrict__ partials) {
   __shared__ double sm[256];
-  double a[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (type[i] != tsel) continue;
-    const double m = ff.atom[tsel].mass, v0 = vx[i], v1 = vy[i], v2 = vz[i];
-    a[0] += 1.0; a[1] += 0.5 * m * (v0 * v0 + v1 * v1 + v2 * v2); a[2] += m * v0; a[3] += m * v1; a[4] += m * v2; a[5] += m;
+  for (int tsel = 1; tsel <= nso; ++tsel) {
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    const double m = ff.atom[tsel].mass;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      if (type[i] != tsel) continue;
+      const double v0 = vx[i], v1 = vy[i], v2 = vz[i];
+      a[0] += 1.0; a[1] += 0.5 * m * (v0 * v0 + v1 * v1 + v2 * v2); a[2] += m * v0; a[3] += m * v1; a[4] += m * v2; a[5] += m;
+    }
+    for (int c = 0; c < 6; ++c) {
+      sm[threadIdx.x] = a[c];
+      __syncthreads();
+      for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+      if (threadIdx.x == 0) partials[(tsel * 6 + c) * gridDim.x + blockIdx.x] = sm[0];
+      __syncthreads();
+    }
   }
-  for (int c = 0; c < 6; ++c) {
-    sm[threadIdx.x] = a[c];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) partials[blockIdx.x * 6 + c] = sm[0];
-    __syncthreads();
-  }
+}
+__global__ void k_type_sums_final(int nblocks, int nso, const double *__restrict__ partials, double *__restrict__ tsum) {
+  const int e = threadIdx.x;                       // t * 6 + c
+  if (e >= 6 * (nso + 1)) return;
+  double s = 0.0;
+  if (e >= 6) for (int b = 0; b < nblocks; ++b) s += partials[e * nblocks + b];
+  tsum[e] = s;
 }
 __global__ void k_sum6(int nblocks, const double *__restrict__ partials, double *__restrict__ out6) {
   const int c = threadIdx.x;
@@ -315,11 +336,56 @@ __global__ void k_random_velocities(int n, unsigned long long seed, unsigned lon
   vx[i] = v[0]; vy[i] = v[1]; vz[i] = v[2];
 }
 struct ScaleArgs { double c[16]; double vcm[3]; };
-__global__ void k_scale_velocities(int n, ScaleArgs a, const int *__restrict__ type, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz) {
+// the factors of one velocity-scaling action from the (all-reduced) per-type sums; mdmode -1: LinearMomentum alone (c = 1)
+__global__ void k_scale_coeffs(int mdmode, int nso, double treq, double vsfact, double gke, const double *__restrict__ sums, ScaleArgs *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double UTEMP0 = 503.398008, UTEMP = UTEMP0 * 2.0 / 3.0;      // module.F90:198-199
+  ScaleArgs sa;
+  for (int t = 0; t < 16; ++t) sa.c[t] = 1.0;
+  sa.vcm[0] = sa.vcm[1] = sa.vcm[2] = 0.0;
+  double ntot = 0, ektot = 0, mtot = 0;
+  for (int t = 1; t <= nso; ++t) { ntot += sums[6 * t]; ektot += sums[6 * t + 1]; mtot += sums[6 * t + 5]; }
+  bool remove_momentum = mdmode == -1;
+  if (mdmode == 4) { for (int t = 0; t < 16; ++t) sa.c[t] = vsfact; }
+  else if (mdmode == 5) {
+    const double g = gke > 0.0 ? gke : ektot / ntot;                 // GKE of the last PRINTE, main.F90:49,250
+    const double c = sqrt((treq * UTEMP0) / (g * UTEMP));
+    for (int t = 0; t < 16; ++t) sa.c[t] = c;
+  } else if (mdmode == 8) {
+    const double c = sqrt((treq * UTEMP0) / (ektot / ntot * UTEMP));
+    if (fabs(c - 1.0) > 0.05) {                                      // within 5 %: the velocities are left alone (main.F90:704-705): c = 1, vcm = 0
+      for (int t = 0; t < 16; ++t) sa.c[t] = c;
+      remove_momentum = true;
+    }
+  } else if (mdmode == 7) {
+    for (int t = 1; t <= nso; ++t) {
+      const double n = sums[6 * t];
+      sa.c[t] = n > 1.0 ? sqrt((treq * UTEMP0) / (sums[6 * t + 1] / n * UTEMP)) : 0.0;   // main.F90:742-751
+    }
+    remove_momentum = true;
+  } else if (mdmode == 0 || mdmode == 6) {
+    // centre-of-mass velocity off (MPI_ALLREDUCE of sum m v and sum m, init.F90:333-341), then every velocity scaled so that the kinetic energy
+    // per atom is 1.5 treq (init.F90:343-358).  KE of the shifted velocities from the sums at hand: sum m/2 |v - c|^2 = KE - |P|^2 / (2 M).
+    double P2 = 0.0, Pa[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) { for (int t = 1; t <= nso; ++t) Pa[a] += sums[6 * t + 2 + a]; P2 += Pa[a] * Pa[a]; }
+    const double gke_new = (ektot - 0.5 * P2 / mtot) / ntot;
+    const double vfactor = sqrt(1.5 * treq / gke_new);
+    for (int t = 0; t < 16; ++t) sa.c[t] = vfactor;
+    for (int a = 0; a < 3; ++a) sa.vcm[a] = vfactor * Pa[a] / mtot;
+  }
+  if (remove_momentum)                                               // LinearMomentum of the scaled velocities (main.F90:766-797)
+    for (int a = 0; a < 3; ++a) {
+      double p = 0.0;
+      for (int t = 1; t <= nso; ++t) p += sa.c[t] * sums[6 * t + 2 + a];
+      sa.vcm[a] = p / mtot;
+    }
+  *out = sa;
+}
+__global__ void k_scale_velocities(int n, const ScaleArgs *__restrict__ ap, const int *__restrict__ type, double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double c = a.c[type[i]];
-  vx[i] = c * vx[i] - a.vcm[0]; vy[i] = c * vy[i] - a.vcm[1]; vz[i] = c * vz[i] - a.vcm[2];
+  const double c = ap->c[type[i]];
+  vx[i] = c * vx[i] - ap->vcm[0]; vy[i] = c * vy[i] - ap->vcm[1]; vz[i] = c * vz[i] - ap->vcm[2];
 }
 
 void Engine::kinetic_and_charge(double &ke, double &qsum) {
@@ -331,66 +397,37 @@ void Engine::kinetic_and_charge(double &ke, double &qsum) {
   ke = h_scal[56]; qsum = h_scal[57];
 }
 
+// the per-type sums of the residents' velocities, summed over all ranks, in tsum (device memory) -- no host wait with the native transport
+void Engine::type_sums_device() {
+  k_type_sums<<<TSUM_BLOCKS, 256, 0, stream>>>(N, ff.nso, type, dff, vel[0], vel[1], vel[2], partials);
+  k_type_sums_final<<<1, 128, 0, stream>>>(TSUM_BLOCKS, ff.nso, partials, tsum);
+  if (nprocs > 1) {                                                  // MPI_ALLREDUCE, main.F90:699,738,783
+    const int n = 6 * (ff.nso + 1);
+    const bool kt = kt_begin(&st.ms_allreduce, nullptr, &st.allreduce_calls);
+    struct End { Engine *e; bool kt; ~End() { e->kt_end(kt); } } end_{this, kt};
+    if (nccl) { rccl_allreduce_dev(tsum, n); return; }               // in stream order
+    if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm or rxmd_hip_comm_init_rccl first");
+    RX_HIP(hipMemcpyAsync(h_scal + 192, tsum, sizeof(double) * n, hipMemcpyDeviceToHost, stream));      // a host transport (MPI callbacks): its all-reduce IS a host call
+    sync_stream();
+    if (comm.allreduce_sum(comm.ctx, h_scal + 192, n)) throw EngineError(RXMD_E_COMM, "allreduce callback failed");
+    RX_HIP(hipMemcpyAsync(tsum, h_scal + 192, sizeof(double) * n, hipMemcpyHostToDevice, stream));
+  }
+}
+
 void Engine::thermostat(int mdmode, double treq_K, double vsfact, double gke) {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   if (ff.nso > 15) throw EngineError(RXMD_E_ARG, "more than 15 atom types");
-  const double UTEMP0 = 503.398008, UTEMP = UTEMP0 * 2.0 / 3.0;      // module.F90:198-199
+  if (!(mdmode == 0 || (mdmode >= 4 && mdmode <= 8))) throw EngineError(RXMD_E_ARG, "thermostat: mdmode must be 0, 4, 5, 6, 7 or 8");
+  const double UTEMP0 = 503.398008;                                  // module.F90:198
   const double treq = treq_K / UTEMP0;                               // init.F90:72
-  ScaleArgs sa{};
-  std::vector<double> sums(6 * (ff.nso + 1), 0.0);
   if (mdmode == 0 || mdmode == 6) {                                  // main.F90:54-55 -> INITVELOCITY: fresh Gaussian velocities before the sums
     static const unsigned long long seed = std::getenv("RXMD_SEED") ? std::strtoull(std::getenv("RXMD_SEED"), nullptr, 10) : 0x5DEECE66DULL;
     k_random_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, seed, velocity_draws++, gid, vel[0], vel[1], vel[2]);
   }
   const bool need_sums = (mdmode == 0 || mdmode == 6 || mdmode == 7 || mdmode == 8 || (mdmode == 5 && gke <= 0.0));
-  if (need_sums) {
-    const int nb = 240;
-    for (int t = 1; t <= ff.nso; ++t) {
-      k_type_sums<<<nb, 256, 0, stream>>>(N, t, type, dff, vel[0], vel[1], vel[2], partials);
-      k_sum6<<<1, 64, 0, stream>>>(nb, partials, scal + 56);
-      RX_HIP(hipMemcpyAsync(sums.data() + 6 * t, scal + 56, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
-      sync_stream();
-    }
-    if (nprocs > 1) allreduce_host(sums.data(), static_cast<int>(sums.size()));      // MPI_ALLREDUCE, main.F90:699,738,783
-  }
-  double ntot = 0, ektot = 0, mtot = 0;
-  for (int t = 1; t <= ff.nso; ++t) { ntot += sums[6 * t]; ektot += sums[6 * t + 1]; mtot += sums[6 * t + 5]; }
-  bool remove_momentum = false;
-  if (mdmode == 4) { for (int t = 0; t < 16; ++t) sa.c[t] = vsfact; }
-  else if (mdmode == 5) {
-    const double g = gke > 0.0 ? gke : ektot / ntot;                 // GKE of the last PRINTE, main.F90:49,250
-    const double c = std::sqrt((treq * UTEMP0) / (g * UTEMP));
-    for (int t = 0; t < 16; ++t) sa.c[t] = c;
-  } else if (mdmode == 8) {
-    const double c = std::sqrt((treq * UTEMP0) / (ektot / ntot * UTEMP));
-    if (!(std::fabs(c - 1.0) > 0.05)) return;                        // within 5 %: leave the velocities alone (main.F90:704-705)
-    for (int t = 0; t < 16; ++t) sa.c[t] = c;
-    remove_momentum = true;
-  } else if (mdmode == 7) {
-    for (int t = 1; t <= ff.nso; ++t) {
-      const double n = sums[6 * t];
-      sa.c[t] = n > 1.0 ? std::sqrt((treq * UTEMP0) / (sums[6 * t + 1] / n * UTEMP)) : 0.0;   // main.F90:742-751
-    }
-    remove_momentum = true;
-  } else if (mdmode == 0 || mdmode == 6) {
-    // centre-of-mass velocity off (MPI_ALLREDUCE of sum m v and sum m, init.F90:333-341), then every velocity scaled so that the kinetic energy
-    // per atom is 1.5 treq (init.F90:343-358).  KE of the shifted velocities from the sums at hand: sum m/2 |v - c|^2 = KE - |P|^2 / (2 M).
-    double P2 = 0.0, Pa[3] = {0, 0, 0};
-    for (int a = 0; a < 3; ++a) { for (int t = 1; t <= ff.nso; ++t) Pa[a] += sums[6 * t + 2 + a]; P2 += Pa[a] * Pa[a]; }
-    const double gke_new = (ektot - 0.5 * P2 / mtot) / ntot;
-    const double vfactor = std::sqrt(1.5 * treq / gke_new);
-    for (int t = 0; t < 16; ++t) sa.c[t] = vfactor;
-    for (int a = 0; a < 3; ++a) sa.vcm[a] = vfactor * Pa[a] / mtot;
-  } else {
-    throw EngineError(RXMD_E_ARG, "thermostat: mdmode must be 0, 4, 5, 6, 7 or 8");
-  }
-  if (remove_momentum)                                               // LinearMomentum of the scaled velocities
-    for (int a = 0; a < 3; ++a) {
-      double p = 0.0;
-      for (int t = 1; t <= ff.nso; ++t) p += sa.c[t] * sums[6 * t + 2 + a];
-      sa.vcm[a] = p / mtot;
-    }
-  k_scale_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, sa, type, vel[0], vel[1], vel[2]);
+  if (need_sums) type_sums_device();
+  k_scale_coeffs<<<1, 64, 0, stream>>>(mdmode, ff.nso, treq, vsfact, gke, tsum, sargs);
+  k_scale_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, sargs, type, vel[0], vel[1], vel[2]);
 }
 
 __global__ void k_drift(int N, double dt, const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ vz,
@@ -404,22 +441,10 @@ __global__ void k_lex_drift(int N, double dt, double *__restrict__ qsfp, const d
   if (i < N) qsfp[i] = qsfp[i] + dt * qsfv[i];
 }
 
-void Engine::remove_momentum() {
-  ScaleArgs sa{};
-  std::vector<double> sums(6 * (ff.nso + 1), 0.0);
-  const int nb = 240;
-  for (int t = 1; t <= ff.nso; ++t) {
-    k_type_sums<<<nb, 256, 0, stream>>>(N, t, type, dff, vel[0], vel[1], vel[2], partials);
-    k_sum6<<<1, 64, 0, stream>>>(nb, partials, scal + 56);
-    RX_HIP(hipMemcpyAsync(sums.data() + 6 * t, scal + 56, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
-    sync_stream();
-  }
-  if (nprocs > 1) allreduce_host(sums.data(), static_cast<int>(sums.size()));
-  double mtot = 0.0, p[3] = {0, 0, 0};
-  for (int t = 1; t <= ff.nso; ++t) { mtot += sums[6 * t + 5]; for (int a = 0; a < 3; ++a) p[a] += sums[6 * t + 2 + a]; }
-  for (int t = 0; t < 16; ++t) sa.c[t] = 1.0;
-  for (int a = 0; a < 3; ++a) sa.vcm[a] = p[a] / mtot;
-  k_scale_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, sa, type, vel[0], vel[1], vel[2]);
+void Engine::remove_momentum() {                  // LinearMomentum (main.F90:766-797) inside the step: sums, all-reduce and factors in stream order
+  type_sums_device();
+  k_scale_coeffs<<<1, 64, 0, stream>>>(-1, ff.nso, 0.0, 1.0, 0.0, tsum, sargs);
+  k_scale_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, sargs, type, vel[0], vel[1], vel[2]);
 }
 
 void Engine::step(int nsteps) {

@@ -837,9 +837,11 @@ __global__ void __launch_bounds__(256) k_ehb_sweep(int S10, DevFF ff, const int2
       wave_lds_sync();
       for (int q = lane; q < qn; q += 64) {
         EHB_CHECKC(5, static_cast<int>(s_cand[w][q] & NB10_IDX_MASK), lim_nb, i)
-        const int ks = static_cast<int>(s_cand[w][q] & NB10_IDX_MASK);       // list entries are cell-sorted positions (by now the w component of the packed copy holds the charge: the atom comes from perm)
-        const double4 p = pk[ks];
-        s_px[w][q] = p.x; s_py[w][q] = p.y; s_pz[w][q] = p.z; s_k[w][q] = perm[ks];
+        const int ks = static_cast<int>(s_cand[w][q] & NB10_IDX_MASK);       // list entries are cell-sorted positions; the atom comes from perm
+        // x, y, z ONLY: the w component of the packed copy is rewritten with the charge by k_sorted_charge on the MAIN stream while this kernel runs
+        // on the bonded chain's stream (assemble.hip: bonded_chain_begin) -- a 32-byte load of the element would be an unordered read of that word
+        const double2 pxy = *reinterpret_cast<const double2 *>(pk + ks);
+        s_px[w][q] = pxy.x; s_py[w][q] = pxy.y; s_pz[w][q] = reinterpret_cast<const double *>(pk + ks)[2]; s_k[w][q] = perm[ks];
       }
       wave_lds_sync();
       double akx[EHB_CAP / 64], aky[EHB_CAP / 64], akz[EHB_CAP / 64];       // acceptor force of this lane's candidate of each batch, summed over the hydrogen slots

@@ -144,6 +144,7 @@ constexpr int WIN_UNIT = 8;         // cell-sorted positions per window unit (8 
 constexpr int WIN_MAXUNITS = 448;   // units a group's descriptor holds: 3,584 slots = 56 KB of LDS (two workgroups per CU)
 constexpr int WIN_BMW = 2048;       // 64-bit words of the coverage map the build kernel keeps in LDS: a group's positions may span 2048 x 64 x 8 = 1 M
 
+struct ScaleArgs;
 struct Engine {
   rxmd_config cfg{};
   std::string ffield_path, pqeq_path, err;
@@ -359,6 +360,8 @@ struct Engine {
   void nonbonded_pqeq();          // ENbond_PQEq, pot.F90:784-923
   void efield_force();            // EEfield, module.F90:359-383
   void remove_momentum();         // LinearMomentum, main.F90:766-797
+  void type_sums_device();        // per-type count / KE / momentum / mass of the residents, all ranks, left in tsum (assemble.hip)
+  double *tsum = nullptr; struct ScaleArgs *sargs = nullptr;   // 6 x 16 per-type sums ; the factors of a velocity-scaling action (device memory)
   void assemble_forces();
   void accumulate_stress(bool kinetic);   // astr(1:6) on the device (scal[48..53])
   void check_device_error(const char *where, bool fetch = true);

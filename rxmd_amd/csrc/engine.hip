@@ -396,7 +396,8 @@ void Engine::alloc_device() {
     dmalloc(rows_sorted, ng * WIN_ROWS); dmalloc(rowcols, ng * WIN_ROWS * 64); dmalloc(grp_base, ng * 32); dmalloc(win_flag, ng + 1); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dzalloc(scal, 192);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
-  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 192 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip)
+  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 320 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip); [192,288): the per-type sums of a host transport
+  dzalloc(tsum, 128); { double *sa_ = nullptr; dzalloc(sa_, 32); sargs = reinterpret_cast<ScaleArgs *>(sa_); }
   dzalloc(d_err, 16);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 32 * sizeof(int)));
   h_cnt = h_err + 16;
@@ -432,7 +433,7 @@ void Engine::free_device() {
   dfree(ehb_don); dfree(ehb_cnt);
   dfree(ecoef); dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   dfree(rows_int); dfree(rows_bnd); dfree(rows_sorted); dfree(rowcols); dfree(grp_base); dfree(win_flag); dfree(win_k); dfree(win_cnt); dfree(win_gint); dfree(win_gbnd); dfree(sl10);
-  dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err);
+  dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err); dfree(tsum); { double *sa_ = reinterpret_cast<double *>(sargs); dfree(sa_); sargs = nullptr; }
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }
   if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
@@ -899,6 +900,9 @@ __global__ void __launch_bounds__(256) k_seg_finish_move(int N, BoxDev B, const 
 }
 
 void Engine::migrate_fused() {
+  // Single rank only: every resident is LIVE (type > 0) -- an atom that leaves through a face comes back in through the opposite one, nothing
+  // is ever handed to another rank, so N does not change and there is no dead slot to compact out (the staged path, which several ranks run,
+  // does both: k_pack_move marks type = -1, comm.F90:440, and the compaction behind the stages shrinks N).
   const BoxDev B = boxdev(box);
   SegGeom sg;
   for (int a = 0; a < 3; ++a) { sg.lbox[a] = box.lbox[a]; sg.dr[a] = 0.0; }
@@ -1400,32 +1404,6 @@ void Engine::migrate() {
       cp[d0] = cp[d0 - 1] + c0; cp[d1] = cp[d0] + c1;
       moved += t0 + t1 + c0 + c1;
     }
-  } else if (!multi() && stage_pairs) {
-    for (int d0 = 1; d0 <= 5; d0 += 2) {           // single rank: the same pairing, one host wait per axis
-      const int d1 = d0 + 1, nscan = cp[cptridx_[d0]], axis = (d0 - 1) / 2;
-      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d0, box.lbox[axis], 0.0, spos[axis], type, 1, flags);
-      k_slab_flags<<<nblk(nscan + 1, 256), 256, 0, stream>>>(nscan, d1, box.lbox[axis], 0.0, spos[axis], type, 1, flags2);
-      size_t tb = cubtmp_bytes;
-      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, nscan + 1, stream));
-      tb = cubtmp_bytes;
-      RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, nscan + 1, stream));
-      int t0 = 0, t1 = 0;
-      RX_HIP(hipMemcpyAsync(h_cnt + 0, scanout + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      RX_HIP(hipMemcpyAsync(h_cnt + 1, scanout2 + nscan, sizeof(int), hipMemcpyDeviceToHost, stream));
-      sync_stream();
-      t0 = h_cnt[0]; t1 = h_cnt[1];   // counts arrive in pinned host memory
-      if (static_cast<long long>(cp[d0 - 1]) + t0 + t1 > NB) throw EngineError(RXMD_E_NBUFFER, "over capacity in append_atoms (MODE_MOVE)");
-      cp[d0] = cp[d0 - 1] + t0; cp[d1] = cp[d0] + t1;
-      if (t0 > 0) {
-        if (ff.pqeq) for (int a = 0; a < 3; ++a) k_move_append_extra<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d0 - 1], flags, scanout, shl[a]);
-        k_move_append<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d0 - 1], axis, -box.lbox[axis], flags, scanout, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
-      }
-      if (t1 > 0) {
-        if (ff.pqeq) for (int a = 0; a < 3; ++a) k_move_append_extra<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d0], flags2, scanout2, shl[a]);
-        k_move_append<<<nblk(nscan, 256), 256, 0, stream>>>(nscan, cp[d0], axis, box.lbox[axis], flags2, scanout2, spos[0], spos[1], spos[2], vel[0], vel[1], vel[2], type, gid, q, qsfp, qsfv);
-      }
-      moved += t0 + t1;
-    }
   } else
   for (int d = 1; d <= 6; ++d) {
     const int nscan = cp[cptridx_[d]], axis = (d - 1) / 2;
@@ -1608,6 +1586,7 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     free_bond_tables();
     alloc_bond_tables(static_cast<size_t>(h_err[7]) + static_cast<size_t>(h_err[7]) / 4 + 4096);
     build_bonded_list(true);
+    fetch_device_error();          // the re-pack searched the mirror slots of the atoms the first pass had skipped: its DERR_NBRINDX must be seen THIS step, under this label
   }
   try {
     check_device_error("list build", false);             // (the words are here already)

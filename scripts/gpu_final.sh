@@ -7,7 +7,8 @@ O=gpurun_out/$1; mkdir -p $O
 COMMIT=${COMMIT:-unknown} timeout -k 10 1500 bash scripts/gpu_pmc_kernels.sh $1/pmc > $O/pmc.log 2>&1; tail -26 $O/pmc.log | cut -c1-170
 find $O/pmc -name '*.csv' -size +2M -delete; find $O/pmc -name '*.db' -delete
 [ -s $O/pmc/kernel_traffic.json ] && cp $O/pmc/kernel_traffic.json profiles/kernel_traffic.json
-timeout -k 10 900 python3 bench.py > $O/bench_default.log 2>&1; grep '^{"metric' $O/bench_default.log > $O/bench_default.json
+timeout -k 10 900 python3 bench.py --full-line $O/bench_default_full.json > $O/bench_default.log 2>&1; grep '^{"metric' $O/bench_default.log > $O/bench_default_line.json; cp $O/bench_default_full.json $O/bench_default.json
+echo "stdout line: $(wc -c < $O/bench_default_line.json) bytes"
 python3 -c "
 import json; d=json.load(open('$O/bench_default.json')); r=d['roofline']
 print('steps/s', round(d['value'],3), 'ms/step', round(d['ms_per_step'],2), 'pass', round(r['avg_launch_ms'],4), 'frac', round(r['frac'],3), 'frac_real', r.get('frac_real_traffic'), 'iters', d['qeq_iters_per_step'])
@@ -16,18 +17,15 @@ print('alt', d.get('alt',{}).get('ms_per_step'), 'lex', d.get('alt_lex',{}).get(
 print('other', [(o.get('workload','')[:30], o.get('ms_per_step'), o.get('roofline',{}).get('avg_launch_ms'), o.get('roofline',{}).get('frac')) for o in d.get('other_configs',[])])
 print('cpu', d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('cores'))
 print({k: round(v,2) for k,v in d['breakdown_ms_per_step'].items() if v}); print([(k['name'][:14], round(k['ms'],3), k.get('bound'), k.get('frac_of_bound') and round(k['frac_of_bound'],2)) for k in r['kernels']])"
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline --no-other-configs > $O/bench_prof.log 2>&1
-grep '^{"metric' $O/bench_prof.log > $O/bench_prof.json
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline --no-other-configs --full-line $O/bench_prof.json > $O/bench_prof.log 2>&1
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats.csv; head -24 $O/kernel_stats.csv | cut -c1-130
 find $O/prof -name '*.csv' ! -name '*stats*' -delete; find $O/prof -name '*.db' -delete
 # the same trace with the charge-free part of FORCE on the main stream again: kernel durations that mean a kernel ALONE (the default run shares the GPU between ENbond and the bonded chain)
-RXMD_NO_BOND_OVERLAP=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_one -- python3 bench.py --no-cpu-baseline --no-other-configs --no-alt --no-steady > $O/bench_prof_one.log 2>&1
-grep '^{"metric' $O/bench_prof_one.log > $O/bench_prof_one.json
+RXMD_NO_BOND_OVERLAP=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_one -- python3 bench.py --no-cpu-baseline --no-other-configs --no-alt --no-steady --full-line $O/bench_prof_one.json > $O/bench_prof_one.log 2>&1
 f=$(find $O/prof_one -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats_one_stream.csv; head -12 $O/kernel_stats_one_stream.csv | cut -c1-130
 find $O/prof_one -name '*.csv' ! -name '*stats*' -delete; find $O/prof_one -name '*.db' -delete
 for w in water sicnp; do
-  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -- python3 bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-steady > $O/bench_$w.log 2>&1
-  grep '^{"metric' $O/bench_$w.log > $O/bench_$w.json
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -- python3 bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-steady --full-line $O/bench_$w.json > $O/bench_$w.log 2>&1
   f=$(find $O/prof_$w -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats_$w.csv; head -8 $O/kernel_stats_$w.csv | cut -c1-130
   find $O/prof_$w -name '*.csv' ! -name '*stats*' -delete; find $O/prof_$w -name '*.db' -delete
   for ctr in FETCH_SIZE WRITE_SIZE; do
