@@ -289,6 +289,8 @@ struct Engine {
   void bin_cells();
   void build_bonded_list(bool pack_only = false);
   void build_list10();
+  void build_prologue(int what);   // lists.hip: the words a list build starts from, one launch (1: bonded list, 2: 10 A list and windows)
+  bool list10_retry = false;
   // Window form of the 10 A matrix (lists.hip, qeq.hip k_spmv_win): the residents in cell-sorted order in groups of WIN_ROWS rows; per group the
   // set of cell-sorted positions its rows couple to, in units of WIN_UNIT consecutive positions (win_k: first position of each unit, ascending;
   // win_cnt: units); per list entry a 16-bit slot in that window (sl10, bit 15 = ghost column).  The matrix pass stages the window's vector

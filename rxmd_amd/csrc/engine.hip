@@ -1574,6 +1574,7 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   poison_step_scratch();
   { const bool kt = kt_begin(&st.ms_ghost_build); ghost_build(); kt_end(kt); }
   bin_cells();
+  build_prologue(3);
   { const bool kt = kt_begin(&st.ms_k_blist); build_bonded_list(); kt_end(kt); }
   sums_from_list = qeq_prepass;
   if (qeq_prepass) qeq_start_vectors();             // the sweep below also forms H.(qs,qt) of the CG start vector
@@ -1601,7 +1602,9 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
     dfree(nb10); dfree(hess); dfree(sl10); dmalloc(nb10, n); dmalloc(hess, n); dmalloc(sl10, n);
     if (ff.pqeq) { dfree(hsc); dmalloc(hsc, n); }
     st.n10_stride = S10;
-    build_list10();
+    list10_retry = true;
+    try { build_list10(); } catch (...) { list10_retry = false; throw; }
+    list10_retry = false;
     check_device_error("list build");
   }
   nbonds = h_err[7]; nbonds_res = h_err[9];

@@ -152,11 +152,12 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int MAXNB, Grid g, R
 // totals).  This pass packs them: bond o = boff[i] + s (boff = exclusive prefix of the counts) carries its partner nbr[o], its owner bown[o] = i
 // and its MIRROR brev[o] = boff[j] + j1 with nbrlist(j, j1) == i -- the reference's nbrindx (main.F90:383-399) as a direct index into the
 // compact tables.  Every per-bond array of the engine is indexed by o: 5.3 entries per RDX atom instead of a 30-slot stride.
-__global__ void k_bond_csr(int G, int NB, long long bcap, const int *__restrict__ nbr_sm, const int *__restrict__ nbrcnt, const int *__restrict__ boff,
+__global__ void k_bond_csr(int G, int nres, int NB, long long bcap, const int *__restrict__ nbr_sm, const int *__restrict__ nbrcnt, const int *__restrict__ boff,
                            int *__restrict__ nbr, int *__restrict__ brev, int *__restrict__ bown, const int *__restrict__ type, unsigned char *__restrict__ btype, int *err) {
   // one thread per (atom, slot): eight neighbouring lanes take eight consecutive slots of ONE atom (its staging line is read as a 32-byte piece, not by 8 workgroups),
   // a workgroup 32 consecutive atoms; blockIdx.y = the block of eight slots -- the workgroups of slots no atom of theirs uses leave after one read of the counts
   const int i = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x >> 3) + (threadIdx.x >> 3), s = 8 * blockIdx.y + (threadIdx.x & 7);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { err[7] = boff[G]; err[9] = boff[nres]; }   // bonds of this build and the residents' share: the host reads them with the error word it waits for anyway (until round 6: two 5 us copy launches)
   if (i >= G) return;
   const int ni = nbrcnt[i];
   if (s >= ni) return;
@@ -532,9 +533,14 @@ __global__ void k_split_rows(int N, const int *__restrict__ flag, const int *__r
 }
 
 // ---- window form of the 10 A matrix (engine.h: WIN_*) -------------------------------------------------------------------------------
-__global__ void k_resident_flags(int G, int N, const int *__restrict__ perm, int *__restrict__ flag) {
+__global__ void k_resident_flags(int G, int N, const int *__restrict__ perm, int *__restrict__ flag, int *__restrict__ rows_sorted, int nrows_fill, int *__restrict__ win_cnt, int *__restrict__ win_flag, int ngroups_fill) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k <= G) flag[k] = (k < G && perm[k] < N) ? 1 : 0;
+  // what three memsets did until round 6: every row slot a sentinel >= N until k_rows_sorted names its row, empty windows and "interior" for the groups
+  // between this build's count and the launch bound
+  for (int t = k; t < nrows_fill; t += gridDim.x * blockDim.x) rows_sorted[t] = 0x7f7f7f7f;
+  for (int t = k; t < ngroups_fill; t += gridDim.x * blockDim.x) { win_cnt[t] = 0; win_flag[t] = 0; }
+  if (k == 0) win_flag[ngroups_fill] = 0;
 }
 // Window groups never straddle a cell column (x, y) of the grid: the rows of a group then share their 25 stencil columns, and what each of those
 // contributes to the group's window is ONE short z-interval.  (A group that ran over into the next cell column held rows from the top of one
@@ -546,8 +552,9 @@ __global__ void k_col_groups(int ncol, int nzf, const int *__restrict__ cellstar
   colg[c] = c < ncol ? (rank[cellstart[(c + 1) * nzf]] - rank[cellstart[c * nzf]] + WIN_ROWS - 1) / WIN_ROWS : 0;
 }
 __global__ void k_rows_sorted(int G, int N, int nzf, const int *__restrict__ perm, const int *__restrict__ rank, const int *__restrict__ cid_sorted, const int *__restrict__ cellstart,
-                              const int *__restrict__ colgo, int *__restrict__ rows_sorted) {
+                              const int *__restrict__ colgo, int *__restrict__ rows_sorted, int ncol, int *__restrict__ err) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) err[8] = colgo[ncol];                              // groups of this build: the sweep's workgroups beyond it leave at once; the host reads it with the error word
   if (k >= G || perm[k] >= N) return;
   const int c = cid_sorted[k] / nzf;
   const int r = rank[k] - rank[cellstart[c * nzf]];              // this resident's place among the residents of its column
@@ -561,35 +568,37 @@ __global__ void k_split_groups(int ng, const int *__restrict__ flag, const int *
 
 // the residents in cell-sorted order (rows_sorted): the rows of a window group, and the work order of the 10 A sweep that builds the windows
 void Engine::build_windows() {
-  k_resident_flags<<<nblk(G + 1, 256), 256, 0, stream>>>(G, N, perm, flags2);
+  win_groups = static_cast<int>(win_groups_bound(N));                                                         // until the host has read this build's count: the bound (launch size of the sweep)
+  k_resident_flags<<<nblk(G + 1, 256), 256, 0, stream>>>(G, N, perm, flags2, rows_sorted, win_groups * WIN_ROWS, win_cnt, win_flag, win_groups);
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags2, scanout2, G + 1, stream));
   const int ncol = grid.n[0] * grid.n[1];
   k_col_groups<<<nblk(ncol + 1, 256), 256, 0, stream>>>(ncol, grid.nzf, cellstart, scanout2, flags);     // (flags / scanout: free until the sweep writes its row flags)
   tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, flags, scanout, ncol + 1, stream));
-  RX_HIP(hipMemcpyAsync(d_err + 8, scanout + ncol, sizeof(int), hipMemcpyDeviceToDevice, stream));         // groups of this build: the sweep's workgroups beyond it leave at once; the host reads it with the error word
-  win_groups = static_cast<int>(win_groups_bound(N));                                                         // until then: the bound (launch size of the sweep)
-  RX_HIP(hipMemsetAsync(rows_sorted, 0x7f, sizeof(int) * static_cast<size_t>(win_groups) * WIN_ROWS, stream));   // 0x7f7f7f7f >= N: not a row
-  k_rows_sorted<<<nblk(G, 256), 256, 0, stream>>>(G, N, grid.nzf, perm, scanout2, cellid_sorted, cellstart, scanout, rows_sorted);
-  RX_HIP(hipMemsetAsync(d_err + 5, 0, 2 * sizeof(int), stream));
-  RX_HIP(hipMemsetAsync(win_cnt, 0, sizeof(int) * static_cast<size_t>(win_groups), stream));               // (groups between the count and the bound: empty windows)
-  RX_HIP(hipMemsetAsync(win_flag, 0, sizeof(int) * (static_cast<size_t>(win_groups) + 1), stream));              // ... and interior until the sweep finds a row with a ghost partner
+  k_rows_sorted<<<nblk(G, 256), 256, 0, stream>>>(G, N, grid.nzf, perm, scanout2, cellid_sorted, cellstart, scanout, rows_sorted, ncol, d_err);
 }
+
+// The words a list build starts from, in ONE launch (until round 6: nine 4-byte memsets of ~5 us each, spread over the build): the error word's
+// companions -- err[2] longest bonded list, [3] longest / [4] shortest 10 A row, [5] largest window, [6] window overflow -- and the count behind the last
+// atom that the prefix sum of the bond counts reads.
+__global__ void k_build_prologue(int *__restrict__ err, int *__restrict__ nbrcnt_end, int what) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (what & 1) { err[2] = 0; *nbrcnt_end = 0; }
+  if (what & 2) { err[3] = 0; err[4] = 0x7f7f7f7f; err[5] = 0; err[6] = 0; }      // 0x7f7f7f7f: larger than any row
+}
+void Engine::build_prologue(int what) { k_build_prologue<<<1, 64, 0, stream>>>(d_err, nbrcnt + G, what); }
 
 void Engine::build_bonded_list(bool pack_only) {
   // pack_only: the compact tables were too small for this build and have been re-allocated; the staging lines and the counts of the sweep are intact
   if (!pack_only) {
-  RX_HIP(hipMemsetAsync(d_err + 2, 0, sizeof(int), stream));
   if (grid.ortho) k_bonded_list<true><<<nblk(G, 256), 256, 0, stream>>>(G, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
   else k_bonded_list<false><<<nblk(G, 256), 256, 0, stream>>>(G, MAXNB, grid, rmesh, dff, cellid, cellstart, sorted_xyzi, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, nbr_sm, nbrcnt, d_err);
   }
-  RX_HIP(hipMemsetAsync(nbrcnt + G, 0, sizeof(int), stream));                       // (G < NB always: the scan below runs over G + 1 counts)
+  // (nbrcnt[G] = 0 by build_prologue: G < NB always, the scan below runs over G + 1 counts)
   size_t tb = cubtmp_bytes;
   RX_HIP(hipcub::DeviceScan::ExclusiveSum(cubtmp, tb, nbrcnt, boff, G + 1, stream));
-  RX_HIP(hipMemcpyAsync(d_err + 7, boff + G, sizeof(int), hipMemcpyDeviceToDevice, stream));   // bonds of this build: read with the error word the host waits for anyway
-  RX_HIP(hipMemcpyAsync(d_err + 9, boff + N, sizeof(int), hipMemcpyDeviceToDevice, stream));   // ... and the residents' share of them
-  k_bond_csr<<<dim3(nblk(G, 32), (MAXNB + 7) / 8), 256, 0, stream>>>(G, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, type, btype, d_err);
+  k_bond_csr<<<dim3(nblk(G, 32), (MAXNB + 7) / 8), 256, 0, stream>>>(G, N, NB, static_cast<long long>(bcap), nbr_sm, nbrcnt, boff, nbr, brev, bown, type, btype, d_err);
 }
 
 constexpr int L10_ROWS_LAUNCH = L10_ROWS;
@@ -597,8 +606,7 @@ void Engine::build_list10() {
 #ifdef RXMD_EXPERIMENTS
   if (const char *pv = std::getenv("RXMD_LIST_PROBE")) grid.probe = std::atoi(pv);
 #endif
-  RX_HIP(hipMemsetAsync(d_err + 3, 0, sizeof(int), stream));
-  RX_HIP(hipMemsetAsync(d_err + 4, 0x7f, sizeof(int), stream));      // 0x7f7f7f7f: larger than any row
+  if (list10_retry) build_prologue(2);                              // (a first build of the step had them from build_prologue(3) at the head of the build)
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);
   list_selfcheck = selfcheck;

@@ -965,6 +965,107 @@ void Engine::tune_window_placement() {
     hipEventElapsedTime(&ms, ev[2], ev[3]);
     return static_cast<double>(ms) / 30.0;
   };
+#ifdef RXMD_EXPERIMENTS
+  // RXMD_PLACE_SCAN=<slabs> (experiments build): is the placement lottery a RULE?  The two streams of the pass are copied into ONE allocation at
+  // controlled offsets -- the value stream at slab + oh, the slot stream behind it at a 2 MB boundary + os -- and the real pass is timed at each
+  // (oh, os); repeated for <slabs> fresh allocations.  If the time followed the relative position of the two streams (channel / stack aliasing),
+  // it would show as a pattern in os that repeats from slab to slab; a time that changes from slab to slab but not with the offsets inside one
+  // says the draw is the physical pages the driver hands out.  Output: one line per measurement on stderr (scripts/gpu_place_scan.sh).
+  if (const char *scan = std::getenv("RXMD_PLACE_SCAN")) {
+    if (!ff.pqeq) {
+      const int nslab = std::max(1, std::atoi(scan));
+      const size_t MB2 = size_t(2) << 20, hb = ne * sizeof(double), sb = ne * sizeof(unsigned short);
+      const size_t pad = size_t(64) << 20, total = hb + sb + 3 * pad;
+      const size_t offs[] = {0, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, size_t(1) << 20, (size_t(1) << 20) + 4096, size_t(2) << 20, size_t(4) << 20, size_t(8) << 20, size_t(16) << 20, size_t(32) << 20};
+      std::fprintf(stderr, "[place_scan] engine's own placement: %.4f ms  hess %p sl10 %p  (ne %zu)\n", time_pass(hess, sl10, hsc), static_cast<void *>(hess), static_cast<void *>(sl10), ne);
+      std::vector<char *> held;
+      for (int sidx = 0; sidx < nslab; ++sidx) {
+        char *slab = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&slab), total) != hipSuccess) { (void)hipGetLastError(); break; }
+        held.push_back(slab);                        // kept until the end: a freed slab would come straight back
+        auto at = [&](size_t oh, size_t os) {
+          double *h2 = reinterpret_cast<double *>(slab + oh);
+          unsigned short *s2 = reinterpret_cast<unsigned short *>(slab + ((pad + hb + MB2 - 1) / MB2) * MB2 + os);
+          RX_HIP(hipMemcpyAsync(h2, hess, hb, hipMemcpyDeviceToDevice, stream));
+          RX_HIP(hipMemcpyAsync(s2, sl10, sb, hipMemcpyDeviceToDevice, stream));
+          const double t = time_pass(h2, s2, hsc);
+          std::fprintf(stderr, "[place_scan] slab %d %p  oh %9zu  os %9zu  %.4f ms\n", sidx, static_cast<void *>(slab), oh, os, t);
+        };
+        for (size_t os : offs) at(0, os);
+        for (size_t oh : offs) if (oh) at(oh, 0);
+        at(0, 0);                                    // repeatability inside the slab
+      }
+      // (round 6, second series) WHERE does the draw come from?  The same scan point (0, 0) on slabs obtained in other ways: physically contiguous
+      // memory (hipExtMallocWithFlags(hipDeviceMallocContiguous)) and virtual-memory-management slabs built from physical chunks of a chosen size
+      // (hipMemCreate / hipMemMap: 2 MB, 64 MB, 1 GB) -- if the slow draws are allocations the driver had to back with small page fragments, large
+      // chunks are always of the fast kind.  Next to each pass time the plain sequential read of the value stream from the same slab.
+      auto seq_ms = [&](const void *ptr) {
+        hipEventRecord(ev[2], stream);
+        for (int r = 0; r < 5; ++r) k_stream_probe<<<num_cu * 8, 256, 0, stream>>>(hb / 16, reinterpret_cast<const f64x2 *>(ptr), partials);
+        hipEventRecord(ev[3], stream); hipEventSynchronize(ev[3]);
+        float ms = 0; hipEventElapsedTime(&ms, ev[2], ev[3]); return static_cast<double>(ms) / 5.0;
+      };
+      auto on_slab = [&](const char *how, char *slab) {
+        double *h2 = reinterpret_cast<double *>(slab);
+        unsigned short *s2 = reinterpret_cast<unsigned short *>(slab + ((pad + hb + MB2 - 1) / MB2) * MB2);
+        RX_HIP(hipMemcpyAsync(h2, hess, hb, hipMemcpyDeviceToDevice, stream));
+        RX_HIP(hipMemcpyAsync(s2, sl10, sb, hipMemcpyDeviceToDevice, stream));
+        const double t = time_pass(h2, s2, hsc), t_hv = time_pass(h2, sl10, hsc), t_sv = time_pass(hess, s2, hsc);
+        std::fprintf(stderr, "[place_scan] %-28s %p  pass %.4f ms (its values + engine slots %.4f, engine values + its slots %.4f)  sequential read of its value stream %.4f ms = %.0f GB/s\n", how, static_cast<void *>(slab), t, t_hv, t_sv, seq_ms(h2), hb / (seq_ms(h2) * 1e-3) / 1e9);
+      };
+      std::fprintf(stderr, "[place_scan] engine's own value stream: sequential read %.4f ms\n", seq_ms(hess));
+      for (char *p : held) on_slab("hipMalloc slab (above)", p);
+      for (int c = 0; c < 3; ++c) {
+        char *slab = nullptr;
+        if (hipExtMallocWithFlags(reinterpret_cast<void **>(&slab), total, hipDeviceMallocContiguous) != hipSuccess) { (void)hipGetLastError(); std::fprintf(stderr, "[place_scan] contiguous allocation refused\n"); break; }
+        on_slab("hipDeviceMallocContiguous", slab);
+        held.push_back(slab);
+      }
+      for (size_t chunk : {size_t(2) << 20, size_t(64) << 20, size_t(1) << 30}) {
+        for (int rep = 0; rep < 2; ++rep) {
+          hipMemAllocationProp prop{};
+          prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = cfg.device;
+          size_t gran = 0;
+          if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess) { (void)hipGetLastError(); std::fprintf(stderr, "[place_scan] no VMM on this device\n"); break; }
+          const size_t ck = ((chunk + gran - 1) / gran) * gran, nck = (total + ck - 1) / ck, vsz = nck * ck;
+          void *va = nullptr;
+          if (hipMemAddressReserve(&va, vsz, ck, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); std::fprintf(stderr, "[place_scan] VMM reserve failed\n"); break; }
+          std::vector<hipMemGenericAllocationHandle_t> hs;
+          bool ok = true;
+          for (size_t k = 0; k < nck && ok; ++k) {
+            hipMemGenericAllocationHandle_t hnd;
+            ok = hipMemCreate(&hnd, ck, &prop, 0) == hipSuccess;
+            if (ok) { hs.push_back(hnd); ok = hipMemMap(static_cast<char *>(va) + k * ck, ck, 0, hnd, 0) == hipSuccess; }
+          }
+          hipMemAccessDesc ad{}; ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+          if (ok) ok = hipMemSetAccess(va, vsz, &ad, 1) == hipSuccess;
+          if (ok) {
+            char how[64]; std::snprintf(how, sizeof how, "VMM chunks of %zu MB (gran %zu KB)", ck >> 20, gran >> 10);
+            on_slab(how, static_cast<char *>(va));
+          } else { (void)hipGetLastError(); std::fprintf(stderr, "[place_scan] VMM slab with %zu MB chunks failed\n", ck >> 20); }
+          RX_HIP(hipStreamSynchronize(stream));
+          (void)hipMemUnmap(va, vsz);
+          for (auto &hnd : hs) (void)hipMemRelease(hnd);
+          (void)hipMemAddressFree(va, vsz);
+        }
+      }
+      // and the lottery itself next to it: separate allocations, as the search draws them
+      std::vector<std::unique_ptr<Cand>> dr;
+      for (int c = 0; c < 6; ++c) {
+        dr.push_back(std::make_unique<Cand>());
+        Cand &cd_ = *dr.back();
+        if (hipMalloc(reinterpret_cast<void **>(&cd_.h), hb) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&cd_.s), sb) != hipSuccess) { (void)hipGetLastError(); break; }
+        RX_HIP(hipMemcpyAsync(cd_.h, hess, hb, hipMemcpyDeviceToDevice, stream));
+        RX_HIP(hipMemcpyAsync(cd_.s, sl10, sb, hipMemcpyDeviceToDevice, stream));
+        std::fprintf(stderr, "[place_scan] separate draw %d: %.4f ms  hess %p sl10 %p\n", c, time_pass(cd_.h, cd_.s, hsc), static_cast<void *>(cd_.h), static_cast<void *>(cd_.s));
+        // cross pairs: this draw's value stream with the engine's slot stream and the other way round -- which of the two streams carries the draw?
+        std::fprintf(stderr, "[place_scan]   its value stream + the engine's slots: %.4f ms ; the engine's values + its slot stream: %.4f ms\n", time_pass(cd_.h, sl10, hsc), time_pass(hess, cd_.s, hsc));
+      }
+      dr.clear();
+      for (char *p : held) (void)hipFree(p);
+    }
+  }
+#endif
   const auto t_search0 = std::chrono::steady_clock::now();
   double best = time_pass(hess, sl10, hsc);
   st.place_ms_first = best;
@@ -1012,11 +1113,26 @@ void Engine::tune_window_placement() {
     RX_HIP(hipMemcpyAsync(h2, hess, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
     RX_HIP(hipMemcpyAsync(s2, sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, stream));
     if (ff.pqeq) RX_HIP(hipMemcpyAsync(c2, hsc, ne * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    const double t = time_pass(h2, s2, ff.pqeq ? c2 : hsc);
-    worst = std::max(worst, t);
-    if (verbose) std::fprintf(stderr, "[rxmd_hip] placement draw %d: %.4f ms  hess %p sl10 %p\n", c, t, static_cast<void *>(h2), static_cast<void *>(s2));
-    if (t < 0.99 * best) { best = t; std::swap(hess, h2); std::swap(sl10, s2); if (ff.pqeq) std::swap(hsc, c2); }   // (cd_ now holds the previous best)
-    if (best < 0.92 * worst && c >= 3 && !draw_all) break;          // a placement of the fast kind is in hand (and a slow one was seen): stop drawing
+    // Round 6 (profiles/r06_place_scan*.txt): the draw is carried by EACH stream on its own -- a value stream of the slow kind costs 0.08-0.10 ms
+    // whatever slot stream runs with it, a slot stream of the slow kind 0.02-0.04 ms -- and not by their relative position (no pattern in 32 offsets
+    // inside one allocation), nor by physical contiguity (hipDeviceMallocContiguous draws both kinds), nor by the size of the physical chunks (VMM
+    // slabs of 2 MB / 64 MB / 1 GB chunks: all mediocre), and a plain sequential read of a slow value stream is as fast as that of a fast one.  So
+    // every candidate stream is timed next to the best partner in hand and adopted on its own: the kept pair is the best value stream and the best
+    // slot stream of all draws, not the best PAIR.
+    const double t_h = time_pass(h2, sl10, hsc);
+    if (verbose) std::fprintf(stderr, "[rxmd_hip] placement draw %d: value stream %p with the slots in hand %.4f ms (best so far %.4f)\n", c, static_cast<void *>(h2), t_h, best);
+    worst = std::max(worst, t_h);
+    if (t_h < 0.99 * best) { best = t_h; std::swap(hess, h2); }                 // (cd_ now holds the previous best of this stream)
+    const double t_s = time_pass(hess, s2, hsc);
+    if (verbose) std::fprintf(stderr, "[rxmd_hip] placement draw %d: slot stream %p with the values in hand %.4f ms (best so far %.4f)\n", c, static_cast<void *>(s2), t_s, best);
+    worst = std::max(worst, t_s);
+    if (t_s < 0.99 * best) { best = t_s; std::swap(sl10, s2); }
+    if (ff.pqeq) {
+      const double t_c = time_pass(hess, sl10, c2);
+      worst = std::max(worst, t_c);
+      if (t_c < 0.99 * best) { best = t_c; std::swap(hsc, c2); }
+    }
+    if (best < 0.92 * worst && c >= 3 && !draw_all) break;          // a value stream of the fast kind is in hand (and a slow one was seen): stop drawing
   }
   drawn.clear();                                        // frees every loser; the stream is idle: time_pass waited for its last launch
   st.place_ms_kept = best;

@@ -30,8 +30,8 @@ def summary(tag, its, dqs):
 
 
 if __name__ == "__main__":
-    g = np.load(os.path.join(oa.GOLD, "rdx222_md110.npz")); gd = np.load(os.path.join(oa.GOLD, "rdx222_md110_dq.npz"))
-    summary("reference (110 steps)", g["qeq_iters"], gd["dq_tight"])
+    g = np.load(os.path.join(oa.GOLD, "rdx222_md1000.npz")); gd = np.load(os.path.join(oa.GOLD, "rdx222_md1000_dq.npz"))
+    summary("reference", g["qeq_iters"], gd["dq_tight"])
     ff, names, frac, lat = oa.make_system("rdx222")
     res = {}
     for qeq_mode, win, seed in ((1, "1", 0), (1, "1", 1), (1, "1", 2), (0, "1", 0), (1, "0", 0), (0, "0", 0), (1, "0", 1), (0, "1", 1)):

@@ -96,6 +96,7 @@ CASES = {
     # (round 6) 110 steps at the default tolerance 1e-7: the reference's own iteration count per step above one cell -- the statistic a change of the
     # CG's rounding is judged against (the count of a single step is REAL(4) noise; the mean over 100 steps is not)
     "rdx222_md110":  ("rdx.xyz", "ffield_rdx", (2, 2, 2), [], 110),
+    "rdx222_md1000": ("rdx.xyz", "ffield_rdx", (2, 2, 2), [], 1000),     # the same over 1000 steps: 110 calls are too few for the tails (runs of one-iteration exits)
     "ice644_tight":  ("ICE", "ffield_water", (6, 4, 4), ["--QEq_tol", "1e-12", "--NMAXQEq", "2000"], 0),
     # PQEq (pqeq.F90): SiC nanoparticle in O2, conf/init.sicnp, polarizable shells; the --pqeq file is copied next to the run
     "sicnp547_pqeq_tol7":  ("sicnp.xyz", "ffield_sicnp", (1, 1, 1), ["--pqeq", "pqeq.in"], 0),

@@ -211,39 +211,60 @@ def test_benchmark_tolerance_report(qeq_mode):
     e.close()
 
 
+def _one_exit_runs(its):
+    """lengths of the runs of consecutive QEq calls that left after at most one iteration"""
+    out, r = [], 0
+    for x in its:
+        if x <= 1:
+            r += 1
+        else:
+            if r:
+                out.append(r)
+            r = 0
+    if r:
+        out.append(r)
+    return out
+
+
 @pytest.mark.parametrize("qeq_mode,win", [(1, "1"), (0, "1"), (1, "0"), (0, "0")])
-def test_iteration_statistics_over_110_steps(qeq_mode, win, monkeypatch):
+def test_iteration_statistics_over_1000_steps(qeq_mode, win, monkeypatch):
     """What a change of the CG's rounding is judged by (round 6).  The iteration count of a SINGLE QEq call at QEq_tol 1e-7 is decided by REAL(4) noise
-    of the step length (the reference itself: 35 -> 31..39 under atom re-ordering, and 13 of these 100 calls leave after ONE iteration), so
-    no test can pin it; the MEAN over many calls above one cell can be pinned.  RDX 2 x 2 x 2, 110 MD steps at the bench settings, both QEq algebras,
-    window pass and row pass:
-      * mean iterations per step over steps 11..110 within 15 % of the reference's own 29.71 (tests/golden/rdx222_md110.npz: `rxmd` itself, 110 steps;
-        the one-cell figure of 24 and the 36.2 of steps 6..25 are NOT the bar);
-      * at EVERY step the charges against the converged solution of the same geometry (a second engine at QEq_tol 1e-12 started from them): the
-        reference's own distance is tests/golden/rdx222_md110_dq.npz (bit-path oracle: 90th percentile 4.2e-5, worst step 1.2e-4 -- the third of
-        three one-iteration exits in a row).  Gate: 90th percentile <= REF_TRUNCATION_ERR + REF_REORDER_SPREAD, worst step <= 1.5 x the reference's worst."""
+    of the step length (the reference itself: 35 -> 31..39 under atom re-ordering, and one call in ten leaves after ONE iteration -- the
+    relative change of Est over a steepest-descent step from nearly converged charges is below 1e-7 -- sometimes several steps in a row, the charges
+    drifting ~4e-5 from the converged solution per such step), so no test can pin it; its STATISTICS over many calls above one cell can be pinned.
+    RDX 2 x 2 x 2, 1000 MD steps at the bench settings, both QEq algebras, window pass and row pass, against the reference's own numbers over the same
+    1000 steps (tests/golden/rdx222_md1000.npz: `rxmd` itself, iteration counts; rdx222_md1000_dq.npz: the bit-path oracle, which reproduces those
+    counts call by call, + the distance of its charges from the converged solution of each geometry):
+      reference: mean 30.50 iterations per step over steps 11..1000 (one cell: 24; steps 6..25: 36 -- neither is the bar), 9.7 % one-iteration exits,
+                 longest run 6, |dq| against converged: median 5.6e-6, 90th percentile 7.9e-5, 99th 4.1e-4, worst 6.7e-4.
+    Gates: mean within 10 %; one-iteration exits within a factor 1.6 either way; 90th percentile <= 1.5 x, 99th <= 2 x, worst step <= 3 x the reference's
+    (tails of 1000 samples; the four variants measured 0.6-0.9 x, 0.7-1.1 x, 0.8-1.6 x: scripts/gpu_iterstat.py, profiles/r06_iterstat1000.log)."""
     import rxmd_amd
     monkeypatch.setenv("RXMD_SPMV_WIN", win)
-    g = np.load(os.path.join(oa.GOLD, "rdx222_md110.npz")); gd = np.load(os.path.join(oa.GOLD, "rdx222_md110_dq.npz"))
-    ref_mean = g["qeq_iters"][11:].mean()
-    assert np.array_equal(g["qeq_iters"], gd["qeq_iters"]) and abs(ref_mean - 29.71) < 0.01
+    g = np.load(os.path.join(oa.GOLD, "rdx222_md1000.npz")); gd = np.load(os.path.join(oa.GOLD, "rdx222_md1000_dq.npz"))
+    ref_its = g["qeq_iters"]; ref_dq = gd["dq_tight"]
+    assert np.array_equal(ref_its, gd["qeq_iters"])                    # the oracle stayed on the reference's bit path for all 1001 calls
+    ref_mean = ref_its[11:].mean(); ref_ones = (ref_its[11:] <= 1).mean()
     e = _engine("rdx222", (2, 2, 2), qeq_mode=qeq_mode)
-    t = rxmd_amd.RxmdEngine(oa.make_system("rdx222")[0], e.lattice, QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=qeq_mode)
+    t = rxmd_amd.RxmdEngine(oa.make_system("rdx222")[0], e.lattice, QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=0)
     it0, _ = e.QEq(); e.FORCE()
     its, dqs = [it0], []
-    for s in range(110):
+    for s in range(1000):
         e.step(1)
         its.append(e.stats()["qeq_iters_last"])
         rec = e.get_atoms_rxff()
-        t.set_atoms_rxff(rec); t.QEq()
+        t.set_atoms_rxff(rec); t.QEq()                                 # the converged charges of this geometry, started from the engine's
         dqs.append(np.abs(t.atoms()["q"] - rec[:, 6]).max())
     its = np.array(its); dqs = np.array(dqs)
-    mean = its[11:].mean()
-    print("qeq_mode %d win %s: mean iterations/step over steps 11..110 %.2f (reference %.2f), one-iteration exits %d (reference %d); |dq| vs converged: p90 %.2e max %.2e (reference %.2e / %.2e)"
-          % (qeq_mode, win, mean, ref_mean, (its[11:] <= 1).sum(), (g["qeq_iters"][11:] <= 1).sum(), np.percentile(dqs, 90), dqs.max(), np.percentile(gd["dq_tight"], 90), gd["dq_tight"].max()))
-    assert abs(mean - ref_mean) <= 0.15 * ref_mean, (mean, ref_mean)
-    assert np.percentile(dqs, 90) <= REF_TRUNCATION_ERR + REF_REORDER_SPREAD
-    assert dqs.max() <= 1.5 * gd["dq_tight"].max()
+    mean = its[11:].mean(); ones = (its[11:] <= 1).mean(); rl = _one_exit_runs(its[11:])
+    print("qeq_mode %d win %s: mean iterations/step %.2f (reference %.2f), one-iteration exits %.3f (%.3f), longest run %d (%d); |dq| vs converged p50 %.2e p90 %.2e p99 %.2e max %.2e (reference %.2e %.2e %.2e %.2e)"
+          % (qeq_mode, win, mean, ref_mean, ones, ref_ones, max(rl), max(_one_exit_runs(ref_its[11:])), np.percentile(dqs, 50), np.percentile(dqs, 90), np.percentile(dqs, 99), dqs.max(),
+             np.percentile(ref_dq, 50), np.percentile(ref_dq, 90), np.percentile(ref_dq, 99), ref_dq.max()))
+    assert abs(mean - ref_mean) <= 0.10 * ref_mean, (mean, ref_mean)
+    assert ref_ones / 1.6 <= ones <= 1.6 * ref_ones, (ones, ref_ones)
+    assert np.percentile(dqs, 90) <= 1.5 * np.percentile(ref_dq, 90)
+    assert np.percentile(dqs, 99) <= 2.0 * np.percentile(ref_dq, 99)
+    assert dqs.max() <= 3.0 * ref_dq.max()
     e.close(); t.close()
 
 
