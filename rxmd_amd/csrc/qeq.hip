@@ -228,6 +228,14 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
   const d2v *cv2 = reinterpret_cast<const d2v *>((PQ ? hsc : hess) + base);
   const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
+  // VAR & 4: a group none of whose rows has a ghost partner (gflags[grp] == 0: three groups in four of a large domain) takes a body WITHOUT the
+  // ghost-column sums -- two selects and four FMAs of the twelve vector instructions per pair of entries, and two of the four reductions.  The flag
+  // rides with round trip 1 and the choice is ONE scalar branch per workgroup around two complete copies of everything below (round 6: as two loops
+  // inside one body the compiler kept the first batches alive for "the other loop" and paid with folded spills under the 64-register cap -- 48 B of
+  // scratch per lane, 20 after the register sets took turns, 0 now).
+  const bool gh = !((VAR & WIN_LEAN) != 0 && !PQ && gflags != nullptr) || gflags[grp] != 0;
+  auto whole = [&](auto ghc) {
+  constexpr bool GHC = decltype(ghc)::value;
   double2 v[STEPS], c[STEPS]; unsigned ss[STEPS];
   auto request = [&](int kb, int bound) {          // entries kb + 128 u + 2 lane and the next one
 #pragma unroll
@@ -278,37 +286,46 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   if (PRE && n > 128 * STEPS) request_next(128 * STEPS);
   __syncthreads();
   double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-  // VAR & 4: a group none of whose rows has a ghost partner (gflags[grp] == 0: three groups in four of a large domain) takes a loop WITHOUT the
-  // ghost-column sums -- two selects and four FMAs of the twelve vector instructions per pair of entries, and two of the four reductions.  The
-  // choice is one scalar branch per workgroup around two straight-line loops, not a branch per row inside one (round 3: that lost).
-  const bool gh = !((VAR & WIN_LEAN) != 0 && !PQ && gflags != nullptr) || gflags[grp] != 0;
-  auto products = [&](auto ghc) {
-    constexpr bool GHC = decltype(ghc)::value;
-    for (int kb = 0; kb < n; kb += 128 * STEPS) {     // wave-uniform trip count
-      if (!PRE && kb > 0) request(kb, n);             // (an odd row end: entry n is the zero padding of the row, slot 0)
-      if (PRE && kb > 0) {
-#pragma unroll
-        for (int u = 0; u < STEPS; ++u) { v[u] = vn[u]; ss[u] = sn[u]; }
-        if (kb + 128 * STEPS < n) request_next(kb + 128 * STEPS);
-      }
+    auto batch = [&](const double2 (&vv)[STEPS], const unsigned (&sv)[STEPS]) {      // one batch of 128 x STEPS entries out of registers and the LDS window
 #pragma unroll
       for (int u = 0; u < STEPS; ++u) {
-        const double2 y0 = s_x[ss[u] & 0x7fffu], y1 = s_x[(ss[u] >> 16) & 0x7fffu];
-        as += v[u].x * y0.x; at += v[u].x * y0.y; as += v[u].y * y1.x; at += v[u].y * y1.y;
+        const double2 y0 = s_x[sv[u] & 0x7fffu], y1 = s_x[(sv[u] >> 16) & 0x7fffu];
+        as += vv[u].x * y0.x; at += vv[u].x * y0.y; as += vv[u].y * y1.x; at += vv[u].y * y1.y;
         if (GHC && (MODE == MODE_GRAD || STORE) && !PQ) {
-          const double g0 = (ss[u] & 0x8000u) ? v[u].x : 0.0, g1 = (ss[u] & 0x80000000u) ? v[u].y : 0.0;     // select the weight, not the sums
+          const double g0 = (sv[u] & 0x8000u) ? vv[u].x : 0.0, g1 = (sv[u] & 0x80000000u) ? vv[u].y : 0.0;     // select the weight, not the sums
           gs_ += g0 * y0.x; gt_ += g0 * y0.y; gs_ += g1 * y1.x; gt_ += g1 * y1.y;
         }
         if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * y0.x; gt_ += c[u].x * y0.y; gs_ += c[u].y * y1.x; gt_ += c[u].y * y1.y; }
       }
+    };
+    constexpr int B = 128 * STEPS;
+    if (PRE) {
+      // Two register sets take turns (round 6): batch k sits in (v, ss) for even k and in (vn, sn) for odd k, and the batch after the next one is
+      // requested into the set that has just been used.  Until round 6 the loop rotated `v = vn` at its head: under the 64-register cap of eight
+      // workgroups per CU that copy went through 48 bytes of scratch per lane on every row longer than two batches (rows > 512 entries: any
+      // condensed system at PQEq's 12.5 A cut-off, dense metals) -- and cost ten moves per row on the others.  Same products in the same order.
+      for (int kb = 0;;) {                               // wave-uniform trip count
+        batch(v, ss);
+        kb += B; if (kb >= n) break;
+        if (kb + B < n) request(kb + B, n);               // (an odd row end: entry n is the zero padding of the row, slot 0)
+        batch(vn, sn);
+        kb += B; if (kb >= n) break;
+        if (kb + B < n) request_next(kb + B);
+      }
+    } else {
+      for (int kb = 0; kb < n; kb += B) {                 // wave-uniform trip count
+        if (kb > 0) request(kb, n);
+        batch(v, ss);
+      }
     }
-  };
-  if (gh) products(std::true_type{}); else products(std::false_type{});
+
   as = wave_sum(as); at = wave_sum(at);
-  if ((MODE == MODE_GRAD || STORE) && gh) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
+  if ((MODE == MODE_GRAD || STORE) && GHC) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
   // The row's tail by its own wavefront (the rows of a group are scattered residents: nothing would coalesce if one wavefront ran all of them,
   // and a workgroup whose last wavefront works alone keeps 15 wavefront slots of the CU empty); a wavefront leaves when it is done.  The
   // workgroup's four partial sums: every wavefront leaves its terms in LDS, the LAST one to arrive adds them in wavefront order.
+  // the lane number afresh (two mbcnt instructions): `lane` kept alive across the loop for these four uses was the one register the PQ instances spilled
+  const int lane_t = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (live) {
     const DevAtomP ap = ff.atom[tl_t];
@@ -316,7 +333,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
       const double ts = ap.eta * tl_a.x + as, tt = ap.eta * tl_a.y + at;      // qeq.F90:294-302
       a0 = ts * tl_a.x; a1 = tt * tl_a.y;                                     // hshs_sum, hsht_sum (:309-310)
       a2 = tl_b.x * tl_a.x; a3 = tl_b.y * tl_a.y;                             // g.h (:119,123)
-      if (STORE && lane == 0) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+      if (STORE && lane_t == 0) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
     } else {
       const double mu = scal[S_MU];
       const double4 pr = PQ ? pqrow[row] : make_double4(0.0, 0.0, 0.0, 0.0);
@@ -327,11 +344,11 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
       const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
       if (PQ) a2 = pq_est_row(ap, ff.Zpq[tl_t], pr, qi, hq_all, gs_ - mu * gt_);
       else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
-      if (lane == 0) { gst[row] = make_double2(g1, g2); if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); } }
+      if (lane_t == 0) { gst[row] = make_double2(g1, g2); if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); } }
     }
   }
   int arrived = 0;
-  if (lane == 0) {
+  if (lane_t == 0) {
     s_row[wave][0] = a0; s_row[wave][1] = a1; s_row[wave][2] = a2; s_row[wave][3] = a3;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     arrived = __hip_atomic_fetch_add(&s_arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -339,12 +356,14 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   arrived = __builtin_amdgcn_readfirstlane(arrived);
   if (arrived != WIN_ROWS - 1) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (lane < 4) {
+  if (lane_t < 4) {
     double sum = 0.0;
 #pragma unroll
-    for (int w = 0; w < WIN_ROWS; ++w) sum += s_row[w][lane];                 // fixed order: the result does not depend on which wavefront is last
-    __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int w = 0; w < WIN_ROWS; ++w) sum += s_row[w][lane_t];                 // fixed order: the result does not depend on which wavefront is last
+    __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane_t, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  };
+  if (gh) whole(std::true_type{}); else whole(std::false_type{});
 }
 
 #ifdef RXMD_EXPERIMENTS
@@ -1273,6 +1292,10 @@ void Engine::qeq() {
       hipEventRecord(ev_pass[k & 1][0], stream);   // read once the host has confirmed that the iteration happened (a pass that returned at once is not timed)
       const int np1 = pass(MODE_HSH, true, wall, wgh);
       hipEventRecord(ev_pass[k & 1][1], stream);
+      // (round 6, measured and dropped: the pass finishing its own reduction -- chunks of 256 workgroups, the last to arrive adds its chunk, the last chunk
+      //  adds the chunk sums and runs the stage-1 algebra.  The launch of k_reduce_fused goes away, 81 -> 71-74 us per iteration outside the pass, but
+      //  every workgroup's last wavefront then waits for its four stores and a ticket before it frees the workgroup's LDS: the pass in the loop went from
+      //  0.877-0.880 to 0.919-0.924 ms, +36 us per iteration net; profiles/r06_ab_reduce_in_pass.txt)
       reduce(1, np1);
       k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag);
       // Est and the stop flags of this iteration travel to the host on the second stream, from the snapshot the update kernel's tail left: the

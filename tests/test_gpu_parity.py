@@ -518,7 +518,8 @@ def test_matrix_pass_without_the_software_pipeline_is_the_same_operator(qeq_mode
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("case,mc,qeq_mode", [("rdx222", (2, 2, 2), 0), ("rdx222", (2, 2, 2), 1), ("rdx168", (5, 5, 5), 1), ("ice644", (6, 4, 4), 1), ("sicnp", (1, 1, 1), 0), ("sicnp", (1, 1, 1), 1)])
+@pytest.mark.parametrize("case,mc,qeq_mode", [("rdx222", (2, 2, 2), 0), ("rdx222", (2, 2, 2), 1), ("rdx168", (5, 5, 5), 1), ("ice644", (6, 4, 4), 1), ("sicnp", (1, 1, 1), 0), ("sicnp", (1, 1, 1), 1),
+                                              ("example1", (2, 3, 5), 1), ("example1", (2, 3, 5), 0)])     # polyethylene: rows LONGER than two batches of the window pass (see below)
 def test_window_pass_and_row_pass_are_the_same_operator(case, mc, qeq_mode, monkeypatch):
     """The default QEq matrix pass (k_spmv_win) holds the partners of a group of 16 cell-sorted rows in LDS and reads them through a 16-bit
     slot per entry; RXMD_SPMV_WIN=0 is the wavefront-per-row pass with its 16-byte gather per entry (also the fallback when a window does
@@ -527,13 +528,21 @@ def test_window_pass_and_row_pass_are_the_same_operator(case, mc, qeq_mode, monk
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
     if case == "sicnp":
         kw["pqeq"] = oa.PQEQ_SICNP                  # PQEq: a third stream (shell-core matrix) over the same slots
-    o = _oracle(case, mc, **kw); o.qeq(); o.force()
+    o = _oracle(case, mc, **kw)
+    if "pqeq" in kw:
+        o.set_pqeq_clean(1)
+    o.qeq(); o.force()
     res = {}
     for win in ("1", "0"):
         monkeypatch.setenv("RXMD_SPMV_WIN", win)
         e = _engine(case, mc, qeq_mode=qeq_mode, **kw)
         it, est = e.QEq(); pe = e.FORCE(); a = e.atoms(); st = e.stats()
         assert st["win_in_use"] == int(win), st
+        if case.startswith("example"):
+            # rows of more than 512 entries: the window pass keeps two batches of 256 entries in flight and takes a THIRD trip through its loop here (the
+            # path that carried 48 bytes of scratch per lane until round 6; crystalline polyethylene has 0.13 atoms / A^3: ~545 entries at 10 A.  At PQEq's 12.5 A its ~1,050-entry rows need more window slots
+            # than a workgroup's LDS holds and the engine falls back to the row pass: test_reference_example3_small_box_pqeq_*)
+            assert st["max_n10"] > 512, st["max_n10"]
         assert (st["natoms"] + 15) // 16 <= st["win_groups"] <= st["natoms"] // 16 + st["cells10"][0] * st["cells10"][1] + 1 and 0 < st["win_max_units"] <= 448
         assert q_err(a["q"], o.charges()) <= QTOL
         assert f_err(a["f"], o.forces()) <= FTOL
@@ -552,7 +561,8 @@ def test_window_pass_and_row_pass_are_the_same_operator(case, mc, qeq_mode, monk
     # (how close: the step length of every iteration is rounded to REAL(4), qeq.F90:23,133 -- a last-bit difference of a row sum can move that
     #  rounding by one float ulp, 6e-8 of the step, and the two CG paths then run 1e-7 .. 1e-5 apart in Est while both are still far from the
     #  fixed point they share; measured 8.3e-6 of max |Est| on RDX 2 x 2 x 2.  A wrong or missing matrix entry shows at the first iteration.)
-    assert m >= 10 and np.abs(tw[:m] - tr[:m]).max() <= 5e-5 * np.abs(tr[:m]).max(), (len(tw), len(tr), np.abs(tw[:m] - tr[:m]).max())
+    # (polyethylene: nearly uniform charges, the CG is through after 7-8 iterations)
+    assert m >= (5 if case.startswith("example") else 10) and np.abs(tw[:m] - tr[:m]).max() <= 5e-5 * np.abs(tr[:m]).max(), (len(tw), len(tr), np.abs(tw[:m] - tr[:m]).max())
     assert np.abs(tw[:3] - tr[:3]).max() <= 1e-10 * np.abs(tr[:3]).max()          # start vector and first two iterations: rounding of the row sums only
     to = o.trace()[:, 0]                             # ... and against the oracle's own trace (sequential row sums, the reference's bit path)
     mo = min(m, len(to))
