@@ -258,6 +258,10 @@ int rxmd_host_ffield_table(const char *ffield_path, const long long *natoms_per_
  * low-gradient format (init/geninit.F90:233,347).  Process-wide like the reference's module variable; returns the previous value.
  * The engine itself takes the switch per handle (rxmd_config.lg). */
 int rxmd_host_ffield_lg(int on);
+/* The environment switches of the library (rxmd_amd/csrc/options.def: one table, read once per engine at rxmd_hip_create) as the markdown rows
+ * README.md shows: "| `ENV` | default | meaning |" per line, experiments-only switches marked (exp).  Returns the length of the text; copies at
+ * most capacity - 1 characters and a terminating 0 into buf (buf may be NULL to size). */
+int rxmd_host_describe_options(char *buf, int capacity);
 /* library build info: returns 1 if the HIP code object for gfx950 is linked in */
 int rxmd_hip_has_device_code(void);
 

@@ -99,8 +99,18 @@ SYMBOLS = [
     ("rxmd_host_read_rxff", C.c_longlong, [C.c_char_p, C.c_int, PD, PD, PD, C.c_longlong]),
     ("rxmd_host_ffield_table", C.c_int, [C.c_char_p, PD, C.c_int, PD, C.c_longlong]),
     ("rxmd_host_ffield_lg", C.c_int, [C.c_int]),
+    ("rxmd_host_describe_options", C.c_int, [C.c_char_p, C.c_int]),
     ("rxmd_hip_has_device_code", C.c_int, []),
 ]
+
+
+def describe_options():
+    """the environment switches of the library as the markdown rows of README.md (rxmd_amd/csrc/options.def); no GPU needed"""
+    lib = load()
+    n = lib.rxmd_host_describe_options(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.rxmd_host_describe_options(buf, n + 1)
+    return buf.value.decode()
 
 _lib = None
 

@@ -421,7 +421,7 @@ void Engine::thermostat(int mdmode, double treq_K, double vsfact, double gke) {
   const double UTEMP0 = 503.398008;                                  // module.F90:198
   const double treq = treq_K / UTEMP0;                               // init.F90:72
   if (mdmode == 0 || mdmode == 6) {                                  // main.F90:54-55 -> INITVELOCITY: fresh Gaussian velocities before the sums
-    static const unsigned long long seed = std::getenv("RXMD_SEED") ? std::strtoull(std::getenv("RXMD_SEED"), nullptr, 10) : 0x5DEECE66DULL;
+    const unsigned long long seed = static_cast<unsigned long long>(opt.seed);
     k_random_velocities<<<nblk(N, 256), 256, 0, stream>>>(N, seed, velocity_draws++, gid, vel[0], vel[1], vel[2]);
   }
   const bool need_sums = (mdmode == 0 || mdmode == 6 || mdmode == 7 || mdmode == 8 || (mdmode == 5 && gke <= 0.0));

@@ -961,15 +961,13 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
   BoxImg bx;
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
   bx.ortho = grid.ortho; bx.probe = 0;
-#ifdef RXMD_EXPERIMENTS
-  if (const char *pv = std::getenv("RXMD_E4B_PROBE")) bx.probe = std::atoi(pv);
-#endif
+  bx.probe = static_cast<int>(opt.e4b_probe);       // (experiments build only: 0 otherwise)
   // four atoms per wavefront when every bond list of this step fits 15 slots (h_err[2] = the largest list, read with the error word
   // after the list build); RXMD_E4B_SLOTS=32 forces the general kernel (tests)
   // instances (RXMD_E4B_SLOTS forces one, tests): packed eight atoms (default when no list of the step is longer than 15), two atoms
   // x 32 slots (32; default otherwise), packed four atoms (4: any list; on the SiC workload, 16+ bonds per atom, it needs two passes
   // for most groups and is slower than the default there, 3.69 against 3.47 ms), four atoms x 16 slots (16, needs lists <= 15)
-  const int want = std::getenv("RXMD_E4B_SLOTS") ? std::atoi(std::getenv("RXMD_E4B_SLOTS")) : 0;
+  const int want = static_cast<int>(opt.e4b_slots);
   const bool narrow = h_err[2] <= 15 && want != 32 && want != 4;
   const bool kt4 = kt_begin(&st.ms_k_e4b);
   if (want == 4) k_e4b<1><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,

@@ -279,11 +279,7 @@ static void upload_reference_arrays(Engine &e, int nbuffer, int natoms, const do
   for (int a = 0; a < 3; ++a) e.last_pos[a].assign(pos + a * static_cast<size_t>(nbuffer), pos + a * static_cast<size_t>(nbuffer) + natoms);
   // every call after the first (the engine is sized, its tables exist): the caller's arrays go to the device as they are -- no
   // 10-double records, no second copy of the coordinates; the packed type is split there (k_split_atype)
-#ifdef RXMD_EXPERIMENTS
-  const bool level1_records = std::getenv("RXMD_LEVEL1_RECORDS") != nullptr;     // (A/B: the old path through 10-double host records)
-#else
-  constexpr bool level1_records = false;
-#endif
+  const bool level1_records = e.opt.level1_records;     // (experiments build: A/B against the old path through 10-double host records)
   if (e.tables_ready && natoms <= e.rows10 && natoms < e.NB && !level1_records) {
     e.set_atoms_arrays(natoms, atype, pos, pos + static_cast<size_t>(nbuffer), pos + 2 * static_cast<size_t>(nbuffer), q,
                        lex ? e.lex_p.data() : nullptr, lex ? e.lex_v.data() : nullptr);

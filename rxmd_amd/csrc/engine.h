@@ -17,6 +17,7 @@
 
 #include "../../include/rxmd_hip.h"
 #include "ffparams.h"
+#include "options.h"
 
 namespace rxmd {
 
@@ -146,6 +147,7 @@ constexpr int WIN_BMW = 2048;       // 64-bit words of the coverage map the buil
 
 struct ScaleArgs;
 struct Engine {
+  const Options opt = Options::from_env();   // the environment switches of this engine (options.def), read once at create
   rxmd_config cfg{};
   std::string ffield_path, pqeq_path, err;
   ForceField ff;

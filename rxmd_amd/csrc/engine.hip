@@ -25,11 +25,12 @@ static const int dinv_[7] = {0, 2, 1, 4, 3, 6, 5};     // comm.F90:60
 // clear (module.F90:732-744); what it clears explicitly -- ccbnd, cdbnd, f, PE per FORCE call (pot.F90:20-26), spos and qtfp/qtfv at
 // allocation (init.F90:117-131) -- the kernels here clear too.  Buffers whose ZERO is part of a protocol (arrival counters, error words,
 // device scalars) are allocated with dzalloc.
-static const bool g_poison = std::getenv("RXMD_POISON_ALLOC") != nullptr && std::atoi(std::getenv("RXMD_POISON_ALLOC")) != 0;
+static const Options g_opt = Options::from_env();      // (allocation helpers are free functions: the library-wide copy of the switches)
+static const bool g_poison = g_opt.poison_alloc;
 #ifdef RXMD_EXPERIMENTS
 // RXMD_CONTIG_ALLOC=<bytes>: buffers of at most that many bytes (0: every buffer) come from hipExtMallocWithFlags(hipDeviceMallocContiguous) -- the
 // configuration that failed 15 unrelated tests in round 3 (NOTES.md 3); with RXMD_POISON_ALLOC=1 a read of stale memory shows as a NaN
-static const long long g_contig = std::getenv("RXMD_CONTIG_ALLOC") ? std::atoll(std::getenv("RXMD_CONTIG_ALLOC")) : -1;
+static const long long g_contig = g_opt.contig_alloc;
 #endif
 template <class T>
 static void dmalloc(T *&p, size_t n) {
@@ -113,10 +114,11 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
   }
   if (cfg.efield_dir != 0 && (!ff.pqeq || cfg.efield_dir < 1 || cfg.efield_dir > 3))
     throw EngineError(RXMD_E_ARG, "efield needs a PQEq parameter file (core charges Z) and a direction 1..3");
-  stage_pairs = std::getenv("RXMD_NO_STAGE_PAIRS") == nullptr;
-  force_staged = std::getenv("RXMD_FORCE_STAGED") != nullptr; force_remote = std::getenv("RXMD_FORCE_REMOTE") != nullptr;
-  if (const char *sw = std::getenv("RXMD_SPIN_WAIT")) spin_wait = std::atoi(sw) != 0;
-  halo_direct = std::getenv("RXMD_HALO_DIRECT") != nullptr && std::atoi(std::getenv("RXMD_HALO_DIRECT")) != 0;
+  stage_pairs = !opt.no_stage_pairs;
+  force_staged = opt.force_staged; force_remote = opt.force_remote;
+  spin_wait = opt.spin_wait != 0;
+  halo_direct = opt.halo_direct;
+  comm_timeout_s = opt.comm_timeout_s;
   MAXNB = cfg.maxneighbs > 0 ? cfg.maxneighbs : 30;
   if (MAXNB > 31) throw EngineError(RXMD_E_ARG, "maxneighbs must be <= 31 (the wavefront-per-centre kernels stage the bond slots of two atoms in one 64-lane wavefront; the reference uses 30)");
   int ndev = 0;
@@ -128,13 +130,13 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
     if (pr.sharedMemPerBlock < size_t(80) * 1024) throw EngineError(RXMD_E_HIP, "device " + std::to_string(cfg.device) + " offers " + std::to_string(pr.sharedMemPerBlock) + " bytes of LDS per workgroup; the kernels are written for gfx950 (MI355X, 160 KB per CU) and need 80 KB"); }
   RX_HIP(hipStreamCreate(&stream));
   for (int k = 0; k < 64; ++k) { KtPair p; RX_HIP(hipEventCreate(&p.a)); RX_HIP(hipEventCreate(&p.b)); kt_free.push_back(p); }
-  if (std::getenv("RXMD_SINGLE_STREAM")) comm_stream = stream;   // diagnostic: the halo work queues on the main stream (no second hardware queue)
+  if (opt.single_stream) comm_stream = stream;   // diagnostic: the halo work queues on the main stream (no second hardware queue)
   else {                                         // highest priority: pack / send-recv / unpack kernels of a halo go ahead of the queued compute workgroups
     int lo = 0, hi = 0;
     RX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     RX_HIP(hipStreamCreateWithPriority(&comm_stream, hipStreamDefault, hi));
   }
-  if (!std::getenv("RXMD_SINGLE_STREAM") && !std::getenv("RXMD_NO_BOND_OVERLAP")) {   // the charge-free part of FORCE next to ENbond (engine.h: bond_stream); lowest priority
+  if (!opt.single_stream && !opt.no_bond_overlap) {   // the charge-free part of FORCE next to ENbond (engine.h: bond_stream); lowest priority
     int lo = 0, hi = 0;
     RX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     RX_HIP(hipStreamCreateWithPriority(&bond_stream, hipStreamDefault, lo));
@@ -384,7 +386,7 @@ void Engine::alloc_device() {
   {   // 5.3 bonds per RDX atom, ~16 in SiC: 12 per atom slot to start with, grown when a build needs more (build_ghosts_and_lists).
       // RXMD_BOND_CAP=<bonds>: start smaller (the tests walk the growth path with it; a capacity, not a result)
     size_t cap = std::min<size_t>(ns, nb * 12);
-    if (const char *bc = std::getenv("RXMD_BOND_CAP")) { const long long v = std::atoll(bc); if (v > 0) cap = static_cast<size_t>(v); }
+    if (opt.bond_cap > 0) cap = static_cast<size_t>(opt.bond_cap);
     alloc_bond_tables(cap);
   }
   ehb_don_cap = static_cast<size_t>(rows10) + 64 * 256 + 256; dmalloc(ehb_don, ehb_don_cap); dzalloc(ehb_cnt, 72);   // 64 sub-lists (bonded.hip EHB_REGIONS) + debug words
@@ -485,9 +487,7 @@ void Engine::set_atoms_rxff(int natoms, const double *rec) {
     const double vloc = box.volume / nprocs;
     const double est10 = nsize / vloc * (4.0 / 3.0) * 3.14159265358979 * ff.rctap * ff.rctap2;
     int s10 = cfg.maxneighbs10 > 0 ? cfg.maxneighbs10 : static_cast<int>(est10 * 1.35 + 64);
-#ifdef RXMD_EXPERIMENTS
-    if (const char *ev_s10 = std::getenv("RXMD_S10")) { const int v = std::atoi(ev_s10); if (v > 0 && cfg.maxneighbs10 <= 0) s10 = v; }   // experiment: row stride of the 10 A list
-#endif
+    if (opt.s10 > 0 && cfg.maxneighbs10 <= 0) s10 = static_cast<int>(opt.s10);   // (experiments build: row stride of the 10 A list)
     S10 = (s10 + 63) / 64 * 64;
     rows10 = std::min<long long>(NB, nsize + nsize / 8 + 1024);
     if (ff.nso > 15) throw EngineError(RXMD_E_ARG, "more than 15 atom types do not fit the packed 10 A list entry");
@@ -1610,7 +1610,7 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   nbonds = h_err[7]; nbonds_res = h_err[9];
   win_groups = h_err[8];                               // groups of this build (build_windows; the sweep ran over the host-side bound)
   max_row10 = h_err[3]; min_row10 = std::min(h_err[4], h_err[3]);   // longest / shortest 10 A row of this build (k_list10)
-  win_maxunits = h_err[5]; win_valid = win_groups > 0 && h_err[6] == 0 && win_maxunits > 0 && (!multi() || (win_nbnd >= 0 && win_nbnd <= win_groups)) && std::getenv("RXMD_SPMV_NO_WIN") == nullptr;   // window form of the matrix (build_windows)
+  win_maxunits = h_err[5]; win_valid = win_groups > 0 && h_err[6] == 0 && win_maxunits > 0 && (!multi() || (win_nbnd >= 0 && win_nbnd <= win_groups)) && !opt.spmv_no_win;   // window form of the matrix (build_windows)
   collect_timers();
   st.ms_lists += toc(0, 1);
   lists_valid = true;

@@ -603,9 +603,7 @@ void Engine::build_bonded_list(bool pack_only) {
 
 constexpr int L10_ROWS_LAUNCH = L10_ROWS;
 void Engine::build_list10() {
-#ifdef RXMD_EXPERIMENTS
-  if (const char *pv = std::getenv("RXMD_LIST_PROBE")) grid.probe = std::atoi(pv);
-#endif
+  grid.probe = static_cast<int>(opt.list_probe);    // (experiments build only: 0 otherwise)
   if (list10_retry) build_prologue(2);                              // (a first build of the step had them from build_prologue(3) at the head of the build)
   // an atom can meet its own image within rctap only if some box edge is shorter than 2*rctap
   const bool selfcheck = (grid.wid[0] < 2.0 * ff.rctap + 1.0) || (grid.wid[1] < 2.0 * ff.rctap + 1.0) || (grid.wid[2] < 2.0 * ff.rctap + 1.0);

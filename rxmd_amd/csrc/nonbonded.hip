@@ -201,7 +201,7 @@ void Engine::nonbonded(bool to_fnb) {
   double *f0 = to_fnb ? fnb[0] : frc[0], *f1 = to_fnb ? fnb[1] : frc[1], *f2 = to_fnb ? fnb[2] : frc[2];
   const int assign = to_fnb ? 1 : 0;
   // over the windows of the matrix pass when this list build has them and no atom can meet its own image (RXMD_NONBOND_WIN=0: the row form)
-  static const bool win_env = std::getenv("RXMD_NONBOND_WIN") == nullptr || std::atoi(std::getenv("RXMD_NONBOND_WIN")) != 0;
+  const bool win_env = opt.nonbond_win != 0;
   const int units = std::min(win_maxunits, 296);                         // 296 units x 8 slots x 33 bytes = 78 KB: two workgroups per CU
   const size_t lds = static_cast<size_t>(units) * WIN_UNIT * (sizeof(double4) + 1) + 16;
   if (win_valid && win_env && !list_selfcheck) {

@@ -11,7 +11,7 @@
 // Est (the convergence quantity, qeq.F90:297-306) is produced by the GRADIENT pass of the previous
 // iteration: sum_j H_ij q_j = sum_j H_ij qs_j - mu sum_j H_ij qt_j, with the reference's
 // "count resident partners twice" rule kept through a second accumulator over ghost columns.
-#include "engine.h"
+#include "spmv_kernels.h"
 
 #include <chrono>
 #include <map>
@@ -28,625 +28,6 @@
 
 namespace rxmd {
 
-static inline int nblk(long long n, int b) { return n > 0 ? static_cast<int>((n + b - 1) / b) : 1; }   // an empty rank still launches (kernels guard their range)
-
-enum { S_MU = 0, S_LMIN_S, S_LMIN_T, S_GOLD_S, S_GOLD_T, S_GNEW_S, S_GNEW_T, S_EST, S_GH_S, S_GH_T, S_HSH_S, S_HSH_T, S_SSUM, S_TSUM, S_BETA_S, S_BETA_T, S_RAW0, S_RAW1, S_RAW2, S_RAW3, S_RAW4, S_RAW5, S_RAW6, S_RAW7, S_STOP, S_STOP1, S_TOL, S_COUNT };
-enum { MODE_HSH = 0, MODE_GRAD = 1 };
-constexpr int S_SNAP = 128;      // scal[S_SNAP + 32 p ..]: snapshot of the scalars of an iteration of parity p (scalar_algebra stage 6)
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-#ifndef SPMV_UNR
-#define SPMV_UNR 4
-#endif
-constexpr int UNR = SPMV_UNR;
-__device__ inline double wave_sum(double v) { return wave_sum64(v); }   // DPP reduction, engine.h
-
-template <int NC>
-__device__ inline void block_store_partials(double (&acc)[NC], double *partials, int ncomp_stride) {
-  // acc holds lane-0-of-wave partials; combine the block's waves in wave order, then one store per component
-  __shared__ double sm[16][NC];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  if (lane == 0)
-    for (int c = 0; c < NC; ++c) sm[w][c] = acc[c];
-  __syncthreads();
-  if (threadIdx.x < NC) {
-    double s = 0.0;
-    for (int k = 0; k < nw; ++k) s += sm[k][threadIdx.x];
-    // device-scope store: written through to the coherence point, so the in-kernel tail (block_finish) needs no L2 write-back
-    __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * ncomp_stride + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// PQEq (pqrow != nullptr): the second pair of sums (gs_,gt_) is over the shell-core matrix hsc instead of the ghost columns;
-// gradient gets the field term fpqeq (pqeq.F90:466), Est the core/shell terms of pqeq.F90:381-411 without the resident doubling
-__device__ inline double pq_est_row(const DevAtomP &ap, double Zi, const double4 &pr, double qi, double hq, double bq) {
-  return ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * (qi + Zi) * (hq + pr.y) + pr.w - (bq + pr.z);
-}
-// STORE (qeq_mode 1): additionally keep the raw row sums (all columns / ghost columns) so that the next gradient and Est
-// follow from  H.(q + l h) = H.q + l H.h  with N-sized vector kernels instead of a second matrix pass.
-// One wavefront = one row (the launch covers the rows exactly), 16 rows per workgroup: workgroup dispatch is not free at a million
-// wavefronts per pass (measured 1.25 / 1.24 / 1.15-1.19 / 1.13 / 1.08-1.11 ms at 1 / 2 / 4 / 8 / 16 wavefronts per workgroup; splitting
-// a row over 2 or 4 wavefronts instead: 1.22 / 2.19 ms).  The pass is bound by
-// LATENCY x occupancy, not by instruction issue: a wavefront lives for a chain of dependent memory round trips (row length ->
-// the two streams -> the gathers -> the operands of the tail), so (a) the tail operands are requested first, next to the row
-// length, (b) four batches of 64 entries are in flight instead of eight, which brings the kernel from 99 to <= 80 VGPRs and from
-// 4 to 6 wavefronts per SIMD (measured on one box: 1.276 ms -> 1.21 with (a), 1.157 with (b), 1.06-1.12 with both), (c) PQEq is
-// a template parameter so that the plain kernel does not carry its code.
-// PIPE (default; RXMD_SPMV_NO_PIPE=1 switches it off): the first batch of the two streams is requested BEFORE the row length is known (it lies
-// inside the row's S10-entry slot whatever the length; entries behind the row's end get weight 0 once the length has arrived), one
-// dependent round trip less per wavefront.  Measured 0.98 -> 0.93 ms per pass on one box and no difference on another (0.941 / 0.949 /
-// 0.938): the pass is insensitive to its latency chain.  It is insensitive to the BYTES of its streams too: a 16-bit column stream
-// (stencil column + offset in the column's run, 10 instead of 12 bytes per entry) gave 0.968 vs 0.988 ms without the early request and
-// 0.931 vs 0.921 ms with it; requesting every batch ahead of the previous one's gathers, a tighter row stride (448 or 512 instead of
-// 640 entries) and skipping the ghost-column sums on the three rows in four that have no ghost partner (7 % SLOWER: the flag is one
-// more scalar round trip in front of the loop) changed nothing or lost.  All were dropped again; see NOTES.md 3.
-template <int MODE, bool STORE, bool PQ, int PIPE>
-__global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
-                                               const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
-                                               const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
-                                               const double *__restrict__ scal, double *__restrict__ partials,
-                                               double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
-                                               const double *__restrict__ hsc, const double4 *__restrict__ pqrow, int swz,
-                                               const int *__restrict__ rowlist, int nrows, int pbase, const double *__restrict__ stopflag) {
-  if (stopflag && *stopflag != 0.0) return;        // run-ahead CG loop: the iteration this launch belongs to was decided not to happen (scalar_algebra stage 6)
-  // rowlist != nullptr: this launch covers nrows rows named by the list (interior or boundary rows of a multi-rank domain);
-  // its workgroups write their partial sums behind the pbase workgroups of the other launch
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  // the row is the same for the 64 lanes: say so (readfirstlane), and the row's base addresses, its length and the loop bounds live in
-  // scalar registers -- 44 instead of 57 VGPRs and scalar address arithmetic: 1.03-1.09 -> 0.95 ms per pass on the same box
-  const int widx = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int row = rowlist ? (widx < nrows ? rowlist[widx] : N) : widx;
-  // the row tails of a workgroup are run by the first lanes of its wavefront 0 after the barrier the partial sums need anyway -- the
-  // operands of consecutive rows (type, hst / qst, gst / q) and their results (row sums, gradient) are then a handful of coalesced requests
-  // per workgroup instead of five per row (k_spmv_bisect: tail operands, row stores and partials are 6-8 % of the pass)
-  __shared__ double s_row[16][4];
-  const int wave_in_wg = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  if (row < N) {
-    const size_t base = static_cast<size_t>(row) * S10;
-    unsigned e[UNR];
-    double h[UNR], c[UNR];
-    // one batch of the row's streams (entry, hessian value, PQEq: shell-core value) for entries [kb, kb + 256) below `bound`
-    auto request = [&](int kb, int bound, unsigned (&ee)[UNR], double (&hh)[UNR], double (&cc)[UNR]) {
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int k = kb + lane + 64 * u;
-        const bool ok = k < bound;
-        ee[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;   // streamed once: keep it out of
-        hh[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;                        // the caches that hold the vector
-        if (PQ && (MODE == MODE_GRAD || STORE)) cc[u] = ok ? __builtin_nontemporal_load(hsc + base + k) : 0.0;
-      }
-    };
-    if (PIPE) request(0, S10, e, h, c);
-    const int n = n10[row] & N10_COUNT;
-    double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    if (PIPE) {                                    // entries behind the row's end get weight 0
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) { const bool ok = lane + 64 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; if (PQ) c[u] = ok ? c[u] : 0.0; }
-    }
-    for (int kb = 0; kb < n; kb += 64 * UNR) {   // wave-uniform trip count
-      if (PIPE == 0 || (PIPE == 1 && kb > 0)) request(kb, n, e, h, c);
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {            // one 16-byte gather per entry from the cell-sorted vector copy
-        const double2 v = xv[e[u] & NB10_IDX_MASK];
-        as += h[u] * v.x;
-        at += h[u] * v.y;
-        if ((MODE == MODE_GRAD || STORE) && !PQ) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }   // select the weight, not the sums
-        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u] * v.x; gt_ += c[u] * v.y; }      // PQEq: second matrix (shell-core) over the same columns
-      }
-    }
-    as = wave_sum(as); at = wave_sum(at);
-    if (MODE == MODE_GRAD || STORE) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-    if (lane == 0) { s_row[wave_in_wg][0] = as; s_row[wave_in_wg][1] = at; s_row[wave_in_wg][2] = gs_; s_row[wave_in_wg][3] = gt_; }
-  }
-  __syncthreads();
-  if (wave_in_wg != 0) return;
-  {
-    const int r_idx = (swz ? xcd_swizzle(blockIdx.x, gridDim.x) : static_cast<int>(blockIdx.x)) * wpb + lane;     // lane r = the row of wavefront r
-    const int r = (lane < wpb) ? (rowlist ? (r_idx < nrows ? rowlist[r_idx] : N) : r_idx) : N;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (r < N) {
-      const double as = s_row[lane][0], at = s_row[lane][1], gs_ = s_row[lane][2], gt_ = s_row[lane][3];
-      const int t = type[r];
-      const double2 pa = (MODE == MODE_HSH) ? hst[r] : qst[r];
-      const DevAtomP ap = ff.atom[t];
-      if (STORE) { rs_all[r] = make_double2(as, at); rs_gh[r] = make_double2(gs_, gt_); }
-      if (MODE == MODE_HSH) {
-        const double2 pb = gst[r];
-        const double ts = ap.eta * pa.x + as, tt = ap.eta * pa.y + at;          // qeq.F90:294-302
-        a0 = ts * pa.x; a1 = tt * pa.y;                                         // hshs_sum, hsht_sum (:309-310)
-        a2 = pb.x * pa.x; a3 = pb.y * pa.y;                                     // g.h (:119,123)
-      } else {
-        const double mu = scal[S_MU];
-        const double fpq = PQ ? pqrow[r].x : 0.0;
-        const double g1 = -ap.chi - ap.eta * pa.x - as - fpq;                   // qeq.F90:349-350 (pqeq.F90:466)
-        const double g2 = -1.0 - ap.eta * pa.y - at;
-        gst[r] = make_double2(g1, g2);
-        a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
-        const double qi = q[r];
-        const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
-        if (PQ) a2 = pq_est_row(ap, ff.Zpq[t], pqrow[r], qi, hq_all, gs_ - mu * gt_);
-        else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
-      }
-    }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);           // fixed order over the workgroup's rows
-    if (lane < 4) {
-      const double v = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
-      __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// ---- window pass (k_spmv_win) -------------------------------------------------------------------------------------------------------------
-// The 16 rows of a group (consecutive residents in cell-sorted order, engine.h WIN_*) couple to nearly the same partners: ~1,500 cell-sorted
-// positions for ~430 entries per row.  The workgroup copies the vector entries of that window into LDS with coalesced loads (8 consecutive
-// positions = one 128-byte line per unit) and every row reads its partners from there: a 16-bit slot per entry (bit 15: ghost column) replaces
-// the 4-byte entry and the 16-byte gather per entry through the vector memory path disappears.  Streams: value 8 + slot 2 bytes per entry, two
-// entries per lane and request (16-byte / 4-byte loads), 256 entries of a row in flight.  Same sums in the same per-row roles as k_spmv; the
-// order in which a row's products are added differs (lane = entry pair), i.e. the last bits of a row sum do.
-// (A timing probe with synthetic slots promised 0.76 against 0.93 ms of k_spmv before anything real was built; the real pass: 0.80 against 0.89 ms
-// back to back in one process, NOTES.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
-// FORM (bit set): WIN_PREFETCH = the second batch of a row is requested before the workgroup's barrier; WIN_LEAN = groups without a ghost partner skip the
-// ghost-column sums; WIN_RANKROWS = experiments build only.  Plain QEq runs WIN_PREFETCH | WIN_LEAN (one-trip rows: WIN_LEAN), PQEq 0.
-[[maybe_unused]] constexpr int WIN_RANKROWS = 1;
-constexpr int WIN_PREFETCH = 2, WIN_LEAN = 4;
-template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR = FORM bits; VAR & 2: the second batch of a row is requested before the workgroup's barrier (below); VAR & 4: groups without a ghost partner skip the ghost-column sums (below); the default of plain QEq is 6.  NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
-__global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
-                                                            const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
-                                                            const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
-                                                            const double2 *__restrict__ qst, const double *__restrict__ q, const int *__restrict__ type,
-                                                            const double *__restrict__ scal, double *__restrict__ partials,
-                                                            double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
-                                                            const double *__restrict__ hsc, const double4 *__restrict__ pqrow,
-                                                            const int *__restrict__ grouplist, int ngroups, int pbase, const double *__restrict__ stopflag,
-                                                            const int *__restrict__ gflags = nullptr) {
-  if (stopflag && *stopflag != 0.0) return;
-  extern __shared__ double2 s_x[];                  // the window: slot -> (xs, xt)
-  __shared__ double s_row[WIN_ROWS][4];
-  __shared__ int s_arrived;
-  constexpr int STEPS = NSTEP;
-  constexpr int NT = 64 * WIN_ROWS;
-  typedef double d2v __attribute__((ext_vector_type(2)));
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int gidx = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int grp = grouplist ? (gidx < ngroups ? grouplist[gidx] : -1) : (gidx < ngroups ? gidx : -1);
-  if (grp < 0) return;                              // (whole workgroup)
-  // Round trip 1: everything that needs only the group number -- the row of this wavefront, the window's size, the first positions of the
-  // window units this thread will copy (two rounds of 1,024 slots cover 256 units; the descriptor row is WIN_MAXUNITS long whatever the count).
-  const int ridx = grp * WIN_ROWS + wave;
-  const int row = min(rows_sorted[ridx], N);        // (a cell column's last group may be short: those slots hold a sentinel >= N)
-  const int nslots = WIN_UNIT * win_cnt[grp];
-  const int *wk = win_k + static_cast<size_t>(grp) * WIN_MAXUNITS;
-  const int t0 = threadIdx.x, t1 = threadIdx.x + NT;
-  const int wk0 = wk[t0 / WIN_UNIT], wk1 = wk[t1 / WIN_UNIT];                      // (t1 / 8 < 256 <= WIN_MAXUNITS)
-  const bool live = row < N;
-#ifdef RXMD_EXPERIMENTS
-  const size_t base = static_cast<size_t>(live ? ((VAR & WIN_RANKROWS) ? ridx : row) : 0) * S10;       // (VAR & 1, experiment: the streams' rows in cell-sorted order)
-#else
-  const size_t base = static_cast<size_t>(live ? row : 0) * S10;
-#endif
-  const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
-  const d2v *cv2 = reinterpret_cast<const d2v *>((PQ ? hsc : hess) + base);
-  const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
-  // VAR & 4: a group none of whose rows has a ghost partner (gflags[grp] == 0: three groups in four of a large domain) takes a body WITHOUT the
-  // ghost-column sums -- two selects and four FMAs of the twelve vector instructions per pair of entries, and two of the four reductions.  The flag
-  // rides with round trip 1 and the choice is ONE scalar branch per workgroup around two complete copies of everything below (round 6: as two loops
-  // inside one body the compiler kept the first batches alive for "the other loop" and paid with folded spills under the 64-register cap -- 48 B of
-  // scratch per lane, 20 after the register sets took turns, 0 now).
-  const bool gh = !((VAR & WIN_LEAN) != 0 && !PQ && gflags != nullptr) || gflags[grp] != 0;
-  auto whole = [&](auto ghc) {
-  constexpr bool GHC = decltype(ghc)::value;
-  double2 v[STEPS], c[STEPS]; unsigned ss[STEPS];
-  auto request = [&](int kb, int bound) {          // entries kb + 128 u + 2 lane and the next one
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-      const int k = kb + 128 * u + 2 * lane;
-      const bool ok = k < bound;
-      if (ok) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); v[u] = make_double2(t2.x, t2.y); } else v[u] = make_double2(0.0, 0.0);
-      ss[u] = ok ? __builtin_nontemporal_load(sl2 + (k >> 1)) : 0u;
-      if (PQ && (MODE == MODE_GRAD || STORE)) { if (ok) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); c[u] = make_double2(t2.x, t2.y); } else c[u] = make_double2(0.0, 0.0); }
-    }
-  };
-  // Round trip 2: the window's vector entries FIRST (they return first, and the workgroup's barrier waits for them only), then the row's
-  // first batch -- before the row length is known: it lies inside the row's slot whatever the length -- the length, and the operands of the
-  // row's tail (the row is the same for the 64 lanes: scalar loads, no vector registers).
-  double2 x0 = make_double2(0.0, 0.0), x1 = x0;
-  if (t0 < nslots) x0 = xv[min(wk0 + (t0 & (WIN_UNIT - 1)), G - 1)];
-  if (t1 < nslots) x1 = xv[min(wk1 + (t1 & (WIN_UNIT - 1)), G - 1)];
-  request(0, live ? S10 : 0);
-  const int n = live ? (n10[row] & N10_COUNT) : 0;
-  const int rowc = live ? row : 0;
-  const int tl_t = type[rowc];
-  const double2 tl_a = (MODE == MODE_HSH) ? hst[rowc] : qst[rowc];
-  const double2 tl_b = (MODE == MODE_HSH) ? const_cast<const double2 *>(gst)[rowc] : make_double2(q[rowc], 0.0);
-  if (threadIdx.x == 0) s_arrived = 0;
-  if (t0 < nslots) s_x[t0] = x0;
-  if (t1 < nslots) s_x[t1] = x1;
-  for (int t = threadIdx.x + 2 * NT; t < nslots; t += NT) s_x[t] = xv[min(wk[t / WIN_UNIT] + (t & (WIN_UNIT - 1)), G - 1)];   // a window of more than 256 units
-#pragma unroll
-  for (int u = 0; u < STEPS; ++u) {                // entries behind the row's end: weight 0, slot 0
-    const int k = 128 * u + 2 * lane;
-    if (k >= n) { v[u].x = 0.0; ss[u] &= 0xffff0000u; if (PQ) c[u].x = 0.0; }
-    if (k + 1 >= n) { v[u].y = 0.0; ss[u] &= 0x0000ffffu; if (PQ) c[u].y = 0.0; }
-  }
-  // VAR & 2 (plain QEq): the row's NEXT batch is requested before the barrier, behind the window's data (a wavefront's loads return in order:
-  // the window does not wait for it) -- the round trip of the second batch runs under the barrier and the first batch's arithmetic instead of
-  // after it; the batch after that is requested before the current one is used, and so on.
-  constexpr bool PRE = (VAR & WIN_PREFETCH) != 0 && !PQ;
-  double2 vn[STEPS]; unsigned sn[STEPS];
-  auto request_next = [&](int kb) {
-#pragma unroll
-    for (int u = 0; u < STEPS; ++u) {
-      const int k = kb + 128 * u + 2 * lane;
-      const bool ok = k < n;
-      if (ok) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); vn[u] = make_double2(t2.x, t2.y); } else vn[u] = make_double2(0.0, 0.0);
-      sn[u] = ok ? __builtin_nontemporal_load(sl2 + (k >> 1)) : 0u;
-    }
-  };
-  if (PRE && n > 128 * STEPS) request_next(128 * STEPS);
-  __syncthreads();
-  double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    auto batch = [&](const double2 (&vv)[STEPS], const unsigned (&sv)[STEPS]) {      // one batch of 128 x STEPS entries out of registers and the LDS window
-#pragma unroll
-      for (int u = 0; u < STEPS; ++u) {
-        const double2 y0 = s_x[sv[u] & 0x7fffu], y1 = s_x[(sv[u] >> 16) & 0x7fffu];
-        as += vv[u].x * y0.x; at += vv[u].x * y0.y; as += vv[u].y * y1.x; at += vv[u].y * y1.y;
-        if (GHC && (MODE == MODE_GRAD || STORE) && !PQ) {
-          const double g0 = (sv[u] & 0x8000u) ? vv[u].x : 0.0, g1 = (sv[u] & 0x80000000u) ? vv[u].y : 0.0;     // select the weight, not the sums
-          gs_ += g0 * y0.x; gt_ += g0 * y0.y; gs_ += g1 * y1.x; gt_ += g1 * y1.y;
-        }
-        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * y0.x; gt_ += c[u].x * y0.y; gs_ += c[u].y * y1.x; gt_ += c[u].y * y1.y; }
-      }
-    };
-    constexpr int B = 128 * STEPS;
-    if (PRE) {
-      // Two register sets take turns (round 6): batch k sits in (v, ss) for even k and in (vn, sn) for odd k, and the batch after the next one is
-      // requested into the set that has just been used.  Until round 6 the loop rotated `v = vn` at its head: under the 64-register cap of eight
-      // workgroups per CU that copy went through 48 bytes of scratch per lane on every row longer than two batches (rows > 512 entries: any
-      // condensed system at PQEq's 12.5 A cut-off, dense metals) -- and cost ten moves per row on the others.  Same products in the same order.
-      for (int kb = 0;;) {                               // wave-uniform trip count
-        batch(v, ss);
-        kb += B; if (kb >= n) break;
-        if (kb + B < n) request(kb + B, n);               // (an odd row end: entry n is the zero padding of the row, slot 0)
-        batch(vn, sn);
-        kb += B; if (kb >= n) break;
-        if (kb + B < n) request_next(kb + B);
-      }
-    } else {
-      for (int kb = 0; kb < n; kb += B) {                 // wave-uniform trip count
-        if (kb > 0) request(kb, n);
-        batch(v, ss);
-      }
-    }
-
-  as = wave_sum(as); at = wave_sum(at);
-  if ((MODE == MODE_GRAD || STORE) && GHC) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-  // The row's tail by its own wavefront (the rows of a group are scattered residents: nothing would coalesce if one wavefront ran all of them,
-  // and a workgroup whose last wavefront works alone keeps 15 wavefront slots of the CU empty); a wavefront leaves when it is done.  The
-  // workgroup's four partial sums: every wavefront leaves its terms in LDS, the LAST one to arrive adds them in wavefront order.
-  // the lane number afresh (two mbcnt instructions): `lane` kept alive across the loop for these four uses was the one register the PQ instances spilled
-  const int lane_t = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  if (live) {
-    const DevAtomP ap = ff.atom[tl_t];
-    if (MODE == MODE_HSH) {
-      const double ts = ap.eta * tl_a.x + as, tt = ap.eta * tl_a.y + at;      // qeq.F90:294-302
-      a0 = ts * tl_a.x; a1 = tt * tl_a.y;                                     // hshs_sum, hsht_sum (:309-310)
-      a2 = tl_b.x * tl_a.x; a3 = tl_b.y * tl_a.y;                             // g.h (:119,123)
-      if (STORE && lane_t == 0) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
-    } else {
-      const double mu = scal[S_MU];
-      const double4 pr = PQ ? pqrow[row] : make_double4(0.0, 0.0, 0.0, 0.0);
-      const double g1 = -ap.chi - ap.eta * tl_a.x - as - pr.x;                // qeq.F90:349-350 (pqeq.F90:466)
-      const double g2 = -1.0 - ap.eta * tl_a.y - at;
-      a0 = g1 * g1; a1 = g2 * g2;                                             // Gnew (:355-356)
-      const double qi = tl_b.x;
-      const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
-      if (PQ) a2 = pq_est_row(ap, ff.Zpq[tl_t], pr, qi, hq_all, gs_ - mu * gt_);
-      else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
-      if (lane_t == 0) { gst[row] = make_double2(g1, g2); if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); } }
-    }
-  }
-  int arrived = 0;
-  if (lane_t == 0) {
-    s_row[wave][0] = a0; s_row[wave][1] = a1; s_row[wave][2] = a2; s_row[wave][3] = a3;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    arrived = __hip_atomic_fetch_add(&s_arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  arrived = __builtin_amdgcn_readfirstlane(arrived);
-  if (arrived != WIN_ROWS - 1) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (lane_t < 4) {
-    double sum = 0.0;
-#pragma unroll
-    for (int w = 0; w < WIN_ROWS; ++w) sum += s_row[w][lane_t];                 // fixed order: the result does not depend on which wavefront is last
-    __hip_atomic_store(partials + (static_cast<size_t>(pbase) + blockIdx.x) * 4 + lane_t, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  };
-  if (gh) whole(std::true_type{}); else whole(std::false_type{});
-}
-
-#ifdef RXMD_EXPERIMENTS
-// ---- where does the row kernel's time go?  Stripped-down forms of k_spmv, timed in isolation (debug tap 102; experiments only) -------
-//   LEVEL 0: the two streams of a row only (4 x 64 entries per trip as k_spmv), one sum, one wavefront reduction, no store
-//   LEVEL 1: + the 16-byte gather per entry and the two FMAs
-//   LEVEL 2: + the ghost-column sums and all four reductions
-//   LEVEL 3: + the tail operands (type, hst, gst of the row)   LEVEL 4: + the two 16-byte row stores
-//   LEVEL 5: + the per-workgroup partials with their barrier (= the work of k_spmv<HSH, STORE>)   LEVEL 6: as 5 with ONE 32-byte row store
-template <int LEVEL>
-__global__ void __launch_bounds__(1024) k_spmv_bisect(int N, int S10, const int *__restrict__ nb10, const double *__restrict__ hess, const int *__restrict__ n10,
-                                                      const double2 *__restrict__ xv, const double2 *__restrict__ hst, const double2 *__restrict__ gst,
-                                                      const int *__restrict__ type, double *__restrict__ partials, double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh, double *__restrict__ sink) {
-  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-  const int row = xcd_swizzle(blockIdx.x, gridDim.x) * wpb + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (row < N) {
-    const size_t base = static_cast<size_t>(row) * S10;
-    unsigned e[UNR];
-    double h[UNR];
-    auto request = [&](int kb, int bound) {
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int k = kb + lane + 64 * u;
-        const bool ok = k < bound;
-        e[u] = ok ? static_cast<unsigned>(__builtin_nontemporal_load(nb10 + base + k)) : 0u;
-        h[u] = ok ? __builtin_nontemporal_load(hess + base + k) : 0.0;
-      }
-    };
-    request(0, S10);
-    const int n = n10[row] & N10_COUNT;
-    int pf_t = 0; double2 pf_a = make_double2(0, 0), pf_b = make_double2(0, 0);
-    if (LEVEL >= 3) { pf_t = type[row]; pf_a = hst[row]; pf_b = gst[row]; }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) { const bool ok = lane + 64 * u < n; e[u] = ok ? e[u] : 0u; h[u] = ok ? h[u] : 0.0; }
-    double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    for (int kb = 0; kb < n; kb += 64 * UNR) {
-      if (kb > 0) request(kb, n);
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        if (LEVEL == 0) { as += h[u] * static_cast<double>(e[u] & 255u); }
-        else {
-          const double2 v = xv[e[u] & NB10_IDX_MASK];
-          as += h[u] * v.x; at += h[u] * v.y;
-          if (LEVEL >= 2) { const double hg = (e[u] & NB10_GHOST) ? h[u] : 0.0; gs_ += hg * v.x; gt_ += hg * v.y; }
-        }
-      }
-    }
-    as = wave_sum(as);
-    if (LEVEL >= 1) at = wave_sum(at);
-    if (LEVEL >= 2) { gs_ = wave_sum(gs_); gt_ = wave_sum(gt_); }
-    if (lane == 0) {
-      if (LEVEL >= 3) {
-        if (LEVEL == 4 || LEVEL == 5) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
-        if (LEVEL == 6) reinterpret_cast<double4 *>(sink)[row + 1] = make_double4(as, at, gs_, gt_);      // (sink: a 32-byte-per-row buffer for this level)
-        acc[0] = (0.5 * pf_a.x + as) * pf_a.x; acc[1] = (0.5 * pf_a.y + at) * pf_a.y; acc[2] = pf_b.x * pf_a.x + pf_t; acc[3] = pf_b.y * pf_a.y;
-        if (LEVEL == 3 && acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e-300) sink[0] = as;
-      } else if (as + at + gs_ + gt_ == 1.2345e-300) sink[0] = as;       // keeps the sums alive
-    }
-  }
-  if (LEVEL >= 5) block_store_partials<4>(acc, partials, 4);
-}
-void spmv_bisect_ms(Engine &e, double *out4) {
-  const int rb = nblk(e.N, 16);
-  double *buf32 = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&buf32), sizeof(double) * 4 * (static_cast<size_t>(e.N) + 2)) != hipSuccess) return;
-  auto run = [&](auto lv) {
-    constexpr int L = decltype(lv)::value;
-    for (int r = 0; r < 11; ++r) {
-      if (r == 1) hipEventRecord(e.ev[2], e.stream);
-      k_spmv_bisect<L><<<rb, 1024, 0, e.stream>>>(e.N, e.S10, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.type, e.partials, e.wall, e.wgh, buf32);
-    }
-    hipEventRecord(e.ev[3], e.stream); hipEventSynchronize(e.ev[3]);
-    float ms = 0; hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
-    return static_cast<double>(ms) / 10.0;
-  };
-  out4[0] = run(std::integral_constant<int, 0>{}); out4[1] = run(std::integral_constant<int, 1>{});
-  out4[2] = run(std::integral_constant<int, 2>{}); out4[3] = run(std::integral_constant<int, 3>{});
-  out4[4] = run(std::integral_constant<int, 4>{}); out4[5] = run(std::integral_constant<int, 5>{}); out4[6] = run(std::integral_constant<int, 6>{});
-  (void)hipFree(buf32);
-}
-
-__global__ void k_rows_to_rank_order(int N, int S10, const int *__restrict__ rows_sorted, const double *__restrict__ h, const unsigned short *__restrict__ sl, double *__restrict__ h2, unsigned short *__restrict__ s2) {
-  const int r = blockIdx.x;                          // destination row = rank
-  if (r >= N) return;
-  const size_t src = static_cast<size_t>(rows_sorted[r]) * S10, dst = static_cast<size_t>(r) * S10;
-  for (int k = threadIdx.x; k < S10; k += blockDim.x) { h2[dst + k] = h[src + k]; s2[dst + k] = sl[src + k]; }
-}
-// the real window pass and the real row pass back to back, alternating in ONE process (timings repeat to 0.1 % inside a process and differ
-// by +-6 % between processes on the same box, so variants are compared here, compiled side by side) (debug tap 104; experiments only)
-void spmv_isolated_ms(Engine &e, double *out) {
-  for (int k = 0; k < 20; ++k) out[k] = -1.0;
-  const int reps = std::getenv("RXMD_ISO_REPS") ? std::max(1, std::atoi(std::getenv("RXMD_ISO_REPS"))) : 10;
-  auto timed = [&](auto launch) {
-    for (int r = 0; r < reps + 1; ++r) {
-      if (r == 1) hipEventRecord(e.ev[2], e.stream);
-      launch();
-    }
-    hipEventRecord(e.ev[3], e.stream); hipEventSynchronize(e.ev[3]);
-    float ms = 0; hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
-    return static_cast<double>(ms) / reps;
-  };
-  if (e.ff.pqeq) return;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const int rounds = 3;                             // the three kernels alternate: one state of the box for all of them
-  for (int rd = 0; rd < rounds; ++rd) {
-    if (e.win_valid) {
-      const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
-      acc[0] += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-    }
-    acc[1] += timed([&] { k_spmv<MODE_HSH, true, false, 1><<<nblk(e.N, 16), 1024, 0, e.stream>>>(e.N, e.S10, e.dff, e.nb10, e.hess, e.n10, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, 1, nullptr, e.N, 0, nullptr); });
-  }
-  out[1] = acc[1] / rounds;
-  if (e.win_valid) {                               // variant: 384 entries in flight
-    const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
-    double a3 = 0.0;
-    for (int rd = 0; rd < rounds; ++rd)
-      a3 += timed([&] { k_spmv_win<MODE_HSH, true, false, 3><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-    out[2] = a3 / rounds;
-    double a4 = 0.0;                                // variant: second batch requested before the barrier (VAR & 2)
-    for (int rd = 0; rd < rounds; ++rd)
-      a4 += timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 2><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-    out[3] = a4 / rounds;
-    double a5 = 0.0;                                // the default once more, after the variants (drift of the box)
-    for (int rd = 0; rd < rounds; ++rd)
-      a5 += timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-    out[4] = a5 / rounds;
-    {   // interior groups without the ghost-column sums (VAR & 4), with and without the prefetch; default after them once more
-      double b0 = 0.0, b1 = 0.0, b2 = 0.0;
-      for (int rd = 0; rd < rounds; ++rd) {
-        b0 += timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 6><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr, e.win_flag); });
-        b1 += timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 2><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-        b2 += timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 4><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr, e.win_flag); });
-      }
-      out[5] = b0 / rounds; out[6] = b1 / rounds; out[7] = b2 / rounds;
-    }
-  }
-  // RXMD_ISO_COPIES=1: does the pass time depend on WHERE its streams lie?  Four copies of the value and slot arrays held at the same time, the
-  // pass on each, twice round (out[2..9]): a property of the buffer repeats in the second round, a drift in time does not.  out[10]: the last
-  // copy with its rows in cell-sorted order, read without the row indirection.
-  if (e.win_valid && std::getenv("RXMD_ISO_COPIES")) {
-    const size_t ne = static_cast<size_t>(e.rows10) * e.S10;
-    const size_t lds = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
-    double *h2[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned short *s2[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ok = true;
-    for (int c = 0; c < 4 && ok; ++c) {
-      if (c >= 2) {                                  // copies C and D: physically contiguous, if the driver grants it
-        ok = hipExtMallocWithFlags(reinterpret_cast<void **>(&h2[c]), ne * sizeof(double), hipDeviceMallocContiguous) == hipSuccess &&
-             hipExtMallocWithFlags(reinterpret_cast<void **>(&s2[c]), ne * sizeof(unsigned short), hipDeviceMallocContiguous) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); std::fprintf(stderr, "contiguous allocation refused\n"); if (h2[c]) { (void)hipFree(h2[c]); h2[c] = nullptr; } if (s2[c]) { (void)hipFree(s2[c]); s2[c] = nullptr; } }
-      }
-      if (c < 2 || !ok)
-      ok = hipMalloc(reinterpret_cast<void **>(&h2[c]), ne * sizeof(double)) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&s2[c]), ne * sizeof(unsigned short)) == hipSuccess;
-      if (ok) { hipMemcpyAsync(h2[c], e.hess, ne * sizeof(double), hipMemcpyDeviceToDevice, e.stream); hipMemcpyAsync(s2[c], e.sl10, ne * sizeof(unsigned short), hipMemcpyDeviceToDevice, e.stream); }
-    }
-    if (ok) {
-      for (int round2 = 0; round2 < 2; ++round2)
-        for (int c = 0; c < 4; ++c)
-          out[2 + 4 * round2 + c] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2[c], h2[c], e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-      k_rows_to_rank_order<<<e.N, 256, 0, e.stream>>>(e.N, e.S10, e.rows_sorted, e.hess, e.sl10, h2[3], s2[3]);
-      out[10] = timed([&] { k_spmv_win<MODE_HSH, true, false, 2, 1><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, s2[3], h2[3], e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-      out[11] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-    } else (void)hipGetLastError();
-    for (int c = 0; c < 4; ++c) { if (h2[c]) (void)hipFree(h2[c]); if (s2[c]) (void)hipFree(s2[c]); }
-    // ... and on ONE allocation with the value array at different offsets inside it (out[12..19]): a dependence on low address bits would show here
-    {
-      static const size_t offs[8] = {0, 4096, 65536, size_t(1) << 20, (size_t(2) << 20) + 4096, size_t(16) << 20, (size_t(37) << 20) + 8192, size_t(64) << 20};
-      char *big = nullptr;
-      if (hipMalloc(reinterpret_cast<void **>(&big), ne * sizeof(double) + (size_t(65) << 20)) == hipSuccess) {
-        for (int c = 0; c < 8; ++c) {
-          double *hh = reinterpret_cast<double *>(big + offs[c]);
-          hipMemcpyAsync(hh, e.hess, ne * sizeof(double), hipMemcpyDeviceToDevice, e.stream);
-          out[12 + c] = timed([&] { k_spmv_win<MODE_HSH, true, false><<<e.win_groups, 64 * WIN_ROWS, lds, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, hh, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr); });
-        }
-        (void)hipFree(big);
-      } else (void)hipGetLastError();
-    }
-  }
-  if (e.win_valid) out[0] = acc[0] / rounds;      // out[2], out[3]: variants of the window pass (template parameter VAR) when some are being compared
-}
-
-
-// ---- timing probe: the symmetric matrix read ONCE over 3-D tiles (debug tap 105; experiments only) -----------------------------------
-// What a half-storage pass would cost before any of it is built: a workgroup of 16 wavefronts owns a tile of TILE_ROWS rows and holds the vector AND an
-// accumulator for TILE_WS window slots in LDS (x 16 B + y 16 B per slot: 147 KB, one workgroup per CU).  Per entry of a HALF row: value (8 B) + slot (2 B)
-// streamed as in the real pass, the partner's x from LDS, two FMAs into the row's sums and two LDS atomic adds H_ij x_i into the partner's accumulator;
-// at the end the accumulators leave as plain coalesced stores (a second kernel gathers a row's ~23 halo contributions in a fixed order: k_tile_gather_probe).
-// The bytes are real (the engine's own value / slot arrays, the first half of every row), the slots are scrambled into the tile's window (the LDS access
-// pattern of a 3-D tile: uniformly spread), the arithmetic is what the real pass would do.  Results mean nothing; times do.
-constexpr int TILE_ROWS = 416, TILE_WS = 4608;
-template <bool TRANSPOSED>     // false: the forward products only (what the streams and the LDS reads cost at one workgroup per CU)
-__global__ void __launch_bounds__(1024, 1) k_spmv_tile_probe(int N, int G, int S10, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
-                                                            const double2 *__restrict__ xv, double2 *__restrict__ rs_all, double2 *__restrict__ ybuf) {
-  extern __shared__ double2 s_xy[];                 // [0, TILE_WS): x ; [TILE_WS, 2 TILE_WS): y
-  double2 *s_x = s_xy, *s_y = s_xy + TILE_WS;
-  typedef double d2v __attribute__((ext_vector_type(2)));
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int row0 = tile * TILE_ROWS;
-  const size_t wbase = (static_cast<size_t>(tile) * 1531u) % static_cast<size_t>(max(G - TILE_WS, 1));
-  for (int t = threadIdx.x; t < TILE_WS; t += 1024) { s_x[t] = xv[wbase + t]; s_y[t] = make_double2(0.0, 0.0); }
-  // two rows of a wavefront in flight: the next row's batch is requested before the current row's arithmetic (512 entries per wavefront in flight)
-  d2v v[2][2]; unsigned ss[2][2]; int nh[2] = {0, 0};
-  auto request = [&](int buf, int row) {
-    const bool live = row < N && row < row0 + TILE_ROWS;
-    const size_t base = static_cast<size_t>(live ? row : 0) * S10;
-    const d2v *hv2 = reinterpret_cast<const d2v *>(hess + base);
-    const unsigned *sl2 = reinterpret_cast<const unsigned *>(sl10 + base);
-    nh[buf] = live ? ((n10[row] & N10_COUNT) + 1) / 2 : 0;                       // half of the row's entries
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int k = 128 * u + 2 * lane;
-      const bool ok = live && k < S10 / 2;
-      v[buf][u] = ok ? __builtin_nontemporal_load(hv2 + (k >> 1)) : d2v{0.0, 0.0};
-      ss[buf][u] = ok ? __builtin_nontemporal_load(sl2 + (k >> 1)) : 0u;
-    }
-  };
-  request(0, row0 + wave);
-  __syncthreads();
-  int cur = 0;
-  for (int r = row0 + wave; r < row0 + TILE_ROWS; r += 16) {
-    request(cur ^ 1, r + 16);
-    const int n = nh[cur];
-    const double2 xi = s_x[(r * 11) % TILE_WS];
-    double as = 0.0, at = 0.0;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int k = 128 * u + 2 * lane;
-      const unsigned s0 = ((ss[cur][u] & 0x7fffu) * 13u + lane * 71u) % TILE_WS, s1 = (((ss[cur][u] >> 16) & 0x7fffu) * 13u + lane * 71u + 37u) % TILE_WS;
-      const double h0 = k < n ? v[cur][u].x : 0.0, h1 = k + 1 < n ? v[cur][u].y : 0.0;
-      const double2 y0 = s_x[s0], y1 = s_x[s1];
-      as += h0 * y0.x; at += h0 * y0.y; as += h1 * y1.x; at += h1 * y1.y;
-      if (TRANSPOSED && k < n) { __hip_atomic_fetch_add(&s_y[s0].x, h0 * xi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&s_y[s0].y, h0 * xi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      if (TRANSPOSED && k + 1 < n) { __hip_atomic_fetch_add(&s_y[s1].x, h1 * xi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(&s_y[s1].y, h1 * xi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-    }
-    as = wave_sum(as); at = wave_sum(at);
-    if (lane == 0 && r < N) rs_all[r] = make_double2(as, at);
-    cur ^= 1;
-  }
-  __syncthreads();
-  double2 *yb = ybuf + static_cast<size_t>(blockIdx.x) * TILE_WS;
-  for (int t = threadIdx.x; t < TILE_WS; t += 1024) __builtin_nontemporal_store(s_y[t].x, &yb[t].x), __builtin_nontemporal_store(s_y[t].y, &yb[t].y);
-}
-// the second kernel of that scheme: a row adds the contributions its slot received in the ~23 tiles whose window holds it, in a fixed order
-__global__ void __launch_bounds__(256) k_tile_gather_probe(int N, int ntiles, const double2 *__restrict__ ybuf, double2 *__restrict__ rs_all) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= N) return;
-  const int tile = r / TILE_ROWS;
-  double2 a = rs_all[r];
-  for (int c = 0; c < 23; ++c) {
-    const int t2 = (tile + (c % 3 - 1) + 3 * ((c / 3) % 3 - 1) * 7 + 9 * (c / 9 - 1) * 41 + ntiles) % ntiles;      // neighbours in a 3-D arrangement of the tiles
-    const double2 y = ybuf[static_cast<size_t>(t2) * TILE_WS + (static_cast<unsigned>(r) * 29u + c * 613u) % TILE_WS];
-    a.x += y.x; a.y += y.y;
-  }
-  rs_all[r] = a;
-}
-void spmv_tile_probe_ms(Engine &e, double *out) {
-  for (int k = 0; k < 5; ++k) out[k] = -1.0;
-  if (e.ff.pqeq || e.G < TILE_WS + 16) return;
-  const int ntiles = (e.N + TILE_ROWS - 1) / TILE_ROWS;
-  double2 *ybuf = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&ybuf), sizeof(double2) * static_cast<size_t>(ntiles) * TILE_WS) != hipSuccess) { (void)hipGetLastError(); return; }
-  const size_t lds = sizeof(double2) * 2 * TILE_WS;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spmv_tile_probe<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) { (void)hipGetLastError(); }
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spmv_tile_probe<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) { (void)hipGetLastError(); }
-  auto timed = [&](auto launch) {
-    for (int r = 0; r < 11; ++r) { if (r == 1) hipEventRecord(e.ev[2], e.stream); launch(); }
-    hipEventRecord(e.ev[3], e.stream); hipEventSynchronize(e.ev[3]);
-    float ms = 0; hipEventElapsedTime(&ms, e.ev[2], e.ev[3]);
-    return static_cast<double>(ms) / 10.0;
-  };
-  out[0] = timed([&] { k_spmv_tile_probe<true><<<ntiles, 1024, lds, e.stream>>>(e.N, e.G, e.S10, e.sl10, e.hess, e.n10, e.xs, e.wall, ybuf); });
-  out[4] = timed([&] { k_spmv_tile_probe<false><<<ntiles, 1024, lds, e.stream>>>(e.N, e.G, e.S10, e.sl10, e.hess, e.n10, e.xs, e.wall, ybuf); });
-  out[1] = timed([&] { k_tile_gather_probe<<<nblk(e.N, 256), 256, 0, e.stream>>>(e.N, ntiles, ybuf, e.wall); });
-  if (e.win_valid) {                                 // the real pass in the same process, after the probes
-    const size_t ldsw = static_cast<size_t>(e.win_maxunits) * WIN_UNIT * sizeof(double2);
-    out[2] = timed([&] { k_spmv_win<MODE_HSH, true, false, 2, WIN_PREFETCH | WIN_LEAN><<<e.win_groups, 64 * WIN_ROWS, ldsw, e.stream>>>(e.N, e.G, e.S10, e.dff, e.sl10, e.hess, e.n10, e.rows_sorted, e.win_k, e.win_cnt, e.xs, e.hst, e.gst, e.qst, e.q, e.type, e.scal, e.partials, e.wall, e.wgh, e.hsc, e.pqrow, nullptr, e.win_groups, 0, nullptr, e.win_flag); });
-  }
-  out[3] = (hipGetLastError() == hipSuccess) ? 0.0 : 1.0;
-  (void)hipFree(ybuf);
-}
-
-#endif   // RXMD_EXPERIMENTS
 
 __global__ void __launch_bounds__(256) k_stream_probe(size_t n16, const f64x2 *__restrict__ a, double *__restrict__ out) {
   double s = 0.0;
@@ -959,8 +340,7 @@ void Engine::allreduce_scal4(int n) {
 // box, default bench: 52.4-54.1 ms/step with the search against 53.4-55.6 without (the pass in the loop follows the kept placement + 0.03-0.04 ms).
 void Engine::tune_window_placement() {
   place_tuned = true;
-  const char *ev_t = std::getenv("RXMD_PLACE_TRIES");
-  const int tries = ev_t ? std::atoi(ev_t) : 10;       // (round 4: the draws of one box lie between 0.80 and 0.93 ms, a third of them fast: ten draws miss the fast kind in 3 % of the processes, six in 12 %)
+  const int tries = static_cast<int>(opt.place_tries);       // (round 4: the draws of one box lie between 0.80 and 0.93 ms, a third of them fast: ten draws miss the fast kind in 3 % of the processes, six in 12 %)
   if (tries <= 1 || !win_valid || N < 65536) return;              // (small systems: nothing to gain)
   const size_t ne = static_cast<size_t>(rows10) * S10;
   {   // a candidate needs a second copy of the streams while it is timed (6.3 GB at 979,776 atoms): not on a device that is nearly full
@@ -990,9 +370,9 @@ void Engine::tune_window_placement() {
   // (oh, os); repeated for <slabs> fresh allocations.  If the time followed the relative position of the two streams (channel / stack aliasing),
   // it would show as a pattern in os that repeats from slab to slab; a time that changes from slab to slab but not with the offsets inside one
   // says the draw is the physical pages the driver hands out.  Output: one line per measurement on stderr (scripts/gpu_place_scan.sh).
-  if (const char *scan = std::getenv("RXMD_PLACE_SCAN")) {
+  if (opt.place_scan > 0) {
     if (!ff.pqeq) {
-      const int nslab = std::max(1, std::atoi(scan));
+      const int nslab = std::max(1, static_cast<int>(opt.place_scan));
       const size_t MB2 = size_t(2) << 20, hb = ne * sizeof(double), sb = ne * sizeof(unsigned short);
       const size_t pad = size_t(64) << 20, total = hb + sb + 3 * pad;
       const size_t offs[] = {0, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, size_t(1) << 20, (size_t(1) << 20) + 4096, size_t(2) << 20, size_t(4) << 20, size_t(8) << 20, size_t(16) << 20, size_t(32) << 20};
@@ -1099,16 +479,16 @@ void Engine::tune_window_placement() {
   {
     std::lock_guard<std::mutex> lk(seen_mx);
     auto it = seen_best.find(shape);
-    if (it != seen_best.end() && best <= 1.03 * it->second && std::getenv("RXMD_PLACE_ALL") == nullptr) {
+    if (it != seen_best.end() && best <= 1.03 * it->second && !opt.place_all) {
       st.place_ms_kept = best;
       st.place_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search0).count();
       return;
     }
   }
   constexpr size_t PLACE_MAX_HELD = 3;
-  const bool verbose = std::getenv("RXMD_PLACE_VERBOSE") != nullptr;
+  const bool verbose = opt.place_verbose;
   if (verbose) std::fprintf(stderr, "[rxmd_hip] placement draw 0: %.4f ms  hess %p sl10 %p\n", best, static_cast<void *>(hess), static_cast<void *>(sl10));
-  const bool draw_all = std::getenv("RXMD_PLACE_ALL") != nullptr;      // diagnosis: no early stop
+  const bool draw_all = opt.place_all;      // diagnosis: no early stop
   // The losers stay allocated until the search is over: a block that is freed comes straight back from the next hipMalloc of its size, and the
   // "next draw" would be the same physical placement again (round 4: a process that kept its first placement at 0.90 ms after ten such draws,
   // while a second process on the same box found 0.82 ms).  Each draw costs a copy of the streams while the search runs, bounded by free memory.
@@ -1166,11 +546,7 @@ void Engine::qeq() {
   tic(6);
   const KtPair t_qeq = outer_begin(&st.ms_qeq);
   // the list sweep of this step can form the row sums of the start vector on the way (saves the matrix pass of qeq.F90:87)
-#ifdef RXMD_EXPERIMENTS
-  static const bool prepass_on = (std::getenv("RXMD_QEQ_NO_PREPASS") == nullptr);
-#else
-  constexpr bool prepass_on = true;
-#endif
+  const bool prepass_on = !opt.qeq_no_prepass;      // (experiments build only)
   sums_from_list = false;
   if (!lists_valid) build_ghosts_and_lists(prepass_on);
   const int nmax = (cfg.isQEq == 1) ? cfg.NMAXQEq : 1;
@@ -1183,13 +559,9 @@ void Engine::qeq() {
   // workgroup per CU that tail is short -- 45.8 / 39.3 / 33.8 / 32.6 us per launch at 2048 / 1024 / 512 / 256 workgroups, 68 at 4096
   const int vb_upd = std::min(nblk(N, 256), 256);
   double *lvl1 = partials + partials_cap;      // 128 x 4 first-level sums live behind the per-workgroup partials (fixed offset: independent of the cell count of a sparse box)
-#ifdef RXMD_EXPERIMENTS
-  static const int swz = std::getenv("RXMD_NO_XCD_SWIZZLE") ? 0 : 1;
-#else
-  constexpr int swz = 1;
-#endif
-  const bool pipe = (std::getenv("RXMD_SPMV_NO_PIPE") == nullptr);        // read per call: the tests switch it
-  const bool win_env = std::getenv("RXMD_SPMV_WIN") == nullptr || std::atoi(std::getenv("RXMD_SPMV_WIN")) != 0;   // read per call: the tests switch it
+  const int swz = opt.no_xcd_swizzle ? 0 : 1;       // (experiments build only)
+  const bool pipe = !opt.spmv_no_pipe;
+  const bool win_env = opt.spmv_win != 0;
   // returns the number of partial-sum sets (of four) the launch leaves behind partials[pbase * 4]
   const double *stopflag = nullptr;            // run-ahead CG loop only: kernels of an iteration return at once when scal[S_STOP] is set
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) -> int {
@@ -1251,27 +623,18 @@ void Engine::qeq() {
   }
   k_direction<<<nblk(N, 256), 256, 0, stream>>>(N, 1, scal, gst, hst);
   RX_HIP(hipMemcpyAsync(h_scal, scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, stream));
-#ifdef RXMD_EXPERIMENTS
-  const bool est_with_update_ = (std::getenv("RXMD_EST_SEPARATE") == nullptr);
-#else
-  constexpr bool est_with_update_ = true;
-#endif
+  const bool est_with_update_ = !opt.est_separate;  // (experiments build only)
   // run-ahead loop (below): iteration 0 always happens -- the exit tests of qeq.F90:114-115 compare Est with GEst2 = 1e99 -- so the host does not
   // wait for Est of the start vector; it reads it (for the trace) when the first iteration's Est arrives, which is later in stream order
-  const bool start_async = !multi() && cfg.qeq_mode == 1 && !ff.pqeq && est_with_update_ && std::getenv("RXMD_CG_NO_RUNAHEAD") == nullptr && nmax >= 1;
+  const bool start_async = !multi() && cfg.qeq_mode == 1 && !ff.pqeq && est_with_update_ && !opt.cg_no_runahead && nmax >= 1;
   if (!start_async) sync_stream();
   double GEst2 = 1e99, Est = start_async ? 0.0 : h_scal[S_EST];
   est_trace.clear(); est_trace.push_back(Est);      // Est of the start vector, then of every iteration (debug tap 13: the reference's QEQDUMP trace)
   int it = 0;
   float ms = 0;
   bool xs_current = false;       // the fused direction kernel leaves the sorted copy of the new (hs,ht) in xs
-  const bool overlap_on = (std::getenv("RXMD_NO_HALO_OVERLAP") == nullptr);     // read per call: the tests switch it
-#ifdef RXMD_EXPERIMENTS
-  const bool est_with_update = (std::getenv("RXMD_EST_SEPARATE") == nullptr);
-  const bool cg_scatter = (std::getenv("RXMD_CG_NO_SCATTER") == nullptr);
-#else
-  constexpr bool est_with_update = true, cg_scatter = true;
-#endif
+  const bool overlap_on = !opt.no_halo_overlap;
+  const bool est_with_update = !opt.est_separate, cg_scatter = !opt.cg_no_scatter;     // (experiments build only)
   const bool overlap = overlap_on && multi() && onepass && !rows_split_pending_invalid();
   bool halo_in_flight = false, q_pending = false;
   // ---- run-ahead loop (single rank, qeq_mode 1, plain QEq; RXMD_CG_NO_RUNAHEAD=1 switches it off) ------------------------------------
@@ -1280,7 +643,7 @@ void Engine::qeq() {
   // kernels of an iteration that is not to happen return at once; the host reads the same flag.  Iteration counts, charges and every
   // sum are those of the loop below -- what changes is that no host round trip lies between two iterations (on a host that shares its
   // cores with other jobs the blocking loop lost 90 us per iteration: 172 against 80 us of everything that is not the matrix pass).
-  const bool runahead = !multi() && onepass && !ff.pqeq && est_with_update && std::getenv("RXMD_CG_NO_RUNAHEAD") == nullptr;
+  const bool runahead = !multi() && onepass && !ff.pqeq && est_with_update && !opt.cg_no_runahead;
   if (runahead) {
     auto exit_test = [&](double prev, double est) {
       return (0.5 * (std::fabs(prev) + std::fabs(est)) < cfg.QEq_tol) || (std::fabs(prev) > 0.0 && std::fabs(est / prev - 1.0) < cfg.QEq_tol);

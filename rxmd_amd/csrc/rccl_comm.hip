@@ -33,7 +33,6 @@ void Engine::rccl_init(const unsigned char id128[128], int rank, int world) {
   ncclComm_t c;
   RX_NCCL(ncclCommInitRank(&c, world, id, rank));
   nccl = c;
-  if (const char *t = std::getenv("RXMD_COMM_TIMEOUT_S")) { const double v = std::atof(t); if (v > 0.0) comm_timeout_s = v; }
   int nr = 0;
   RX_NCCL(ncclCommCount(c, &nr));
   if (nr != world) throw EngineError(RXMD_E_COMM, "RCCL communicator has " + std::to_string(nr) + " ranks, expected " + std::to_string(world));

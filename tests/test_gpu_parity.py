@@ -233,17 +233,21 @@ def test_iteration_statistics_over_1000_steps(qeq_mode, win, monkeypatch):
     relative change of Est over a steepest-descent step from nearly converged charges is below 1e-7 -- sometimes several steps in a row, the charges
     drifting ~4e-5 from the converged solution per such step), so no test can pin it; its STATISTICS over many calls above one cell can be pinned.
     RDX 2 x 2 x 2, 1000 MD steps at the bench settings, both QEq algebras, window pass and row pass, against the reference's own numbers over the same
-    1000 steps (tests/golden/rdx222_md1000.npz: `rxmd` itself, iteration counts; rdx222_md1000_dq.npz: the bit-path oracle, which reproduces those
-    counts call by call, + the distance of its charges from the converged solution of each geometry):
-      reference: mean 30.50 iterations per step over steps 11..1000 (one cell: 24; steps 6..25: 36 -- neither is the bar), 9.7 % one-iteration exits,
-                 longest run 6, |dq| against converged: median 5.6e-6, 90th percentile 7.9e-5, 99th 4.1e-4, worst 6.7e-4.
+    1000 steps (tests/golden/rdx222_md1000.npz: `rxmd` itself, iteration counts; rdx222_md1000_dq.npz: the bit-path oracle + the distance of its
+    charges from the converged solution of each geometry):
+      reference: mean 30.82 iterations per step over steps 11..1000 (one cell: 24; steps 6..25: 36 -- neither is the bar), 9.0 % one-iteration exits;
+      oracle:    30.50, 9.7 %, longest run 6, |dq| against converged: median 5.6e-6, 90th percentile 7.9e-5, 99th 4.1e-4, worst 6.7e-4.
     Gates: mean within 10 %; one-iteration exits within a factor 1.6 either way; 90th percentile <= 1.5 x, 99th <= 2 x, worst step <= 3 x the reference's
     (tails of 1000 samples; the four variants measured 0.6-0.9 x, 0.7-1.1 x, 0.8-1.6 x: scripts/gpu_iterstat.py, profiles/r06_iterstat1000.log)."""
     import rxmd_amd
     monkeypatch.setenv("RXMD_SPMV_WIN", win)
     g = np.load(os.path.join(oa.GOLD, "rdx222_md1000.npz")); gd = np.load(os.path.join(oa.GOLD, "rdx222_md1000_dq.npz"))
     ref_its = g["qeq_iters"]; ref_dq = gd["dq_tight"]
-    assert np.array_equal(ref_its, gd["qeq_iters"])                    # the oracle stayed on the reference's bit path for all 1001 calls
+    # the oracle reproduces the reference's count call by call for the first 369 calls (and for every shorter golden); there one call takes 38 instead of 36
+    # iterations -- a last-bit difference somewhere flipped one REAL(4) rounding -- and from then on the two are different draws of the SAME statistics:
+    # mean 30.50 / 30.82 iterations, 9.7 % / 9.0 % one-iteration exits.  Iteration statistics are held against the reference's own run, the distance from
+    # the converged charges against the oracle's.
+    assert np.array_equal(ref_its[:369], gd["qeq_iters"][:369]) and abs(gd["qeq_iters"][11:].mean() - ref_its[11:].mean()) < 0.02 * ref_its[11:].mean()
     ref_mean = ref_its[11:].mean(); ref_ones = (ref_its[11:] <= 1).mean()
     e = _engine("rdx222", (2, 2, 2), qeq_mode=qeq_mode)
     t = rxmd_amd.RxmdEngine(oa.make_system("rdx222")[0], e.lattice, QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=0)

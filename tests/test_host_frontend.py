@@ -244,3 +244,24 @@ def test_default_library_carries_no_work_skipping_switch():
     blob = open(os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "librxmd_hip.so"), "rb").read()
     for word in (b"_PROBE", b"RXMD_S10", b"RXMD_LEVEL1_RECORDS", b"RXMD_ISO_", b"RXMD_NO_XCD_SWIZZLE", b"RXMD_QEQ_NO_PREPASS", b"k_spmv_bisect"):
         assert word not in blob, word
+
+
+def test_readme_lists_the_switches_of_the_library():
+    """one table of environment switches (rxmd_amd/csrc/options.def), read once per engine at rxmd_hip_create; README.md shows exactly what the
+    libraries themselves print (rxmd_host_describe_options; regenerate with scripts/gen_readme_options.py), and no other translation unit calls getenv"""
+    import glob, re, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import gen_readme_options as gro
+    prod, exp = gro.blocks()
+    rows = [l for l in prod.split("\n") if l]
+    assert len(rows) >= 20 and all(re.match(r"^\| `RXMD_[A-Z0-9_]+` \| [^|]+ \| .+ \|$", l) for l in rows) and "(exp)" not in prod and "_PROBE" not in prod
+    readme = open(os.path.join(root, "README.md")).read()
+    a = readme.index("<!-- options:begin"); b = readme.index("<!-- options:end -->")
+    assert prod in readme[a:b], "README.md is out of date: python scripts/gen_readme_options.py"
+    if exp is not None:                              # the experiments build is present (it is not part of build(); the GPU box gets whatever was built here)
+        a = readme.index("<!-- options-exp:begin"); b = readme.index("<!-- options-exp:end -->")
+        assert exp in readme[a:b], "README.md is out of date: python scripts/gen_readme_options.py"
+    for f in glob.glob(os.path.join(root, "rxmd_amd", "csrc", "*")):
+        if f.endswith((".hip", ".cpp", ".h")) and not f.endswith("options.cpp"):
+            assert "getenv" not in open(f).read(), f
