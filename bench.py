@@ -294,7 +294,7 @@ def compact_line(full, limit=7600):
     """the line for stdout: every key of the driver's contract, `roofline` and `cpu_baseline` without their tables, the per-rank record of an N > 1
     run, and -- LAST, so that a recorded tail holds it -- `legs`: one short record per leg (steady, isQEq 2, the other algebra, water, SiC-NP + PQEq ...)."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-            "ns_per_day", "atom_steps_per_s", "qeq_iters_per_step", "ms_qeq_per_iter", "n10", "nb", "bond_overlap", "energy_per_atom", "bench_wall_s", "full_record")
+            "ns_per_day", "atom_steps_per_s", "qeq_iters_per_step", "ms_qeq_per_iter", "n10", "nb", "bond_overlap", "timer_pairs_dropped", "energy_per_atom", "bench_wall_s", "full_record")
     out = {k: full[k] for k in keep if k in full}
     r = dict(full["roofline"])
     rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_real_traffic", "frac_streamed", "algorithmic_bytes_per_launch", "bytes_per_entry",
@@ -739,6 +739,7 @@ def main():
             "breakdown_ms_per_step": {k: st.get(k, 0.0) / a.steps for k in ("ms_qeq", "ms_qeq_spmv", "ms_lists", "ms_force", "ms_bo", "ms_nonbond", "ms_bonded", "ms_k_blist",
                                                                     "ms_ghost_build", "ms_migrate", "ms_halo", "ms_halo_exposed", "ms_allreduce", "ms_fold", "ms_k_winbuild", "ms_bond_exposed")},
             "bond_overlap": st.get("bond_overlap", 0),
+            "timer_pairs_dropped": st.get("timer_pairs_dropped", 0),      # > 0: the ms_* breakdown of the timed region under-counts (rxmd_stats)
             "energy_per_atom": {"PE": en["PE"][0] / natoms, "KE": en["KE"] / natoms, "qsum": en["qsum"]},
         }
         if per_rank:

@@ -184,7 +184,9 @@ typedef struct rxmd_stats {
   /* (append-only) the charge-free part of FORCE (bond orders, bonded terms, assembly: ms_bo, ms_bonded, ms_k_e3b ... are its stream times) runs on a
    * stream of its own next to the QEq iterations and ENbond: what of it the main stream had to WAIT for in front of the stress sums, and 1 when it ran so */
   double ms_bond_exposed;
-  int bond_overlap, reserved4;
+  int bond_overlap;
+  int timer_pairs_dropped;              /* event pairs the ms_* timers could not get since rxmd_hip_reset_timers (the pool of 64 ran dry: long rxmd_hip_step calls without a list build or
+                                         * a CG loop to collect them): when > 0 the ms_* breakdown under-counts */
 } rxmd_stats;
 int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out);
 int rxmd_hip_reset_timers(rxmd_handle h);

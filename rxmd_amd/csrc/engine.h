@@ -379,7 +379,7 @@ struct Engine {
   int kt_open = -1;                                // (one nesting level is enough: begin ... end on the stream current at the time)
   KtPair kt_cur{};
   bool kt_begin(double *dst, double *dst2 = nullptr, long long *cnt = nullptr) {
-    if (kt_free.empty() || kt_cur.a) return false;
+    if (kt_free.empty() || kt_cur.a) { if (kt_free.empty()) ++st.timer_pairs_dropped; return false; }
     kt_cur = kt_free.back(); kt_free.pop_back();
     kt_cur.dst = dst; kt_cur.dst2 = dst2; kt_cur.cnt = cnt;
     hipEventRecord(kt_cur.a, stream);
@@ -394,7 +394,7 @@ struct Engine {
   // the same for a section that CONTAINS begin ... end pairs (a whole QEq call, a whole FORCE): its own pair from the pool, handed back explicitly
   KtPair outer_begin(double *dst) {
     KtPair p{};
-    if (kt_free.empty()) return p;
+    if (kt_free.empty()) { ++st.timer_pairs_dropped; return p; }
     p = kt_free.back(); kt_free.pop_back();
     p.dst = dst; p.dst2 = nullptr; p.cnt = nullptr;
     hipEventRecord(p.a, stream);

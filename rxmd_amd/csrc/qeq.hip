@@ -652,9 +652,9 @@ void Engine::qeq() {
       stopflag = (k == 0) ? nullptr : scal + S_STOP + (k & 1);    // iteration 0 is decided by the host (Est of the start vector is here already)
       if (!xs_current) sorted_copy(hst);           // first iteration only: afterwards the direction kernel leaves the sorted copy behind
       xs_current = false;
-      hipEventRecord(ev_pass[k & 1][0], stream);   // read once the host has confirmed that the iteration happened (a pass that returned at once is not timed)
+      if (!opt.no_pass_events) hipEventRecord(ev_pass[k & 1][0], stream);   // read once the host has confirmed that the iteration happened (a pass that returned at once is not timed)
       const int np1 = pass(MODE_HSH, true, wall, wgh);
-      hipEventRecord(ev_pass[k & 1][1], stream);
+      if (!opt.no_pass_events) hipEventRecord(ev_pass[k & 1][1], stream);
       // (round 6, measured and dropped: the pass finishing its own reduction -- chunks of 256 workgroups, the last to arrive adds its chunk, the last chunk
       //  adds the chunk sums and runs the stage-1 algebra.  The launch of k_reduce_fused goes away, 81 -> 71-74 us per iteration outside the pass, but
       //  every workgroup's last wavefront then waits for its four stores and a ticket before it frees the workgroup's LDS: the pass in the loop went from
@@ -687,7 +687,7 @@ void Engine::qeq() {
         const double *hs = h_scal + 64 + 64 * ((it - 1) & 1);
         Est = hs[S_EST];
         est_trace.push_back(Est);
-        { float pms = 0; if (hipEventElapsedTime(&pms, ev_pass[(it - 1) & 1][0], ev_pass[(it - 1) & 1][1]) == hipSuccess) st.ms_qeq_spmv += pms; }
+        if (!opt.no_pass_events) { float pms = 0; if (hipEventElapsedTime(&pms, ev_pass[(it - 1) & 1][0], ev_pass[(it - 1) & 1][1]) == hipSuccess) st.ms_qeq_spmv += pms; }
         st.spmv_launches += 1;
         if (!queued) break;                        // NMAXQEq iterations done
         if (hs[S_STOP + (it & 1)] != 0.0) { std::swap(hst, hst2); st.spmv_noop_launches += 1; break; }       // iteration it did not happen: its direction kernel wrote nothing, undo the swap
