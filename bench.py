@@ -298,7 +298,7 @@ def compact_line(full, limit=7600):
     out = {k: full[k] for k in keep if k in full}
     r = dict(full["roofline"])
     rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_real_traffic", "frac_streamed", "algorithmic_bytes_per_launch", "bytes_per_entry",
-          "bytes_per_entry_streamed", "avg_launch_ms", "launches", "launches_that_returned_at_once", "measured_read_stream_GBs", "frac_of_measured_read_stream",
+          "bytes_per_entry_streamed", "avg_launch_ms", "launches", "launches_timed", "launches_that_returned_at_once", "measured_read_stream_GBs", "frac_of_measured_read_stream",
           "spmv_launches_per_step", "step_frac_of_hbm_roofline")
     out["roofline"] = {k: r[k] for k in rk if k in r}
     if r.get("traffic_source"):
@@ -730,7 +730,9 @@ def main():
                                               "draws": st.get("place_draws", 0), "total_ms": st.get("place_total_ms", 0.0), "bytes_held": st.get("place_bytes_held", 0.0),
                                               "in_timed_region": bool(st.get("place_draws", 0) > place_draws_before),      # measured: draws counted after the timers were reset
                                               "note": "where the pass's streams lie in physical memory is worth up to 15 % of its time; the engine times a few placements once and keeps the fastest (RXMD_PLACE_TRIES)"},
-                         "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"], "launches_that_returned_at_once": st.get("spmv_noop_launches", 0),
+                         "avg_launch_ms": ms_spmv, "launches": st["spmv_launches"], "launches_timed": st.get("spmv_launches_timed", st["spmv_launches"]),
+                         "timing": "HIP event pair on the engine's stream around every %s-th launch of the timed region (RXMD_PASS_TIMING_EVERY); avg_launch_ms = their mean" % os.environ.get("RXMD_PASS_TIMING_EVERY", "8"),
+                         "launches_that_returned_at_once": st.get("spmv_noop_launches", 0),
                          "measured_read_stream_GBs": probe, "frac_of_measured_read_stream": (achieved / probe) if probe else None,
                          "spmv_launches_per_step": passes,
                          "bytes_per_entry": 20 if pqeq else 12,

@@ -185,6 +185,8 @@ typedef struct rxmd_stats {
    * stream of its own next to the QEq iterations and ENbond: what of it the main stream had to WAIT for in front of the stress sums, and 1 when it ran so */
   double ms_bond_exposed;
   int bond_overlap;
+  long long spmv_launches_timed;        /* (round 6) matrix passes that carried the HIP event pair (RXMD_PASS_TIMING_EVERY, default every 8th in the run-ahead CG loop, every launch elsewhere);
+                                         * ms_qeq_spmv = their average duration x spmv_launches */
   int timer_pairs_dropped;              /* event pairs the ms_* timers could not get since rxmd_hip_reset_timers (the pool of 64 ran dry: long rxmd_hip_step calls without a list build or
                                          * a CG loop to collect them): when > 0 the ms_* breakdown under-counts */
 } rxmd_stats;

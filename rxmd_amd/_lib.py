@@ -33,7 +33,7 @@ class RxmdStats(C.Structure):
                 ("place_ms_first", C.c_double), ("place_ms_kept", C.c_double),
                 ("place_total_ms", C.c_double), ("place_bytes_held", C.c_double), ("place_draws", C.c_int),
                 ("spmv_nstep", C.c_int), ("spmv_var", C.c_int), ("reserved3", C.c_int), ("ms_k_blist", C.c_double),
-                ("ms_bond_exposed", C.c_double), ("bond_overlap", C.c_int), ("timer_pairs_dropped", C.c_int)]
+                ("ms_bond_exposed", C.c_double), ("bond_overlap", C.c_int), ("spmv_launches_timed", C.c_longlong), ("timer_pairs_dropped", C.c_int)]
 
     def asdict(self):
         d = {}

@@ -391,6 +391,9 @@ int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out) {
     e.st.natoms = e.N;
     e.st.n_boundary_rows = (e.multi() && e.lists_valid && !e.rows_split_pending_invalid()) ? e.n_bnd : 0;
     e.st.win_groups = e.win_groups; e.st.win_max_units = e.win_maxunits; e.st.win_in_use = e.win_used ? 1 : 0;
+    // the matrix pass is timed on a sample of its launches (Engine::qeq): average of the timed ones x all of them
+    e.st.spmv_launches_timed = e.pass_timed_n;
+    e.st.ms_qeq_spmv = e.pass_timed_n > 0 ? e.pass_timed_ms / static_cast<double>(e.pass_timed_n) * static_cast<double>(e.st.spmv_launches) : 0.0;
     *out = e.st;
   });
 }
@@ -400,7 +403,7 @@ int rxmd_hip_reset_timers(rxmd_handle h) {
     e.st.ms_qeq = e.st.ms_qeq_list = e.st.ms_qeq_spmv = e.st.ms_force = e.st.ms_lists = e.st.ms_bo = e.st.ms_nonbond = e.st.ms_bonded = e.st.ms_step_total = 0.0;
     e.st.spmv_launches = 0; e.st.spmv_noop_launches = 0; e.st.qeq_iters_total = 0; e.st.qeq_calls = 0;
     e.st.ms_ghost_build = e.st.ms_migrate = e.st.ms_halo = e.st.ms_halo_exposed = e.st.ms_allreduce = e.st.ms_fold = 0.0;
-    e.st.halo_calls = e.st.allreduce_calls = 0; e.st.timer_pairs_dropped = 0;
+    e.st.halo_calls = e.st.allreduce_calls = 0; e.st.timer_pairs_dropped = 0; e.pass_timed_ms = 0.0; e.pass_timed_n = 0; e.st.spmv_launches_timed = 0;
     e.st.ms_k_list10 = e.st.ms_k_nonbond = e.st.ms_k_e3b = e.st.ms_k_e4b = e.st.ms_k_ehb = e.st.ms_k_bondorder = e.st.ms_k_assemble = e.st.ms_k_winbuild = e.st.ms_k_blist = e.st.ms_bond_exposed = 0.0;
   });
 }

@@ -274,7 +274,13 @@ struct Engine {
   void qeq();
   void force(bool defer_host_read = false);   // defer: the energies stay in the pinned buffer until finish_force() (step(): no host wait between FORCE and the next step)
   void finish_force();
-  bool force_pending = false; int spec_pending = -1;   // spec_pending: the Est copy of a queued-ahead CG iteration that the last QEq call did not wait for
+  bool force_pending = false;
+  // run-ahead CG loop (qeq.hip): the scalars of an iteration reach the host as a snapshot the update kernel's tail writes straight into pinned host memory
+  // (h_scal + 64 + 64 * parity, sequence number in word 63), no copy, no event: the host polls the sequence number
+  unsigned long long snap_seq = 0; double snap_expect[2] = {0.0, 0.0};
+  void wait_snapshot(int parity, double seq);
+  // the matrix pass is timed on a SAMPLE of its launches there (opt.pass_timing_every): sum and count of the timed ones; rxmd_stats.ms_qeq_spmv = average x all launches
+  unsigned long long pass_counter = 0; bool pass_timed_k[2] = {false, false}; double pass_timed_ms = 0.0; long long pass_timed_n = 0;
   void step(int nsteps);
   void migrate();                  // COPYATOMS(MODE_MOVE)
   void thermostat(int mdmode, double treq_K, double vsfact, double gke);   // velocity scaling of the MD loop head (assemble.hip)

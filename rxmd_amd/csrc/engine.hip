@@ -398,7 +398,7 @@ void Engine::alloc_device() {
     dmalloc(rows_sorted, ng * WIN_ROWS); dmalloc(rowcols, ng * WIN_ROWS * 64); dmalloc(grp_base, ng * 32); dmalloc(win_flag, ng + 1); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dzalloc(scal, 192);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
-  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 320 * sizeof(double)));      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip); [192,288): the per-type sums of a host transport
+  RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 320 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));   // coherent: the update kernel's tail stores the CG snapshot into it and the host polls it      // [0,64): as before; [64,192): the two slots of the run-ahead CG loop (qeq.hip); [192,288): the per-type sums of a host transport
   dzalloc(tsum, 128); { double *sa_ = nullptr; dzalloc(sa_, 32); sargs = reinterpret_cast<ScaleArgs *>(sa_); }
   dzalloc(d_err, 16);
   RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), 32 * sizeof(int)));

@@ -68,7 +68,7 @@ __device__ inline double block_sum_256(double v, double *sm) {
 // stage 4 (qeq_mode 1, fused loop): sums (qs, qt, gs.gs, gt.gt) -> mu, Gold<-Gnew, Gnew, beta;  stage 5: Est
 // stage 6 (qeq_mode 1, multi-rank): stage 4 and Est in one -- Est is a quadratic in mu whose three coefficients are sums the
 //          update kernel can form before mu exists (k_cg_update<true>), so the iteration needs two all-reduces instead of three
-__device__ inline void scalar_algebra(int stage, double *__restrict__ scal) {
+__device__ inline void scalar_algebra(int stage, double *__restrict__ scal, double *hsnap = nullptr, double hseq = 0.0) {
   const int par = stage >> 4;                     // run-ahead CG loop: which of the two stop flags this iteration's decision goes to (the NEXT iteration's parity)
   stage &= 15;
   const double r[4] = {scal[S_RAW0], scal[S_RAW1], scal[S_RAW2], scal[S_RAW3]};
@@ -104,6 +104,15 @@ __device__ inline void scalar_algebra(int stage, double *__restrict__ scal) {
       // direction kernel; the slot is rewritten two iterations later, after the host has read it (run-ahead loop of Engine::qeq)
       double *snap = scal + S_SNAP + 32 * (par ^ 1);
       for (int c = 0; c < S_COUNT; ++c) snap[c] = scal[c];
+      // run-ahead loop (round 6): the same snapshot straight into PINNED HOST memory, then its sequence number -- the host polls that word.  Until round 6
+      // an event on the main stream, a wait + a 200-byte copy + an event on the second stream carried it: the event record alone cost the dependent
+      // chain update -> direction ~7 us per iteration.
+      if (hsnap != nullptr) {
+        double *hp = hsnap + 64 * (par ^ 1);
+        for (int c = 0; c < S_COUNT; ++c) __hip_atomic_store(hp + c, scal[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                  // system scope: the data before the sequence number
+        __hip_atomic_store(hp + 63, hseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   } else {
     scal[S_EST] = r[0];
@@ -118,7 +127,7 @@ __global__ void k_scalar_algebra(int stage, double *__restrict__ scal) {
 // (arrival counter) adds all of them in a fixed order (thread t takes partials t, t+256, ...; then the fixed LDS tree), writes
 // scal[S_RAW0..3] and, single rank only, runs the scalar algebra of `stage` -- so a reduction costs no extra launch.
 // The result does not depend on which workgroup happens to be last.
-__device__ inline void block_finish(int nblocks, double *partials, unsigned *ticket, int stage, double *scal, int nsets = 1) {
+__device__ inline void block_finish(int nblocks, double *partials, unsigned *ticket, int stage, double *scal, int nsets = 1, double *hsnap = nullptr, double hseq = 0.0) {
   __shared__ double smf[256];
   __shared__ bool last;
   // The partials were stored with device-scope atomics (write-through); waiting for those stores to complete is all the
@@ -141,7 +150,7 @@ __device__ inline void block_finish(int nblocks, double *partials, unsigned *tic
   }
   if (threadIdx.x == 0) {
     *ticket = 0u;                                    // ready for the next launch (stream order)
-    if (stage > 0) scalar_algebra(stage, scal);
+    if (stage > 0) scalar_algebra(stage, scal, hsnap, hseq);
   }
 }
 
@@ -186,7 +195,8 @@ __global__ void __launch_bounds__(256) k_update_qst(int N, const double *__restr
 template <bool EST3>
 __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ hst, double2 *__restrict__ qst,
                                                     const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
-                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage, const double *__restrict__ stopflag) {
+                                                    double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage, const double *__restrict__ stopflag,
+                                                    double *hsnap = nullptr, double hseq = 0.0) {
   if (stopflag && *stopflag != 0.0) return;
   const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
   double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0;
@@ -219,7 +229,7 @@ __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__re
     double acc2[4] = {wave_sum(e0), wave_sum(e1), wave_sum(e2), 0.0};
     block_store_partials<4>(acc2, partials + static_cast<size_t>(gridDim.x) * 4, 4);
   }
-  block_finish(gridDim.x, partials, ticket, stage, scal, EST3 ? 2 : 1);   // stage 4, or 0 = sums only (the all-reduce of a multi-rank run comes first)
+  block_finish(gridDim.x, partials, ticket, stage, scal, EST3 ? 2 : 1, hsnap, hseq);   // stage 4, or 0 = sums only (the all-reduce of a multi-rank run comes first)
 }
 // B: new direction h = g + beta h written to the other (hs,ht) buffer; q = qs - mu qt and the Est term (qeq.F90:150,160-164,297-306)
 //    -> tail: Est (stage 5), sums only (0) or no reduction at all (-1: Est came with the update kernel's sums)
@@ -542,7 +552,6 @@ void Engine::tune_window_placement() {
 void Engine::qeq() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   if (cfg.isQEq != 1 && cfg.isQEq != 2) { nstep_qeq = 0; return; }   // qeq.F90:60-61
-  if (spec_pending >= 0) { sync_event(ev_spec[spec_pending]); spec_pending = -1; }   // the Est copy of the iteration the last call queued ahead and did not need (long done; it writes the pinned slot this call reads)
   tic(6);
   const KtPair t_qeq = outer_begin(&st.ms_qeq);
   // the list sweep of this step can form the row sums of the start vector on the way (saves the matrix pass of qeq.F90:87)
@@ -652,23 +661,24 @@ void Engine::qeq() {
       stopflag = (k == 0) ? nullptr : scal + S_STOP + (k & 1);    // iteration 0 is decided by the host (Est of the start vector is here already)
       if (!xs_current) sorted_copy(hst);           // first iteration only: afterwards the direction kernel leaves the sorted copy behind
       xs_current = false;
-      if (!opt.no_pass_events) hipEventRecord(ev_pass[k & 1][0], stream);   // read once the host has confirmed that the iteration happened (a pass that returned at once is not timed)
+      // the HIP event pair that times the pass rides on every n-th launch only (opt.pass_timing_every, default 8): an event between two dependent
+      // kernels costs the chain ~7 us, two per iteration were 15-20 us of every CG iteration (profiles/r06_ab_pass_events.txt).  Read once the host has
+      // confirmed that the iteration happened (a pass that returned at once is not timed).
+      const bool timed = !opt.no_pass_events && (pass_counter++ % static_cast<unsigned long long>(std::max<long long>(opt.pass_timing_every, 1))) == 0;
+      pass_timed_k[k & 1] = timed;
+      if (timed) hipEventRecord(ev_pass[k & 1][0], stream);
       const int np1 = pass(MODE_HSH, true, wall, wgh);
-      if (!opt.no_pass_events) hipEventRecord(ev_pass[k & 1][1], stream);
+      if (timed) hipEventRecord(ev_pass[k & 1][1], stream);
       // (round 6, measured and dropped: the pass finishing its own reduction -- chunks of 256 workgroups, the last to arrive adds its chunk, the last chunk
       //  adds the chunk sums and runs the stage-1 algebra.  The launch of k_reduce_fused goes away, 81 -> 71-74 us per iteration outside the pass, but
       //  every workgroup's last wavefront then waits for its four stores and a ticket before it frees the workgroup's LDS: the pass in the loop went from
       //  0.877-0.880 to 0.919-0.924 ms, +36 us per iteration net; profiles/r06_ab_reduce_in_pass.txt)
       reduce(1, np1);
-      k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag);
-      // Est and the stop flags of this iteration travel to the host on the second stream, from the snapshot the update kernel's tail left: the
-      // copy (a 4 us blit kernel) no longer sits between the update and the direction kernel
-      // (large systems only: where an iteration is shorter than the host's own work per iteration -- small boxes, tight tolerance -- the host
-      // waits for every copy, and a wait on the second stream's event costs it milliseconds: the suite's 168-atom trajectories ran ten times longer)
-      hipStream_t cs = (N >= 65536) ? comm_stream : stream;
-      if (cs != stream) { RX_HIP(hipEventRecord(ev_upd[k & 1], stream)); RX_HIP(hipStreamWaitEvent(cs, ev_upd[k & 1], 0)); }
-      RX_HIP(hipMemcpyAsync(h_scal + 64 + 64 * (k & 1), scal + S_SNAP + 32 * (k & 1), sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, cs));
-      RX_HIP(hipEventRecord(ev_spec[k & 1], cs));
+      // Est and the stop flags of this iteration reach the host as a snapshot the update kernel's tail stores into pinned host memory (slot k & 1), its
+      // sequence number last: nothing sits between the update and the direction kernel, and the host polls a word of its own memory
+      snap_expect[k & 1] = static_cast<double>(++snap_seq);
+      k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag,
+                                                    h_scal + 64, snap_expect[k & 1]);
       const bool scatter = cg_scatter && k + 1 <= nmax - 1;
       k_cg_direction<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, stopflag);
       std::swap(hst, hst2);
@@ -681,13 +691,13 @@ void Engine::qeq() {
       for (it = 1;; ++it) {
         const bool queued = it <= nmax - 1;
         if (queued) enqueue(it);                   // ahead of the decision
-        sync_event(ev_spec[(it - 1) & 1]);         // iteration it - 1 has produced its Est and the decision about iteration it
+        wait_snapshot((it - 1) & 1, snap_expect[(it - 1) & 1]);     // iteration it - 1 has produced its Est and the decision about iteration it
         if (it == 1 && start_async) est_trace[0] = h_scal[S_EST];      // (the start vector's Est: copied before anything of iteration 0 ran)
         collect_timers();
         const double *hs = h_scal + 64 + 64 * ((it - 1) & 1);
         Est = hs[S_EST];
         est_trace.push_back(Est);
-        if (!opt.no_pass_events) { float pms = 0; if (hipEventElapsedTime(&pms, ev_pass[(it - 1) & 1][0], ev_pass[(it - 1) & 1][1]) == hipSuccess) st.ms_qeq_spmv += pms; }
+        if (pass_timed_k[(it - 1) & 1]) { float pms = 0; if (hipEventElapsedTime(&pms, ev_pass[(it - 1) & 1][0], ev_pass[(it - 1) & 1][1]) == hipSuccess) { pass_timed_ms += pms; pass_timed_n += 1; } }
         st.spmv_launches += 1;
         if (!queued) break;                        // NMAXQEq iterations done
         if (hs[S_STOP + (it & 1)] != 0.0) { std::swap(hst, hst2); st.spmv_noop_launches += 1; break; }       // iteration it did not happen: its direction kernel wrote nothing, undo the swap
@@ -699,9 +709,8 @@ void Engine::qeq() {
     if (ff.pqeq) pqeq_update_shells();
     nstep_qeq = it; last_est = Est;
     st.qeq_iters_last = it; st.qeq_iters_total += it; st.qeq_calls += 1; qeq_iters_smooth = qeq_iters_smooth < 0.0 ? it : 0.75 * qeq_iters_smooth + 0.25 * it;
-    // No host wait here (round 5): the kernels of the iteration that did not happen are still in the queue and FORCE queues behind them in stream
-    // order; its Est copy on the second stream is waited for at the head of the next call.  (Until round 5 a sync here cost ~50 us of idle GPU per step.)
-    if (it >= 1 && it <= nmax - 1) spec_pending = it & 1;
+    // No host wait here (round 5): the kernels of the iteration that did not happen are still in the queue (they return at once and store no snapshot)
+    // and FORCE queues behind them in stream order.  (Until round 5 a sync here cost ~50 us of idle GPU per step.)
     outer_end(t_qeq);
     if (!place_tuned && win_used && it >= 1) { sync_stream(); collect_timers(); tune_window_placement(); }
     return;
@@ -771,7 +780,7 @@ void Engine::qeq() {
       collect_timers();
       Est = h_scal[S_EST];
       est_trace.push_back(Est);
-      hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
+      hipEventElapsedTime(&ms, ev[2], ev[3]); pass_timed_ms += ms; pass_timed_n += 1;
       st.spmv_launches += 1;
       continue;
     }
@@ -788,8 +797,9 @@ void Engine::qeq() {
     sync_stream();
     Est = h_scal[S_EST];
     est_trace.push_back(Est);
-    hipEventElapsedTime(&ms, ev[2], ev[3]); st.ms_qeq_spmv += ms;
-    hipEventElapsedTime(&ms, ev[4], ev[5]); st.ms_qeq_spmv += ms;
+    hipEventElapsedTime(&ms, ev[2], ev[3]); pass_timed_ms += ms;
+    hipEventElapsedTime(&ms, ev[4], ev[5]); pass_timed_ms += ms;
+    pass_timed_n += 2;
     st.spmv_launches += 2;
   }
   if (halo_in_flight) join_comm_stream();             // the loop ended while a halo it will not use was still in flight

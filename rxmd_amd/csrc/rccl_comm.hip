@@ -6,6 +6,7 @@
 // scalars stay in stream order with the kernels that pack, unpack and consume them.
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -82,6 +83,27 @@ void Engine::sync_event(hipEvent_t ev_) {
     RX_HIP(hipEventSynchronize(ev_)); return;
   }
   watched_wait(*this, [&] { return hipEventQuery(ev_); }, "event synchronisation");
+}
+
+// The host's wait of the run-ahead CG loop: the update kernel's tail stores the iteration's scalars into pinned host memory and their sequence number
+// last (qeq.hip: scalar_algebra stage 6); the host polls that word -- no HIP call on the way.  Bounded: beyond 2 ms (twice a matrix pass) every round
+// asks the stream whether the device is still alive, yields the core, and gives up after the time limit of every other wait.
+void Engine::wait_snapshot(int parity, double seq) {
+  volatile const double *flag = h_scal + 64 + 64 * parity + 63;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  for (;;) {
+    if (*flag == seq) break;
+    if ((++spins & 1023u) != 0u && spin_wait) continue;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (dt <= 2e-3 && spin_wait) continue;
+    const hipError_t r = hipStreamQuery(stream);
+    if (r != hipSuccess && r != hipErrorNotReady) RX_HIP(r);
+    if (r == hipSuccess) { if (*flag == seq) break; throw EngineError(RXMD_E_HIP, "the CG scalars of an iteration never reached the host"); }
+    if (dt > comm_timeout_s) throw EngineError(RXMD_E_HIP, "timeout waiting for the CG scalars of an iteration");
+    std::this_thread::yield();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
 }
 
 void Engine::rccl_destroy() {
