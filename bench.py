@@ -246,9 +246,10 @@ def vprocs_for(n):
 #   the (hs,ht) halo of every CG iteration (16 B per ghost) runs under the interior window groups of the matrix pass and counts only beyond them;
 #   two small all-reduces per CG iteration at the latency of N peers instead of one.
 PREDICT = {
-    "source": "profiles/r06_selfloop_staged_overlap.json (single MI355X through the multi-rank code path) + assumed wire figures",
-    "selfloop_fixed_ms": 15.4,           # per step: exchange + lists + FORCE + kicks of the self-loop run (its ms per step minus its CG iterations)
-    "selfloop_ms_per_cg_iteration": 1.035,   # matrix pass (interior + boundary launch) + vector kernels + halo to itself + two all-reduces to itself
+    "source": "profiles/r06_selfloop_staged_overlap.json (one MI355X through the multi-rank code path: 53.40 ms per step at K = 36.55, pass 0.9115 ms in the loop) + assumed wire figures",
+    "selfloop_fixed_ms": 15.77,          # per step: exchange + lists + FORCE + kicks of the self-loop run (its ms per step minus its CG iterations)
+    "selfloop_cg_ms_beyond_the_pass": 0.118,   # per CG iteration beyond the matrix pass itself: vector kernels, the second launch of the split pass, the exposed part of the halo to itself, two all-reduces to itself
+    "single_rank_fixed_ms": 14.8, "single_rank_cg_ms_beyond_the_pass": 0.064,   # the same two figures of the single-rank fast path (profiles/r06_selfloop_single_rank*.json): the N = 1 row of DESIGN.md 6
     "allreduce_self_us": 5.5,            # an 8-double ncclAllReduce with one rank: its launch
     "allreduce_us": {1: 5.5, 2: 10.0, 4: 15.0, 8: 20.0},   # ASSUMED small-message latency of RCCL over xGMI (no two-GPU lease inside a round to measure it)
     "xgmi_link_GBs_per_direction": 60.0,  # ASSUMED achieved rate for MB-sized messages (7 links x ~153 GB/s bidirectional per GPU = 76.8 GB/s per direction and link at peak)
@@ -257,7 +258,8 @@ PREDICT = {
 
 
 def predict_ms_per_step(vp, K, nghost, pass_ms):
-    """predicted wall time of one MD step on the rank grid vp at K CG iterations per step (weak scaling, the per-rank size of the self-loop run)"""
+    """predicted wall time of one MD step on the rank grid vp at K CG iterations per step and the (slowest rank's) matrix-pass time of THIS run
+    (weak scaling, the per-rank size of the self-loop run: 979,776 atoms, 400,262 ghosts)"""
     nsplit = sum(1 for v in vp if v > 1)
     world = vp[0] * vp[1] * vp[2]
     link = PREDICT["xgmi_link_GBs_per_direction"] * 1e9
@@ -267,8 +269,9 @@ def predict_ms_per_step(vp, K, nghost, pass_ms):
     halo_exposed_ms = max(0.0, halo_ms - PREDICT["interior_fraction_of_pass"] * pass_ms)
     ar = PREDICT["allreduce_us"].get(world, 20.0 + 2.0 * max(world - 8, 0) ** 0.5)
     allreduce_ms = 2.0 * K * (ar - PREDICT["allreduce_self_us"]) * 1e-3
-    total = PREDICT["selfloop_fixed_ms"] + K * PREDICT["selfloop_ms_per_cg_iteration"] + wire_fixed_ms + K * halo_exposed_ms + allreduce_ms
-    return {"ms_per_step": round(total, 2), "at_cg_iterations_per_step": round(K, 2), "self_loop_part_ms": round(PREDICT["selfloop_fixed_ms"] + K * PREDICT["selfloop_ms_per_cg_iteration"], 2),
+    self_loop = PREDICT["selfloop_fixed_ms"] + K * (pass_ms + PREDICT["selfloop_cg_ms_beyond_the_pass"])
+    total = self_loop + wire_fixed_ms + K * halo_exposed_ms + allreduce_ms
+    return {"ms_per_step": round(total, 2), "at_cg_iterations_per_step": round(K, 2), "at_pass_ms": round(pass_ms, 4), "self_loop_part_ms": round(self_loop, 2),
             "wire_ms": round(wire_fixed_ms, 3), "vector_halo_ms_per_iteration": round(halo_ms, 3), "vector_halo_exposed_ms_per_iteration": round(halo_exposed_ms, 3),
             "allreduce_extra_ms": round(allreduce_ms, 3), "assumptions": PREDICT["source"] + "; link %g GB/s per direction, all-reduce %g us" % (PREDICT["xgmi_link_GBs_per_direction"], ar)}
 
