@@ -311,6 +311,10 @@ struct Engine {
   int *rowcols = nullptr, *grp_base = nullptr;   // per row: first position and length of its 25 candidate runs (64 ints) ; per group: slot base of its 25 stencil columns (32 ints)
   int *win_gint = nullptr, *win_gbnd = nullptr; int win_nbnd = 0;     // multi-rank: groups without / with a row that has a ghost partner
   unsigned short *sl10 = nullptr;
+  // run-ahead CG loop in ROW ORDER (qeq.hip): the CG vectors of the residents indexed by their place in rows_sorted (group * WIN_ROWS + wavefront of the window pass)
+  double2 *r_qst = nullptr, *r_hst = nullptr, *r_hst2 = nullptr, *r_gst = nullptr, *r_sall = nullptr, *r_sgh = nullptr, *r_wall = nullptr, *r_wgh = nullptr;
+  bool rows_live = false;       // the last QEq call ran its loop in row order: r_type, r_n10, r_hst, r_gst hold that call's rows (the placement search times the pass in the form that runs)
+  int *r_type = nullptr, *r_n10 = nullptr, *r_xpos = nullptr, *rpos = nullptr, *g_rrow = nullptr;   // per row: type (0 = not a row), row length, cell-sorted position; per atom: its row; per ghost: the row of its owner
   int win_groups = 0, win_maxunits = 0;
   // upper bound of the window groups of n rows: a group holds WIN_ROWS rows of ONE cell column (x, y) of the grid, every column may end in a short group
   size_t win_groups_bound(long long n) const { return static_cast<size_t>(n) / WIN_ROWS + static_cast<size_t>(grid.n[0]) * grid.n[1] + 1; }

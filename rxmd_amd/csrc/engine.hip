@@ -395,6 +395,8 @@ void Engine::alloc_device() {
   dmalloc(rows_int, static_cast<size_t>(rows10)); dmalloc(rows_bnd, static_cast<size_t>(rows10));
   dmalloc(hess, static_cast<size_t>(rows10) * S10); dmalloc(n10, static_cast<size_t>(rows10));
   { const size_t ng = win_groups_bound(rows10) + 1;       // groups never straddle a cell column of the grid: up to one short group per column
+    for (double2 **pp : {&r_qst, &r_hst, &r_hst2, &r_gst, &r_sall, &r_sgh, &r_wall, &r_wgh}) dmalloc(*pp, ng * WIN_ROWS);
+    dmalloc(r_type, ng * WIN_ROWS); dmalloc(r_n10, ng * WIN_ROWS); dmalloc(r_xpos, ng * WIN_ROWS); dmalloc(rpos, nb); dmalloc(g_rrow, nb);
     dmalloc(rows_sorted, ng * WIN_ROWS); dmalloc(rowcols, ng * WIN_ROWS * 64); dmalloc(grp_base, ng * 32); dmalloc(win_flag, ng + 1); dmalloc(win_k, ng * WIN_MAXUNITS); dmalloc(win_cnt, ng); dmalloc(win_gint, ng); dmalloc(win_gbnd, ng); dmalloc(sl10, static_cast<size_t>(rows10) * S10); }
   partials_cap = std::max<size_t>(size_t(1) << 16, 4 * static_cast<size_t>(rows10) + 16384);   // up to one workgroup (4 partial sums) per row
   dmalloc(partials, partials_cap + 1024); dzalloc(scal, 192);   // + the 128 x 4 first-level sums of k_reduce_fused, behind the per-workgroup partials at a fixed offset
@@ -434,6 +436,8 @@ void Engine::free_device() {
   free_bond_tables();
   dfree(ehb_don); dfree(ehb_cnt);
   dfree(ecoef); dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
+  for (double2 **pp : {&r_qst, &r_hst, &r_hst2, &r_gst, &r_sall, &r_sgh, &r_wall, &r_wgh}) dfree(*pp);
+  dfree(r_type); dfree(r_n10); dfree(r_xpos); dfree(rpos); dfree(g_rrow);
   dfree(rows_int); dfree(rows_bnd); dfree(rows_sorted); dfree(rowcols); dfree(grp_base); dfree(win_flag); dfree(win_k); dfree(win_cnt); dfree(win_gint); dfree(win_gbnd); dfree(sl10);
   dfree(nb10); dfree(hess); dfree(n10); dfree(partials); dfree(scal); dfree(d_err); dfree(tsum); { double *sa_ = reinterpret_cast<double *>(sargs); dfree(sa_); sargs = nullptr; }
   if (xbuf_owned) { dfree(xbuf_send); dfree(xbuf_recv); }

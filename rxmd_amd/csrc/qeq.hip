@@ -196,11 +196,14 @@ template <bool EST3>
 __global__ void __launch_bounds__(256) k_cg_update(int N, DevFF ff, double *__restrict__ scal, const int *__restrict__ type, const double2 *__restrict__ hst, double2 *__restrict__ qst,
                                                     const double2 *__restrict__ wall, const double2 *__restrict__ wgh, double2 *__restrict__ sall, double2 *__restrict__ sgh,
                                                     double2 *__restrict__ gst, double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage, const double *__restrict__ stopflag,
-                                                    double *hsnap = nullptr, double hseq = 0.0) {
+                                                    double *hsnap = nullptr, double hseq = 0.0, const int *__restrict__ rows = nullptr, int nres = 0) {
+  // rows != nullptr (row order, run-ahead loop): the arrays are indexed by the rows' places in rows_sorted, N = the number of places, a place whose entry is
+  // >= nres holds no row
   if (stopflag && *stopflag != 0.0) return;
   const double l1 = scal[S_LMIN_S], l2 = scal[S_LMIN_T];
   double s = 0.0, t = 0.0, g1s = 0.0, g2s = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    if (rows != nullptr && rows[i] >= nres) continue;
     double2 qv = qst[i];
     const double2 hv = hst[i];
     qv.x = qv.x + l1 * hv.x; qv.y = qv.y + l2 * hv.y;
@@ -240,15 +243,19 @@ __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *_
                                                        const double2 *__restrict__ gst, const double2 *__restrict__ hst, double2 *__restrict__ hst_new,
                                                        const double2 *__restrict__ qst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh, double *__restrict__ q,
                                                        double *__restrict__ partials, unsigned *ticket, const double4 *__restrict__ pqrow, int stage,
-                                                       int G, const int *__restrict__ invpos, const int *__restrict__ groot, double2 *__restrict__ xs, const double *__restrict__ stopflag) {
+                                                       int G, const int *__restrict__ invpos, const int *__restrict__ groot, double2 *__restrict__ xs, const double *__restrict__ stopflag,
+                                                       const int *__restrict__ rows = nullptr, int nres = -1, const int *__restrict__ xpos = nullptr) {
+  // rows != nullptr (row order): N places, xpos[place] = the row's cell-sorted position, groot[ghost] = the PLACE of the ghost's owner, nres = residents
   if (stopflag && *stopflag != 0.0) return;
   const double mu = scal[S_MU], b1 = scal[S_BETA_S], b2 = scal[S_BETA_T];
   double es = 0.0;
+  if (nres < 0) nres = N;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    if (rows != nullptr && rows[i] >= nres) continue;
     const double2 g = gst[i], h = hst[i];
     const double2 hn = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
     hst_new[i] = hn;
-    if (xs) xs[invpos[i]] = hn;                      // single rank: the cell-sorted gather copy of the next matrix pass (QCOPY2, qeq.F90:164) is written here ...
+    if (xs) xs[xpos != nullptr ? xpos[i] : invpos[i]] = hn;                      // single rank: the cell-sorted gather copy of the next matrix pass (QCOPY2, qeq.F90:164) is written here ...
     if (!QEST) continue;
     const DevAtomP ap = ff.atom[type[i]];
     const double2 qv = qst[i], a = sall[i], gh = sgh[i];
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *_
     else es += ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);
   }
   if (xs)                                            // ... including the periodic images: a ghost recomputes the value of its owner (two coalesced-by-owner reads)
-    for (int t = N + blockIdx.x * blockDim.x + threadIdx.x; t < G; t += gridDim.x * blockDim.x) {
+    for (int t = nres + blockIdx.x * blockDim.x + threadIdx.x; t < G; t += gridDim.x * blockDim.x) {
       const int r = groot[t];
       const double2 g = gst[r], h = hst[r];
       xs[invpos[t]] = make_double2(g.x + b1 * h.x, g.y + b2 * h.y);
@@ -268,6 +275,37 @@ __global__ void __launch_bounds__(256) k_cg_direction(int N, DevFF ff, double *_
   double acc[4] = {wave_sum(es), 0.0, 0.0, 0.0};
   block_store_partials<4>(acc, partials, 4);
   block_finish(gridDim.x, partials, ticket, stage, scal);     // stage 5 or 0
+}
+
+// ---- row order of the run-ahead CG loop (round 6) ----------------------------------------------------------------------------------------------
+// For the iterations of ONE QEq call the CG vectors of the residents live in the order of rows_sorted (place = group * WIN_ROWS + wavefront of the window
+// pass): what the pass reads and writes per row -- (hs,ht), (gs,gt), type, length; the two row sums -- is then one contiguous run per workgroup, and the
+// direction kernel's scatter into the cell-sorted gather copy is nearly a copy (rows_sorted IS cell-sorted order).  Entered behind the start gradient, left
+// with the charges: two gathers per call.  The reductions of the vector kernels run over places instead of atoms: the same numbers in another order.
+__global__ void k_rows_enter(int R, int N, const int *__restrict__ rows, const int *__restrict__ type, const int *__restrict__ n10, const int *__restrict__ invpos,
+                             const double2 *__restrict__ qst, const double2 *__restrict__ hst, const double2 *__restrict__ gst, const double2 *__restrict__ sall, const double2 *__restrict__ sgh,
+                             double2 *__restrict__ r_qst, double2 *__restrict__ r_hst, double2 *__restrict__ r_gst, double2 *__restrict__ r_sall, double2 *__restrict__ r_sgh,
+                             int *__restrict__ r_type, int *__restrict__ r_n10, int *__restrict__ r_xpos, int *__restrict__ rpos) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int a = rows[r];
+  if (a >= N || a < 0) { r_type[r] = 1; r_n10[r] = 0; r_xpos[r] = 0; return; }      // not a row: every kernel skips the place by rows[r] >= N
+  r_qst[r] = qst[a]; r_hst[r] = hst[a]; r_gst[r] = gst[a]; r_sall[r] = sall[a]; r_sgh[r] = sgh[a];
+  r_type[r] = type[a]; r_n10[r] = n10[a]; r_xpos[r] = invpos[a]; rpos[a] = r;
+}
+__global__ void k_ghost_rows(int N, int G, const int *__restrict__ groot, const int *__restrict__ rpos, int *__restrict__ g_rrow) {
+  const int t = N + blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < G) g_rrow[t] = rpos[groot[t]];
+}
+// back to atom order: (qs,qt) and q = qs - mu qt (qeq.F90:150) with the mu of the last iteration that happened
+__global__ void k_rows_exit(int R, int N, const int *__restrict__ rows, const double *__restrict__ scal, const double2 *__restrict__ r_qst, double2 *__restrict__ qst, double *__restrict__ q) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int a = rows[r];
+  if (a >= N || a < 0) return;
+  const double2 v = r_qst[r];
+  qst[a] = v;
+  q[a] = v.x - scal[S_MU] * v.y;
 }
 
 // q = qs - mu*qt (qeq.F90:150)
@@ -367,7 +405,9 @@ void Engine::tune_window_placement() {
     for (int r = 0; r < 35; ++r) {
       if (r == 5) hipEventRecord(ev[2], stream);
       if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
+      else if (max_row10 > 256 && max_row10 <= 384 && rows_live) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, r_n10, rows_sorted, win_k, win_cnt, xs, r_hst, r_gst, qst, q, r_type, scal, partials, r_wall, r_wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag, 1);
       else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
+      else if (rows_live) k_spmv_win<MODE_HSH, true, false, 2, WIN_PREFETCH | WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, r_n10, rows_sorted, win_k, win_cnt, xs, r_hst, r_gst, qst, q, r_type, scal, partials, r_wall, r_wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag, 1);   // (the form the run-ahead loop launches: per-row operands in row order)
       else k_spmv_win<MODE_HSH, true, false, 2, WIN_PREFETCH | WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
     }
     hipEventRecord(ev[3], stream); hipEventSynchronize(ev[3]);
@@ -552,6 +592,7 @@ void Engine::tune_window_placement() {
 void Engine::qeq() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   if (cfg.isQEq != 1 && cfg.isQEq != 2) { nstep_qeq = 0; return; }   // qeq.F90:60-61
+  rows_live = false;
   tic(6);
   const KtPair t_qeq = outer_begin(&st.ms_qeq);
   // the list sweep of this step can form the row sums of the start vector on the way (saves the matrix pass of qeq.F90:87)
@@ -573,6 +614,7 @@ void Engine::qeq() {
   const bool win_env = opt.spmv_win != 0;
   // returns the number of partial-sum sets (of four) the launch leaves behind partials[pbase * 4]
   const double *stopflag = nullptr;            // run-ahead CG loop only: kernels of an iteration return at once when scal[S_STOP] is set
+  bool pass_roword = false;                    // set by the run-ahead loop while its vectors are in row order
   auto pass = [&](int mode, bool store, double2 *ra, double2 *rg, const int *rowlist = nullptr, int nrows = 0, int pbase = 0) -> int {
     win_used = false;
     if (win_valid && win_env && (!rowlist || rowlist == rows_int || rowlist == rows_bnd)) {   // window pass: the group's partners in LDS, 16-bit slots (k_spmv_win)
@@ -583,8 +625,11 @@ void Engine::qeq() {
       const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
       const bool one_trip = !ff.pqeq && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
       st.spmv_nstep = one_trip ? 3 : 2; st.spmv_var = one_trip ? WIN_LEAN : (WIN_PREFETCH | WIN_LEAN);   // what the line below dispatches (bench.py names the instance whose counters it quotes)
-#define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3, WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); \
-                              else k_spmv_win<M, S, P, 2, WIN_PREFETCH | WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag); } while (0)
+      // per-row operands of the tail: by atom, or (run-ahead loop in row order, MODE_HSH only) by the row's place in rows_sorted
+      const int *p_n10 = pass_roword ? r_n10 : n10, *p_type = pass_roword ? r_type : type;
+      const double2 *p_hst = pass_roword ? r_hst : hst; double2 *p_gst = pass_roword ? r_gst : gst;
+#define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3, WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, p_n10, rows_sorted, win_k, win_cnt, xs, p_hst, p_gst, qst, q, p_type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag, pass_roword ? 1 : 0); \
+                              else k_spmv_win<M, S, P, 2, WIN_PREFETCH | WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, p_n10, rows_sorted, win_k, win_cnt, xs, p_hst, p_gst, qst, q, p_type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag, pass_roword ? 1 : 0); } while (0)
 #define RX_WIN(M, S) do { if (ff.pqeq) RX_WIN3(M, S, true); else RX_WIN3(M, S, false); } while (0)
       if (mode == MODE_HSH) { if (store) RX_WIN(MODE_HSH, true); else RX_WIN(MODE_HSH, false); }
       else { if (store) RX_WIN(MODE_GRAD, true); else RX_WIN(MODE_GRAD, false); }
@@ -657,6 +702,9 @@ void Engine::qeq() {
     auto exit_test = [&](double prev, double est) {
       return (0.5 * (std::fabs(prev) + std::fabs(est)) < cfg.QEq_tol) || (std::fabs(prev) > 0.0 && std::fabs(est / prev - 1.0) < cfg.QEq_tol);
     };
+    // row order (above: k_rows_enter): the window pass must be the one that runs, and its rows are the places
+    const bool roword = opt.cg_row_order != 0 && win_valid && win_env;
+    const int R = win_groups * WIN_ROWS;
     auto enqueue = [&](int k) {                    // everything of iteration k; on the device a no-op when its stop flag is set
       stopflag = (k == 0) ? nullptr : scal + S_STOP + (k & 1);    // iteration 0 is decided by the host (Est of the start vector is here already)
       if (!xs_current) sorted_copy(hst);           // first iteration only: afterwards the direction kernel leaves the sorted copy behind
@@ -667,7 +715,9 @@ void Engine::qeq() {
       const bool timed = !opt.no_pass_events && (pass_counter++ % static_cast<unsigned long long>(std::max<long long>(opt.pass_timing_every, 1))) == 0;
       pass_timed_k[k & 1] = timed;
       if (timed) hipEventRecord(ev_pass[k & 1][0], stream);
-      const int np1 = pass(MODE_HSH, true, wall, wgh);
+      pass_roword = roword;
+      const int np1 = pass(MODE_HSH, true, roword ? r_wall : wall, roword ? r_wgh : wgh);
+      pass_roword = false;
       if (timed) hipEventRecord(ev_pass[k & 1][1], stream);
       // (round 6, measured and dropped: the pass finishing its own reduction -- chunks of 256 workgroups, the last to arrive adds its chunk, the last chunk
       //  adds the chunk sums and runs the stage-1 algebra.  The launch of k_reduce_fused goes away, 81 -> 71-74 us per iteration outside the pass, but
@@ -677,16 +727,26 @@ void Engine::qeq() {
       // Est and the stop flags of this iteration reach the host as a snapshot the update kernel's tail stores into pinned host memory (slot k & 1), its
       // sequence number last: nothing sits between the update and the direction kernel, and the host polls a word of its own memory
       snap_expect[k & 1] = static_cast<double>(++snap_seq);
-      k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag,
-                                                    h_scal + 64, snap_expect[k & 1]);
+      if (roword) k_cg_update<true><<<vb_upd, 256, 0, stream>>>(R, dff, scal, r_type, r_hst, r_qst, r_wall, r_wgh, r_sall, r_sgh, r_gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag,
+                                                                h_scal + 64, snap_expect[k & 1], rows_sorted, N);
+      else k_cg_update<true><<<vb_upd, 256, 0, stream>>>(N, dff, scal, type, hst, qst, wall, wgh, sall, sgh, gst, partials, tickets + 1, pqrow, 6 | (((k + 1) & 1) << 4), stopflag,
+                                                         h_scal + 64, snap_expect[k & 1]);
       const bool scatter = cg_scatter && k + 1 <= nmax - 1;
-      k_cg_direction<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, stopflag);
-      std::swap(hst, hst2);
-      if (k + 1 <= nmax - 1) { if (!scatter) sorted_copy(hst); xs_current = true; }
+      if (roword) { k_cg_direction<false><<<vb, 256, 0, stream>>>(R, dff, scal, r_type, r_gst, r_hst, r_hst2, r_qst, r_sall, r_sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, g_rrow, scatter ? xs : nullptr, stopflag,
+                                                                  rows_sorted, N, r_xpos); std::swap(r_hst, r_hst2); }
+      else { k_cg_direction<false><<<vb, 256, 0, stream>>>(N, dff, scal, type, gst, hst, hst2, qst, sall, sgh, q, partials, tickets + 2, pqrow, -1, G, invpos, groot, scatter ? xs : nullptr, stopflag); std::swap(hst, hst2); }
+      if (k + 1 <= nmax - 1) { if (!scatter) { if (roword) throw EngineError(RXMD_E_STATE, "row order needs the scatter form of the direction kernel"); sorted_copy(hst); } xs_current = true; }
     };
     it = 0;
     if (nmax >= 1 && (start_async || !exit_test(GEst2, Est))) {
       GEst2 = Est;
+      if (roword) {                                // the start vectors (qs,qt), (hs,ht) = (gs,gt), the row sums of the start vector: into row order
+        if (!cg_scatter) throw EngineError(RXMD_E_STATE, "row order needs the scatter form of the direction kernel");
+        sorted_copy(hst); xs_current = true;       // (the first iteration's gather copy, from the atom-ordered start direction)
+        k_rows_enter<<<nblk(R, 256), 256, 0, stream>>>(R, N, rows_sorted, type, n10, invpos, qst, hst, gst, sall, sgh, r_qst, r_hst, r_gst, r_sall, r_sgh, r_type, r_n10, r_xpos, rpos);
+        if (G > N) k_ghost_rows<<<nblk(G - N, 256), 256, 0, stream>>>(N, G, groot, rpos, g_rrow);
+        rows_live = true;
+      }
       enqueue(0);
       for (it = 1;; ++it) {
         const bool queued = it <= nmax - 1;
@@ -700,11 +760,12 @@ void Engine::qeq() {
         if (pass_timed_k[(it - 1) & 1]) { float pms = 0; if (hipEventElapsedTime(&pms, ev_pass[(it - 1) & 1][0], ev_pass[(it - 1) & 1][1]) == hipSuccess) { pass_timed_ms += pms; pass_timed_n += 1; } }
         st.spmv_launches += 1;
         if (!queued) break;                        // NMAXQEq iterations done
-        if (hs[S_STOP + (it & 1)] != 0.0) { std::swap(hst, hst2); st.spmv_noop_launches += 1; break; }       // iteration it did not happen: its direction kernel wrote nothing, undo the swap
+        if (hs[S_STOP + (it & 1)] != 0.0) { if (roword) std::swap(r_hst, r_hst2); else std::swap(hst, hst2); st.spmv_noop_launches += 1; break; }       // iteration it did not happen: its direction kernel wrote nothing, undo the swap
         GEst2 = Est;
       }
       stopflag = nullptr;
-      k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);     // q = qs - mu qt with the mu of the last iteration that happened (qeq.F90:150)
+      if (roword) k_rows_exit<<<nblk(R, 256), 256, 0, stream>>>(R, N, rows_sorted, scal, r_qst, qst, q);      // back to atom order: (qs,qt) and q = qs - mu qt
+      else k_apply_q<<<nblk(N, 256), 256, 0, stream>>>(N, scal, qst, q);     // q = qs - mu qt with the mu of the last iteration that happened (qeq.F90:150)
     }
     if (ff.pqeq) pqeq_update_shells();
     nstep_qeq = it; last_est = Est;

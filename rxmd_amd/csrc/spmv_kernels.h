@@ -179,7 +179,10 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
                                                             double2 *__restrict__ rs_all, double2 *__restrict__ rs_gh,
                                                             const double *__restrict__ hsc, const double4 *__restrict__ pqrow,
                                                             const int *__restrict__ grouplist, int ngroups, int pbase, const double *__restrict__ stopflag,
-                                                            const int *__restrict__ gflags = nullptr) {
+                                                            const int *__restrict__ gflags = nullptr, int roword = 0) {
+  // roword (round 6, run-ahead CG loop): the per-row operands and results of the tail -- type, (hs,ht), (gs,gt), row length in; the two row sums out -- are
+  // indexed by the row's PLACE in rows_sorted (group * WIN_ROWS + wavefront) instead of by its atom: the 16 wavefronts of a workgroup then touch one
+  // contiguous run per array instead of 16 scattered 64-byte sectors (the caller hands over the row-ordered arrays)
   if (stopflag && *stopflag != 0.0) return;
   extern __shared__ double2 s_x[];                  // the window: slot -> (xs, xt)
   __shared__ double s_row[WIN_ROWS][4];
@@ -235,8 +238,8 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   if (t0 < nslots) x0 = xv[min(wk0 + (t0 & (WIN_UNIT - 1)), G - 1)];
   if (t1 < nslots) x1 = xv[min(wk1 + (t1 & (WIN_UNIT - 1)), G - 1)];
   request(0, live ? S10 : 0);
-  const int n = live ? (n10[row] & N10_COUNT) : 0;
-  const int rowc = live ? row : 0;
+  const int rowc = live ? (roword ? ridx : row) : 0;         // index of this row in the per-row arrays
+  const int n = live ? (n10[rowc] & N10_COUNT) : 0;
   const int tl_t = type[rowc];
   const double2 tl_a = (MODE == MODE_HSH) ? hst[rowc] : qst[rowc];
   const double2 tl_b = (MODE == MODE_HSH) ? const_cast<const double2 *>(gst)[rowc] : make_double2(q[rowc], 0.0);
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
       const double ts = ap.eta * tl_a.x + as, tt = ap.eta * tl_a.y + at;      // qeq.F90:294-302
       a0 = ts * tl_a.x; a1 = tt * tl_a.y;                                     // hshs_sum, hsht_sum (:309-310)
       a2 = tl_b.x * tl_a.x; a3 = tl_b.y * tl_a.y;                             // g.h (:119,123)
-      if (STORE && lane_t == 0) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); }
+      if (STORE && lane_t == 0) { rs_all[rowc] = make_double2(as, at); rs_gh[rowc] = make_double2(gs_, gt_); }
     } else {
       const double mu = scal[S_MU];
       const double4 pr = PQ ? pqrow[row] : make_double4(0.0, 0.0, 0.0, 0.0);
@@ -325,7 +328,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
       const double hq_all = as - mu * at, hq_res = (as - gs_) - mu * (at - gt_);
       if (PQ) a2 = pq_est_row(ap, ff.Zpq[tl_t], pr, qi, hq_all, gs_ - mu * gt_);
       else a2 = ap.chi * qi + 0.5 * ap.eta * qi * qi + 0.5 * qi * (hq_all + hq_res);  // Est (:297-306)
-      if (lane_t == 0) { gst[row] = make_double2(g1, g2); if (STORE) { rs_all[row] = make_double2(as, at); rs_gh[row] = make_double2(gs_, gt_); } }
+      if (lane_t == 0) { gst[rowc] = make_double2(g1, g2); if (STORE) { rs_all[rowc] = make_double2(as, at); rs_gh[rowc] = make_double2(gs_, gt_); } }
     }
   }
   int arrived = 0;
