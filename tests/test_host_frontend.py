@@ -265,3 +265,28 @@ def test_readme_lists_the_switches_of_the_library():
     for f in glob.glob(os.path.join(root, "rxmd_amd", "csrc", "*")):
         if f.endswith((".hip", ".cpp", ".h")) and not f.endswith("options.cpp"):
             assert "getenv" not in open(f).read(), f
+
+
+def test_bench_line_stays_under_the_drivers_tail_and_ends_with_the_legs():
+    """bench.py prints the compact form of its record: every key of the driver's contract, `roofline` and `cpu_baseline` without their tables, and `legs`
+    (one short record per leg) as the LAST key, under 8 KB -- the driver keeps the tail of stdout, and the long line of round 5 had lost alt / alt_lex / energy_per_atom there.
+    Fed with the full record of the round's final run (profiles/); and the N > 1 prediction of DESIGN.md 6 (the self loop + the wire) behaves like a scaling model."""
+    import json, sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_final_bench_default_full_line.json")))
+    line = bench.compact_line(full)
+    assert len(line) < 8000
+    out = json.loads(line)
+    assert list(out)[-1] == "legs" and [l["leg"] for l in out["legs"]][:3] == ["headline", "steady (100 steps after 10)", "isQEq 2"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches_timed"] > 0 and r["traffic"] > 0
+    assert out["cpu_baseline"]["kind"] == "reference" and out["cpu_baseline"]["cores"] >= 1
+    assert all(len(json.dumps(l)) < 400 for l in out["legs"])
+    # the prediction: more split axes = more wire and more all-reduce latency, nothing else; exposed halo only beyond the interior part of the pass
+    p2, p4, p8 = (bench.predict_ms_per_step(vp, 36.55, 400262, 0.87) for vp in ((2, 1, 1), (2, 2, 1), (2, 2, 2)))
+    assert p2["ms_per_step"] < p4["ms_per_step"] < p8["ms_per_step"] and p2["self_loop_part_ms"] == p8["self_loop_part_ms"]
+    assert abs(p8["wire_ms"] - 3 * p2["wire_ms"]) < 2e-3 and p8["vector_halo_exposed_ms_per_iteration"] == 0.0
+    assert bench.predict_ms_per_step((2, 2, 2), 36.55, 400262, 0.10)["vector_halo_exposed_ms_per_iteration"] > 0.0
