@@ -404,7 +404,8 @@ void Engine::tune_window_placement() {
     float ms = 0;
     for (int r = 0; r < 35; ++r) {
       if (r == 5) hipEventRecord(ev[2], stream);
-      if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
+      if (ff.pqeq && opt.pq_prefetch != 0) k_spmv_win<MODE_HSH, true, true, 1, WIN_PREFETCH><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
+      else if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
       else if (max_row10 > 256 && max_row10 <= 384 && rows_live) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, r_n10, rows_sorted, win_k, win_cnt, xs, r_hst, r_gst, qst, q, r_type, scal, partials, r_wall, r_wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag, 1);
       else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
       else if (rows_live) k_spmv_win<MODE_HSH, true, false, 2, WIN_PREFETCH | WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, r_n10, rows_sorted, win_k, win_cnt, xs, r_hst, r_gst, qst, q, r_type, scal, partials, r_wall, r_wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag, 1);   // (the form the run-ahead loop launches: per-row operands in row order)
@@ -624,11 +625,13 @@ void Engine::qeq() {
       if (ng == 0) return 0;
       const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
       const bool one_trip = !ff.pqeq && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
-      st.spmv_nstep = one_trip ? 3 : 2; st.spmv_var = one_trip ? WIN_LEAN : (WIN_PREFETCH | WIN_LEAN);   // what the line below dispatches (bench.py names the instance whose counters it quotes)
+      const bool pq_pre = ff.pqeq && opt.pq_prefetch != 0;
+      st.spmv_nstep = pq_pre ? 1 : (one_trip ? 3 : 2); st.spmv_var = pq_pre ? WIN_PREFETCH : (one_trip ? WIN_LEAN : (WIN_PREFETCH | WIN_LEAN));   // what the line below dispatches (bench.py names the instance whose counters it quotes)
       // per-row operands of the tail: by atom, or (run-ahead loop in row order, MODE_HSH only) by the row's place in rows_sorted
       const int *p_n10 = pass_roword ? r_n10 : n10, *p_type = pass_roword ? r_type : type;
       const double2 *p_hst = pass_roword ? r_hst : hst; double2 *p_gst = pass_roword ? r_gst : gst;
-#define RX_WIN3(M, S, P) do { if (one_trip && !P) k_spmv_win<M, S, false, 3, WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, p_n10, rows_sorted, win_k, win_cnt, xs, p_hst, p_gst, qst, q, p_type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag, pass_roword ? 1 : 0); \
+#define RX_WIN3(M, S, P) do { if (P && pq_pre) k_spmv_win<M, S, P, 1, WIN_PREFETCH><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, p_n10, rows_sorted, win_k, win_cnt, xs, p_hst, p_gst, qst, q, p_type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag, pass_roword ? 1 : 0); \
+                              else if (one_trip && !P) k_spmv_win<M, S, false, 3, WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, p_n10, rows_sorted, win_k, win_cnt, xs, p_hst, p_gst, qst, q, p_type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag, pass_roword ? 1 : 0); \
                               else k_spmv_win<M, S, P, 2, WIN_PREFETCH | WIN_LEAN><<<ng, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl10, hess, p_n10, rows_sorted, win_k, win_cnt, xs, p_hst, p_gst, qst, q, p_type, scal, partials, ra, rg, hsc, pqrow, glist, ng, pbase, stopflag, win_flag, pass_roword ? 1 : 0); } while (0)
 #define RX_WIN(M, S) do { if (ff.pqeq) RX_WIN3(M, S, true); else RX_WIN3(M, S, false); } while (0)
       if (mode == MODE_HSH) { if (store) RX_WIN(MODE_HSH, true); else RX_WIN(MODE_HSH, false); }

@@ -256,8 +256,10 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
   // VAR & 2 (plain QEq): the row's NEXT batch is requested before the barrier, behind the window's data (a wavefront's loads return in order:
   // the window does not wait for it) -- the round trip of the second batch runs under the barrier and the first batch's arithmetic instead of
   // after it; the batch after that is requested before the current one is used, and so on.
-  constexpr bool PRE = (VAR & WIN_PREFETCH) != 0 && !PQ;
-  double2 vn[STEPS]; unsigned sn[STEPS];
+  // PQEq takes the prefetch form with ONE batch of 128 entries per register set (NSTEP 1): its third stream (the shell-core values) doubles the registers of a
+  // set, and two sets of two batches do not fit the 64 registers of eight workgroups per CU
+  constexpr bool PRE = (VAR & WIN_PREFETCH) != 0 && (!PQ || NSTEP == 1);
+  double2 vn[STEPS], cn[STEPS]; unsigned sn[STEPS];
   auto request_next = [&](int kb) {
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
@@ -265,12 +267,13 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
       const bool ok = k < n;
       if (ok) { const d2v t2 = __builtin_nontemporal_load(hv2 + (k >> 1)); vn[u] = make_double2(t2.x, t2.y); } else vn[u] = make_double2(0.0, 0.0);
       sn[u] = ok ? __builtin_nontemporal_load(sl2 + (k >> 1)) : 0u;
+      if (PQ && (MODE == MODE_GRAD || STORE)) { if (ok) { const d2v t2 = __builtin_nontemporal_load(cv2 + (k >> 1)); cn[u] = make_double2(t2.x, t2.y); } else cn[u] = make_double2(0.0, 0.0); }
     }
   };
   if (PRE && n > 128 * STEPS) request_next(128 * STEPS);
   __syncthreads();
   double as = 0.0, at = 0.0, gs_ = 0.0, gt_ = 0.0;
-    auto batch = [&](const double2 (&vv)[STEPS], const unsigned (&sv)[STEPS]) {      // one batch of 128 x STEPS entries out of registers and the LDS window
+    auto batch = [&](const double2 (&vv)[STEPS], const unsigned (&sv)[STEPS], const double2 (&cv)[STEPS]) {      // one batch of 128 x STEPS entries out of registers and the LDS window
 #pragma unroll
       for (int u = 0; u < STEPS; ++u) {
         const double2 y0 = s_x[sv[u] & 0x7fffu], y1 = s_x[(sv[u] >> 16) & 0x7fffu];
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
           const double g0 = (sv[u] & 0x8000u) ? vv[u].x : 0.0, g1 = (sv[u] & 0x80000000u) ? vv[u].y : 0.0;     // select the weight, not the sums
           gs_ += g0 * y0.x; gt_ += g0 * y0.y; gs_ += g1 * y1.x; gt_ += g1 * y1.y;
         }
-        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += c[u].x * y0.x; gt_ += c[u].x * y0.y; gs_ += c[u].y * y1.x; gt_ += c[u].y * y1.y; }
+        if ((MODE == MODE_GRAD || STORE) && PQ) { gs_ += cv[u].x * y0.x; gt_ += cv[u].x * y0.y; gs_ += cv[u].y * y1.x; gt_ += cv[u].y * y1.y; }
       }
     };
     constexpr int B = 128 * STEPS;
@@ -289,17 +292,17 @@ __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int
       // workgroups per CU that copy went through 48 bytes of scratch per lane on every row longer than two batches (rows > 512 entries: any
       // condensed system at PQEq's 12.5 A cut-off, dense metals) -- and cost ten moves per row on the others.  Same products in the same order.
       for (int kb = 0;;) {                               // wave-uniform trip count
-        batch(v, ss);
+        batch(v, ss, c);
         kb += B; if (kb >= n) break;
         if (kb + B < n) request(kb + B, n);               // (an odd row end: entry n is the zero padding of the row, slot 0)
-        batch(vn, sn);
+        batch(vn, sn, cn);
         kb += B; if (kb >= n) break;
         if (kb + B < n) request_next(kb + B);
       }
     } else {
       for (int kb = 0; kb < n; kb += B) {                 // wave-uniform trip count
         if (kb > 0) request(kb, n);
-        batch(v, ss);
+        batch(v, ss, c);
       }
     }
 
