@@ -406,8 +406,8 @@ void Engine::tune_window_placement() {
       if (r == 5) hipEventRecord(ev[2], stream);
       if (ff.pqeq && opt.pq_prefetch != 0) k_spmv_win<MODE_HSH, true, true, 1, WIN_PREFETCH><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
       else if (ff.pqeq) k_spmv_win<MODE_HSH, true, true><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr);
-      else if (max_row10 > 256 && max_row10 <= 384 && rows_live) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, r_n10, rows_sorted, win_k, win_cnt, xs, r_hst, r_gst, qst, q, r_type, scal, partials, r_wall, r_wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag, 1);
-      else if (max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
+      else if (opt.spmv_one_trip != 0 && max_row10 > 256 && max_row10 <= 384 && rows_live) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, r_n10, rows_sorted, win_k, win_cnt, xs, r_hst, r_gst, qst, q, r_type, scal, partials, r_wall, r_wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag, 1);
+      else if (opt.spmv_one_trip != 0 && max_row10 > 256 && max_row10 <= 384) k_spmv_win<MODE_HSH, true, false, 3, WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
       else if (rows_live) k_spmv_win<MODE_HSH, true, false, 2, WIN_PREFETCH | WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, r_n10, rows_sorted, win_k, win_cnt, xs, r_hst, r_gst, qst, q, r_type, scal, partials, r_wall, r_wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag, 1);   // (the form the run-ahead loop launches: per-row operands in row order)
       else k_spmv_win<MODE_HSH, true, false, 2, WIN_PREFETCH | WIN_LEAN><<<win_groups, 64 * WIN_ROWS, lds, stream>>>(N, G, S10, dff, sl, h, n10, rows_sorted, win_k, win_cnt, xs, hst, gst, qst, q, type, scal, partials, wall, wgh, hc, pqrow, nullptr, win_groups, 0, nullptr, win_flag);
     }
@@ -624,7 +624,7 @@ void Engine::qeq() {
       const int ng = !rowlist ? win_groups : (rowlist == rows_int ? win_groups - win_nbnd : win_nbnd);
       if (ng == 0) return 0;
       const size_t lds = static_cast<size_t>(win_maxunits) * WIN_UNIT * sizeof(double2);
-      const bool one_trip = !ff.pqeq && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
+      const bool one_trip = !ff.pqeq && opt.spmv_one_trip != 0 && max_row10 > 256 && max_row10 <= 384;      // (PQEq: the third stream of 384 entries does not fit the 64 registers of two workgroups per CU)
       const bool pq_pre = ff.pqeq && opt.pq_prefetch != 0;
       st.spmv_nstep = pq_pre ? 1 : (one_trip ? 3 : 2); st.spmv_var = pq_pre ? WIN_PREFETCH : (one_trip ? WIN_LEAN : (WIN_PREFETCH | WIN_LEAN));   // what the line below dispatches (bench.py names the instance whose counters it quotes)
       // per-row operands of the tail: by atom, or (run-ahead loop in row order, MODE_HSH only) by the row's place in rows_sorted
