@@ -167,10 +167,10 @@ __global__ void __launch_bounds__(1024) k_spmv(int N, int S10, DevFF ff, const i
 // (A timing probe with synthetic slots promised 0.76 against 0.93 ms of k_spmv before anything real was built; the real pass: 0.80 against 0.89 ms
 // back to back in one process, NOTES.md 3.  Variants are compared compiled side by side through VAR and debug tap 104.)
 // FORM (bit set): WIN_PREFETCH = the second batch of a row is requested before the workgroup's barrier; WIN_LEAN = groups without a ghost partner skip the
-// ghost-column sums; WIN_RANKROWS = experiments build only.  Plain QEq runs WIN_PREFETCH | WIN_LEAN (one-trip rows: WIN_LEAN), PQEq 0.
+// ghost-column sums; WIN_RANKROWS = experiments build only.  Plain QEq runs WIN_PREFETCH | WIN_LEAN (RXMD_SPMV_ONE_TRIP=1 and rows of 257-384 entries: NSTEP 3, WIN_LEAN), PQEq NSTEP 1 with WIN_PREFETCH (RXMD_PQ_PREFETCH=0: NSTEP 2, no prefetch).
 [[maybe_unused]] constexpr int WIN_RANKROWS = 1;
 constexpr int WIN_PREFETCH = 2, WIN_LEAN = 4;
-template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR = FORM bits; VAR & 2: the second batch of a row is requested before the workgroup's barrier (below); VAR & 4: groups without a ghost partner skip the ghost-column sums (below); the default of plain QEq is 6.  NSTEP x 128 entries of a row in flight (2; 3 when no row is longer than 384: then every row is one trip -- water 1.478 against 1.529 ms, RDX with its 447-entry rows 0.822 against 0.782); VAR: variants under measurement, compiled side by side and timed by debug tap 104
+template <int MODE, bool STORE, bool PQ, int NSTEP = 2, int VAR = 0>      // VAR = FORM bits; VAR & 2: the second batch of a row is requested before the workgroup's barrier (below); VAR & 4: groups without a ghost partner skip the ghost-column sums (below); the default of plain QEq is 6.  NSTEP x 128 entries of a row in flight per register set (2; 3 = every row of at most 384 entries is one trip, the choice for water in rounds 4-5 -- 1.478 against 1.529 ms then, 1.61 against 1.58 since round 6, no longer the default; 1 for PQEq, whose third stream doubles a set); VAR: variants under measurement, compiled side by side and timed by debug tap 104
 __global__ void __launch_bounds__(64 * WIN_ROWS, 8) k_spmv_win(int N, int G, int S10, DevFF ff, const unsigned short *__restrict__ sl10, const double *__restrict__ hess, const int *__restrict__ n10,
                                                             const int *__restrict__ rows_sorted, const int *__restrict__ win_k, const int *__restrict__ win_cnt,
                                                             const double2 *__restrict__ xv, const double2 *__restrict__ hst, double2 *__restrict__ gst,
