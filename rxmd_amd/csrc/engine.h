@@ -244,7 +244,7 @@ struct Engine {
   bool bond_overlap() const { return bond_stream != nullptr && !ff.pqeq; }
   void bonded_chain_begin();
   // main stream waits for what on_comm_stream queued; the wait itself is timed: that is the part of the exchange the compute did not hide
-  void join_comm_stream() { const bool kt = kt_begin(&st.ms_halo_exposed); RX_HIP(hipStreamWaitEvent(stream, ev_comm, 0)); kt_end(kt); }
+  void join_comm_stream() { const bool kt = kt_begin(&st.ms_halo_exposed, nullptr, nullptr, 2); RX_HIP(hipStreamWaitEvent(stream, ev_comm, 0)); kt_end(kt); }
   hipEvent_t ev[8] = {};
   std::vector<double> last_atype, last_pos[3];    // what the array-shaped entry points uploaded last (capi.hip)
   std::vector<double> lex_p, lex_v; bool lex_pending = false;   // qsfp/qsfv handed over by rxmd_hip_put_lex for the next array-shaped QEq/PQEq
@@ -384,14 +384,25 @@ struct Engine {
   // Event pairs around single launches / exchanges, from a small pool; a finished pair is read back the next time the host has synchronised
   // with a stream anyway (collect_timers: only pairs whose end event has completed -- an exchange on the second stream may still be running),
   // so timing costs no host wait.  A pair adds its milliseconds to up to two rxmd_stats fields.
-  struct KtPair { hipEvent_t a = nullptr, b = nullptr; double *dst = nullptr, *dst2 = nullptr; long long *cnt = nullptr; };
+  struct KtPair { hipEvent_t a = nullptr, b = nullptr; double *dst = nullptr, *dst2 = nullptr; long long *cnt = nullptr; double scale = 1.0; };
   std::vector<KtPair> kt_free, kt_pending;
   int kt_open = -1;                                // (one nesting level is enough: begin ... end on the stream current at the time)
   KtPair kt_cur{};
-  bool kt_begin(double *dst, double *dst2 = nullptr, long long *cnt = nullptr) {
+  // site >= 0: a timer that fires in EVERY CG iteration (the all-reduces, the vector halo and the join behind it on several ranks): an event pair between two
+  // dependent operations costs the chain ~7 us per event (profiles/r06_ab_pass_events.txt), four pairs per iteration were ~50 us of every iteration of the
+  // multi-rank loop.  Such a site is timed on every n-th call only (opt.pass_timing_every) and its milliseconds count n-fold; its calls are all counted.
+  unsigned long long kt_site_calls[4] = {0, 0, 0, 0};
+  bool kt_begin(double *dst, double *dst2 = nullptr, long long *cnt = nullptr, int site = -1) {
+    double scale = 1.0;
+    if (site >= 0) {
+      if (cnt) { *cnt += 1; cnt = nullptr; }
+      const unsigned long long every = static_cast<unsigned long long>(opt.pass_timing_every > 1 ? opt.pass_timing_every : 1);
+      if ((kt_site_calls[site & 3]++ % every) != 0) return false;
+      scale = static_cast<double>(every);
+    }
     if (kt_free.empty() || kt_cur.a) { if (kt_free.empty()) ++st.timer_pairs_dropped; return false; }
     kt_cur = kt_free.back(); kt_free.pop_back();
-    kt_cur.dst = dst; kt_cur.dst2 = dst2; kt_cur.cnt = cnt;
+    kt_cur.dst = dst; kt_cur.dst2 = dst2; kt_cur.cnt = cnt; kt_cur.scale = scale;
     hipEventRecord(kt_cur.a, stream);
     return true;
   }
@@ -406,7 +417,7 @@ struct Engine {
     KtPair p{};
     if (kt_free.empty()) { ++st.timer_pairs_dropped; return p; }
     p = kt_free.back(); kt_free.pop_back();
-    p.dst = dst; p.dst2 = nullptr; p.cnt = nullptr;
+    p.dst = dst; p.dst2 = nullptr; p.cnt = nullptr; p.scale = 1.0;
     hipEventRecord(p.a, stream);
     return p;
   }

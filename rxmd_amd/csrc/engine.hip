@@ -197,8 +197,8 @@ void Engine::collect_timers() {
     KtPair p = kt_pending[i];
     float ms = 0;
     if (hipEventQuery(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-      if (p.dst) *p.dst += ms;
-      if (p.dst2) *p.dst2 += ms;
+      if (p.dst) *p.dst += ms * p.scale;
+      if (p.dst2) *p.dst2 += ms * p.scale;
       if (p.cnt) *p.cnt += 1;
       p.dst = p.dst2 = nullptr; p.cnt = nullptr;
       kt_free.push_back(p);
@@ -1245,7 +1245,7 @@ void Engine::halo_direct_exchange(double *v, int ncomp) {
 // MODE_QCOPY1 / MODE_QCOPY2 (comm.F90:187-212): ghost slots of an ncomp-interleaved vector, axis by axis
 void Engine::halo_staged(double *v, int ncomp) {
   // QCOPY1 / QCOPY2 (comm.F90:2-100 with MODE_QCOPY*): on the second stream the part the main stream waits for is measured at the join
-  const bool kt = kt_begin(&st.ms_halo, in_comm_region ? nullptr : &st.ms_halo_exposed, &st.halo_calls);
+  const bool kt = kt_begin(&st.ms_halo, in_comm_region ? nullptr : &st.ms_halo_exposed, &st.halo_calls, 1);
   struct End { Engine *e; bool kt; ~End() { e->kt_end(kt); } } end_{this, kt};
   if (halo_direct && dh_ready) { halo_direct_exchange(v, ncomp); return; }
   if (stage_pairs && (nccl || (has_comm && comm.exchange_known))) {

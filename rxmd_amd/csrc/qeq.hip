@@ -370,7 +370,7 @@ void Engine::qeq_start_vectors() {
 
 void Engine::allreduce_scal4(int n) {
   if (nprocs == 1 && !nccl) return;
-  const bool kt = kt_begin(&st.ms_allreduce, nullptr, &st.allreduce_calls);
+  const bool kt = kt_begin(&st.ms_allreduce, nullptr, &st.allreduce_calls, 0);
   struct End { Engine *e; bool kt; ~End() { e->kt_end(kt); } } end_{this, kt};              // forced staged mode of a single rank without a communicator: nothing to add
   if (nccl) { rccl_allreduce_dev(scal + S_RAW0, n); return; }      // in stream order, no host round trip
   if (!has_comm || !comm.allreduce_sum) throw EngineError(RXMD_E_COMM, "vprocs > 1 needs a transport: call rxmd_hip_set_comm or rxmd_hip_comm_init_rccl first");
@@ -783,23 +783,25 @@ void Engine::qeq() {
     if (0.5 * (std::fabs(GEst2) + std::fabs(Est)) < cfg.QEq_tol) break;                          // qeq.F90:114
     if (std::fabs(GEst2) > 0.0 && std::fabs(Est / GEst2 - 1.0) < cfg.QEq_tol) break;            // qeq.F90:115
     GEst2 = Est;
+    // (the event pair around the pass on every n-th iteration only, as in the run-ahead loop: an event costs the dependent chain ~7 us)
+    const bool timed_it = onepass ? (pass_counter++ % static_cast<unsigned long long>(std::max<long long>(opt.pass_timing_every, 1))) == 0 : true;
     if (halo_in_flight) {
       // multi-rank overlap: the (hs,ht) halo of this iteration was started on the second stream right after the direction update;
       // rows without a ghost partner do not need it
       const int n_int = N - n_bnd;
-      hipEventRecord(ev[2], stream);
+      if (timed_it) hipEventRecord(ev[2], stream);
       const int np_int = pass(MODE_HSH, onepass, wall, wgh, rows_int, n_int, 0);
       join_comm_stream();
       const int np_bnd = pass(MODE_HSH, onepass, wall, wgh, rows_bnd, n_bnd, np_int);
-      hipEventRecord(ev[3], stream);
+      if (timed_it) hipEventRecord(ev[3], stream);
       reduce(1, np_int + np_bnd);
       halo_in_flight = false;
     } else {
       if (!xs_current) sorted_copy(hst);                                                         // QCOPY2, qeq.F90:93,164
       xs_current = false;
-      hipEventRecord(ev[2], stream);
+      if (timed_it) hipEventRecord(ev[2], stream);
       const int np1 = pass(MODE_HSH, onepass, onepass ? wall : nullptr, onepass ? wgh : nullptr);
-      hipEventRecord(ev[3], stream);
+      if (timed_it) hipEventRecord(ev[3], stream);
       reduce(1, np1);
     }
     if (onepass) {       // qeq_mode 1: one matrix pass per iteration; gradient and Est by recurrence on the stored row sums
@@ -844,7 +846,7 @@ void Engine::qeq() {
       collect_timers();
       Est = h_scal[S_EST];
       est_trace.push_back(Est);
-      hipEventElapsedTime(&ms, ev[2], ev[3]); pass_timed_ms += ms; pass_timed_n += 1;
+      if (timed_it) { hipEventElapsedTime(&ms, ev[2], ev[3]); pass_timed_ms += ms; pass_timed_n += 1; }
       st.spmv_launches += 1;
       continue;
     }
