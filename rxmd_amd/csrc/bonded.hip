@@ -1,8 +1,8 @@
 // bonded.hip -- bonded energy terms of FORCE (reference src/pot.F90) as own-slot accumulation kernels.
 //   Ebond (pot.F90:926-977) + Elnpr (pot.F90:148-316) -> k_ebond_terms, k_elnpr_atoms, k_elnpr_bonds
 //   E3b   (pot.F90:319-557)                           -> k_e3b   (thread per centre atom)
-//   E4b   (pot.F90:980-1227)                          -> k_e4b   (wavefront per eight / four / two centre atoms, ballot-compacted work queue;
-//                                                                  every torsion visited from both ends)
+//   E4b   (pot.F90:980-1227)                          -> k_e4b   (wavefront per eight / four / two centre atoms, ballot-compacted work queue, persistent grid;
+//                                                                  every torsion evaluated once, its k-l side delivered by k_e4b_deliver)
 //   Ehb   (pot.F90:559-673)                           -> k_ehb_donors + k_ehb_sweep (donor list; a wavefront takes whole donors, acceptors staged in LDS)
 // The reference scatters every derivative at once with atomics (ForceB/ForceBbo/ForceA3/ForceA4,
 // pot.F90:1276-1521).  Here a thread owns one centre atom and accumulates ONLY into that atom's own
@@ -18,7 +18,9 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace rxmd {
 
@@ -163,6 +165,7 @@ __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+constexpr int E4B_SEG = ~(31 << 5);   // k_e4b queue key without its i1 field: (atom, centre bond, l)
 constexpr int WSLOT = 31;   // bonded slots a wavefront-per-centre kernel stages in LDS (MAXNEIGHBS = 30; slot 31 = the centre atom itself)
 
 // ------------------------------------------------------------------------------------------------
@@ -348,39 +351,47 @@ struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // lattice 
 // of the lanes; eight atoms: 6.3 -> 3.9 ms).  Phase A enumerates every (k1,i1,l1) combination of the atoms, applies the reference's
 // cheap bond-order cut-offs (pot.F90:1023,1044,1072,1078,1081) and compacts the survivors with a ballot into an LDS queue; phase B
 // evaluates 64 surviving torsions at a time with every lane busy (only ~1 in 8 combinations survives in RDX).
-// A torsion is visited from both ends: a lane books the energy, the j-k bond coefficient and the cdbnd terms only when
-// gid(j) < gid(k) (the reference's orientation, which the index-ordered ccbnd rule depends on), the forces on i and j and
+// ONCE = false (until round 6): a torsion is visited from both ends: a lane books the energy, the j-k bond coefficient and the cdbnd
+// terms only when gid(j) < gid(k) (the reference's orientation, which the index-ordered ccbnd rule depends on), the forces on i and j and
 // the i-j bond coefficient always; the k/l side is booked when atom k is the centre.  Per-bond sums are formed by each
 // evaluating lane adding its results to the (atom, slot) accumulators in LDS (ds_add_f64): no global atomics, and the order of the
 // additions is fixed by the queue order and the lane order inside one LDS instruction.
-template <int LSL>
-__global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ nbrcnt, const int *__restrict__ type,
+// ONCE = true (default since round 6): only the centre bonds with gid(j) < gid(k) are enumerated -- the reference's loop, pot.F90:1021 -- and a
+// visit books all four atoms: i, j and the centre bond as before, the force on k into the slot of k (k IS a neighbour of j), and the k-l side
+// (ForceB coefficient of bond k-l, force on l), which belongs to a bond slot of ANOTHER wavefront's atom, through a delivery table: the queue runs
+// with i fastest, so the torsions of one (centre bond, l) are neighbouring lanes; a batch is cut where such a run ends, the run's sum is formed by
+// a fixed shuffle tree, and its first lane stores it at [bond (k, l1)][slot of j in the list of k] with a flag byte.  k_e4b_deliver then adds
+// the flagged columns of every bond in slot order: no atomics, the same bits run to run.  Half the enumeration, 12.9 instead of 25.8
+// evaluations per atom (RDX), no stress correction (all four forces are booked in the frame of j, as in the reference).
+template <int LSL, bool ONCE, int WPB>
+__global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ nbrcnt, const int *__restrict__ type,
                                               const long long *__restrict__ gid, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ delta,
                                               const double *__restrict__ etor, const double *__restrict__ econ,
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, BoxImg bx) {
+                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, BoxImg bx,
+                                              const int *__restrict__ brev, double4 *__restrict__ tkl, unsigned char *__restrict__ tflag, int TW, int VB) {
   // per (atom g, slot): the bond as seen from the centre
-  __shared__ double s_bo[4][64], s_et[4][64], s_ec[4][64], s_rx[4][64], s_ry[4][64], s_rz[4][64], s_rn[4][64];
-  __shared__ int s_nb[4][64], s_meta[4][64];     // s_meta: type of the neighbour | its bond count << 8 | "this centre owns the bond" << 16
-  __shared__ int s_bofn[4][64];                  // first bond (CSR offset) of the neighbour in this slot: its list is bonds s_bofn .. + count
+  __shared__ double s_bo[WPB][64], s_et[WPB][64], s_ec[WPB][64], s_rx[WPB][64], s_ry[WPB][64], s_rz[WPB][64], s_rn[WPB][64];
+  __shared__ int s_nb[WPB][64], s_meta[WPB][64];     // s_meta: type of the neighbour | its bond count << 8 | "this centre owns the bond" << 16
+  __shared__ int s_bofn[WPB][64];                  // first bond (CSR offset) of the neighbour in this slot: its list is bonds s_bofn .. + count
   // per (atom g, slot) as CENTRE bond k1: factors shared by all torsions around it; a bond count of 0 marks "no torsion through this bond"
-  __shared__ double s_btb2[4][64], s_dfn11[4][64];
-  __shared__ int s_q[4][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
-  __shared__ int s_ql[4][128]; __shared__ unsigned short s_qx[4][128];     // ... with atom l and the torsion row of (i, j, k, l): phase A has both at hand (round 5: phase B fetched them again, four dependent round trips in front of its arithmetic)
+  __shared__ double s_btb2[WPB][64], s_dfn11[WPB][64];
+  __shared__ int s_q[WPB][128];                    // queue of surviving combinations: g<<15 | k1<<10 | i1<<5 | l1
+  __shared__ int s_ql[WPB][128]; __shared__ unsigned short s_qx[WPB][128];     // ... with atom l and the torsion row of (i, j, k, l): phase A has both at hand (round 5: phase B fetched them again, four dependent round trips in front of its arithmetic)
   // phase A walks only bonds above the cut-off: the slots of each centre atom that qualify, and per centre bond the qualifying slots
   // of k with what the filter needs of them (bond order, atom l, its type) -- staged once per centre bond by the lanes side by side
-  __shared__ int s_cap[4][64], s_capl[4][64], s_ll[4][64], s_tl[4][64], s_gj[4][8][2];   // s_gj: bond count and type of each centre atom
-  __shared__ int s_cb[4][64];                    // the centre bonds of the pass: atom << 8 | lane of the slot
-  __shared__ int s_cd[4][4][9];                  // per centre bond of a round: atom, lane, first lane of the atom, type of j, k, j, number of qualifying k-slots, 1/that, combinations
-  __shared__ int s_base[4][9];                   // LSL == 0: first lane of each atom of the pass, and the end
-  __shared__ double s_bokl[4][64];
+  __shared__ int s_cap[WPB][64], s_capl[WPB][64], s_ll[WPB][64], s_tl[WPB][64], s_gj[WPB][8][2];   // s_gj: bond count and type of each centre atom
+  __shared__ int s_cb[WPB][64];                    // the centre bonds of the pass: atom << 8 | lane of the slot
+  __shared__ int s_cd[WPB][4][9];                  // per centre bond of a round: atom, lane, first lane of the atom, type of j, k, j, number of qualifying k-slots, 1/that, combinations
+  __shared__ int s_base[WPB][9];                   // LSL == 0: first lane of each atom of the pass, and the end
+  __shared__ double s_bokl[WPB][64];
   // per (atom g, slot) accumulators, updated with LDS atomics by the lanes that evaluate torsions: [0] cf1 and [1..3] force of the
   // i-j bond / its neighbour, [4] cf1, [5] cf2, [6] cdbnd of the centre bond; slot 31 (never a bond) holds the centre atom's own
   // force in [1..3] and cdbnd in [6].  (An earlier version wrote 11 results per torsion to LDS and let every owner lane scan all 64
   // of them: that scan cost about as many instructions as the torsion itself.)
-  __shared__ double s_acc[4][64][7];
+  __shared__ double s_acc[WPB][64][7];
   // LSL = 5 / 4: two / four atoms with a fixed range of 32 / 16 lanes each.  LSL = 0 / 1 ("packed"): eight atoms with lists <= 15 /
   // four atoms with any list, each with as many lanes as it has bonds plus one, laid end to end -- RDX atoms have 5.3 bonds on
   // average, so the set-up and the enumeration run with most lanes busy instead of a third; the few groups that need more than 64
@@ -392,16 +403,20 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
   // "is there a torsion row for these four types" (pot.F90:1078) as a bit table in LDS when the ffield has at most 7 atom types
   // (n1^4 <= 4096 bits): the enumeration asks it for every candidate, and a look-up in global memory is a dependent round trip
   // per centre bond
-  __shared__ unsigned char s_tor[4096];           // the torsion row of every type quadruple (0: none), n1^4 <= 4096 entries of a force field with at most 255 rows
+  extern __shared__ unsigned char s_tor[];        // the torsion row of every type quadruple (0: none), n1^4 <= 4096 entries of a force field with at most 255 rows (dynamic: e4b_tor_bytes)
   const bool tor_lds = ff.n1 <= 8 && ff.ntoty <= 255;
   if (tor_lds) {
     const int n4 = ff.n1 * ff.n1 * ff.n1 * ff.n1;
-    for (int t = threadIdx.x; t < n4; t += 256) s_tor[t] = static_cast<unsigned char>(ff.inxn4[t]);
+    for (int t = threadIdx.x; t < n4; t += 64 * WPB) s_tor[t] = static_cast<unsigned char>(ff.inxn4[t]);
     __syncthreads();
   }
-  const int jbase = (xcd_swizzle(blockIdx.x, gridDim.x) * 4 + w) * NG;
-  if (jbase >= N) return;                        // whole wavefront leaves together; no block-level barrier below
   double e8 = 0.0, e9 = 0.0;                      // energies: per evaluating lane, summed over the wave at the end
+  // The grid may be smaller than the number of atom groups (persistent: as many workgroups as fit the device at once, each walking every
+  // gridDim.x-th group): a group is a "virtual workgroup" vb of VB; the XCD-aware order is that of the full grid (gridDim.x is a multiple of 8, so a
+  // workgroup stays on the eighth of the atoms its XCD owns).
+  for (int vb = blockIdx.x; vb < VB; vb += gridDim.x) {
+  const int jbase = (xcd_swizzle(vb, VB) * WPB + w) * NG;
+  if (jbase >= N) continue;                      // whole wavefront skips together; no block-level barrier below
   int npass = 1, c_me = 0, cpre = 0;
   if (PACK) {                                     // lanes 0..PKN-1: lanes the atom needs, inclusive prefix
     if (lane < PKN && jbase + lane < N) c_me = min(nbrcnt[jbase + lane], CAP) + 1;
@@ -440,7 +455,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
   const double xj_me = has_me ? x[j_me] : 0.0, yj_me = has_me ? y[j_me] : 0.0, zj_me = has_me ? z[j_me] : 0.0;
   const int ob_me = has_me ? boff[j_me] : 0;      // bonds of an atom are consecutive (CSR): the lanes of this wavefront read consecutive addresses
   s_meta[w][lane] = 0;
-  bool cap_me = false;
+  bool cap_me = false, cb_me = false;              // this slot qualifies as an i / as a centre bond of this wavefront (ONCE: only in the reference's orientation gid(j) < gid(k))
   if (sl_me < nj_me) {
     const int o = ob_me + sl_me;
     const int i = nbr[o], ti = btype[o];
@@ -459,8 +474,12 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
       const double fn11 = (2.0 + exp_tor3) * exp_tor34_i;
       s_dfn11[w][lane] = (-ff.ptor3 * exp_tor3 + (ff.ptor3 * exp_tor3 - ff.ptor4 * exp_tor4) * (2.0 + exp_tor3) * exp_tor34_i) * exp_tor34_i;
       s_btb2[w][lane] = 2.0 - bo2[o] - fn11;
-      meta |= (min(nbrcnt[i], 255) << 8) | (gid[j_me] < gid[i] ? 1 << 16 : 0);
-      s_bofn[w][lane] = boff[i];
+      const bool own = gid[j_me] < gid[i];
+      const int bi = boff[i];
+      meta |= (min(nbrcnt[i], 255) << 8) | (own ? 1 << 16 : 0);
+      s_bofn[w][lane] = bi;
+      if (ONCE) { meta |= (brev[o] - bi) << 17; cb_me = own; }   // the slot of j in the list of k (< MAXNEIGHBS = 30): where the k-l side of this centre bond is delivered
+      else cb_me = true;
     }
     s_meta[w][lane] = meta;
   }
@@ -474,29 +493,36 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
     if (sl_me == 0 && (has_me || !PACK)) { s_gj[w][g_me][0] = nj_me; s_gj[w][g_me][1] = tj_me; }
   }
   wave_lds_sync();
-  int qn = 0;
+  int qn = 0, qh = 0;                             // entries in the queue; its head (ONCE: a ring of 128, otherwise always 0)
 
   auto evaluate = [&](int cnt) {                  // phase B: the first cnt (<= 64) queue entries, one per lane
 #ifdef RXMD_EXPERIMENTS
     if (bx.probe == 2) return;
     if (bx.probe == 5) { if (lane == 0) { atomicAdd(pe + 8, 1.0); atomicAdd(pe + 9, static_cast<double>(cnt)); } return; }
 #endif
+#ifdef RXMD_EXPERIMENTS
+    const bool once_math = ONCE && bx.probe != 7;   // probe 7: the one-visit enumeration with the arithmetic of a two-visit evaluation (timing only)
+#else
+    constexpr bool once_math = ONCE;
+#endif
     double o[7] = {0, 0, 0, 0, 0, 0, 0};
     V3 fself = {0.0, 0.0, 0.0};
+    V3 fkk = {0.0, 0.0, 0.0}, fll = {0.0, 0.0, 0.0};   // ONCE: forces on k and on l
+    double c3kl = 0.0;                                 // ONCE: ForceB(k-l, C4body_b(3)), pot.F90:1197-1198
     double cd_self = 0.0;
     int key = -1;
     if (lane < cnt) {
-      key = s_q[w][lane];
+      key = s_q[w][(qh + lane) & 127];
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31, l1 = key & 31;
       const int gb = gbase(g);
       const int sk = gb + k1, si = gb + i1;
       const int k = s_nb[w][sk], mk_ = s_meta[w][sk], tk = mk_ & 255, tj = s_gj[w][g][1];
       const double BOjk_f = s_bo[w][sk], BOij_f = s_bo[w][si];
       const double BOjk = BOjk_f - cutof2_esub, BOij = BOij_f - cutof2_esub;
-      const bool own = (mk_ >> 16) != 0;
+      const bool own = ONCE || (mk_ >> 16) != 0;
       const int ol = s_bofn[w][sk] + l1;
-      const int l = s_ql[w][lane];
-      const DevTorsP tp = ff.tors[s_qx[w][lane]];
+      const int l = s_ql[w][(qh + lane) & 127];
+      const DevTorsP tp = ff.tors[s_qx[w][(qh + lane) & 127]];
       (void)tj; (void)tk;
       const V3 rjk = {-s_rx[w][sk], -s_ry[w][sk], -s_rz[w][sk]};          // r_j - r_k
       const double njk = s_rn[w][sk];
@@ -548,6 +574,7 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
       const double CEt9 = fn10 * ss * (0.5 * tp.V1 - 2.0 * tp.V2 * exp_tor1 * c1 + 1.5 * tp.V3 * (cos_2w + 2.0 * c1sq));
       const double Cconj = -2.0 * ff.pcot2 * PEconj;
       const double CEc1 = Cconj * (BOij - 1.5), CEc2 = Cconj * (BOjk - 1.5);
+      if (once_math) c3kl = Cconj * (BOkl - 1.5) + CEt1 * ff.ptor2 * (1.0 - et1) * (1.0 - et2) * et3;    // CEconj(3) + CEtors(6)
       const double CEc4 = -tp.pcot1 * fn12 * (c1sq - 1.0) * tan_ijk_i * sin_jkl;
       const double CEc5 = -tp.pcot1 * fn12 * (c1sq - 1.0) * sin_ijk * tan_jkl_i;
       const double CEc6 = 2.0 * tp.pcot1 * fn12 * c1 * ss;
@@ -558,10 +585,12 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
       angle_forces(CEc4 + CEt7, rij, nij, rjk, njk, fi, fk);
       o[1] = fi.x; o[2] = fi.y; o[3] = fi.z;
       fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z;
+      if (once_math) fkk = fk;
       // angle j-k-l (coefficient C4body_a(2)): j is the first atom
       V3 fj2, fl2;
       angle_forces(CEc5 + CEt8, rjk, njk, rkl, nkl, fj2, fl2);
       fself.x += fj2.x; fself.y += fj2.y; fself.z += fj2.z;
+      if (once_math) { fkk.x -= fj2.x + fl2.x; fkk.y -= fj2.y + fl2.y; fkk.z -= fj2.z + fl2.z; fll = fl2; }
       // dihedral (ForceA4, pot.F90:1369-1459): forces on i (fij) and j (-fij + fjk)
       {
         const double coeff = CEc6 + CEt9;
@@ -581,12 +610,19 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
                         coDD * ((Cwj1 + Cwi1) * rij.z + (Cwj2 + Cwi2) * rjk.z + (Cwj3 + Cwi3) * rkl.z)};
         o[1] += fij.x; o[2] += fij.y; o[3] += fij.z;
         fself.x += -fij.x + fjk.x; fself.y += -fij.y + fjk.y; fself.z += -fij.z + fjk.z;
+        if (once_math) {                                                     // k gets -fjk + fkl, l gets -fkl (pot.F90:1417-1452)
+          const double Cwl2 = C01 + C12 * cDm, Cwl3 = -(C11 * cDm);         // Cwl1 = -C11
+          const V3 fkl = {-coDD * (-C11 * rij.x + Cwl2 * rjk.x + Cwl3 * rkl.x), -coDD * (-C11 * rij.y + Cwl2 * rjk.y + Cwl3 * rkl.y),
+                          -coDD * (-C11 * rij.z + Cwl2 * rjk.z + Cwl3 * rkl.z)};
+          fkk.x += -fjk.x + fkl.x; fkk.y += -fjk.y + fkl.y; fkk.z += -fjk.z + fkl.z;
+          fll.x -= fkl.x; fll.y -= fkl.y; fll.z -= fkl.z;
+        }
       }
       // stress: this visit books f_i and f_j in the frame of centre j; f_k and f_l are booked by the visit whose centre is the
       // OWNER of k.  When k is an image beyond the periodic box that owner sits one lattice vector T away, and the virial
       // sum_a pos_a f_a (pot.F90:65-72) would hold T (f_k + f_l) = -T (f_i + f_j) too much.  The owner's visit sees j as an
       // image at -T and finds the same product, so each of the two visits takes out half (rare lanes only).
-      {
+      if (!ONCE) {
         const double xk = x[k], yk = y[k], zk = z[k];
         // k is bonded to a resident: it lies inside the box or in the first image layer, so comparisons name the lattice vector
         // (floor(x / L) costs three FP64 divisions per torsion)
@@ -607,19 +643,50 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
         }
       }
     }
+#ifdef RXMD_EXPERIMENTS
+    if (ONCE && bx.probe != 3 && bx.probe != 7)
+#else
+    if (ONCE)
+#endif
+    {
+      // the k-l side: C4body_b(3) and the force on l, summed over the i of one (centre bond, l) run -- neighbouring lanes of this batch (a fixed
+      // tree: the same bits run to run) -- and stored ONCE by the run's first lane where the bond k-l finds it: row = bond (k, l1), column = the
+      // slot of j in the list of k.  k_e4b_deliver adds the columns of a row in slot order.
+      const int seg = (key >= 0) ? (key & E4B_SEG) : (-1 - lane);
+      for (int d = 1; d < 32; d <<= 1) {
+        const int sd = __shfl_down(seg, d, 64);                              // (every lane takes part in the exchange: no short circuit in front of it)
+        const bool same = (lane + d < 64) && sd == seg;
+        if (__ballot(same) == 0ULL) break;                                  // runs are contiguous: none at this distance, none beyond
+        const double u0 = __shfl_down(c3kl, d, 64), u1 = __shfl_down(fll.x, d, 64), u2 = __shfl_down(fll.y, d, 64), u3 = __shfl_down(fll.z, d, 64);
+        if (same) { c3kl += u0; fll.x += u1; fll.y += u2; fll.z += u3; }
+      }
+      const int segup = __shfl_up(seg, 1, 64);
+      if (key >= 0 && (lane == 0 || segup != seg)) {
+        const int g = key >> 15, sk = gbase(g) + ((key >> 10) & 31);
+        const size_t ti = static_cast<size_t>(s_bofn[w][sk] + (key & 31)) * TW + ((s_meta[w][sk] >> 17) & 31);
+#ifdef RXMD_EXPERIMENTS
+        if (bx.probe != 6)
+#endif
+        { tkl[ti] = make_double4(c3kl, fll.x, fll.y, fll.z); tflag[ti] = 1; }
+      }
+    }
+#ifdef RXMD_EXPERIMENTS
+    if (bx.probe == 4) { if (o[0] + o[1] + o[2] + o[3] + o[4] + o[5] + o[6] + fkk.x + fkk.y + fkk.z + fself.x + fself.y + fself.z + cd_self + c3kl + fll.x == 1.2345e300) e8 += 1.0; key = -1; }
+#endif
     if (key >= 0) {
       const int g = key >> 15, k1 = (key >> 10) & 31, i1 = (key >> 5) & 31;
       const int gb = gbase(g), gself = PACK ? s_base[w][g + 1] - 1 : gb + SL - 1;
       double *ai = &s_acc[w][gb + i1][0], *ak = &s_acc[w][gb + k1][0], *as = &s_acc[w][gself][0];
       atomicAdd(ai + 0, o[0]); atomicAdd(ai + 1, o[1]); atomicAdd(ai + 2, o[2]); atomicAdd(ai + 3, o[3]);
       atomicAdd(ak + 4, o[4]); atomicAdd(ak + 5, o[5]); atomicAdd(ak + 6, o[6]);
+      if (once_math) { atomicAdd(ak + 1, fkk.x); atomicAdd(ak + 2, fkk.y); atomicAdd(ak + 3, fkk.z); }     // k is the neighbour in slot k1: its force rides where f_i does
       atomicAdd(as + 1, fself.x); atomicAdd(as + 2, fself.y); atomicAdd(as + 3, fself.z); atomicAdd(as + 6, cd_self);
     }
     wave_lds_sync();
   };
 
 #ifdef RXMD_EXPERIMENTS
-  if (bx.probe == 1) return;                      // timing experiment: set-up only
+  if (bx.probe == 1) break;                       // timing experiment: set-up only
 #endif
   // phase A: enumerate, filter, compact.  The centre bonds of the pass (every slot above the cut-off, in (atom, slot) order) are taken
   // CPB at a time: the lanes stage the qualifying slots of their k atoms (pot.F90:1072: bond order, atom l, its type -- three
@@ -627,8 +694,9 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
   // such rounds instead of 40 (one centre bond at a time: set-up + enumeration 2.43 ms of the 3.96 ms kernel); the enumeration of a
   // centre bond then reads LDS only.
   constexpr int KW = (LSL == 5 || LSL == 1) ? 32 : 16, CPB = 64 / KW;   // lanes per centre bond (longest list of any atom + 1), centre bonds per round
-  const int ncb = __popcll(capmask);
-  if (cap_me) { const int r = __popcll(capmask & ((1ULL << lane) - 1ULL)); s_cb[w][r] = (g_me << 8) | lane; }
+  const unsigned long long cbmask = ONCE ? __ballot(cb_me) : capmask;
+  const int ncb = __popcll(cbmask);
+  if (cb_me) { const int r = __popcll(cbmask & ((1ULL << lane) - 1ULL)); s_cb[w][r] = (g_me << 8) | lane; }
   wave_lds_sync();
   for (int r0 = 0; r0 < ncb; r0 += CPB) {
     unsigned long long ml;
@@ -661,8 +729,13 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
         const int ncj = __popc(static_cast<unsigned>(capmask >> gb) & ((gw == 32) ? 0xffffffffu : ((1u << (gw & 31)) - 1u)));
         const int nck = __popc(static_cast<unsigned>(ml >> (lane * KW)) & ((KW == 32) ? 0xffffffffu : 0xffffu));
         int *d = &s_cd[w][lane][0];
-        d[0] = g; d[1] = sk; d[2] = gb; d[3] = s_gj[w][g][1]; d[4] = s_nb[w][sk]; d[5] = jbase + g0 + g; d[6] = nck;
-        d[7] = __float_as_int(1.0f / static_cast<float>(max(nck, 1)));     // c / nck for c < 1024, nck <= 31: exact through (c + 0.5) * (1 / nck) in FP32
+#ifdef RXMD_EXPERIMENTS
+        const int dv = (ONCE && bx.probe != 8) ? ncj : nck;                 // probe 8: one-visit enumeration in the two-visit order, batches of 64 (timing only)
+#else
+        const int dv = ONCE ? ncj : nck;
+#endif                                    // the index that runs fastest: l (two visits) / i (one visit: the torsions of one (centre bond, l) are neighbours in the queue)
+        d[0] = g; d[1] = sk; d[2] = gb; d[3] = s_gj[w][g][1]; d[4] = s_nb[w][sk]; d[5] = jbase + g0 + g; d[6] = dv;
+        d[7] = __float_as_int(1.0f / static_cast<float>(max(dv, 1)));      // c / dv for c < 1024, dv <= 31: exact through (c + 0.5) * (1 / dv) in FP32
         T = ncj * nck;
       }
       s_cd[w][lane][8] = T;
@@ -685,8 +758,14 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
 #pragma unroll
         for (int c = 1; c < CPB; ++c) pb = (cb >= c) ? P[c] : pb;
         const int *d = &s_cd[w][cb][0];
-        const int g = d[0], sk = d[1], gb = d[2], tjc = d[3], k = d[4], j = d[5], nck = d[6], k1 = sk - gb, c = idx - pb;
-        const int ci = static_cast<int>((static_cast<float>(c) + 0.5f) * __int_as_float(d[7])), cl = cb * KW + (c - ci * nck);
+        const int g = d[0], sk = d[1], gb = d[2], tjc = d[3], k = d[4], j = d[5], dv = d[6], k1 = sk - gb, c = idx - pb;
+        const int cq = static_cast<int>((static_cast<float>(c) + 0.5f) * __int_as_float(d[7])), cr = c - cq * dv;
+#ifdef RXMD_EXPERIMENTS
+        const bool ifast = ONCE && bx.probe != 8;
+#else
+        constexpr bool ifast = ONCE;
+#endif
+        const int ci = ifast ? cr : cq, cl = cb * KW + (ifast ? cq : cr);
         const int i1 = s_cap[w][gb + ci], l1 = s_capl[w][cl];
         const double BOjk_f = s_bo[w][sk], BOij_f = s_bo[w][gb + i1], BOkl_f = s_bokl[w][cl];
         const int i = s_nb[w][gb + i1], l = s_ll[w][cl];
@@ -701,10 +780,24 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
         ql = l;
       }
       const unsigned long long m = __ballot(go);
-      if (go) { const int qp = qn + __popcll(m & ((1ULL << lane) - 1ULL)); s_q[w][qp] = key; s_ql[w][qp] = ql; s_qx[w][qp] = static_cast<unsigned short>(qx); }
+      if (go) { const int qp = (qh + qn + __popcll(m & ((1ULL << lane) - 1ULL))) & 127; s_q[w][qp] = key; s_ql[w][qp] = ql; s_qx[w][qp] = static_cast<unsigned short>(qx); }
       qn += __popcll(m);
       wave_lds_sync();
-      if (qn >= 64) {
+      if (ONCE) {
+        // one visit: the queue is a ring, and a batch ends where a (centre bond, l) run ends -- the run's sum over i is formed inside the batch and
+        // leaves the wavefront ONCE (a run has <= 31 entries: among 64 there is always a boundary; the run at the tail may still grow)
+        while (qn >= 64) {
+          const int a = s_q[w][(qh + lane) & 127] & E4B_SEG, b = s_q[w][(qh + lane + 1) & 127] & E4B_SEG;
+          const unsigned long long bm = __ballot(lane + 1 < qn && a != b);
+#ifdef RXMD_EXPERIMENTS
+          const int n = (bm && bx.probe != 8) ? 64 - __clzll(bm) : 64;
+#else
+          const int n = bm ? 64 - __clzll(bm) : 64;
+#endif
+          evaluate(n);
+          qh = (qh + n) & 127; qn -= n;
+        }
+      } else if (qn >= 64) {
         evaluate(64);
         const int rest = qn - 64;
         const int v = (lane < rest) ? s_q[w][64 + lane] : 0, vl = (lane < rest) ? s_ql[w][64 + lane] : 0, vx = (lane < rest) ? s_qx[w][64 + lane] : 0;
@@ -734,11 +827,36 @@ __global__ void __launch_bounds__(256, E4B_MINB) k_e4b(int N, DevFF ff, const in
   }
   wave_lds_sync();                                // the next pass (packed form, two passes) rebuilds the tables
   }   // pass
+  }   // groups
   e8 = wave_sum_b(e8); e9 = wave_sum_b(e9);
   if (lane == 0) {
     if (e8 != 0.0) atomicAdd(pe + 8, e8);
     if (e9 != 0.0) atomicAdd(pe + 9, e9);
   }
+}
+
+// The k-l side of the one-visit torsions (k_e4b<*, true>): row = bond (k, l1) of the compact tables, column = slot of j in the list of k, TW columns
+// per row (TW = the longest bond list of the step, a multiple of 4).  A thread per bond adds the flagged columns of its row in slot order to the
+// bond's own accumulators -- cf1 (ForceB on k-l) and the force on the neighbour l -- and clears the flags it used: the flag array is all zero
+// again behind this kernel.
+__global__ void __launch_bounds__(256) k_e4b_deliver(int nbonds, int TW, const double4 *__restrict__ tkl, unsigned *__restrict__ tflag4,
+                                                      double *__restrict__ cf1, double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz) {
+  const int o = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (o >= nbonds) return;
+  const int nw = TW >> 2;
+  unsigned *fw = tflag4 + static_cast<size_t>(o) * nw;
+  const double4 *row = tkl + static_cast<size_t>(o) * TW;
+  double c = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0;
+  bool any = false;
+  for (int wd = 0; wd < nw; ++wd) {
+    unsigned m = fw[wd];
+    if (m == 0u) continue;
+    fw[wd] = 0u;
+    any = true;
+    for (int b = 0; b < 4; ++b, m >>= 8)
+      if (m & 255u) { const double4 t = row[4 * wd + b]; c += t.x; f0 += t.y; f1 += t.z; f2 += t.w; }
+  }
+  if (any) { cf1[o] += c; fnx[o] += f0; fny[o] += f1; fnz[o] += f2; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -962,7 +1080,7 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
   for (int a = 0; a < 3; ++a) { for (int c = 0; c < 3; ++c) { bx.H[3 * a + c] = box.H[a][c]; bx.Hi[3 * a + c] = box.Hi[a][c]; } bx.L[a] = box.lat[a]; }
   bx.ortho = grid.ortho; bx.probe = 0;
   bx.probe = static_cast<int>(opt.e4b_probe);       // (experiments build only: 0 otherwise)
-  // four atoms per wavefront when every bond list of this step fits 15 slots (h_err[2] = the largest list, read with the error word
+  // four atoms per wavefront when every bond list of this step fits 15 slots (h_err[2] = the largest list if longer than 8, read with the error word
   // after the list build); RXMD_E4B_SLOTS=32 forces the general kernel (tests)
   // instances (RXMD_E4B_SLOTS forces one, tests): packed eight atoms (default when no list of the step is longer than 15), two atoms
   // x 32 slots (32; default otherwise), packed four atoms (4: any list; on the SiC workload, 16+ bonds per atom, it needs two passes
@@ -970,14 +1088,49 @@ const bool kt3 = kt_begin(&st.ms_k_e3b);
   const int want = static_cast<int>(opt.e4b_slots);
   const bool narrow = h_err[2] <= 15 && want != 32 && want != 4;
   const bool kt4 = kt_begin(&st.ms_k_e4b);
-  if (want == 4) k_e4b<1><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                                                       cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else if (narrow && want != 16) k_e4b<0><<<nblk(N, 32), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                                                         cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else if (narrow) k_e4b<4><<<nblk(N, 16), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                                         cds, frc[0], frc[1], frc[2], pe_d, bx);
-  else k_e4b<5><<<nblk(N, 8), 256, 0, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
-                                                 cds, frc[0], frc[1], frc[2], pe_d, bx);
+  bool once = opt.e4b_once != 0;
+  const int TW = (std::max(h_err[2], 8) + 3) & ~3;                          // columns of the k-l delivery table: the longest bond list of the step (h_err[2]: 0 when none is longer than 8)
+  if (once) {
+    const size_t need = static_cast<size_t>(std::max(nbonds, 1)) * TW;
+    if (need > e4b_cap) {                                                   // 33 bytes per (bond, column), touched sparsely: RDX 18^3 2.9 GB; a table that would take more than
+      size_t fre = 0, tot = 0;                                              // half of what is free is not allocated -- the step falls back to the two-visit form
+      RX_HIP(hipMemGetInfo(&fre, &tot));
+      const size_t want_entries = need + need / 4;
+      if (want_entries * 33 > (fre + e4b_cap * 33) / 2) once = false; else alloc_e4b_delivery(want_entries);
+    }
+  }
+  if (once) {
+    if (e4b_dirty) RX_HIP(hipMemsetAsync(e4b_flag, 0, e4b_cap, stream));   // (an error between the torsion kernel and the delivery of an earlier call left flags behind)
+    e4b_dirty = true;
+  }
+  // A persistent grid (default): three workgroups per CU, each walking every gridDim.x-th group of centre atoms.  One workgroup per group -- 30,618 on
+  // RDX 18^3, each needing four 168-register wavefront slots and 49 KB of LDS at once -- kept only 2.0-2.4 of the 3 wavefronts per SIMD resident (SQ
+  // counters, profiles/r06_e4b_*): 3.16 -> 2.54 ms for the two-visit form, 3.54 -> 1.98 ms for the one-visit form.  RXMD_E4B_WPB=1 (workgroups of one
+  // wavefront, tables released per wavefront) gains 0.05 ms without the persistent grid and loses with it (the dispatcher does not spread them evenly
+  // over the SIMDs).
+  const int n4 = dff.n1 * dff.n1 * dff.n1 * dff.n1;
+  const size_t tor_bytes = (dff.n1 <= 8 && dff.ntoty <= 255) ? static_cast<size_t>((n4 + 15) & ~15) : 0;
+  const bool wpb1 = opt.e4b_wpb == 1;
+  auto launch = [&](auto inst, int per_wave) {
+    constexpr int L = decltype(inst)::value;
+    auto go = [&](auto kern, int wpb) {
+      const int VB = nblk(N, per_wave * wpb);                              // groups of atoms = workgroups of the full grid
+      const int grid = opt.e4b_persist != 0 ? std::min(VB, (num_cu * (12 / wpb) + 7) & ~7) : VB;   // persistent: 3 wavefronts per SIMD resident (LDS and registers allow no more)
+      kern<<<grid, 64 * wpb, tor_bytes, stream>>>(N, dff, boff, nbr, btype, nbrcnt, type, gid, pos[0], pos[1], pos[2], bo0, bo2, delta, etor, econ, cf1, cf2, cdn, fnx, fny, fnz,
+                                                  cds, frc[0], frc[1], frc[2], pe_d, bx, brev, e4b_t, e4b_flag, TW, VB);
+    };
+    if (once) { if (wpb1) go(k_e4b<L, true, 1>, 1); else go(k_e4b<L, true, 4>, 4); }
+    else      { if (wpb1) go(k_e4b<L, false, 1>, 1); else go(k_e4b<L, false, 4>, 4); }
+    RX_HIP(hipGetLastError());
+  };
+  if (want == 4) launch(std::integral_constant<int, 1>{}, 4);
+  else if (narrow && want != 16) launch(std::integral_constant<int, 0>{}, 8);
+  else if (narrow) launch(std::integral_constant<int, 4>{}, 4);
+  else launch(std::integral_constant<int, 5>{}, 2);
+  if (once) {
+    k_e4b_deliver<<<nblk(nbonds, 256), 256, 0, stream>>>(nbonds, TW, e4b_t, reinterpret_cast<unsigned *>(e4b_flag), cf1, fnx, fny, fnz);
+    e4b_dirty = false;
+  }
   kt_end(kt4);
   const bool kth = kt_begin(&st.ms_k_ehb);
   if (ehb_donor_types != 0u) {                    // (a force field without a hydrogen-bond row for hydrogen = type 2 has no donors: water, pot.F90:595)

@@ -206,6 +206,10 @@ struct Engine {
   double *etor = nullptr, *econ = nullptr, *epen = nullptr, *ecoa = nullptr;   // per-bond exponentials shared by many angles/torsions
   double *bt1 = nullptr, *bt2 = nullptr, *bt3 = nullptr;                        // per-bond scratch: terms a lane-per-bond kernel leaves for the per-atom sum behind it
   double *ecoef = nullptr;                                                      // 6 per-atom coefficients of Elnpr (bonded.hip)
+  // one-visit torsions (bonded.hip, k_e4b<*, true>): the k-l side of a torsion -- ForceB coefficient of bond k-l and the force on l, summed over i -- per
+  // (bond (k, l1), slot of j in the list of k), TW columns per bond, with one flag byte per entry (all zero between FORCE calls)
+  double4 *e4b_t = nullptr; unsigned char *e4b_flag = nullptr; size_t e4b_cap = 0; bool e4b_dirty = false;
+  void alloc_e4b_delivery(size_t entries);
   int nbonds_res = 0;                                                           // bonds of the residents = boff[N]: the first nbonds_res entries of the tables
   int2 *ehb_don = nullptr; size_t ehb_don_cap = 0; int *ehb_cnt = nullptr; unsigned ehb_donor_types = 0u; int ehb_blocks_per_cu = 0; // hydrogen bonds (bonded.hip): donor list (atom, mask of its hydrogen slots), its length, types X with a row (X, H = 2, any)
   double *deltap = nullptr, *delta = nullptr, *nlp = nullptr, *dDlp = nullptr, *deltalp = nullptr;

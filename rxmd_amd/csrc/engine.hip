@@ -418,6 +418,12 @@ void Engine::alloc_bond_tables(size_t cap) {
   dmalloc(nbr, bcap); dmalloc(brev, bcap); dmalloc(bown, bcap); dmalloc(btype, bcap);
   for (double **t : {&bo0, &bo1, &bo2, &bo3, &dln2, &dln3, &dBOp, &A0, &A1, &A2, &A3, &cf1, &cf2, &cf3, &cdn, &fnx, &fny, &fnz, &etor, &econ, &epen, &ecoa, &bt1, &bt2, &bt3}) dmalloc(*t, bcap);
 }
+void Engine::alloc_e4b_delivery(size_t entries) {
+  dfree(e4b_t); dfree(e4b_flag);
+  e4b_cap = (std::max<size_t>(entries, 1024) + 3) & ~static_cast<size_t>(3);
+  dmalloc(e4b_t, e4b_cap); dzalloc(e4b_flag, e4b_cap);
+  e4b_dirty = false;
+}
 void Engine::free_bond_tables() {
   dfree(nbr); dfree(brev); dfree(bown); dfree(btype);
   for (double **t : {&bo0, &bo1, &bo2, &bo3, &dln2, &dln3, &dBOp, &A0, &A1, &A2, &A3, &cf1, &cf2, &cf3, &cdn, &fnx, &fny, &fnz, &etor, &econ, &epen, &ecoa, &bt1, &bt2, &bt3}) dfree(*t);
@@ -434,7 +440,7 @@ void Engine::free_device() {
   dfree(gsrc); dfree(groot); dfree(sendidx); dfree(rootperm); dfree(invpos); dfree(xs); for (int a = 0; a < 3; ++a) { dfree(fnb[a]); dfree(fsort[a]); } dfree(cellid); dfree(cellid_sorted); dfree(perm); dfree(perm_in); dfree(cellstart);
   dfree(sorted_xyzi); dfree(sorted_type); dfree(flags); dfree(scanout); dfree(nbr_sm); dfree(nbrcnt); dfree(boff);
   free_bond_tables();
-  dfree(ehb_don); dfree(ehb_cnt);
+  dfree(ehb_don); dfree(ehb_cnt); dfree(e4b_t); dfree(e4b_flag); e4b_cap = 0;
   dfree(ecoef); dfree(deltap); dfree(delta); dfree(nlp); dfree(dDlp); dfree(deltalp); dfree(cds); dfree(cd); dfree(cc_);
   for (double2 **pp : {&r_qst, &r_hst, &r_hst2, &r_gst, &r_sall, &r_sgh, &r_wall, &r_wgh}) dfree(*pp);
   dfree(r_type); dfree(r_n10); dfree(r_xpos); dfree(rpos); dfree(g_rrow);

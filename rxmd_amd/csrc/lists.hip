@@ -144,8 +144,9 @@ __global__ void __launch_bounds__(256) k_bonded_list(int G, int MAXNB, Grid g, R
   }
   if (cnt > MAXNB) { atomicMax(&err[1], cnt); atomicCAS(&err[0], DERR_NONE, DERR_MAXNB); cnt = MAXNB; }  // main.F90:402-407
   nbrcnt[i] = cnt;
-  // err[2] = the longest list of this build if any is longer than 15 (the torsion kernel packs four atoms into a wavefront otherwise)
-  if (cnt > 15 && __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[2], cnt);
+  // err[2] = the longest list of this build if any is longer than 8 (the torsion kernel packs eight atoms into a wavefront when none is longer than 15,
+  // and sizes the rows of its k-l delivery table by it)
+  if (cnt > 8 && __hip_atomic_load(&err[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt) atomicMax(&err[2], cnt);
 }
 
 // The sweep above leaves the lists in an atom-major staging array (slot s of atom i at i * 32 + s: a thread appends without knowing the

@@ -590,13 +590,17 @@ def test_window_slots_lead_back_to_the_list_entries(case, mc):
     e.close()
 
 
+@pytest.mark.parametrize("once", ["1", "0"])
 @pytest.mark.parametrize("case,mc", [("rdx222", (2, 2, 2)), ("ice644", (6, 4, 4)), ("example1", (2, 3, 5))])
-def test_torsion_kernel_instances_give_the_same_forces(case, mc, monkeypatch):
+def test_torsion_kernel_instances_give_the_same_forces(case, mc, once, monkeypatch):
     """k_e4b has four instances: eight centre atoms per wavefront with their bond slots laid end to end (default when no bond list of
     the step is longer than 15, as in RDX), four atoms laid end to end (any list; RXMD_E4B_SLOTS=4), four atoms with 16 slots each
     (RXMD_E4B_SLOTS=16, lists <= 15) and two with 32 (any list, the default otherwise; RXMD_E4B_SLOTS=32).  Every (atom, slot) accumulator receives the same additions in the same order in all of them, so the forces must
-    be bit-identical; the torsion energies are summed per lane and may differ in the last bits."""
+    be bit-identical; the torsion energies are summed per lane and may differ in the last bits.  That holds for the two-visit form
+    (RXMD_E4B_ONCE=0).  In the one-visit form (default) the forces on i and on k of the torsions of a batch meet in the same slot accumulators,
+    all i first, and where a batch ends depends on the instance: the same additions in another order, 1e-11 apart at most."""
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000)
+    monkeypatch.setenv("RXMD_E4B_ONCE", once)
     o = _oracle(case, mc, **kw); o.qeq(); o.force()
     res = []
     for slots in (None, "4", "16", "32"):
@@ -609,8 +613,35 @@ def test_torsion_kernel_instances_give_the_same_forces(case, mc, monkeypatch):
         res.append((a["f"].copy(), pe.copy()))
         e.close()
     for r in res[1:]:
-        assert np.array_equal(res[0][0], r[0])
+        assert np.array_equal(res[0][0], r[0]) if once == "0" else np.abs(res[0][0] - r[0]).max() <= 1e-11
         assert np.allclose(res[0][1], r[1], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("case,mc,kw", [("rdx168", (1, 1, 1), {}), ("rdx222", (2, 2, 2), {}), ("rdx168", (5, 5, 5), {}), ("ice644", (6, 4, 4), {}), ("example1", (2, 3, 5), {}),
+                                        ("sicnp", (1, 1, 1), dict(pqeq=oa.PQEQ_SICNP))])
+def test_torsions_visited_once_and_twice_and_the_persistent_grid(case, mc, kw, monkeypatch):
+    """Three switches of the torsion kernel: every torsion evaluated once with its k-l side delivered through the table (default) or visited from both
+    ends (RXMD_E4B_ONCE=0, rounds 1-5); a persistent grid (default) or one workgroup per group of centre atoms (RXMD_E4B_PERSIST=0); workgroups of four
+    wavefronts (default) or of one (RXMD_E4B_WPB=1).  One and two visits book the same terms in other places and orders: forces within 1e-10, stress
+    accumulators within 1e-9 relative (the two-visit form corrects the frame of the k-l half, the one-visit form needs no correction), energies
+    within 1e-12 relative.  The grid and the workgroup size do not change which additions an accumulator sees: bit-identical forces (where no hydrogen bond adds its atomics)."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000, **kw)
+    res = {}
+    for once, pers, wpb in (("1", "1", "4"), ("0", "1", "4"), ("1", "0", "4"), ("1", "1", "1"), ("0", "0", "1")):
+        monkeypatch.setenv("RXMD_E4B_ONCE", once); monkeypatch.setenv("RXMD_E4B_PERSIST", pers); monkeypatch.setenv("RXMD_E4B_WPB", wpb)
+        e = _engine(case, mc, **kw)
+        e.QEq(); pe = e.FORCE(); a = e.atoms(); en = e.energy()
+        res[(once, pers, wpb)] = (a["f"].copy(), pe.copy(), en["astr"].copy())
+        e.close()
+    f1, pe1, s1 = res[("1", "1", "4")]
+    f2, pe2, s2 = res[("0", "1", "4")]
+    assert np.abs(f1 - f2).max() <= 1e-10
+    assert np.allclose(pe1, pe2, rtol=1e-12, atol=1e-10)
+    assert np.abs(s1 - s2).max() <= 1e-9 * max(np.abs(s2).max(), 1.0)
+    # (the acceptor forces of the hydrogen bonds are FP64 atomics, the one sum of FORCE whose order is not fixed: bit for bit only without them)
+    same = (lambda a, b: np.array_equal(a, b)) if pe1[10] == 0.0 else (lambda a, b: np.abs(a - b).max() <= 1e-11)
+    assert same(f1, res[("1", "0", "4")][0]) and same(f1, res[("1", "1", "1")][0])
+    assert same(f2, res[("0", "0", "1")][0])
 
 
 # ---- PQEq (pqeq.F90 / ENbond_PQEq): SiC nanoparticle in O2, conf/init.sicnp, 547 atoms, polarizable shells ----------------
