@@ -319,7 +319,7 @@ def compact_line(full, limit=7600):
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "atom_steps_per_s", "measured_by") if k in cb}
     legs = [leg_summary("headline", dict(full, roofline=r))]
     for name, key in (("steady (100 steps after 10)", "steady"), ("isQEq 2", "alt_lex"), ("reference algebra (qeq_mode %d)" % (1 - full["config"].get("qeq_mode", 1)), "alt"),
-                      ("no placement search", "alt_no_placement_search"), ("one stream", "alt_one_stream")):
+                      ("no placement search", "alt_no_placement_search"), ("bonded chain on the other stream" if not full.get("bond_overlap") else "one stream", "alt_bond_streams")):
         if full.get(key):
             legs.append(leg_summary(name, full[key]))
     for rec in full.get("other_configs") or []:
@@ -584,16 +584,21 @@ def main():
             noplace = {"error": str(ex)}
         finally:
             os.environ.pop("RXMD_PLACE_TRIES", None)
-        # the charge-free part of FORCE on the main stream again (engine.h: bond_stream; RXMD_NO_BOND_OVERLAP=1): what the headline gains from running
-        # it next to ENbond -- and the per-kernel times of roofline.kernels[], which describe a kernel that has the GPU to itself
+        # The charge-free part of FORCE on a stream of its own next to ENbond (engine.h: bond_stream; RXMD_BOND_OVERLAP=1, the default of rounds 4-5): what
+        # that would buy now.  The headline runs the one-stream order: its per-kernel times describe kernels that have the GPU to themselves.  (When
+        # the headline itself is run with RXMD_BOND_OVERLAP=1 this leg is the one-stream order, and roofline.kernels[] takes its times from it.)
+        headline_overlap = os.environ.get("RXMD_BOND_OVERLAP", "0") not in ("", "0")
+        saved_overlap = os.environ.get("RXMD_BOND_OVERLAP")
         try:
-            os.environ["RXMD_NO_BOND_OVERLAP"] = "1"
+            os.environ["RXMD_BOND_OVERLAP"] = "0" if headline_overlap else "1"
             one_stream = compact_leg("rdx", ATOMS_PER_GPU_CELLS, a.steps, a.warmup, local)
-            one_stream["note"] = "the headline configuration in another engine of this process with RXMD_NO_BOND_OVERLAP=1: bond orders, bonded terms and assembly queued on the main stream behind ENbond"
+            one_stream["note"] = ("the headline configuration in another engine of this process with RXMD_BOND_OVERLAP=%s: bond orders, bonded terms and assembly %s"
+                                  % (os.environ["RXMD_BOND_OVERLAP"], "queued on the main stream behind ENbond" if headline_overlap else "on a stream of their own next to ENbond"))
         except Exception as ex:
             one_stream = {"error": str(ex)}
         finally:
-            os.environ.pop("RXMD_NO_BOND_OVERLAP", None)
+            if saved_overlap is None: os.environ.pop("RXMD_BOND_OVERLAP", None)
+            else: os.environ["RXMD_BOND_OVERLAP"] = saved_overlap
         other = []
         for w in ("water", "sicnp"):                              # BASELINE configs[2] and configs[4] at their one-GPU sizes
             try:
@@ -694,7 +699,7 @@ def main():
             kernels.append({"name": name, "ms": ms, "algorithmic_bytes": byts, "achieved_GBs": ach_k, "frac": ach_k / HBM_PEAK_GBS, "traffic": tr_k,
                             "frac_real_traffic": (tr_k / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr_k and ms > 0) else None, "valu_floor_ms": vf_k,
                             "bound": bnd, "frac_of_bound": fb, "frac_of_each_ceiling": fr_all, "note": note,
-                            "timed": "alt_one_stream leg" if (alone and key in alone) else "headline leg"})
+                            "timed": "alt_bond_streams leg (one stream)" if (alone and key in alone) else "headline leg"})
         kernels.append({"name": "CG vector kernels (k_cg_update, k_cg_direction, k_sorted_vec, k_reduce_fused)", "ms": ms_cg_vec, "algorithmic_bytes": st["natoms"] * 300.0,
                         "achieved_GBs": st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 if ms_cg_vec > 0 else 0.0,
                         "frac": (st["natoms"] * 300.0 / (ms_cg_vec * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_cg_vec > 0 else 0.0, "traffic": traffic_for("k_cg_update", "k_cg_direction", "k_sorted_vec", "k_reduce_fused"),
@@ -763,7 +768,7 @@ def main():
         if noplace:
             out["alt_no_placement_search"] = noplace
         if one_stream:
-            out["alt_one_stream"] = one_stream
+            out["alt_bond_streams"] = one_stream
         if other:
             out["other_configs"] = other
         if cb:

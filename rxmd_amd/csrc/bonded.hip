@@ -579,18 +579,18 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
       const double CEc5 = -tp.pcot1 * fn12 * (c1sq - 1.0) * sin_ijk * tan_jkl_i;
       const double CEc6 = 2.0 * tp.pcot1 * fn12 * c1 * ss;
       o[0] = CEc1 + CEt4;                                                   // ForceB(i-j, C4body_b(1)), pot.F90:1185-1186
-      if (own) { o[4] = CEc2 + CEt5; o[5] = CEt2; o[6] = CEt3; cd_self += CEt3; }   // pot.F90:1178-1194
+      if (own) { o[4] = CEc2 + CEt5; o[5] = CEt2; o[6] = CEt3; if (!once_math) cd_self += CEt3; }   // pot.F90:1178-1194 (one visit: the centre's own cdbnd is the sum of its slots' terms, formed at the end)
       // angle i-j-k (coefficient C4body_a(1)): forces on i and j
       V3 fi, fk;
       angle_forces(CEc4 + CEt7, rij, nij, rjk, njk, fi, fk);
       o[1] = fi.x; o[2] = fi.y; o[3] = fi.z;
-      fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z;
-      if (once_math) fkk = fk;
+      if (once_math) fkk = fk;                                               // (one visit: the force on j is minus the sum of the other three, formed at the end)
+      else { fself.x -= fi.x + fk.x; fself.y -= fi.y + fk.y; fself.z -= fi.z + fk.z; }
       // angle j-k-l (coefficient C4body_a(2)): j is the first atom
       V3 fj2, fl2;
       angle_forces(CEc5 + CEt8, rjk, njk, rkl, nkl, fj2, fl2);
-      fself.x += fj2.x; fself.y += fj2.y; fself.z += fj2.z;
       if (once_math) { fkk.x -= fj2.x + fl2.x; fkk.y -= fj2.y + fl2.y; fkk.z -= fj2.z + fl2.z; fll = fl2; }
+      else { fself.x += fj2.x; fself.y += fj2.y; fself.z += fj2.z; }
       // dihedral (ForceA4, pot.F90:1369-1459): forces on i (fij) and j (-fij + fjk)
       {
         const double coeff = CEc6 + CEt9;
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
                         coDD * ((Cwj1 + Cwi1) * rij.y + (Cwj2 + Cwi2) * rjk.y + (Cwj3 + Cwi3) * rkl.y),
                         coDD * ((Cwj1 + Cwi1) * rij.z + (Cwj2 + Cwi2) * rjk.z + (Cwj3 + Cwi3) * rkl.z)};
         o[1] += fij.x; o[2] += fij.y; o[3] += fij.z;
-        fself.x += -fij.x + fjk.x; fself.y += -fij.y + fjk.y; fself.z += -fij.z + fjk.z;
+        if (!once_math) { fself.x += -fij.x + fjk.x; fself.y += -fij.y + fjk.y; fself.z += -fij.z + fjk.z; }
         if (once_math) {                                                     // k gets -fjk + fkl, l gets -fkl (pot.F90:1417-1452)
           const double Cwl2 = C01 + C12 * cDm, Cwl3 = -(C11 * cDm);         // Cwl1 = -C11
           const V3 fkl = {-coDD * (-C11 * rij.x + Cwl2 * rjk.x + Cwl3 * rkl.x), -coDD * (-C11 * rij.y + Cwl2 * rjk.y + Cwl3 * rkl.y),
@@ -668,6 +668,10 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
         if (bx.probe != 6)
 #endif
         { tkl[ti] = make_double4(c3kl, fll.x, fll.y, fll.z); tflag[ti] = 1; }
+        // the centre atom's own force is minus the sum of the three others of every torsion: the l part once per run, here; the i and k parts from
+        // the slot accumulators at the end (four LDS atomics per lane less, the ones with the most lanes per address)
+        double *as = &s_acc[w][PACK ? s_base[w][g + 1] - 1 : gbase(g) + SL - 1][0];
+        atomicAdd(as + 1, -fll.x); atomicAdd(as + 2, -fll.y); atomicAdd(as + 3, -fll.z);
       }
     }
 #ifdef RXMD_EXPERIMENTS
@@ -680,7 +684,7 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
       atomicAdd(ai + 0, o[0]); atomicAdd(ai + 1, o[1]); atomicAdd(ai + 2, o[2]); atomicAdd(ai + 3, o[3]);
       atomicAdd(ak + 4, o[4]); atomicAdd(ak + 5, o[5]); atomicAdd(ak + 6, o[6]);
       if (once_math) { atomicAdd(ak + 1, fkk.x); atomicAdd(ak + 2, fkk.y); atomicAdd(ak + 3, fkk.z); }     // k is the neighbour in slot k1: its force rides where f_i does
-      atomicAdd(as + 1, fself.x); atomicAdd(as + 2, fself.y); atomicAdd(as + 3, fself.z); atomicAdd(as + 6, cd_self);
+      if (!once_math) { atomicAdd(as + 1, fself.x); atomicAdd(as + 2, fself.y); atomicAdd(as + 3, fself.z); atomicAdd(as + 6, cd_self); }
     }
     wave_lds_sync();
   };
@@ -698,24 +702,33 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
   const int ncb = __popcll(cbmask);
   if (cb_me) { const int r = __popcll(cbmask & ((1ULL << lane) - 1ULL)); s_cb[w][r] = (g_me << 8) | lane; }
   wave_lds_sync();
+  // The k-side list of a round -- bond order, atom l and its type of every slot of k, KW lanes per centre bond -- is requested ONE ROUND AHEAD into
+  // three registers (round 6): all three loads at once, whatever the bond order turns out to be, and behind them the enumeration and evaluation of the
+  // round before.  (Until then: the bond order, then -- for the slots above the cut-off -- l and its type: two dependent round trips at the head of
+  // every round, ~10 rounds per wavefront.)
+  double nx_bl = 0.0; int nx_l = 0, nx_tl = 0;
+  auto fetch_round = [&](int r0) {
+    const int cbl = lane / KW, ks = lane % KW, r = r0 + cbl;
+    nx_bl = 0.0; nx_l = 0; nx_tl = 0;
+    if (r < ncb) {
+      const int sk = s_cb[w][r] & 255;
+      const int bk = s_bofn[w][sk];                 // first bond of atom k (the far end of centre bond r): its slots are bonds bk, bk + 1, ...
+      if (ks < min((s_meta[w][sk] >> 8) & 255, KW == 32 ? WSLOT : KW)) { nx_bl = bo0[bk + ks]; nx_l = nbr[bk + ks]; nx_tl = btype[bk + ks]; }
+    }
+  };
+  fetch_round(0);
   for (int r0 = 0; r0 < ncb; r0 += CPB) {
     unsigned long long ml;
     {
-      const int cbl = lane / KW, ks = lane % KW, r = r0 + cbl;
-      double bl = 0.0;
-      bool capl = false;
-      int bk = 0;                                   // first bond of atom k (the far end of centre bond r): its slots are bonds bk, bk + 1, ...
-      if (r < ncb) {
-        const int sk = s_cb[w][r] & 255;
-        bk = s_bofn[w][sk];
-        if (ks < min((s_meta[w][sk] >> 8) & 255, KW == 32 ? WSLOT : KW)) { bl = bo0[bk + ks]; capl = bl > cutof2_esub; }
-      }
+      const int cbl = lane / KW, ks = lane % KW;
+      const double bl = nx_bl; const int l = nx_l, tl = nx_tl;
+      if (r0 + CPB < ncb) fetch_round(r0 + CPB);
+      const bool capl = bl > cutof2_esub;
       ml = __ballot(capl);
       if (capl) {
         const unsigned sub = static_cast<unsigned>(ml >> (cbl * KW)) & ((KW == 32) ? 0xffffffffu : 0xffffu);
         const int pos = cbl * KW + __popc(sub & ((1u << ks) - 1u));
-        const int l = nbr[bk + ks];
-        s_capl[w][pos] = ks; s_bokl[w][pos] = bl; s_ll[w][pos] = l; s_tl[w][pos] = btype[bk + ks];      // (no gather behind the load of l)
+        s_capl[w][pos] = ks; s_bokl[w][pos] = bl; s_ll[w][pos] = l; s_tl[w][pos] = tl;
       }
     }
     // what the combinations of each centre bond of the round need, written by lanes 0..CPB-1: the combinations of all of them are
@@ -822,8 +835,13 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
     if (a_fx != 0.0 || a_fy != 0.0 || a_fz != 0.0) { fnx[o] += a_fx; fny[o] += a_fy; fnz[o] += a_fz; }
   }
   if (self_me) {
-    cds[j_me] += a_cdk;
-    fx[j_me] += a_fx; fy[j_me] += a_fy; fz[j_me] += a_fz;
+    double sx = a_fx, sy = a_fy, sz = a_fz, scd = a_cdk;
+    if (ONCE) {                                     // (this lane's accumulators hold minus the forces on the l atoms)
+      const int gb = gbase(g_me);
+      for (int t = 0; t < nj_me; ++t) { sx -= s_acc[w][gb + t][1]; sy -= s_acc[w][gb + t][2]; sz -= s_acc[w][gb + t][3]; scd += s_acc[w][gb + t][6]; }
+    }
+    cds[j_me] += scd;
+    fx[j_me] += sx; fy[j_me] += sy; fz[j_me] += sz;
   }
   wave_lds_sync();                                // the next pass (packed form, two passes) rebuilds the tables
   }   // pass

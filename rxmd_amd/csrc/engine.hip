@@ -136,7 +136,7 @@ Engine::Engine(const rxmd_config &c) : cfg(c) {
     RX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     RX_HIP(hipStreamCreateWithPriority(&comm_stream, hipStreamDefault, hi));
   }
-  if (!opt.single_stream && !opt.no_bond_overlap) {   // the charge-free part of FORCE next to ENbond (engine.h: bond_stream); lowest priority
+  if (!opt.single_stream && !opt.no_bond_overlap && opt.bond_overlap != 0) {   // the charge-free part of FORCE next to ENbond (engine.h: bond_stream); lowest priority.  Opt-in since round 6: with the torsion kernel at 2 ms it buys nothing any more (profiles/r06_ab_bond_overlap_after_e4b.txt)
     int lo = 0, hi = 0;
     RX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     RX_HIP(hipStreamCreateWithPriority(&bond_stream, hipStreamDefault, lo));

@@ -17,7 +17,7 @@ for probe in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("0", "1", "2", "
     e.set_atoms_rxff(rec); e.QEq(); e.FORCE(); e.reset_timers()
     for _ in range(5): e.FORCE()
     st = e.stats()
-    print("visits %s  probe %s: k_e4b %.3f ms  k_e3b %.3f  k_ehb %.3f" % ("1" if os.environ.get("RXMD_E4B_ONCE", "0") == "1" else "2", probe, st["ms_k_e4b"] / 5, st["ms_k_e3b"] / 5, st["ms_k_ehb"] / 5), flush=True)
+    print("visits %s  probe %s: k_e4b %.3f ms  k_e3b %.3f  k_ehb %.3f" % ("2" if os.environ.get("RXMD_E4B_ONCE", "1") == "0" else "1", probe, st["ms_k_e4b"] / 5, st["ms_k_e3b"] / 5, st["ms_k_ehb"] / 5), flush=True)
     if probe == "5":
         pe = e.energy()["PE"]; print("   evaluate calls per FORCE %.0f, entries %.0f (%.1f per call; %.2f calls per wavefront of 8 atoms)" % (pe[8], pe[9], pe[9] / max(pe[8], 1), pe[8] / (len(rec) / 8)), flush=True)
     e.close()

@@ -13,7 +13,7 @@ python3 -c "
 import json; d=json.load(open('$O/bench_default.json')); r=d['roofline']
 print('steps/s', round(d['value'],3), 'ms/step', round(d['ms_per_step'],2), 'pass', round(r['avg_launch_ms'],4), 'frac', round(r['frac'],3), 'frac_real', r.get('frac_real_traffic'), 'iters', d['qeq_iters_per_step'])
 print('steady', {k: (round(v,3) if isinstance(v,float) else v) for k,v in d.get('steady',{}).items() if k in ('ms_per_step','steps_per_s','qeq_iters_per_step','avg_pass_ms')})
-print('alt', d.get('alt',{}).get('ms_per_step'), 'lex', d.get('alt_lex',{}).get('ms_per_step'), 'one_stream', d.get('alt_one_stream',{}).get('ms_per_step'), 'noplace', d.get('alt_no_placement_search',{}).get('ms_per_step'), 'placement', r.get('placement_search'))
+print('alt', d.get('alt',{}).get('ms_per_step'), 'lex', d.get('alt_lex',{}).get('ms_per_step'), 'bond_streams', d.get('alt_bond_streams',{}).get('ms_per_step'), 'noplace', d.get('alt_no_placement_search',{}).get('ms_per_step'), 'placement', r.get('placement_search'))
 print('other', [(o.get('workload','')[:30], o.get('ms_per_step'), o.get('roofline',{}).get('avg_launch_ms'), o.get('roofline',{}).get('frac')) for o in d.get('other_configs',[])])
 print('cpu', d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('cores'))
 print({k: round(v,2) for k,v in d['breakdown_ms_per_step'].items() if v}); print([(k['name'][:14], round(k['ms'],3), k.get('bound'), k.get('frac_of_bound') and round(k['frac_of_bound'],2)) for k in r['kernels']])"

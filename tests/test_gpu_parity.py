@@ -930,13 +930,12 @@ def test_other_force_fields_and_systems_the_reference_ships(case, qeq_mode):
 @pytest.mark.parametrize("case,mc,kw", [("rdx222", (2, 2, 2), {}), ("rdx168", (5, 5, 5), {}), ("ice644", (6, 4, 4), {}), ("rdx222", (2, 2, 2), {"isQEq": 2}), ("rdx168", (1, 1, 1), {"qstep": 3})])
 def test_bonded_chain_on_its_own_stream_gives_the_same_trajectory(case, mc, kw, monkeypatch):
     """The charge-free part of FORCE (bond orders, bonded terms, assembly of the bonded forces) runs on a stream of its own next to the QEq
-    iterations and ENbond (engine.h: bond_stream); RXMD_NO_BOND_OVERLAP=1 is the one-stream order.  Same kernels on the same inputs: what
+    iterations and ENbond (engine.h: bond_stream) when RXMD_BOND_OVERLAP=1; the default is the one-stream order.  Same kernels on the same inputs: what
     differs is that ENbond's force is added behind the bonded forces instead of before them -- the last bit of a sum.  Standalone calls
     (QEq, FORCE) and 8 steps through step(), with every QEq setting that changes what is in flight when the chain starts."""
     res = {}
     for overlap in (True, False):
-        if not overlap:
-            monkeypatch.setenv("RXMD_NO_BOND_OVERLAP", "1")
+        monkeypatch.setenv("RXMD_BOND_OVERLAP", "1" if overlap else "0")
         e = _engine(case, mc, QEq_tol=1e-12, NMAXQEq=2000, qeq_mode=1, **kw)
         e.QEq(); pe0 = np.array(e.FORCE()); a0 = e.atoms()
         assert e.stats()["bond_overlap"] == int(overlap)
