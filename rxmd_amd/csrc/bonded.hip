@@ -418,8 +418,16 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
   const int jbase = (xcd_swizzle(vb, VB) * WPB + w) * NG;
   if (jbase >= N) continue;                      // whole wavefront skips together; no block-level barrier below
   int npass = 1, c_me = 0, cpre = 0;
+  // (round 6) packed forms: what the slot lanes need of their centre atom -- first bond, type, position, delta, global id -- is loaded by the atom's lane
+  // WITH the bond count and handed over through LDS -- rows 0..7 of the slot accumulators, which the set-up clears only after it has read them --: one round
+  // trip less in front of the bond data than loading it by j_me once the lanes are laid out (the rare second pass of a group loads it that way)
   if (PACK) {                                     // lanes 0..PKN-1: lanes the atom needs, inclusive prefix
-    if (lane < PKN && jbase + lane < N) c_me = min(nbrcnt[jbase + lane], CAP) + 1;
+    if (lane < PKN && jbase + lane < N) {
+      const int ja = jbase + lane;
+      c_me = min(nbrcnt[ja], CAP) + 1;
+      s_acc[w][lane][0] = x[ja]; s_acc[w][lane][1] = y[ja]; s_acc[w][lane][2] = z[ja]; s_acc[w][lane][3] = delta[ja];
+      s_acc[w][lane][4] = __longlong_as_double(gid[ja]); s_acc[w][lane][5] = __hiloint2double(boff[ja], type[ja]);
+    }
     cpre = c_me;
 #pragma unroll
     for (int o = 1; o < PKN; o <<= 1) { const int t = __shfl_up(cpre, o, 64); if (lane >= o) cpre += t; }
@@ -451,9 +459,18 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
     nj_me = has_me ? min(nbrcnt[j_me], SL - 1) : 0;
   }
   const bool self_me = has_me && (PACK ? sl_me == nj_me : sl_me == SL - 1);   // the lane that stands for the atom itself (never a bond)
-  const int tj_me = has_me ? type[j_me] : 1;
-  const double xj_me = has_me ? x[j_me] : 0.0, yj_me = has_me ? y[j_me] : 0.0, zj_me = has_me ? z[j_me] : 0.0;
-  const int ob_me = has_me ? boff[j_me] : 0;      // bonds of an atom are consecutive (CSR): the lanes of this wavefront read consecutive addresses
+  int tj_me, ob_me; double xj_me, yj_me, zj_me, dj_me; long long gj_me;
+  if (PACK && pass == 0) {                        // (behind the wave_lds_sync of the lane layout above)
+    const int src = g0 + g_me;
+    const double ot = s_acc[w][src][5];
+    tj_me = has_me ? __double2loint(ot) : 1; ob_me = has_me ? __double2hiint(ot) : 0;
+    xj_me = s_acc[w][src][0]; yj_me = s_acc[w][src][1]; zj_me = s_acc[w][src][2]; dj_me = s_acc[w][src][3]; gj_me = __double_as_longlong(s_acc[w][src][4]);
+  } else {
+    tj_me = has_me ? type[j_me] : 1;
+    xj_me = has_me ? x[j_me] : 0.0; yj_me = has_me ? y[j_me] : 0.0; zj_me = has_me ? z[j_me] : 0.0;
+    ob_me = has_me ? boff[j_me] : 0;              // bonds of an atom are consecutive (CSR): the lanes of this wavefront read consecutive addresses
+    dj_me = has_me ? delta[j_me] : 0.0; gj_me = has_me ? gid[j_me] : 0;
+  }
   s_meta[w][lane] = 0;
   bool cap_me = false, cb_me = false;              // this slot qualifies as an i / as a centre bond of this wavefront (ONCE: only in the reference's orientation gid(j) < gid(k))
   if (sl_me < nj_me) {
@@ -461,6 +478,8 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
     const int i = nbr[o], ti = btype[o];
     const double rx = x[i] - xj_me, ry = y[i] - yj_me, rz = z[i] - zj_me;      // r_i - r_j
     const double b = bo0[o];
+    // what a centre bond needs of its far end and of the bond, requested with the rest and not behind the test of the bond order (one round trip less)
+    const double d_i = delta[i], b2_o = bo2[o]; const long long g_i = gid[i]; const int bi = boff[i], nc_i = nbrcnt[i], br_o = ONCE ? brev[o] : 0;
     cap_me = b > cutof2_esub;
     s_nb[w][lane] = i;
     int meta = ti;
@@ -468,17 +487,16 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
     s_rx[w][lane] = rx; s_ry[w][lane] = ry; s_rz[w][lane] = rz; s_rn[w][lane] = sqrt(rx * rx + ry * ry + rz * rz);
     if (b > cutof2_esub) {                       // this slot as a centre bond j-k (pot.F90:1023)
       const DevAtomP aj = ff.atom[tj_me];
-      const double delta_ang_jk = (delta[j_me] + aj.Val - aj.Valangle) + (delta[i] + ff.atom[ti].Val - ff.atom[ti].Valangle);
+      const double delta_ang_jk = (dj_me + aj.Val - aj.Valangle) + (d_i + ff.atom[ti].Val - ff.atom[ti].Valangle);
       const double exp_tor3 = exp(-ff.ptor3 * delta_ang_jk), exp_tor4 = exp(ff.ptor4 * delta_ang_jk);
       const double exp_tor34_i = 1.0 / (1.0 + exp_tor3 + exp_tor4);
       const double fn11 = (2.0 + exp_tor3) * exp_tor34_i;
       s_dfn11[w][lane] = (-ff.ptor3 * exp_tor3 + (ff.ptor3 * exp_tor3 - ff.ptor4 * exp_tor4) * (2.0 + exp_tor3) * exp_tor34_i) * exp_tor34_i;
-      s_btb2[w][lane] = 2.0 - bo2[o] - fn11;
-      const bool own = gid[j_me] < gid[i];
-      const int bi = boff[i];
-      meta |= (min(nbrcnt[i], 255) << 8) | (own ? 1 << 16 : 0);
+      s_btb2[w][lane] = 2.0 - b2_o - fn11;
+      const bool own = gj_me < g_i;
+      meta |= (min(nc_i, 255) << 8) | (own ? 1 << 16 : 0);
       s_bofn[w][lane] = bi;
-      if (ONCE) { meta |= (brev[o] - bi) << 17; cb_me = own; }   // the slot of j in the list of k (< MAXNEIGHBS = 30): where the k-l side of this centre bond is delivered
+      if (ONCE) { meta |= (br_o - bi) << 17; cb_me = own; }   // the slot of j in the list of k (< MAXNEIGHBS = 30): where the k-l side of this centre bond is delivered
       else cb_me = true;
     }
     s_meta[w][lane] = meta;
