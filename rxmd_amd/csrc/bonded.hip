@@ -741,7 +741,13 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
       const int cbl = lane / KW, ks = lane % KW;
       const double bl = nx_bl; const int l = nx_l, tl = nx_tl;
       if (r0 + CPB < ncb) fetch_round(r0 + CPB);
-      const bool capl = bl > cutof2_esub;
+      // a slot of k stays in the round's list only if it can be the k-l bond of THIS centre bond: above the cut-off, BO(j,k) BO(k,l) above it, l not j
+      // (pot.F90:1072,1081 -- tests that do not depend on i: applied here, once per slot, instead of once per (i, l) combination)
+      bool capl = bl > cutof2_esub;
+      if (r0 + cbl < ncb) {
+        const int ent = s_cb[w][r0 + cbl];
+        capl = capl && (s_bo[w][ent & 255] * bl > cutof2_esub) && (l != jbase + g0 + (ent >> 8));
+      }
       ml = __ballot(capl);
       if (capl) {
         const unsigned sub = static_cast<unsigned>(ml >> (cbl * KW)) & ((KW == 32) ? 0xffffffffu : 0xffffu);

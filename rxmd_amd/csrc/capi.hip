@@ -380,6 +380,7 @@ int rxmd_hip_get_stats(rxmd_handle h, rxmd_stats *out) {
   return guarded(h, [&](Engine &e) {
     if (e.atoms_set && e.lists_valid) {
       RX_HIP(hipStreamSynchronize(e.stream));
+      e.collect_timers();
       std::vector<int> n10(e.N), nb(e.G);
       RX_HIP(hipMemcpy(n10.data(), e.n10, sizeof(int) * e.N, hipMemcpyDeviceToHost));
       RX_HIP(hipMemcpy(nb.data(), e.nbrcnt, sizeof(int) * e.G, hipMemcpyDeviceToHost));

@@ -297,6 +297,10 @@ struct Engine {
   void free_device();
   void ghost_build();
   void ghost_build_fused(); void migrate_fused(); void ensure_seg_buffers(int nblocks);   // single rank: the six-stage self exchange as 26 image segments (engine.hip)
+  // counts the host waits for, handed over through pinned host memory: word = sequence number << 32 | value; the host polls until every word carries the
+  // sequence number of its request (rccl_comm.hip: pinned_wait) -- no copy, no stream synchronisation, and the kernels queued behind the producer keep running
+  unsigned long long *h_pub = nullptr; unsigned pub_seq = 0u;
+  void pinned_wait(int nwords, unsigned seq, const char *what);
   int *seg_cnt = nullptr, *seg_tot = nullptr, *h_seg = nullptr; unsigned char *seg_code_ = nullptr; int seg_blocks_cap = 0;
   void bin_cells();
   void build_bonded_list(bool pack_only = false);
@@ -396,8 +400,14 @@ struct Engine {
   // dependent operations costs the chain ~7 us per event (profiles/r06_ab_pass_events.txt), four pairs per iteration were ~50 us of every iteration of the
   // multi-rank loop.  Such a site is timed on every n-th call only (opt.pass_timing_every) and its milliseconds count n-fold; its calls are all counted.
   unsigned long long kt_site_calls[4] = {0, 0, 0, 0};
+  int kt_every = 1, kt_phase = 0;                  // Engine::step: section / kernel timers on every kt_every-th step of a long call, milliseconds counted kt_every-fold
   bool kt_begin(double *dst, double *dst2 = nullptr, long long *cnt = nullptr, int site = -1) {
     double scale = 1.0;
+    if (site < 0 && kt_every > 1) {
+      if (cnt) { *cnt += 1; cnt = nullptr; }
+      if (kt_phase % kt_every != 0) return false;
+      scale = static_cast<double>(kt_every);
+    }
     if (site >= 0) {
       if (cnt) { *cnt += 1; cnt = nullptr; }
       const unsigned long long every = static_cast<unsigned long long>(opt.pass_timing_every > 1 ? opt.pass_timing_every : 1);
@@ -421,7 +431,7 @@ struct Engine {
     KtPair p{};
     if (kt_free.empty()) { ++st.timer_pairs_dropped; return p; }
     p = kt_free.back(); kt_free.pop_back();
-    p.dst = dst; p.dst2 = nullptr; p.cnt = nullptr; p.scale = 1.0;
+    p.dst = dst; p.dst2 = nullptr; p.cnt = nullptr; p.scale = 1.0;          // (the sections -- a whole QEq call, FORCE, the list build -- are timed on every step: the iteration count differs from step to step)
     hipEventRecord(p.a, stream);
     return p;
   }

@@ -451,6 +451,7 @@ void Engine::free_device() {
   if (h_err) { (void)hipHostFree(h_err); h_err = nullptr; }
   dfree(seg_cnt); dfree(seg_tot); dfree(seg_code_); seg_blocks_cap = 0;
   if (h_seg) { (void)hipHostFree(h_seg); h_seg = nullptr; }
+  if (h_pub) { (void)hipHostFree(h_pub); h_pub = nullptr; }
   if (cubtmp) { (void)hipFree(cubtmp); cubtmp = nullptr; }
   if (ffblob) { (void)hipFree(ffblob); ffblob = nullptr; }
 }
@@ -770,7 +771,9 @@ __global__ void __launch_bounds__(256) k_seg_count(int N, BoxDev B, SegGeom sg, 
   if (threadIdx.x < (MOVE ? 27 : 26)) cnt[static_cast<size_t>(threadIdx.x) * gridDim.x + blockIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
 }
 // pass 2: one workgroup per segment: exclusive prefix of its per-workgroup counts in place, its total -> tot[seg]
-__global__ void __launch_bounds__(256) k_seg_scan(int nblocks, int *__restrict__ cnt, int *__restrict__ tot) {
+// hpub (the ghost build of one rank): the total also goes straight into pinned host memory, tagged with the build's sequence number in the upper half of
+// the word -- the host polls these words instead of waiting for a copy behind the placement kernel (pinned_wait)
+__global__ void __launch_bounds__(256) k_seg_scan(int nblocks, int *__restrict__ cnt, int *__restrict__ tot, unsigned long long *hpub = nullptr, unsigned seq = 0u) {
   __shared__ int s_p[256];
   int *c = cnt + static_cast<size_t>(blockIdx.x) * nblocks;
   const int per = (nblocks + 255) / 256, b0 = threadIdx.x * per, b1 = min(b0 + per, nblocks);
@@ -786,7 +789,14 @@ __global__ void __launch_bounds__(256) k_seg_scan(int nblocks, int *__restrict__
   }
   int run = s_p[threadIdx.x] - sum;
   for (int b = b0; b < b1; ++b) { const int v = c[b]; c[b] = run; run += v; }
-  if (threadIdx.x == 255) tot[blockIdx.x] = s_p[255];
+  if (threadIdx.x == 255) {
+    tot[blockIdx.x] = s_p[255];
+    if (hpub) __hip_atomic_store(hpub + blockIdx.x, (static_cast<unsigned long long>(seq) << 32) | static_cast<unsigned>(s_p[255]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// the error word and the counts of a list build (d_err[0..15]) into pinned host memory, each tagged with the build's sequence number
+__global__ void k_publish_words(int n, const int *__restrict__ src, unsigned long long *hpub, unsigned seq) {
+  if (threadIdx.x < n) __hip_atomic_store(hpub + threadIdx.x, (static_cast<unsigned long long>(seq) << 32) | static_cast<unsigned>(src[threadIdx.x]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // rank of this thread's atom among the atoms of its workgroup that segment `need` takes (lanes before it + wavefronts before it), from the
 // per-wavefront counts in LDS
@@ -845,10 +855,14 @@ void Engine::ghost_build_fused() {
   const int nbk = nblk(N, 256);
   ensure_seg_buffers(nbk);
   k_seg_count<false><<<nbk, 256, 0, stream>>>(N, B, sg, pos[0], pos[1], pos[2], spos[0], spos[1], spos[2], type, seg_code_, seg_cnt);
-  k_seg_scan<<<26, 256, 0, stream>>>(nbk, seg_cnt, seg_tot);
+  // The one host wait of the ghost build: the ghost count sizes every launch behind it.  The scan kernel hands the 26 totals to the host through pinned
+  // memory (round 6, late): the host has them while the placement kernel still runs and queues the next kernels behind it -- until then a copy behind the
+  // placement kernel and a stream synchronisation left the GPU idle for ~35 us per step.
+  const unsigned seq = ++pub_seq;
+  k_seg_scan<<<26, 256, 0, stream>>>(nbk, seg_cnt, seg_tot, h_pub, seq);
   k_seg_place_ghosts<<<nbk, 256, 0, stream>>>(N, NB, B, sg, seg_code_, seg_cnt, seg_tot, spos[0], spos[1], spos[2], pos[0], pos[1], pos[2], type, gid, q, gsrc, groot, sendidx);
-  RX_HIP(hipMemcpyAsync(h_seg, seg_tot, sizeof(int) * 26, hipMemcpyDeviceToHost, stream));
-  sync_stream();                                                         // the one host wait of the build: the ghost count sizes every launch behind it
+  pinned_wait(26, seq, "ghost counts");
+  for (int s = 0; s < 26; ++s) h_seg[s] = static_cast<int>(h_pub[s] & 0xffffffffull);
   copyptr[0] = N; sendoff[1] = 0;
   for (int d = 1; d <= 6; ++d) {
     long long t = 0;
@@ -940,6 +954,7 @@ void Engine::ensure_seg_buffers(int nbk) {
   seg_blocks_cap = nbk + nbk / 4 + 16;
   dmalloc(seg_cnt, static_cast<size_t>(27) * seg_blocks_cap); dzalloc(seg_tot, 32); dmalloc(seg_code_, static_cast<size_t>(seg_blocks_cap) * 256);   // (one face code per RESIDENT: sized with the workgroup count, not with the NB of the day)
   if (!h_seg) RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_seg), 32 * sizeof(int)));
+  if (!h_pub) { RX_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_pub), 32 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped)); for (int k = 0; k < 32; ++k) h_pub[k] = 0ull; }
 }
 
 void Engine::halo_refresh(double2 *v2, double *v1) {
@@ -1580,7 +1595,7 @@ void Engine::poison_step_scratch() {
 
 void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
-  tic(0);
+  const KtPair t_lists = outer_begin(&st.ms_lists);   // (an event pair read at a later host wait: no wait of its own)
   poison_step_scratch();
   { const bool kt = kt_begin(&st.ms_ghost_build); ghost_build(); kt_end(kt); }
   bin_cells();
@@ -1592,7 +1607,13 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   // The host wait of the build.  First of all the bond tables: a build with more bonds than they hold left them partially packed (k_bond_csr skips
   // the atoms beyond the capacity) -- they are grown and packed again from the intact staging lines BEFORE anything else can throw, so that no
   // error path leaves undersized tables and stale counts behind.
-  fetch_device_error();
+  if (h_pub && !multi()) {                           // (one rank: the words through pinned memory, no copy + stream synchronisation; h_pub exists once the fused ghost build has run)
+    const unsigned seq = ++pub_seq;
+    k_publish_words<<<1, 64, 0, stream>>>(16, d_err, h_pub, seq);
+    pinned_wait(16, seq, "list build");
+    for (int k = 0; k < 16; ++k) h_err[k] = static_cast<int>(h_pub[k] & 0xffffffffull);
+  } else
+    fetch_device_error();
   if (static_cast<size_t>(h_err[7]) > bcap) {
     free_bond_tables();
     alloc_bond_tables(static_cast<size_t>(h_err[7]) + static_cast<size_t>(h_err[7]) / 4 + 4096);
@@ -1622,7 +1643,7 @@ void Engine::build_ghosts_and_lists(bool qeq_prepass) {
   max_row10 = h_err[3]; min_row10 = std::min(h_err[4], h_err[3]);   // longest / shortest 10 A row of this build (k_list10)
   win_maxunits = h_err[5]; win_valid = win_groups > 0 && h_err[6] == 0 && win_maxunits > 0 && (!multi() || (win_nbnd >= 0 && win_nbnd <= win_groups)) && !opt.spmv_no_win;   // window form of the matrix (build_windows)
   collect_timers();
-  st.ms_lists += toc(0, 1);
+  outer_end(t_lists);
   lists_valid = true;
 }
 

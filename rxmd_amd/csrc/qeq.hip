@@ -594,7 +594,6 @@ void Engine::qeq() {
   if (!atoms_set) throw EngineError(RXMD_E_STATE, "atoms were never set");
   if (cfg.isQEq != 1 && cfg.isQEq != 2) { nstep_qeq = 0; return; }   // qeq.F90:60-61
   rows_live = false;
-  tic(6);
   const KtPair t_qeq = outer_begin(&st.ms_qeq);
   // the list sweep of this step can form the row sums of the start vector on the way (saves the matrix pass of qeq.F90:87)
   const bool prepass_on = !opt.qeq_no_prepass;      // (experiments build only)

@@ -106,6 +106,26 @@ void Engine::wait_snapshot(int parity, double seq) {
   std::atomic_thread_fence(std::memory_order_acquire);
 }
 
+// The same for counts a kernel leaves in pinned host memory (engine.h: h_pub): every word must carry the sequence number of the request.
+void Engine::pinned_wait(int nwords, unsigned seq, const char *what) {
+  volatile const unsigned long long *w = h_pub;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  auto all_here = [&] { for (int k = 0; k < nwords; ++k) if (static_cast<unsigned>(w[k] >> 32) != seq) return false; return true; };
+  for (;;) {
+    if (all_here()) break;
+    if ((++spins & 1023u) != 0u && spin_wait) continue;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (dt <= 2e-3 && spin_wait) continue;
+    const hipError_t r = hipStreamQuery(stream);
+    if (r != hipSuccess && r != hipErrorNotReady) RX_HIP(r);
+    if (r == hipSuccess) { if (all_here()) break; throw EngineError(RXMD_E_HIP, std::string(what) + ": the counts never reached the host"); }
+    if (dt > comm_timeout_s) throw EngineError(RXMD_E_HIP, std::string(what) + ": timeout waiting for the counts of a kernel");
+    std::this_thread::yield();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+}
+
 void Engine::rccl_destroy() {
   if (nccl) { (void)ncclCommDestroy(C(nccl)); nccl = nullptr; }
   if (cnt_dev) { (void)hipFree(cnt_dev); cnt_dev = nullptr; }
