@@ -657,7 +657,7 @@ def main():
                  ("k_nonbond_win+k_nonbond", "ms_k_nonbond", st["nnz10"] * 4.0 + st["natoms"] * 64.0, a.steps, "ENbond: the entry stream (pot.F90:676-781)"),
                  ("k_bo_prime+k_deltap+k_bo_full+k_delta_lp", "ms_k_bondorder", G * nb * 104.0, a.steps, "BOPRIM + BOFULL over residents and ghosts (bo.F90:28-298)"),
                  ("k_e3b", "ms_k_e3b", st["natoms"] * nb * 104.0, a.steps, "E3b (pot.F90:319-557): FP64 chains, not bytes, bound it"),
-                 ("k_e4b", "ms_k_e4b", st["natoms"] * nb * 104.0, a.steps, "E4b (pot.F90:980-1227): FP64 chains"),
+                 ("k_e4b+k_e4b_deliver", "ms_k_e4b", st["natoms"] * nb * 104.0, a.steps, "E4b (pot.F90:980-1227): every torsion evaluated once on a persistent grid, its k-l side through the delivery table; latency of dependent loads and LDS, not bytes or issue, bounds it"),
                  ("k_ehb_donors+k_ehb_sweep+k_ehb", "ms_k_ehb", st["natoms"] * nb * 104.0, a.steps, "Ehb (pot.F90:559-673): bound by the 51 M memory-side FP64 atomics of the acceptor forces"),
                  ("k_bonded_list+k_bond_csr", "ms_k_blist", G * (32.0 + nb * 13.0), a.steps, "NEIGHBORLIST + nbrindx (main.F90:321-417): positions read once, partner / owner / mirror / type written per bond"),
                  ("k_cd_gather+k_ccbnd_terms+k_ccbnd_sum+k_bond_force_terms+k_bond_force_sum", "ms_k_assemble", G * nb * 104.0, a.steps, "ForceBondedTerms as gathers (pot.F90:113-144)")]

@@ -20,10 +20,6 @@ print({k: round(v,2) for k,v in d['breakdown_ms_per_step'].items() if v}); print
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline --no-other-configs --full-line $O/bench_prof.json > $O/bench_prof.log 2>&1
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats.csv; head -24 $O/kernel_stats.csv | cut -c1-130
 find $O/prof -name '*.csv' ! -name '*stats*' -delete; find $O/prof -name '*.db' -delete
-# the same trace with the charge-free part of FORCE on the main stream again: kernel durations that mean a kernel ALONE (the default run shares the GPU between ENbond and the bonded chain)
-RXMD_NO_BOND_OVERLAP=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_one -- python3 bench.py --no-cpu-baseline --no-other-configs --no-alt --no-steady --full-line $O/bench_prof_one.json > $O/bench_prof_one.log 2>&1
-f=$(find $O/prof_one -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats_one_stream.csv; head -12 $O/kernel_stats_one_stream.csv | cut -c1-130
-find $O/prof_one -name '*.csv' ! -name '*stats*' -delete; find $O/prof_one -name '*.db' -delete
 for w in water sicnp; do
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -- python3 bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-alt --no-steady --full-line $O/bench_$w.json > $O/bench_$w.log 2>&1
   f=$(find $O/prof_$w -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats_$w.csv; head -8 $O/kernel_stats_$w.csv | cut -c1-130
