@@ -685,7 +685,12 @@ __global__ void __launch_bounds__(64 * WPB, E4B_MINB) k_e4b(int N, DevFF ff, con
 #ifdef RXMD_EXPERIMENTS
         if (bx.probe != 6)
 #endif
-        { tkl[ti] = make_double4(c3kl, fll.x, fll.y, fll.z); tflag[ti] = 1; }
+        {   // (written once, read once by another kernel: past the L2's write-allocate)
+          typedef double d4v __attribute__((ext_vector_type(4)));
+          d4v tv; tv.x = c3kl; tv.y = fll.x; tv.z = fll.y; tv.w = fll.z;
+          __builtin_nontemporal_store(tv, reinterpret_cast<d4v *>(tkl) + ti);
+          __builtin_nontemporal_store(static_cast<unsigned char>(1), tflag + ti);
+        }
         // the centre atom's own force is minus the sum of the three others of every torsion: the l part once per run, here; the i and k parts from
         // the slot accumulators at the end (four LDS atomics per lane less, the ones with the most lanes per address)
         double *as = &s_acc[w][PACK ? s_base[w][g + 1] - 1 : gbase(g) + SL - 1][0];
