@@ -246,10 +246,10 @@ def vprocs_for(n):
 #   the (hs,ht) halo of every CG iteration (16 B per ghost) runs under the interior window groups of the matrix pass and counts only beyond them;
 #   two small all-reduces per CG iteration at the latency of N peers instead of one.
 PREDICT = {
-    "source": "profiles/r06_selfloop_staged_overlap.json (one MI355X through the multi-rank code path: 51.79 ms per step at K = 36.55, pass 0.9008 ms in the loop) + assumed wire figures",
-    "selfloop_fixed_ms": 15.52,          # per step: exchange + lists + FORCE + kicks of the self-loop run (its ms per step minus its CG iterations)
-    "selfloop_cg_ms_beyond_the_pass": 0.092,   # per CG iteration beyond the matrix pass itself: vector kernels, the second launch of the split pass, the exposed part of the halo to itself, two all-reduces to itself
-    "single_rank_fixed_ms": 14.8, "single_rank_cg_ms_beyond_the_pass": 0.068,   # the same two figures of the single-rank fast path (profiles/r06_selfloop_single_rank*.json): the N = 1 row of DESIGN.md 6
+    "source": "profiles/r06_final2_selfloop_staged_overlap.json (one MI355X through the multi-rank code path: 49.02 ms per step at K = 36.55, pass 0.8569 ms in the loop) + assumed wire figures",
+    "selfloop_fixed_ms": 14.37,          # per step: exchange + lists + FORCE + kicks of the self-loop run (its ms per step minus its CG iterations)
+    "selfloop_cg_ms_beyond_the_pass": 0.091,   # per CG iteration beyond the matrix pass itself: vector kernels, the second launch of the split pass, the exposed part of the halo to itself, two all-reduces to itself
+    "single_rank_fixed_ms": 13.55, "single_rank_cg_ms_beyond_the_pass": 0.068,   # the same two figures of the single-rank fast path (profiles/r06_final2_selfloop_single_rank*.json): the N = 1 row of DESIGN.md 6
     "allreduce_self_us": 5.5,            # an 8-double ncclAllReduce with one rank: its launch
     "allreduce_us": {1: 5.5, 2: 10.0, 4: 15.0, 8: 20.0},   # ASSUMED small-message latency of RCCL over xGMI (no two-GPU lease inside a round to measure it)
     "xgmi_link_GBs_per_direction": 60.0,  # ASSUMED achieved rate for MB-sized messages (7 links x ~153 GB/s bidirectional per GPU = 76.8 GB/s per direction and link at peak)
