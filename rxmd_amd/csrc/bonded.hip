@@ -341,6 +341,189 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const in
   block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
 }
 
+// Valence angles through a work queue (round 6, late).  k_e3b gives every centre atom a thread: a lane's trip count is its own number of angles (1 to ~40)
+// and a wavefront runs as long as its busiest lane -- the vector unit issues for 0.62 of the kernel's 1.25 ms with mostly empty lanes.  Here a wavefront owns
+// SIXTEEN consecutive centre atoms (the shape of k_e4b): lanes 0..15 set the atoms up (per-centre factors -> LDS), all 64 lanes enumerate the pairs of
+// qualifying bonds (four lanes per atom), apply the reference's cut-offs (pot.F90:385-400) and compact the survivors with a ballot into an LDS ring; a full
+// batch of 64 angles is then evaluated one per lane.  Every angle adds to the accumulators of its two bonds in LDS (ds_add_f64, queue order: the same bits
+// run to run); the centre's own force is minus the sum of its bonds' forces, its all-bond terms are sums per atom; one coalesced pass adds everything to
+// the bond tables.  Persistent grid.  Needs the angle tables in LDS (at most 7 atom types, 63 angle rows) and bond lists of at most E3Q_MAXL entries;
+// otherwise k_e3b runs.
+constexpr int E3Q_NA = 16, E3Q_MAXL = 12, E3Q_BC = E3Q_NA * E3Q_MAXL;     // centre atoms per wavefront, longest bond list, bonds of a wavefront's atoms
+template <int MINW>                                   // wavefronts per SIMD the register budget is cut for (3: 168 registers + scratch, 2: 256)
+__global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ type,
+                                              const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                              const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
+                                              const double *__restrict__ delta, const double *__restrict__ nlp, const double *__restrict__ dDlp,
+                                              const double *__restrict__ epen, const double *__restrict__ ecoa,
+                                              double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
+                                              double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
+                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+  __shared__ int s_ix3[512];
+  __shared__ double s_ang[64][7];
+  // per wavefront: factors of the 16 centres, accumulators of their bonds and of the atoms, the qualifying slots, the queue
+  __shared__ double s_c[4][E3Q_NA][12];            // x, y, z, delta_ang, exp6, ex10, CSBO2, dSBO1, dSBO2, fn9, Cf9j / fn9, exp_coa2
+  __shared__ int s_ci[4][E3Q_NA][4];               // type, first bond, bonds, qualifying bonds
+  __shared__ double s_acc[4][5][E3Q_BC];           // per bond: cf1, cdn, force on the neighbour
+  __shared__ double s_at[4][E3Q_NA][4];            // per atom: S_d1, S_v6, S_v5 (the terms every bond of the centre receives, pot.F90:526-532)
+  __shared__ unsigned char s_cap[4][E3Q_NA][16], s_own[4][E3Q_BC];
+  __shared__ int s_q[4][128];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  for (int t = threadIdx.x; t < ff.n1 * ff.n1 * ff.n1; t += 256) s_ix3[t] = ff.inxn3[t];
+  for (int t = threadIdx.x; t < 7 * (ff.nvaty + 1); t += 256) s_ang[t / 7][t % 7] = reinterpret_cast<const double *>(ff.angle)[t];
+  __syncthreads();
+  double e5 = 0.0, e6 = 0.0, e7 = 0.0;
+  for (int vb = blockIdx.x; vb < NG; vb += gridDim.x) {
+  const int jbase = (xcd_swizzle(vb, NG) * 4 + w) * E3Q_NA;
+  if (jbase >= N) continue;                        // (whole wavefront; no block-level barrier below)
+  const int na = min(E3Q_NA, N - jbase);
+  const int ob_w = boff[jbase], nb_w = boff[jbase + na] - ob_w;             // the bonds of the wavefront's atoms: one contiguous stretch of the compact tables
+  for (int t = lane; t < 5 * E3Q_BC; t += 64) (&s_acc[w][0][0])[t] = 0.0;
+  if (lane < E3Q_NA) { s_at[w][lane][0] = 0.0; s_at[w][lane][1] = 0.0; s_at[w][lane][2] = 0.0; s_ci[w][lane][2] = 0; s_ci[w][lane][3] = 0; }
+  if (lane < na) {                                 // set-up of a centre (pot.F90:352-437, 460-462, 481-483): everything that depends on the centre only
+    const int j = jbase + lane;
+    const int tj = type[j], ob = boff[j], nj = min(boff[j + 1] - ob, E3Q_MAXL);
+    const DevAtomP aj = ff.atom[tj];
+    double sum_BO8 = 0.0, sum_SBO1 = 0.0;
+    int nc = 0;
+    for (int n1 = 0; n1 < nj; ++n1) {
+      const int o = ob + n1;
+      const double b = bo0[o], b2 = b * b, b4 = b2 * b2;
+      sum_BO8 -= b4 * b4;                                                  // BO**8, pot.F90:362
+      sum_SBO1 += bo2[o] + bo3[o];
+      if (b - cutof2_esub > 0.0) s_cap[w][lane][nc++] = static_cast<unsigned char>(n1);   // pot.F90:372-373, 385-386
+      s_own[w][o - ob_w] = static_cast<unsigned char>(lane);
+    }
+    const double prod_SBO = exp(sum_BO8);
+    const double dlj = delta[j];
+    const double delta_ang = dlj + aj.Val - aj.Valangle;
+    const double nlpj = nlp[j], dDj = dDlp[j];
+    const double exp_pen3 = exp(-ff.ppen3 * dlj), exp_pen4 = exp(ff.ppen4 * dlj);
+    const double trm34 = 1.0 + exp_pen3 + exp_pen4;
+    const double fn9 = (2.0 + exp_pen3) / trm34;
+    const double Cf9j = (-ff.ppen3 * exp_pen3 * trm34 - (2.0 + exp_pen3) * (-ff.ppen3 * exp_pen3 + ff.ppen4 * exp_pen4)) / (trm34 * trm34);
+    const double delta_val = dlj + aj.Val - aj.Valval;
+    const double SBO = sum_SBO1 + (1.0 - prod_SBO) * (-delta_ang - ff.pval8 * nlpj);
+    double SBO2 = 0.0, CSBO2 = 0.0;
+    if (SBO > 0.0 && SBO <= 1.0) { SBO2 = pow(SBO, ff.pval9); CSBO2 = ff.pval9 * pow(SBO, ff.pval9 - 1.0); }
+    else if (SBO > 1.0 && SBO <= 2.0) { SBO2 = 2.0 - pow(2.0 - SBO, ff.pval9); CSBO2 = ff.pval9 * pow(2.0 - SBO, ff.pval9 - 1.0); }
+    else if (SBO > 2.0) SBO2 = 2.0;
+    double *c = s_c[w][lane];
+    c[0] = x[j]; c[1] = y[j]; c[2] = z[j]; c[3] = delta_ang; c[4] = exp(ff.pval6 * delta_ang); c[5] = exp(-ff.pval10 * (2.0 - SBO2)); c[6] = CSBO2;
+    c[7] = -8.0 * prod_SBO * (delta_ang + ff.pval8 * nlpj); c[8] = (prod_SBO - 1.0) * (1.0 - ff.pval8 * dDj); c[9] = fn9; c[10] = Cf9j / fn9; c[11] = exp(ff.pcoa2 * delta_val);
+    s_ci[w][lane][0] = tj; s_ci[w][lane][1] = ob; s_ci[w][lane][2] = nj; s_ci[w][lane][3] = nc;
+  }
+  wave_lds_sync();
+  int qn = 0, qh = 0;
+  auto evaluate = [&](int cnt) {                   // one angle per lane: queue entry = atom << 10 | slot i1 << 5 | slot k1 (i1 < k1)
+    if (lane < cnt) {
+      const int key = s_q[w][(qh + lane) & 127];
+      const int a = key >> 10, i1 = (key >> 5) & 31, k1 = key & 31;
+      const double *c = s_c[w][a];
+      const int tj = s_ci[w][a][0], ob = s_ci[w][a][1];
+      const int oi = ob + i1, ok = ob + k1;
+      const double xj = c[0], yj = c[1], zj = c[2], delta_ang = c[3], exp6 = c[4], ex10 = c[5], CSBO2 = c[6], dSBO1 = c[7], dSBO2 = c[8], fn9 = c[9], Cf9j_fn9 = c[10], exp_coa2 = c[11];
+      const DevAtomP aj = ff.atom[tj];
+      const int i = nbr[oi], ti = btype[oi], k = nbr[ok], tk = btype[ok];
+      const double BOij = bo0[oi] - cutof2_esub, BOjk = bo0[ok] - cutof2_esub;
+      const V3 rij = {x[i] - xj, y[i] - yj, z[i] - zj};
+      const double nij = sqrt(dot(rij, rij));
+      const V3 rjk = {xj - x[k], yj - y[k], zj - z[k]};
+      const double njk = sqrt(dot(rjk, rjk));
+      const double *a_ = s_ang[s_ix3[(ti * ff.n1 + tj) * ff.n1 + tk]];
+      const DevAngleP ap = DevAngleP{a_[0], a_[1], a_[2], a_[3], a_[4], a_[5], a_[6]};
+      double cos_ijk = -dot(rij, rjk) / (nij * njk);
+      if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
+      if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
+      const double theta_ijk = acos(cos_ijk), sin_ijk = sqrt((1.0 - cos_ijk) * (1.0 + cos_ijk));   // sin(acos(c))
+      const double BOij_p4 = pow(BOij, ap.pval4), exp3ij = exp(-aj.pval3 * BOij_p4), fn7ij = 1.0 - exp3ij;
+      const double BOjk_p4 = pow(BOjk, ap.pval4), exp3jk = exp(-aj.pval3 * BOjk_p4), fn7jk = 1.0 - exp3jk;
+      const double exp7 = exp(-ap.pval7 * delta_ang), trm8 = 1.0 + exp6 + exp7;
+      const double fn8j = aj.pval5 - (aj.pval5 - 1.0) * (2.0 + exp6) / trm8;
+      const double theta0 = PI_ - ap.theta00 * (1.0 - ex10);
+      const double theta_diff = theta0 - theta_ijk;
+      const double exp2 = exp(-ap.pval2 * theta_diff * theta_diff);
+      e5 += fn7ij * fn7jk * fn8j * (ap.pval1 - ap.pval1 * exp2);
+      const double Cf7ij = aj.pval3 * ap.pval4 * (BOij_p4 / BOij) * exp3ij;                 // BO**(pval4-1) = BO**pval4 / BO
+      const double Cf7jk = aj.pval3 * ap.pval4 * (BOjk_p4 / BOjk) * exp3jk;
+      const double Cf8j = (1.0 - aj.pval5) / (trm8 * trm8) * (ff.pval6 * exp6 * trm8 - (2.0 + exp6) * (ff.pval6 * exp6 - ap.pval7 * exp7));
+      const double Ctheta0 = ff.pval10 * ap.theta00 * ex10;
+      const double CEval1 = Cf7ij * fn7jk * fn8j * ap.pval1 * (1.0 - exp2);
+      const double CEval2 = fn7ij * Cf7jk * fn8j * ap.pval1 * (1.0 - exp2);
+      const double CEval3 = fn7ij * fn7jk * Cf8j * ap.pval1 * (1.0 - exp2);
+      const double CEval4 = 2.0 * ap.pval1 * ap.pval2 * fn7ij * fn7jk * fn8j * exp2 * theta_diff;
+      const double CEval5 = CEval4 * Ctheta0 * CSBO2;
+      const double CEval6 = CEval5 * dSBO1, CEval7 = CEval5 * dSBO2, CEval8 = CEval4 / sin_ijk;
+      const double PEpen = ap.ppen1 * fn9 * epen[oi] * epen[ok];             // penalty, pot.F90:460-476
+      e6 += PEpen;
+      const double CEpen1 = Cf9j_fn9 * PEpen, CEpen2 = -2.0 * ff.ppen2 * (BOij - 2.0) * PEpen, CEpen3 = -2.0 * ff.ppen2 * (BOjk - 2.0) * PEpen;
+      const double sum_BOi = delta[i] + ff.atom[ti].Val, sum_BOk = delta[k] + ff.atom[tk].Val;   // three-body conjugation, pot.F90:479-497
+      const double ui = -BOij + sum_BOi, uk = -BOjk + sum_BOk;
+      const double PEcoa = ap.pcoa1 / (1.0 + exp_coa2) * ecoa[oi] * ecoa[ok];
+      e7 += PEcoa;
+      const double CEcoa1 = -2.0 * ff.pcoa4 * (BOij - 1.5) * PEcoa, CEcoa2 = -2.0 * ff.pcoa4 * (BOjk - 1.5) * PEcoa;
+      const double CEcoa3 = -ff.pcoa2 * exp_coa2 / (1.0 + exp_coa2) * PEcoa;
+      const double CEcoa4 = -2.0 * ff.pcoa3 * ui * PEcoa, CEcoa5 = -2.0 * ff.pcoa3 * uk * PEcoa;
+      V3 fi, fk;
+      angle_forces(CEval8, rij, nij, rjk, njk, fi, fk);
+      const int ri = oi - ob_w, rk = ok - ob_w;                             // accumulate, pot.F90:509-541
+      atomicAdd(&s_acc[w][0][ri], CEpen2 + CEcoa1 - CEcoa4 + CEval1); atomicAdd(&s_acc[w][1][ri], CEcoa4);
+      atomicAdd(&s_acc[w][2][ri], fi.x); atomicAdd(&s_acc[w][3][ri], fi.y); atomicAdd(&s_acc[w][4][ri], fi.z);
+      atomicAdd(&s_acc[w][0][rk], CEpen3 + CEcoa2 - CEcoa5 + CEval2); atomicAdd(&s_acc[w][1][rk], CEcoa5);
+      atomicAdd(&s_acc[w][2][rk], fk.x); atomicAdd(&s_acc[w][3][rk], fk.y); atomicAdd(&s_acc[w][4][rk], fk.z);
+      atomicAdd(&s_at[w][a][0], CEpen1 + CEcoa3 + CEval3 + CEval7); atomicAdd(&s_at[w][a][1], CEval6); atomicAdd(&s_at[w][a][2], CEval5);
+    }
+    wave_lds_sync();
+  };
+  // enumeration: four lanes per atom; lane s of an atom takes the first bonds u = s, s + 4, ... of its qualifying list, each with every later one
+  {
+    const int a = lane >> 2, sub = lane & 3;
+    const int nc = s_ci[w][a][3], tj = s_ci[w][a][0], ob = s_ci[w][a][1];
+    int u = sub, v = sub + 1;
+    for (;;) {
+      bool live = u < nc - 1;
+      const unsigned long long any = __ballot(live);
+      if (any == 0ULL) break;
+      bool go = false;
+      int key = 0;
+      if (live) {
+        const int i1 = s_cap[w][a][u], k1 = s_cap[w][a][v];
+        const int oi = ob + i1, ok = ob + k1;
+        go = bo0[oi] * bo0[ok] > cutof2_esub;                               // pot.F90:397
+        if (go) go = s_ix3[(static_cast<int>(btype[oi]) * ff.n1 + tj) * ff.n1 + static_cast<int>(btype[ok])] != 0;
+        key = (a << 10) | (i1 << 5) | k1;
+        if (++v >= nc) { u += 4; v = u + 1; }
+      }
+      const unsigned long long m = __ballot(go);
+      if (go) s_q[w][(qh + qn + __popcll(m & ((1ULL << lane) - 1ULL))) & 127] = key;
+      qn += __popcll(m);
+      wave_lds_sync();
+      if (qn >= 64) { evaluate(64); qh = (qh + 64) & 127; qn -= 64; }
+    }
+    if (qn > 0) evaluate(qn);
+  }
+  // write-out: every bond of the wavefront's atoms, coalesced; then the centres' own forces
+  for (int r = lane; r < nb_w; r += 64) {
+    const int o = ob_w + r, a = s_own[w][r];
+    const double S_d1 = s_at[w][a][0], S_v6 = s_at[w][a][1], S_v5 = s_at[w][a][2];
+    const double c1 = s_acc[w][0][r] + (S_d1 + S_v6 * ipow7(bo0[o]));
+    if (c1 != 0.0) cf1[o] += c1;
+    if (S_v5 != 0.0) { cf2[o] += S_v5; cf3[o] += S_v5; }
+    const double cd = s_acc[w][1][r], f0 = s_acc[w][2][r], f1 = s_acc[w][3][r], f2 = s_acc[w][4][r];
+    if (cd != 0.0) cdn[o] += cd;
+    if (f0 != 0.0 || f1 != 0.0 || f2 != 0.0) { fnx[o] += f0; fny[o] += f1; fnz[o] += f2; }
+  }
+  if (lane < na) {                                 // the centre's force: minus the sum of the forces on its neighbours (ForceA3 books -(fi + fk) on j)
+    const int j = jbase + lane, r0 = s_ci[w][lane][1] - ob_w, nj = s_ci[w][lane][2];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < nj; ++t) { s0 += s_acc[w][2][r0 + t]; s1 += s_acc[w][3][r0 + t]; s2 += s_acc[w][4][r0 + t]; }
+    if (s0 != 0.0 || s1 != 0.0 || s2 != 0.0) { fx[j] -= s0; fy[j] -= s1; fz[j] -= s2; }
+  }
+  wave_lds_sync();                                 // the next group rebuilds the tables
+  }   // groups
+  block_energy_add(e5, pe + 5); block_energy_add(e6, pe + 6); block_energy_add(e7, pe + 7);
+}
+
 struct BoxImg { double H[9], Hi[9], L[3]; int ortho; int probe; };   // lattice vectors for the image test of the torsion's stress correction; probe: RXMD_EXPERIMENTS builds only (RXMD_E4B_PROBE: 1 = set-up only, 2 = phase B skipped, 5 = PE(8), PE(9) count batches and entries)
 // Torsion + four-body conjugation.  The reference walks centre bonds j-k with gid(j) < gid(k) and scatters to i,j,k,l.
 // Here ONE WAVEFRONT owns several consecutive centre atoms; every bond slot of an atom has a lane that owns its accumulators, and
@@ -1118,7 +1301,15 @@ void Engine::bonded_energies() {
   k_ebond_terms<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, btype, type, gid, bo0, bo1, bo2, bo3, delta, deltalp, cf1, cf2, cf3, ecoa, bt1, bt2, pe_d);
   k_elnpr_atoms<<<nblk(N, 256), 256, 0, stream>>>(N, dff, boff, type, bt1, bt2, delta, deltalp, dDlp, ecoef, pe_d);
   k_elnpr_bonds<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, btype, type, bo2, bo3, delta, deltalp, dDlp, ecoef, cf1, cf2, cf3, cdn);
-const bool kt3 = kt_begin(&st.ms_k_e3b);
+  const bool kt3 = kt_begin(&st.ms_k_e3b);
+  // the work-queue form (k_e3q) when the angle tables fit LDS and no bond list of the step is longer than E3Q_MAXL (h_err[2]: the longest list, 0 up to 8)
+  if (opt.e3b_queue != 0 && dff.n1 <= 8 && dff.nvaty <= 63 && h_err[2] <= E3Q_MAXL) {
+    const int NG = nblk(N, 4 * E3Q_NA);
+    if (opt.e3b_queue == 3) k_e3q<3><<<std::min(NG, (num_cu * 3 + 7) & ~7), 256, 0, stream>>>(N, NG, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+                                                                                            cds, frc[0], frc[1], frc[2], pe_d);
+    else k_e3q<2><<<std::min(NG, (num_cu * 2 + 7) & ~7), 256, 0, stream>>>(N, NG, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+                                                                         cds, frc[0], frc[1], frc[2], pe_d);
+  } else
     k_e3b<<<nblk(N, 256), 256, 4 * 5 * E3B_CAP * sizeof(double), stream>>>(N, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);
   RX_HIP(hipGetLastError());                       // 70 KB of dynamic LDS: a refused launch must not pass for "no valence angles"

@@ -644,6 +644,27 @@ def test_torsions_visited_once_and_twice_and_the_persistent_grid(case, mc, kw, m
     assert same(f2, res[("0", "0", "1")][0])
 
 
+@pytest.mark.parametrize("case,mc,kw", [("rdx168", (1, 1, 1), {}), ("rdx222", (2, 2, 2), {}), ("rdx168", (5, 5, 5), {}), ("ice644", (6, 4, 4), {}), ("example1", (2, 3, 5), {}),
+                                        ("sicnp", (1, 1, 1), dict(pqeq=oa.PQEQ_SICNP))])
+def test_valence_angles_through_the_queue_and_per_thread(case, mc, kw, monkeypatch):
+    """Two forms of E3b (pot.F90:319-557): a thread per centre atom (`k_e3b`, RXMD_E3B_QUEUE=0) and sixteen centre atoms per wavefront with the surviving
+    angles compacted into a queue and evaluated 64 at a time (`k_e3q`, default where no bond list is longer than 12 and the angle tables fit LDS; 2 / 3 =
+    the register budget).  The same terms summed in another order: forces within 1e-10, energies within 1e-12 relative, both against the oracle."""
+    kw = dict(QEq_tol=1e-12, NMAXQEq=2000, **kw)
+    o = _oracle(case, mc, **kw); o.qeq(); o.force()
+    res = {}
+    for form in ("0", "2", "3"):
+        monkeypatch.setenv("RXMD_E3B_QUEUE", form)
+        e = _engine(case, mc, **kw)
+        e.QEq(); pe = e.FORCE(); a = e.atoms()
+        assert f_err(a["f"], o.forces()) <= FTOL and e_err(pe, o.energy()) <= ETOL
+        res[form] = (a["f"].copy(), pe.copy())
+        e.close()
+    for form in ("2", "3"):
+        assert np.abs(res[form][0] - res["0"][0]).max() <= 1e-10
+        assert np.allclose(res[form][1], res["0"][1], rtol=1e-12, atol=1e-10)
+
+
 # ---- PQEq (pqeq.F90 / ENbond_PQEq): SiC nanoparticle in O2, conf/init.sicnp, 547 atoms, polarizable shells ----------------
 @pytest.mark.parametrize("qeq_mode", [0, 1])
 def test_pqeq_step0_against_the_reference_golden(qeq_mode):
