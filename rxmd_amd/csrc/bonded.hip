@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
                                               const double *__restrict__ epen, const double *__restrict__ ecoa,
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
-                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe) {
+                                              double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, int probe) {
   __shared__ int s_ix3[512];
   __shared__ double s_ang[64][7];
   // per wavefront: factors of the 16 centres, accumulators of their bonds and of the atoms, the qualifying slots, the queue
@@ -405,9 +405,10 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
     const double delta_val = dlj + aj.Val - aj.Valval;
     const double SBO = sum_SBO1 + (1.0 - prod_SBO) * (-delta_ang - ff.pval8 * nlpj);
     double SBO2 = 0.0, CSBO2 = 0.0;
-    if (SBO > 0.0 && SBO <= 1.0) { SBO2 = pow(SBO, ff.pval9); CSBO2 = ff.pval9 * pow(SBO, ff.pval9 - 1.0); }
-    else if (SBO > 1.0 && SBO <= 2.0) { SBO2 = 2.0 - pow(2.0 - SBO, ff.pval9); CSBO2 = ff.pval9 * pow(2.0 - SBO, ff.pval9 - 1.0); }
-    else if (SBO > 2.0) SBO2 = 2.0;
+    // (b ** p and b ** (p - 1) from ONE exp(p log b), b > 0 in both branches: two calls of the library's pow are ~600 of the set-up's ~900 instructions)
+    if (SBO > 0.0 && SBO <= 1.0) { const double pw = exp(ff.pval9 * log(SBO)); SBO2 = pw; CSBO2 = ff.pval9 * (pw / SBO); }
+    else if (SBO > 1.0 && SBO < 2.0) { const double b_ = 2.0 - SBO, pw = exp(ff.pval9 * log(b_)); SBO2 = 2.0 - pw; CSBO2 = ff.pval9 * (pw / b_); }
+    else if (SBO >= 2.0) SBO2 = 2.0;
     double *c = s_c[w][lane];
     c[0] = x[j]; c[1] = y[j]; c[2] = z[j]; c[3] = delta_ang; c[4] = exp(ff.pval6 * delta_ang); c[5] = exp(-ff.pval10 * (2.0 - SBO2)); c[6] = CSBO2;
     c[7] = -8.0 * prod_SBO * (delta_ang + ff.pval8 * nlpj); c[8] = (prod_SBO - 1.0) * (1.0 - ff.pval8 * dDj); c[9] = fn9; c[10] = Cf9j / fn9; c[11] = exp(ff.pcoa2 * delta_val);
@@ -416,6 +417,10 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
   wave_lds_sync();
   int qn = 0, qh = 0;
   auto evaluate = [&](int cnt) {                   // one angle per lane: queue entry = atom << 10 | slot i1 << 5 | slot k1 (i1 < k1)
+#ifdef RXMD_EXPERIMENTS
+    if (probe == 2) return;
+    if (probe == 5) { if (lane == 0) { atomicAdd(pe + 5, 1.0); atomicAdd(pe + 6, static_cast<double>(cnt)); } return; }
+#endif
     if (lane < cnt) {
       const int key = s_q[w][(qh + lane) & 127];
       const int a = key >> 10, i1 = (key >> 5) & 31, k1 = key & 31;
@@ -436,8 +441,9 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
       if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
       if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
       const double theta_ijk = acos(cos_ijk), sin_ijk = sqrt((1.0 - cos_ijk) * (1.0 + cos_ijk));   // sin(acos(c))
-      const double BOij_p4 = pow(BOij, ap.pval4), exp3ij = exp(-aj.pval3 * BOij_p4), fn7ij = 1.0 - exp3ij;
-      const double BOjk_p4 = pow(BOjk, ap.pval4), exp3jk = exp(-aj.pval3 * BOjk_p4), fn7jk = 1.0 - exp3jk;
+      // BO ** pval4 as exp(pval4 log BO): BO > 0 here, and the library's pow spends most of its ~300 instructions on cases that cannot occur (1e-15 relative apart)
+      const double BOij_p4 = exp(ap.pval4 * log(BOij)), exp3ij = exp(-aj.pval3 * BOij_p4), fn7ij = 1.0 - exp3ij;
+      const double BOjk_p4 = exp(ap.pval4 * log(BOjk)), exp3jk = exp(-aj.pval3 * BOjk_p4), fn7jk = 1.0 - exp3jk;
       const double exp7 = exp(-ap.pval7 * delta_ang), trm8 = 1.0 + exp6 + exp7;
       const double fn8j = aj.pval5 - (aj.pval5 - 1.0) * (2.0 + exp6) / trm8;
       const double theta0 = PI_ - ap.theta00 * (1.0 - ex10);
@@ -475,6 +481,9 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
     }
     wave_lds_sync();
   };
+#ifdef RXMD_EXPERIMENTS
+  if (probe == 1) continue;
+#endif
   // enumeration: four lanes per atom; lane s of an atom takes the first bonds u = s, s + 4, ... of its qualifying list, each with every later one
   {
     const int a = lane >> 2, sub = lane & 3;
@@ -1306,9 +1315,9 @@ void Engine::bonded_energies() {
   if (opt.e3b_queue != 0 && dff.n1 <= 8 && dff.nvaty <= 63 && h_err[2] <= E3Q_MAXL) {
     const int NG = nblk(N, 4 * E3Q_NA);
     if (opt.e3b_queue == 3) k_e3q<3><<<std::min(NG, (num_cu * 3 + 7) & ~7), 256, 0, stream>>>(N, NG, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
-                                                                                            cds, frc[0], frc[1], frc[2], pe_d);
+                                                                                            cds, frc[0], frc[1], frc[2], pe_d, static_cast<int>(opt.e4b_probe));
     else k_e3q<2><<<std::min(NG, (num_cu * 2 + 7) & ~7), 256, 0, stream>>>(N, NG, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
-                                                                         cds, frc[0], frc[1], frc[2], pe_d);
+                                                                         cds, frc[0], frc[1], frc[2], pe_d, static_cast<int>(opt.e4b_probe));
   } else
     k_e3b<<<nblk(N, 256), 256, 4 * 5 * E3B_CAP * sizeof(double), stream>>>(N, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);

@@ -18,6 +18,8 @@ for probe in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("0", "1", "2", "
     for _ in range(5): e.FORCE()
     st = e.stats()
     print("visits %s  probe %s: k_e4b %.3f ms  k_e3b %.3f  k_ehb %.3f" % ("2" if os.environ.get("RXMD_E4B_ONCE", "1") == "0" else "1", probe, st["ms_k_e4b"] / 5, st["ms_k_e3b"] / 5, st["ms_k_ehb"] / 5), flush=True)
+    if probe == "5" and os.environ.get("RXMD_E3Q_COUNT"):
+        pe = e.energy()["PE"]; print("   angle kernel: evaluate calls per FORCE %.0f, angles %.0f (%.1f per call; %.2f calls per wavefront of 16 atoms; %.2f angles per atom)" % (pe[5], pe[6], pe[6] / max(pe[5], 1), pe[5] / (len(rec) / 16), pe[6] / len(rec)), flush=True)
     if probe == "5":
         pe = e.energy()["PE"]; print("   evaluate calls per FORCE %.0f, entries %.0f (%.1f per call; %.2f calls per wavefront of 8 atoms)" % (pe[8], pe[9], pe[9] / max(pe[8], 1), pe[8] / (len(rec) / 8)), flush=True)
     e.close()

@@ -613,7 +613,10 @@ def test_torsion_kernel_instances_give_the_same_forces(case, mc, once, monkeypat
         res.append((a["f"].copy(), pe.copy()))
         e.close()
     for r in res[1:]:
-        assert np.array_equal(res[0][0], r[0]) if once == "0" else np.abs(res[0][0] - r[0]).max() <= 1e-11
+        # (bit for bit where no hydrogen bond adds its acceptor atomics -- the one sum of FORCE whose order is not fixed: one or two components in thousands
+        #  then differ by 1e-16 from engine to engine whatever the instance, scripts/gpu_bits_check.py)
+        if once == "0" and res[0][1][10] == 0.0: assert np.array_equal(res[0][0], r[0])
+        else: assert np.abs(res[0][0] - r[0]).max() <= (1e-13 if once == "0" else 1e-11)
         assert np.allclose(res[0][1], r[1], rtol=1e-12, atol=1e-12)
 
 
@@ -657,7 +660,7 @@ def test_valence_angles_through_the_queue_and_per_thread(case, mc, kw, monkeypat
         monkeypatch.setenv("RXMD_E3B_QUEUE", form)
         e = _engine(case, mc, **kw)
         e.QEq(); pe = e.FORCE(); a = e.atoms()
-        assert f_err(a["f"], o.forces()) <= FTOL and e_err(pe, o.energy()) <= ETOL
+        assert f_err(a["f"], o.forces()) <= FTOL and e_err(pe, o.energy()) <= (1e-8 if "pqeq" in kw else ETOL)    # (PQEq: PE(12) is the small remainder of large sums, see above)
         res[form] = (a["f"].copy(), pe.copy())
         e.close()
     for form in ("2", "3"):
