@@ -656,7 +656,7 @@ def main():
         kdefs = [("k_win_columns+k_list10", "ms_k_list10", st["nnz10"] * 14.0 + st["natoms"] * 40.0, a.steps, "10 A sweep: entry + value + 16-bit window slot written once (qeq.F90:183-268, main.F90:420-477)"),
                  ("k_nonbond_win+k_nonbond", "ms_k_nonbond", st["nnz10"] * 4.0 + st["natoms"] * 64.0, a.steps, "ENbond: the entry stream (pot.F90:676-781)"),
                  ("k_bo_prime+k_deltap+k_bo_full+k_delta_lp", "ms_k_bondorder", G * nb * 104.0, a.steps, "BOPRIM + BOFULL over residents and ghosts (bo.F90:28-298)"),
-                 ("k_e3b", "ms_k_e3b", st["natoms"] * nb * 104.0, a.steps, "E3b (pot.F90:319-557): FP64 chains, not bytes, bound it"),
+                 ("k_e3q+k_e3b", "ms_k_e3b", st["natoms"] * nb * 104.0, a.steps, "E3b (pot.F90:319-557): the surviving angles through a queue, 64 per wavefront batch (k_e3q; k_e3b = a thread per centre atom where a bond list is longer than 12): FP64 exp / log / acos chains, not bytes, bound it"),
                  ("k_e4b+k_e4b_deliver", "ms_k_e4b", st["natoms"] * nb * 104.0, a.steps, "E4b (pot.F90:980-1227): every torsion evaluated once on a persistent grid, its k-l side through the delivery table; latency of dependent loads and LDS, not bytes or issue, bounds it"),
                  ("k_ehb_donors+k_ehb_sweep+k_ehb", "ms_k_ehb", st["natoms"] * nb * 104.0, a.steps, "Ehb (pot.F90:559-673): bound by the 51 M memory-side FP64 atomics of the acceptor forces"),
                  ("k_bonded_list+k_bond_csr", "ms_k_blist", G * (32.0 + nb * 13.0), a.steps, "NEIGHBORLIST + nbrindx (main.F90:321-417): positions read once, partner / owner / mirror / type written per bond"),
