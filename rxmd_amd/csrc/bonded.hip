@@ -359,17 +359,18 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, int probe) {
-  __shared__ int s_ix3[512];
+  __shared__ unsigned char s_ix3[512];             // angle row of a type triple (at most 63 rows)
   __shared__ double s_ang[64][7];
   // per wavefront: factors of the 16 centres, accumulators of their bonds and of the atoms, the qualifying slots, the queue
   __shared__ double s_c[4][E3Q_NA][12];            // x, y, z, delta_ang, exp6, ex10, CSBO2, dSBO1, dSBO2, fn9, Cf9j / fn9, exp_coa2
   __shared__ int s_ci[4][E3Q_NA][4];               // type, first bond, bonds, qualifying bonds
   __shared__ double s_acc[4][5][E3Q_BC];           // per bond: cf1, cdn, force on the neighbour
-  __shared__ double s_at[4][E3Q_NA][4];            // per atom: S_d1, S_v6, S_v5 (the terms every bond of the centre receives, pot.F90:526-532)
+  __shared__ double s_at[4][E3Q_NA][3];            // per atom: S_d1, S_v6, S_v5 (the terms every bond of the centre receives, pot.F90:526-532)
   __shared__ unsigned char s_cap[4][E3Q_NA][16], s_own[4][E3Q_BC];
-  __shared__ int s_q[4][128];
+  __shared__ float s_cbo[4][E3Q_NA][E3Q_MAXL];     // bond orders of the qualifying slots, single precision: the product test of the enumeration asks memory only at the edge
+  __shared__ unsigned short s_q[4][128];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  for (int t = threadIdx.x; t < ff.n1 * ff.n1 * ff.n1; t += 256) s_ix3[t] = ff.inxn3[t];
+  for (int t = threadIdx.x; t < ff.n1 * ff.n1 * ff.n1; t += 256) s_ix3[t] = static_cast<unsigned char>(ff.inxn3[t]);
   for (int t = threadIdx.x; t < 7 * (ff.nvaty + 1); t += 256) s_ang[t / 7][t % 7] = reinterpret_cast<const double *>(ff.angle)[t];
   __syncthreads();
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
@@ -378,8 +379,12 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
   if (jbase >= N) continue;                        // (whole wavefront; no block-level barrier below)
   const int na = min(E3Q_NA, N - jbase);
   const int ob_w = boff[jbase], nb_w = boff[jbase + na] - ob_w;             // the bonds of the wavefront's atoms: one contiguous stretch of the compact tables
-  for (int t = lane; t < 5 * E3Q_BC; t += 64) (&s_acc[w][0][0])[t] = 0.0;
+  // the bond orders of the wavefront's bonds with coalesced loads into the (not yet used) accumulator rows 0 and 1: the centres' loops over their bonds
+  // below read LDS -- as loads from memory they were up to twelve round trips one after the other in front of everything else
+  for (int r = lane; r < nb_w; r += 64) { s_acc[w][0][r] = bo0[ob_w + r]; s_acc[w][1][r] = bo2[ob_w + r] + bo3[ob_w + r]; }
+  for (int t = lane; t < 3 * E3Q_BC; t += 64) (&s_acc[w][2][0])[t] = 0.0;
   if (lane < E3Q_NA) { s_at[w][lane][0] = 0.0; s_at[w][lane][1] = 0.0; s_at[w][lane][2] = 0.0; s_ci[w][lane][2] = 0; s_ci[w][lane][3] = 0; }
+  wave_lds_sync();
   if (lane < na) {                                 // set-up of a centre (pot.F90:352-437, 460-462, 481-483): everything that depends on the centre only
     const int j = jbase + lane;
     const int tj = type[j], ob = boff[j], nj = min(boff[j + 1] - ob, E3Q_MAXL);
@@ -387,12 +392,12 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
     double sum_BO8 = 0.0, sum_SBO1 = 0.0;
     int nc = 0;
     for (int n1 = 0; n1 < nj; ++n1) {
-      const int o = ob + n1;
-      const double b = bo0[o], b2 = b * b, b4 = b2 * b2;
+      const int r = ob + n1 - ob_w;
+      const double b = s_acc[w][0][r], b2 = b * b, b4 = b2 * b2;
       sum_BO8 -= b4 * b4;                                                  // BO**8, pot.F90:362
-      sum_SBO1 += bo2[o] + bo3[o];
-      if (b - cutof2_esub > 0.0) s_cap[w][lane][nc++] = static_cast<unsigned char>(n1);   // pot.F90:372-373, 385-386
-      s_own[w][o - ob_w] = static_cast<unsigned char>(lane);
+      sum_SBO1 += s_acc[w][1][r];
+      if (b - cutof2_esub > 0.0) { s_cbo[w][lane][nc] = static_cast<float>(b); s_cap[w][lane][nc++] = static_cast<unsigned char>(n1); }   // pot.F90:372-373, 385-386
+      s_own[w][r] = static_cast<unsigned char>(lane);
     }
     const double prod_SBO = exp(sum_BO8);
     const double dlj = delta[j];
@@ -415,15 +420,17 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
     s_ci[w][lane][0] = tj; s_ci[w][lane][1] = ob; s_ci[w][lane][2] = nj; s_ci[w][lane][3] = nc;
   }
   wave_lds_sync();
+  for (int t = lane; t < 2 * E3Q_BC; t += 64) (&s_acc[w][0][0])[t] = 0.0;         // rows 0 and 1 become accumulators
+  wave_lds_sync();
   int qn = 0, qh = 0;
-  auto evaluate = [&](int cnt) {                   // one angle per lane: queue entry = atom << 10 | slot i1 << 5 | slot k1 (i1 < k1)
+  auto evaluate = [&](int cnt) {                   // one angle per lane: queue entry = atom << 8 | slot i1 << 4 | slot k1 (i1 < k1 < 12)
 #ifdef RXMD_EXPERIMENTS
     if (probe == 2) return;
     if (probe == 5) { if (lane == 0) { atomicAdd(pe + 5, 1.0); atomicAdd(pe + 6, static_cast<double>(cnt)); } return; }
 #endif
     if (lane < cnt) {
       const int key = s_q[w][(qh + lane) & 127];
-      const int a = key >> 10, i1 = (key >> 5) & 31, k1 = key & 31;
+      const int a = key >> 8, i1 = (key >> 4) & 15, k1 = key & 15;
       const double *c = s_c[w][a];
       const int tj = s_ci[w][a][0], ob = s_ci[w][a][1];
       const int oi = ob + i1, ok = ob + k1;
@@ -498,13 +505,15 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
       if (live) {
         const int i1 = s_cap[w][a][u], k1 = s_cap[w][a][v];
         const int oi = ob + i1, ok = ob + k1;
-        go = bo0[oi] * bo0[ok] > cutof2_esub;                               // pot.F90:397
+        const float pr = s_cbo[w][a][u] * s_cbo[w][a][v];                   // pot.F90:397, BO(i,j) BO(j,k) > cut-off: decided in single precision except within 1e-3 of the
+        go = pr > 1.001e-4f;                                                // cut-off, where the double-precision product from memory decides (the same answers)
+        if (!go && pr > 0.999e-4f) go = bo0[oi] * bo0[ok] > cutof2_esub;
         if (go) go = s_ix3[(static_cast<int>(btype[oi]) * ff.n1 + tj) * ff.n1 + static_cast<int>(btype[ok])] != 0;
-        key = (a << 10) | (i1 << 5) | k1;
+        key = (a << 8) | (i1 << 4) | k1;
         if (++v >= nc) { u += 4; v = u + 1; }
       }
       const unsigned long long m = __ballot(go);
-      if (go) s_q[w][(qh + qn + __popcll(m & ((1ULL << lane) - 1ULL))) & 127] = key;
+      if (go) s_q[w][(qh + qn + __popcll(m & ((1ULL << lane) - 1ULL))) & 127] = static_cast<unsigned short>(key);
       qn += __popcll(m);
       wave_lds_sync();
       if (qn >= 64) { evaluate(64); qh = (qh + 64) & 127; qn -= 64; }
