@@ -347,10 +347,10 @@ __global__ void __launch_bounds__(256, E3B_MINB) k_e3b(int N, DevFF ff, const in
 // qualifying bonds (four lanes per atom), apply the reference's cut-offs (pot.F90:385-400) and compact the survivors with a ballot into an LDS ring; a full
 // batch of 64 angles is then evaluated one per lane.  Every angle adds to the accumulators of its two bonds in LDS (ds_add_f64, queue order: the same bits
 // run to run); the centre's own force is minus the sum of its bonds' forces, its all-bond terms are sums per atom; one coalesced pass adds everything to
-// the bond tables.  Persistent grid.  Needs the angle tables in LDS (at most 7 atom types, 63 angle rows) and bond lists of at most E3Q_MAXL entries;
-// otherwise k_e3b runs.
-constexpr int E3Q_NA = 16, E3Q_MAXL = 12, E3Q_BC = E3Q_NA * E3Q_MAXL;     // centre atoms per wavefront, longest bond list, bonds of a wavefront's atoms
-template <int MINW>                                   // wavefronts per SIMD the register budget is cut for (3: 168 registers + scratch, 2: 256)
+// the bond tables.  Persistent grid.  Sixteen centres per wavefront with bond lists up to 12, eight up to 24, four beyond; needs the type-triple table in
+// LDS (at most 7 atom types, 255 angle rows; the rows' parameters from LDS up to 63 rows, from memory beyond); otherwise k_e3b runs.
+constexpr int E3Q_BC = 192;                           // bonds of a wavefront's centre atoms: NA atoms x MAXL = 192 / NA list entries -- 16 x 12 (RDX, water), 8 x 24, 4 x 48 (lists up to MAXNEIGHBS: SiC, iron sulfide)
+template <int MINW, int NA>                           // wavefronts per SIMD the register budget is cut for (3: 168 registers + scratch, 2: 256); centre atoms per wavefront
 __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, const int *__restrict__ boff, const int *__restrict__ nbr, const unsigned char *__restrict__ btype, const int *__restrict__ type,
                                               const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                               const double *__restrict__ bo0, const double *__restrict__ bo2, const double *__restrict__ bo3,
@@ -359,19 +359,22 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
                                               double *__restrict__ cf1, double *__restrict__ cf2, double *__restrict__ cf3, double *__restrict__ cdn,
                                               double *__restrict__ fnx, double *__restrict__ fny, double *__restrict__ fnz,
                                               double *__restrict__ cds, double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz, double *__restrict__ pe, int probe) {
+  constexpr int E3Q_NA = NA, E3Q_MAXL = (E3Q_BC / NA < 32) ? E3Q_BC / NA : 32, LPA = 64 / NA;     // longest bond list (MAXNEIGHBS = 30), lanes per atom of the enumeration
   __shared__ unsigned char s_ix3[512];             // angle row of a type triple (at most 63 rows)
   __shared__ double s_ang[64][7];
   // per wavefront: factors of the 16 centres, accumulators of their bonds and of the atoms, the qualifying slots, the queue
-  __shared__ double s_c[4][E3Q_NA][12];            // x, y, z, delta_ang, exp6, ex10, CSBO2, dSBO1, dSBO2, fn9, Cf9j / fn9, exp_coa2
-  __shared__ int s_ci[4][E3Q_NA][4];               // type, first bond, bonds, qualifying bonds
+  __shared__ double s_c[4][16][12];            // x, y, z, delta_ang, exp6, ex10, CSBO2, dSBO1, dSBO2, fn9, Cf9j / fn9, exp_coa2
+  __shared__ int s_ci[4][16][4];               // type, first bond, bonds, qualifying bonds
   __shared__ double s_acc[4][5][E3Q_BC];           // per bond: cf1, cdn, force on the neighbour
-  __shared__ double s_at[4][E3Q_NA][3];            // per atom: S_d1, S_v6, S_v5 (the terms every bond of the centre receives, pot.F90:526-532)
-  __shared__ unsigned char s_cap[4][E3Q_NA][16], s_own[4][E3Q_BC];
-  __shared__ float s_cbo[4][E3Q_NA][E3Q_MAXL];     // bond orders of the qualifying slots, single precision: the product test of the enumeration asks memory only at the edge
+  __shared__ double s_at[4][16][3];            // per atom: S_d1, S_v6, S_v5 (the terms every bond of the centre receives, pot.F90:526-532)
+  __shared__ unsigned char s_cap[4][256], s_own[4][E3Q_BC];        // qualifying slots: NA x (at most 32 = 256 / NA ... 16) entries, [a * CAPW + u]
+  __shared__ float s_cbo[4][E3Q_BC];               // [a * MAXL + u]     // bond orders of the qualifying slots, single precision: the product test of the enumeration asks memory only at the edge
   __shared__ unsigned short s_q[4][128];
+  constexpr int CAPW = (256 / NA < 32) ? 256 / NA : 32;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   for (int t = threadIdx.x; t < ff.n1 * ff.n1 * ff.n1; t += 256) s_ix3[t] = static_cast<unsigned char>(ff.inxn3[t]);
-  for (int t = threadIdx.x; t < 7 * (ff.nvaty + 1); t += 256) s_ang[t / 7][t % 7] = reinterpret_cast<const double *>(ff.angle)[t];
+  const bool ang_lds = ff.nvaty <= 63;              // (more angle rows than the LDS table holds, up to 255: their parameters come from memory, requested with the angle's other operands)
+  if (ang_lds) for (int t = threadIdx.x; t < 7 * (ff.nvaty + 1); t += 256) s_ang[t / 7][t % 7] = reinterpret_cast<const double *>(ff.angle)[t];
   __syncthreads();
   double e5 = 0.0, e6 = 0.0, e7 = 0.0;
   for (int vb = blockIdx.x; vb < NG; vb += gridDim.x) {
@@ -396,7 +399,7 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
       const double b = s_acc[w][0][r], b2 = b * b, b4 = b2 * b2;
       sum_BO8 -= b4 * b4;                                                  // BO**8, pot.F90:362
       sum_SBO1 += s_acc[w][1][r];
-      if (b - cutof2_esub > 0.0) { s_cbo[w][lane][nc] = static_cast<float>(b); s_cap[w][lane][nc++] = static_cast<unsigned char>(n1); }   // pot.F90:372-373, 385-386
+      if (b - cutof2_esub > 0.0) { s_cbo[w][lane * E3Q_MAXL + nc] = static_cast<float>(b); s_cap[w][lane * CAPW + nc++] = static_cast<unsigned char>(n1); }   // pot.F90:372-373, 385-386
       s_own[w][r] = static_cast<unsigned char>(lane);
     }
     const double prod_SBO = exp(sum_BO8);
@@ -423,14 +426,14 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
   for (int t = lane; t < 2 * E3Q_BC; t += 64) (&s_acc[w][0][0])[t] = 0.0;         // rows 0 and 1 become accumulators
   wave_lds_sync();
   int qn = 0, qh = 0;
-  auto evaluate = [&](int cnt) {                   // one angle per lane: queue entry = atom << 8 | slot i1 << 4 | slot k1 (i1 < k1 < 12)
+  auto evaluate = [&](int cnt) {                   // one angle per lane: queue entry = atom << 10 | slot i1 << 5 | slot k1 (i1 < k1)
 #ifdef RXMD_EXPERIMENTS
     if (probe == 2) return;
     if (probe == 5) { if (lane == 0) { atomicAdd(pe + 5, 1.0); atomicAdd(pe + 6, static_cast<double>(cnt)); } return; }
 #endif
     if (lane < cnt) {
       const int key = s_q[w][(qh + lane) & 127];
-      const int a = key >> 8, i1 = (key >> 4) & 15, k1 = key & 15;
+      const int a = key >> 10, i1 = (key >> 5) & 31, k1 = key & 31;
       const double *c = s_c[w][a];
       const int tj = s_ci[w][a][0], ob = s_ci[w][a][1];
       const int oi = ob + i1, ok = ob + k1;
@@ -442,8 +445,10 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
       const double nij = sqrt(dot(rij, rij));
       const V3 rjk = {xj - x[k], yj - y[k], zj - z[k]};
       const double njk = sqrt(dot(rjk, rjk));
-      const double *a_ = s_ang[s_ix3[(ti * ff.n1 + tj) * ff.n1 + tk]];
-      const DevAngleP ap = DevAngleP{a_[0], a_[1], a_[2], a_[3], a_[4], a_[5], a_[6]};
+      const int inxn = s_ix3[(ti * ff.n1 + tj) * ff.n1 + tk];
+      DevAngleP ap;
+      if (ang_lds) { const double *a_ = s_ang[inxn]; ap = DevAngleP{a_[0], a_[1], a_[2], a_[3], a_[4], a_[5], a_[6]}; }
+      else ap = ff.angle[inxn];
       double cos_ijk = -dot(rij, rjk) / (nij * njk);
       if (cos_ijk > MAXANGLE) cos_ijk = MAXANGLE;
       if (cos_ijk < MINANGLE) cos_ijk = MINANGLE;
@@ -491,9 +496,9 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
 #ifdef RXMD_EXPERIMENTS
   if (probe == 1) continue;
 #endif
-  // enumeration: four lanes per atom; lane s of an atom takes the first bonds u = s, s + 4, ... of its qualifying list, each with every later one
+  // enumeration: LPA = 64 / NA lanes per atom; lane s of an atom takes the first bonds u = s, s + LPA, ... of its qualifying list, each with every later one
   {
-    const int a = lane >> 2, sub = lane & 3;
+    const int a = lane / LPA, sub = lane % LPA;
     const int nc = s_ci[w][a][3], tj = s_ci[w][a][0], ob = s_ci[w][a][1];
     int u = sub, v = sub + 1;
     for (;;) {
@@ -503,14 +508,14 @@ __global__ void __launch_bounds__(256, MINW) k_e3q(int N, int NG, DevFF ff, cons
       bool go = false;
       int key = 0;
       if (live) {
-        const int i1 = s_cap[w][a][u], k1 = s_cap[w][a][v];
+        const int i1 = s_cap[w][a * CAPW + u], k1 = s_cap[w][a * CAPW + v];
         const int oi = ob + i1, ok = ob + k1;
-        const float pr = s_cbo[w][a][u] * s_cbo[w][a][v];                   // pot.F90:397, BO(i,j) BO(j,k) > cut-off: decided in single precision except within 1e-3 of the
+        const float pr = s_cbo[w][a * E3Q_MAXL + u] * s_cbo[w][a * E3Q_MAXL + v];                   // pot.F90:397, BO(i,j) BO(j,k) > cut-off: decided in single precision except within 1e-3 of the
         go = pr > 1.001e-4f;                                                // cut-off, where the double-precision product from memory decides (the same answers)
         if (!go && pr > 0.999e-4f) go = bo0[oi] * bo0[ok] > cutof2_esub;
         if (go) go = s_ix3[(static_cast<int>(btype[oi]) * ff.n1 + tj) * ff.n1 + static_cast<int>(btype[ok])] != 0;
-        key = (a << 8) | (i1 << 4) | k1;
-        if (++v >= nc) { u += 4; v = u + 1; }
+        key = (a << 10) | (i1 << 5) | k1;
+        if (++v >= nc) { u += LPA; v = u + 1; }
       }
       const unsigned long long m = __ballot(go);
       if (go) s_q[w][(qh + qn + __popcll(m & ((1ULL << lane) - 1ULL))) & 127] = static_cast<unsigned short>(key);
@@ -1320,13 +1325,19 @@ void Engine::bonded_energies() {
   k_elnpr_atoms<<<nblk(N, 256), 256, 0, stream>>>(N, dff, boff, type, bt1, bt2, delta, deltalp, dDlp, ecoef, pe_d);
   k_elnpr_bonds<<<nblk(nbonds_res, 256), 256, 0, stream>>>(nbonds_res, dff, bown, nbr, btype, type, bo2, bo3, delta, deltalp, dDlp, ecoef, cf1, cf2, cf3, cdn);
   const bool kt3 = kt_begin(&st.ms_k_e3b);
-  // the work-queue form (k_e3q) when the angle tables fit LDS and no bond list of the step is longer than E3Q_MAXL (h_err[2]: the longest list, 0 up to 8)
-  if (opt.e3b_queue != 0 && dff.n1 <= 8 && dff.nvaty <= 63 && h_err[2] <= E3Q_MAXL) {
-    const int NG = nblk(N, 4 * E3Q_NA);
-    if (opt.e3b_queue == 3) k_e3q<3><<<std::min(NG, (num_cu * 3 + 7) & ~7), 256, 0, stream>>>(N, NG, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
-                                                                                            cds, frc[0], frc[1], frc[2], pe_d, static_cast<int>(opt.e4b_probe));
-    else k_e3q<2><<<std::min(NG, (num_cu * 2 + 7) & ~7), 256, 0, stream>>>(N, NG, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
-                                                                         cds, frc[0], frc[1], frc[2], pe_d, static_cast<int>(opt.e4b_probe));
+  // the work-queue form (k_e3q) when the angle tables fit LDS: sixteen centre atoms per wavefront where no bond list of the step is longer than 12
+  // (h_err[2]: the longest list, 0 up to 8), eight up to 24, four beyond
+  if (opt.e3b_queue != 0 && dff.n1 <= 8 && dff.nvaty <= 255) {
+    const int maxl = h_err[2];
+    auto go = [&](auto kern, int na, int minw) {
+      const int NG = nblk(N, 4 * na);
+      kern<<<std::min(NG, (num_cu * minw + 7) & ~7), 256, 0, stream>>>(N, NG, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
+                                                                     cds, frc[0], frc[1], frc[2], pe_d, static_cast<int>(opt.e4b_probe));
+    };
+    const bool w3 = opt.e3b_queue == 3;
+    if (maxl <= 12) { if (w3) go(k_e3q<3, 16>, 16, 3); else go(k_e3q<2, 16>, 16, 2); }
+    else if (maxl <= 24) { if (w3) go(k_e3q<3, 8>, 8, 3); else go(k_e3q<2, 8>, 8, 2); }
+    else { if (w3) go(k_e3q<3, 4>, 4, 3); else go(k_e3q<2, 4>, 4, 2); }
   } else
     k_e3b<<<nblk(N, 256), 256, 4 * 5 * E3B_CAP * sizeof(double), stream>>>(N, dff, boff, nbr, btype, type, pos[0], pos[1], pos[2], bo0, bo2, bo3, delta, nlp, dDlp, epen, ecoa, cf1, cf2, cf3, cdn, fnx, fny, fnz,
                                           cds, frc[0], frc[1], frc[2], pe_d);

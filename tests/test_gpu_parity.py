@@ -651,8 +651,8 @@ def test_torsions_visited_once_and_twice_and_the_persistent_grid(case, mc, kw, m
                                         ("sicnp", (1, 1, 1), dict(pqeq=oa.PQEQ_SICNP))])
 def test_valence_angles_through_the_queue_and_per_thread(case, mc, kw, monkeypatch):
     """Two forms of E3b (pot.F90:319-557): a thread per centre atom (`k_e3b`, RXMD_E3B_QUEUE=0) and sixteen centre atoms per wavefront with the surviving
-    angles compacted into a queue and evaluated 64 at a time (`k_e3q`, default where no bond list is longer than 12 and the angle tables fit LDS; 2 / 3 =
-    the register budget).  The same terms summed in another order: forces within 1e-10, energies within 1e-12 relative, both against the oracle."""
+    angles compacted into a queue and evaluated 64 at a time (`k_e3q`, default for force fields with at most 7 atom types and 255 angle rows: sixteen / eight /
+    four centres per wavefront for bond lists up to 12 / 24 / 30; 2 / 3 = the register budget).  The same terms summed in another order: forces within 1e-10, energies within 1e-12 relative, both against the oracle."""
     kw = dict(QEq_tol=1e-12, NMAXQEq=2000, **kw)
     o = _oracle(case, mc, **kw); o.qeq(); o.force()
     res = {}
