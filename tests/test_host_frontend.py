@@ -274,7 +274,7 @@ def test_bench_line_stays_under_the_drivers_tail_and_ends_with_the_legs():
     import json, sys
     sys.path.insert(0, ROOT)
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r06_final4_bench_default_full_line.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_final5_bench_default_full_line.json")))
     line = bench.compact_line(full)
     assert len(line) < 8000
     out = json.loads(line)
